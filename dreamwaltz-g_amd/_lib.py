@@ -1,0 +1,65 @@
+"""ctypes binding of the C-ABI in include/*.h (libdwg_hip.so).
+
+The product path has no CPU fallback: if the HIP library is missing this module raises at first use.
+"""
+import ctypes
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "csrc", "libdwg_hip.so")
+_lib = None
+
+c_f32p = ctypes.c_void_p
+c_i32p = ctypes.c_void_p
+
+
+class RasterSettingsC(ctypes.Structure):
+    """struct dwg_raster_settings (include/dwg_raster.h)."""
+    _fields_ = [
+        ("image_height", ctypes.c_int32), ("image_width", ctypes.c_int32),
+        ("tanfovx", ctypes.c_float), ("tanfovy", ctypes.c_float), ("scale_modifier", ctypes.c_float),
+        ("sh_degree", ctypes.c_int32), ("sh_coeffs", ctypes.c_int32),
+        ("prefiltered", ctypes.c_int32), ("debug", ctypes.c_int32),
+        ("bg", ctypes.c_void_p), ("viewmatrix", ctypes.c_void_p), ("projmatrix", ctypes.c_void_p),
+        ("campos", ctypes.c_void_p),
+    ]
+
+
+# name -> (restype, argtypes); every symbol include/*.h declares must be listed here (tests check it)
+_vp, _i32, _i64, _f32, _sz = ctypes.c_void_p, ctypes.c_int32, ctypes.c_int64, ctypes.c_float, ctypes.c_size_t
+SIGNATURES = {
+    "dwg_raster_workspace_sizes": (ctypes.c_int, [_i32, _i32, _i32, _i64, ctypes.POINTER(_sz), ctypes.POINTER(_sz),
+                                                  ctypes.POINTER(_sz)]),
+    "dwg_raster_num_pairs_ptr": (_vp, [_vp]),
+    "dwg_raster_forward_bin": (ctypes.c_int, [ctypes.POINTER(RasterSettingsC), _i32] + [_vp] * 9 + [_vp]),
+    "dwg_raster_forward_render": (ctypes.c_int, [ctypes.POINTER(RasterSettingsC), _i32, _vp, _vp, _i64, _vp, _vp, _vp,
+                                                 _vp, _vp]),
+    "dwg_raster_backward": (ctypes.c_int, [ctypes.POINTER(RasterSettingsC), _i32] + [_vp] * 7 + [_vp, _vp, _i64, _vp, _vp]
+                            + [_vp] * 3 + [_vp] * 8 + [_vp]),
+}
+
+
+def lib():
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise RuntimeError(
+                "libdwg_hip.so not found at %s -- run `python dreamwaltz-g_amd/build.py` "
+                "(there is no CPU fallback for the product path)" % LIB_PATH)
+        l = ctypes.CDLL(LIB_PATH)
+        for name, (res, args) in SIGNATURES.items():
+            fn = getattr(l, name)
+            fn.restype = res
+            fn.argtypes = args
+        _lib = l
+    return _lib
+
+
+def check(rc, what):
+    if rc != 0:
+        raise RuntimeError("%s failed with DWG error %d" % (what, rc))
+
+
+def ptr(t):
+    """Device (or host) address of a torch tensor, None -> NULL."""
+    return None if t is None else ctypes.c_void_p(t.data_ptr())

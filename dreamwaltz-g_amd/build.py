@@ -1,0 +1,69 @@
+"""Builds libdwg_hip.so (all HIP kernels + C-ABI) for gfx950 with hipcc, in-tree.
+
+    python dreamwaltz-g_amd/build.py [--force]
+
+Objects are cached by mtime under csrc/_obj/; the shared library lands next to the sources so that it
+travels with the repo snapshot to the GPU box (it is git-ignored, not gpurun-ignored).
+"""
+import concurrent.futures
+import os
+import subprocess
+import sys
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+CSRC = os.path.join(HERE, "csrc")
+OBJ = os.path.join(CSRC, "_obj")
+LIB = os.path.join(CSRC, "libdwg_hip.so")
+HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
+FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-munsafe-fp-atomics", "-Wall",
+         "-Wno-unused-function", "-Wno-unused-variable", "-Wno-misleading-indentation"]
+
+
+def _sources():
+    return sorted(f for f in os.listdir(CSRC) if f.endswith(".hip") or f.endswith(".cpp"))
+
+
+def _headers_mtime():
+    inc = os.path.join(HERE, "..", "include")
+    m = 0.0
+    for d in (CSRC, inc):
+        for f in os.listdir(d):
+            if f.endswith(".h"):
+                m = max(m, os.path.getmtime(os.path.join(d, f)))
+    return m
+
+
+def _compile(src, force):
+    obj = os.path.join(OBJ, src + ".o")
+    sp = os.path.join(CSRC, src)
+    if (not force and os.path.exists(obj) and os.path.getmtime(obj) >= os.path.getmtime(sp)
+            and os.path.getmtime(obj) >= _headers_mtime()):
+        return obj, False
+    cmd = [HIPCC] + FLAGS + ["-x", "hip", "-c", sp, "-o", obj]
+    r = subprocess.run(cmd, capture_output=True, text=True)
+    if r.returncode != 0:
+        raise RuntimeError("hipcc failed for %s:\n%s\n%s" % (src, r.stdout, r.stderr))
+    return obj, True
+
+
+def build(force=False, verbose=True):
+    os.makedirs(OBJ, exist_ok=True)
+    srcs = _sources()
+    with concurrent.futures.ThreadPoolExecutor(max_workers=min(8, len(srcs))) as ex:
+        res = list(ex.map(lambda s: _compile(s, force), srcs))
+    objs = [o for o, _ in res]
+    changed = any(c for _, c in res)
+    if changed or force or not os.path.exists(LIB):
+        cmd = [HIPCC, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", LIB] + objs
+        r = subprocess.run(cmd, capture_output=True, text=True)
+        if r.returncode != 0:
+            raise RuntimeError("link failed:\n%s\n%s" % (r.stdout, r.stderr))
+        if verbose:
+            print("[dwg build] linked", LIB)
+    elif verbose:
+        print("[dwg build] up to date:", LIB)
+    return LIB
+
+
+if __name__ == "__main__":
+    build(force="--force" in sys.argv)

@@ -1,0 +1,45 @@
+// dwg_common.h -- shared helpers for the gfx950 (CDNA4, wave64) kernels of libdwg_hip.so.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stddef.h>
+#include <stdint.h>
+
+#define DWG_OK 0
+#define DWG_E_ARG (-1)
+#define DWG_E_LAUNCH (-2)
+#define DWG_E_CAPACITY (-3)
+
+#define DWG_TILE 16
+#define DWG_WAVE 64
+
+#define DWG_RETURN_IF_LAUNCH_FAILED()                    \
+    do {                                                 \
+        hipError_t e__ = hipGetLastError();              \
+        if (e__ != hipSuccess) return DWG_E_LAUNCH;      \
+    } while (0)
+
+static inline size_t dwg_align_up(size_t x, size_t a) { return (x + a - 1) / a * a; }
+static inline int dwg_cdiv(int a, int b) { return (a + b - 1) / b; }
+
+#if defined(__HIPCC__)
+// ---- wave64 reductions through DPP (no LDS traffic). Total ends up in lane 63. ----
+template <int CTRL, int ROW_MASK>
+__device__ __forceinline__ float dwg_dpp_add(float v) {
+    int r = __builtin_amdgcn_update_dpp(0, __float_as_int(v), CTRL, ROW_MASK, 0xF, false);
+    return v + __int_as_float(r);
+}
+__device__ __forceinline__ float dwg_wave_sum_to_lane63(float v) {
+    v = dwg_dpp_add<0xB1, 0xF>(v);   // quad_perm [1,0,3,2]
+    v = dwg_dpp_add<0x4E, 0xF>(v);   // quad_perm [2,3,0,1]
+    v = dwg_dpp_add<0x114, 0xF>(v);  // row_shr:4
+    v = dwg_dpp_add<0x118, 0xF>(v);  // row_shr:8   -> lane 15 of every row holds the row sum
+    v = dwg_dpp_add<0x142, 0xA>(v);  // row_bcast:15 into rows 1,3
+    v = dwg_dpp_add<0x143, 0xC>(v);  // row_bcast:31 into rows 2,3 -> lane 63 = wave total
+    return v;
+}
+__device__ __forceinline__ float dwg_wave_sum_all(float v) {
+    v = dwg_wave_sum_to_lane63(v);
+    return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), 63));
+}
+__device__ __forceinline__ int dwg_lane() { return (int)(threadIdx.x & 63); }
+#endif

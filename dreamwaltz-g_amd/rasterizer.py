@@ -1,0 +1,171 @@
+"""Drop-in for the `diff_gaussian_rasterization` Python module (boundary B1).
+
+Mirrors the interface the reference uses at /root/reference/core/gaussian/gaussian_renderer.py:
+  :5      from diff_gaussian_rasterization import GaussianRasterizationSettings, GaussianRasterizer
+  :60-70  GaussianRasterizationSettings(**kwargs, scale_modifier=1., prefiltered=False, debug=False)
+  :186-195 rasterizer(means3D=, means2D=, shs=, colors_precomp=, opacities=, scales=, rotations=, cov3D_precomp=)
+           -> (image[3,H,W], radii[G], depth[1,H,W], alpha[1,H,W])
+All arithmetic runs in the hand-written HIP kernels of csrc/raster.hip through the C-ABI in
+include/dwg_raster.h; there is no CPU fallback.
+"""
+import ctypes
+from typing import NamedTuple, Optional
+
+import torch
+
+from . import _lib
+
+
+class GaussianRasterizationSettings(NamedTuple):
+    image_height: int
+    image_width: int
+    tanfovx: float
+    tanfovy: float
+    bg: torch.Tensor
+    scale_modifier: float
+    viewmatrix: torch.Tensor
+    projmatrix: torch.Tensor
+    sh_degree: int
+    campos: torch.Tensor
+    prefiltered: bool
+    debug: bool
+
+
+def _f32c(t: Optional[torch.Tensor]) -> Optional[torch.Tensor]:
+    return None if t is None else t.float().contiguous()
+
+
+def _settings_struct(rs: GaussianRasterizationSettings, device, sh_coeffs: int, keep: list):
+    def dev(t):
+        t = torch.as_tensor(t, dtype=torch.float32, device=device).contiguous()
+        keep.append(t)
+        return t.data_ptr()
+    c = _lib.RasterSettingsC()
+    c.image_height = int(rs.image_height); c.image_width = int(rs.image_width)
+    c.tanfovx = float(rs.tanfovx); c.tanfovy = float(rs.tanfovy)
+    c.scale_modifier = float(rs.scale_modifier)
+    c.sh_degree = int(rs.sh_degree); c.sh_coeffs = int(sh_coeffs)
+    c.prefiltered = int(bool(rs.prefiltered)); c.debug = int(bool(rs.debug))
+    c.bg = dev(rs.bg); c.viewmatrix = dev(rs.viewmatrix); c.projmatrix = dev(rs.projmatrix)
+    c.campos = dev(rs.campos)
+    return c
+
+
+def _stream(device):
+    return ctypes.c_void_p(torch.cuda.current_stream(device).cuda_stream)
+
+
+class _RasterizeGaussians(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, means3D, means2D, sh, colors_precomp, opacities, scales, rotations, cov3Ds_precomp,
+                raster_settings: GaussianRasterizationSettings):
+        if not means3D.is_cuda:
+            raise RuntimeError("dreamwaltz_g_amd rasterizer runs on the GPU only (HIP kernels); got a CPU tensor")
+        L = _lib.lib()
+        device = means3D.device
+        G = int(means3D.shape[0])
+        H, W = int(raster_settings.image_height), int(raster_settings.image_width)
+        means3D = _f32c(means3D)
+        sh = _f32c(sh) if sh is not None and sh.numel() > 0 else None
+        colors_precomp = _f32c(colors_precomp) if colors_precomp is not None and colors_precomp.numel() > 0 else None
+        if G == 0:
+            sh, colors_precomp = None, torch.zeros(0, 3, device=device)
+        opac = _f32c(opacities).reshape(-1)
+        scales = _f32c(scales) if scales is not None and scales.numel() > 0 else None
+        rotations = _f32c(rotations) if rotations is not None and rotations.numel() > 0 else None
+        cov3D = _f32c(cov3Ds_precomp) if cov3Ds_precomp is not None and cov3Ds_precomp.numel() > 0 else None
+        if G == 0 and cov3D is None:
+            scales = torch.zeros(0, 3, device=device); rotations = torch.zeros(0, 4, device=device)
+        keep = []
+        M = int(sh.shape[1]) if sh is not None else 0
+        cfg = _settings_struct(raster_settings, device, M, keep)
+        gb, pb, ib = ctypes.c_size_t(), ctypes.c_size_t(), ctypes.c_size_t()
+        _lib.check(L.dwg_raster_workspace_sizes(G, H, W, 0, ctypes.byref(gb), ctypes.byref(pb), ctypes.byref(ib)),
+                   "dwg_raster_workspace_sizes")
+        ws_geom = torch.empty(gb.value, dtype=torch.uint8, device=device)
+        ws_image = torch.empty(ib.value, dtype=torch.uint8, device=device)
+        radii = torch.zeros(G, dtype=torch.int32, device=device)
+        st = _stream(device)
+        p = _lib.ptr
+        _lib.check(L.dwg_raster_forward_bin(ctypes.byref(cfg), G, p(means3D), p(sh), p(colors_precomp), p(opac),
+                                            p(scales), p(rotations), p(cov3D), p(radii), p(ws_geom), st),
+                   "dwg_raster_forward_bin")
+        # one 4-byte read-back sizes the pair buffers (the reference's extension does the same D2H copy)
+        K = int(ws_geom[:4].view(torch.int32).item())
+        cap = max(K, 1)
+        _lib.check(L.dwg_raster_workspace_sizes(G, H, W, cap, ctypes.byref(gb), ctypes.byref(pb), ctypes.byref(ib)),
+                   "dwg_raster_workspace_sizes")
+        ws_pairs = torch.empty(pb.value, dtype=torch.uint8, device=device)
+        color = torch.empty(3, H, W, dtype=torch.float32, device=device)
+        depth = torch.empty(1, H, W, dtype=torch.float32, device=device)
+        alpha = torch.empty(1, H, W, dtype=torch.float32, device=device)
+        _lib.check(L.dwg_raster_forward_render(ctypes.byref(cfg), G, p(ws_geom), p(ws_pairs), cap, p(ws_image),
+                                               p(color), p(depth), p(alpha), st), "dwg_raster_forward_render")
+        ctx.raster_settings = raster_settings
+        ctx.cap = cap
+        ctx.num_pairs = K
+        ctx.has = (sh is not None, colors_precomp is not None, scales is not None, cov3D is not None)
+        ctx.save_for_backward(means3D, sh, colors_precomp, opac, scales, rotations, cov3D, ws_geom, ws_pairs, ws_image)
+        ctx.mark_non_differentiable(radii)
+        return color, radii, depth, alpha
+
+    @staticmethod
+    def backward(ctx, g_color, g_radii, g_depth, g_alpha):
+        L = _lib.lib()
+        means3D, sh, colors_precomp, opac, scales, rotations, cov3D, ws_geom, ws_pairs, ws_image = ctx.saved_tensors
+        rs = ctx.raster_settings
+        device = means3D.device
+        G = int(means3D.shape[0])
+        keep = []
+        M = int(sh.shape[1]) if sh is not None else 0
+        cfg = _settings_struct(rs, device, M, keep)
+        H, W = int(rs.image_height), int(rs.image_width)
+        g_color = torch.zeros(3, H, W, device=device) if g_color is None else _f32c(g_color)
+        g_depth = None if g_depth is None else _f32c(g_depth)
+        g_alpha = None if g_alpha is None else _f32c(g_alpha)
+        d_means3D = torch.empty(G, 3, device=device)
+        d_means2D = torch.empty(G, 3, device=device)
+        d_opac = torch.empty(G, 1, device=device)
+        d_sh = torch.empty_like(sh) if sh is not None else None
+        d_colors = torch.empty(G, 3, device=device) if colors_precomp is not None else None
+        d_scales = torch.empty(G, 3, device=device) if scales is not None else None
+        d_rots = torch.empty(G, 4, device=device) if rotations is not None else None
+        d_cov = torch.empty(G, 6, device=device) if cov3D is not None else None
+        ws_grad = torch.empty(max(G, 1) * 12, dtype=torch.float32, device=device)
+        p = _lib.ptr
+        _lib.check(L.dwg_raster_backward(ctypes.byref(cfg), G, p(means3D), p(sh), p(colors_precomp), p(opac), p(scales),
+                                         p(rotations), p(cov3D), p(ws_geom), p(ws_pairs), ctx.cap, p(ws_image),
+                                         p(ws_grad), p(g_color), p(g_depth), p(g_alpha), p(d_means3D), p(d_means2D),
+                                         p(d_sh), p(d_colors), p(d_opac), p(d_scales), p(d_rots), p(d_cov),
+                                         _stream(device)), "dwg_raster_backward")
+        return d_means3D, d_means2D, d_sh, d_colors, d_opac, d_scales, d_rots, d_cov, None
+
+
+def rasterize_gaussians(means3D, means2D, sh, colors_precomp, opacities, scales, rotations, cov3Ds_precomp,
+                        raster_settings):
+    return _RasterizeGaussians.apply(means3D, means2D, sh, colors_precomp, opacities, scales, rotations,
+                                     cov3Ds_precomp, raster_settings)
+
+
+class GaussianRasterizer(torch.nn.Module):
+    def __init__(self, raster_settings: GaussianRasterizationSettings):
+        super().__init__()
+        self.raster_settings = raster_settings
+
+    def markVisible(self, positions: torch.Tensor) -> torch.Tensor:
+        """Frustum test used by some callers of the original package: p_view.z > 0.2."""
+        with torch.no_grad():
+            v = self.raster_settings.viewmatrix
+            z = positions[:, 0] * v[0, 2] + positions[:, 1] * v[1, 2] + positions[:, 2] * v[2, 2] + v[3, 2]
+            return z > 0.2
+
+    def forward(self, means3D, means2D, opacities, shs=None, colors_precomp=None, scales=None, rotations=None,
+                cov3D_precomp=None):
+        rs = self.raster_settings
+        if (shs is None and colors_precomp is None) or (shs is not None and colors_precomp is not None):
+            raise Exception("Please provide excatly one of either SHs or precomputed colors!")
+        if ((scales is None or rotations is None) and cov3D_precomp is None) or (
+                (scales is not None or rotations is not None) and cov3D_precomp is not None):
+            raise Exception("Please provide exactly one of either scale/rotation pair or precomputed 3D covariance!")
+        return rasterize_gaussians(means3D, means2D, shs, colors_precomp, opacities, scales, rotations, cov3D_precomp,
+                                   rs)

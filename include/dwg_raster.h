@@ -1,0 +1,99 @@
+/*
+ * include/dwg_raster.h -- C-ABI of the MI355X-native differentiable Gaussian-splat rasterizer.
+ *
+ * Drop-in boundary B1: replaces the third-party CUDA extension
+ * `diff_gaussian_rasterization` that the reference imports at
+ *   /root/reference/core/gaussian/gaussian_renderer.py:5   (GaussianRasterizationSettings, GaussianRasterizer)
+ * and calls at gaussian_renderer.py:60-70 (settings) and :186-195 (forward).
+ *
+ * Conventions
+ *  - every pointer is a DEVICE pointer unless the name ends in _host;
+ *  - all tensors are dense fp32 row-major, exactly the layouts the reference hands to its extension:
+ *      means3D [G,3], colors_precomp [G,3] | shs [G,M,3], opacities [G] (the reference's [G,1]),
+ *      scales [G,3], rotations [G,4] (real-first, used UN-normalised), cov3D_precomp [G,6],
+ *      viewmatrix / projmatrix [4,4] in the reference's row-vector form
+ *      (gaussian_renderer.py:38-39: viewmatrix = extrinsic^T, projmatrix = viewmatrix @ projection^T);
+ *  - outputs: color [3,H,W], depth [1,H,W], alpha [1,H,W], radii [G] int32;
+ *  - nothing is allocated inside; the caller supplies workspaces sized by dwg_raster_workspace_sizes();
+ *  - every launch goes to the caller's hipStream_t; no host synchronisation happens inside
+ *    (the number of (Gaussian,tile) pairs is left in the geometry workspace, see dwg_raster_num_pairs_ptr);
+ *  - return value: 0 on success, negative DWG_E_* on error (bad arguments, launch failure).
+ */
+#ifndef DWG_RASTER_H
+#define DWG_RASTER_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define DWG_OK 0
+#define DWG_E_ARG (-1)
+#define DWG_E_LAUNCH (-2)
+#define DWG_E_CAPACITY (-3)
+
+typedef void* dwg_stream_t; /* hipStream_t */
+
+/* Mirrors GaussianRasterizationSettings (kwargs at gaussian_renderer.py:43-64). */
+typedef struct dwg_raster_settings {
+    int32_t image_height;
+    int32_t image_width;
+    float tanfovx;
+    float tanfovy;
+    float scale_modifier;
+    int32_t sh_degree;      /* active SH degree (0..3); ignored when colors_precomp is given */
+    int32_t sh_coeffs;      /* M: coefficients per Gaussian in `shs` (>= (sh_degree+1)^2) */
+    int32_t prefiltered;    /* accepted for API parity; no effect */
+    int32_t debug;          /* accepted for API parity; no effect */
+    const float* bg;         /* [3]  device */
+    const float* viewmatrix; /* [16] device */
+    const float* projmatrix; /* [16] device */
+    const float* campos;     /* [3]  device (only read for SH colours) */
+} dwg_raster_settings;
+
+/* Byte sizes of the three caller-owned workspaces.
+ *  geom : per-Gaussian splat records + per-tile counters (kept from forward to backward)
+ *  pairs: (Gaussian,tile) pair keys + depth-sorted id lists, for `pair_capacity` pairs
+ *  image: per-pixel final transmittance + contributor count (kept from forward to backward) */
+int dwg_raster_workspace_sizes(int32_t num_gaussians, int32_t image_height, int32_t image_width,
+                               int64_t pair_capacity, size_t* geom_bytes, size_t* pairs_bytes,
+                               size_t* image_bytes);
+
+/* Device address (inside the geometry workspace) of the int32 pair count K written by stage A,
+ * followed by an int32 overflow flag written by stage B. */
+const int32_t* dwg_raster_num_pairs_ptr(const void* ws_geom);
+
+/* Stage A: project, build splat records, count tiles, exclusive-scan the tile histogram. */
+int dwg_raster_forward_bin(const dwg_raster_settings* cfg, int32_t num_gaussians,
+                           const float* means3D, const float* shs, const float* colors_precomp,
+                           const float* opacities, const float* scales, const float* rotations,
+                           const float* cov3D_precomp, int32_t* radii, void* ws_geom,
+                           dwg_stream_t stream);
+
+/* Stage B: scatter pairs into tile lists, depth-sort every tile in LDS, composite front-to-back. */
+int dwg_raster_forward_render(const dwg_raster_settings* cfg, int32_t num_gaussians, void* ws_geom,
+                              void* ws_pairs, int64_t pair_capacity, void* ws_image,
+                              float* out_color, float* out_depth, float* out_alpha,
+                              dwg_stream_t stream);
+
+/* Backward of the whole rasterizer. dL_dout_depth / dL_dout_alpha may be NULL (treated as zero).
+ * Gradient buffers are OVERWRITTEN (not accumulated). Any of dL_dshs / dL_dcolors / dL_dscales /
+ * dL_drotations / dL_dcov3D may be NULL when the corresponding input was not supplied.
+ * ws_geom / ws_pairs / ws_image must be the ones the forward of the same frame filled. */
+int dwg_raster_backward(const dwg_raster_settings* cfg, int32_t num_gaussians,
+                        const float* means3D, const float* shs, const float* colors_precomp,
+                        const float* opacities, const float* scales, const float* rotations,
+                        const float* cov3D_precomp, const void* ws_geom, const void* ws_pairs,
+                        int64_t pair_capacity /* same value as in forward_render */,
+                        const void* ws_image, void* ws_grad /* >= 12*G floats scratch */,
+                        const float* dL_dout_color, const float* dL_dout_depth,
+                        const float* dL_dout_alpha, float* dL_dmeans3D, float* dL_dmeans2D,
+                        float* dL_dshs, float* dL_dcolors, float* dL_dopacities, float* dL_dscales,
+                        float* dL_drotations, float* dL_dcov3D, dwg_stream_t stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* DWG_RASTER_H */

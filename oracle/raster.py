@@ -1,0 +1,85 @@
+"""ctypes front-end of oracle/raster_oracle.c (CPU restatement of the 3DGS tile rasterizer).
+
+TEST INFRASTRUCTURE.  PARITY UNPINNED against the third-party CUDA package (see raster_oracle.c header).
+"""
+import ctypes
+import os
+import subprocess
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_BUILD = os.path.join(_HERE, "_build")
+_libs = {}
+
+
+def build():
+    subprocess.run(["make", "-C", _HERE, "-s"], check=True)
+
+
+def _lib(dtype):
+    key = "f64" if np.dtype(dtype) == np.float64 else "f32"
+    if key not in _libs:
+        path = os.path.join(_BUILD, "liboracle_raster_%s.so" % key)
+        if not os.path.exists(path):
+            build()
+        _libs[key] = ctypes.CDLL(path)
+    return _libs[key]
+
+
+def _p(a):
+    return None if a is None else a.ctypes.data_as(ctypes.c_void_p)
+
+
+def _prep(dtype, *arrs):
+    out = []
+    for a in arrs:
+        out.append(None if a is None else np.ascontiguousarray(np.asarray(a, dtype=dtype)))
+    return out
+
+
+def forward(means3D, opacities, viewmatrix, projmatrix, tanfovx, tanfovy, bg, H, W, colors=None, shs=None,
+            sh_degree=0, campos=None, scales=None, rotations=None, cov3D=None, scale_modifier=1.0,
+            dtype=np.float32):
+    """Returns dict(color[3,H,W], depth[H,W], alpha[H,W], radii[G], final_T, n_contrib, num_pairs)."""
+    L = _lib(dtype)
+    real = ctypes.c_double if np.dtype(dtype) == np.float64 else ctypes.c_float
+    means3D, opacities, viewmatrix, projmatrix, bg, colors, shs, campos, scales, rotations, cov3D = _prep(
+        dtype, means3D, opacities, viewmatrix, projmatrix, bg, colors, shs, campos, scales, rotations, cov3D)
+    G = means3D.shape[0]
+    ncoef = 0 if shs is None else shs.shape[1]
+    color = np.zeros((3, H, W), dtype); depth = np.zeros((H, W), dtype); alpha = np.zeros((H, W), dtype)
+    radii = np.zeros(G, np.int32); fT = np.zeros((H, W), dtype); nc = np.zeros((H, W), np.int32)
+    K = ctypes.c_int64(0)
+    L.dwg_oracle_raster_forward.restype = ctypes.c_int
+    L.dwg_oracle_raster_forward(
+        ctypes.c_int(G), ctypes.c_int(H), ctypes.c_int(W), _p(means3D), _p(colors), _p(shs), ctypes.c_int(sh_degree),
+        ctypes.c_int(ncoef), _p(campos), _p(opacities.reshape(-1)), _p(scales), _p(rotations), _p(cov3D),
+        _p(viewmatrix.reshape(-1)), _p(projmatrix.reshape(-1)), real(tanfovx), real(tanfovy), _p(bg),
+        real(scale_modifier), _p(color), _p(depth), _p(alpha), _p(radii), _p(fT), _p(nc), ctypes.byref(K))
+    return dict(color=color, depth=depth, alpha=alpha, radii=radii, final_T=fT, n_contrib=nc, num_pairs=K.value)
+
+
+def backward(means3D, opacities, viewmatrix, projmatrix, tanfovx, tanfovy, bg, H, W, g_color, g_depth=None,
+             g_alpha=None, colors=None, shs=None, sh_degree=0, campos=None, scales=None, rotations=None, cov3D=None,
+             scale_modifier=1.0, dtype=np.float32):
+    L = _lib(dtype)
+    real = ctypes.c_double if np.dtype(dtype) == np.float64 else ctypes.c_float
+    (means3D, opacities, viewmatrix, projmatrix, bg, colors, shs, campos, scales, rotations, cov3D, g_color, g_depth,
+     g_alpha) = _prep(dtype, means3D, opacities, viewmatrix, projmatrix, bg, colors, shs, campos, scales, rotations,
+                      cov3D, g_color, g_depth, g_alpha)
+    G = means3D.shape[0]
+    ncoef = 0 if shs is None else shs.shape[1]
+    out = dict(
+        means3D=np.zeros((G, 3), dtype), means2D=np.zeros((G, 3), dtype), opacities=np.zeros(G, dtype),
+        colors=np.zeros((G, 3), dtype), shs=None if shs is None else np.zeros_like(shs),
+        scales=np.zeros((G, 3), dtype), rotations=np.zeros((G, 4), dtype), cov3D=np.zeros((G, 6), dtype))
+    L.dwg_oracle_raster_backward.restype = ctypes.c_int
+    L.dwg_oracle_raster_backward(
+        ctypes.c_int(G), ctypes.c_int(H), ctypes.c_int(W), _p(means3D), _p(colors), _p(shs), ctypes.c_int(sh_degree),
+        ctypes.c_int(ncoef), _p(campos), _p(opacities.reshape(-1)), _p(scales), _p(rotations), _p(cov3D),
+        _p(viewmatrix.reshape(-1)), _p(projmatrix.reshape(-1)), real(tanfovx), real(tanfovy), _p(bg),
+        real(scale_modifier), _p(g_color), _p(g_depth), _p(g_alpha), _p(out["means3D"]), _p(out["means2D"]),
+        _p(out["colors"]), _p(out["shs"]), _p(out["opacities"]), _p(out["scales"]), _p(out["rotations"]),
+        _p(out["cov3D"]))
+    return out
