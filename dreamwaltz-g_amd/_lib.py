@@ -27,6 +27,7 @@ class RasterSettingsC(ctypes.Structure):
 
 # name -> (restype, argtypes); every symbol include/*.h declares must be listed here (tests check it)
 _vp, _i32, _i64, _f32, _sz = ctypes.c_void_p, ctypes.c_int32, ctypes.c_int64, ctypes.c_float, ctypes.c_size_t
+_u32 = ctypes.c_uint32
 SIGNATURES = {
     "dwg_raster_workspace_sizes": (ctypes.c_int, [_i32, _i32, _i32, _i64, ctypes.POINTER(_sz), ctypes.POINTER(_sz),
                                                   ctypes.POINTER(_sz)]),
@@ -36,6 +37,16 @@ SIGNATURES = {
                                                  _vp, _vp]),
     "dwg_raster_backward": (ctypes.c_int, [ctypes.POINTER(RasterSettingsC), _i32] + [_vp] * 7 + [_vp, _vp, _i64, _vp, _vp]
                             + [_vp] * 3 + [_vp] * 8 + [_vp]),
+    # include/dwg_lbs.h
+    "dwg_lbs_joint_chain": (ctypes.c_int, [_i32, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
+    "dwg_lbs_blend_forward": (ctypes.c_int, [_i32, _i32, _i32] + [_vp] * 7 + [_vp]),
+    "dwg_lbs_blend_backward": (ctypes.c_int, [_i32] + [_vp] * 7 + [_vp]),
+    "dwg_lbs_vertex_transform": (ctypes.c_int, [_i32] * 5 + [_vp] * 9 + [_vp]),
+    # include/dwg_gridenc.h
+    "dwg_grid_encode_forward": (ctypes.c_int, [_vp, _vp, _vp, _vp, _u32, _u32, _u32, _u32, _f32, _u32, _vp, _u32, _u32, _u32,
+                                               _u32, _vp]),
+    "dwg_grid_encode_backward": (ctypes.c_int, [_vp, _vp, _vp, _vp, _vp, _u32, _u32, _u32, _u32, _f32, _u32, _vp, _vp, _u32,
+                                                _u32, _u32, _u32, _vp]),
 }
 
 

@@ -4,10 +4,7 @@
 #include <stddef.h>
 #include <stdint.h>
 
-#define DWG_OK 0
-#define DWG_E_ARG (-1)
-#define DWG_E_LAUNCH (-2)
-#define DWG_E_CAPACITY (-3)
+#include "../../include/dwg_types.h"
 
 #define DWG_TILE 16
 #define DWG_WAVE 64

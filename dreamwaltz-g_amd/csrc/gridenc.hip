@@ -1,0 +1,210 @@
+// gridenc.hip -- multi-resolution hash / tiled grid encoder (D = 3, C = 2) for gfx950.
+//
+// Native restatement of the reference's in-repo CUDA extension
+//   /root/reference/core/nerf/gridencoder/src/gridencoder.cu : get_grid_index :66-84, kernel_grid :87-242,
+//   kernel_grid_backward :245-337, kernel_input_backward :340-366   (boundary B2: `_gridencoder` backend,
+//   prototypes gridencoder.h:12-14, Python caller grid.py:28-96)
+// with a different work decomposition: one lane per (point, level) with the 16 levels of a point in 16 adjacent
+// lanes, so that the [B, L*C] feature row (128 B), the dy_dx row (384 B) and the upstream gradient row are each
+// written / read as whole cache lines by a quarter-wave, while the 8 corner gathers of every lane are independent
+// 8-byte loads in flight (the 50 MB table lives in the 256 MB Infinity Cache / per-XCD L2).
+// Gather-bound: 16 levels x 8 corners x 8 B = 1 KiB gathered per point and direction.
+#include "dwg_common.h"
+#include "../../include/dwg_gridenc.h"
+
+namespace {
+
+struct GridP {
+    uint32_t B, L;
+    float S;
+    uint32_t H, gridtype, align_corners, interp, layout;  // layout 0: [L,B,C] (reference backend), 1: [B,L*C]
+};
+
+__device__ __forceinline__ uint32_t grid_index(uint32_t gridtype, bool align, uint32_t hashmap_size, uint32_t res,
+                                               uint32_t x, uint32_t y, uint32_t z) {
+    // gridencoder.cu:66-84 for D = 3
+    uint32_t stride = 1, index = 0;
+    const uint32_t step = align ? res : (res + 1);
+    if (stride <= hashmap_size) { index += x * stride; stride *= step; }
+    if (stride <= hashmap_size) { index += y * stride; stride *= step; }
+    if (stride <= hashmap_size) { index += z * stride; stride *= step; }
+    if (gridtype == 0 && stride > hashmap_size) index = (x * 1u) ^ (y * 2654435761u) ^ (z * 805459861u);
+    return (index % hashmap_size) * 2u;
+}
+
+struct Cell {
+    bool oob;
+    float scale;
+    uint32_t res, hsize;
+    float w[3], dw[3];
+    uint32_t g[3];
+};
+
+__device__ __forceinline__ Cell locate(const GridP& p, const int* __restrict__ offsets, uint32_t level, float x0, float x1,
+                                       float x2) {
+    Cell c;
+    c.oob = (x0 < 0.f || x0 > 1.f || x1 < 0.f || x1 > 1.f || x2 < 0.f || x2 > 1.f);
+    c.hsize = (uint32_t)(offsets[level + 1] - offsets[level]);
+    c.scale = exp2f((float)level * p.S) * (float)p.H - 1.0f;
+    c.res = (uint32_t)ceilf(c.scale) + 1u;
+    const float xs[3] = {x0, x1, x2};
+    // NB (bug-compatible with gridencoder.cu:137): pos_deriv is initialised {1, 0, 0}; smoothstep overwrites all three
+    c.dw[0] = 1.f; c.dw[1] = 0.f; c.dw[2] = 0.f;
+#pragma unroll
+    for (int d = 0; d < 3; d++) {
+        float pos = xs[d] * c.scale + (p.align_corners ? 0.0f : 0.5f);
+        float fl = floorf(pos);
+        c.g[d] = (uint32_t)fl;
+        pos -= fl;
+        if (p.interp == 1) { c.dw[d] = 6.f * pos * (1.f - pos); pos = pos * pos * (3.f - 2.f * pos); }
+        c.w[d] = pos;
+    }
+    return c;
+}
+
+__global__ __launch_bounds__(256) void k_grid_fwd(GridP p, const float* __restrict__ x, const float2* __restrict__ table,
+                                                  const int* __restrict__ offsets, float* __restrict__ out,
+                                                  float* __restrict__ dy_dx) {
+    const uint32_t t = blockIdx.x * 256u + threadIdx.x;
+    const uint32_t b = t / p.L, level = t - b * p.L;
+    if (b >= p.B) return;
+    const float x0 = x[3 * b], x1 = x[3 * b + 1], x2 = x[3 * b + 2];
+    Cell c = locate(p, offsets, level, x0, x1, x2);
+    float* o = p.layout ? out + (size_t)b * p.L * 2 + level * 2 : out + ((size_t)level * p.B + b) * 2;
+    float* dd = dy_dx ? dy_dx + ((size_t)b * p.L + level) * 6 : nullptr;
+    if (c.oob) {
+        o[0] = 0.f; o[1] = 0.f;
+        if (dd) { for (int k = 0; k < 6; k++) dd[k] = 0.f; }
+        return;
+    }
+    const float2* g = table + (uint32_t)offsets[level];
+    float2 v[8];
+#pragma unroll
+    for (int idx = 0; idx < 8; idx++) {
+        uint32_t gx = c.g[0] + (idx & 1), gy = c.g[1] + ((idx >> 1) & 1), gz = c.g[2] + ((idx >> 2) & 1);
+        v[idx] = g[grid_index(p.gridtype, p.align_corners, c.hsize, c.res, gx, gy, gz) >> 1];
+    }
+    float r0 = 0.f, r1 = 0.f;
+#pragma unroll
+    for (int idx = 0; idx < 8; idx++) {
+        float w = ((idx & 1) ? c.w[0] : 1.f - c.w[0]) * ((idx & 2) ? c.w[1] : 1.f - c.w[1]) * ((idx & 4) ? c.w[2] : 1.f - c.w[2]);
+        r0 += w * v[idx].x; r1 += w * v[idx].y;
+    }
+    *reinterpret_cast<float2*>(o) = make_float2(r0, r1);
+    if (dd) {
+        // d out / d x_gd = scale * dsmooth(gd) * sum over the 4 corner pairs along gd (gridencoder.cu:196-240)
+#pragma unroll
+        for (int gd = 0; gd < 3; gd++) {
+            float g0 = 0.f, g1 = 0.f;
+            const int d1 = gd == 0 ? 1 : 0, d2 = gd == 2 ? 1 : 2;
+#pragma unroll
+            for (int k = 0; k < 4; k++) {
+                int b1 = k & 1, b2 = (k >> 1) & 1;
+                float w = c.scale * (b1 ? c.w[d1] : 1.f - c.w[d1]) * (b2 ? c.w[d2] : 1.f - c.w[d2]);
+                int left = (b1 << d1) | (b2 << d2), right = left | (1 << gd);
+                g0 += w * (v[right].x - v[left].x) * c.dw[gd];
+                g1 += w * (v[right].y - v[left].y) * c.dw[gd];
+            }
+            dd[gd * 2] = g0; dd[gd * 2 + 1] = g1;
+        }
+    }
+}
+
+// grad_table += w * grad (atomics), and grad_x[b,d] = sum_{l,c} grad[b,l,c] * dy_dx[b,l,d,c]
+__global__ __launch_bounds__(256) void k_grid_bwd(GridP p, const float* __restrict__ grad, const float* __restrict__ x,
+                                                  const int* __restrict__ offsets, float* __restrict__ grad_table,
+                                                  const float* __restrict__ dy_dx, float* __restrict__ grad_x) {
+    const uint32_t t = blockIdx.x * 256u + threadIdx.x;
+    const uint32_t b = t / p.L, level = t - b * p.L;
+    const bool live = b < p.B;
+    float g0 = 0.f, g1 = 0.f;
+    float gx[3] = {0.f, 0.f, 0.f};
+    if (live) {
+        const float* gsrc = p.layout ? grad + (size_t)b * p.L * 2 + level * 2 : grad + ((size_t)level * p.B + b) * 2;
+        g0 = gsrc[0]; g1 = gsrc[1];
+        const float x0 = x[3 * b], x1 = x[3 * b + 1], x2 = x[3 * b + 2];
+        Cell c = locate(p, offsets, level, x0, x1, x2);
+        if (!c.oob) {
+            if (grad_table) {
+                float* gt = grad_table + (size_t)(uint32_t)offsets[level] * 2;
+#pragma unroll
+                for (int idx = 0; idx < 8; idx++) {
+                    uint32_t cx = c.g[0] + (idx & 1), cy = c.g[1] + ((idx >> 1) & 1), cz = c.g[2] + ((idx >> 2) & 1);
+                    float w = ((idx & 1) ? c.w[0] : 1.f - c.w[0]) * ((idx & 2) ? c.w[1] : 1.f - c.w[1]) *
+                              ((idx & 4) ? c.w[2] : 1.f - c.w[2]);
+                    uint32_t index = grid_index(p.gridtype, p.align_corners, c.hsize, c.res, cx, cy, cz);
+                    atomicAdd(gt + index, w * g0);
+                    atomicAdd(gt + index + 1, w * g1);
+                }
+            }
+            if (dy_dx && grad_x) {
+                const float* dd = dy_dx + ((size_t)b * p.L + level) * 6;
+#pragma unroll
+                for (int d = 0; d < 3; d++) gx[d] = g0 * dd[2 * d] + g1 * dd[2 * d + 1];
+            }
+        }
+    }
+    if (dy_dx && grad_x) {
+        // reduce over the L (<= 16, power of two lanes) levels of a point: they sit in adjacent lanes
+        if (p.L == 16) {
+#pragma unroll
+            for (int d = 0; d < 3; d++) {
+                float v = gx[d];
+                v += __shfl_xor(v, 1); v += __shfl_xor(v, 2); v += __shfl_xor(v, 4); v += __shfl_xor(v, 8);
+                gx[d] = v;
+            }
+            if (live && level == 0) { grad_x[3 * b] = gx[0]; grad_x[3 * b + 1] = gx[1]; grad_x[3 * b + 2] = gx[2]; }
+        } else if (live) {
+            atomicAdd(&grad_x[3 * b], gx[0]); atomicAdd(&grad_x[3 * b + 1], gx[1]); atomicAdd(&grad_x[3 * b + 2], gx[2]);
+        }
+    }
+}
+
+static int check(uint32_t B, uint32_t D, uint32_t C, uint32_t L) {
+    if (D != 3 || C != 2 || L == 0 || L > 32) return DWG_E_ARG;  // the avatar's encoder: D=3, C=2, L=16
+    if ((uint64_t)B * L > 0xffffff00ull) return DWG_E_ARG;
+    return DWG_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+int dwg_grid_encode_forward(const float* inputs, const float* embeddings, const int32_t* offsets, float* outputs,
+                            uint32_t B, uint32_t D, uint32_t C, uint32_t L, float S, uint32_t H, float* dy_dx,
+                            uint32_t gridtype, uint32_t align_corners, uint32_t interp, uint32_t out_layout,
+                            dwg_stream_t stream) {
+    int rc = check(B, D, C, L);
+    if (rc) return rc;
+    if (B == 0) return DWG_OK;
+    if (!inputs || !embeddings || !offsets || !outputs) return DWG_E_ARG;
+    GridP p{B, L, S, H, gridtype, align_corners, interp, out_layout};
+    uint32_t n = B * L;
+    hipLaunchKernelGGL(k_grid_fwd, dim3((n + 255) / 256), dim3(256), 0, (hipStream_t)stream, p, inputs,
+                       (const float2*)embeddings, offsets, outputs, dy_dx);
+    DWG_RETURN_IF_LAUNCH_FAILED();
+    return DWG_OK;
+}
+
+int dwg_grid_encode_backward(const float* grad, const float* inputs, const float* embeddings, const int32_t* offsets,
+                             float* grad_embeddings, uint32_t B, uint32_t D, uint32_t C, uint32_t L, float S, uint32_t H,
+                             const float* dy_dx, float* grad_inputs, uint32_t gridtype, uint32_t align_corners,
+                             uint32_t interp, uint32_t grad_layout, dwg_stream_t stream) {
+    int rc = check(B, D, C, L);
+    if (rc) return rc;
+    if (B == 0) return DWG_OK;
+    (void)embeddings;
+    if (!grad || !inputs || !offsets) return DWG_E_ARG;
+    if ((dy_dx == nullptr) != (grad_inputs == nullptr)) return DWG_E_ARG;
+    GridP p{B, L, S, H, gridtype, align_corners, interp, grad_layout};
+    uint32_t n = B * L;
+    if (grad_inputs && L != 16) {
+        if (hipMemsetAsync(grad_inputs, 0, (size_t)B * 3 * sizeof(float), (hipStream_t)stream) != hipSuccess) return DWG_E_LAUNCH;
+    }
+    hipLaunchKernelGGL(k_grid_bwd, dim3((n + 255) / 256), dim3(256), 0, (hipStream_t)stream, p, grad, inputs, offsets,
+                       grad_embeddings, dy_dx, grad_inputs);
+    DWG_RETURN_IF_LAUNCH_FAILED();
+    return DWG_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,260 @@
+// lbs.hip -- SMPL-X linear-blend-skinning stage for gfx950.
+//
+//   k_joint_chain      one 64-lane workgroup: Rodrigues for all joints, kinematic chain through LDS,
+//                      rest-pose removal and global translation  -> A[J,4,4]
+//                      (replaces smplx.lbs.batch_rodrigues / batch_rigid_transform as called from
+//                       /root/reference/core/human/inverse_lbs.py:688,696 and the compose at avatar.py:1441-1444)
+//   k_blend_fwd / bwd  per-Gaussian blend T_i = sum_j w_ij A_j, point transform and the row-flipped quaternion
+//                      path (inverse_lbs.py:190-242, avatar.py:1426-1462).  HBM-bound on the [N,J] weight rows
+//                      (220 B/Gaussian at J=55): each wave streams its 64 rows with fully coalesced dword loads
+//                      into LDS (row stride J is odd -> conflict-free per-lane row walks), A lives in LDS as
+//                      broadcast reads.
+//   k_vertex_transform per-vertex transform_V = compose(shape offset, pose offset, rigid blend, transl) applied to
+//                      the mesh-bound vertex subset (inverse_lbs.py:652-717,758-772; avatar.py:1570-1576)
+#include "dwg_common.h"
+#include "lbs_math.h"
+#include "../../include/dwg_lbs.h"
+
+namespace {
+
+#define MAXJ 64
+
+__global__ __launch_bounds__(64) void k_joint_chain(int J, const float* __restrict__ pose /*[J,3]*/,
+                                                    const float* __restrict__ joints /*[J,3]*/,
+                                                    const int* __restrict__ parents, const float* __restrict__ transl,
+                                                    float* __restrict__ A /*[J,16]*/, float* __restrict__ rot_mats /*[J,9]|null*/) {
+    __shared__ float tm[MAXJ][16];
+    __shared__ float ch[MAXJ][16];
+    __shared__ int par[MAXJ];
+    const int t = threadIdx.x;
+    if (t < J) {
+        // Rodrigues with angle = |r + 1e-8| (smplx.lbs.batch_rodrigues)
+        float rx = pose[3 * t], ry = pose[3 * t + 1], rz = pose[3 * t + 2];
+        float ax = rx + 1e-8f, ay = ry + 1e-8f, az = rz + 1e-8f;
+        float angle = sqrtf(ax * ax + ay * ay + az * az);
+        float dx = rx / angle, dy = ry / angle, dz = rz / angle;
+        float s = sinf(angle), c = cosf(angle);
+        float K[9] = {0.f, -dz, dy, dz, 0.f, -dx, -dy, dx, 0.f};
+        float R[9];
+        for (int r = 0; r < 3; r++)
+            for (int cc = 0; cc < 3; cc++) {
+                float kk = K[3 * r] * K[cc] + K[3 * r + 1] * K[3 + cc] + K[3 * r + 2] * K[6 + cc];
+                R[3 * r + cc] = (r == cc ? 1.f : 0.f) + s * K[3 * r + cc] + (1.f - c) * kk;
+            }
+        int p = parents[t];
+        par[t] = p;
+        float rel[3];
+        for (int k = 0; k < 3; k++) rel[k] = joints[3 * t + k] - (t > 0 ? joints[3 * p + k] : 0.f);
+        for (int r = 0; r < 3; r++) {
+            for (int cc = 0; cc < 3; cc++) tm[t][4 * r + cc] = R[3 * r + cc];
+            tm[t][4 * r + 3] = rel[r];
+        }
+        tm[t][12] = 0.f; tm[t][13] = 0.f; tm[t][14] = 0.f; tm[t][15] = 1.f;
+        if (rot_mats) for (int k = 0; k < 9; k++) rot_mats[9 * t + k] = R[k];
+    }
+    __syncthreads();
+    if (t < 16) ch[0][t] = tm[0][t];
+    __syncthreads();
+    for (int i = 1; i < J; i++) {
+        if (t < 16) {
+            int r = t >> 2, c = t & 3, p = par[i];
+            ch[i][t] = ch[p][4 * r] * tm[i][c] + ch[p][4 * r + 1] * tm[i][4 + c] + ch[p][4 * r + 2] * tm[i][8 + c] +
+                       ch[p][4 * r + 3] * tm[i][12 + c];
+        }
+        __syncthreads();
+    }
+    if (t < J) {
+        float jx = joints[3 * t], jy = joints[3 * t + 1], jz = joints[3 * t + 2];
+        float o[16];
+        for (int k = 0; k < 16; k++) o[k] = ch[t][k];
+        for (int r = 0; r < 4; r++) o[4 * r + 3] -= ch[t][4 * r] * jx + ch[t][4 * r + 1] * jy + ch[t][4 * r + 2] * jz;
+        if (transl) { o[3] += transl[0]; o[7] += transl[1]; o[11] += transl[2]; }  // compose(J_pose_rigid, G_transl_offset)
+        for (int k = 0; k < 16; k++) A[16 * t + k] = o[k];
+    }
+}
+
+// 256 threads = 4 waves; each wave owns 64 consecutive Gaussians and its own LDS slab of weight rows.
+template <bool HAS_Q>
+__global__ __launch_bounds__(256) void k_blend_fwd(int N, int J, int normalize, const float* __restrict__ A,
+                                                   const float* __restrict__ w, const float* __restrict__ p,
+                                                   const float* __restrict__ q, float* __restrict__ pout,
+                                                   float* __restrict__ qout, float* __restrict__ T12save) {
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    float* sA = smem;                 // [J][12]
+    float* sW = smem + MAXJ * 12;     // [4 waves][64][J]
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    for (int k = tid; k < J * 12; k += 256) { int j = k / 12, e = k - j * 12; sA[k] = A[16 * j + e]; }
+    const int base = blockIdx.x * 256 + wave * 64;
+    const int rows = min(64, N - base);
+    float* myW = sW + wave * 64 * J;
+    if (rows > 0) {
+        const float* src = w + (size_t)base * J;
+        for (int k = lane; k < rows * J; k += 64) myW[k] = src[k];
+    }
+    __syncthreads();
+    const int i = base + lane;
+    if (lane >= rows || rows <= 0) return;
+    float T[12];
+#pragma unroll
+    for (int e = 0; e < 12; e++) T[e] = 0.f;
+    float wsum = 0.f;
+    const float* row = myW + lane * J;
+    for (int j = 0; j < J; j++) {
+        float wj = row[j];
+        wsum += wj;
+#pragma unroll
+        for (int e = 0; e < 12; e++) T[e] += wj * sA[j * 12 + e];
+    }
+    if (normalize) {
+        float inv = 1.f / wsum;
+#pragma unroll
+        for (int e = 0; e < 12; e++) T[e] *= inv;
+    }
+    float pi[3] = {p[3 * i], p[3 * i + 1], p[3 * i + 2]}, po[3], qi[4], qo[4];
+    if (HAS_Q) { qi[0] = q[4 * i]; qi[1] = q[4 * i + 1]; qi[2] = q[4 * i + 2]; qi[3] = q[4 * i + 3]; }
+    dwg_lbs_apply(T, pi, HAS_Q ? qi : nullptr, po, qo);
+    pout[3 * i] = po[0]; pout[3 * i + 1] = po[1]; pout[3 * i + 2] = po[2];
+    if (HAS_Q) { qout[4 * i] = qo[0]; qout[4 * i + 1] = qo[1]; qout[4 * i + 2] = qo[2]; qout[4 * i + 3] = qo[3]; }
+    if (T12save) {
+        float4* dst = reinterpret_cast<float4*>(T12save + (size_t)i * 12);
+        dst[0] = make_float4(T[0], T[1], T[2], T[3]); dst[1] = make_float4(T[4], T[5], T[6], T[7]);
+        dst[2] = make_float4(T[8], T[9], T[10], T[11]);
+    }
+}
+
+template <bool HAS_Q>
+__global__ __launch_bounds__(256) void k_blend_bwd(int N, const float* __restrict__ T12, const float* __restrict__ p,
+                                                   const float* __restrict__ q, const float* __restrict__ gpout,
+                                                   const float* __restrict__ gqout, float* __restrict__ gp,
+                                                   float* __restrict__ gq) {
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= N) return;
+    const float4* src = reinterpret_cast<const float4*>(T12 + (size_t)i * 12);
+    float4 a = src[0], b = src[1], c = src[2];
+    float T[12] = {a.x, a.y, a.z, a.w, b.x, b.y, b.z, b.w, c.x, c.y, c.z, c.w};
+    float pi[3] = {p[3 * i], p[3 * i + 1], p[3 * i + 2]};
+    float go[3] = {gpout[3 * i], gpout[3 * i + 1], gpout[3 * i + 2]};
+    float qi[4], gqo[4], gpi[3], gqi[4];
+    if (HAS_Q) {
+        for (int k = 0; k < 4; k++) { qi[k] = q[4 * i + k]; gqo[k] = gqout[4 * i + k]; }
+    }
+    dwg_lbs_apply_bwd(T, pi, HAS_Q ? qi : nullptr, go, HAS_Q ? gqo : nullptr, gpi, gqi, nullptr);
+    gp[3 * i] = gpi[0]; gp[3 * i + 1] = gpi[1]; gp[3 * i + 2] = gpi[2];
+    if (HAS_Q) { for (int k = 0; k < 4; k++) gq[4 * i + k] = gqi[k]; }
+}
+
+// transform_V for a vertex subset: out = T_rigid(v) * (x + shape_off(v) + pose_off(v)) [+ transl already in A]
+__global__ __launch_bounds__(256) void k_vertex_transform(int Vp, int V, int J, int n_shape, int n_posefeat,
+                                                          const int* __restrict__ vidx, const float* __restrict__ x,
+                                                          const float* __restrict__ A /*[J,16] incl. transl*/,
+                                                          const float* __restrict__ lbs_w /*[V,J]*/,
+                                                          const float* __restrict__ shapedirs /*[V,3,n_shape] or null*/,
+                                                          const float* __restrict__ shape /*[n_shape]*/,
+                                                          const float* __restrict__ posedirs /*[n_posefeat, 3V] or null*/,
+                                                          const float* __restrict__ rot_mats /*[J,9]*/,
+                                                          float* __restrict__ out) {
+    __shared__ float sA[MAXJ * 12];
+    __shared__ float sfeat[(MAXJ - 1) * 9];
+    const int tid = threadIdx.x;
+    for (int k = tid; k < J * 12; k += 256) { int j = k / 12, e = k - j * 12; sA[k] = A[16 * j + e]; }
+    for (int k = tid; k < n_posefeat; k += 256) {
+        int j = k / 9 + 1, e = k % 9;
+        sfeat[k] = rot_mats[9 * j + e] - ((e == 0 || e == 4 || e == 8) ? 1.f : 0.f);
+    }
+    __syncthreads();
+    int t = blockIdx.x * 256 + tid;
+    if (t >= Vp) return;
+    int v = vidx[t];
+    float px = x[3 * t], py = x[3 * t + 1], pz = x[3 * t + 2];
+    if (shapedirs) {
+        const float* sd = shapedirs + (size_t)v * 3 * n_shape;
+        float o0 = 0.f, o1 = 0.f, o2 = 0.f;
+        for (int l = 0; l < n_shape; l++) { float b = shape[l]; o0 += sd[l] * b; o1 += sd[n_shape + l] * b; o2 += sd[2 * n_shape + l] * b; }
+        px += o0; py += o1; pz += o2;
+    }
+    if (posedirs) {
+        float o0 = 0.f, o1 = 0.f, o2 = 0.f;
+        const float* pd = posedirs + (size_t)3 * v;
+        for (int f = 0; f < n_posefeat; f++) {
+            float s = sfeat[f];
+            const float* r = pd + (size_t)f * 3 * V;
+            o0 += s * r[0]; o1 += s * r[1]; o2 += s * r[2];
+        }
+        px += o0; py += o1; pz += o2;
+    }
+    float T[12];
+    for (int e = 0; e < 12; e++) T[e] = 0.f;
+    const float* wr = lbs_w + (size_t)v * J;
+    for (int j = 0; j < J; j++) {
+        float wj = wr[j];
+        if (wj != 0.f) for (int e = 0; e < 12; e++) T[e] += wj * sA[j * 12 + e];
+    }
+    out[3 * t] = T[0] * px + T[1] * py + T[2] * pz + T[3];
+    out[3 * t + 1] = T[4] * px + T[5] * py + T[6] * pz + T[7];
+    out[3 * t + 2] = T[8] * px + T[9] * py + T[10] * pz + T[11];
+}
+
+}  // namespace
+
+extern "C" {
+
+int dwg_lbs_joint_chain(int32_t J, const float* pose, const float* joints, const int32_t* parents, const float* transl,
+                        float* A_out, float* rot_mats_out, dwg_stream_t stream) {
+    if (J <= 0 || J > MAXJ || !pose || !joints || !parents || !A_out) return DWG_E_ARG;
+    hipLaunchKernelGGL(k_joint_chain, dim3(1), dim3(64), 0, (hipStream_t)stream, J, pose, joints, parents, transl, A_out,
+                       rot_mats_out);
+    DWG_RETURN_IF_LAUNCH_FAILED();
+    return DWG_OK;
+}
+
+int dwg_lbs_blend_forward(int32_t N, int32_t J, int32_t normalize_weights, const float* A, const float* weights,
+                          const float* points, const float* quats, float* points_out, float* quats_out, float* T12_save,
+                          dwg_stream_t stream) {
+    if (N < 0 || J <= 0 || J > MAXJ) return DWG_E_ARG;
+    if (N == 0) return DWG_OK;
+    if (!A || !weights || !points || !points_out || (quats && !quats_out)) return DWG_E_ARG;
+    size_t lds = (size_t)(MAXJ * 12 + 256 * J) * sizeof(float);
+    dim3 grid(dwg_cdiv(N, 256)), block(256);
+    if (quats)
+        hipLaunchKernelGGL((k_blend_fwd<true>), grid, block, lds, (hipStream_t)stream, N, J, normalize_weights, A, weights,
+                           points, quats, points_out, quats_out, T12_save);
+    else
+        hipLaunchKernelGGL((k_blend_fwd<false>), grid, block, lds, (hipStream_t)stream, N, J, normalize_weights, A, weights,
+                           points, quats, points_out, quats_out, T12_save);
+    DWG_RETURN_IF_LAUNCH_FAILED();
+    return DWG_OK;
+}
+
+int dwg_lbs_blend_backward(int32_t N, const float* T12, const float* points, const float* quats, const float* g_points_out,
+                           const float* g_quats_out, float* g_points, float* g_quats, dwg_stream_t stream) {
+    if (N < 0) return DWG_E_ARG;
+    if (N == 0) return DWG_OK;
+    if (!T12 || !points || !g_points_out || !g_points || (quats && (!g_quats_out || !g_quats))) return DWG_E_ARG;
+    dim3 grid(dwg_cdiv(N, 256)), block(256);
+    if (quats)
+        hipLaunchKernelGGL((k_blend_bwd<true>), grid, block, 0, (hipStream_t)stream, N, T12, points, quats, g_points_out,
+                           g_quats_out, g_points, g_quats);
+    else
+        hipLaunchKernelGGL((k_blend_bwd<false>), grid, block, 0, (hipStream_t)stream, N, T12, points, quats, g_points_out,
+                           g_quats_out, g_points, g_quats);
+    DWG_RETURN_IF_LAUNCH_FAILED();
+    return DWG_OK;
+}
+
+int dwg_lbs_vertex_transform(int32_t Vp, int32_t V, int32_t J, int32_t n_shape, int32_t n_posefeat,
+                             const int32_t* vertex_indices, const float* vertex_coords, const float* A,
+                             const float* lbs_weights, const float* shapedirs, const float* shape_coeffs,
+                             const float* posedirs, const float* rot_mats, float* out, dwg_stream_t stream) {
+    if (Vp < 0 || V <= 0 || J <= 0 || J > MAXJ || n_posefeat > (MAXJ - 1) * 9) return DWG_E_ARG;
+    if (Vp == 0) return DWG_OK;
+    if (!vertex_indices || !vertex_coords || !A || !lbs_weights || !out) return DWG_E_ARG;
+    if (shapedirs && !shape_coeffs) return DWG_E_ARG;
+    if (posedirs && !rot_mats) return DWG_E_ARG;
+    hipLaunchKernelGGL(k_vertex_transform, dim3(dwg_cdiv(Vp, 256)), dim3(256), 0, (hipStream_t)stream, Vp, V, J, n_shape,
+                       posedirs ? n_posefeat : 0, vertex_indices, vertex_coords, A, lbs_weights, shapedirs, shape_coeffs,
+                       posedirs, rot_mats, out);
+    DWG_RETURN_IF_LAUNCH_FAILED();
+    return DWG_OK;
+}
+
+}  // extern "C"

@@ -707,11 +707,14 @@ int dwg_raster_forward_bin(const dwg_raster_settings* cfg, int32_t G, const floa
     Params p;
     int rc = make_params(cfg, G, &p);
     if (rc) return rc;
-    if (!ws_geom || (G > 0 && (!means3D || !opacities || !radii))) return DWG_E_ARG;
-    if ((shs == nullptr) == (colors_precomp == nullptr)) return DWG_E_ARG;          // exactly one colour source
-    if (((scales == nullptr) || (rotations == nullptr)) == (cov3D_precomp == nullptr)) return DWG_E_ARG;
-    if (shs && (!cfg->campos || cfg->sh_degree < 0 || cfg->sh_degree > 3 ||
-                cfg->sh_coeffs < (cfg->sh_degree + 1) * (cfg->sh_degree + 1))) return DWG_E_ARG;
+    if (!ws_geom) return DWG_E_ARG;
+    if (G > 0) {  // with G == 0 every per-Gaussian pointer may be NULL
+        if (!means3D || !opacities || !radii) return DWG_E_ARG;
+        if ((shs == nullptr) == (colors_precomp == nullptr)) return DWG_E_ARG;      // exactly one colour source
+        if (((scales == nullptr) || (rotations == nullptr)) == (cov3D_precomp == nullptr)) return DWG_E_ARG;
+        if (shs && (!cfg->campos || cfg->sh_degree < 0 || cfg->sh_degree > 3 ||
+                    cfg->sh_coeffs < (cfg->sh_degree + 1) * (cfg->sh_degree + 1))) return DWG_E_ARG;
+    }
     hipStream_t stream = (hipStream_t)stream_;
     GeomLayout L = geom_layout(G, p.H, p.W);
     char* ws = (char*)ws_geom;
@@ -777,10 +780,10 @@ int dwg_raster_backward(const dwg_raster_settings* cfg, int32_t G, const float* 
     if (rc) return rc;
     if (!ws_geom || !ws_pairs || !ws_image || !ws_grad || !dL_dout_color || !dL_dmeans3D || pair_capacity < 0)
         return DWG_E_ARG;
-    if ((shs == nullptr) == (colors_precomp == nullptr)) return DWG_E_ARG;
-    if (((scales == nullptr) || (rotations == nullptr)) == (cov3D_precomp == nullptr)) return DWG_E_ARG;
     (void)opacities;
     if (G == 0) return DWG_OK;
+    if ((shs == nullptr) == (colors_precomp == nullptr)) return DWG_E_ARG;
+    if (((scales == nullptr) || (rotations == nullptr)) == (cov3D_precomp == nullptr)) return DWG_E_ARG;
     hipStream_t stream = (hipStream_t)stream_;
     GeomLayout L = geom_layout(G, p.H, p.W);
     PairLayout PL = pair_layout(pair_capacity);

@@ -1,0 +1,124 @@
+"""MI355X-native grid encoder behind the reference's interfaces (boundary B2).
+
+  GridEncoder / grid_encode      mirror /root/reference/core/nerf/gridencoder/grid.py:28-165 (same ctor args,
+                                 same offset table, same autograd contract)
+  grid_encode_forward/backward   mirror the pybind backend `_gridencoder` (src/bindings.cpp:5-9) so that the
+                                 reference's own grid.py can bind to this module unchanged (dropin/_gridencoder.py)
+The arithmetic is csrc/gridenc.hip through include/dwg_gridenc.h; no CPU fallback.
+"""
+import ctypes
+
+import numpy as np
+import torch
+import torch.nn as nn
+from torch.autograd import Function
+
+from . import _lib
+
+_gridtype_to_id = {'hash': 0, 'tiled': 1}
+_interp_to_id = {'linear': 0, 'smoothstep': 1}
+
+
+def _st(t):
+    return ctypes.c_void_p(torch.cuda.current_stream(t.device).cuda_stream)
+
+
+def _need_cuda(t):
+    if not t.is_cuda:
+        raise RuntimeError("dreamwaltz_g_amd grid encoder runs on the GPU only (HIP kernels)")
+
+
+def grid_encode_forward(inputs, embeddings, offsets, outputs, B, D, C, L, S, H, dy_dx, gridtype, align_corners, interp,
+                        out_layout=0):
+    """Backend-compatible entry (outputs [L,B,C] when out_layout == 0)."""
+    _need_cuda(inputs)
+    p = _lib.ptr
+    _lib.check(_lib.lib().dwg_grid_encode_forward(p(inputs), p(embeddings), p(offsets), p(outputs), B, D, C, L,
+                                                  ctypes.c_float(S), H, p(dy_dx), gridtype, int(bool(align_corners)),
+                                                  interp, out_layout, _st(inputs)), "dwg_grid_encode_forward")
+
+
+def grid_encode_backward(grad, inputs, embeddings, offsets, grad_embeddings, B, D, C, L, S, H, dy_dx, grad_inputs,
+                         gridtype, align_corners, interp, grad_layout=0):
+    _need_cuda(inputs)
+    p = _lib.ptr
+    _lib.check(_lib.lib().dwg_grid_encode_backward(p(grad), p(inputs), p(embeddings), p(offsets), p(grad_embeddings), B, D,
+                                                   C, L, ctypes.c_float(S), H, p(dy_dx), p(grad_inputs), gridtype,
+                                                   int(bool(align_corners)), interp, grad_layout, _st(inputs)),
+               "dwg_grid_encode_backward")
+
+
+class _grid_encode(Function):
+    @staticmethod
+    def forward(ctx, inputs, embeddings, offsets, per_level_scale, base_resolution, calc_grad_inputs=False, gridtype=0,
+                align_corners=False, interpolation=0):
+        inputs = inputs.contiguous().float()
+        embeddings = embeddings.contiguous().float()
+        B, D = inputs.shape
+        L = offsets.shape[0] - 1
+        C = embeddings.shape[1]
+        S = float(np.log2(per_level_scale))
+        H = int(base_resolution)
+        outputs = torch.empty(B, L * C, device=inputs.device, dtype=torch.float32)   # written directly as [B, L*C]
+        dy_dx = torch.empty(B, L * D * C, device=inputs.device, dtype=torch.float32) if calc_grad_inputs else None
+        grid_encode_forward(inputs, embeddings, offsets, outputs, B, D, C, L, S, H, dy_dx, gridtype, align_corners,
+                            interpolation, out_layout=1)
+        ctx.save_for_backward(inputs, embeddings, offsets, dy_dx)
+        ctx.dims = [B, D, C, L, S, H, gridtype, interpolation]
+        ctx.align_corners = align_corners
+        return outputs
+
+    @staticmethod
+    def backward(ctx, grad):
+        inputs, embeddings, offsets, dy_dx = ctx.saved_tensors
+        B, D, C, L, S, H, gridtype, interpolation = ctx.dims
+        grad = grad.contiguous().float()
+        grad_embeddings = torch.zeros_like(embeddings)
+        grad_inputs = torch.empty_like(inputs) if dy_dx is not None else None
+        grid_encode_backward(grad, inputs, embeddings, offsets, grad_embeddings, B, D, C, L, S, H, dy_dx, grad_inputs,
+                             gridtype, ctx.align_corners, interpolation, grad_layout=1)
+        return grad_inputs, grad_embeddings, None, None, None, None, None, None, None
+
+
+grid_encode = _grid_encode.apply
+
+
+class GridEncoder(nn.Module):
+    """Same constructor / buffers / parameter names as the reference's GridEncoder (grid.py:99-144)."""
+
+    def __init__(self, input_dim=3, num_levels=16, level_dim=2, per_level_scale=2, base_resolution=16,
+                 log2_hashmap_size=19, desired_resolution=None, gridtype='hash', align_corners=False,
+                 interpolation='linear'):
+        super().__init__()
+        if desired_resolution is not None:
+            per_level_scale = np.exp2(np.log2(desired_resolution / base_resolution) / (num_levels - 1))
+        self.input_dim, self.num_levels, self.level_dim = input_dim, num_levels, level_dim
+        self.per_level_scale, self.log2_hashmap_size, self.base_resolution = per_level_scale, log2_hashmap_size, base_resolution
+        self.output_dim = num_levels * level_dim
+        self.gridtype, self.gridtype_id = gridtype, _gridtype_to_id[gridtype]
+        self.interpolation, self.interp_id = interpolation, _interp_to_id[interpolation]
+        self.align_corners = align_corners
+        offsets, offset = [], 0
+        self.max_params = 2 ** log2_hashmap_size
+        for i in range(num_levels):
+            resolution = int(np.ceil(base_resolution * per_level_scale ** i))
+            params_in_level = min(self.max_params, (resolution if align_corners else resolution + 1) ** input_dim)
+            params_in_level = int(np.ceil(params_in_level / 8) * 8)
+            offsets.append(offset)
+            offset += params_in_level
+        offsets.append(offset)
+        self.register_buffer('offsets', torch.from_numpy(np.array(offsets, dtype=np.int32)))
+        self.n_params = offsets[-1] * level_dim
+        self.embeddings = nn.Parameter(torch.empty(offset, level_dim))
+        self.reset_parameters()
+
+    def reset_parameters(self):
+        self.embeddings.data.uniform_(-1e-4, 1e-4)
+
+    def forward(self, inputs, bound=1):
+        inputs = (inputs + bound) / (2 * bound)
+        prefix_shape = list(inputs.shape[:-1])
+        inputs = inputs.view(-1, self.input_dim)
+        outputs = grid_encode(inputs, self.embeddings, self.offsets, self.per_level_scale, self.base_resolution,
+                              inputs.requires_grad, self.gridtype_id, self.align_corners, self.interp_id)
+        return outputs.view(prefix_shape + [self.output_dim])

@@ -1,0 +1,38 @@
+/*
+ * include/dwg_gridenc.h -- C-ABI of the multi-resolution grid encoder (boundary B2).
+ *
+ * Replaces the pybind backend `_gridencoder` of the reference:
+ *   prototypes  /root/reference/core/nerf/gridencoder/src/gridencoder.h:12-14
+ *   bindings    /root/reference/core/nerf/gridencoder/src/bindings.cpp:5-9
+ *   caller      /root/reference/core/nerf/gridencoder/grid.py:51-58 (forward), :79-86 (backward)
+ * Argument order and meaning follow grid_encode_forward / grid_encode_backward one for one; the extra trailing
+ * `*_layout` selects the feature layout: 0 = [L,B,C] exactly as the reference backend writes it, 1 = [B,L*C]
+ * (what grid.py produces after its permute+reshape, written directly with no extra copy).
+ * Specialised for D = 3, C = 2, L <= 32 (the avatar's encoder is D=3, C=2, L=16: nerf_model.py:223-231).
+ * Inputs outside [0,1] produce zero features and zero gradients (gridencoder.cu:110-135,272-278).
+ * All pointers are device pointers; buffers are caller-allocated; grad_embeddings must be pre-zeroed (accumulated).
+ */
+#ifndef DWG_GRIDENC_H
+#define DWG_GRIDENC_H
+#include "dwg_types.h"
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+int dwg_grid_encode_forward(const float* inputs /*[B,D] in [0,1]*/, const float* embeddings /*[sO,C]*/,
+                            const int32_t* offsets /*[L+1]*/, float* outputs, uint32_t B, uint32_t D, uint32_t C,
+                            uint32_t L, float S /*log2(per_level_scale)*/, uint32_t H /*base resolution*/,
+                            float* dy_dx /*[B,L*D*C] or NULL*/, uint32_t gridtype /*0 hash, 1 tiled*/,
+                            uint32_t align_corners, uint32_t interp /*0 linear, 1 smoothstep*/, uint32_t out_layout,
+                            dwg_stream_t stream);
+
+int dwg_grid_encode_backward(const float* grad, const float* inputs, const float* embeddings, const int32_t* offsets,
+                             float* grad_embeddings /*[sO,C] accumulated, may be NULL*/, uint32_t B, uint32_t D, uint32_t C,
+                             uint32_t L, float S, uint32_t H, const float* dy_dx /*or NULL*/,
+                             float* grad_inputs /*[B,D] or NULL (iff dy_dx NULL)*/, uint32_t gridtype,
+                             uint32_t align_corners, uint32_t interp, uint32_t grad_layout, dwg_stream_t stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

@@ -1,0 +1,53 @@
+/*
+ * include/dwg_lbs.h -- C-ABI of the SMPL-X linear-blend-skinning stage (boundary B3).
+ *
+ * The reference keeps this stage in Python objects:
+ *   GeneralLinearBlendSkinning.forward / get_full_transform   /root/reference/core/human/inverse_lbs.py:652-784
+ *   RigidTransform.transform_points / transform_quaternions   /root/reference/core/human/inverse_lbs.py:190-251
+ *   DreamWaltzG.lbs_transform                                 /root/reference/core/system/avatar.py:1426-1462
+ * The Python mirror (dreamwaltz-g_amd/lbs.py) keeps those call signatures and routes the arithmetic here.
+ * All pointers are device pointers to dense fp32 row-major tensors (int32 for indices).
+ */
+#ifndef DWG_LBS_H
+#define DWG_LBS_H
+#include "dwg_types.h"
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* Rodrigues + kinematic chain + rest-pose removal (+ global translation):
+ *   A_out[j] = compose(J_pose_rigid, G_transl_offset)[j]  -- the `joint_pose_transform` of avatar.py:1441-1444.
+ * pose [J,3] axis-angle (the 165-vector of inverse_lbs.py:611-624 after `+= pose_mean`), joints [J,3] (rest joints of
+ * the shaped template, inverse_lbs.py:681), parents [J] with parents[0] = -1, transl [3] or NULL.
+ * rot_mats_out [J,9] (optional) are the per-joint rotation matrices needed for the pose blend-shape feature. J <= 64. */
+int dwg_lbs_joint_chain(int32_t J, const float* pose, const float* joints, const int32_t* parents, const float* transl,
+                        float* A_out /*[J,16]*/, float* rot_mats_out /*[J,9] or NULL*/, dwg_stream_t stream);
+
+/* Per-Gaussian blend + transforms:  T_i = sum_j w_ij A_j ;  p' = R_i p + t_i ;
+ * q' = matrix_to_quaternion(F R_i F quaternion_to_matrix(q)), F = diag(1,-1,-1)  (flip_rotation_axis=True).
+ * weights [N,J]; when normalize_weights != 0 each row is divided by its sum first (LBSUtils.lbs_weight_activation,
+ * avatar.py:913-918).  quats / quats_out may be NULL (points only, the canonical pass avatar.py:1517-1522).
+ * T12_save [N,12] (optional) keeps the blended [R|t] rows for the backward. */
+int dwg_lbs_blend_forward(int32_t N, int32_t J, int32_t normalize_weights, const float* A /*[J,16]*/,
+                          const float* weights, const float* points, const float* quats, float* points_out,
+                          float* quats_out, float* T12_save, dwg_stream_t stream);
+
+/* Gradients w.r.t. points and quats (skinning weights and the skeleton are frozen by default: configs/__init__.py:197). */
+int dwg_lbs_blend_backward(int32_t N, const float* T12 /*[N,12] from forward*/, const float* points, const float* quats,
+                           const float* g_points_out, const float* g_quats_out, float* g_points, float* g_quats,
+                           dwg_stream_t stream);
+
+/* transform_V applied to a vertex subset (mesh-bound Gaussians, avatar.py:1570-1576):
+ *   out_t = T_rigid(v_t) * (x_t + shapedirs[v_t] . shape + posedirs[:, v_t] . (rot_mats[1:] - I)),  v_t = vertex_indices[t]
+ * with T_rigid(v) = sum_j lbs_weights[v,j] A_j (A already carries the translation).  shapedirs [V,3,n_shape] and/or
+ * posedirs [n_posefeat, 3V] may be NULL to skip that offset. */
+int dwg_lbs_vertex_transform(int32_t Vp, int32_t V, int32_t J, int32_t n_shape, int32_t n_posefeat,
+                             const int32_t* vertex_indices, const float* vertex_coords /*[Vp,3]*/, const float* A,
+                             const float* lbs_weights /*[V,J]*/, const float* shapedirs, const float* shape_coeffs,
+                             const float* posedirs, const float* rot_mats /*[J,9]*/, float* out /*[Vp,3]*/,
+                             dwg_stream_t stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

@@ -22,19 +22,11 @@
 #ifndef DWG_RASTER_H
 #define DWG_RASTER_H
 
-#include <stddef.h>
-#include <stdint.h>
+#include "dwg_types.h"
 
 #ifdef __cplusplus
 extern "C" {
 #endif
-
-#define DWG_OK 0
-#define DWG_E_ARG (-1)
-#define DWG_E_LAUNCH (-2)
-#define DWG_E_CAPACITY (-3)
-
-typedef void* dwg_stream_t; /* hipStream_t */
 
 /* Mirrors GaussianRasterizationSettings (kwargs at gaussian_renderer.py:43-64). */
 typedef struct dwg_raster_settings {

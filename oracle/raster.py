@@ -83,3 +83,12 @@ def backward(means3D, opacities, viewmatrix, projmatrix, tanfovx, tanfovy, bg, H
         _p(out["colors"]), _p(out["shs"]), _p(out["opacities"]), _p(out["scales"]), _p(out["rotations"]),
         _p(out["cov3D"]))
     return out
+
+
+def sh_colors(shs, positions, campos, deg, dtype=np.float32):
+    L = _lib(dtype)
+    shs, positions, campos = _prep(dtype, shs, positions, campos)
+    N, M = shs.shape[0], shs.shape[1]
+    out = np.zeros((N, 3), dtype)
+    L.dwg_oracle_sh_colors(ctypes.c_int(N), ctypes.c_int(deg), ctypes.c_int(M), _p(shs), _p(positions), _p(campos), _p(out))
+    return out

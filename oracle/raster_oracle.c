@@ -548,3 +548,13 @@ int dwg_oracle_raster_backward(int G, int H, int W, const REAL* means3D, const R
     free_state(&st);
     return 0;
 }
+
+/* SH colour of N points (get_colors: core/gaussian/gaussian_utils.py:12-17); used to pin eval_sh_color against the
+ * golden vectors captured from the reference's own eval_sh. */
+int dwg_oracle_sh_colors(int N, int deg, int ncoef, const REAL* shs, const REAL* pos, const REAL* campos, REAL* rgb) {
+    for (int i = 0; i < N; i++) {
+        int cl[3];
+        eval_sh_color(deg, ncoef, shs + (size_t)i * ncoef * 3, pos + 3 * i, campos, rgb + 3 * i, cl);
+    }
+    return 0;
+}
