@@ -47,6 +47,12 @@ SIGNATURES = {
                                                _u32, _vp]),
     "dwg_grid_encode_backward": (ctypes.c_int, [_vp, _vp, _vp, _vp, _vp, _u32, _u32, _u32, _u32, _f32, _u32, _vp, _vp, _u32,
                                                 _u32, _u32, _u32, _vp]),
+    # include/dwg_gemm.h
+    "dwg_gemm": (ctypes.c_int, [_vp, _vp]),
+    # include/dwg_prof.h
+    "dwg_prof_enable": (ctypes.c_int, [_i32]),
+    "dwg_prof_query": (ctypes.c_int, [ctypes.c_char_p, ctypes.POINTER(_i64), ctypes.POINTER(ctypes.c_double)]),
+    "dwg_prof_dump": (_i64, [ctypes.c_char_p, _i64]),
 }
 
 
@@ -74,3 +80,20 @@ def check(rc, what):
 def ptr(t):
     """Device (or host) address of a torch tensor, None -> NULL."""
     return None if t is None else ctypes.c_void_p(t.data_ptr())
+
+
+def prof_enable(on=True):
+    check(lib().dwg_prof_enable(int(bool(on))), "dwg_prof_enable")
+
+
+def prof_table():
+    """{kernel name: (launches, total_ms)} recorded since prof_enable(True)."""
+    L = lib()
+    need = L.dwg_prof_dump(None, 0)
+    buf = ctypes.create_string_buffer(int(need) + 16)
+    L.dwg_prof_dump(buf, len(buf))
+    out = {}
+    for line in buf.value.decode().splitlines():
+        n, c, ms = line.split()
+        out[n] = (int(c), float(ms))
+    return out

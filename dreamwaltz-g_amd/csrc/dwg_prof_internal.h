@@ -1,0 +1,15 @@
+// dwg_prof_internal.h -- launch wrapper used by every kernel file: times the launch when profiling is enabled.
+#pragma once
+#include <hip/hip_runtime.h>
+
+bool dwg_prof_on();
+void dwg_prof_begin(const char* name, hipStream_t stream, void** token);
+void dwg_prof_end(const char* name, hipStream_t stream, void* token);
+
+#define DWG_LAUNCH(NAME, KERNEL, GRID, BLOCK, LDS, STREAM, ...)                       \
+    do {                                                                              \
+        void* tok__ = nullptr;                                                        \
+        if (dwg_prof_on()) dwg_prof_begin(NAME, (STREAM), &tok__);                    \
+        hipLaunchKernelGGL(KERNEL, GRID, BLOCK, LDS, (STREAM), __VA_ARGS__);          \
+        if (tok__) dwg_prof_end(NAME, (STREAM), tok__);                               \
+    } while (0)

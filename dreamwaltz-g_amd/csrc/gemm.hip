@@ -1,0 +1,366 @@
+// gemm.hip -- MFMA GEMM / implicit-GEMM convolution for gfx950 (wave64, v_mfma_f32_32x32x16_bf16 and the exact-f32
+// v_mfma_f32_32x32x2_f32), fp32 accumulation, fused epilogue (scale, bias, activation, residual, dtype cast).
+//
+// One kernel template serves every contraction on the hot path:
+//   * the per-Gaussian MLPs (f32-exact): nerf_model.py:12-33, deform_model.py:102-143 -- fwd, dgrad, wgrad (split-K atomics)
+//   * UNet / ControlNet / VAE linear layers, attention QK^T and PV (batched, strided per head)        (bf16 in, f32 acc)
+//   * conv3x3 / conv1x1 forward and input-gradient as implicit GEMM over NHWC activations             (bf16 in, f32 acc)
+//
+// C[m][n] = epi( alpha * sum_k A(m,k) * B(n,k) ).  Operand element addresses are fully strided:
+//   A(m,k) = A + m*sam + k*sak,  B(n,k) = B + n*sbn + k*sbk   (so NT / TN / NN / TT all map onto one kernel)
+// or, for the conv loader, A(m,k) is the im2col view of an NHWC tensor: m=(img,oy,ox), k=(ky,kx,ci), with stride,
+// asymmetric padding and input dilation (the latter turns the same loader into the transposed-conv / dgrad gather).
+// Tiling: 128 x {128,64} x BK workgroup tile, 4 waves, 32x32 MFMA tiles, operands staged global->VGPR->LDS with the
+// next tile's global loads issued before the current tile's MFMAs (one barrier per k-step, two LDS buffers).
+#include "dwg_common.h"
+#include "dwg_prof_internal.h"
+#include "../../include/dwg_gemm.h"
+
+namespace {
+
+typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
+typedef __attribute__((ext_vector_type(16))) float f32x16;
+
+struct ConvP {
+    int enabled, Cin, Hin, Win, Hout, Wout, KH, KW, stride, pad_t, pad_l, dil;  // dil = input dilation (dgrad of strided conv)
+};
+
+struct GemmP {
+    const void* A; const void* B; void* C; const void* bias; const void* residual;
+    int M, N, K;
+    long long sam, sak, sbn, sbk, ldc, ldr;
+    int nb2;
+    long long bA1, bA2, bB1, bB2, bC1, bC2, bR1, bR2;
+    int act; float alpha;
+    int out_bf16, res_bf16, bias_per_row, splitk, accumulate;
+    ConvP conv;
+};
+
+__device__ __forceinline__ float bf2f(__bf16 x) { return (float)x; }
+__device__ __forceinline__ __bf16 f2bf(float x) { return (__bf16)x; }
+
+__device__ __forceinline__ float apply_act(float v, int act) {
+    switch (act) {
+        case 1: return v > 0.f ? v : 0.f;
+        case 2: return v > 0.f ? v : 0.01f * v;
+        case 3: return v / (1.f + __expf(-v));
+        case 4: return 0.5f * v * (1.f + erff(v * 0.70710678118654752f));
+        case 5: return 1.f / (1.f + __expf(-v));
+        default: return v;
+    }
+}
+
+template <typename T> struct TT;
+template <> struct TT<__bf16> { static constexpr int VEC = 8; static constexpr int BK = 32; static constexpr int PAD = 8; };
+template <> struct TT<float> { static constexpr int VEC = 4; static constexpr int BK = 16; static constexpr int PAD = 4; };
+
+// operand load modes
+enum { MODE_KVEC = 0, MODE_RVEC = 1, MODE_SCALAR = 2, MODE_CONV = 3 };
+
+template <typename T, int VEC> struct Chunk { T v[VEC]; };
+
+template <typename T, int VEC>
+__device__ __forceinline__ Chunk<T, VEC> load_vec(const T* p) {
+    Chunk<T, VEC> c;
+    *reinterpret_cast<uint4*>(&c) = *reinterpret_cast<const uint4*>(p);
+    return c;
+}
+template <typename T, int VEC>
+__device__ __forceinline__ Chunk<T, VEC> zero_chunk() {
+    Chunk<T, VEC> c;
+    *reinterpret_cast<uint4*>(&c) = make_uint4(0u, 0u, 0u, 0u);
+    return c;
+}
+
+// Loads this thread's share of a [ROWS][BK] operand tile into registers.
+//   rows r0..r0+ROWS of the operand (row = m for A / n for B), contraction range k0..k0+BK.
+template <typename T, int ROWS, int MODE>
+struct TileLoader {
+    static constexpr int VEC = TT<T>::VEC, BK = TT<T>::BK;
+    static constexpr int NCH = (MODE == MODE_SCALAR) ? (ROWS * BK / 256) : (ROWS * BK / VEC / 256);
+    Chunk<T, VEC> regs[(MODE == MODE_SCALAR) ? 1 : NCH];
+    T sregs[(MODE == MODE_SCALAR) ? NCH : 1];
+
+    __device__ __forceinline__ void load(const T* base, long long srow, long long sk, int nrows, int K, int r0, int k0,
+                                         int kend, const ConvP& cv) {
+        const int tid = threadIdx.x;
+        if (MODE == MODE_KVEC) {
+            constexpr int CPR = BK / VEC;
+#pragma unroll
+            for (int i = 0; i < NCH; i++) {
+                int c = tid + i * 256, row = c / CPR, kc = c - row * CPR;
+                int r = r0 + row, k = k0 + kc * VEC;
+                regs[i] = (r < nrows && k < kend) ? load_vec<T, VEC>(base + (long long)r * srow + k) : zero_chunk<T, VEC>();
+            }
+        } else if (MODE == MODE_RVEC) {
+            constexpr int CPK = ROWS / VEC;
+#pragma unroll
+            for (int i = 0; i < NCH; i++) {
+                int c = tid + i * 256, kk = c / CPK, rc = c - kk * CPK;
+                int r = r0 + rc * VEC, k = k0 + kk;
+                regs[i] = (r < nrows && k < kend) ? load_vec<T, VEC>(base + (long long)k * sk + r) : zero_chunk<T, VEC>();
+            }
+        } else if (MODE == MODE_SCALAR) {
+#pragma unroll
+            for (int i = 0; i < NCH; i++) {
+                int c = tid + i * 256, row = c / BK, kk = c - row * BK;
+                int r = r0 + row, k = k0 + kk;
+                sregs[i] = (r < nrows && k < kend) ? base[(long long)r * srow + (long long)k * sk] : (T)0.f;
+            }
+        } else {  // MODE_CONV: row = (img, oy, ox), k = (ky, kx, ci), NHWC input, Cin % VEC == 0
+            constexpr int CPR = BK / VEC;
+#pragma unroll
+            for (int i = 0; i < NCH; i++) {
+                int c = tid + i * 256, row = c / CPR, kc = c - row * CPR;
+                int r = r0 + row, k = k0 + kc * VEC;
+                bool ok = r < nrows && k < kend;
+                const T* src = base;
+                if (ok) {
+                    int hw = cv.Hout * cv.Wout;
+                    int img = r / hw, rem = r - img * hw;
+                    int oy = rem / cv.Wout, ox = rem - oy * cv.Wout;
+                    int tap = k / cv.Cin, ci = k - tap * cv.Cin;
+                    int ky = tap / cv.KW, kx = tap - ky * cv.KW;
+                    int iy = oy * cv.stride - cv.pad_t + ky, ix = ox * cv.stride - cv.pad_l + kx;
+                    if (cv.dil > 1) {
+                        ok = iy >= 0 && ix >= 0 && (iy % cv.dil == 0) && (ix % cv.dil == 0);
+                        iy /= cv.dil; ix /= cv.dil;
+                    }
+                    ok = ok && iy >= 0 && iy < cv.Hin && ix >= 0 && ix < cv.Win;
+                    src = base + (((long long)img * cv.Hin + iy) * cv.Win + ix) * cv.Cin + ci;
+                }
+                regs[i] = ok ? load_vec<T, VEC>(src) : zero_chunk<T, VEC>();
+            }
+        }
+        (void)K;
+    }
+
+    // LDS tile layout: [ROWS][BK + PAD]
+    __device__ __forceinline__ void store(T* lds) {
+        constexpr int LDT = BK + TT<T>::PAD;
+        const int tid = threadIdx.x;
+        if (MODE == MODE_KVEC || MODE == MODE_CONV) {
+            constexpr int CPR = BK / VEC;
+#pragma unroll
+            for (int i = 0; i < NCH; i++) {
+                int c = tid + i * 256, row = c / CPR, kc = c - row * CPR;
+                *reinterpret_cast<uint4*>(lds + row * LDT + kc * VEC) = *reinterpret_cast<uint4*>(&regs[i]);
+            }
+        } else if (MODE == MODE_RVEC) {
+            constexpr int CPK = ROWS / VEC;
+#pragma unroll
+            for (int i = 0; i < NCH; i++) {
+                int c = tid + i * 256, kk = c / CPK, rc = c - kk * CPK;
+#pragma unroll
+                for (int e = 0; e < VEC; e++) lds[(rc * VEC + e) * LDT + kk] = regs[i].v[e];
+            }
+        } else {
+#pragma unroll
+            for (int i = 0; i < NCH; i++) {
+                int c = tid + i * 256, row = c / BK, kk = c - row * BK;
+                lds[row * LDT + kk] = sregs[i];
+            }
+        }
+    }
+};
+
+template <typename T>
+__device__ __forceinline__ void mma_tile(const T* sa, const T* sb, int lane, f32x16& acc);
+
+// one 32x32 output tile x one BK slab
+template <>
+__device__ __forceinline__ void mma_tile<__bf16>(const __bf16* sa, const __bf16* sb, int lane, f32x16& acc) {
+    constexpr int LDT = TT<__bf16>::BK + TT<__bf16>::PAD;
+    const __bf16* pa = sa + (lane & 31) * LDT + (lane >> 5) * 8;
+    const __bf16* pb = sb + (lane & 31) * LDT + (lane >> 5) * 8;
+#pragma unroll
+    for (int ks = 0; ks < TT<__bf16>::BK / 16; ks++) {
+        bf16x8 a = *reinterpret_cast<const bf16x8*>(pa + ks * 16);
+        bf16x8 b = *reinterpret_cast<const bf16x8*>(pb + ks * 16);
+        acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, acc, 0, 0, 0);
+    }
+}
+template <>
+__device__ __forceinline__ void mma_tile<float>(const float* sa, const float* sb, int lane, f32x16& acc) {
+    constexpr int LDT = TT<float>::BK + TT<float>::PAD;
+    const float* pa = sa + (lane & 31) * LDT + (lane >> 5);
+    const float* pb = sb + (lane & 31) * LDT + (lane >> 5);
+#pragma unroll
+    for (int ks = 0; ks < TT<float>::BK / 2; ks++)
+        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(pa[ks * 2], pb[ks * 2], acc, 0, 0, 0);
+}
+
+template <typename T, int BN, int AMODE, int BMODE>
+__global__ __launch_bounds__(256) void k_gemm(GemmP p) {
+    constexpr int BM = 128, BK = TT<T>::BK, LDT = BK + TT<T>::PAD;
+    constexpr int WN = BN / 64;            // waves along N (2 for BN=128, 1 for BN=64)
+    constexpr int WM = 4 / WN;             // waves along M
+    constexpr int TM = BM / WM / 32;       // 32x32 tiles per wave along M (2 | 1)
+    constexpr int TN = 2;                  // each wave spans 64 columns
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+    T* sA = reinterpret_cast<T*>(smem_raw);            // [2][BM][LDT]
+    T* sB = sA + 2 * BM * LDT;                         // [2][BN][LDT]
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wm = wave / WN, wn = wave % WN;
+    const int m0 = blockIdx.x * BM;
+    const int ntn = (p.N + BN - 1) / BN;
+    const int n0 = (blockIdx.y % ntn) * BN;
+    const int ks_id = blockIdx.y / ntn;                // split-K slice
+    const int z = blockIdx.z, z1 = z / p.nb2, z2 = z - z1 * p.nb2;
+    const T* A = reinterpret_cast<const T*>(p.A) + z1 * p.bA1 + z2 * p.bA2;
+    const T* B = reinterpret_cast<const T*>(p.B) + z1 * p.bB1 + z2 * p.bB2;
+    // contraction range of this slice (multiple of BK so that vector loads stay aligned)
+    int kbeg = 0, kend = p.K;
+    if (p.splitk > 1) {
+        int per = ((p.K + p.splitk - 1) / p.splitk + BK - 1) / BK * BK;
+        kbeg = ks_id * per; kend = min(p.K, kbeg + per);
+    }
+    f32x16 acc[TM][TN];
+#pragma unroll
+    for (int i = 0; i < TM; i++)
+#pragma unroll
+        for (int j = 0; j < TN; j++)
+#pragma unroll
+            for (int r = 0; r < 16; r++) acc[i][j][r] = 0.f;
+
+    TileLoader<T, BM, AMODE> la;
+    TileLoader<T, BN, BMODE> lb;
+    const int nk = kend > kbeg ? (kend - kbeg + BK - 1) / BK : 0;
+    if (nk > 0) {
+        la.load(A, p.sam, p.sak, p.M, p.K, m0, kbeg, kend, p.conv);
+        lb.load(B, p.sbn, p.sbk, p.N, p.K, n0, kbeg, kend, p.conv);
+        la.store(sA); lb.store(sB);
+    }
+    __syncthreads();
+    for (int kt = 0; kt < nk; kt++) {
+        const int cur = kt & 1;
+        if (kt + 1 < nk) {
+            la.load(A, p.sam, p.sak, p.M, p.K, m0, kbeg + (kt + 1) * BK, kend, p.conv);
+            lb.load(B, p.sbn, p.sbk, p.N, p.K, n0, kbeg + (kt + 1) * BK, kend, p.conv);
+        }
+        const T* a = sA + cur * BM * LDT + (wm * TM * 32) * LDT;
+        const T* b = sB + cur * BN * LDT + (wn * 64) * LDT;
+#pragma unroll
+        for (int i = 0; i < TM; i++)
+#pragma unroll
+            for (int j = 0; j < TN; j++) mma_tile<T>(a + i * 32 * LDT, b + j * 32 * LDT, lane, acc[i][j]);
+        if (kt + 1 < nk) { la.store(sA + (cur ^ 1) * BM * LDT); lb.store(sB + (cur ^ 1) * BN * LDT); }
+        __syncthreads();
+    }
+    // epilogue
+    const long long coff = z1 * p.bC1 + z2 * p.bC2, roff = z1 * p.bR1 + z2 * p.bR2;
+#pragma unroll
+    for (int i = 0; i < TM; i++)
+#pragma unroll
+        for (int j = 0; j < TN; j++) {
+            const int col = n0 + wn * 64 + j * 32 + (lane & 31);
+            if (col >= p.N) continue;
+#pragma unroll
+            for (int r = 0; r < 16; r++) {
+                const int row = m0 + (wm * TM + i) * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+                if (row >= p.M) continue;
+                float v = acc[i][j][r] * p.alpha;
+                const long long ci = coff + (long long)row * p.ldc + col;
+                if (p.splitk > 1) { atomicAdd(reinterpret_cast<float*>(p.C) + ci, v); continue; }
+                if (p.bias) v += reinterpret_cast<const float*>(p.bias)[p.bias_per_row ? row : col];
+                v = apply_act(v, p.act);
+                if (p.residual) {
+                    const long long ri = roff + (long long)row * p.ldr + col;
+                    v += p.res_bf16 ? bf2f(reinterpret_cast<const __bf16*>(p.residual)[ri])
+                                    : reinterpret_cast<const float*>(p.residual)[ri];
+                }
+                if (p.out_bf16) reinterpret_cast<__bf16*>(p.C)[ci] = f2bf(v);
+                else if (p.accumulate) reinterpret_cast<float*>(p.C)[ci] += v;
+                else reinterpret_cast<float*>(p.C)[ci] = v;
+            }
+        }
+}
+
+template <typename T, int BN, int AMODE, int BMODE>
+static void launch(const GemmP& p, int batch, hipStream_t stream, const char* name) {
+    constexpr int LDT = TT<T>::BK + TT<T>::PAD;
+    size_t lds = (size_t)2 * (128 + BN) * LDT * sizeof(T);
+    dim3 grid((p.M + 127) / 128, ((p.N + BN - 1) / BN) * (p.splitk > 1 ? p.splitk : 1), batch);
+    DWG_LAUNCH(name, (k_gemm<T, BN, AMODE, BMODE>), grid, dim3(256), lds, stream, p);
+}
+
+template <typename T, int BN, int AMODE>
+static void dispatch_b(const GemmP& p, int bmode, int batch, hipStream_t s, const char* name) {
+    if (bmode == MODE_KVEC) launch<T, BN, AMODE, MODE_KVEC>(p, batch, s, name);
+    else if (bmode == MODE_RVEC) launch<T, BN, AMODE, MODE_RVEC>(p, batch, s, name);
+    else launch<T, BN, AMODE, MODE_SCALAR>(p, batch, s, name);
+}
+template <typename T, int BN>
+static void dispatch_a(const GemmP& p, int amode, int bmode, int batch, hipStream_t s, const char* name) {
+    if (amode == MODE_KVEC) dispatch_b<T, BN, MODE_KVEC>(p, bmode, batch, s, name);
+    else if (amode == MODE_RVEC) dispatch_b<T, BN, MODE_RVEC>(p, bmode, batch, s, name);
+    else if (amode == MODE_CONV) dispatch_b<T, BN, MODE_CONV>(p, bmode, batch, s, name);
+    else dispatch_b<T, BN, MODE_SCALAR>(p, bmode, batch, s, name);
+}
+
+template <typename T>
+static int pick_mode(const void* base, long long srow, long long sk, int nrows, int K, const long long* boffs, int nboffs) {
+    constexpr int VEC = TT<T>::VEC;
+    bool aligned = ((uintptr_t)base % 16) == 0;
+    for (int i = 0; i < nboffs; i++) aligned = aligned && (boffs[i] % VEC == 0);
+    if (sk == 1 && aligned && K % VEC == 0 && srow % VEC == 0) return MODE_KVEC;
+    if (srow == 1 && aligned && nrows % VEC == 0 && sk % VEC == 0) return MODE_RVEC;
+    return MODE_SCALAR;
+}
+
+}  // namespace
+
+extern "C" {
+
+int dwg_gemm(const dwg_gemm_desc* d, dwg_stream_t stream_) {
+    if (!d || !d->A || !d->B || !d->C) return DWG_E_ARG;
+    if (d->M < 0 || d->N < 0 || d->K < 0 || d->batch1 < 1 || d->batch2 < 1) return DWG_E_ARG;
+    if (d->M == 0 || d->N == 0) return DWG_OK;
+    if (d->dtype != DWG_DTYPE_F32 && d->dtype != DWG_DTYPE_BF16) return DWG_E_ARG;
+    if (d->splitk > 1 && (d->out_dtype != DWG_DTYPE_F32 || d->bias || d->residual || d->act)) return DWG_E_ARG;
+    if (d->accumulate && d->out_dtype != DWG_DTYPE_F32) return DWG_E_ARG;
+    GemmP p;
+    p.A = d->A; p.B = d->B; p.C = d->C; p.bias = d->bias; p.residual = d->residual;
+    p.M = d->M; p.N = d->N; p.K = d->K;
+    p.sam = d->a_row_stride; p.sak = d->a_k_stride; p.sbn = d->b_row_stride; p.sbk = d->b_k_stride;
+    p.ldc = d->ldc; p.ldr = d->ldr ? d->ldr : d->ldc;
+    p.nb2 = d->batch2;
+    p.bA1 = d->a_batch1_stride; p.bA2 = d->a_batch2_stride; p.bB1 = d->b_batch1_stride; p.bB2 = d->b_batch2_stride;
+    p.bC1 = d->c_batch1_stride; p.bC2 = d->c_batch2_stride; p.bR1 = d->r_batch1_stride; p.bR2 = d->r_batch2_stride;
+    p.act = d->act; p.alpha = d->alpha;
+    p.out_bf16 = d->out_dtype == DWG_DTYPE_BF16; p.res_bf16 = d->residual_dtype == DWG_DTYPE_BF16;
+    p.bias_per_row = d->bias_per_row; p.splitk = d->splitk > 1 ? d->splitk : 1; p.accumulate = d->accumulate;
+    p.conv.enabled = d->conv_enabled;
+    p.conv.Cin = d->conv_cin; p.conv.Hin = d->conv_hin; p.conv.Win = d->conv_win; p.conv.Hout = d->conv_hout;
+    p.conv.Wout = d->conv_wout; p.conv.KH = d->conv_kh; p.conv.KW = d->conv_kw; p.conv.stride = d->conv_stride;
+    p.conv.pad_t = d->conv_pad_t; p.conv.pad_l = d->conv_pad_l; p.conv.dil = d->conv_in_dilation > 1 ? d->conv_in_dilation : 1;
+    const int batch = d->batch1 * d->batch2;
+    hipStream_t stream = (hipStream_t)stream_;
+    const char* name = d->name ? d->name : (d->conv_enabled ? "conv_igemm" : "gemm");
+    const bool narrow = d->N <= 64;
+    if (d->dtype == DWG_DTYPE_BF16) {
+        typedef __bf16 T;
+        int amode, bmode;
+        long long ao[2] = {p.bA1, p.bA2}, bo[2] = {p.bB1, p.bB2};
+        if (d->conv_enabled) {
+            if (d->conv_cin % 8 != 0 || ((uintptr_t)d->A % 16) != 0) return DWG_E_ARG;
+            if (d->K != d->conv_kh * d->conv_kw * d->conv_cin) return DWG_E_ARG;
+            amode = MODE_CONV;
+        } else amode = pick_mode<T>(p.A, p.sam, p.sak, p.M, p.K, ao, 2);
+        bmode = pick_mode<T>(p.B, p.sbn, p.sbk, p.N, p.K, bo, 2);
+        if (narrow) dispatch_a<T, 64>(p, amode, bmode, batch, stream, name);
+        else dispatch_a<T, 128>(p, amode, bmode, batch, stream, name);
+    } else {
+        typedef float T;
+        if (d->conv_enabled) return DWG_E_ARG;  // convolutions run in bf16
+        long long ao[2] = {p.bA1, p.bA2}, bo[2] = {p.bB1, p.bB2};
+        int amode = pick_mode<T>(p.A, p.sam, p.sak, p.M, p.K, ao, 2);
+        int bmode = pick_mode<T>(p.B, p.sbn, p.sbk, p.N, p.K, bo, 2);
+        if (narrow) dispatch_a<T, 64>(p, amode, bmode, batch, stream, name);
+        else dispatch_a<T, 128>(p, amode, bmode, batch, stream, name);
+    }
+    DWG_RETURN_IF_LAUNCH_FAILED();
+    return DWG_OK;
+}
+
+}  // extern "C"

@@ -10,6 +10,7 @@
 // 8-byte loads in flight (the 50 MB table lives in the 256 MB Infinity Cache / per-XCD L2).
 // Gather-bound: 16 levels x 8 corners x 8 B = 1 KiB gathered per point and direction.
 #include "dwg_common.h"
+#include "dwg_prof_internal.h"
 #include "../../include/dwg_gridenc.h"
 
 namespace {
@@ -180,7 +181,7 @@ int dwg_grid_encode_forward(const float* inputs, const float* embeddings, const 
     if (!inputs || !embeddings || !offsets || !outputs) return DWG_E_ARG;
     GridP p{B, L, S, H, gridtype, align_corners, interp, out_layout};
     uint32_t n = B * L;
-    hipLaunchKernelGGL(k_grid_fwd, dim3((n + 255) / 256), dim3(256), 0, (hipStream_t)stream, p, inputs,
+    DWG_LAUNCH("grid_fwd", k_grid_fwd, dim3((n + 255) / 256), dim3(256), 0, (hipStream_t)stream, p, inputs,
                        (const float2*)embeddings, offsets, outputs, dy_dx);
     DWG_RETURN_IF_LAUNCH_FAILED();
     return DWG_OK;
@@ -201,7 +202,7 @@ int dwg_grid_encode_backward(const float* grad, const float* inputs, const float
     if (grad_inputs && L != 16) {
         if (hipMemsetAsync(grad_inputs, 0, (size_t)B * 3 * sizeof(float), (hipStream_t)stream) != hipSuccess) return DWG_E_LAUNCH;
     }
-    hipLaunchKernelGGL(k_grid_bwd, dim3((n + 255) / 256), dim3(256), 0, (hipStream_t)stream, p, grad, inputs, offsets,
+    DWG_LAUNCH("grid_bwd", k_grid_bwd, dim3((n + 255) / 256), dim3(256), 0, (hipStream_t)stream, p, grad, inputs, offsets,
                        grad_embeddings, dy_dx, grad_inputs);
     DWG_RETURN_IF_LAUNCH_FAILED();
     return DWG_OK;

@@ -12,6 +12,7 @@
 //   k_vertex_transform per-vertex transform_V = compose(shape offset, pose offset, rigid blend, transl) applied to
 //                      the mesh-bound vertex subset (inverse_lbs.py:652-717,758-772; avatar.py:1570-1576)
 #include "dwg_common.h"
+#include "dwg_prof_internal.h"
 #include "lbs_math.h"
 #include "../../include/dwg_lbs.h"
 
@@ -201,7 +202,7 @@ extern "C" {
 int dwg_lbs_joint_chain(int32_t J, const float* pose, const float* joints, const int32_t* parents, const float* transl,
                         float* A_out, float* rot_mats_out, dwg_stream_t stream) {
     if (J <= 0 || J > MAXJ || !pose || !joints || !parents || !A_out) return DWG_E_ARG;
-    hipLaunchKernelGGL(k_joint_chain, dim3(1), dim3(64), 0, (hipStream_t)stream, J, pose, joints, parents, transl, A_out,
+    DWG_LAUNCH("lbs_joint_chain", k_joint_chain, dim3(1), dim3(64), 0, (hipStream_t)stream, J, pose, joints, parents, transl, A_out,
                        rot_mats_out);
     DWG_RETURN_IF_LAUNCH_FAILED();
     return DWG_OK;
@@ -216,10 +217,10 @@ int dwg_lbs_blend_forward(int32_t N, int32_t J, int32_t normalize_weights, const
     size_t lds = (size_t)(MAXJ * 12 + 256 * J) * sizeof(float);
     dim3 grid(dwg_cdiv(N, 256)), block(256);
     if (quats)
-        hipLaunchKernelGGL((k_blend_fwd<true>), grid, block, lds, (hipStream_t)stream, N, J, normalize_weights, A, weights,
+        DWG_LAUNCH("lbs_blend_fwd", (k_blend_fwd<true>), grid, block, lds, (hipStream_t)stream, N, J, normalize_weights, A, weights,
                            points, quats, points_out, quats_out, T12_save);
     else
-        hipLaunchKernelGGL((k_blend_fwd<false>), grid, block, lds, (hipStream_t)stream, N, J, normalize_weights, A, weights,
+        DWG_LAUNCH("lbs_blend_fwd", (k_blend_fwd<false>), grid, block, lds, (hipStream_t)stream, N, J, normalize_weights, A, weights,
                            points, quats, points_out, quats_out, T12_save);
     DWG_RETURN_IF_LAUNCH_FAILED();
     return DWG_OK;
@@ -232,10 +233,10 @@ int dwg_lbs_blend_backward(int32_t N, const float* T12, const float* points, con
     if (!T12 || !points || !g_points_out || !g_points || (quats && (!g_quats_out || !g_quats))) return DWG_E_ARG;
     dim3 grid(dwg_cdiv(N, 256)), block(256);
     if (quats)
-        hipLaunchKernelGGL((k_blend_bwd<true>), grid, block, 0, (hipStream_t)stream, N, T12, points, quats, g_points_out,
+        DWG_LAUNCH("lbs_blend_bwd", (k_blend_bwd<true>), grid, block, 0, (hipStream_t)stream, N, T12, points, quats, g_points_out,
                            g_quats_out, g_points, g_quats);
     else
-        hipLaunchKernelGGL((k_blend_bwd<false>), grid, block, 0, (hipStream_t)stream, N, T12, points, quats, g_points_out,
+        DWG_LAUNCH("lbs_blend_bwd", (k_blend_bwd<false>), grid, block, 0, (hipStream_t)stream, N, T12, points, quats, g_points_out,
                            g_quats_out, g_points, g_quats);
     DWG_RETURN_IF_LAUNCH_FAILED();
     return DWG_OK;
@@ -250,7 +251,7 @@ int dwg_lbs_vertex_transform(int32_t Vp, int32_t V, int32_t J, int32_t n_shape, 
     if (!vertex_indices || !vertex_coords || !A || !lbs_weights || !out) return DWG_E_ARG;
     if (shapedirs && !shape_coeffs) return DWG_E_ARG;
     if (posedirs && !rot_mats) return DWG_E_ARG;
-    hipLaunchKernelGGL(k_vertex_transform, dim3(dwg_cdiv(Vp, 256)), dim3(256), 0, (hipStream_t)stream, Vp, V, J, n_shape,
+    DWG_LAUNCH("lbs_vertex_transform", k_vertex_transform, dim3(dwg_cdiv(Vp, 256)), dim3(256), 0, (hipStream_t)stream, Vp, V, J, n_shape,
                        posedirs ? n_posefeat : 0, vertex_indices, vertex_coords, A, lbs_weights, shapedirs, shape_coeffs,
                        posedirs, rot_mats, out);
     DWG_RETURN_IF_LAUNCH_FAILED();

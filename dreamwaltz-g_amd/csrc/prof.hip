@@ -1,0 +1,93 @@
+// prof.hip -- per-kernel HIP-event timing on the launch stream (include/dwg_prof.h).
+#include "dwg_common.h"
+#include "dwg_prof_internal.h"
+#include "../../include/dwg_prof.h"
+
+#include <map>
+#include <mutex>
+#include <string>
+#include <vector>
+#include <cstdio>
+#include <cstring>
+
+namespace {
+struct Sample { hipEvent_t a, b; };
+std::mutex g_mu;
+bool g_on = false;
+std::map<std::string, std::vector<Sample>> g_samples;
+
+void clear_locked() {
+    for (auto& kv : g_samples)
+        for (auto& s : kv.second) { hipEventDestroy(s.a); hipEventDestroy(s.b); }
+    g_samples.clear();
+}
+}  // namespace
+
+bool dwg_prof_on() { return g_on; }
+
+void dwg_prof_begin(const char* name, hipStream_t stream, void** token) {
+    *token = nullptr;
+    if (!g_on) return;
+    Sample s;
+    if (hipEventCreate(&s.a) != hipSuccess || hipEventCreate(&s.b) != hipSuccess) return;
+    hipEventRecord(s.a, stream);
+    std::lock_guard<std::mutex> lk(g_mu);
+    auto& v = g_samples[name];
+    v.push_back(s);
+    *token = (void*)(uintptr_t)v.size();  // 1-based index
+}
+
+void dwg_prof_end(const char* name, hipStream_t stream, void* token) {
+    if (!token) return;
+    std::lock_guard<std::mutex> lk(g_mu);
+    auto it = g_samples.find(name);
+    if (it == g_samples.end()) return;
+    size_t idx = (size_t)(uintptr_t)token - 1;
+    if (idx < it->second.size()) hipEventRecord(it->second[idx].b, stream);
+}
+
+extern "C" {
+
+int dwg_prof_enable(int32_t enable) {
+    std::lock_guard<std::mutex> lk(g_mu);
+    clear_locked();
+    g_on = enable != 0;
+    return DWG_OK;
+}
+
+int dwg_prof_query(const char* name, int64_t* count, double* total_ms) {
+    if (!name || !count || !total_ms) return DWG_E_ARG;
+    std::lock_guard<std::mutex> lk(g_mu);
+    *count = 0; *total_ms = 0.0;
+    auto it = g_samples.find(name);
+    if (it == g_samples.end()) return DWG_OK;
+    for (auto& s : it->second) {
+        if (hipEventSynchronize(s.b) != hipSuccess) continue;
+        float ms = 0.f;
+        if (hipEventElapsedTime(&ms, s.a, s.b) == hipSuccess) { *total_ms += ms; *count += 1; }
+    }
+    return DWG_OK;
+}
+
+int64_t dwg_prof_dump(char* buf, int64_t cap) {
+    std::string out;
+    std::vector<std::string> names;
+    {
+        std::lock_guard<std::mutex> lk(g_mu);
+        for (auto& kv : g_samples) names.push_back(kv.first);
+    }
+    for (auto& n : names) {
+        int64_t c = 0; double ms = 0.0;
+        dwg_prof_query(n.c_str(), &c, &ms);
+        char line[256];
+        snprintf(line, sizeof(line), "%s %lld %.6f\n", n.c_str(), (long long)c, ms);
+        out += line;
+    }
+    if (buf && cap > 0) {
+        size_t n = out.size() < (size_t)(cap - 1) ? out.size() : (size_t)(cap - 1);
+        memcpy(buf, out.data(), n); buf[n] = 0;
+    }
+    return (int64_t)out.size() + 1;
+}
+
+}  // extern "C"

@@ -18,6 +18,7 @@
 //
 // Compositing order inside a tile: ascending (depth bits, Gaussian id) -- same tie-break as a stable sort.
 #include "dwg_common.h"
+#include "dwg_prof_internal.h"
 #include "../../include/dwg_raster.h"
 
 namespace {
@@ -721,12 +722,12 @@ int dwg_raster_forward_bin(const dwg_raster_settings* cfg, int32_t G, const floa
     int T = p.tiles_x * p.tiles_y;
     if (hipMemsetAsync(ws + L.tile_count, 0, L.tile_start - L.tile_count, stream) != hipSuccess) return DWG_E_LAUNCH;
     if (G > 0) {
-        hipLaunchKernelGGL(k_preprocess, dim3(dwg_cdiv(G, 256)), dim3(256), 0, stream, p, means3D, shs, colors_precomp,
+        DWG_LAUNCH("raster_preprocess", k_preprocess, dim3(dwg_cdiv(G, 256)), dim3(256), 0, stream, p, means3D, shs, colors_precomp,
                            opacities, scales, rotations, cov3D_precomp, radii, (float4*)(ws + L.rec0),
                            (float4*)(ws + L.rec1), (float4*)(ws + L.rec2), (uint2*)(ws + L.rect),
                            (uint32_t*)(ws + L.tile_count));
     }
-    hipLaunchKernelGGL(k_scan_tiles, dim3(1), dim3(1024), 0, stream, T, (const uint32_t*)(ws + L.tile_count),
+    DWG_LAUNCH("raster_scan_tiles", k_scan_tiles, dim3(1), dim3(1024), 0, stream, T, (const uint32_t*)(ws + L.tile_count),
                        (uint32_t*)(ws + L.tile_start), (int32_t*)(ws + L.header));
     DWG_RETURN_IF_LAUNCH_FAILED();
     return DWG_OK;
@@ -749,18 +750,18 @@ int dwg_raster_forward_render(const dwg_raster_settings* cfg, int32_t G, void* w
     uint32_t* sorted = (uint32_t*)(wp + PL.sorted);
     const uint32_t* tile_start = (const uint32_t*)(ws + L.tile_start);
     if (G > 0) {
-        hipLaunchKernelGGL(k_scatter, dim3(dwg_cdiv(G, 256)), dim3(256), 0, stream, G, p.tiles_x,
+        DWG_LAUNCH("raster_scatter", k_scatter, dim3(dwg_cdiv(G, 256)), dim3(256), 0, stream, G, p.tiles_x,
                            (const float4*)(ws + L.rec0), (const uint2*)(ws + L.rect), tile_start,
                            (uint32_t*)(ws + L.tile_cursor), keys, pair_capacity, (int32_t*)(ws + L.header));
         // three size classes: (1,2048] in 16 KiB LDS, (2048,8192] in 64 KiB LDS, >8192 in global memory
-        hipLaunchKernelGGL((k_tile_sort<2048, false>), dim3(T), dim3(256), 2048 * 8, stream, tile_start, keys, sorted, 0,
+        DWG_LAUNCH("raster_tile_sort", (k_tile_sort<2048, false>), dim3(T), dim3(256), 2048 * 8, stream, tile_start, keys, sorted, 0,
                            pair_capacity);
-        hipLaunchKernelGGL((k_tile_sort<8192, false>), dim3(T), dim3(256), 8192 * 8, stream, tile_start, keys, sorted, 2048,
+        DWG_LAUNCH("raster_tile_sort_l", (k_tile_sort<8192, false>), dim3(T), dim3(256), 8192 * 8, stream, tile_start, keys, sorted, 2048,
                            pair_capacity);
-        hipLaunchKernelGGL((k_tile_sort<0, true>), dim3(T), dim3(256), 0, stream, tile_start, keys, sorted, 8192,
+        DWG_LAUNCH("raster_tile_sort_g", (k_tile_sort<0, true>), dim3(T), dim3(256), 0, stream, tile_start, keys, sorted, 8192,
                            pair_capacity);
     }
-    hipLaunchKernelGGL(k_render_fwd, dim3(T), dim3(256), 0, stream, p, tile_start, (const uint32_t*)sorted,
+    DWG_LAUNCH("raster_render_fwd", k_render_fwd, dim3(T), dim3(256), 0, stream, p, tile_start, (const uint32_t*)sorted,
                        (const float4*)(ws + L.rec0), (const float4*)(ws + L.rec1), (const float4*)(ws + L.rec2),
                        pair_capacity, (float*)(wi + IL.final_T), (int*)(wi + IL.n_contrib), out_color, out_depth,
                        out_alpha);
@@ -791,11 +792,11 @@ int dwg_raster_backward(const dwg_raster_settings* cfg, int32_t G, const float* 
     const char* ws = (const char*)ws_geom; const char* wp = (const char*)ws_pairs; const char* wi = (const char*)ws_image;
     int T = p.tiles_x * p.tiles_y;
     if (hipMemsetAsync(ws_grad, 0, (size_t)G * GSTRIDE * sizeof(float), stream) != hipSuccess) return DWG_E_LAUNCH;
-    hipLaunchKernelGGL(k_render_bwd, dim3(T), dim3(256), 0, stream, p, (const uint32_t*)(ws + L.tile_start),
+    DWG_LAUNCH("raster_render_bwd", k_render_bwd, dim3(T), dim3(256), 0, stream, p, (const uint32_t*)(ws + L.tile_start),
                        (const uint32_t*)(wp + PL.sorted), (const float4*)(ws + L.rec0), (const float4*)(ws + L.rec1),
                        (const float4*)(ws + L.rec2), pair_capacity, (const float*)(wi + IL.final_T),
                        (const int*)(wi + IL.n_contrib), dL_dout_color, dL_dout_depth, dL_dout_alpha, (float*)ws_grad);
-    hipLaunchKernelGGL(k_preprocess_bwd, dim3(dwg_cdiv(G, 256)), dim3(256), 0, stream, p, means3D, shs, colors_precomp,
+    DWG_LAUNCH("raster_preprocess_bwd", k_preprocess_bwd, dim3(dwg_cdiv(G, 256)), dim3(256), 0, stream, p, means3D, shs, colors_precomp,
                        scales, rotations, cov3D_precomp, (const uint2*)(ws + L.rect), (const float4*)(ws + L.rec2),
                        (const float*)ws_grad, dL_dmeans3D, dL_dmeans2D, dL_dshs, dL_dcolors, dL_dopacities, dL_dscales,
                        dL_drotations, dL_dcov3D);

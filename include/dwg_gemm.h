@@ -1,0 +1,65 @@
+/*
+ * include/dwg_gemm.h -- C-ABI of the MFMA GEMM / implicit-GEMM convolution primitive.
+ *
+ * It is the contraction engine behind three reference seams:
+ *   - the per-Gaussian MLPs:   MLP.forward /root/reference/core/nerf/nerf_model.py:28-33,
+ *                              DeformNetwork.forward /root/reference/core/deformation/deform_model.py:102-143   (f32)
+ *   - the denoiser (boundary B4): ControlNetScoreDistillation._predict /root/reference/core/guidance/controlnet.py:83-114
+ *                              and AutoEncoderSD.encode_images /root/reference/core/guidance/vae.py:34-40 -- every
+ *                              conv / linear / attention product of the SD-1.5 UNet, ControlNet and VAE encoder (bf16)
+ * The reference reaches these through torch.nn.functional (cuDNN / cuBLAS); there is no reference C interface to
+ * mirror, so the descriptor below is this library's own.
+ *
+ *   C[m][n] = epilogue( alpha * sum_k A(m,k) * B(n,k) ),   A(m,k) = A[m*a_row_stride + k*a_k_stride],
+ *                                                          B(n,k) = B[n*b_row_stride + k*b_k_stride]
+ *   epilogue: + bias (f32, per column or per row) -> activation -> + residual -> store (f32 or bf16) | atomicAdd (split-K)
+ * With conv_enabled, A is an NHWC tensor [img, Hin, Win, Cin] read through an im2col view:
+ *   m = (img, oy, ox), k = (ky, kx, ci); iy = oy*stride - pad_t + ky (divided by conv_in_dilation when > 1, rows/cols that
+ *   do not divide are zero: this is the gather form of a transposed convolution, used for input gradients).
+ * Strides are in ELEMENTS.  batch = batch1 * batch2 with independent strides (image x head).
+ */
+#ifndef DWG_GEMM_H
+#define DWG_GEMM_H
+#include "dwg_types.h"
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define DWG_DTYPE_F32 0
+#define DWG_DTYPE_BF16 1
+
+#define DWG_ACT_NONE 0
+#define DWG_ACT_RELU 1
+#define DWG_ACT_LEAKY_RELU 2 /* slope 0.01 (F.leaky_relu default, deform_model.py:121) */
+#define DWG_ACT_SILU 3
+#define DWG_ACT_GELU 4       /* exact erf form */
+#define DWG_ACT_SIGMOID 5
+
+typedef struct dwg_gemm_desc {
+    const void* A; const void* B; void* C;
+    const float* bias;        /* may be NULL */
+    const void* residual;     /* may be NULL; same indexing as C with ldr */
+    int32_t M, N, K;
+    int64_t a_row_stride, a_k_stride, b_row_stride, b_k_stride, ldc, ldr;
+    int32_t batch1, batch2;
+    int64_t a_batch1_stride, a_batch2_stride, b_batch1_stride, b_batch2_stride, c_batch1_stride, c_batch2_stride,
+        r_batch1_stride, r_batch2_stride;
+    int32_t dtype;            /* DWG_DTYPE_* of A and B */
+    int32_t out_dtype;        /* DWG_DTYPE_* of C */
+    int32_t residual_dtype;
+    int32_t act;              /* DWG_ACT_* */
+    float alpha;
+    int32_t bias_per_row;
+    int32_t splitk;           /* > 1: split the contraction, atomicAdd into a pre-zeroed f32 C (no bias/act/residual) */
+    int32_t accumulate;       /* C += result (f32 C only) */
+    int32_t conv_enabled, conv_cin, conv_hin, conv_win, conv_hout, conv_wout, conv_kh, conv_kw, conv_stride, conv_pad_t,
+        conv_pad_l, conv_in_dilation;
+    const char* name;         /* optional label for dwg_prof */
+} dwg_gemm_desc;
+
+int dwg_gemm(const dwg_gemm_desc* desc, dwg_stream_t stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

@@ -116,9 +116,11 @@ def test_grid_encoder_forward_backward(B, gridtype):
     xc = x.cuda().requires_grad_(True); tc = table.cuda().requires_grad_(True)
     out = grid_encode(xc, tc, torch.from_numpy(offsets).cuda(), pls, 16, True, gridtype, False, 1)
     err = (out.detach().cpu().double() - ref.detach()).abs()
-    # a floor() flip between fma and mul+add evaluation of x*scale+0.5 moves a point to the neighbouring cell where the
-    # interpolant is continuous -> tiny differences only
-    assert err.max() < 2e-5, err.max()
+    # fp32 position arithmetic at the finest level (scale 4095: ulp(pos) = 2.4e-4 of a cell) against the float64 oracle:
+    # |err| <= ulp * smoothstep' (1.5) * neighbour difference (<= 2 * 0.1 table amplitude) ~ 7e-5; the reference's table is
+    # initialised to +-1e-4 (grid.py:142-144), i.e. 1000x smaller absolute errors in practice.  A floor() flip between
+    # fma and mul+add evaluation moves a point to the neighbouring cell where the interpolant is continuous.
+    assert err.max() < 7e-5, err.max()
     g = torch.Generator().manual_seed(1)
     go = torch.randn(ref.shape, generator=g, dtype=torch.float64)
     gx_ref, gt_ref = torch.autograd.grad(ref, [xd, td], go)
@@ -136,7 +138,7 @@ def test_grid_encoder_backend_layout_and_module():
     ge.grid_encode_forward(x.cuda(), table.cuda(), torch.from_numpy(offsets).cuda(), outs, 512, 3, 2, 16,
                            float(np.log2(pls)), 16, None, 1, False, 1, 0)
     got = outs.permute(1, 0, 2).reshape(512, 32).cpu().double()
-    assert (got - ref).abs().max() < 2e-5
+    assert (got - ref).abs().max() < 7e-5
     enc = ge.GridEncoder(input_dim=3, num_levels=16, level_dim=2, base_resolution=16, log2_hashmap_size=19,
                          desired_resolution=4096, gridtype='tiled', align_corners=False, interpolation='smoothstep').cuda()
     assert enc.embeddings.shape == (6328848, 2)
