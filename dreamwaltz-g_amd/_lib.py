@@ -38,7 +38,7 @@ SIGNATURES = {
     "dwg_raster_backward": (ctypes.c_int, [ctypes.POINTER(RasterSettingsC), _i32] + [_vp] * 7 + [_vp, _vp, _i64, _vp, _vp]
                             + [_vp] * 3 + [_vp] * 8 + [_vp]),
     # include/dwg_lbs.h
-    "dwg_lbs_joint_chain": (ctypes.c_int, [_i32, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
+    "dwg_lbs_joint_chain": (ctypes.c_int, [_i32, _vp, _vp, _vp, _vp, _vp, _vp, _i32, _vp, _vp, _vp]),
     "dwg_lbs_blend_forward": (ctypes.c_int, [_i32, _i32, _i32] + [_vp] * 7 + [_vp]),
     "dwg_lbs_blend_backward": (ctypes.c_int, [_i32] + [_vp] * 7 + [_vp]),
     "dwg_lbs_vertex_transform": (ctypes.c_int, [_i32] * 5 + [_vp] * 9 + [_vp]),
@@ -49,6 +49,9 @@ SIGNATURES = {
                                                 _u32, _u32, _u32, _vp]),
     # include/dwg_gemm.h
     "dwg_gemm": (ctypes.c_int, [_vp, _vp]),
+    # include/dwg_elementwise.h
+    "dwg_act_backward_colsum": (ctypes.c_int, [_i32, _i32, _i32, _vp, _vp, _vp, _vp, _vp]),
+    "dwg_adam_step": (ctypes.c_int, [_i64, _vp, _vp, _vp, _vp, _f32, _f32, _f32, _f32, _i32, _f32, _vp]),
     # include/dwg_prof.h
     "dwg_prof_enable": (ctypes.c_int, [_i32]),
     "dwg_prof_query": (ctypes.c_int, [ctypes.c_char_p, ctypes.POINTER(_i64), ctypes.POINTER(ctypes.c_double)]),

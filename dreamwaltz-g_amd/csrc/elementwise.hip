@@ -1,0 +1,106 @@
+// elementwise.hip -- small bandwidth-bound helpers around the GEMM primitive (activation backward + bias gradient,
+// fused multi-tensor Adam).  Each is a grid-stride kernel with 16-byte accesses where the layout allows.
+#include "dwg_common.h"
+#include "dwg_prof_internal.h"
+#include "../../include/dwg_elementwise.h"
+
+namespace {
+
+__device__ __forceinline__ float act_grad_from_output(float y, int act) {
+    switch (act) {
+        case 1: return y > 0.f ? 1.f : 0.f;            // relu
+        case 2: return y > 0.f ? 1.f : 0.01f;          // leaky relu (sign of output == sign of input)
+        case 5: return y * (1.f - y);                  // sigmoid
+        default: return 1.f;
+    }
+}
+
+// dz = dy * act'(y); colsum[n] += sum_m dz[m][n].  N <= 256.  One block handles ROWS_PER_BLOCK rows.
+__global__ __launch_bounds__(256) void k_act_bwd_colsum(int M, int N, int act, const float* __restrict__ dy,
+                                                        const float* __restrict__ y, float* __restrict__ dz,
+                                                        float* __restrict__ colsum, int rows_per_block) {
+    __shared__ float part[256];
+    const int tid = threadIdx.x;
+    const int tpr = N;                       // threads per row (one thread per column)
+    const int rows_par = 256 / tpr;          // rows processed in parallel
+    const int col = tid % tpr, rsub = tid / tpr;
+    const int r0 = blockIdx.x * rows_per_block;
+    const int r1 = min(M, r0 + rows_per_block);
+    float s = 0.f;
+    if (rsub < rows_par) {
+        for (int r = r0 + rsub; r < r1; r += rows_par) {
+            size_t i = (size_t)r * N + col;
+            float g = dy[i] * (y ? act_grad_from_output(y[i], act) : 1.f);
+            if (dz) dz[i] = g;
+            s += g;
+        }
+    }
+    part[tid] = (rsub < rows_par) ? s : 0.f;
+    __syncthreads();
+    if (colsum && tid < tpr) {
+        float t = 0.f;
+        for (int k = 0; k < rows_par; k++) t += part[k * tpr + tid];
+        atomicAdd(&colsum[tid], t);
+    }
+}
+
+// Adam (torch.optim.Adam semantics, amsgrad=False, weight_decay=0, maximize=False):
+//   m = b1 m + (1-b1) g ; v = b2 v + (1-b2) g^2 ; p -= lr/(1-b1^t) * m / (sqrt(v)/sqrt(1-b2^t) + eps)
+__global__ __launch_bounds__(256) void k_adam(size_t n, float* __restrict__ p, const float* __restrict__ g,
+                                              float* __restrict__ m, float* __restrict__ v, float lr, float b1, float b2,
+                                              float eps, float bc1, float bc2_sqrt, float grad_scale) {
+    size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+    const size_t stride = (size_t)gridDim.x * 256;
+    const size_t n4 = n / 4;
+    float4* p4 = reinterpret_cast<float4*>(p); const float4* g4 = reinterpret_cast<const float4*>(g);
+    float4* m4 = reinterpret_cast<float4*>(m); float4* v4 = reinterpret_cast<float4*>(v);
+    const float step = lr / bc1;
+    for (size_t k = i; k < n4; k += stride) {
+        float4 pp = p4[k], gg = g4[k], mm = m4[k], vv = v4[k];
+#define UPD(c) { float gr = gg.c * grad_scale; mm.c = b1 * mm.c + (1.f - b1) * gr; vv.c = b2 * vv.c + (1.f - b2) * gr * gr; \
+                 pp.c -= step * mm.c / (sqrtf(vv.c) / bc2_sqrt + eps); }
+        UPD(x) UPD(y) UPD(z) UPD(w)
+#undef UPD
+        p4[k] = pp; m4[k] = mm; v4[k] = vv;
+    }
+    for (size_t k = n4 * 4 + i; k < n; k += stride) {
+        float gr = g[k] * grad_scale;
+        float mm = b1 * m[k] + (1.f - b1) * gr, vv = b2 * v[k] + (1.f - b2) * gr * gr;
+        m[k] = mm; v[k] = vv;
+        p[k] -= step * mm / (sqrtf(vv) / bc2_sqrt + eps);
+    }
+}
+
+}  // namespace
+
+extern "C" {
+
+int dwg_act_backward_colsum(int32_t M, int32_t N, int32_t act, const float* dy, const float* y, float* dz, float* colsum,
+                            dwg_stream_t stream) {
+    if (M < 0 || N <= 0 || N > 256 || !dy) return DWG_E_ARG;
+    if (M == 0) return DWG_OK;
+    int rows_per_block = 512;
+    DWG_LAUNCH("act_bwd_colsum", k_act_bwd_colsum, dim3(dwg_cdiv(M, rows_per_block)), dim3(256), 0, (hipStream_t)stream, M, N,
+               act, dy, y, dz, colsum, rows_per_block);
+    DWG_RETURN_IF_LAUNCH_FAILED();
+    return DWG_OK;
+}
+
+int dwg_adam_step(int64_t n, float* param, const float* grad, float* exp_avg, float* exp_avg_sq, float lr, float beta1,
+                  float beta2, float eps, int32_t step, float grad_scale, dwg_stream_t stream) {
+    if (n < 0 || step < 1) return DWG_E_ARG;
+    if (n == 0) return DWG_OK;
+    if (!param || !grad || !exp_avg || !exp_avg_sq) return DWG_E_ARG;
+    if (((uintptr_t)param | (uintptr_t)grad | (uintptr_t)exp_avg | (uintptr_t)exp_avg_sq) % 16) return DWG_E_ARG;
+    float bc1 = 1.f - powf(beta1, (float)step);
+    float bc2_sqrt = sqrtf(1.f - powf(beta2, (float)step));
+    size_t blocks = ((size_t)n / 4 + 255) / 256;
+    if (blocks < 1) blocks = 1;
+    if (blocks > 2048) blocks = 2048;
+    DWG_LAUNCH("adam_step", k_adam, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, (size_t)n, param, grad, exp_avg,
+               exp_avg_sq, lr, beta1, beta2, eps, bc1, bc2_sqrt, grad_scale);
+    DWG_RETURN_IF_LAUNCH_FAILED();
+    return DWG_OK;
+}
+
+}  // extern "C"

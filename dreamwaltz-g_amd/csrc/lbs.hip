@@ -23,11 +23,23 @@ namespace {
 __global__ __launch_bounds__(64) void k_joint_chain(int J, const float* __restrict__ pose /*[J,3]*/,
                                                     const float* __restrict__ joints /*[J,3]*/,
                                                     const int* __restrict__ parents, const float* __restrict__ transl,
+                                                    const float* __restrict__ jdirs /*[J,3,S]|null*/,
+                                                    const float* __restrict__ shape /*[S]*/, int S,
                                                     float* __restrict__ A /*[J,16]*/, float* __restrict__ rot_mats /*[J,9]|null*/) {
     __shared__ float tm[MAXJ][16];
     __shared__ float ch[MAXJ][16];
+    __shared__ float sj[MAXJ][3];
     __shared__ int par[MAXJ];
     const int t = threadIdx.x;
+    if (t < J) {
+        // rest joints of the shaped template: J = J_template + (J_regressor . shapedirs) . shape
+        for (int k = 0; k < 3; k++) {
+            float v = joints[3 * t + k];
+            if (jdirs) { const float* d = jdirs + ((size_t)t * 3 + k) * S; for (int l = 0; l < S; l++) v += d[l] * shape[l]; }
+            sj[t][k] = v;
+        }
+    }
+    __syncthreads();
     if (t < J) {
         // Rodrigues with angle = |r + 1e-8| (smplx.lbs.batch_rodrigues)
         float rx = pose[3 * t], ry = pose[3 * t + 1], rz = pose[3 * t + 2];
@@ -45,7 +57,7 @@ __global__ __launch_bounds__(64) void k_joint_chain(int J, const float* __restri
         int p = parents[t];
         par[t] = p;
         float rel[3];
-        for (int k = 0; k < 3; k++) rel[k] = joints[3 * t + k] - (t > 0 ? joints[3 * p + k] : 0.f);
+        for (int k = 0; k < 3; k++) rel[k] = sj[t][k] - (t > 0 ? sj[p][k] : 0.f);
         for (int r = 0; r < 3; r++) {
             for (int cc = 0; cc < 3; cc++) tm[t][4 * r + cc] = R[3 * r + cc];
             tm[t][4 * r + 3] = rel[r];
@@ -65,7 +77,7 @@ __global__ __launch_bounds__(64) void k_joint_chain(int J, const float* __restri
         __syncthreads();
     }
     if (t < J) {
-        float jx = joints[3 * t], jy = joints[3 * t + 1], jz = joints[3 * t + 2];
+        float jx = sj[t][0], jy = sj[t][1], jz = sj[t][2];
         float o[16];
         for (int k = 0; k < 16; k++) o[k] = ch[t][k];
         for (int r = 0; r < 4; r++) o[4 * r + 3] -= ch[t][4 * r] * jx + ch[t][4 * r + 1] * jy + ch[t][4 * r + 2] * jz;
@@ -200,10 +212,12 @@ __global__ __launch_bounds__(256) void k_vertex_transform(int Vp, int V, int J, 
 extern "C" {
 
 int dwg_lbs_joint_chain(int32_t J, const float* pose, const float* joints, const int32_t* parents, const float* transl,
-                        float* A_out, float* rot_mats_out, dwg_stream_t stream) {
+                        const float* joint_shape_dirs, const float* shape_coeffs, int32_t n_shape, float* A_out,
+                        float* rot_mats_out, dwg_stream_t stream) {
     if (J <= 0 || J > MAXJ || !pose || !joints || !parents || !A_out) return DWG_E_ARG;
-    DWG_LAUNCH("lbs_joint_chain", k_joint_chain, dim3(1), dim3(64), 0, (hipStream_t)stream, J, pose, joints, parents, transl, A_out,
-                       rot_mats_out);
+    if (joint_shape_dirs && (!shape_coeffs || n_shape <= 0)) return DWG_E_ARG;
+    DWG_LAUNCH("lbs_joint_chain", k_joint_chain, dim3(1), dim3(64), 0, (hipStream_t)stream, J, pose, joints, parents, transl,
+               joint_shape_dirs, shape_coeffs, n_shape, A_out, rot_mats_out);
     DWG_RETURN_IF_LAUNCH_FAILED();
     return DWG_OK;
 }

@@ -62,7 +62,7 @@ def lbs_blend(A, weights, points, quats=None, normalize_weights=False):
     return _LbsBlend.apply(A, weights, points, quats, normalize_weights)
 
 
-def joint_chain(pose, joints, parents, transl=None, return_rot_mats=False):
+def joint_chain(pose, joints, parents, transl=None, return_rot_mats=False, joint_shape_dirs=None, shape_coeffs=None):
     """pose [J,3] axis-angle, joints [J,3], parents int32 [J] -> A [J,4,4] (= compose(J_pose_rigid, G_transl_offset))."""
     if not pose.is_cuda:
         raise RuntimeError("dreamwaltz_g_amd LBS runs on the GPU only (HIP kernels)")
@@ -73,7 +73,10 @@ def joint_chain(pose, joints, parents, transl=None, return_rot_mats=False):
     A = torch.empty(J, 4, 4, device=pose.device)
     R = torch.empty(J, 3, 3, device=pose.device) if return_rot_mats else None
     p = _lib.ptr
-    _lib.check(_lib.lib().dwg_lbs_joint_chain(J, p(pose), p(joints), p(parents), p(transl), p(A), p(R), _st(pose)),
+    jd = None if joint_shape_dirs is None else joint_shape_dirs.contiguous().float()
+    sc = None if shape_coeffs is None else shape_coeffs.reshape(-1).contiguous().float()
+    _lib.check(_lib.lib().dwg_lbs_joint_chain(J, p(pose), p(joints), p(parents), p(transl), p(jd), p(sc),
+                                              0 if sc is None else sc.numel(), p(A), p(R), _st(pose)),
                "dwg_lbs_joint_chain")
     return (A, R) if return_rot_mats else A
 

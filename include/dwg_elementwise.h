@@ -1,0 +1,31 @@
+/*
+ * include/dwg_elementwise.h -- C-ABI of the small bandwidth-bound helpers of the hot path.
+ *   dwg_act_backward_colsum : activation backward + bias gradient of one Linear layer of the per-Gaussian MLPs
+ *                             (autograd of /root/reference/core/nerf/nerf_model.py:28-33 and
+ *                              /root/reference/core/deformation/deform_model.py:119-122)
+ *   dwg_adam_step           : one fused Adam update over a flat fp32 buffer -- the optimizer step that closes the SDS
+ *                             step (/root/reference/core/trainer.py:888-890; torch.optim.Adam groups built at
+ *                             /root/reference/core/gaussian/gaussian_optimizer.py:67-93 and core/system/avatar.py:1590-1635)
+ * All pointers are device pointers to fp32 buffers.
+ */
+#ifndef DWG_ELEMENTWISE_H
+#define DWG_ELEMENTWISE_H
+#include "dwg_types.h"
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* dz[m][n] = dy[m][n] * act'(y[m][n]) (act = DWG_ACT_* of dwg_gemm.h, derivative taken from the OUTPUT y; y == NULL means
+ * identity); colsum[n] += sum_m dz[m][n] (colsum pre-zeroed by the caller, may be NULL; dz may be NULL). N <= 256. */
+int dwg_act_backward_colsum(int32_t M, int32_t N, int32_t act, const float* dy, const float* y, float* dz, float* colsum,
+                            dwg_stream_t stream);
+
+/* torch.optim.Adam update (amsgrad=False, weight_decay=0) on n contiguous floats, step >= 1 is the 1-based step count;
+ * grad is multiplied by grad_scale first (1/world_size after a sum all-reduce).  Buffers must be 16-byte aligned. */
+int dwg_adam_step(int64_t n, float* param, const float* grad, float* exp_avg, float* exp_avg_sq, float lr, float beta1,
+                  float beta2, float eps, int32_t step, float grad_scale, dwg_stream_t stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

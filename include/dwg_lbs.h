@@ -19,8 +19,12 @@ extern "C" {
  *   A_out[j] = compose(J_pose_rigid, G_transl_offset)[j]  -- the `joint_pose_transform` of avatar.py:1441-1444.
  * pose [J,3] axis-angle (the 165-vector of inverse_lbs.py:611-624 after `+= pose_mean`), joints [J,3] (rest joints of
  * the shaped template, inverse_lbs.py:681), parents [J] with parents[0] = -1, transl [3] or NULL.
+ * When joint_shape_dirs is given, `joints` is the TEMPLATE joint set and the shaped joints are joints + dirs . shape
+ * (vertices2joints(J_regressor, v_template + blend_shapes(...)) of inverse_lbs.py:676-681, re-associated).
  * rot_mats_out [J,9] (optional) are the per-joint rotation matrices needed for the pose blend-shape feature. J <= 64. */
 int dwg_lbs_joint_chain(int32_t J, const float* pose, const float* joints, const int32_t* parents, const float* transl,
+                        const float* joint_shape_dirs /*[J,3,S] = J_regressor . [shapedirs|expr_dirs], or NULL*/,
+                        const float* shape_coeffs /*[S] = cat(betas, expression)*/, int32_t n_shape,
                         float* A_out /*[J,16]*/, float* rot_mats_out /*[J,9] or NULL*/, dwg_stream_t stream);
 
 /* Per-Gaussian blend + transforms:  T_i = sum_j w_ij A_j ;  p' = R_i p + t_i ;

@@ -146,3 +146,88 @@ def test_grid_encoder_backend_layout_and_module():
     y = enc(pos.cuda(), bound=2)
     ref2 = oa.grid_encode(((pos + 2) / 4).double(), enc.embeddings.detach().cpu().double(), offsets, pls)
     assert (y.detach().cpu().double() - ref2).abs().max() < 1e-6
+
+
+def _avatar_pair(N=3000, with_mesh=True, seed=0):
+    """Builds the oracle inputs and the product avatar from the SAME tensors."""
+    from dreamwaltz_g_amd import avatar as av
+    body = oa.SyntheticBody(V=1500, F_=2500, seed=seed)
+    nets = oa.init_avatar_networks(seed=seed, table_std=0.05)   # large table -> visible encoder signal
+    g = torch.Generator().manual_seed(seed + 1)
+    params = dict(_positions=(torch.rand(N, 3, generator=g) * 2 - 1) * torch.tensor([0.4, 0.9, 0.2]),
+                  _scales=torch.log(torch.rand(N, 3, generator=g) * 0.018 + 0.002),
+                  _quaternions=torch.randn(N, 4, generator=g),
+                  _lbs_weights=torch.rand(N, 55, generator=g) * (torch.rand(N, 55, generator=g) < 0.1) + 1e-4)
+    cnl = dict(body_pose=torch.zeros(1, 63), global_orient=torch.zeros(1, 3), left_hand_pose=torch.zeros(1, 45),
+               right_hand_pose=torch.zeros(1, 45), expression=torch.zeros(1, 100))
+    obs = oa.random_smpl_inputs(seed=seed + 2)
+    mesh = None
+    if with_mesh:
+        vi = torch.randperm(body.V, generator=g)[:300]
+        tri = torch.randint(0, 300, (200, 3), generator=g)
+        tri = tri[(tri[:, 0] != tri[:, 1]) & (tri[:, 1] != tri[:, 2]) & (tri[:, 0] != tri[:, 2])]
+        base = torch.tensor([[2 / 3, 1 / 6, 1 / 6], [1 / 6, 2 / 3, 1 / 6], [1 / 6, 1 / 6, 2 / 3], [1 / 6, 5 / 12, 5 / 12],
+                             [5 / 12, 1 / 6, 5 / 12], [5 / 12, 5 / 12, 1 / 6]])
+        bary = base.expand(tri.shape[0], -1, -1).clone() * (1 + 0.1 * torch.rand(tri.shape[0], 6, 3, generator=g))
+        mesh = dict(vertex_indices=vi, triangles=tri, vertex_coords=body.v_template[vi], bary=bary,
+                    scales=torch.rand(tri.shape[0] * 6, 3, generator=g) * 2.5)
+    bd = {k: getattr(body, k) for k in ("v_template", "shapedirs", "expr_dirs", "posedirs", "J_regressor", "lbs_weights", "betas",
+                                        "expression", "pose_mean", "jaw_pose", "leye_pose", "reye_pose")}
+    bd["parents"] = torch.from_numpy(body.parents)
+    glbs = av.GeneralLinearBlendSkinning(bd)
+    mb = None
+    if with_mesh:
+        m = av.MeshBindingGaussianModel(mesh["vertex_coords"], mesh["triangles"], mesh["vertex_indices"])
+        m._bary_coords.data.copy_(mesh["bary"]); m._scales.data.copy_(mesh["scales"])
+        mb = {"hands": m}
+    a = av.DreamWaltzG(glbs, params["_positions"], torch.exp(params["_scales"]), params["_quaternions"], params["_lbs_weights"],
+                       {k: v.cuda() for k, v in cnl.items()}, mb)
+    a.nerf_encoder.embeddings.data.copy_(nets["table"])
+    for l in range(3):
+        a.nerf_opacity_and_color_net.net[l].weight.data.copy_(nets["static_w"][l])
+        a.nerf_opacity_and_color_net.net[l].bias.data.copy_(nets["static_b"][l])
+    a.nerf_scale_and_quaternion_net.load_state_dict(nets["deform"])
+    return a.cuda(), params, nets, body, obs, cnl, mesh
+
+
+@pytest.mark.parametrize("with_mesh", [False, True])
+def test_animate_matches_oracle_forward_and_backward(with_mesh):
+    a, params, nets, body, obs, cnl, mesh = _avatar_pair(with_mesh=with_mesh)
+    # oracle in float64 with autograd
+    to64 = lambda d: {k: (v.double() if torch.is_tensor(v) and v.is_floating_point() else v) for k, v in d.items()}  # noqa: E731
+    body64 = oa.SyntheticBody(V=1500, F_=2500, seed=0).to(torch.float64)
+    p64 = {k: v.double().requires_grad_(k != "_lbs_weights") for k, v in params.items()}
+    n64 = dict(offsets=nets["offsets"], per_level_scale=nets["per_level_scale"], table=nets["table"].double().requires_grad_(True),
+               static_w=[w.double().requires_grad_(True) for w in nets["static_w"]],
+               static_b=[b.double().requires_grad_(True) for b in nets["static_b"]],
+               deform={k: v.double().requires_grad_(True) for k, v in nets["deform"].items()})
+    m64 = None
+    if mesh is not None:
+        m64 = dict(mesh); m64["vertex_coords"] = mesh["vertex_coords"].double()
+        m64["bary"] = mesh["bary"].double().requires_grad_(True); m64["scales"] = mesh["scales"].double().requires_grad_(True)
+    ref = oa.animate(p64, n64, body64, to64(obs), to64(cnl), mesh=m64)
+    out = a.animate({k: v.cuda() for k, v in obs.items()})
+    tol = dict(positions=5e-5, opacities=2e-5, colors=2e-5, quaternions=2e-4, scales=2e-5)
+    for k, t in tol.items():
+        err = (out[k].detach().cpu().double() - ref[k].detach()).abs().max()
+        assert err < t, (k, float(err))
+    g = torch.Generator().manual_seed(9)
+    gs = {k: torch.randn(ref[k].shape, generator=g, dtype=torch.float64) for k in tol}
+    loss_ref = sum((ref[k] * gs[k]).sum() for k in tol)
+    loss = sum((out[k] * gs[k].float().cuda()).sum() for k in tol)
+    loss_ref.backward(); loss.backward()
+    pairs = [("_positions", a._positions.grad, p64["_positions"].grad), ("_scales", a._scales.grad, p64["_scales"].grad),
+             ("_quaternions", a._quaternions.grad, p64["_quaternions"].grad),
+             ("table", a.nerf_encoder.embeddings.grad, n64["table"].grad)]
+    for l in range(3):
+        pairs.append(("static_w%d" % l, a.nerf_opacity_and_color_net.net[l].weight.grad, n64["static_w"][l].grad))
+        pairs.append(("static_b%d" % l, a.nerf_opacity_and_color_net.net[l].bias.grad, n64["static_b"][l].grad))
+    sd = dict(a.nerf_scale_and_quaternion_net.named_parameters())
+    for k in ("layers.0.weight", "layers.0.bias", "layers.3.weight", "gaussian_warp.weight", "gaussian_scaling.bias"):
+        pairs.append(("deform." + k, sd[k].grad, n64["deform"][k].grad))
+    if mesh is not None:
+        gm = a.mesh_binding_gaussians["hands"]
+        pairs += [("bary", gm._bary_coords.grad, m64["bary"].grad), ("mesh_scales", gm._scales.grad, m64["scales"].grad)]
+    for name, got, want in pairs:
+        assert got is not None, name
+        assert _rel_l2(got, want) < 2e-3, (name, _rel_l2(got, want))
