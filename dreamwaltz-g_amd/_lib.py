@@ -52,6 +52,15 @@ SIGNATURES = {
     # include/dwg_elementwise.h
     "dwg_act_backward_colsum": (ctypes.c_int, [_i32, _i32, _i32, _vp, _vp, _vp, _vp, _vp]),
     "dwg_adam_step": (ctypes.c_int, [_i64, _vp, _vp, _vp, _vp, _f32, _f32, _f32, _f32, _i32, _f32, _vp]),
+    # include/dwg_nn.h
+    "dwg_groupnorm_forward": (ctypes.c_int, [_i32, _i32, _i32, _i32, _vp, _vp, _vp, _f32, _i32, _vp, _vp, _vp]),
+    "dwg_groupnorm_backward": (ctypes.c_int, [_i32, _i32, _i32, _i32, _vp, _vp, _vp, _vp, _vp, _f32, _i32, _vp, _vp, _vp]),
+    "dwg_layernorm_forward": (ctypes.c_int, [_i32, _i32, _vp, _vp, _vp, _f32, _vp, _vp]),
+    "dwg_geglu_forward": (ctypes.c_int, [_i64, _i32, _vp, _vp, _vp]),
+    "dwg_attention_forward": (ctypes.c_int, [_i32, _i32, _i32, _i32, _i32, _vp, _i64, _i64, _vp, _i64, _i64, _vp, _i64, _i64,
+                                             _vp, _i64, _i64, _f32, _vp]),
+    "dwg_softmax_rows_forward": (ctypes.c_int, [_i32, _i32, _f32, _vp, _i64, _vp, _i64, _vp]),
+    "dwg_softmax_rows_backward": (ctypes.c_int, [_i32, _i32, _f32, _vp, _i64, _vp, _i64, _vp, _i64, _vp]),
     # include/dwg_prof.h
     "dwg_prof_enable": (ctypes.c_int, [_i32]),
     "dwg_prof_query": (ctypes.c_int, [ctypes.c_char_p, ctypes.POINTER(_i64), ctypes.POINTER(ctypes.c_double)]),

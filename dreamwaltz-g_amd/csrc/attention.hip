@@ -1,0 +1,191 @@
+// attention.hip -- fused (flash-style) multi-head attention forward for gfx950: bf16 in/out, fp32 online softmax.
+//
+// Used for every attention site of the SD-1.5 UNet / ControlNet (self: N = 4096/1024/256/64 tokens, cross: 77 keys;
+// 8 heads of dim 40/80/160) inside boundary B4 (controlnet.py:98-114).  The reference gets the same math from
+// diffusers' AttnProcessor2_0 -> F.scaled_dot_product_attention.
+//
+// Wave64 design (not a warp-shaped tiling):
+//   * workgroup = 4 waves, each wave owns 32 queries; K/V tiles of 32 keys are staged once per workgroup in LDS.
+//   * S^T = K Q^T is computed "swapped" with v_mfma_f32_32x32x16_bf16 (A = K tile rows, B = Q rows held in VGPRs), so a
+//     lane holds ONE query column: its 16 accumulator registers are 16 of the 32 keys of the tile, the other 16 sit in
+//     lane^32.  Row max / row sum are therefore 15 in-lane ops + one cross-half exchange -- no LDS round trip.
+//   * O^T += V^T P^T reuses the probabilities straight from those registers as the MFMA B operand: the contraction over
+//     keys is order-free, so V^T is read from LDS in the SAME key permutation the accumulator layout implies
+//     (two 8-byte reads per fragment) instead of shuffling P between lanes.
+//   * per-query rescale of O is a per-lane scalar multiply (each lane owns one query column of O^T).
+#include "dwg_common.h"
+#include "dwg_prof_internal.h"
+#include "../../include/dwg_nn.h"
+
+namespace {
+
+typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
+typedef __attribute__((ext_vector_type(4))) __bf16 bf16x4;
+typedef __attribute__((ext_vector_type(16))) float f32x16;
+
+struct AttnP {
+    const __bf16* Q; const __bf16* K; const __bf16* V; __bf16* O;
+    int Nq, Nk, H, d;
+    long long ldq, ldk, ldv, ldo;          // row strides (elements)
+    long long bq, bk, bv, bo;              // per-image strides (elements); head h starts at column h*d
+    float scale_log2;                      // softmax scale * log2(e)
+};
+
+// DK = head dim padded to a multiple of 16 (contraction of QK^T), DV = padded to a multiple of 32 (rows of O^T)
+template <int DK, int DV>
+__global__ __launch_bounds__(256) void k_flash_fwd(AttnP p) {
+    constexpr int KT = 32;                 // keys per tile
+    constexpr int LDK = DK + 8;            // K tile row stride (bf16), 16-byte aligned rows
+    constexpr int LDV = KT + 8;            // V^T tile row stride
+    constexpr int NKS = DK / 16, NVB = DV / 32;
+    __shared__ __attribute__((aligned(16))) __bf16 sK[KT * LDK];
+    __shared__ __attribute__((aligned(16))) __bf16 sVt[DV * LDV];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, half = lane >> 5, ql = lane & 31;
+    const int img = blockIdx.y / p.H, head = blockIdx.y % p.H;
+    const int q0 = blockIdx.x * 128 + wave * 32;
+    const __bf16* Q = p.Q + img * p.bq + (long long)head * p.d;
+    const __bf16* K = p.K + img * p.bk + (long long)head * p.d;
+    const __bf16* V = p.V + img * p.bv + (long long)head * p.d;
+    __bf16* O = p.O + img * p.bo + (long long)head * p.d;
+
+    // this lane's query row as MFMA B-operand fragments: element e of step s = Q[q][16 s + 8 half + e]
+    bf16x8 qf[NKS];
+    {
+        const int q = q0 + ql;
+#pragma unroll
+        for (int s = 0; s < NKS; s++) {
+            const int c = 16 * s + 8 * half;
+            bf16x8 v;
+#pragma unroll
+            for (int e = 0; e < 8; e++) v[e] = (__bf16)0.f;
+            if (q < p.Nq && c < p.d) v = *reinterpret_cast<const bf16x8*>(Q + (long long)q * p.ldq + c);   // d % 8 == 0
+            qf[s] = v;
+        }
+    }
+    f32x16 acc[NVB];
+#pragma unroll
+    for (int j = 0; j < NVB; j++)
+#pragma unroll
+        for (int r = 0; r < 16; r++) acc[j][r] = 0.f;
+    float m_run = -3.0e38f, l_run = 0.f;
+
+    const int ntiles = (p.Nk + KT - 1) / KT;
+    for (int t = 0; t < ntiles; t++) {
+        const int k0 = t * KT;
+        __syncthreads();   // previous tile fully consumed
+        // stage K tile [key][d] (zero padded) and V tile transposed [d][key]
+        for (int c = tid; c < KT * (DK / 8); c += 256) {
+            int key = c / (DK / 8), dc = (c % (DK / 8)) * 8;
+            bf16x8 v;
+#pragma unroll
+            for (int e = 0; e < 8; e++) v[e] = (__bf16)0.f;
+            if (k0 + key < p.Nk && dc < p.d) v = *reinterpret_cast<const bf16x8*>(K + (long long)(k0 + key) * p.ldk + dc);
+            *reinterpret_cast<bf16x8*>(&sK[key * LDK + dc]) = v;
+        }
+        for (int c = tid; c < KT * (DV / 8); c += 256) {
+            int key = c % KT, dc = (c / KT) * 8;      // consecutive threads -> consecutive keys: conflict-light transposed writes
+            bf16x8 v;
+#pragma unroll
+            for (int e = 0; e < 8; e++) v[e] = (__bf16)0.f;
+            if (k0 + key < p.Nk && dc < p.d) v = *reinterpret_cast<const bf16x8*>(V + (long long)(k0 + key) * p.ldv + dc);
+#pragma unroll
+            for (int e = 0; e < 8; e++) sVt[(dc + e) * LDV + key] = v[e];
+        }
+        __syncthreads();
+        // S^T tile: rows = keys, cols = queries
+        f32x16 s;
+#pragma unroll
+        for (int r = 0; r < 16; r++) s[r] = 0.f;
+#pragma unroll
+        for (int ks = 0; ks < NKS; ks++) {
+            bf16x8 kf = *reinterpret_cast<const bf16x8*>(&sK[ql * LDK + 16 * ks + 8 * half]);
+            s = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf, qf[ks], s, 0, 0, 0);
+        }
+        // online softmax for this lane's query; register r <-> key k0 + (r&3) + 8*(r>>2) + 4*half
+        float mx = -3.0e38f;
+#pragma unroll
+        for (int r = 0; r < 16; r++) {
+            int key = k0 + (r & 3) + 8 * (r >> 2) + 4 * half;
+            s[r] = key < p.Nk ? s[r] * p.scale_log2 : -3.0e38f;
+            mx = fmaxf(mx, s[r]);
+        }
+        mx = fmaxf(mx, __shfl_xor(mx, 32));
+        const float m_new = fmaxf(m_run, mx);
+        const float alpha = exp2f(m_run - m_new);
+        float rs = 0.f;
+#pragma unroll
+        for (int r = 0; r < 16; r++) { s[r] = exp2f(s[r] - m_new); rs += s[r]; }
+        rs += __shfl_xor(rs, 32);
+        l_run = l_run * alpha + rs;
+        m_run = m_new;
+#pragma unroll
+        for (int j = 0; j < NVB; j++)
+#pragma unroll
+            for (int r = 0; r < 16; r++) acc[j][r] *= alpha;
+        // P^T as B operand: step st uses registers 8 st .. 8 st + 7 of this lane
+        bf16x8 pf[2];
+#pragma unroll
+        for (int st = 0; st < 2; st++)
+#pragma unroll
+            for (int e = 0; e < 8; e++) pf[st][e] = (__bf16)s[8 * st + e];
+        // O^T += V^T P^T ; A operand row = dv, elements follow the same key permutation:
+        //   e in 0..3 -> key 16 st + 4 half + e ; e in 4..7 -> key 16 st + 8 + 4 half + (e - 4)
+#pragma unroll
+        for (int j = 0; j < NVB; j++) {
+#pragma unroll
+            for (int st = 0; st < 2; st++) {
+                const __bf16* vrow = &sVt[(32 * j + ql) * LDV + 16 * st + 4 * half];
+                bf16x4 lo = *reinterpret_cast<const bf16x4*>(vrow);
+                bf16x4 hi = *reinterpret_cast<const bf16x4*>(vrow + 8);
+                bf16x8 vf;
+                vf[0] = lo[0]; vf[1] = lo[1]; vf[2] = lo[2]; vf[3] = lo[3];
+                vf[4] = hi[0]; vf[5] = hi[1]; vf[6] = hi[2]; vf[7] = hi[3];
+                acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf, pf[st], acc[j], 0, 0, 0);
+            }
+        }
+    }
+    // epilogue: O[q][dv] = acc / l ; lane owns query column ql, register r of block j <-> dv = 32 j + (r&3) + 8 (r>>2) + 4 half.
+    // Stage through LDS so that rows go out as contiguous 16-byte stores.
+    constexpr int LDO = DV + 8;
+    __shared__ __attribute__((aligned(16))) __bf16 sOut[4 * 32 * LDO];
+    const float inv = l_run > 0.f ? 1.f / l_run : 0.f;
+    __bf16* myO = sOut + wave * 32 * LDO;
+#pragma unroll
+    for (int j = 0; j < NVB; j++)
+#pragma unroll
+        for (int r = 0; r < 16; r++) {
+            int dv = 32 * j + (r & 3) + 8 * (r >> 2) + 4 * half;
+            myO[ql * LDO + dv] = (__bf16)(acc[j][r] * inv);
+        }
+    __syncthreads();
+    for (int c = lane; c < 32 * (p.d / 8); c += 64) {
+        int q = c / (p.d / 8), dc = (c % (p.d / 8)) * 8;
+        if (q0 + q < p.Nq)
+            *reinterpret_cast<bf16x8*>(O + (long long)(q0 + q) * p.ldo + dc) = *reinterpret_cast<const bf16x8*>(&myO[q * LDO + dc]);
+    }
+}
+
+}  // namespace
+
+extern "C" {
+
+int dwg_attention_forward(int32_t B, int32_t H, int32_t Nq, int32_t Nk, int32_t d, const void* Q, int64_t ldq, int64_t bq,
+                          const void* K, int64_t ldk, int64_t bk, const void* V, int64_t ldv, int64_t bv, void* O, int64_t ldo,
+                          int64_t bo, float scale, dwg_stream_t stream_) {
+    if (B <= 0 || H <= 0 || Nq <= 0 || Nk <= 0 || d <= 0 || d % 8 || d > 160 || !Q || !K || !V || !O) return DWG_E_ARG;
+    if ((ldq | ldk | ldv | ldo | bq | bk | bv | bo) % 8) return DWG_E_ARG;   // 16-byte aligned rows
+    if (((uintptr_t)Q | (uintptr_t)K | (uintptr_t)V | (uintptr_t)O) % 16) return DWG_E_ARG;
+    AttnP p{(const __bf16*)Q, (const __bf16*)K, (const __bf16*)V, (__bf16*)O, Nq, Nk, H, d, ldq, ldk, ldv, ldo, bq, bk, bv, bo,
+            scale * 1.4426950408889634f};
+    dim3 grid(dwg_cdiv(Nq, 128), B * H), block(256);
+    hipStream_t stream = (hipStream_t)stream_;
+    if (d <= 32) DWG_LAUNCH("flash_attn_d32", (k_flash_fwd<32, 32>), grid, block, 0, stream, p);
+    else if (d <= 48) DWG_LAUNCH("flash_attn_d48", (k_flash_fwd<48, 64>), grid, block, 0, stream, p);
+    else if (d <= 64) DWG_LAUNCH("flash_attn_d64", (k_flash_fwd<64, 64>), grid, block, 0, stream, p);
+    else if (d <= 96) DWG_LAUNCH("flash_attn_d96", (k_flash_fwd<96, 96>), grid, block, 0, stream, p);
+    else DWG_LAUNCH("flash_attn_d160", (k_flash_fwd<160, 160>), grid, block, 0, stream, p);
+    DWG_RETURN_IF_LAUNCH_FAILED();
+    return DWG_OK;
+}
+
+}  // extern "C"

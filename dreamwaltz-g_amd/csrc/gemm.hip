@@ -23,6 +23,9 @@ typedef __attribute__((ext_vector_type(16))) float f32x16;
 
 struct ConvP {
     int enabled, Cin, Hin, Win, Hout, Wout, KH, KW, stride, pad_t, pad_l, dil;  // dil = input dilation (dgrad of strided conv)
+    int up;          // nearest-neighbour input upsampling factor (1 | 2): Upsample2D fused into the following conv
+    int cin1;        // channels [0,cin1) come from A, [cin1,Cin) from A2 (skip-connection concat fused into the conv)
+    const void* A2;
 };
 
 struct GemmP {
@@ -33,6 +36,7 @@ struct GemmP {
     long long bA1, bA2, bB1, bB2, bC1, bC2, bR1, bR2;
     int act; float alpha;
     int out_bf16, res_bf16, bias_per_row, splitk, accumulate;
+    int bias_row_div;   // > 0: bias index = (row / bias_row_div) * N + col  (per-image channel bias: conv bias + time embedding)
     ConvP conv;
 };
 
@@ -126,8 +130,14 @@ struct TileLoader {
                         ok = iy >= 0 && ix >= 0 && (iy % cv.dil == 0) && (ix % cv.dil == 0);
                         iy /= cv.dil; ix /= cv.dil;
                     }
+                    if (cv.up > 1) {  // virtual input is the nearest-neighbour upsampled tensor
+                        ok = ok && iy >= 0 && ix >= 0 && iy < cv.Hin * cv.up && ix < cv.Win * cv.up;
+                        iy /= cv.up; ix /= cv.up;
+                    }
                     ok = ok && iy >= 0 && iy < cv.Hin && ix >= 0 && ix < cv.Win;
-                    src = base + (((long long)img * cv.Hin + iy) * cv.Win + ix) * cv.Cin + ci;
+                    const long long pix = ((long long)img * cv.Hin + iy) * cv.Win + ix;
+                    if (ci < cv.cin1) src = base + pix * cv.cin1 + ci;
+                    else src = reinterpret_cast<const T*>(cv.A2) + pix * (cv.Cin - cv.cin1) + (ci - cv.cin1);
                 }
                 regs[i] = ok ? load_vec<T, VEC>(src) : zero_chunk<T, VEC>();
             }
@@ -262,7 +272,8 @@ __global__ __launch_bounds__(256) void k_gemm(GemmP p) {
                 float v = acc[i][j][r] * p.alpha;
                 const long long ci = coff + (long long)row * p.ldc + col;
                 if (p.splitk > 1) { atomicAdd(reinterpret_cast<float*>(p.C) + ci, v); continue; }
-                if (p.bias) v += reinterpret_cast<const float*>(p.bias)[p.bias_per_row ? row : col];
+                if (p.bias) v += reinterpret_cast<const float*>(p.bias)[p.bias_row_div > 0 ? (long long)(row / p.bias_row_div) * p.N + col
+                                                                                         : (p.bias_per_row ? row : col)];
                 v = apply_act(v, p.act);
                 if (p.residual) {
                     const long long ri = roff + (long long)row * p.ldr + col;
@@ -334,6 +345,9 @@ int dwg_gemm(const dwg_gemm_desc* d, dwg_stream_t stream_) {
     p.conv.Cin = d->conv_cin; p.conv.Hin = d->conv_hin; p.conv.Win = d->conv_win; p.conv.Hout = d->conv_hout;
     p.conv.Wout = d->conv_wout; p.conv.KH = d->conv_kh; p.conv.KW = d->conv_kw; p.conv.stride = d->conv_stride;
     p.conv.pad_t = d->conv_pad_t; p.conv.pad_l = d->conv_pad_l; p.conv.dil = d->conv_in_dilation > 1 ? d->conv_in_dilation : 1;
+    p.conv.up = d->conv_in_upsample > 1 ? d->conv_in_upsample : 1;
+    p.conv.A2 = d->A2; p.conv.cin1 = d->A2 ? d->conv_cin1 : d->conv_cin;
+    p.bias_row_div = d->bias_row_div;
     const int batch = d->batch1 * d->batch2;
     hipStream_t stream = (hipStream_t)stream_;
     const char* name = d->name ? d->name : (d->conv_enabled ? "conv_igemm" : "gemm");
@@ -344,6 +358,8 @@ int dwg_gemm(const dwg_gemm_desc* d, dwg_stream_t stream_) {
         long long ao[2] = {p.bA1, p.bA2}, bo[2] = {p.bB1, p.bB2};
         if (d->conv_enabled) {
             if (d->conv_cin % 8 != 0 || ((uintptr_t)d->A % 16) != 0) return DWG_E_ARG;
+            if (d->A2 && (d->conv_cin1 % 8 != 0 || d->conv_cin1 <= 0 || d->conv_cin1 >= d->conv_cin || ((uintptr_t)d->A2 % 16) != 0))
+                return DWG_E_ARG;
             if (d->K != d->conv_kh * d->conv_kw * d->conv_cin) return DWG_E_ARG;
             amode = MODE_CONV;
         } else amode = pick_mode<T>(p.A, p.sam, p.sak, p.M, p.K, ao, 2);

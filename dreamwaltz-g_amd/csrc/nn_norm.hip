@@ -1,0 +1,323 @@
+// nn_norm.hip -- bandwidth-bound layers of the SD-1.5 denoiser / VAE encoder on NHWC bf16 activations, fp32 statistics:
+//   GroupNorm(32) (+ fused SiLU) forward and input-gradient, LayerNorm forward, GEGLU, row softmax forward/backward.
+// They sit between the MFMA contractions of boundary B4 (controlnet.py:83-114, vae.py:34-40); the reference reaches the
+// same math through torch.nn.functional.group_norm / layer_norm / gelu / softmax inside diffusers.
+// Access pattern: every kernel walks the tensor in 16-byte (8 x bf16) chunks, whole rows per wave, so HBM sees full lines.
+#include "dwg_common.h"
+#include "dwg_prof_internal.h"
+#include "../../include/dwg_nn.h"
+
+namespace {
+
+typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
+
+__device__ __forceinline__ float silu_f(float z) { return z / (1.f + __expf(-z)); }
+__device__ __forceinline__ float silu_grad(float z) { float s = 1.f / (1.f + __expf(-z)); return s * (1.f + z * (1.f - s)); }
+
+// ---------------------------------------------------------------------------------------------------------------------
+// GroupNorm statistics: sums[b][g] = (sum x, sum x^2)  |  backward: (sum dyh, sum dyh*xhat)
+// grid (chunks, B); each block owns a contiguous pixel range of one image and ALL channels (full-row, coalesced reads).
+// ---------------------------------------------------------------------------------------------------------------------
+template <bool BWD>
+__global__ __launch_bounds__(256) void k_gn_reduce(int HW, int C, int G, int pix_per_block, const __bf16* __restrict__ x,
+                                                   const __bf16* __restrict__ dy, const float* __restrict__ stats,
+                                                   const float* __restrict__ gamma, const float* __restrict__ beta, int silu,
+                                                   float eps, float* __restrict__ sums /*[B][G][2]*/) {
+    extern __shared__ __attribute__((aligned(16))) float lds[];   // [rows][Cb*2] partials for the current channel pass
+    __shared__ float gacc[64 * 2];
+    __shared__ float gstat[64 * 2];
+    const int b = blockIdx.y, tid = threadIdx.x;
+    const int p0 = blockIdx.x * pix_per_block, p1 = min(HW, p0 + pix_per_block);
+    const int C8 = C / 8, cg = C / G;
+    const float inv_n = 1.f / ((float)HW * cg);
+    if (tid < 2 * G) gacc[tid] = 0.f;
+    if (BWD && tid < G) {
+        float m = stats[((size_t)b * G + tid) * 2] * inv_n;
+        float var = stats[((size_t)b * G + tid) * 2 + 1] * inv_n - m * m;
+        gstat[2 * tid] = m; gstat[2 * tid + 1] = rsqrtf(fmaxf(var, 0.f) + eps);
+    }
+    __syncthreads();
+    for (int cb = 0; cb < C8; cb += 256) {
+        const int tpx = min(256, C8 - cb);      // threads along the channel-chunk axis
+        const int rows = 256 / tpx;             // pixels handled in parallel
+        const int cc = cb + tid % tpx, prow = tid / tpx;
+        float s1[8], s2[8];
+#pragma unroll
+        for (int e = 0; e < 8; e++) { s1[e] = 0.f; s2[e] = 0.f; }
+        if (prow < rows) {
+            float ga[8], be[8], mu[8], rs[8];
+            if (BWD) {
+#pragma unroll
+                for (int e = 0; e < 8; e++) {
+                    int ch = cc * 8 + e, g = ch / cg;
+                    ga[e] = gamma[ch]; be[e] = beta[ch]; mu[e] = gstat[2 * g]; rs[e] = gstat[2 * g + 1];
+                }
+            }
+            for (int p = p0 + prow; p < p1; p += rows) {
+                size_t off = ((size_t)b * HW + p) * C + (size_t)cc * 8;
+                bf16x8 xv = *reinterpret_cast<const bf16x8*>(x + off);
+                if (!BWD) {
+#pragma unroll
+                    for (int e = 0; e < 8; e++) { float v = (float)xv[e]; s1[e] += v; s2[e] += v * v; }
+                } else {
+                    bf16x8 dv = *reinterpret_cast<const bf16x8*>(dy + off);
+#pragma unroll
+                    for (int e = 0; e < 8; e++) {
+                        float xh = ((float)xv[e] - mu[e]) * rs[e];
+                        float g = (float)dv[e];
+                        if (silu) g *= silu_grad(xh * ga[e] + be[e]);
+                        g *= ga[e];
+                        s1[e] += g; s2[e] += g * xh;
+                    }
+                }
+            }
+        }
+        // per-channel partials -> LDS -> per-group sums
+        const int Cb = tpx * 8;
+        if (prow < rows) {
+#pragma unroll
+            for (int e = 0; e < 8; e++) {
+                lds[(prow * Cb + (tid % tpx) * 8 + e) * 2] = s1[e];
+                lds[(prow * Cb + (tid % tpx) * 8 + e) * 2 + 1] = s2[e];
+            }
+        }
+        __syncthreads();
+        // one thread per channel of this pass: sum over rows, then add into its group
+        for (int c = tid; c < Cb; c += 256) {
+            float a = 0.f, q = 0.f;
+            for (int r = 0; r < rows; r++) { a += lds[(r * Cb + c) * 2]; q += lds[(r * Cb + c) * 2 + 1]; }
+            int g = (cb * 8 + c) / cg;
+            atomicAdd(&gacc[2 * g], a); atomicAdd(&gacc[2 * g + 1], q);
+        }
+        __syncthreads();
+    }
+    if (tid < 2 * G) atomicAdd(&sums[(size_t)b * G * 2 + tid], gacc[tid]);
+}
+
+// forward apply: y = silu?((x - mean) * rstd * gamma + beta)
+// backward apply: dx = rstd * (dyh - mean(dyh) - xhat * mean(dyh * xhat))
+template <bool BWD>
+__global__ __launch_bounds__(256) void k_gn_apply(int HW, int C, int G, int pix_per_block, const __bf16* __restrict__ x,
+                                                  const __bf16* __restrict__ dy, const float* __restrict__ stats,
+                                                  const float* __restrict__ bsums, const float* __restrict__ gamma,
+                                                  const float* __restrict__ beta, int silu, float eps,
+                                                  __bf16* __restrict__ out) {
+    __shared__ float gstat[64 * 4];
+    const int b = blockIdx.y, tid = threadIdx.x;
+    const int C8 = C / 8, cg = C / G;
+    const float inv_n = 1.f / ((float)HW * cg);
+    if (tid < G) {
+        float m = stats[((size_t)b * G + tid) * 2] * inv_n;
+        float var = stats[((size_t)b * G + tid) * 2 + 1] * inv_n - m * m;
+        gstat[4 * tid] = m; gstat[4 * tid + 1] = rsqrtf(fmaxf(var, 0.f) + eps);
+        if (BWD) { gstat[4 * tid + 2] = bsums[((size_t)b * G + tid) * 2] * inv_n; gstat[4 * tid + 3] = bsums[((size_t)b * G + tid) * 2 + 1] * inv_n; }
+    }
+    __syncthreads();
+    const int p0 = blockIdx.x * pix_per_block, p1 = min(HW, p0 + pix_per_block);
+    const long long n = (long long)(p1 - p0) * C8;
+    for (long long i = tid; i < n; i += 256) {
+        int p = p0 + (int)(i / C8), cc = (int)(i % C8);
+        size_t off = ((size_t)b * HW + p) * C + (size_t)cc * 8;
+        bf16x8 xv = *reinterpret_cast<const bf16x8*>(x + off);
+        bf16x8 dv;
+        if (BWD) dv = *reinterpret_cast<const bf16x8*>(dy + off);
+        bf16x8 o;
+#pragma unroll
+        for (int e = 0; e < 8; e++) {
+            int ch = cc * 8 + e, g = ch / cg;
+            float mu = gstat[4 * g], rs = gstat[4 * g + 1];
+            float xh = ((float)xv[e] - mu) * rs;
+            float ga = gamma[ch], be = beta[ch];
+            if (!BWD) {
+                float z = xh * ga + be;
+                o[e] = (__bf16)(silu ? silu_f(z) : z);
+            } else {
+                float gq = (float)dv[e];
+                if (silu) gq *= silu_grad(xh * ga + be);
+                gq *= ga;
+                o[e] = (__bf16)(rs * (gq - gstat[4 * g + 2] - xh * gstat[4 * g + 3]));
+            }
+        }
+        *reinterpret_cast<bf16x8*>(out + off) = o;
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------------------------
+// LayerNorm over the last dim (C % 8 == 0, C <= 2048): one wave per row, values kept in registers between the passes
+// ---------------------------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_layernorm(int M, int C, const __bf16* __restrict__ x, const float* __restrict__ gamma,
+                                                   const float* __restrict__ beta, float eps, __bf16* __restrict__ y) {
+    const int row = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+    if (row >= M) return;
+    const int C8 = C / 8;
+    float v[4][8];
+    float s = 0.f;
+#pragma unroll
+    for (int it = 0; it < 4; it++) {
+        int cc = lane + it * 64;
+        if (cc < C8) {
+            bf16x8 xv = *reinterpret_cast<const bf16x8*>(x + (size_t)row * C + (size_t)cc * 8);
+#pragma unroll
+            for (int e = 0; e < 8; e++) { v[it][e] = (float)xv[e]; s += v[it][e]; }
+        }
+    }
+    s = dwg_wave_sum_all(s);
+    const float mean = s / C;
+    float q = 0.f;
+#pragma unroll
+    for (int it = 0; it < 4; it++) {
+        int cc = lane + it * 64;
+        if (cc < C8) {
+#pragma unroll
+            for (int e = 0; e < 8; e++) { float d = v[it][e] - mean; q += d * d; }
+        }
+    }
+    q = dwg_wave_sum_all(q);
+    const float rstd = rsqrtf(q / C + eps);
+#pragma unroll
+    for (int it = 0; it < 4; it++) {
+        int cc = lane + it * 64;
+        if (cc < C8) {
+            bf16x8 o;
+#pragma unroll
+            for (int e = 0; e < 8; e++) { int ch = cc * 8 + e; o[e] = (__bf16)((v[it][e] - mean) * rstd * gamma[ch] + beta[ch]); }
+            *reinterpret_cast<bf16x8*>(y + (size_t)row * C + (size_t)cc * 8) = o;
+        }
+    }
+}
+
+// GEGLU: out[m][f] = x[m][f] * gelu(x[m][F + f])   (diffusers GEGLU: hidden, gate = proj(x).chunk(2); hidden * gelu(gate))
+__global__ __launch_bounds__(256) void k_geglu(long long M, int F, const __bf16* __restrict__ x, __bf16* __restrict__ out) {
+    const int F8 = F / 8;
+    const long long n = M * F8;
+    for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long long)gridDim.x * 256) {
+        long long m = i / F8; int fc = (int)(i % F8);
+        bf16x8 a = *reinterpret_cast<const bf16x8*>(x + m * 2 * F + (size_t)fc * 8);
+        bf16x8 g = *reinterpret_cast<const bf16x8*>(x + m * 2 * F + F + (size_t)fc * 8);
+        bf16x8 o;
+#pragma unroll
+        for (int e = 0; e < 8; e++) {
+            float gv = (float)g[e];
+            o[e] = (__bf16)((float)a[e] * 0.5f * gv * (1.f + erff(gv * 0.70710678118654752f)));
+        }
+        *reinterpret_cast<bf16x8*>(out + m * F + (size_t)fc * 8) = o;
+    }
+}
+
+// Row softmax of fp32 scores (one wave per row, n <= 8192): P = softmax(scale * S) stored as bf16 (row stride ldp)
+__global__ __launch_bounds__(256) void k_softmax_rows(int rows, int n, float scale, const float* __restrict__ S, long long lds_,
+                                                      __bf16* __restrict__ P, long long ldp) {
+    const int row = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+    if (row >= rows) return;
+    const float* s = S + (size_t)row * lds_;
+    float mx = -3.0e38f;
+    for (int j = lane; j < n; j += 64) mx = fmaxf(mx, s[j] * scale);
+    for (int o = 32; o > 0; o >>= 1) mx = fmaxf(mx, __shfl_xor(mx, o));
+    float sum = 0.f;
+    for (int j = lane; j < n; j += 64) sum += __expf(s[j] * scale - mx);
+    sum = dwg_wave_sum_all(sum);
+    const float inv = 1.f / sum;
+    __bf16* p = P + (size_t)row * ldp;
+    for (int j = lane; j < n; j += 64) p[j] = (__bf16)(__expf(s[j] * scale - mx) * inv);
+}
+
+// dS = scale * P * (dP - sum_j dP_j P_j)   (P bf16, dP fp32) -> bf16
+__global__ __launch_bounds__(256) void k_softmax_rows_bwd(int rows, int n, float scale, const __bf16* __restrict__ P, long long ldp,
+                                                          const float* __restrict__ dP, long long lddp, __bf16* __restrict__ dS,
+                                                          long long ldds) {
+    const int row = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+    if (row >= rows) return;
+    const __bf16* p = P + (size_t)row * ldp; const float* dp = dP + (size_t)row * lddp;
+    float dot = 0.f;
+    for (int j = lane; j < n; j += 64) dot += (float)p[j] * dp[j];
+    dot = dwg_wave_sum_all(dot);
+    __bf16* ds = dS + (size_t)row * ldds;
+    for (int j = lane; j < n; j += 64) ds[j] = (__bf16)(scale * (float)p[j] * (dp[j] - dot));
+}
+
+static int gn_geometry(int HW, int C, int G, int* pix_per_block, int* chunks, size_t* lds) {
+    if (C % 8 || G <= 0 || G > 64 || C % G) return DWG_E_ARG;
+    int ppb = HW / 64; if (ppb < 16) ppb = 16; if (ppb > 1024) ppb = 1024;
+    *pix_per_block = ppb; *chunks = dwg_cdiv(HW, ppb);
+    *lds = (size_t)256 * 8 * 2 * sizeof(float);
+    return DWG_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+int dwg_groupnorm_forward(int32_t B, int32_t HW, int32_t C, int32_t G, const void* x, const float* gamma, const float* beta,
+                          float eps, int32_t fuse_silu, void* y, float* stats, dwg_stream_t stream_) {
+    if (B <= 0 || HW <= 0 || !x || !gamma || !beta || !y || !stats) return DWG_E_ARG;
+    int ppb, chunks; size_t lds;
+    int rc = gn_geometry(HW, C, G, &ppb, &chunks, &lds);
+    if (rc) return rc;
+    hipStream_t stream = (hipStream_t)stream_;
+    if (hipMemsetAsync(stats, 0, (size_t)B * G * 2 * sizeof(float), stream) != hipSuccess) return DWG_E_LAUNCH;
+    DWG_LAUNCH("gn_stats", (k_gn_reduce<false>), dim3(chunks, B), dim3(256), lds, stream, HW, C, G, ppb, (const __bf16*)x,
+               (const __bf16*)nullptr, (const float*)nullptr, gamma, beta, 0, eps, stats);
+    DWG_LAUNCH("gn_apply", (k_gn_apply<false>), dim3(chunks, B), dim3(256), 0, stream, HW, C, G, ppb, (const __bf16*)x,
+               (const __bf16*)nullptr, (const float*)stats, (const float*)nullptr, gamma, beta, fuse_silu, eps, (__bf16*)y);
+    DWG_RETURN_IF_LAUNCH_FAILED();
+    return DWG_OK;
+}
+
+int dwg_groupnorm_backward(int32_t B, int32_t HW, int32_t C, int32_t G, const void* x, const void* dy, const float* stats,
+                           const float* gamma, const float* beta, float eps, int32_t fuse_silu, void* dx, float* scratch,
+                           dwg_stream_t stream_) {
+    if (B <= 0 || HW <= 0 || !x || !dy || !stats || !gamma || !beta || !dx || !scratch) return DWG_E_ARG;
+    int ppb, chunks; size_t lds;
+    int rc = gn_geometry(HW, C, G, &ppb, &chunks, &lds);
+    if (rc) return rc;
+    hipStream_t stream = (hipStream_t)stream_;
+    if (hipMemsetAsync(scratch, 0, (size_t)B * G * 2 * sizeof(float), stream) != hipSuccess) return DWG_E_LAUNCH;
+    DWG_LAUNCH("gn_bwd_stats", (k_gn_reduce<true>), dim3(chunks, B), dim3(256), lds, stream, HW, C, G, ppb, (const __bf16*)x,
+               (const __bf16*)dy, stats, gamma, beta, fuse_silu, eps, scratch);
+    DWG_LAUNCH("gn_bwd_apply", (k_gn_apply<true>), dim3(chunks, B), dim3(256), 0, stream, HW, C, G, ppb, (const __bf16*)x,
+               (const __bf16*)dy, stats, (const float*)scratch, gamma, beta, fuse_silu, eps, (__bf16*)dx);
+    DWG_RETURN_IF_LAUNCH_FAILED();
+    return DWG_OK;
+}
+
+int dwg_layernorm_forward(int32_t M, int32_t C, const void* x, const float* gamma, const float* beta, float eps, void* y,
+                          dwg_stream_t stream) {
+    if (M < 0 || C <= 0 || C % 8 || C > 2048 || !x || !gamma || !beta || !y) return DWG_E_ARG;
+    if (M == 0) return DWG_OK;
+    DWG_LAUNCH("layernorm", k_layernorm, dim3(dwg_cdiv(M, 4)), dim3(256), 0, (hipStream_t)stream, M, C, (const __bf16*)x, gamma,
+               beta, eps, (__bf16*)y);
+    DWG_RETURN_IF_LAUNCH_FAILED();
+    return DWG_OK;
+}
+
+int dwg_geglu_forward(int64_t M, int32_t F, const void* x, void* out, dwg_stream_t stream) {
+    if (M < 0 || F <= 0 || F % 8 || !x || !out) return DWG_E_ARG;
+    if (M == 0) return DWG_OK;
+    long long n = M * (F / 8);
+    int blocks = (int)((n + 255) / 256); if (blocks > 4096) blocks = 4096;
+    DWG_LAUNCH("geglu", k_geglu, dim3(blocks), dim3(256), 0, (hipStream_t)stream, (long long)M, F, (const __bf16*)x, (__bf16*)out);
+    DWG_RETURN_IF_LAUNCH_FAILED();
+    return DWG_OK;
+}
+
+int dwg_softmax_rows_forward(int32_t rows, int32_t n, float scale, const float* S, int64_t lds, void* P, int64_t ldp,
+                             dwg_stream_t stream) {
+    if (rows < 0 || n <= 0 || !S || !P) return DWG_E_ARG;
+    if (rows == 0) return DWG_OK;
+    DWG_LAUNCH("softmax_rows", k_softmax_rows, dim3(dwg_cdiv(rows, 4)), dim3(256), 0, (hipStream_t)stream, rows, n, scale, S,
+               (long long)lds, (__bf16*)P, (long long)ldp);
+    DWG_RETURN_IF_LAUNCH_FAILED();
+    return DWG_OK;
+}
+
+int dwg_softmax_rows_backward(int32_t rows, int32_t n, float scale, const void* P, int64_t ldp, const float* dP, int64_t lddp,
+                              void* dS, int64_t ldds, dwg_stream_t stream) {
+    if (rows < 0 || n <= 0 || !P || !dP || !dS) return DWG_E_ARG;
+    if (rows == 0) return DWG_OK;
+    DWG_LAUNCH("softmax_rows_bwd", k_softmax_rows_bwd, dim3(dwg_cdiv(rows, 4)), dim3(256), 0, (hipStream_t)stream, rows, n, scale,
+               (const __bf16*)P, (long long)ldp, dP, (long long)lddp, (__bf16*)dS, (long long)ldds);
+    DWG_RETURN_IF_LAUNCH_FAILED();
+    return DWG_OK;
+}
+
+}  // extern "C"

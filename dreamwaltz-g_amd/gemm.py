@@ -27,6 +27,8 @@ class GemmDesc(ctypes.Structure):
         ("conv_win", ctypes.c_int32), ("conv_hout", ctypes.c_int32), ("conv_wout", ctypes.c_int32),
         ("conv_kh", ctypes.c_int32), ("conv_kw", ctypes.c_int32), ("conv_stride", ctypes.c_int32),
         ("conv_pad_t", ctypes.c_int32), ("conv_pad_l", ctypes.c_int32), ("conv_in_dilation", ctypes.c_int32),
+        ("conv_in_upsample", ctypes.c_int32), ("A2", ctypes.c_void_p), ("conv_cin1", ctypes.c_int32),
+        ("bias_row_div", ctypes.c_int32),
         ("name", ctypes.c_char_p),
     ]
 
@@ -45,7 +47,7 @@ def _stream(t):
 
 def gemm_raw(A, B, C, M, N, K, a_strides, b_strides, ldc, bias=None, residual=None, ldr=0, act=None, alpha=1.0,
              batch=(1, 1), a_batch=(0, 0), b_batch=(0, 0), c_batch=(0, 0), r_batch=(0, 0), bias_per_row=False, splitk=1,
-             accumulate=False, conv=None, name=None):
+             accumulate=False, conv=None, name=None, conv_upsample=1, A2=None, cin1=0, bias_row_div=0, run=True):
     """Thin descriptor builder; all strides in elements.  A/B/C/bias/residual are CUDA tensors (used for their pointers)."""
     if not A.is_cuda:
         raise RuntimeError("dreamwaltz_g_amd GEMM runs on the GPU only (HIP kernels)")
@@ -75,9 +77,22 @@ def gemm_raw(A, B, C, M, N, K, a_strides, b_strides, ldc, bias=None, residual=No
         d.conv_enabled = 1
         (d.conv_cin, d.conv_hin, d.conv_win, d.conv_hout, d.conv_wout, d.conv_kh, d.conv_kw, d.conv_stride, d.conv_pad_t,
          d.conv_pad_l, d.conv_in_dilation) = conv
+    d.conv_in_upsample = conv_upsample
+    if A2 is not None:
+        d.A2 = A2.data_ptr(); d.conv_cin1 = cin1
+    d.bias_row_div = bias_row_div
     d.name = name.encode() if name else None
+    if not run:
+        return d
     _lib.check(_lib.lib().dwg_gemm(ctypes.byref(d), _stream(A)), "dwg_gemm")
     return C
+
+
+def run_desc(d, stream):
+    """Launch a prebuilt descriptor (static plans: no per-step Python work besides this call)."""
+    rc = _lib.lib().dwg_gemm(ctypes.byref(d), stream)
+    if rc != 0:
+        raise RuntimeError("dwg_gemm failed with DWG error %d" % rc)
 
 
 def linear(x, w, bias=None, act=None, out_dtype=None, residual=None, out=None, name=None):

@@ -54,6 +54,10 @@ typedef struct dwg_gemm_desc {
     int32_t accumulate;       /* C += result (f32 C only) */
     int32_t conv_enabled, conv_cin, conv_hin, conv_win, conv_hout, conv_wout, conv_kh, conv_kw, conv_stride, conv_pad_t,
         conv_pad_l, conv_in_dilation;
+    int32_t conv_in_upsample; /* 2: the conv reads a virtual nearest-neighbour 2x upsampled input (Upsample2D + conv fused) */
+    const void* A2;           /* optional second NHWC source: channels [conv_cin1, conv_cin) (torch.cat([h, skip], 1) fused) */
+    int32_t conv_cin1;
+    int32_t bias_row_div;     /* > 0: bias is [M / bias_row_div, N] and row m uses bias[m / bias_row_div] (per-image channel bias) */
     const char* name;         /* optional label for dwg_prof */
 } dwg_gemm_desc;
 

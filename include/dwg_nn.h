@@ -1,0 +1,51 @@
+/*
+ * include/dwg_nn.h -- C-ABI of the non-GEMM layers of the SD-1.5 denoiser / VAE encoder (boundary B4):
+ * GroupNorm(+SiLU) forward / input-gradient, LayerNorm, GEGLU, fused multi-head attention, row softmax fwd/bwd.
+ * Reference seams they serve: ControlNetScoreDistillation._predict (/root/reference/core/guidance/controlnet.py:83-114)
+ * and AutoEncoderSD.encode_images with autograd (/root/reference/core/guidance/vae.py:34-40, basic.py:368-372); the
+ * reference reaches this math through diffusers -> torch.nn.functional, so the signatures below are this library's own.
+ * Activations are NHWC / token-major bf16 (void* = __bf16 device pointers); affine parameters and statistics are fp32.
+ */
+#ifndef DWG_NN_H
+#define DWG_NN_H
+#include "dwg_types.h"
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* y = [silu]( (x - mean_g) * rstd_g * gamma + beta ), x/y [B, HW, C] bf16, G groups over channels (C % 8 == 0, C % G == 0,
+ * G <= 64).  stats [B, G, 2] fp32 receives (sum x, sum x^2) per group -- keep it for dwg_groupnorm_backward. */
+int dwg_groupnorm_forward(int32_t B, int32_t HW, int32_t C, int32_t G, const void* x, const float* gamma, const float* beta,
+                          float eps, int32_t fuse_silu, void* y, float* stats, dwg_stream_t stream);
+
+/* dx of the above w.r.t. x (affine parameters are frozen: basic.py:347-352). dy/dx bf16 [B,HW,C]; scratch [B,G,2] fp32. */
+int dwg_groupnorm_backward(int32_t B, int32_t HW, int32_t C, int32_t G, const void* x, const void* dy, const float* stats,
+                           const float* gamma, const float* beta, float eps, int32_t fuse_silu, void* dx, float* scratch,
+                           dwg_stream_t stream);
+
+/* LayerNorm over the last dimension: x/y [M, C] bf16, C % 8 == 0, C <= 2048. */
+int dwg_layernorm_forward(int32_t M, int32_t C, const void* x, const float* gamma, const float* beta, float eps, void* y,
+                          dwg_stream_t stream);
+
+/* GEGLU: out[m, f] = x[m, f] * gelu(x[m, F + f]) (exact erf), x [M, 2F] bf16 -> out [M, F] bf16, F % 8 == 0. */
+int dwg_geglu_forward(int64_t M, int32_t F, const void* x, void* out, dwg_stream_t stream);
+
+/* O = softmax(scale * Q K^T) V per (image, head).  Q [B, Nq, H*d], K/V [B, Nk, H*d], O [B, Nq, H*d] bf16 addressed with
+ * row strides ld* and per-image strides b* (elements, multiples of 8); head h occupies columns [h*d, (h+1)*d).
+ * d % 8 == 0, d <= 160. */
+int dwg_attention_forward(int32_t B, int32_t H, int32_t Nq, int32_t Nk, int32_t d, const void* Q, int64_t ldq, int64_t bq,
+                          const void* K, int64_t ldk, int64_t bk, const void* V, int64_t ldv, int64_t bv, void* O, int64_t ldo,
+                          int64_t bo, float scale, dwg_stream_t stream);
+
+/* P = softmax(scale * S) row-wise: S fp32 [rows, n] (row stride lds) -> P bf16 (row stride ldp).  Used for the single-head
+ * d = 512 attention of the VAE encoder mid block, whose backward needs P. */
+int dwg_softmax_rows_forward(int32_t rows, int32_t n, float scale, const float* S, int64_t lds, void* P, int64_t ldp,
+                             dwg_stream_t stream);
+/* dS = scale * P * (dP - rowsum(dP * P)): P bf16, dP fp32 -> dS bf16. */
+int dwg_softmax_rows_backward(int32_t rows, int32_t n, float scale, const void* P, int64_t ldp, const float* dP, int64_t lddp,
+                              void* dS, int64_t ldds, dwg_stream_t stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif
