@@ -36,7 +36,8 @@ struct GemmP {
     long long bA1, bA2, bB1, bB2, bC1, bC2, bR1, bR2;
     int act; float alpha;
     int out_bf16, res_bf16, bias_per_row, splitk, accumulate;
-    int bias_row_div;   // > 0: bias index = (row / bias_row_div) * N + col  (per-image channel bias: conv bias + time embedding)
+    int bias_row_div;   // > 0: bias index = (row / bias_row_div) * bias_ld + col  (per-image channel bias: conv bias + time embedding)
+    long long bias_ld;
     ConvP conv;
 };
 
@@ -272,7 +273,7 @@ __global__ __launch_bounds__(256) void k_gemm(GemmP p) {
                 float v = acc[i][j][r] * p.alpha;
                 const long long ci = coff + (long long)row * p.ldc + col;
                 if (p.splitk > 1) { atomicAdd(reinterpret_cast<float*>(p.C) + ci, v); continue; }
-                if (p.bias) v += reinterpret_cast<const float*>(p.bias)[p.bias_row_div > 0 ? (long long)(row / p.bias_row_div) * p.N + col
+                if (p.bias) v += reinterpret_cast<const float*>(p.bias)[p.bias_row_div > 0 ? (long long)(row / p.bias_row_div) * p.bias_ld + col
                                                                                          : (p.bias_per_row ? row : col)];
                 v = apply_act(v, p.act);
                 if (p.residual) {
@@ -347,7 +348,7 @@ int dwg_gemm(const dwg_gemm_desc* d, dwg_stream_t stream_) {
     p.conv.pad_t = d->conv_pad_t; p.conv.pad_l = d->conv_pad_l; p.conv.dil = d->conv_in_dilation > 1 ? d->conv_in_dilation : 1;
     p.conv.up = d->conv_in_upsample > 1 ? d->conv_in_upsample : 1;
     p.conv.A2 = d->A2; p.conv.cin1 = d->A2 ? d->conv_cin1 : d->conv_cin;
-    p.bias_row_div = d->bias_row_div;
+    p.bias_row_div = d->bias_row_div; p.bias_ld = d->bias_ld > 0 ? d->bias_ld : d->N;
     const int batch = d->batch1 * d->batch2;
     hipStream_t stream = (hipStream_t)stream_;
     const char* name = d->name ? d->name : (d->conv_enabled ? "conv_igemm" : "gemm");

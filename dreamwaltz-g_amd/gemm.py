@@ -28,7 +28,7 @@ class GemmDesc(ctypes.Structure):
         ("conv_kh", ctypes.c_int32), ("conv_kw", ctypes.c_int32), ("conv_stride", ctypes.c_int32),
         ("conv_pad_t", ctypes.c_int32), ("conv_pad_l", ctypes.c_int32), ("conv_in_dilation", ctypes.c_int32),
         ("conv_in_upsample", ctypes.c_int32), ("A2", ctypes.c_void_p), ("conv_cin1", ctypes.c_int32),
-        ("bias_row_div", ctypes.c_int32),
+        ("bias_row_div", ctypes.c_int32), ("bias_ld", ctypes.c_int64),
         ("name", ctypes.c_char_p),
     ]
 
@@ -47,7 +47,7 @@ def _stream(t):
 
 def gemm_raw(A, B, C, M, N, K, a_strides, b_strides, ldc, bias=None, residual=None, ldr=0, act=None, alpha=1.0,
              batch=(1, 1), a_batch=(0, 0), b_batch=(0, 0), c_batch=(0, 0), r_batch=(0, 0), bias_per_row=False, splitk=1,
-             accumulate=False, conv=None, name=None, conv_upsample=1, A2=None, cin1=0, bias_row_div=0, run=True):
+             accumulate=False, conv=None, name=None, conv_upsample=1, A2=None, cin1=0, bias_row_div=0, bias_ld=0, run=True):
     """Thin descriptor builder; all strides in elements.  A/B/C/bias/residual are CUDA tensors (used for their pointers)."""
     if not A.is_cuda:
         raise RuntimeError("dreamwaltz_g_amd GEMM runs on the GPU only (HIP kernels)")
@@ -81,6 +81,7 @@ def gemm_raw(A, B, C, M, N, K, a_strides, b_strides, ldc, bias=None, residual=No
     if A2 is not None:
         d.A2 = A2.data_ptr(); d.conv_cin1 = cin1
     d.bias_row_div = bias_row_div
+    d.bias_ld = bias_ld
     d.name = name.encode() if name else None
     if not run:
         return d

@@ -1,0 +1,666 @@
+"""SD-1.5 UNet + ControlNet + VAE-encoder graphs on the HIP kernels (boundary B4).
+
+The reference obtains these networks from `diffusers` (UNet2DConditionModel, ControlNetModel, AutoencoderKL.encoder; call
+sites /root/reference/core/guidance/controlnet.py:98-114, vae.py:34-40, basic.py:147,176,208).  diffusers is a third-party
+package that is not installed here; the layer graph below follows its published SD-1.5 architecture [3P-memory, SURVEY G9]
+and uses diffusers' state_dict key names, so a real checkpoint converts with `convert_state_dict()`.
+
+Execution model: every network is compiled ONCE into a static plan -- a flat list of pre-built C-ABI calls over
+pre-allocated NHWC bf16 buffers (shapes never change during SDS) -- so a step is a tight loop of library calls on one HIP
+stream with no allocation, no shape logic and no host synchronisation; the plan is hipGraph-capturable as is.
+"""
+import ctypes
+import math
+from collections import OrderedDict
+from dataclasses import dataclass
+from typing import Dict, List, Optional, Tuple
+
+import torch
+
+from . import _lib, gemm
+
+BF16 = torch.bfloat16
+
+
+# ----------------------------------------------------------------------------------------------------------------------
+# configuration + parameter inventory (diffusers key names / shapes)
+# ----------------------------------------------------------------------------------------------------------------------
+@dataclass
+class UNetConfig:
+    in_channels: int = 4
+    out_channels: int = 4
+    block_out_channels: Tuple[int, ...] = (320, 640, 1280, 1280)
+    layers_per_block: int = 2
+    heads: int = 8
+    cross_dim: int = 768
+    groups: int = 32
+    attn_blocks: Tuple[bool, ...] = (True, True, True, False)
+    cond_channels: Tuple[int, ...] = (16, 32, 96, 256)      # ControlNet conditioning embedding
+    cond_in_channels: int = 3
+
+    @property
+    def temb_dim(self):
+        return self.block_out_channels[0] * 4
+
+
+@dataclass
+class VAEConfig:
+    in_channels: int = 3
+    block_out_channels: Tuple[int, ...] = (128, 256, 512, 512)
+    layers_per_block: int = 2
+    latent_channels: int = 4
+    groups: int = 32
+    scaling_factor: float = 0.18215
+
+
+def _resnet_shapes(sh, pre, cin, cout, temb):
+    sh[pre + ".norm1.weight"] = (cin,); sh[pre + ".norm1.bias"] = (cin,)
+    sh[pre + ".conv1.weight"] = (cout, cin, 3, 3); sh[pre + ".conv1.bias"] = (cout,)
+    if temb:
+        sh[pre + ".time_emb_proj.weight"] = (cout, temb); sh[pre + ".time_emb_proj.bias"] = (cout,)
+    sh[pre + ".norm2.weight"] = (cout,); sh[pre + ".norm2.bias"] = (cout,)
+    sh[pre + ".conv2.weight"] = (cout, cout, 3, 3); sh[pre + ".conv2.bias"] = (cout,)
+    if cin != cout:
+        sh[pre + ".conv_shortcut.weight"] = (cout, cin, 1, 1); sh[pre + ".conv_shortcut.bias"] = (cout,)
+
+
+def _transformer_shapes(sh, pre, c, cross):
+    sh[pre + ".norm.weight"] = (c,); sh[pre + ".norm.bias"] = (c,)
+    sh[pre + ".proj_in.weight"] = (c, c, 1, 1); sh[pre + ".proj_in.bias"] = (c,)
+    t = pre + ".transformer_blocks.0"
+    for n in ("norm1", "norm2", "norm3"):
+        sh["%s.%s.weight" % (t, n)] = (c,); sh["%s.%s.bias" % (t, n)] = (c,)
+    for a, kd in (("attn1", c), ("attn2", cross)):
+        sh["%s.%s.to_q.weight" % (t, a)] = (c, c)
+        sh["%s.%s.to_k.weight" % (t, a)] = (c, kd)
+        sh["%s.%s.to_v.weight" % (t, a)] = (c, kd)
+        sh["%s.%s.to_out.0.weight" % (t, a)] = (c, c); sh["%s.%s.to_out.0.bias" % (t, a)] = (c,)
+    sh[t + ".ff.net.0.proj.weight"] = (8 * c, c); sh[t + ".ff.net.0.proj.bias"] = (8 * c,)
+    sh[t + ".ff.net.2.weight"] = (c, 4 * c); sh[t + ".ff.net.2.bias"] = (c,)
+    sh[pre + ".proj_out.weight"] = (c, c, 1, 1); sh[pre + ".proj_out.bias"] = (c,)
+
+
+def _encoder_shapes(sh, cfg: UNetConfig):
+    """conv_in, time embedding, down blocks, mid block: shared by UNet and ControlNet."""
+    boc = cfg.block_out_channels
+    sh["conv_in.weight"] = (boc[0], cfg.in_channels, 3, 3); sh["conv_in.bias"] = (boc[0],)
+    sh["time_embedding.linear_1.weight"] = (cfg.temb_dim, boc[0]); sh["time_embedding.linear_1.bias"] = (cfg.temb_dim,)
+    sh["time_embedding.linear_2.weight"] = (cfg.temb_dim, cfg.temb_dim); sh["time_embedding.linear_2.bias"] = (cfg.temb_dim,)
+    cin = boc[0]
+    for i, cout in enumerate(boc):
+        for j in range(cfg.layers_per_block):
+            _resnet_shapes(sh, "down_blocks.%d.resnets.%d" % (i, j), cin, cout, cfg.temb_dim)
+            if cfg.attn_blocks[i]:
+                _transformer_shapes(sh, "down_blocks.%d.attentions.%d" % (i, j), cout, cfg.cross_dim)
+            cin = cout
+        if i != len(boc) - 1:
+            sh["down_blocks.%d.downsamplers.0.conv.weight" % i] = (cout, cout, 3, 3)
+            sh["down_blocks.%d.downsamplers.0.conv.bias" % i] = (cout,)
+    c = boc[-1]
+    _resnet_shapes(sh, "mid_block.resnets.0", c, c, cfg.temb_dim)
+    _transformer_shapes(sh, "mid_block.attentions.0", c, cfg.cross_dim)
+    _resnet_shapes(sh, "mid_block.resnets.1", c, c, cfg.temb_dim)
+
+
+def _skip_channels(cfg: UNetConfig) -> List[int]:
+    boc = cfg.block_out_channels
+    ch = [boc[0]]
+    for i, cout in enumerate(boc):
+        ch += [cout] * cfg.layers_per_block
+        if i != len(boc) - 1:
+            ch.append(cout)
+    return ch
+
+
+def unet_param_shapes(cfg: UNetConfig) -> "OrderedDict[str, tuple]":
+    sh = OrderedDict()
+    _encoder_shapes(sh, cfg)
+    boc = cfg.block_out_channels
+    skips = _skip_channels(cfg)
+    rev = list(reversed(boc))
+    prev = rev[0]
+    for i, cout in enumerate(rev):
+        for j in range(cfg.layers_per_block + 1):
+            skip = skips.pop()
+            _resnet_shapes(sh, "up_blocks.%d.resnets.%d" % (i, j), prev + skip, cout, cfg.temb_dim)
+            if list(reversed(cfg.attn_blocks))[i]:
+                _transformer_shapes(sh, "up_blocks.%d.attentions.%d" % (i, j), cout, cfg.cross_dim)
+            prev = cout
+        if i != len(rev) - 1:
+            sh["up_blocks.%d.upsamplers.0.conv.weight" % i] = (cout, cout, 3, 3)
+            sh["up_blocks.%d.upsamplers.0.conv.bias" % i] = (cout,)
+    sh["conv_norm_out.weight"] = (boc[0],); sh["conv_norm_out.bias"] = (boc[0],)
+    sh["conv_out.weight"] = (cfg.out_channels, boc[0], 3, 3); sh["conv_out.bias"] = (cfg.out_channels,)
+    return sh
+
+
+def controlnet_param_shapes(cfg: UNetConfig) -> "OrderedDict[str, tuple]":
+    sh = OrderedDict()
+    _encoder_shapes(sh, cfg)
+    cc = cfg.cond_channels
+    e = "controlnet_cond_embedding"
+    sh[e + ".conv_in.weight"] = (cc[0], cfg.cond_in_channels, 3, 3); sh[e + ".conv_in.bias"] = (cc[0],)
+    k = 0
+    for i in range(len(cc) - 1):
+        sh["%s.blocks.%d.weight" % (e, k)] = (cc[i], cc[i], 3, 3); sh["%s.blocks.%d.bias" % (e, k)] = (cc[i],); k += 1
+        sh["%s.blocks.%d.weight" % (e, k)] = (cc[i + 1], cc[i], 3, 3); sh["%s.blocks.%d.bias" % (e, k)] = (cc[i + 1],); k += 1
+    sh[e + ".conv_out.weight"] = (cfg.block_out_channels[0], cc[-1], 3, 3); sh[e + ".conv_out.bias"] = (cfg.block_out_channels[0],)
+    for k, c in enumerate(_skip_channels(cfg)):
+        sh["controlnet_down_blocks.%d.weight" % k] = (c, c, 1, 1); sh["controlnet_down_blocks.%d.bias" % k] = (c,)
+    c = cfg.block_out_channels[-1]
+    sh["controlnet_mid_block.weight"] = (c, c, 1, 1); sh["controlnet_mid_block.bias"] = (c,)
+    return sh
+
+
+def vae_encoder_param_shapes(cfg: VAEConfig) -> "OrderedDict[str, tuple]":
+    sh = OrderedDict()
+    boc = cfg.block_out_channels
+    sh["encoder.conv_in.weight"] = (boc[0], cfg.in_channels, 3, 3); sh["encoder.conv_in.bias"] = (boc[0],)
+    cin = boc[0]
+    for i, cout in enumerate(boc):
+        for j in range(cfg.layers_per_block):
+            _resnet_shapes(sh, "encoder.down_blocks.%d.resnets.%d" % (i, j), cin, cout, 0)
+            cin = cout
+        if i != len(boc) - 1:
+            sh["encoder.down_blocks.%d.downsamplers.0.conv.weight" % i] = (cout, cout, 3, 3)
+            sh["encoder.down_blocks.%d.downsamplers.0.conv.bias" % i] = (cout,)
+    c = boc[-1]
+    _resnet_shapes(sh, "encoder.mid_block.resnets.0", c, c, 0)
+    a = "encoder.mid_block.attentions.0"
+    sh[a + ".group_norm.weight"] = (c,); sh[a + ".group_norm.bias"] = (c,)
+    for n in ("to_q", "to_k", "to_v", "to_out.0"):
+        sh["%s.%s.weight" % (a, n)] = (c, c); sh["%s.%s.bias" % (a, n)] = (c,)
+    _resnet_shapes(sh, "encoder.mid_block.resnets.1", c, c, 0)
+    sh["encoder.conv_norm_out.weight"] = (c,); sh["encoder.conv_norm_out.bias"] = (c,)
+    sh["encoder.conv_out.weight"] = (2 * cfg.latent_channels, c, 3, 3); sh["encoder.conv_out.bias"] = (2 * cfg.latent_channels,)
+    sh["quant_conv.weight"] = (2 * cfg.latent_channels, 2 * cfg.latent_channels, 1, 1)
+    sh["quant_conv.bias"] = (2 * cfg.latent_channels,)
+    return sh
+
+
+def random_state_dict(shapes, seed=0, gain=1.0) -> Dict[str, torch.Tensor]:
+    """Seeded random-init weights of the given architecture (no checkpoints on the GPU box: BASELINE `data: synthetic`)."""
+    g = torch.Generator().manual_seed(seed)
+    sd = OrderedDict()
+    for name, shp in shapes.items():
+        if "norm" in name and name.endswith("weight") and len(shp) == 1:
+            sd[name] = 1.0 + 0.1 * torch.randn(shp, generator=g)
+        elif name.endswith("bias"):
+            sd[name] = 0.05 * torch.randn(shp, generator=g)
+        else:
+            fan_in = 1
+            for s in shp[1:]:
+                fan_in *= s
+            sd[name] = torch.randn(shp, generator=g) * (gain / math.sqrt(fan_in))
+    return sd
+
+
+# ----------------------------------------------------------------------------------------------------------------------
+# plan machinery
+# ----------------------------------------------------------------------------------------------------------------------
+def _pad8(c):
+    return (c + 7) // 8 * 8
+
+
+class Plan:
+    """Flat list of prebuilt library calls; run() is the only per-step Python work."""
+
+    def __init__(self, device):
+        self.device = device
+        self.ops = []
+        self.keep = []          # descriptors / tensors kept alive
+        self._lib = _lib.lib()
+
+    def buf(self, *shape, dtype=BF16, zero=False):
+        t = (torch.zeros if zero else torch.empty)(*shape, device=self.device, dtype=dtype)
+        self.keep.append(t)
+        return t
+
+    def add_gemm(self, desc):
+        self.keep.append(desc)
+        fn, ref = self._lib.dwg_gemm, ctypes.byref(desc)
+        self.ops.append(lambda s, fn=fn, ref=ref: fn(ref, s))
+
+    def add_call(self, fn, *args):
+        self.ops.append(lambda s, fn=fn, args=args: fn(*args, s))
+
+    def add_py(self, f):
+        self.ops.append(lambda s, f=f: (f(), 0)[1])
+
+    def run(self):
+        s = ctypes.c_void_p(torch.cuda.current_stream(self.device).cuda_stream)
+        for op in self.ops:
+            rc = op(s)
+            if rc:
+                raise RuntimeError("plan op failed with DWG error %s" % rc)
+
+
+class Weights:
+    """Kernel-layout copies of a diffusers-format state_dict: conv [Cout,KH,KW,Cin(pad 8)] bf16, linear [out,in] bf16,
+    biases / norm affine fp32."""
+
+    def __init__(self, sd: Dict[str, torch.Tensor], device):
+        self.device = device
+        self.sd = sd
+        self.cache = {}
+
+    def conv(self, name, flip_for_dgrad=False):
+        key = (name, flip_for_dgrad)
+        if key not in self.cache:
+            w = self.sd[name + ".weight"].float()
+            if flip_for_dgrad:   # input-gradient of a conv = conv with spatially flipped, channel-transposed weights
+                w = w.flip(2, 3).permute(1, 0, 2, 3)
+            cout, cin = w.shape[0], w.shape[1]
+            wp = torch.zeros(_pad8(cout) if flip_for_dgrad else cout, w.shape[2], w.shape[3], _pad8(cin))
+            wp[:cout, :, :, :cin] = w.permute(0, 2, 3, 1)
+            self.cache[key] = wp.to(self.device, BF16).contiguous()
+        return self.cache[key]
+
+    def lin(self, *names):
+        key = ("lin",) + names
+        if key not in self.cache:
+            self.cache[key] = torch.cat([self.sd[n + ".weight"].float().reshape(self.sd[n + ".weight"].shape[0], -1)
+                                         for n in names], 0).to(self.device, BF16).contiguous()
+        return self.cache[key]
+
+    def f32(self, name):
+        if name not in self.cache:
+            self.cache[name] = self.sd[name].float().to(self.device).contiguous()
+        return self.cache[name]
+
+    def bias_cat(self, *names):
+        key = ("bias",) + names
+        if key not in self.cache:
+            self.cache[key] = torch.cat([self.sd[n].float() for n in names], 0).to(self.device).contiguous()
+        return self.cache[key]
+
+
+class Builder:
+    def __init__(self, plan: Plan, w: Weights, groups=32):
+        self.p, self.w, self.groups = plan, w, groups
+        self.L = _lib.lib()
+
+    # -- contractions -------------------------------------------------------------------------------------------
+    def conv(self, x, name, stride=1, pad=1, act=None, residual=None, upsample=1, bias_img=None, out_dtype=BF16, out_hw=None,
+             pad_tl=None, r_batch_bcast=False, weight=None, bias=True, in_dilation=1, tag=None):
+        """x [B,H,W,C] NHWC bf16. bias_img: (tensor [B, ld] fp32, ld) per-image channel bias replacing the conv bias."""
+        B, H, W, C = x.shape
+        wt = self.w.conv(name) if weight is None else weight
+        Cout, KH, KW, Cin = wt.shape
+        assert Cin == C, (name, Cin, C)
+        Hv, Wv = ((H - 1) * in_dilation + 1) * upsample, ((W - 1) * in_dilation + 1) * upsample
+        pt, pl = (pad, pad) if pad_tl is None else pad_tl
+        if out_hw is None:
+            Ho, Wo = (Hv + 2 * pad - KH) // stride + 1, (Wv + 2 * pad - KW) // stride + 1
+        else:
+            Ho, Wo = out_hw
+        y = self.p.buf(B, Ho, Wo, Cout, dtype=out_dtype)
+        b = None
+        if bias_img is None and bias:
+            b = self.w.f32(name + ".bias")
+            if b.numel() < Cout:   # dgrad weights are channel padded
+                b = None
+        conv = (C, H, W, Ho, Wo, KH, KW, stride, pt, pl, in_dilation)
+        K = KH * KW * C
+        if r_batch_bcast:   # residual is [1,Ho,Wo,Cout] broadcast over the batch: run as a batched GEMM, one image per batch
+            d = gemm.gemm_raw(x, wt, y, Ho * Wo, Cout, K, (0, 1), (K, 1), Cout, bias=b, residual=residual, ldr=Cout, act=act,
+                              batch=(B, 1), a_batch=(H * W * C, 0), c_batch=(Ho * Wo * Cout, 0), r_batch=(0, 0), conv=conv,
+                              conv_upsample=upsample, name=tag or "conv3x3" if KH == 3 else "conv1x1", run=False)
+        else:
+            kw = {}
+            if bias_img is not None:
+                kw = dict(bias=bias_img[0], bias_row_div=Ho * Wo, bias_ld=bias_img[1])
+            else:
+                kw = dict(bias=b)
+            d = gemm.gemm_raw(x, wt, y, B * Ho * Wo, Cout, K, (0, 1), (K, 1), Cout, residual=residual,
+                              ldr=Cout if residual is not None else 0, act=act, conv=conv, conv_upsample=upsample,
+                              name=tag or ("conv3x3" if KH == 3 else "conv1x1"), run=False, **kw)
+        self.p.add_gemm(d)
+        return y
+
+    def linear(self, x, wt, bias=None, act=None, residual=None, out_dtype=BF16, tag="linear"):
+        K = x.shape[-1]
+        M = x.numel() // K
+        N = wt.shape[0]
+        y = self.p.buf(*x.shape[:-1], N, dtype=out_dtype)
+        d = gemm.gemm_raw(x, wt, y, M, N, K, (K, 1), (wt.stride(0), 1), N, bias=bias, residual=residual,
+                          ldr=N if residual is not None else 0, act=act, name=tag, run=False)
+        self.p.add_gemm(d)
+        return y
+
+    # -- norms / activations ------------------------------------------------------------------------------------
+    def groupnorm(self, x, name, eps, silu, keep_stats=False):
+        B, C = x.shape[0], x.shape[-1]
+        HW = x.numel() // (B * C)
+        y = self.p.buf(*x.shape)
+        stats = self.p.buf(B, self.groups, 2, dtype=torch.float32)
+        pp = lambda t: ctypes.c_void_p(t.data_ptr())  # noqa: E731
+        self.p.add_call(self.L.dwg_groupnorm_forward, B, HW, C, self.groups, pp(x), pp(self.w.f32(name + ".weight")),
+                        pp(self.w.f32(name + ".bias")), eps, int(silu), pp(y), pp(stats))
+        return (y, stats) if keep_stats else y
+
+    def groupnorm_bwd(self, x, dy, stats, name, eps, silu):
+        B, C = x.shape[0], x.shape[-1]
+        HW = x.numel() // (B * C)
+        dx = self.p.buf(*x.shape)
+        scratch = self.p.buf(B, self.groups, 2, dtype=torch.float32)
+        pp = lambda t: ctypes.c_void_p(t.data_ptr())  # noqa: E731
+        self.p.add_call(self.L.dwg_groupnorm_backward, B, HW, C, self.groups, pp(x), pp(dy), pp(stats),
+                        pp(self.w.f32(name + ".weight")), pp(self.w.f32(name + ".bias")), eps, int(silu), pp(dx), pp(scratch))
+        return dx
+
+    def layernorm(self, x, name):
+        C = x.shape[-1]
+        M = x.numel() // C
+        y = self.p.buf(*x.shape)
+        pp = lambda t: ctypes.c_void_p(t.data_ptr())  # noqa: E731
+        self.p.add_call(self.L.dwg_layernorm_forward, M, C, pp(x), pp(self.w.f32(name + ".weight")), pp(self.w.f32(name + ".bias")),
+                        1e-5, pp(y))
+        return y
+
+    def geglu(self, x):
+        F2 = x.shape[-1]
+        M = x.numel() // F2
+        y = self.p.buf(*x.shape[:-1], F2 // 2)
+        pp = lambda t: ctypes.c_void_p(t.data_ptr())  # noqa: E731
+        self.p.add_call(self.L.dwg_geglu_forward, M, F2 // 2, pp(x), pp(y))
+        return y
+
+    def attention(self, q, k, v, heads):
+        B, Nq, HD = q.shape
+        Nk, d = k.shape[1], HD // heads
+        o = self.p.buf(B, Nq, HD)
+        pp = lambda t: ctypes.c_void_p(t.data_ptr())  # noqa: E731
+        self.p.add_call(self.L.dwg_attention_forward, B, heads, Nq, Nk, d, pp(q), q.stride(1), q.stride(0), pp(k), k.stride(1),
+                        k.stride(0), pp(v), v.stride(1), v.stride(0), pp(o), o.stride(1), o.stride(0), float(d) ** -0.5)
+        return o
+
+    def cat(self, a, b):
+        y = self.p.buf(*a.shape[:-1], a.shape[-1] + b.shape[-1])
+        self.p.add_py(lambda: torch.cat([a, b], dim=-1, out=y))
+        return y
+
+    def add(self, a, b):
+        y = self.p.buf(*a.shape)
+        self.p.add_py(lambda: torch.add(a, b, out=y))
+        return y
+
+    # -- blocks ----------------------------------------------------------------------------------------------------
+    def resnet(self, x, pre, temb_bias, eps=1e-5):
+        C = x.shape[-1]
+        n1 = self.groupnorm(x, pre + ".norm1", eps, True)
+        h1 = self.conv(n1, pre + ".conv1", bias_img=temb_bias)
+        n2 = self.groupnorm(h1, pre + ".norm2", eps, True)
+        Cout = h1.shape[-1]
+        sc = x if C == Cout else self.conv(x, pre + ".conv_shortcut", pad=0)
+        return self.conv(n2, pre + ".conv2", residual=sc)
+
+    def transformer(self, x, pre, text, heads):
+        B, H, W, C = x.shape
+        n = self.groupnorm(x, pre + ".norm", 1e-6, False)
+        h = self.conv(n, pre + ".proj_in", pad=0).view(B, H * W, C)
+        t = pre + ".transformer_blocks.0"
+        l1 = self.layernorm(h, t + ".norm1")
+        qkv = self.linear(l1, self.w.lin(t + ".attn1.to_q", t + ".attn1.to_k", t + ".attn1.to_v"), tag="attn_qkv")
+        a = self.attention(qkv[..., :C], qkv[..., C:2 * C], qkv[..., 2 * C:], heads)
+        h = self.linear(a, self.w.lin(t + ".attn1.to_out.0"), bias=self.w.f32(t + ".attn1.to_out.0.bias"), residual=h, tag="attn_out")
+        l2 = self.layernorm(h, t + ".norm2")
+        q = self.linear(l2, self.w.lin(t + ".attn2.to_q"), tag="attn_q")
+        kv = self.linear(text, self.w.lin(t + ".attn2.to_k", t + ".attn2.to_v"), tag="attn_kv")
+        a = self.attention(q, kv[..., :C], kv[..., C:], heads)
+        h = self.linear(a, self.w.lin(t + ".attn2.to_out.0"), bias=self.w.f32(t + ".attn2.to_out.0.bias"), residual=h, tag="attn_out")
+        l3 = self.layernorm(h, t + ".norm3")
+        f = self.linear(l3, self.w.lin(t + ".ff.net.0.proj"), bias=self.w.f32(t + ".ff.net.0.proj.bias"), tag="ff_in")
+        g = self.geglu(f)
+        h = self.linear(g, self.w.lin(t + ".ff.net.2"), bias=self.w.f32(t + ".ff.net.2.bias"), residual=h, tag="ff_out")
+        return self.conv(h.view(B, H, W, C), pre + ".proj_out", pad=0, residual=x)
+
+
+def timestep_embedding(t: torch.Tensor, dim: int) -> torch.Tensor:
+    """diffusers Timesteps(dim, flip_sin_to_cos=True, downscale_freq_shift=0): [cos | sin] of t * exp(-ln(1e4) i / half)."""
+    half = dim // 2
+    freqs = torch.exp(-math.log(10000.0) * torch.arange(half, dtype=torch.float32, device=t.device) / half)
+    args = t.float()[:, None] * freqs[None]
+    return torch.cat([torch.cos(args), torch.sin(args)], dim=-1)
+
+
+class _TimeEmbed:
+    """time_embedding MLP + every resnet's time_emb_proj as ONE batched projection:
+    temb_bias[r] = conv1.bias + time_emb_proj(silu(emb))  -> consumed by conv1's epilogue as a per-image channel bias."""
+
+    def __init__(self, b: Builder, w: Weights, cfg: UNetConfig, B, resnet_names):
+        self.tin = b.p.buf(B, cfg.block_out_channels[0])
+        e1 = b.linear(self.tin, w.lin("time_embedding.linear_1"), bias=w.f32("time_embedding.linear_1.bias"), act="silu", tag="temb")
+        emb = b.linear(e1, w.lin("time_embedding.linear_2"), bias=w.f32("time_embedding.linear_2.bias"), act="silu", tag="temb")
+        names = [n + ".time_emb_proj" for n in resnet_names]
+        wt = w.lin(*names)
+        bias = w.bias_cat(*[n + ".time_emb_proj.bias" for n in resnet_names]) + w.bias_cat(*[n + ".conv1.bias" for n in resnet_names])
+        b.p.keep.append(bias)
+        self.all = b.linear(emb, wt, bias=bias, out_dtype=torch.float32, tag="temb_proj")     # [B, sum C]
+        self.offsets, off = {}, 0
+        for n in resnet_names:
+            c = w.sd[n + ".conv1.bias"].numel()
+            self.offsets[n] = (off, c); off += c
+        self.ld = off
+
+    def bias_for(self, name):
+        off, c = self.offsets[name]
+        return (self.all[:, off:off + c], self.ld)
+
+
+def _encoder_resnet_names(cfg: UNetConfig):
+    names = []
+    for i in range(len(cfg.block_out_channels)):
+        for j in range(cfg.layers_per_block):
+            names.append("down_blocks.%d.resnets.%d" % (i, j))
+    return names + ["mid_block.resnets.0", "mid_block.resnets.1"]
+
+
+def _build_encoder(b: Builder, cfg: UNetConfig, x, temb: _TimeEmbed, text, hint=None):
+    """conv_in (+ ControlNet hint) -> down blocks -> mid block.  Returns (skips, mid)."""
+    h = b.conv(x, "conv_in", residual=hint, r_batch_bcast=hint is not None)
+    skips = [h]
+    nb = len(cfg.block_out_channels)
+    for i in range(nb):
+        for j in range(cfg.layers_per_block):
+            pre = "down_blocks.%d.resnets.%d" % (i, j)
+            h = b.resnet(h, pre, temb.bias_for(pre))
+            if cfg.attn_blocks[i]:
+                h = b.transformer(h, "down_blocks.%d.attentions.%d" % (i, j), text, cfg.heads)
+            skips.append(h)
+        if i != nb - 1:
+            h = b.conv(h, "down_blocks.%d.downsamplers.0.conv" % i, stride=2)
+            skips.append(h)
+    h = b.resnet(h, "mid_block.resnets.0", temb.bias_for("mid_block.resnets.0"))
+    h = b.transformer(h, "mid_block.attentions.0", text, cfg.heads)
+    h = b.resnet(h, "mid_block.resnets.1", temb.bias_for("mid_block.resnets.1"))
+    return skips, h
+
+
+class DenoiserPlan:
+    """ControlNet-conditioned UNet forward for a CFG batch: eps = UNet(x, t, text, ControlNet(x, t, text, cond)).
+
+    Inputs (static buffers, overwritten before run()):  latents [B,h,w,8] (4 used), t_emb [B,320] x2, text [B,77,768],
+    cond [1,8h,8w,8] (3 used; the condition image is identical for both CFG entries -- controlnet.py:60-72 repeats it --
+    so its embedding is computed once and broadcast).  Output: eps [B,h,w,4] fp32."""
+
+    def __init__(self, cfg: UNetConfig, unet_sd, cn_sd, device, batch=2, latent_hw=64, text_len=77):
+        self.cfg, self.device, self.B, self.hw = cfg, device, batch, latent_hw
+        self.plan = Plan(device)
+        p = self.plan
+        wu, wc = Weights(unet_sd, device), Weights(cn_sd, device)
+        bu, bc = Builder(p, wu, cfg.groups), Builder(p, wc, cfg.groups)
+        B, hw = batch, latent_hw
+        self.latents = p.buf(B, hw, hw, _pad8(cfg.in_channels), zero=True)
+        self.text = p.buf(B, text_len, cfg.cross_dim)
+        self.cond = p.buf(1, hw * 8, hw * 8, _pad8(cfg.cond_in_channels), zero=True)
+        # ---- UNet encoder (does not depend on the ControlNet)
+        up_names = []
+        rev_attn = list(reversed(cfg.attn_blocks))
+        for i in range(len(cfg.block_out_channels)):
+            for j in range(cfg.layers_per_block + 1):
+                up_names.append("up_blocks.%d.resnets.%d" % (i, j))
+        self.temb_u = _TimeEmbed(bu, wu, cfg, B, _encoder_resnet_names(cfg) + up_names)
+        self.temb_c = _TimeEmbed(bc, wc, cfg, B, _encoder_resnet_names(cfg))
+        skips, mid = _build_encoder(bu, cfg, self.latents, self.temb_u, self.text)
+        # ---- ControlNet: hint embedding (batch 1), own encoder, zero convs whose epilogue adds the UNet skip it feeds
+        e = "controlnet_cond_embedding"
+        hnt = bc.conv(self.cond, e + ".conv_in", act="silu")
+        nblk = 2 * (len(cfg.cond_channels) - 1)
+        for k in range(nblk):
+            hnt = bc.conv(hnt, "%s.blocks.%d" % (e, k), stride=2 if k % 2 == 1 else 1, act="silu")
+        hnt = bc.conv(hnt, e + ".conv_out")
+        cskips, cmid = _build_encoder(bc, cfg, self.latents, self.temb_c, self.text, hint=hnt)
+        skips = [bc.conv(cs, "controlnet_down_blocks.%d" % k, pad=0, residual=skips[k]) for k, cs in enumerate(cskips)]
+        h = bc.conv(cmid, "controlnet_mid_block", pad=0, residual=mid)
+        # ---- UNet decoder
+        nb = len(cfg.block_out_channels)
+        for i in range(nb):
+            for j in range(cfg.layers_per_block + 1):
+                pre = "up_blocks.%d.resnets.%d" % (i, j)
+                h = bu.resnet(bu.cat(h, skips.pop()), pre, self.temb_u.bias_for(pre))
+                if rev_attn[i]:
+                    h = bu.transformer(h, "up_blocks.%d.attentions.%d" % (i, j), self.text, cfg.heads)
+            if i != nb - 1:
+                h = bu.conv(h, "up_blocks.%d.upsamplers.0.conv" % i, upsample=2)
+        n = bu.groupnorm(h, "conv_norm_out", 1e-5, True)
+        self.eps = bu.conv(n, "conv_out", out_dtype=torch.float32)
+
+    def set_inputs(self, latents_nchw, t, text, cond_nchw=None):
+        """latents [B,4,h,w] fp32, t [B] or scalar tensor, text [B,77,768], cond [1,3,8h,8w] in [0,1] (optional)."""
+        c = latents_nchw.shape[1]
+        self.latents[..., :c].copy_(latents_nchw.permute(0, 2, 3, 1))
+        te = timestep_embedding(t.reshape(-1).expand(self.B), self.cfg.block_out_channels[0])
+        self.temb_u.tin.copy_(te); self.temb_c.tin.copy_(te)
+        self.text.copy_(text)
+        if cond_nchw is not None:
+            self.cond[..., :cond_nchw.shape[1]].copy_(cond_nchw.permute(0, 2, 3, 1))
+
+    def run(self):
+        self.plan.run()
+        return self.eps.permute(0, 3, 1, 2)   # [B,4,h,w] view (fp32)
+
+
+class VAEEncoderPlan:
+    """AutoencoderKL.encoder + quant_conv forward with the input-gradient backward (no weight gradients: the VAE is frozen
+    but sits INSIDE the autograd graph of SDS -- basic.py:368-372).  forward: image [1,3,H,W] in [0,1] -> moments
+    [1,8,H/8,W/8] (2x-1 normalisation of VaeImageProcessor fused into the input conversion).  backward: d moments -> d image."""
+
+    def __init__(self, cfg: VAEConfig, sd, device, image_hw=512):
+        self.cfg, self.device, self.hw = cfg, device, image_hw
+        self.fwd, self.bwd = Plan(device), Plan(device)
+        w = Weights(sd, device)
+        f, r = Builder(self.fwd, w, cfg.groups), Builder(self.bwd, w, cfg.groups)
+        self.x = self.fwd.buf(1, image_hw, image_hw, 8, zero=True)
+        boc = cfg.block_out_channels
+        tape = []      # closures that extend the backward plan, replayed in reverse order
+
+        def conv_f(xin, name, **kw):
+            y = f.conv(xin, name, **kw)
+            return y
+
+        def resnet_f(xin, pre):
+            C = xin.shape[-1]
+            n1, s1 = f.groupnorm(xin, pre + ".norm1", 1e-6, True, keep_stats=True)
+            h1 = f.conv(n1, pre + ".conv1")
+            n2, s2 = f.groupnorm(h1, pre + ".norm2", 1e-6, True, keep_stats=True)
+            Cout = h1.shape[-1]
+            sc = xin if C == Cout else f.conv(xin, pre + ".conv_shortcut", pad=0)
+            out = f.conv(n2, pre + ".conv2", residual=sc)
+
+            def back(dout):
+                dn2 = r.conv(dout, None, weight=w.conv(pre + ".conv2", True), bias=False)
+                dh1 = r.groupnorm_bwd(h1, dn2, s2, pre + ".norm2", 1e-6, True)
+                dn1 = r.conv(dh1, None, weight=w.conv(pre + ".conv1", True), bias=False)
+                dx = r.groupnorm_bwd(xin, dn1, s1, pre + ".norm1", 1e-6, True)
+                if C == Cout:
+                    return r.add(dx, dout)
+                return r.conv(dout, None, weight=w.conv(pre + ".conv_shortcut", True), pad=0, bias=False, residual=dx)
+            tape.append(back)
+            return out
+
+        h = f.conv(self.x, "encoder.conv_in")
+        tape.append(lambda d: r.conv(d, None, weight=w.conv("encoder.conv_in", True), bias=False))
+        for i, cout in enumerate(boc):
+            for j in range(cfg.layers_per_block):
+                h = resnet_f(h, "encoder.down_blocks.%d.resnets.%d" % (i, j))
+            if i != len(boc) - 1:
+                name = "encoder.down_blocks.%d.downsamplers.0.conv" % i
+                Hin = h.shape[1]
+                h = f.conv(h, name, stride=2, pad=0, out_hw=(Hin // 2, Hin // 2))      # F.pad(0,1,0,1) + conv stride 2
+                tape.append(lambda d, name=name, Hin=Hin: r.conv(d, None, weight=w.conv(name, True), bias=False, stride=1,
+                                                                 pad_tl=(2, 2), out_hw=(Hin, Hin), in_dilation=2))
+        h = resnet_f(h, "encoder.mid_block.resnets.0")
+        h = self._attention(f, r, w, h, "encoder.mid_block.attentions.0", tape)
+        h = resnet_f(h, "encoder.mid_block.resnets.1")
+        n, st = f.groupnorm(h, "encoder.conv_norm_out", 1e-6, True, keep_stats=True)
+        tape.append(lambda d, h=h, st=st: r.groupnorm_bwd(h, d, st, "encoder.conv_norm_out", 1e-6, True))
+        c8 = f.conv(n, "encoder.conv_out")
+        tape.append(lambda d: r.conv(d, None, weight=w.conv("encoder.conv_out", True), bias=False))
+        self.moments = f.conv(c8, "quant_conv", pad=0, out_dtype=torch.float32)
+        tape.append(lambda d: r.conv(d, None, weight=w.conv("quant_conv", True), pad=0, bias=False))
+        # backward plan
+        self.dmoments = self.bwd.buf(*self.moments.shape, zero=True)
+        d = self.dmoments
+        for back in reversed(tape):
+            d = back(d)
+        self.dx = d     # [1,H,W,8] bf16
+
+    @staticmethod
+    def _attention(f: Builder, r: Builder, w: Weights, x, pre, tape):
+        """Single-head self-attention of the VAE mid block (d = C = 512, N = 4096): QK^T / softmax / PV as strided GEMMs +
+        row softmax, because its backward needs P."""
+        B, H, W, C = x.shape
+        N = H * W
+        scale = float(C) ** -0.5
+        n, st = f.groupnorm(x, pre + ".group_norm", 1e-6, False, keep_stats=True)
+        nt = n.view(B, N, C)
+        q = f.linear(nt, w.lin(pre + ".to_q"), bias=w.f32(pre + ".to_q.bias"), tag="vae_qkv")
+        k = f.linear(nt, w.lin(pre + ".to_k"), bias=w.f32(pre + ".to_k.bias"), tag="vae_qkv")
+        v = f.linear(nt, w.lin(pre + ".to_v"), bias=w.f32(pre + ".to_v.bias"), tag="vae_qkv")
+        S = f.p.buf(N, N, dtype=torch.float32)
+        f.p.add_gemm(gemm.gemm_raw(q, k, S, N, N, C, (C, 1), (C, 1), N, name="vae_qk", run=False))
+        P = f.p.buf(N, N)
+        pp = lambda t: ctypes.c_void_p(t.data_ptr())  # noqa: E731
+        f.p.add_call(f.L.dwg_softmax_rows_forward, N, N, scale, pp(S), N, pp(P), N)
+        o = f.p.buf(B, N, C)
+        f.p.add_gemm(gemm.gemm_raw(P, v, o, N, C, N, (N, 1), (1, C), C, name="vae_pv", run=False))
+        out = f.linear(o, w.lin(pre + ".to_out.0"), bias=w.f32(pre + ".to_out.0.bias"), residual=x.view(B, N, C), tag="vae_out")
+        out = out.view(B, H, W, C)
+
+        def back(dout):
+            dt = dout.view(B, N, C)
+            wo, wq, wk, wv = (w.lin(pre + s) for s in (".to_out.0", ".to_q", ".to_k", ".to_v"))
+            do = r.p.buf(B, N, C)      # d o = dout @ Wo
+            r.p.add_gemm(gemm.gemm_raw(dt, wo, do, N, C, C, (C, 1), (1, C), C, name="vae_bwd", run=False))
+            dP = r.p.buf(N, N, dtype=torch.float32)   # dP = do v^T
+            r.p.add_gemm(gemm.gemm_raw(do, v, dP, N, N, C, (C, 1), (C, 1), N, name="vae_bwd_dp", run=False))
+            dv = r.p.buf(B, N, C)      # dv = P^T do
+            r.p.add_gemm(gemm.gemm_raw(P, do, dv, N, C, N, (1, N), (1, C), C, name="vae_bwd_dv", run=False))
+            dS = r.p.buf(N, N)
+            r.p.add_call(r.L.dwg_softmax_rows_backward, N, N, scale, pp(P), N, pp(dP), N, pp(dS), N)
+            dq = r.p.buf(B, N, C)      # dq = dS k
+            r.p.add_gemm(gemm.gemm_raw(dS, k, dq, N, C, N, (N, 1), (1, C), C, name="vae_bwd_dq", run=False))
+            dk = r.p.buf(B, N, C)      # dk = dS^T q
+            r.p.add_gemm(gemm.gemm_raw(dS, q, dk, N, C, N, (1, N), (1, C), C, name="vae_bwd_dk", run=False))
+            dn = r.p.buf(B, N, C, dtype=torch.float32)   # dn = dq Wq + dk Wk + dv Wv (fp32 accumulate across the three products)
+            for i, (g_, wt) in enumerate(((dq, wq), (dk, wk), (dv, wv))):
+                r.p.add_gemm(gemm.gemm_raw(g_, wt, dn, N, C, C, (C, 1), (1, C), C, accumulate=i > 0, name="vae_bwd_dn", run=False))
+            dnb = r.p.buf(B, H, W, C)
+            r.p.add_py(lambda: dnb.copy_(dn.view(B, H, W, C)))
+            dx = r.groupnorm_bwd(x, dnb, st, pre + ".group_norm", 1e-6, False)
+            return r.add(dx, dout)
+        tape.append(back)
+        return out
+
+    def encode(self, image_nchw):
+        """image [1,3,H,W] fp32 in [0,1] -> moments [1,8,h,w] fp32 (NCHW view)."""
+        self.x[..., :3].copy_((image_nchw * 2.0 - 1.0).permute(0, 2, 3, 1))
+        self.fwd.run()
+        return self.moments.permute(0, 3, 1, 2)
+
+    def backward(self, dmoments_nchw):
+        """d loss / d moments [1,8,h,w] -> d loss / d image [1,3,H,W] fp32."""
+        self.dmoments.copy_(dmoments_nchw.permute(0, 2, 3, 1))
+        self.bwd.run()
+        return self.dx[..., :3].permute(0, 3, 1, 2).float() * 2.0

@@ -57,7 +57,8 @@ typedef struct dwg_gemm_desc {
     int32_t conv_in_upsample; /* 2: the conv reads a virtual nearest-neighbour 2x upsampled input (Upsample2D + conv fused) */
     const void* A2;           /* optional second NHWC source: channels [conv_cin1, conv_cin) (torch.cat([h, skip], 1) fused) */
     int32_t conv_cin1;
-    int32_t bias_row_div;     /* > 0: bias is [M / bias_row_div, N] and row m uses bias[m / bias_row_div] (per-image channel bias) */
+    int32_t bias_row_div;     /* > 0: row m uses bias row m / bias_row_div (per-image channel bias) */
+    int64_t bias_ld;          /* row stride of that bias matrix in elements (0 -> N) */
     const char* name;         /* optional label for dwg_prof */
 } dwg_gemm_desc;
 

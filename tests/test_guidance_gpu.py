@@ -1,0 +1,89 @@
+"""-m gpu parity of the bf16/MFMA denoiser + VAE encoder (HIP plans) against the fp32 PyTorch-CPU oracle with the SAME
+seeded random weights, on reduced-width configurations of the SD-1.5 graph (same block structure, fewer channels).
+
+Stated tolerances (bf16 storage, fp32 accumulation; the reference runs fp32):
+  VAE moments / UNet+ControlNet eps : relative L2 <= 3e-2
+  SDS gradient on the image (CFG 50): relative L2 <= 1.5e-1 (the 50x CFG extrapolation amplifies bf16 rounding)"""
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+
+def _rel(a, r):
+    a = a.detach().double().cpu(); r = r.detach().double().cpu()
+    return float((a - r).norm() / r.norm().clamp_min(1e-30))
+
+
+def _small():
+    from dreamwaltz_g_amd import sd15
+    ucfg = sd15.UNetConfig(block_out_channels=(64, 128, 128, 128), cross_dim=64, cond_channels=(16, 32, 32, 64))
+    vcfg = sd15.VAEConfig(block_out_channels=(32, 64, 64, 64))
+    return ucfg, vcfg
+
+
+def test_vae_encoder_forward_backward():
+    from dreamwaltz_g_amd import sd15
+    from oracle import sd15 as osd
+    _, vcfg = _small()
+    sd = sd15.random_state_dict(sd15.vae_encoder_param_shapes(vcfg), seed=3)
+    plan = sd15.VAEEncoderPlan(vcfg, sd, torch.device("cuda"), image_hw=128)
+    g = torch.Generator().manual_seed(0)
+    img = torch.rand(1, 3, 128, 128, generator=g)
+    imgd = img.double().requires_grad_(True)
+    ref = osd.vae_encode_moments(vcfg, {k: v.double() for k, v in sd.items()}, imgd)
+    got = plan.encode(img.cuda())
+    assert _rel(got, ref) < 3e-2, _rel(got, ref)
+    gm = torch.randn(ref.shape, generator=g)
+    (gref,) = torch.autograd.grad(ref, imgd, gm.double())
+    gimg = plan.backward(gm.cuda())
+    assert _rel(gimg, gref) < 6e-2, _rel(gimg, gref)
+
+
+def test_denoiser_matches_oracle():
+    from dreamwaltz_g_amd import sd15
+    from oracle import sd15 as osd
+    ucfg, _ = _small()
+    usd = sd15.random_state_dict(sd15.unet_param_shapes(ucfg), seed=1)
+    csd = sd15.random_state_dict(sd15.controlnet_param_shapes(ucfg), seed=2)
+    plan = sd15.DenoiserPlan(ucfg, usd, csd, torch.device("cuda"), batch=2, latent_hw=16)
+    g = torch.Generator().manual_seed(5)
+    lat = torch.randn(1, 4, 16, 16, generator=g).repeat(2, 1, 1, 1)
+    text = torch.randn(2, 77, ucfg.cross_dim, generator=g)
+    cond = torch.rand(1, 3, 128, 128, generator=g)
+    t = torch.tensor([437])
+    ref = osd.predict_noise(ucfg, usd, csd, lat, t, text, cond.repeat(2, 1, 1, 1))
+    plan.set_inputs(lat.cuda(), t.cuda(), text.cuda(), cond.cuda())
+    got = plan.run()
+    assert _rel(got, ref) < 3e-2, _rel(got, ref)
+    # the CFG difference itself (what SDS amplifies by 50)
+    assert _rel(got[1] - got[0], ref[1] - ref[0]) < 8e-2
+
+
+def test_sds_call_matches_oracle():
+    from dreamwaltz_g_amd import guidance, sd15
+    from oracle import sd15 as osd
+    ucfg, vcfg = _small()
+    usd = sd15.random_state_dict(sd15.unet_param_shapes(ucfg), seed=1)
+    csd = sd15.random_state_dict(sd15.controlnet_param_shapes(ucfg), seed=2)
+    vsd = sd15.random_state_dict(sd15.vae_encoder_param_shapes(vcfg), seed=3)
+    dev = torch.device("cuda")
+    gd = guidance.ControlNetScoreDistillation(dev, ucfg, vcfg, usd, csd, vsd, image_hw=128)
+    g = torch.Generator().manual_seed(7)
+    img = torch.rand(1, 3, 128, 128, generator=g)
+    text = torch.randn(2, 77, ucfg.cross_dim, generator=g)
+    cond = torch.rand(1, 3, 128, 128, generator=g)
+    noise = torch.randn(1, 4, 16, 16, generator=g); vnoise = torch.randn(1, 4, 16, 16, generator=g)
+    imgd = img.clone().requires_grad_(True)
+    grads_ref, gimg_ref = osd.sds_step(ucfg, vcfg, usd, csd, vsd, imgd, text, cond, 500, noise, vnoise)
+    ic = img.cuda().requires_grad_(True)
+    out = gd(ic, {"neg": text[:1].cuda(), "text": text[1:].cuda()}, cond_inputs=cond.cuda(), timestep=torch.tensor([500], device=dev),
+             noise=noise.cuda(), posterior_noise=vnoise.cuda())
+    out["diffusion_loss"].backward()
+    assert out["diffusion_loss"].shape == (1,) and float(out["diffusion_loss"]) == 1.0
+    assert _rel(out["gradients"], grads_ref) < 1.5e-1, _rel(out["gradients"], grads_ref)
+    assert _rel(ic.grad, gimg_ref) < 2e-1, _rel(ic.grad, gimg_ref)
+    # RNG order / ranges of the un-forced path
+    torch.manual_seed(0)
+    out2 = gd(img.cuda().requires_grad_(True), {"neg": text[:1].cuda(), "text": text[1:].cuda()}, cond_inputs=cond.cuda())
+    assert 20 <= int(out2["timestep"]) <= 980
