@@ -31,6 +31,9 @@ class GaussianRasterizationSettings(NamedTuple):
     debug: bool
 
 
+LAST_NUM_PAIRS = [0]   # (Gaussian, tile) pair count of the most recent forward (bench.py's roofline bytes)
+
+
 def _f32c(t: Optional[torch.Tensor]) -> Optional[torch.Tensor]:
     return None if t is None else t.float().contiguous()
 
@@ -92,6 +95,7 @@ class _RasterizeGaussians(torch.autograd.Function):
                    "dwg_raster_forward_bin")
         # one 4-byte read-back sizes the pair buffers (the reference's extension does the same D2H copy)
         K = int(ws_geom[:4].view(torch.int32).item())
+        LAST_NUM_PAIRS[0] = K
         cap = max(K, 1)
         _lib.check(L.dwg_raster_workspace_sizes(G, H, W, cap, ctypes.byref(gb), ctypes.byref(pb), ctypes.byref(ib)),
                    "dwg_raster_workspace_sizes")

@@ -209,15 +209,22 @@ class Plan:
         self.device = device
         self.ops = []
         self.keep = []          # descriptors / tensors kept alive
+        self.tags = []
+        self.flops = {}         # algorithmic flops per kernel label (2*M*N*K*batch), for the roofline report
         self._lib = _lib.lib()
 
     def buf(self, *shape, dtype=BF16, zero=False):
+        import os
+        zero = zero or os.environ.get("DWG_PLAN_ZERO") == "1"
         t = (torch.zeros if zero else torch.empty)(*shape, device=self.device, dtype=dtype)
         self.keep.append(t)
+        self.tags.append((len(self.ops), tuple(shape)))
         return t
 
     def add_gemm(self, desc):
         self.keep.append(desc)
+        label = desc.name.decode() if desc.name else ("conv_igemm" if desc.conv_enabled else "gemm")
+        self.flops[label] = self.flops.get(label, 0.0) + 2.0 * desc.M * desc.N * desc.K * desc.batch1 * desc.batch2
         fn, ref = self._lib.dwg_gemm, ctypes.byref(desc)
         self.ops.append(lambda s, fn=fn, ref=ref: fn(ref, s))
 
@@ -233,6 +240,18 @@ class Plan:
             rc = op(s)
             if rc:
                 raise RuntimeError("plan op failed with DWG error %s" % rc)
+
+    def run_debug(self):
+        """Runs op by op and reports the first op after which any plan buffer holds a non-finite value (DWG_PLAN_ZERO=1)."""
+        s = ctypes.c_void_p(torch.cuda.current_stream(self.device).cuda_stream)
+        bufs = [t for t in self.keep if torch.is_tensor(t) and t.is_floating_point()]
+        for i, op in enumerate(self.ops):
+            rc = op(s)
+            torch.cuda.synchronize()
+            bad = [tuple(t.shape) for t in bufs if not torch.isfinite(t.float()).all()]
+            if rc or bad:
+                return i, rc, bad
+        return None
 
 
 class Weights:
@@ -489,6 +508,7 @@ class DenoiserPlan:
         self.plan = Plan(device)
         p = self.plan
         wu, wc = Weights(unet_sd, device), Weights(cn_sd, device)
+        self.weights = (wu, wc)     # kernel-layout weight tensors must outlive the plan that points at them
         bu, bc = Builder(p, wu, cfg.groups), Builder(p, wc, cfg.groups)
         B, hw = batch, latent_hw
         self.latents = p.buf(B, hw, hw, _pad8(cfg.in_channels), zero=True)
@@ -550,6 +570,7 @@ class VAEEncoderPlan:
         self.cfg, self.device, self.hw = cfg, device, image_hw
         self.fwd, self.bwd = Plan(device), Plan(device)
         w = Weights(sd, device)
+        self.weights = w            # kernel-layout weight tensors must outlive the plans that point at them
         f, r = Builder(self.fwd, w, cfg.groups), Builder(self.bwd, w, cfg.groups)
         self.x = self.fwd.buf(1, image_hw, image_hw, 8, zero=True)
         boc = cfg.block_out_channels
