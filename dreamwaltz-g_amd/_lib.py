@@ -49,6 +49,7 @@ SIGNATURES = {
                                                 _u32, _u32, _u32, _vp]),
     # include/dwg_gemm.h
     "dwg_gemm": (ctypes.c_int, [_vp, _vp]),
+    "dwg_gemm_workspace_bytes": (_sz, [_vp]),
     # include/dwg_elementwise.h
     "dwg_act_backward_colsum": (ctypes.c_int, [_i32, _i32, _i32, _vp, _vp, _vp, _vp, _vp]),
     "dwg_adam_step": (ctypes.c_int, [_i64, _vp, _vp, _vp, _vp, _f32, _f32, _f32, _f32, _i32, _f32, _vp]),

@@ -36,6 +36,7 @@ struct GemmP {
     long long bA1, bA2, bB1, bB2, bC1, bC2, bR1, bR2;
     int act; float alpha;
     int out_bf16, res_bf16, bias_per_row, splitk, accumulate;
+    float* ws;          // split-K slab workspace [splitk][M][N] (nullptr: atomicAdd into C)
     int bias_row_div;   // > 0: bias index = (row / bias_row_div) * bias_ld + col  (per-image channel bias: conv bias + time embedding)
     long long bias_ld;
     ConvP conv;
@@ -56,7 +57,7 @@ __device__ __forceinline__ float apply_act(float v, int act) {
 }
 
 template <typename T> struct TT;
-template <> struct TT<__bf16> { static constexpr int VEC = 8; static constexpr int BK = 32; static constexpr int PAD = 8; };
+template <> struct TT<__bf16> { static constexpr int VEC = 8; static constexpr int BK = 64; static constexpr int PAD = 8; };
 template <> struct TT<float> { static constexpr int VEC = 4; static constexpr int BK = 16; static constexpr int PAD = 4; };
 
 // operand load modes
@@ -77,91 +78,112 @@ __device__ __forceinline__ Chunk<T, VEC> zero_chunk() {
     return c;
 }
 
-// Loads this thread's share of a [ROWS][BK] operand tile into registers.
-//   rows r0..r0+ROWS of the operand (row = m for A / n for B), contraction range k0..k0+BK.
+// Loads this thread's share of a [ROWS][BK] operand tile into registers, then stores it to LDS as [ROWS][BK + PAD].
+// In the K-contiguous modes every thread owns ONE 16-byte k-column of the tile and NCH rows of it, so everything that
+// depends on the row (im2col pixel decomposition, row pointers) is computed once in init() and the k-dependent state
+// ((ky, kx, ci) of the im2col view) advances incrementally -- no integer division inside the k-loop.
 template <typename T, int ROWS, int MODE>
 struct TileLoader {
-    static constexpr int VEC = TT<T>::VEC, BK = TT<T>::BK;
-    static constexpr int NCH = (MODE == MODE_SCALAR) ? (ROWS * BK / 256) : (ROWS * BK / VEC / 256);
+    static constexpr int VEC = TT<T>::VEC, BK = TT<T>::BK, LDT = BK + TT<T>::PAD;
+    static constexpr int CPR = BK / VEC, RPI = 256 / CPR;          // chunks per row, rows per pass (K-contiguous modes)
+    static constexpr int CPK = ROWS / VEC, KPI = 256 / CPK;        // chunks per k-row, k-rows per pass (row-contiguous mode)
+    static constexpr int NCH = (MODE == MODE_SCALAR) ? (ROWS * BK / 256) : (MODE == MODE_RVEC ? BK / KPI : ROWS / RPI);
     Chunk<T, VEC> regs[(MODE == MODE_SCALAR) ? 1 : NCH];
     T sregs[(MODE == MODE_SCALAR) ? NCH : 1];
+    const T* rowptr[(MODE == MODE_KVEC) ? NCH : 1];
+    int iy0[(MODE == MODE_CONV) ? NCH : 1], ix0[(MODE == MODE_CONV) ? NCH : 1];
+    long long pix0[(MODE == MODE_CONV) ? NCH : 1];
+    bool rok[(MODE == MODE_CONV) ? NCH : 1];
+    const T* base; long long srow, sk; int nrows, r0, kcur, kend;
+    int ci, ky, kx;
 
-    __device__ __forceinline__ void load(const T* base, long long srow, long long sk, int nrows, int K, int r0, int k0,
-                                         int kend, const ConvP& cv) {
+    __device__ __forceinline__ void init(const T* base_, long long srow_, long long sk_, int nrows_, int r0_, int kbeg, int kend_,
+                                         const ConvP& cv) {
+        base = base_; srow = srow_; sk = sk_; nrows = nrows_; r0 = r0_; kend = kend_;
         const int tid = threadIdx.x;
         if (MODE == MODE_KVEC) {
-            constexpr int CPR = BK / VEC;
+            kcur = kbeg + (tid % CPR) * VEC;
 #pragma unroll
             for (int i = 0; i < NCH; i++) {
-                int c = tid + i * 256, row = c / CPR, kc = c - row * CPR;
-                int r = r0 + row, k = k0 + kc * VEC;
-                regs[i] = (r < nrows && k < kend) ? load_vec<T, VEC>(base + (long long)r * srow + k) : zero_chunk<T, VEC>();
+                int r = r0 + tid / CPR + i * RPI;
+                rowptr[i] = r < nrows ? base + (long long)r * srow : nullptr;
+            }
+        } else if (MODE == MODE_CONV) {
+            kcur = kbeg + (tid % CPR) * VEC;
+            const int hw = cv.Hout * cv.Wout;
+#pragma unroll
+            for (int i = 0; i < NCH; i++) {
+                int r = r0 + tid / CPR + i * RPI;
+                rok[i] = r < nrows;
+                int rr = rok[i] ? r : 0;
+                int img = rr / hw, rem = rr - img * hw;
+                int oy = rem / cv.Wout, ox = rem - oy * cv.Wout;
+                iy0[i] = oy * cv.stride - cv.pad_t; ix0[i] = ox * cv.stride - cv.pad_l;
+                pix0[i] = (long long)img * cv.Hin * cv.Win;
+            }
+            int tap = kcur / cv.Cin;
+            ci = kcur - tap * cv.Cin; ky = tap / cv.KW; kx = tap - ky * cv.KW;
+        } else {
+            kcur = kbeg;
+        }
+    }
+
+    __device__ __forceinline__ void advance(const ConvP& cv) {
+        kcur += BK;
+        if (MODE == MODE_CONV) {
+            ci += BK;
+            while (ci >= cv.Cin) { ci -= cv.Cin; if (++kx == cv.KW) { kx = 0; ++ky; } }
+        }
+    }
+
+    __device__ __forceinline__ void load(const ConvP& cv) {
+        const int tid = threadIdx.x;
+        if (MODE == MODE_KVEC) {
+            const bool kok = kcur < kend;
+#pragma unroll
+            for (int i = 0; i < NCH; i++)
+                regs[i] = (kok && rowptr[i]) ? load_vec<T, VEC>(rowptr[i] + kcur) : zero_chunk<T, VEC>();
+        } else if (MODE == MODE_CONV) {
+            const bool kok = kcur < kend;
+            const T* src0 = ci < cv.cin1 ? base : reinterpret_cast<const T*>(cv.A2);
+            const int cs = ci < cv.cin1 ? cv.cin1 : (cv.Cin - cv.cin1);
+            const int co = ci < cv.cin1 ? ci : ci - cv.cin1;
+#pragma unroll
+            for (int i = 0; i < NCH; i++) {
+                int iy = iy0[i] + ky, ix = ix0[i] + kx;
+                bool ok = kok && rok[i] && iy >= 0 && ix >= 0;
+                if (cv.dil > 1) { ok = ok && (iy % cv.dil == 0) && (ix % cv.dil == 0); iy /= cv.dil; ix /= cv.dil; }
+                if (cv.up > 1) { iy >>= 1; ix >>= 1; }
+                ok = ok && iy < cv.Hin && ix < cv.Win;
+                regs[i] = ok ? load_vec<T, VEC>(src0 + (pix0[i] + (long long)iy * cv.Win + ix) * cs + co) : zero_chunk<T, VEC>();
             }
         } else if (MODE == MODE_RVEC) {
-            constexpr int CPK = ROWS / VEC;
 #pragma unroll
             for (int i = 0; i < NCH; i++) {
-                int c = tid + i * 256, kk = c / CPK, rc = c - kk * CPK;
-                int r = r0 + rc * VEC, k = k0 + kk;
+                int kk = tid / CPK + i * KPI, rc = tid % CPK;
+                int r = r0 + rc * VEC, k = kcur + kk;
                 regs[i] = (r < nrows && k < kend) ? load_vec<T, VEC>(base + (long long)k * sk + r) : zero_chunk<T, VEC>();
             }
-        } else if (MODE == MODE_SCALAR) {
+        } else {
 #pragma unroll
             for (int i = 0; i < NCH; i++) {
                 int c = tid + i * 256, row = c / BK, kk = c - row * BK;
-                int r = r0 + row, k = k0 + kk;
+                int r = r0 + row, k = kcur + kk;
                 sregs[i] = (r < nrows && k < kend) ? base[(long long)r * srow + (long long)k * sk] : (T)0.f;
             }
-        } else {  // MODE_CONV: row = (img, oy, ox), k = (ky, kx, ci), NHWC input, Cin % VEC == 0
-            constexpr int CPR = BK / VEC;
-#pragma unroll
-            for (int i = 0; i < NCH; i++) {
-                int c = tid + i * 256, row = c / CPR, kc = c - row * CPR;
-                int r = r0 + row, k = k0 + kc * VEC;
-                bool ok = r < nrows && k < kend;
-                const T* src = base;
-                if (ok) {
-                    int hw = cv.Hout * cv.Wout;
-                    int img = r / hw, rem = r - img * hw;
-                    int oy = rem / cv.Wout, ox = rem - oy * cv.Wout;
-                    int tap = k / cv.Cin, ci = k - tap * cv.Cin;
-                    int ky = tap / cv.KW, kx = tap - ky * cv.KW;
-                    int iy = oy * cv.stride - cv.pad_t + ky, ix = ox * cv.stride - cv.pad_l + kx;
-                    if (cv.dil > 1) {
-                        ok = iy >= 0 && ix >= 0 && (iy % cv.dil == 0) && (ix % cv.dil == 0);
-                        iy /= cv.dil; ix /= cv.dil;
-                    }
-                    if (cv.up > 1) {  // virtual input is the nearest-neighbour upsampled tensor
-                        ok = ok && iy >= 0 && ix >= 0 && iy < cv.Hin * cv.up && ix < cv.Win * cv.up;
-                        iy /= cv.up; ix /= cv.up;
-                    }
-                    ok = ok && iy >= 0 && iy < cv.Hin && ix >= 0 && ix < cv.Win;
-                    const long long pix = ((long long)img * cv.Hin + iy) * cv.Win + ix;
-                    if (ci < cv.cin1) src = base + pix * cv.cin1 + ci;
-                    else src = reinterpret_cast<const T*>(cv.A2) + pix * (cv.Cin - cv.cin1) + (ci - cv.cin1);
-                }
-                regs[i] = ok ? load_vec<T, VEC>(src) : zero_chunk<T, VEC>();
-            }
         }
-        (void)K;
     }
 
-    // LDS tile layout: [ROWS][BK + PAD]
     __device__ __forceinline__ void store(T* lds) {
-        constexpr int LDT = BK + TT<T>::PAD;
         const int tid = threadIdx.x;
         if (MODE == MODE_KVEC || MODE == MODE_CONV) {
-            constexpr int CPR = BK / VEC;
 #pragma unroll
-            for (int i = 0; i < NCH; i++) {
-                int c = tid + i * 256, row = c / CPR, kc = c - row * CPR;
-                *reinterpret_cast<uint4*>(lds + row * LDT + kc * VEC) = *reinterpret_cast<uint4*>(&regs[i]);
-            }
+            for (int i = 0; i < NCH; i++)
+                *reinterpret_cast<uint4*>(lds + (tid / CPR + i * RPI) * LDT + (tid % CPR) * VEC) = *reinterpret_cast<uint4*>(&regs[i]);
         } else if (MODE == MODE_RVEC) {
-            constexpr int CPK = ROWS / VEC;
 #pragma unroll
             for (int i = 0; i < NCH; i++) {
-                int c = tid + i * 256, kk = c / CPK, rc = c - kk * CPK;
+                int kk = tid / CPK + i * KPI, rc = tid % CPK;
 #pragma unroll
                 for (int e = 0; e < VEC; e++) lds[(rc * VEC + e) * LDT + kk] = regs[i].v[e];
             }
@@ -201,6 +223,20 @@ __device__ __forceinline__ void mma_tile<float>(const float* sa, const float* sb
         acc = __builtin_amdgcn_mfma_f32_32x32x2f32(pa[ks * 2], pb[ks * 2], acc, 0, 0, 0);
 }
 
+__device__ __forceinline__ void epilogue_store(const GemmP& p, float v, int row, int col, long long coff, long long roff) {
+    const long long ci = coff + (long long)row * p.ldc + col;
+    if (p.bias) v += reinterpret_cast<const float*>(p.bias)[p.bias_row_div > 0 ? (long long)(row / p.bias_row_div) * p.bias_ld + col
+                                                                             : (p.bias_per_row ? row : col)];
+    v = apply_act(v, p.act);
+    if (p.residual) {
+        const long long ri = roff + (long long)row * p.ldr + col;
+        v += p.res_bf16 ? bf2f(reinterpret_cast<const __bf16*>(p.residual)[ri]) : reinterpret_cast<const float*>(p.residual)[ri];
+    }
+    if (p.out_bf16) reinterpret_cast<__bf16*>(p.C)[ci] = f2bf(v);
+    else if (p.accumulate) reinterpret_cast<float*>(p.C)[ci] += v;
+    else reinterpret_cast<float*>(p.C)[ci] = v;
+}
+
 template <typename T, int BN, int AMODE, int BMODE>
 __global__ __launch_bounds__(256) void k_gemm(GemmP p) {
     constexpr int BM = 128, BK = TT<T>::BK, LDT = BK + TT<T>::PAD;
@@ -236,18 +272,19 @@ __global__ __launch_bounds__(256) void k_gemm(GemmP p) {
 
     TileLoader<T, BM, AMODE> la;
     TileLoader<T, BN, BMODE> lb;
+    la.init(A, p.sam, p.sak, p.M, m0, kbeg, kend, p.conv);
+    lb.init(B, p.sbn, p.sbk, p.N, n0, kbeg, kend, p.conv);
     const int nk = kend > kbeg ? (kend - kbeg + BK - 1) / BK : 0;
     if (nk > 0) {
-        la.load(A, p.sam, p.sak, p.M, p.K, m0, kbeg, kend, p.conv);
-        lb.load(B, p.sbn, p.sbk, p.N, p.K, n0, kbeg, kend, p.conv);
+        la.load(p.conv); lb.load(p.conv);
         la.store(sA); lb.store(sB);
     }
     __syncthreads();
     for (int kt = 0; kt < nk; kt++) {
         const int cur = kt & 1;
         if (kt + 1 < nk) {
-            la.load(A, p.sam, p.sak, p.M, p.K, m0, kbeg + (kt + 1) * BK, kend, p.conv);
-            lb.load(B, p.sbn, p.sbk, p.N, p.K, n0, kbeg + (kt + 1) * BK, kend, p.conv);
+            la.advance(p.conv); lb.advance(p.conv);
+            la.load(p.conv); lb.load(p.conv);
         }
         const T* a = sA + cur * BM * LDT + (wm * TM * 32) * LDT;
         const T* b = sB + cur * BN * LDT + (wn * 64) * LDT;
@@ -271,21 +308,25 @@ __global__ __launch_bounds__(256) void k_gemm(GemmP p) {
                 const int row = m0 + (wm * TM + i) * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
                 if (row >= p.M) continue;
                 float v = acc[i][j][r] * p.alpha;
-                const long long ci = coff + (long long)row * p.ldc + col;
-                if (p.splitk > 1) { atomicAdd(reinterpret_cast<float*>(p.C) + ci, v); continue; }
-                if (p.bias) v += reinterpret_cast<const float*>(p.bias)[p.bias_row_div > 0 ? (long long)(row / p.bias_row_div) * p.bias_ld + col
-                                                                                         : (p.bias_per_row ? row : col)];
-                v = apply_act(v, p.act);
-                if (p.residual) {
-                    const long long ri = roff + (long long)row * p.ldr + col;
-                    v += p.res_bf16 ? bf2f(reinterpret_cast<const __bf16*>(p.residual)[ri])
-                                    : reinterpret_cast<const float*>(p.residual)[ri];
+                if (p.splitk > 1) {
+                    if (p.ws) p.ws[((long long)ks_id * p.M + row) * p.N + col] = v;          // slab, reduced by k_splitk_epilogue
+                    else atomicAdd(reinterpret_cast<float*>(p.C) + coff + (long long)row * p.ldc + col, v);
+                    continue;
                 }
-                if (p.out_bf16) reinterpret_cast<__bf16*>(p.C)[ci] = f2bf(v);
-                else if (p.accumulate) reinterpret_cast<float*>(p.C)[ci] += v;
-                else reinterpret_cast<float*>(p.C)[ci] = v;
+                epilogue_store(p, v, row, col, coff, roff);
             }
         }
+}
+
+// sums the split-K slabs and applies the fused epilogue (batch == 1)
+__global__ __launch_bounds__(256) void k_splitk_epilogue(GemmP p) {
+    const long long n = (long long)p.M * p.N;
+    for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long long)gridDim.x * 256) {
+        float v = 0.f;
+        for (int s = 0; s < p.splitk; s++) v += p.ws[(long long)s * n + i];
+        int row = (int)(i / p.N), col = (int)(i - (long long)row * p.N);
+        epilogue_store(p, v, row, col, 0, 0);
+    }
 }
 
 template <typename T, int BN, int AMODE, int BMODE>
@@ -293,7 +334,18 @@ static void launch(const GemmP& p, int batch, hipStream_t stream, const char* na
     constexpr int LDT = TT<T>::BK + TT<T>::PAD;
     size_t lds = (size_t)2 * (128 + BN) * LDT * sizeof(T);
     dim3 grid((p.M + 127) / 128, ((p.N + BN - 1) / BN) * (p.splitk > 1 ? p.splitk : 1), batch);
+    static bool attr_set = false;   // > 64 KiB of dynamic LDS needs an explicit opt-in (one per instantiation)
+    if (!attr_set) {
+        hipFuncSetAttribute(reinterpret_cast<const void*>(&k_gemm<T, BN, AMODE, BMODE>), hipFuncAttributeMaxDynamicSharedMemorySize,
+                            (int)lds);
+        attr_set = true;
+    }
     DWG_LAUNCH(name, (k_gemm<T, BN, AMODE, BMODE>), grid, dim3(256), lds, stream, p);
+    if (p.splitk > 1 && p.ws) {
+        long long n = (long long)p.M * p.N;
+        int blocks = (int)((n + 255) / 256); if (blocks > 2048) blocks = 2048;
+        DWG_LAUNCH("splitk_epilogue", k_splitk_epilogue, dim3(blocks), dim3(256), 0, stream, p);
+    }
 }
 
 template <typename T, int BN, int AMODE>
@@ -310,6 +362,17 @@ static void dispatch_a(const GemmP& p, int amode, int bmode, int batch, hipStrea
     else dispatch_b<T, BN, MODE_SCALAR>(p, bmode, batch, s, name);
 }
 
+// split-K factor for shapes that cannot fill 256 CUs with 128 x BN output tiles (small-M layers: 8x8 / 16x16 latents)
+static int auto_splitk(int M, int N, int K, int bn, int bk) {
+    long long blocks = (long long)((M + 127) / 128) * ((N + bn - 1) / bn);
+    if (blocks >= 192 || K < 8 * bk) return 1;
+    long long sk = 256 / blocks;
+    long long kmax = K / (4 * bk);
+    if (sk > kmax) sk = kmax;
+    if (sk > 16) sk = 16;
+    return sk >= 2 ? (int)sk : 1;
+}
+
 template <typename T>
 static int pick_mode(const void* base, long long srow, long long sk, int nrows, int K, const long long* boffs, int nboffs) {
     constexpr int VEC = TT<T>::VEC;
@@ -324,12 +387,19 @@ static int pick_mode(const void* base, long long srow, long long sk, int nrows, 
 
 extern "C" {
 
+size_t dwg_gemm_workspace_bytes(const dwg_gemm_desc* d) {
+    if (!d || d->batch1 * d->batch2 != 1 || d->M <= 0 || d->N <= 0) return 0;
+    const int bn = d->N <= 64 ? 64 : 128, bk = d->dtype == DWG_DTYPE_BF16 ? TT<__bf16>::BK : TT<float>::BK;
+    int sk = d->splitk > 1 ? d->splitk : (d->splitk == 0 ? auto_splitk(d->M, d->N, d->K, bn, bk) : 1);
+    return sk > 1 ? (size_t)sk * d->M * d->N * sizeof(float) : 0;
+}
+
 int dwg_gemm(const dwg_gemm_desc* d, dwg_stream_t stream_) {
     if (!d || !d->A || !d->B || !d->C) return DWG_E_ARG;
     if (d->M < 0 || d->N < 0 || d->K < 0 || d->batch1 < 1 || d->batch2 < 1) return DWG_E_ARG;
     if (d->M == 0 || d->N == 0) return DWG_OK;
     if (d->dtype != DWG_DTYPE_F32 && d->dtype != DWG_DTYPE_BF16) return DWG_E_ARG;
-    if (d->splitk > 1 && (d->out_dtype != DWG_DTYPE_F32 || d->bias || d->residual || d->act)) return DWG_E_ARG;
+    if (d->splitk > 1 && !d->workspace && (d->out_dtype != DWG_DTYPE_F32 || d->bias || d->residual || d->act)) return DWG_E_ARG;
     if (d->accumulate && d->out_dtype != DWG_DTYPE_F32) return DWG_E_ARG;
     GemmP p;
     p.A = d->A; p.B = d->B; p.C = d->C; p.bias = d->bias; p.residual = d->residual;
@@ -342,6 +412,16 @@ int dwg_gemm(const dwg_gemm_desc* d, dwg_stream_t stream_) {
     p.act = d->act; p.alpha = d->alpha;
     p.out_bf16 = d->out_dtype == DWG_DTYPE_BF16; p.res_bf16 = d->residual_dtype == DWG_DTYPE_BF16;
     p.bias_per_row = d->bias_per_row; p.splitk = d->splitk > 1 ? d->splitk : 1; p.accumulate = d->accumulate;
+    p.ws = nullptr;
+    {
+        const int bn = d->N <= 64 ? 64 : 128, bk = d->dtype == DWG_DTYPE_BF16 ? TT<__bf16>::BK : TT<float>::BK;
+        if (d->workspace && d->batch1 * d->batch2 == 1) {
+            int sk = d->splitk > 1 ? d->splitk : (d->splitk == 0 ? auto_splitk(d->M, d->N, d->K, bn, bk) : 1);
+            while (sk > 1 && (size_t)sk * d->M * d->N * sizeof(float) > d->workspace_bytes) sk--;
+            p.splitk = sk;
+            if (sk > 1) p.ws = reinterpret_cast<float*>(d->workspace);
+        }
+    }
     p.conv.enabled = d->conv_enabled;
     p.conv.Cin = d->conv_cin; p.conv.Hin = d->conv_hin; p.conv.Win = d->conv_win; p.conv.Hout = d->conv_hout;
     p.conv.Wout = d->conv_wout; p.conv.KH = d->conv_kh; p.conv.KW = d->conv_kw; p.conv.stride = d->conv_stride;

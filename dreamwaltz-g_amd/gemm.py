@@ -29,6 +29,7 @@ class GemmDesc(ctypes.Structure):
         ("conv_pad_t", ctypes.c_int32), ("conv_pad_l", ctypes.c_int32), ("conv_in_dilation", ctypes.c_int32),
         ("conv_in_upsample", ctypes.c_int32), ("A2", ctypes.c_void_p), ("conv_cin1", ctypes.c_int32),
         ("bias_row_div", ctypes.c_int32), ("bias_ld", ctypes.c_int64),
+        ("workspace", ctypes.c_void_p), ("workspace_bytes", ctypes.c_size_t),
         ("name", ctypes.c_char_p),
     ]
 

@@ -221,7 +221,15 @@ class Plan:
         self.tags.append((len(self.ops), tuple(shape)))
         return t
 
-    def add_gemm(self, desc):
+    def add_gemm(self, desc, allow_split=True):
+        if allow_split and desc.batch1 * desc.batch2 == 1 and desc.splitk <= 1 and not desc.accumulate:
+            desc.splitk = 0     # library picks a split-K factor for shapes that cannot fill the chip
+            need = self._lib.dwg_gemm_workspace_bytes(ctypes.byref(desc))
+            if need > 0:
+                ws = self.buf(int(need) // 4, dtype=torch.float32)
+                desc.workspace, desc.workspace_bytes = ws.data_ptr(), int(need)
+            else:
+                desc.splitk = 1
         self.keep.append(desc)
         label = desc.name.decode() if desc.name else ("conv_igemm" if desc.conv_enabled else "gemm")
         self.flops[label] = self.flops.get(label, 0.0) + 2.0 * desc.M * desc.N * desc.K * desc.batch1 * desc.batch2

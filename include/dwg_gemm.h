@@ -50,7 +50,9 @@ typedef struct dwg_gemm_desc {
     int32_t act;              /* DWG_ACT_* */
     float alpha;
     int32_t bias_per_row;
-    int32_t splitk;           /* > 1: split the contraction, atomicAdd into a pre-zeroed f32 C (no bias/act/residual) */
+    int32_t splitk;           /* > 1: split the contraction.  Without `workspace`: atomicAdd into a pre-zeroed f32 C (no
+                                 bias/act/residual).  With `workspace` (batch 1): fp32 slabs + a reduce pass that applies the
+                                 full epilogue; splitk == 0 then means "let the library choose" (small-M layers). */
     int32_t accumulate;       /* C += result (f32 C only) */
     int32_t conv_enabled, conv_cin, conv_hin, conv_win, conv_hout, conv_wout, conv_kh, conv_kw, conv_stride, conv_pad_t,
         conv_pad_l, conv_in_dilation;
@@ -59,10 +61,15 @@ typedef struct dwg_gemm_desc {
     int32_t conv_cin1;
     int32_t bias_row_div;     /* > 0: row m uses bias row m / bias_row_div (per-image channel bias) */
     int64_t bias_ld;          /* row stride of that bias matrix in elements (0 -> N) */
+    void* workspace;          /* optional split-K slab workspace (device), see dwg_gemm_workspace_bytes */
+    size_t workspace_bytes;
     const char* name;         /* optional label for dwg_prof */
 } dwg_gemm_desc;
 
 int dwg_gemm(const dwg_gemm_desc* desc, dwg_stream_t stream);
+
+/* Bytes of split-K workspace the library would like for this descriptor (0: no split would be used). */
+size_t dwg_gemm_workspace_bytes(const dwg_gemm_desc* desc);
 
 #ifdef __cplusplus
 }

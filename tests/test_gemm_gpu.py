@@ -122,3 +122,24 @@ def test_bf16_conv_asymmetric_pad_and_input_gradient():
     (gx1_ref,) = torch.autograd.grad(ref1, xd, gy1.double())
     gx1 = gemm.conv2d_nhwc(gy1.permute(0, 2, 3, 1).contiguous().cuda(), wf.cuda(), None, stride=1, pad=(1, 1), out_dtype=torch.float32)
     assert _rel(gx1.permute(0, 3, 1, 2).cpu(), gx1_ref) < 2e-3
+
+
+def test_bf16_splitk_slab_epilogue_small_m():
+    """Small-M layers (8x8 / 16x16 latents): library-chosen split-K with fp32 slabs + fused epilogue pass."""
+    import ctypes
+    from dreamwaltz_g_amd import gemm, _lib
+    g = torch.Generator().manual_seed(4)
+    M, N, K = 128, 1280, 11520
+    x = torch.randn(M, K, generator=g).bfloat16(); w = (torch.randn(N, K, generator=g) / K ** 0.5).bfloat16()
+    b = torch.randn(N, generator=g); r = torch.randn(M, N, generator=g).bfloat16()
+    ref = torch.nn.functional.silu(x.double() @ w.double().t() + b.double()) + r.double()
+    xc, wc, bc, rc_ = x.cuda(), w.cuda(), b.cuda(), r.cuda()
+    y = torch.empty(M, N, device="cuda", dtype=torch.bfloat16)
+    d = gemm.gemm_raw(xc, wc, y, M, N, K, (K, 1), (K, 1), N, bias=bc, residual=rc_, ldr=N, act="silu", run=False)
+    d.splitk = 0
+    need = _lib.lib().dwg_gemm_workspace_bytes(ctypes.byref(d))
+    assert need > 0
+    ws = torch.empty(need // 4, device="cuda")
+    d.workspace, d.workspace_bytes = ws.data_ptr(), need
+    gemm.run_desc(d, ctypes.c_void_p(torch.cuda.current_stream().cuda_stream))
+    assert _rel(y.cpu(), ref) < 1.2e-2
