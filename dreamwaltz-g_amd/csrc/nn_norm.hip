@@ -95,7 +95,9 @@ __global__ __launch_bounds__(256) void k_gn_reduce(int HW, int C, int G, int pix
 }
 
 // forward apply: y = silu?((x - mean) * rstd * gamma + beta)
-// backward apply: dx = rstd * (dyh - mean(dyh) - xhat * mean(dyh * xhat))
+// backward apply: dx = rstd * (dyh - mean(dyh) - xhat * mean(dyh * xhat)) [+ residual]
+// Same thread layout as the reduction: a thread owns ONE 8-channel chunk (its affine parameters and group statistics live
+// in registers) and walks the block's pixel range, so the inner loop is load - 8 fma - store with 32-bit index math only.
 template <bool BWD>
 __global__ __launch_bounds__(256) void k_gn_apply(int HW, int C, int G, int pix_per_block, const __bf16* __restrict__ x,
                                                   const __bf16* __restrict__ dy, const float* __restrict__ stats,
@@ -114,31 +116,45 @@ __global__ __launch_bounds__(256) void k_gn_apply(int HW, int C, int G, int pix_
     }
     __syncthreads();
     const int p0 = blockIdx.x * pix_per_block, p1 = min(HW, p0 + pix_per_block);
-    const long long n = (long long)(p1 - p0) * C8;
-    for (long long i = tid; i < n; i += 256) {
-        int p = p0 + (int)(i / C8), cc = (int)(i % C8);
-        size_t off = ((size_t)b * HW + p) * C + (size_t)cc * 8;
-        bf16x8 xv = *reinterpret_cast<const bf16x8*>(x + off);
-        bf16x8 dv;
-        if (BWD) dv = *reinterpret_cast<const bf16x8*>(dy + off);
-        bf16x8 o;
+    for (int cb = 0; cb < C8; cb += 256) {
+        const int tpx = min(256, C8 - cb), rows = 256 / tpx;
+        const int cc = cb + tid % tpx, prow = tid / tpx;
+        if (prow >= rows) continue;
+        float ga[8], be[8], mu[8], rs[8], m1[8], m2[8];
 #pragma unroll
         for (int e = 0; e < 8; e++) {
             int ch = cc * 8 + e, g = ch / cg;
-            float mu = gstat[4 * g], rs = gstat[4 * g + 1];
-            float xh = ((float)xv[e] - mu) * rs;
-            float ga = gamma[ch], be = beta[ch];
-            if (!BWD) {
-                float z = xh * ga + be;
-                o[e] = (__bf16)(silu ? silu_f(z) : z);
-            } else {
-                float gq = (float)dv[e];
-                if (silu) gq *= silu_grad(xh * ga + be);
-                gq *= ga;
-                o[e] = (__bf16)(rs * (gq - gstat[4 * g + 2] - xh * gstat[4 * g + 3]));
-            }
+            ga[e] = gamma[ch]; be[e] = beta[ch]; mu[e] = gstat[4 * g]; rs[e] = gstat[4 * g + 1];
+            m1[e] = BWD ? gstat[4 * g + 2] : 0.f; m2[e] = BWD ? gstat[4 * g + 3] : 0.f;
         }
-        *reinterpret_cast<bf16x8*>(out + off) = o;
+        const __bf16* xp = x + ((size_t)b * HW + p0 + prow) * C + (size_t)cc * 8;
+        const __bf16* dp = BWD ? dy + ((size_t)b * HW + p0 + prow) * C + (size_t)cc * 8 : nullptr;
+        __bf16* op = out + ((size_t)b * HW + p0 + prow) * C + (size_t)cc * 8;
+        const size_t step = (size_t)rows * C;
+        for (int p = p0 + prow; p < p1; p += rows) {
+            bf16x8 xv = *reinterpret_cast<const bf16x8*>(xp);
+            bf16x8 o;
+            if (!BWD) {
+#pragma unroll
+                for (int e = 0; e < 8; e++) {
+                    float z = ((float)xv[e] - mu[e]) * rs[e] * ga[e] + be[e];
+                    o[e] = (__bf16)(silu ? silu_f(z) : z);
+                }
+            } else {
+                bf16x8 dv = *reinterpret_cast<const bf16x8*>(dp);
+#pragma unroll
+                for (int e = 0; e < 8; e++) {
+                    float xh = ((float)xv[e] - mu[e]) * rs[e];
+                    float gq = (float)dv[e];
+                    if (silu) gq *= silu_grad(xh * ga[e] + be[e]);
+                    gq *= ga[e];
+                    o[e] = (__bf16)(rs[e] * (gq - m1[e] - xh * m2[e]));
+                }
+                dp += step;
+            }
+            *reinterpret_cast<bf16x8*>(op) = o;
+            xp += step; op += step;
+        }
     }
 }
 
@@ -237,7 +253,7 @@ __global__ __launch_bounds__(256) void k_softmax_rows_bwd(int rows, int n, float
 
 static int gn_geometry(int HW, int C, int G, int* pix_per_block, int* chunks, size_t* lds) {
     if (C % 8 || G <= 0 || G > 64 || C % G) return DWG_E_ARG;
-    int ppb = HW / 64; if (ppb < 16) ppb = 16; if (ppb > 1024) ppb = 1024;
+    int ppb = HW / 256; if (ppb < 16) ppb = 16; if (ppb > 256) ppb = 256;
     *pix_per_block = ppb; *chunks = dwg_cdiv(HW, ppb);
     *lds = (size_t)256 * 8 * 2 * sizeof(float);
     return DWG_OK;

@@ -71,6 +71,17 @@ class ControlNetScoreDistillation:
         self.vae_scale_factor = down
         self.scaling_factor = self.vae_cfg.scaling_factor
 
+    def plans(self):
+        return (self.denoiser.plan, self.vae.fwd, self.vae.bwd)
+
+    def capture_graphs(self):
+        for p in self.plans():
+            p.capture()
+
+    def set_use_graphs(self, on: bool):
+        for p in self.plans():
+            p.use_graph = bool(on)
+
     # -- vae.py:34-40
     def encode_images(self, images: torch.Tensor, posterior_noise: Optional[torch.Tensor] = None) -> torch.Tensor:
         moments = _VAEEncode.apply(images, self.vae)

@@ -31,6 +31,8 @@ class GaussianRasterizationSettings(NamedTuple):
     debug: bool
 
 
+ASYNC = [False]        # True: no per-frame host sync (pair-buffer capacity from the previous frame; bench / training loop)
+_async_state = {}
 LAST_NUM_PAIRS = [0]   # (Gaussian, tile) pair count of the most recent forward (bench.py's roofline bytes)
 
 
@@ -93,10 +95,29 @@ class _RasterizeGaussians(torch.autograd.Function):
         _lib.check(L.dwg_raster_forward_bin(ctypes.byref(cfg), G, p(means3D), p(sh), p(colors_precomp), p(opac),
                                             p(scales), p(rotations), p(cov3D), p(radii), p(ws_geom), st),
                    "dwg_raster_forward_bin")
-        # one 4-byte read-back sizes the pair buffers (the reference's extension does the same D2H copy)
-        K = int(ws_geom[:4].view(torch.int32).item())
-        LAST_NUM_PAIRS[0] = K
-        cap = max(K, 1)
+        if ASYNC[0] and _async_state.get("cap", 0) > 0:
+            # no host synchronisation: size the pair buffers from the previous frames' pair count (with head-room) and
+            # check the recorded count / overflow flag of the PREVIOUS call, which has long completed
+            st = _async_state
+            if st.get("event") is not None:
+                st["event"].synchronize()
+                kprev, ovf = int(st["host"][0]), int(st["host"][1])
+                LAST_NUM_PAIRS[0] = kprev
+                if ovf or kprev * 5 > st["cap"] * 4:
+                    st["cap"] = max(st["cap"], int(kprev * 2))
+                    if ovf:
+                        import warnings
+                        warnings.warn("dreamwaltz_g_amd rasterizer: pair capacity overflow in the previous frame; capacity grown")
+            cap = st["cap"]
+            K = -1
+        else:
+            # one 4-byte read-back sizes the pair buffers (the reference's extension does the same D2H copy)
+            K = int(ws_geom[:4].view(torch.int32).item())
+            LAST_NUM_PAIRS[0] = K
+            cap = max(K, 1)
+            if ASYNC[0]:
+                _async_state["cap"] = max(int(K * 2), 1024)
+                _async_state["host"] = torch.zeros(2, dtype=torch.int32).pin_memory()
         _lib.check(L.dwg_raster_workspace_sizes(G, H, W, cap, ctypes.byref(gb), ctypes.byref(pb), ctypes.byref(ib)),
                    "dwg_raster_workspace_sizes")
         ws_pairs = torch.empty(pb.value, dtype=torch.uint8, device=device)
@@ -105,6 +126,11 @@ class _RasterizeGaussians(torch.autograd.Function):
         alpha = torch.empty(1, H, W, dtype=torch.float32, device=device)
         _lib.check(L.dwg_raster_forward_render(ctypes.byref(cfg), G, p(ws_geom), p(ws_pairs), cap, p(ws_image),
                                                p(color), p(depth), p(alpha), st), "dwg_raster_forward_render")
+        if ASYNC[0]:
+            st2 = _async_state
+            st2["host"].copy_(ws_geom[:8].view(torch.int32), non_blocking=True)
+            ev = torch.cuda.Event(); ev.record(torch.cuda.current_stream(device))
+            st2["event"] = ev
         ctx.raster_settings = raster_settings
         ctx.cap = cap
         ctx.num_pairs = K

@@ -210,6 +210,8 @@ class Plan:
         self.ops = []
         self.keep = []          # descriptors / tensors kept alive
         self.tags = []
+        self.graph = None
+        self.use_graph = True
         self.flops = {}         # algorithmic flops per kernel label (2*M*N*K*batch), for the roofline report
         self._lib = _lib.lib()
 
@@ -242,12 +244,35 @@ class Plan:
     def add_py(self, f):
         self.ops.append(lambda s, f=f: (f(), 0)[1])
 
-    def run(self):
+    def run_eager(self):
         s = ctypes.c_void_p(torch.cuda.current_stream(self.device).cuda_stream)
         for op in self.ops:
             rc = op(s)
             if rc:
                 raise RuntimeError("plan op failed with DWG error %s" % rc)
+
+    def capture(self):
+        """Capture the whole plan into one hipGraph (launch-bound inner loop -> a single replay per step)."""
+        if self.graph is not None:
+            return
+        _lib.prof_enable(False)
+        cur = torch.cuda.current_stream(self.device)
+        side = torch.cuda.Stream(device=self.device)
+        side.wait_stream(cur)
+        with torch.cuda.stream(side):
+            self.run_eager()            # warm-up outside capture (lazy attribute / module initialisation)
+        cur.wait_stream(side)
+        torch.cuda.synchronize(self.device)
+        g = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(g):
+            self.run_eager()
+        self.graph = g
+
+    def run(self):
+        if self.graph is not None and self.use_graph:
+            self.graph.replay()
+        else:
+            self.run_eager()
 
     def run_debug(self):
         """Runs op by op and reports the first op after which any plan buffer holds a non-finite value (DWG_PLAN_ZERO=1)."""

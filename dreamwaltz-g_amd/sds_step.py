@@ -113,7 +113,16 @@ class SDSStep:
         self.opt = FlatAdam(groups, self.device)
         self.step_idx = 0
         self.num_pairs = 0
+        rasterizer.ASYNC[0] = True       # training loop: no host sync for the pair count (checked one frame late)
         torch.manual_seed(1234 + rank)
+
+    def capture_graphs(self):
+        if self.guidance is not None:
+            self.guidance.capture_graphs()
+
+    def set_use_graphs(self, on):
+        if self.guidance is not None:
+            self.guidance.set_use_graphs(on)
 
     def run(self):
         self.opt.zero_grad()
