@@ -62,6 +62,14 @@ SIGNATURES = {
                                              _vp, _i64, _i64, _f32, _vp]),
     "dwg_softmax_rows_forward": (ctypes.c_int, [_i32, _i32, _f32, _vp, _i64, _vp, _i64, _vp]),
     "dwg_softmax_rows_backward": (ctypes.c_int, [_i32, _i32, _f32, _vp, _i64, _vp, _i64, _vp, _i64, _vp]),
+    "dwg_concat_channels": (ctypes.c_int, [_i64, _i32, _i32, _vp, _vp, _vp, _vp]),
+    "dwg_add_bf16": (ctypes.c_int, [_i64, _vp, _vp, _vp, _vp]),
+    "dwg_cast_f32_to_bf16": (ctypes.c_int, [_i64, _vp, _vp, _vp]),
+    # include/dwg_graph.h
+    "dwg_graph_begin_capture": (ctypes.c_int, [_vp]),
+    "dwg_graph_end_capture": (ctypes.c_int, [_vp, ctypes.POINTER(_vp)]),
+    "dwg_graph_launch": (ctypes.c_int, [_vp, _vp]),
+    "dwg_graph_destroy": (ctypes.c_int, [_vp]),
     # include/dwg_prof.h
     "dwg_prof_enable": (ctypes.c_int, [_i32]),
     "dwg_prof_query": (ctypes.c_int, [ctypes.c_char_p, ctypes.POINTER(_i64), ctypes.POINTER(ctypes.c_double)]),

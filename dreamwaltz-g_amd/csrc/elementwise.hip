@@ -71,9 +71,67 @@ __global__ __launch_bounds__(256) void k_adam(size_t n, float* __restrict__ p, c
     }
 }
 
+typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8_t;
+
+// out[r][0:Ca] = a[r], out[r][Ca:Ca+Cb] = b[r]   (channel concat of two NHWC bf16 tensors; Ca, Cb multiples of 8)
+__global__ __launch_bounds__(256) void k_concat_channels(long long rows, int Ca, int Cb, const __bf16* __restrict__ a,
+                                                         const __bf16* __restrict__ b, __bf16* __restrict__ out) {
+    const int C8 = (Ca + Cb) / 8, A8 = Ca / 8;
+    const long long n = rows * C8;
+    for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long long)gridDim.x * 256) {
+        long long r = i / C8; int c = (int)(i - r * C8);
+        bf16x8_t v = c < A8 ? *reinterpret_cast<const bf16x8_t*>(a + r * Ca + (long long)c * 8)
+                            : *reinterpret_cast<const bf16x8_t*>(b + r * Cb + (long long)(c - A8) * 8);
+        *reinterpret_cast<bf16x8_t*>(out + r * (Ca + Cb) + (long long)c * 8) = v;
+    }
+}
+
+// out = a + b (bf16, n % 8 == 0)
+__global__ __launch_bounds__(256) void k_add_bf16(long long n8, const __bf16* __restrict__ a, const __bf16* __restrict__ b,
+                                                  __bf16* __restrict__ out) {
+    for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < n8; i += (long long)gridDim.x * 256) {
+        bf16x8_t x = reinterpret_cast<const bf16x8_t*>(a)[i], y = reinterpret_cast<const bf16x8_t*>(b)[i], o;
+#pragma unroll
+        for (int e = 0; e < 8; e++) o[e] = (__bf16)((float)x[e] + (float)y[e]);
+        reinterpret_cast<bf16x8_t*>(out)[i] = o;
+    }
+}
+
+__global__ __launch_bounds__(256) void k_cast_f32_bf16(long long n, const float* __restrict__ src, __bf16* __restrict__ dst) {
+    for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long long)gridDim.x * 256) dst[i] = (__bf16)src[i];
+}
+
+static int grid_for(long long n) { long long b = (n + 255) / 256; if (b < 1) b = 1; if (b > 4096) b = 4096; return (int)b; }
+
 }  // namespace
 
 extern "C" {
+
+int dwg_concat_channels(int64_t rows, int32_t Ca, int32_t Cb, const void* a, const void* b, void* out, dwg_stream_t stream) {
+    if (rows < 0 || Ca <= 0 || Cb <= 0 || Ca % 8 || Cb % 8 || !a || !b || !out) return DWG_E_ARG;
+    if (rows == 0) return DWG_OK;
+    DWG_LAUNCH("concat_channels", k_concat_channels, dim3(grid_for(rows * ((Ca + Cb) / 8))), dim3(256), 0, (hipStream_t)stream,
+               (long long)rows, Ca, Cb, (const __bf16*)a, (const __bf16*)b, (__bf16*)out);
+    DWG_RETURN_IF_LAUNCH_FAILED();
+    return DWG_OK;
+}
+
+int dwg_add_bf16(int64_t n, const void* a, const void* b, void* out, dwg_stream_t stream) {
+    if (n < 0 || n % 8 || !a || !b || !out) return DWG_E_ARG;
+    if (n == 0) return DWG_OK;
+    DWG_LAUNCH("add_bf16", k_add_bf16, dim3(grid_for(n / 8)), dim3(256), 0, (hipStream_t)stream, (long long)(n / 8), (const __bf16*)a,
+               (const __bf16*)b, (__bf16*)out);
+    DWG_RETURN_IF_LAUNCH_FAILED();
+    return DWG_OK;
+}
+
+int dwg_cast_f32_to_bf16(int64_t n, const float* src, void* dst, dwg_stream_t stream) {
+    if (n < 0 || !src || !dst) return DWG_E_ARG;
+    if (n == 0) return DWG_OK;
+    DWG_LAUNCH("cast_f32_bf16", k_cast_f32_bf16, dim3(grid_for(n)), dim3(256), 0, (hipStream_t)stream, (long long)n, src, (__bf16*)dst);
+    DWG_RETURN_IF_LAUNCH_FAILED();
+    return DWG_OK;
+}
 
 int dwg_act_backward_colsum(int32_t M, int32_t N, int32_t act, const float* dy, const float* y, float* dz, float* colsum,
                             dwg_stream_t stream) {

@@ -98,17 +98,17 @@ class _RasterizeGaussians(torch.autograd.Function):
         if ASYNC[0] and _async_state.get("cap", 0) > 0:
             # no host synchronisation: size the pair buffers from the previous frames' pair count (with head-room) and
             # check the recorded count / overflow flag of the PREVIOUS call, which has long completed
-            st = _async_state
-            if st.get("event") is not None:
-                st["event"].synchronize()
-                kprev, ovf = int(st["host"][0]), int(st["host"][1])
+            ast = _async_state
+            if ast.get("event") is not None:
+                ast["event"].synchronize()
+                kprev, ovf = int(ast["host"][0]), int(ast["host"][1])
                 LAST_NUM_PAIRS[0] = kprev
-                if ovf or kprev * 5 > st["cap"] * 4:
-                    st["cap"] = max(st["cap"], int(kprev * 2))
+                if ovf or kprev * 5 > ast["cap"] * 4:
+                    ast["cap"] = max(ast["cap"], int(kprev * 2))
                     if ovf:
                         import warnings
                         warnings.warn("dreamwaltz_g_amd rasterizer: pair capacity overflow in the previous frame; capacity grown")
-            cap = st["cap"]
+            cap = ast["cap"]
             K = -1
         else:
             # one 4-byte read-back sizes the pair buffers (the reference's extension does the same D2H copy)

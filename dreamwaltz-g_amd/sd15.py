@@ -212,6 +212,7 @@ class Plan:
         self.tags = []
         self.graph = None
         self.use_graph = True
+        self.has_py_ops = False
         self.flops = {}         # algorithmic flops per kernel label (2*M*N*K*batch), for the roofline report
         self._lib = _lib.lib()
 
@@ -242,6 +243,7 @@ class Plan:
         self.ops.append(lambda s, fn=fn, args=args: fn(*args, s))
 
     def add_py(self, f):
+        self.has_py_ops = True
         self.ops.append(lambda s, f=f: (f(), 0)[1])
 
     def run_eager(self):
@@ -252,25 +254,32 @@ class Plan:
                 raise RuntimeError("plan op failed with DWG error %s" % rc)
 
     def capture(self):
-        """Capture the whole plan into one hipGraph (launch-bound inner loop -> a single replay per step)."""
+        """Record the whole plan into one hipGraph (launch-bound inner loop -> a single hipGraphLaunch per step).  The plan
+        contains only dwg_* launches on caller-owned buffers, so the capture needs nothing from the PyTorch allocator."""
         if self.graph is not None:
             return
+        assert not self.has_py_ops, "plans with Python ops cannot be captured"
         _lib.prof_enable(False)
-        cur = torch.cuda.current_stream(self.device)
-        side = torch.cuda.Stream(device=self.device)
-        side.wait_stream(cur)
-        with torch.cuda.stream(side):
-            self.run_eager()            # warm-up outside capture (lazy attribute / module initialisation)
-        cur.wait_stream(side)
+        self.run_eager()                    # warm-up (lazy kernel attribute initialisation) outside the capture
         torch.cuda.synchronize(self.device)
-        g = torch.cuda.CUDAGraph()
-        with torch.cuda.graph(g):
-            self.run_eager()
-        self.graph = g
+        self._cap_stream = torch.cuda.Stream(device=self.device)
+        s = ctypes.c_void_p(self._cap_stream.cuda_stream)
+        _lib.check(self._lib.dwg_graph_begin_capture(s), "dwg_graph_begin_capture")
+        try:
+            for op in self.ops:
+                rc = op(s)
+                if rc:
+                    raise RuntimeError("plan op failed during capture with DWG error %s" % rc)
+        finally:
+            h = ctypes.c_void_p()
+            rc = self._lib.dwg_graph_end_capture(s, ctypes.byref(h))
+        _lib.check(rc, "dwg_graph_end_capture")
+        self.graph = h
 
     def run(self):
         if self.graph is not None and self.use_graph:
-            self.graph.replay()
+            s = ctypes.c_void_p(torch.cuda.current_stream(self.device).cuda_stream)
+            _lib.check(self._lib.dwg_graph_launch(self.graph, s), "dwg_graph_launch")
         else:
             self.run_eager()
 
@@ -428,13 +437,22 @@ class Builder:
         return o
 
     def cat(self, a, b):
-        y = self.p.buf(*a.shape[:-1], a.shape[-1] + b.shape[-1])
-        self.p.add_py(lambda: torch.cat([a, b], dim=-1, out=y))
+        Ca, Cb = a.shape[-1], b.shape[-1]
+        y = self.p.buf(*a.shape[:-1], Ca + Cb)
+        pp = lambda t: ctypes.c_void_p(t.data_ptr())  # noqa: E731
+        self.p.add_call(self.L.dwg_concat_channels, a.numel() // Ca, Ca, Cb, pp(a), pp(b), pp(y))
         return y
 
     def add(self, a, b):
         y = self.p.buf(*a.shape)
-        self.p.add_py(lambda: torch.add(a, b, out=y))
+        pp = lambda t: ctypes.c_void_p(t.data_ptr())  # noqa: E731
+        self.p.add_call(self.L.dwg_add_bf16, a.numel(), pp(a), pp(b), pp(y))
+        return y
+
+    def cast_bf16(self, x):
+        y = self.p.buf(*x.shape)
+        pp = lambda t: ctypes.c_void_p(t.data_ptr())  # noqa: E731
+        self.p.add_call(self.L.dwg_cast_f32_to_bf16, x.numel(), pp(x), pp(y))
         return y
 
     # -- blocks ----------------------------------------------------------------------------------------------------
@@ -700,8 +718,7 @@ class VAEEncoderPlan:
             dn = r.p.buf(B, N, C, dtype=torch.float32)   # dn = dq Wq + dk Wk + dv Wv (fp32 accumulate across the three products)
             for i, (g_, wt) in enumerate(((dq, wq), (dk, wk), (dv, wv))):
                 r.p.add_gemm(gemm.gemm_raw(g_, wt, dn, N, C, C, (C, 1), (1, C), C, accumulate=i > 0, name="vae_bwd_dn", run=False))
-            dnb = r.p.buf(B, H, W, C)
-            r.p.add_py(lambda: dnb.copy_(dn.view(B, H, W, C)))
+            dnb = r.cast_bf16(dn).view(B, H, W, C)
             dx = r.groupnorm_bwd(x, dnb, st, pre + ".group_norm", 1e-6, False)
             return r.add(dx, dout)
         tape.append(back)

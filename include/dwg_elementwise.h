@@ -25,6 +25,13 @@ int dwg_act_backward_colsum(int32_t M, int32_t N, int32_t act, const float* dy, 
 int dwg_adam_step(int64_t n, float* param, const float* grad, float* exp_avg, float* exp_avg_sq, float lr, float beta1,
                   float beta2, float eps, int32_t step, float grad_scale, dwg_stream_t stream);
 
+/* NHWC channel concat (torch.cat([h, skip], 1) of the UNet up blocks): out[r] = [a[r] | b[r]], bf16, Ca % 8 == Cb % 8 == 0. */
+int dwg_concat_channels(int64_t rows, int32_t Ca, int32_t Cb, const void* a, const void* b, void* out, dwg_stream_t stream);
+/* out = a + b on bf16 buffers (n % 8 == 0): gradient joins of the VAE-encoder backward. */
+int dwg_add_bf16(int64_t n, const void* a, const void* b, void* out, dwg_stream_t stream);
+/* fp32 -> bf16 copy. */
+int dwg_cast_f32_to_bf16(int64_t n, const float* src, void* dst, dwg_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif
