@@ -79,6 +79,7 @@ def main():
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         dist.init_process_group("nccl", device_id=torch.device("cuda", local))
     dev = torch.device("cuda", local)
+    torch.cuda.set_stream(torch.cuda.Stream(device=dev))   # one real (non-default) HIP stream for the whole step: graph-safe
     step = sds_step.SDSStep(n_gaussians=args.gaussians, res=args.res, device=dev, rank=rank, world=world,
                             guidance=not args.no_guidance, dist=dist)
     if not args.eager:

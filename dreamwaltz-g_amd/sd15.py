@@ -278,8 +278,14 @@ class Plan:
 
     def run(self):
         if self.graph is not None and self.use_graph:
-            s = ctypes.c_void_p(torch.cuda.current_stream(self.device).cuda_stream)
-            _lib.check(self._lib.dwg_graph_launch(self.graph, s), "dwg_graph_launch")
+            cur = torch.cuda.current_stream(self.device).cuda_stream
+            if cur == 0:
+                # hipGraphLaunch into the legacy default stream is NOT ordered against work already queued there (ROCm 7.2:
+                # wrong results unless the device is idle).  Callers that want graph replay run under a real stream
+                # (torch.cuda.set_stream(torch.cuda.Stream())); on the default stream the plan silently stays eager.
+                self.run_eager()
+                return
+            _lib.check(self._lib.dwg_graph_launch(self.graph, ctypes.c_void_p(cur)), "dwg_graph_launch")
         else:
             self.run_eager()
 

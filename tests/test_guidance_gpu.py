@@ -112,6 +112,7 @@ def test_graph_replay_matches_eager():
         return out["gradients"].clone(), ic.grad.clone()
     g0, i0 = once()
     gd.capture_graphs()
+    torch.cuda.set_stream(torch.cuda.Stream())     # graph replay needs a real stream (see Plan.run)
     gc.collect(); torch.cuda.empty_cache()
     junk = torch.randn(64, 1024, 1024, device=dev); del junk
     for _ in range(3):
@@ -121,3 +122,5 @@ def test_graph_replay_matches_eager():
     gd.set_use_graphs(False)
     g2, i2 = once()
     assert _rel(g2, g0) < 0.15 and _rel(i2, i0) < 0.15
+    torch.cuda.synchronize()
+    torch.cuda.set_stream(torch.cuda.default_stream())

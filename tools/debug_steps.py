@@ -5,9 +5,13 @@ import torch
 import dwg_import  # noqa
 from dreamwaltz_g_amd import sds_step, rasterizer
 step = sds_step.SDSStep(n_gaussians=100000, res=512, device=torch.device("cuda"))
-rasterizer.ASYNC[0] = False
+mode = sys.argv[1] if len(sys.argv) > 1 else "sync"
+rasterizer.ASYNC[0] = ("async" in mode)
+if "graph" in mode:
+    step.capture_graphs()
+print("mode", mode)
 names = ["pos", "scales", "quats", "table", "mlps", "mesh"]
-for i in range(14):
+for i in range(8):
     step.run()
     torch.cuda.synchronize()
     g = step.opt.grad
