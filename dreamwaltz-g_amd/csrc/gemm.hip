@@ -237,6 +237,31 @@ __device__ __forceinline__ void epilogue_store(const GemmP& p, float v, int row,
     else reinterpret_cast<float*>(p.C)[ci] = v;
 }
 
+template <int TM, int TN>
+__device__ __forceinline__ void tile_epilogue(const GemmP& p, f32x16 (&acc)[TM][TN], int m0, int n0, int wm, int wn, int lane,
+                                              int ks_id, int z1, int z2) {
+    const long long coff = z1 * p.bC1 + z2 * p.bC2, roff = z1 * p.bR1 + z2 * p.bR2;
+#pragma unroll
+    for (int i = 0; i < TM; i++)
+#pragma unroll
+        for (int j = 0; j < TN; j++) {
+            const int col = n0 + wn * 64 + j * 32 + (lane & 31);
+            if (col >= p.N) continue;
+#pragma unroll
+            for (int r = 0; r < 16; r++) {
+                const int row = m0 + (wm * TM + i) * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+                if (row >= p.M) continue;
+                float v = acc[i][j][r] * p.alpha;
+                if (p.splitk > 1) {
+                    if (p.ws) p.ws[((long long)ks_id * p.M + row) * p.N + col] = v;          // slab, reduced by k_splitk_epilogue
+                    else atomicAdd(reinterpret_cast<float*>(p.C) + coff + (long long)row * p.ldc + col, v);
+                    continue;
+                }
+                epilogue_store(p, v, row, col, coff, roff);
+            }
+        }
+}
+
 template <typename T, int BN, int AMODE, int BMODE>
 __global__ __launch_bounds__(256) void k_gemm(GemmP p) {
     constexpr int BM = 128, BK = TT<T>::BK, LDT = BK + TT<T>::PAD;
@@ -295,27 +320,7 @@ __global__ __launch_bounds__(256) void k_gemm(GemmP p) {
         if (kt + 1 < nk) { la.store(sA + (cur ^ 1) * BM * LDT); lb.store(sB + (cur ^ 1) * BN * LDT); }
         __syncthreads();
     }
-    // epilogue
-    const long long coff = z1 * p.bC1 + z2 * p.bC2, roff = z1 * p.bR1 + z2 * p.bR2;
-#pragma unroll
-    for (int i = 0; i < TM; i++)
-#pragma unroll
-        for (int j = 0; j < TN; j++) {
-            const int col = n0 + wn * 64 + j * 32 + (lane & 31);
-            if (col >= p.N) continue;
-#pragma unroll
-            for (int r = 0; r < 16; r++) {
-                const int row = m0 + (wm * TM + i) * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
-                if (row >= p.M) continue;
-                float v = acc[i][j][r] * p.alpha;
-                if (p.splitk > 1) {
-                    if (p.ws) p.ws[((long long)ks_id * p.M + row) * p.N + col] = v;          // slab, reduced by k_splitk_epilogue
-                    else atomicAdd(reinterpret_cast<float*>(p.C) + coff + (long long)row * p.ldc + col, v);
-                    continue;
-                }
-                epilogue_store(p, v, row, col, coff, roff);
-            }
-        }
+    tile_epilogue<TM, TN>(p, acc, m0, n0, wm, wn, lane, ks_id, z1, z2);
 }
 
 // sums the split-K slabs and applies the fused epilogue (batch == 1)
@@ -326,6 +331,162 @@ __global__ __launch_bounds__(256) void k_splitk_epilogue(GemmP p) {
         for (int s = 0; s < p.splitk; s++) v += p.ws[(long long)s * n + i];
         int row = (int)(i / p.N), col = (int)(i - (long long)row * p.N);
         epilogue_store(p, v, row, col, 0, 0);
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------------------------
+// bf16 fast path: operands go HBM/L2 -> LDS directly (global_load_lds_dwordx4, no VGPR staging, no ds_write pass).
+// The LDS image of a tile is lane-linear per wave-instruction (8 rows x 128 B), so bank conflicts are avoided by an XOR
+// swizzle applied on the SOURCE side: LDS slot (row, c) holds logical 16-byte chunk c ^ (row & 7); readers apply the same XOR.
+// Halo / out-of-range chunks are sourced from a 16-byte zero page.
+// ---------------------------------------------------------------------------------------------------------------------
+__device__ __attribute__((aligned(16))) unsigned char g_zero16[16];
+
+template <int ROWS, bool CONV>
+struct GldsLoader {
+    static constexpr int NJ = ROWS / 32;       // wave-instructions per wave per tile (each covers 8 rows)
+    const __bf16* rowptr[CONV ? 1 : NJ];
+    int iy0[CONV ? NJ : 1], ix0[CONV ? NJ : 1];
+    long long pix0[CONV ? NJ : 1];
+    bool rok[CONV ? NJ : 1];
+    const __bf16* base;
+    int kcur, kend, ci, ky, kx;
+
+    __device__ __forceinline__ void init(const __bf16* base_, long long srow, int nrows, int r0, int kbeg, int kend_, const ConvP& cv) {
+        base = base_; kend = kend_;
+        const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, sub = lane >> 3;
+        const int logical = (lane & 7) ^ sub;              // row & 7 == sub for every row this lane loads
+        kcur = kbeg + logical * 8;
+        if (!CONV) {
+#pragma unroll
+            for (int j = 0; j < NJ; j++) {
+                int r = r0 + (wave * NJ + j) * 8 + sub;
+                rowptr[j] = r < nrows ? base + (long long)r * srow : nullptr;
+            }
+        } else {
+            const int hw = cv.Hout * cv.Wout;
+#pragma unroll
+            for (int j = 0; j < NJ; j++) {
+                int r = r0 + (wave * NJ + j) * 8 + sub;
+                rok[j] = r < nrows;
+                int rr = rok[j] ? r : 0;
+                int img = rr / hw, rem = rr - img * hw;
+                int oy = rem / cv.Wout, ox = rem - oy * cv.Wout;
+                iy0[j] = oy * cv.stride - cv.pad_t; ix0[j] = ox * cv.stride - cv.pad_l;
+                pix0[j] = (long long)img * cv.Hin * cv.Win;
+            }
+            int tap = kcur / cv.Cin;
+            ci = kcur - tap * cv.Cin; ky = tap / cv.KW; kx = tap - ky * cv.KW;
+        }
+    }
+    __device__ __forceinline__ void advance(const ConvP& cv) {
+        kcur += 64;
+        if (CONV) {
+            ci += 64;
+            while (ci >= cv.Cin) { ci -= cv.Cin; if (++kx == cv.KW) { kx = 0; ++ky; } }
+        }
+    }
+    // lds_tile: byte address of this operand's tile in LDS (workgroup-uniform)
+    __device__ __forceinline__ void issue(unsigned char* lds_tile, const ConvP& cv) {
+        const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+        const bool kok = kcur < kend;
+        const __bf16* zero = reinterpret_cast<const __bf16*>(g_zero16);
+        const __bf16* src0 = base; int cs = 0, co = 0;
+        if (CONV) {
+            src0 = ci < cv.cin1 ? base : reinterpret_cast<const __bf16*>(cv.A2);
+            cs = ci < cv.cin1 ? cv.cin1 : (cv.Cin - cv.cin1);
+            co = ci < cv.cin1 ? ci : ci - cv.cin1;
+        }
+#pragma unroll
+        for (int j = 0; j < NJ; j++) {
+            const __bf16* src;
+            if (!CONV) {
+                src = (kok && rowptr[j]) ? rowptr[j] + kcur : zero;
+            } else {
+                int iy = iy0[j] + ky, ix = ix0[j] + kx;
+                bool ok = kok && rok[j] && iy >= 0 && ix >= 0;
+                if (cv.dil > 1) { ok = ok && (iy % cv.dil == 0) && (ix % cv.dil == 0); iy /= cv.dil; ix /= cv.dil; }
+                if (cv.up > 1) { iy >>= 1; ix >>= 1; }
+                ok = ok && iy < cv.Hin && ix < cv.Win;
+                src = ok ? src0 + (pix0[j] + (long long)iy * cv.Win + ix) * cs + co : zero;
+            }
+            unsigned char* dst = lds_tile + ((wave * NJ + j) * 8) * 128;
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
+                                             (__attribute__((address_space(3))) void*)dst, 16, 0, 0);
+        }
+    }
+};
+
+template <int BN, bool CONV>
+__global__ __launch_bounds__(256) void k_gemm_glds(GemmP p) {
+    constexpr int BM = 128;
+    constexpr int WN = BN / 64, WM = 4 / WN, TM = BM / WM / 32, TN = 2;
+    constexpr int ABYTES = BM * 128, BBYTES = BN * 128, STAGE = ABYTES + BBYTES;
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];     // [2][A tile | B tile], rows of 128 B
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wm = wave / WN, wn = wave % WN;
+    const int m0 = blockIdx.x * BM;
+    const int ntn = (p.N + BN - 1) / BN;
+    const int n0 = (blockIdx.y % ntn) * BN;
+    const int ks_id = blockIdx.y / ntn;
+    const int z = blockIdx.z, z1 = z / p.nb2, z2 = z - z1 * p.nb2;
+    const __bf16* A = reinterpret_cast<const __bf16*>(p.A) + z1 * p.bA1 + z2 * p.bA2;
+    const __bf16* B = reinterpret_cast<const __bf16*>(p.B) + z1 * p.bB1 + z2 * p.bB2;
+    int kbeg = 0, kend = p.K;
+    if (p.splitk > 1) {
+        int per = ((p.K + p.splitk - 1) / p.splitk + 63) / 64 * 64;
+        kbeg = ks_id * per; kend = min(p.K, kbeg + per);
+    }
+    f32x16 acc[TM][TN];
+#pragma unroll
+    for (int i = 0; i < TM; i++)
+#pragma unroll
+        for (int j = 0; j < TN; j++)
+#pragma unroll
+            for (int r = 0; r < 16; r++) acc[i][j][r] = 0.f;
+    GldsLoader<BM, CONV> la;
+    GldsLoader<BN, false> lb;
+    la.init(A, p.sam, p.M, m0, kbeg, kend, p.conv);
+    lb.init(B, p.sbn, p.N, n0, kbeg, kend, p.conv);
+    const int nk = kend > kbeg ? (kend - kbeg + 63) / 64 : 0;
+    if (nk > 0) { la.issue(smem_raw, p.conv); lb.issue(smem_raw + ABYTES, p.conv); }
+    // fragment addressing: row r, logical chunk cl -> byte r*128 + ((cl ^ (r & 7)) << 4); here r & 7 == lane & 7
+    const int frow = lane & 31, fx = lane & 7, fh = lane >> 5;
+    for (int kt = 0; kt < nk; kt++) {
+        const int cur = kt & 1;
+        __syncthreads();                    // tile kt has landed (vmcnt(0) + barrier); buffer cur^1 is free again
+        if (kt + 1 < nk) {
+            la.advance(p.conv); lb.advance(p.conv);
+            la.issue(smem_raw + (cur ^ 1) * STAGE, p.conv); lb.issue(smem_raw + (cur ^ 1) * STAGE + ABYTES, p.conv);
+        }
+        const unsigned char* ta = smem_raw + cur * STAGE + (wm * TM * 32 + frow) * 128;
+        const unsigned char* tb = smem_raw + cur * STAGE + ABYTES + (wn * 64 + frow) * 128;
+#pragma unroll
+        for (int ks = 0; ks < 4; ks++) {
+            const int off = (((ks * 2 + fh) ^ fx) << 4);
+            bf16x8 af[TM], bf[TN];
+#pragma unroll
+            for (int i = 0; i < TM; i++) af[i] = *reinterpret_cast<const bf16x8*>(ta + i * 32 * 128 + off);
+#pragma unroll
+            for (int j = 0; j < TN; j++) bf[j] = *reinterpret_cast<const bf16x8*>(tb + j * 32 * 128 + off);
+#pragma unroll
+            for (int i = 0; i < TM; i++)
+#pragma unroll
+                for (int j = 0; j < TN; j++) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[i], bf[j], acc[i][j], 0, 0, 0);
+        }
+    }
+    tile_epilogue<TM, TN>(p, acc, m0, n0, wm, wn, lane, ks_id, z1, z2);
+}
+
+template <int BN, bool CONV>
+static void launch_glds(const GemmP& p, int batch, hipStream_t stream, const char* name) {
+    size_t lds = (size_t)2 * (128 + BN) * 128;
+    dim3 grid((p.M + 127) / 128, ((p.N + BN - 1) / BN) * (p.splitk > 1 ? p.splitk : 1), batch);
+    DWG_LAUNCH(name, (k_gemm_glds<BN, CONV>), grid, dim3(256), lds, stream, p);
+    if (p.splitk > 1 && p.ws) {
+        long long n = (long long)p.M * p.N;
+        int blocks = (int)((n + 255) / 256); if (blocks > 2048) blocks = 2048;
+        DWG_LAUNCH("splitk_epilogue", k_splitk_epilogue, dim3(blocks), dim3(256), 0, stream, p);
     }
 }
 
@@ -445,7 +606,11 @@ int dwg_gemm(const dwg_gemm_desc* d, dwg_stream_t stream_) {
             amode = MODE_CONV;
         } else amode = pick_mode<T>(p.A, p.sam, p.sak, p.M, p.K, ao, 2);
         bmode = pick_mode<T>(p.B, p.sbn, p.sbk, p.N, p.K, bo, 2);
-        if (narrow) dispatch_a<T, 64>(p, amode, bmode, batch, stream, name);
+        const bool glds_ok = bmode == MODE_KVEC && (amode == MODE_KVEC || amode == MODE_CONV) && !d->force_register_staging;
+        if (glds_ok) {
+            if (narrow) { if (amode == MODE_CONV) launch_glds<64, true>(p, batch, stream, name); else launch_glds<64, false>(p, batch, stream, name); }
+            else { if (amode == MODE_CONV) launch_glds<128, true>(p, batch, stream, name); else launch_glds<128, false>(p, batch, stream, name); }
+        } else if (narrow) dispatch_a<T, 64>(p, amode, bmode, batch, stream, name);
         else dispatch_a<T, 128>(p, amode, bmode, batch, stream, name);
     } else {
         typedef float T;

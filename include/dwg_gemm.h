@@ -63,6 +63,7 @@ typedef struct dwg_gemm_desc {
     int64_t bias_ld;          /* row stride of that bias matrix in elements (0 -> N) */
     void* workspace;          /* optional split-K slab workspace (device), see dwg_gemm_workspace_bytes */
     size_t workspace_bytes;
+    int32_t force_register_staging; /* != 0: use the register-staged kernel even where the direct-to-LDS path applies (A/B testing) */
     const char* name;         /* optional label for dwg_prof */
 } dwg_gemm_desc;
 
