@@ -41,7 +41,7 @@ SIGNATURES = {
     "dwg_lbs_joint_chain": (ctypes.c_int, [_i32, _vp, _vp, _vp, _vp, _vp, _vp, _i32, _vp, _vp, _vp]),
     "dwg_lbs_blend_forward": (ctypes.c_int, [_i32, _i32, _i32] + [_vp] * 7 + [_vp]),
     "dwg_lbs_blend_backward": (ctypes.c_int, [_i32] + [_vp] * 7 + [_vp]),
-    "dwg_lbs_vertex_transform": (ctypes.c_int, [_i32] * 5 + [_vp] * 9 + [_vp]),
+    "dwg_lbs_vertex_transform": (ctypes.c_int, [_i32] * 4 + [_vp] * 8 + [_vp]),
     # include/dwg_gridenc.h
     "dwg_grid_encode_forward": (ctypes.c_int, [_vp, _vp, _vp, _vp, _u32, _u32, _u32, _u32, _f32, _u32, _vp, _u32, _u32, _u32,
                                                _u32, _vp]),

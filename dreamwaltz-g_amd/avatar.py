@@ -105,6 +105,7 @@ class GeneralLinearBlendSkinning(nn.Module):
         self.register_buffer("joint_shape_dirs", torch.einsum('jv,vcl->jcl', self.J_regressor, shapedirs).contiguous())
         self.num_joints = self.J_regressor.shape[0]
         self.NUM_BODY_JOINTS = 21
+        self._subsets = {}
 
     def get_full_shape(self, betas=None, expression=None, extra_betas=None):
         betas = self.betas if betas is None else betas
@@ -137,9 +138,12 @@ class GeneralLinearBlendSkinning(nn.Module):
 
     @torch.no_grad()
     def transform_vertices(self, tr: LBSTransforms, vertex_indices, vertex_coords):
-        """transform_V.transform_points(vertex_coords, indices=...) (avatar.py:1570,1577)."""
-        return lbs_ops.vertex_transform(vertex_indices, vertex_coords, tr.A, self.lbs_weights, self.shapedirs_all,
-                                        tr.full_shape, self.posedirs, tr.rot_mats)
+        """transform_V.transform_points(vertex_coords, indices=...) (avatar.py:1570,1577).  The subset's blend-shape rows are
+        gathered once per distinct index tensor."""
+        key = (vertex_indices.data_ptr(), int(vertex_indices.numel()))
+        if key not in self._subsets:
+            self._subsets[key] = lbs_ops.gather_vertex_subset(vertex_indices, self.lbs_weights, self.shapedirs_all, self.posedirs)
+        return lbs_ops.vertex_transform(vertex_coords, tr.A, self._subsets[key], tr.full_shape, tr.rot_mats)
 
 
 # ----------------------------------------------------------------------------------------------------------------------

@@ -527,6 +527,7 @@ static void dispatch_a(const GemmP& p, int amode, int bmode, int batch, hipStrea
 static int auto_splitk(int M, int N, int K, int bn, int bk) {
     long long blocks = (long long)((M + 127) / 128) * ((N + bn - 1) / bn);
     if (blocks >= 192 || K < 8 * bk) return 1;
+    if (2.0 * M * N * K < 4.0e8) return 1;      // tiny products are launch-bound: a second (reduce) launch costs more than it buys
     long long sk = 256 / blocks;
     long long kmax = K / (4 * bk);
     if (sk > kmax) sk = kmax;

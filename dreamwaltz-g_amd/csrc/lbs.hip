@@ -156,55 +156,56 @@ __global__ __launch_bounds__(256) void k_blend_bwd(int N, const float* __restric
     if (HAS_Q) { for (int k = 0; k < 4; k++) gq[4 * i + k] = gqi[k]; }
 }
 
-// transform_V for a vertex subset: out = T_rigid(v) * (x + shape_off(v) + pose_off(v)) [+ transl already in A]
-__global__ __launch_bounds__(256) void k_vertex_transform(int Vp, int V, int J, int n_shape, int n_posefeat,
-                                                          const int* __restrict__ vidx, const float* __restrict__ x,
+// transform_V for a vertex subset: out = T_rigid(v) * (x + shape_off(v) + pose_off(v)) [transl already in A].
+// One wave per vertex; the blend-shape rows of the subset are gathered ONCE on the host side into vertex-major
+// [Vp, 3, S] / [Vp, 3, F] arrays, so every lane streams contiguous memory and the three dot products are wave reductions.
+__global__ __launch_bounds__(256) void k_vertex_transform(int Vp, int J, int S, int F, const float* __restrict__ x,
                                                           const float* __restrict__ A /*[J,16] incl. transl*/,
-                                                          const float* __restrict__ lbs_w /*[V,J]*/,
-                                                          const float* __restrict__ shapedirs /*[V,3,n_shape] or null*/,
-                                                          const float* __restrict__ shape /*[n_shape]*/,
-                                                          const float* __restrict__ posedirs /*[n_posefeat, 3V] or null*/,
+                                                          const float* __restrict__ w_sub /*[Vp,J]*/,
+                                                          const float* __restrict__ sdirs /*[Vp,3,S] or null*/,
+                                                          const float* __restrict__ shape /*[S]*/,
+                                                          const float* __restrict__ pdirs /*[Vp,3,F] or null*/,
                                                           const float* __restrict__ rot_mats /*[J,9]*/,
                                                           float* __restrict__ out) {
     __shared__ float sA[MAXJ * 12];
     __shared__ float sfeat[(MAXJ - 1) * 9];
-    const int tid = threadIdx.x;
+    const int tid = threadIdx.x, lane = tid & 63;
     for (int k = tid; k < J * 12; k += 256) { int j = k / 12, e = k - j * 12; sA[k] = A[16 * j + e]; }
-    for (int k = tid; k < n_posefeat; k += 256) {
+    for (int k = tid; k < F; k += 256) {
         int j = k / 9 + 1, e = k % 9;
         sfeat[k] = rot_mats[9 * j + e] - ((e == 0 || e == 4 || e == 8) ? 1.f : 0.f);
     }
     __syncthreads();
-    int t = blockIdx.x * 256 + tid;
+    const int t = blockIdx.x * 4 + (tid >> 6);
     if (t >= Vp) return;
-    int v = vidx[t];
-    float px = x[3 * t], py = x[3 * t + 1], pz = x[3 * t + 2];
-    if (shapedirs) {
-        const float* sd = shapedirs + (size_t)v * 3 * n_shape;
-        float o0 = 0.f, o1 = 0.f, o2 = 0.f;
-        for (int l = 0; l < n_shape; l++) { float b = shape[l]; o0 += sd[l] * b; o1 += sd[n_shape + l] * b; o2 += sd[2 * n_shape + l] * b; }
-        px += o0; py += o1; pz += o2;
+    float o[3] = {0.f, 0.f, 0.f};
+    if (sdirs) {
+        const float* sd = sdirs + (size_t)t * 3 * S;
+        for (int l = lane; l < S; l += 64) { float b = shape[l]; o[0] += sd[l] * b; o[1] += sd[S + l] * b; o[2] += sd[2 * S + l] * b; }
     }
-    if (posedirs) {
-        float o0 = 0.f, o1 = 0.f, o2 = 0.f;
-        const float* pd = posedirs + (size_t)3 * v;
-        for (int f = 0; f < n_posefeat; f++) {
-            float s = sfeat[f];
-            const float* r = pd + (size_t)f * 3 * V;
-            o0 += s * r[0]; o1 += s * r[1]; o2 += s * r[2];
-        }
-        px += o0; py += o1; pz += o2;
+    if (pdirs) {
+        const float* pd = pdirs + (size_t)t * 3 * F;
+        for (int f = lane; f < F; f += 64) { float sf = sfeat[f]; o[0] += pd[f] * sf; o[1] += pd[F + f] * sf; o[2] += pd[2 * F + f] * sf; }
     }
     float T[12];
+#pragma unroll
     for (int e = 0; e < 12; e++) T[e] = 0.f;
-    const float* wr = lbs_w + (size_t)v * J;
-    for (int j = 0; j < J; j++) {
+    const float* wr = w_sub + (size_t)t * J;
+    for (int j = lane; j < J; j += 64) {
         float wj = wr[j];
-        if (wj != 0.f) for (int e = 0; e < 12; e++) T[e] += wj * sA[j * 12 + e];
+#pragma unroll
+        for (int e = 0; e < 12; e++) T[e] += wj * sA[j * 12 + e];
     }
-    out[3 * t] = T[0] * px + T[1] * py + T[2] * pz + T[3];
-    out[3 * t + 1] = T[4] * px + T[5] * py + T[6] * pz + T[7];
-    out[3 * t + 2] = T[8] * px + T[9] * py + T[10] * pz + T[11];
+#pragma unroll
+    for (int c = 0; c < 3; c++) o[c] = dwg_wave_sum_all(o[c]);
+#pragma unroll
+    for (int e = 0; e < 12; e++) T[e] = dwg_wave_sum_all(T[e]);
+    if (lane == 0) {
+        float px = x[3 * t] + o[0], py = x[3 * t + 1] + o[1], pz = x[3 * t + 2] + o[2];
+        out[3 * t] = T[0] * px + T[1] * py + T[2] * pz + T[3];
+        out[3 * t + 1] = T[4] * px + T[5] * py + T[6] * pz + T[7];
+        out[3 * t + 2] = T[8] * px + T[9] * py + T[10] * pz + T[11];
+    }
 }
 
 }  // namespace
@@ -256,18 +257,17 @@ int dwg_lbs_blend_backward(int32_t N, const float* T12, const float* points, con
     return DWG_OK;
 }
 
-int dwg_lbs_vertex_transform(int32_t Vp, int32_t V, int32_t J, int32_t n_shape, int32_t n_posefeat,
-                             const int32_t* vertex_indices, const float* vertex_coords, const float* A,
-                             const float* lbs_weights, const float* shapedirs, const float* shape_coeffs,
-                             const float* posedirs, const float* rot_mats, float* out, dwg_stream_t stream) {
-    if (Vp < 0 || V <= 0 || J <= 0 || J > MAXJ || n_posefeat > (MAXJ - 1) * 9) return DWG_E_ARG;
+int dwg_lbs_vertex_transform(int32_t Vp, int32_t J, int32_t n_shape, int32_t n_posefeat, const float* vertex_coords,
+                             const float* A, const float* lbs_weights_sub, const float* shapedirs_sub, const float* shape_coeffs,
+                             const float* posedirs_sub, const float* rot_mats, float* out, dwg_stream_t stream) {
+    if (Vp < 0 || J <= 0 || J > MAXJ || n_posefeat > (MAXJ - 1) * 9) return DWG_E_ARG;
     if (Vp == 0) return DWG_OK;
-    if (!vertex_indices || !vertex_coords || !A || !lbs_weights || !out) return DWG_E_ARG;
-    if (shapedirs && !shape_coeffs) return DWG_E_ARG;
-    if (posedirs && !rot_mats) return DWG_E_ARG;
-    DWG_LAUNCH("lbs_vertex_transform", k_vertex_transform, dim3(dwg_cdiv(Vp, 256)), dim3(256), 0, (hipStream_t)stream, Vp, V, J, n_shape,
-                       posedirs ? n_posefeat : 0, vertex_indices, vertex_coords, A, lbs_weights, shapedirs, shape_coeffs,
-                       posedirs, rot_mats, out);
+    if (!vertex_coords || !A || !lbs_weights_sub || !out) return DWG_E_ARG;
+    if (shapedirs_sub && !shape_coeffs) return DWG_E_ARG;
+    if (posedirs_sub && !rot_mats) return DWG_E_ARG;
+    DWG_LAUNCH("lbs_vertex_transform", k_vertex_transform, dim3(dwg_cdiv(Vp, 4)), dim3(256), 0, (hipStream_t)stream, Vp, J, n_shape,
+               posedirs_sub ? n_posefeat : 0, vertex_coords, A, lbs_weights_sub, shapedirs_sub, shape_coeffs, posedirs_sub, rot_mats,
+               out);
     DWG_RETURN_IF_LAUNCH_FAILED();
     return DWG_OK;
 }

@@ -202,20 +202,24 @@ __global__ __launch_bounds__(256) void k_preprocess(Params p, const float* __res
                                                     const float* __restrict__ rots, const float* __restrict__ cov3Dp,
                                                     int* __restrict__ radii, float4* __restrict__ rec0,
                                                     float4* __restrict__ rec1, float4* __restrict__ rec2,
-                                                    uint2* __restrict__ rect, uint32_t* __restrict__ tile_count) {
+                                                    uint2* __restrict__ rect, uint32_t* __restrict__ tile_count, int use_lds_hist) {
     __shared__ float cam[32];
+    extern __shared__ uint32_t hist[];      // [T] block-private tile histogram (hot tiles: one global atomic per block, not per splat)
+    const int T = p.tiles_x * p.tiles_y;
     if (threadIdx.x < 16) cam[threadIdx.x] = p.view[threadIdx.x];
     else if (threadIdx.x < 32) cam[threadIdx.x] = p.proj[threadIdx.x - 16];
+    if (use_lds_hist) for (int t = threadIdx.x; t < T; t += 256) hist[t] = 0u;
     __syncthreads();
     int i = blockIdx.x * 256 + threadIdx.x;
-    if (i >= p.G) return;
+    const bool live_thread = i < p.G;
+    if (!live_thread) i = 0;
     const float* view = cam; const float* proj = cam + 16;
     float3 pos = make_float3(means3D[3 * i], means3D[3 * i + 1], means3D[3 * i + 2]);
     int radius = 0;
     uint2 rc = make_uint2(0u, 0u);
     float4 r0 = make_float4(0.f, 0.f, 0.f, 0.f), r1 = r0, r2 = r0;
     float3 pv = xform43(view, pos);
-    if (pv.z > 0.2f) {
+    if (live_thread && pv.z > 0.2f) {
         float4 ph = xform44(proj, pos);
         float pw = 1.f / (ph.w + 1e-7f);
         float ndcx = ph.x * pw, ndcy = ph.y * pw;
@@ -245,13 +249,22 @@ __global__ __launch_bounds__(256) void k_preprocess(Params p, const float* __res
                 r1 = make_float4(e.c * di, -e.b * di, e.a * di, 0.f);
                 r2 = make_float4(col.x, col.y, col.z, __uint_as_float(cb));
                 for (int ty = ty0; ty < ty1; ty++)
-                    for (int tx = tx0; tx < tx1; tx++) atomicAdd(&tile_count[ty * p.tiles_x + tx], 1u);
+                    for (int tx = tx0; tx < tx1; tx++) {
+                        if (use_lds_hist) atomicAdd(&hist[ty * p.tiles_x + tx], 1u);
+                        else atomicAdd(&tile_count[ty * p.tiles_x + tx], 1u);
+                    }
             }
         }
     }
-    radii[i] = radius;
-    rect[i] = rc;
-    rec0[i] = r0; rec1[i] = r1; rec2[i] = r2;
+    if (live_thread) {
+        radii[i] = radius;
+        rect[i] = rc;
+        rec0[i] = r0; rec1[i] = r1; rec2[i] = r2;
+    }
+    if (use_lds_hist) {
+        __syncthreads();
+        for (int t = threadIdx.x; t < T; t += 256) { uint32_t c = hist[t]; if (c) atomicAdd(&tile_count[t], c); }
+    }
 }
 
 // one workgroup of 1024 threads: exclusive scan of T tile counters
@@ -279,20 +292,45 @@ __global__ __launch_bounds__(1024) void k_scan_tiles(int T, const uint32_t* __re
 // ------------------------------------------------------------------------------------------------
 // stage B
 // ------------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void k_scatter(int G, int tiles_x, const float4* __restrict__ rec0,
+__global__ __launch_bounds__(256) void k_scatter(int G, int tiles_x, int T, const float4* __restrict__ rec0,
                                                  const uint2* __restrict__ rect, const uint32_t* __restrict__ tile_start,
                                                  uint32_t* __restrict__ tile_cursor, uint64_t* __restrict__ keys,
-                                                 int64_t cap, int32_t* __restrict__ header) {
+                                                 int64_t cap, int32_t* __restrict__ header, int use_lds) {
+    // Two sweeps over this block's splats: (1) count per tile in LDS, reserve ONE contiguous range per (block, tile) with a
+    // single returning global atomic; (2) hand out slots inside the reserved ranges with LDS atomics.
+    extern __shared__ uint32_t sm[];        // [T] counts / running local rank, [T] reserved base
+    uint32_t* cnt = sm; uint32_t* base = sm + T;
     int i = blockIdx.x * 256 + threadIdx.x;
-    if (i >= G) return;
-    uint2 rc = rect[i];
-    int tx0 = rc.x & 0xffff, ty0 = rc.x >> 16, tx1 = rc.y & 0xffff, ty1 = rc.y >> 16;
-    if (tx1 <= tx0 || ty1 <= ty0) return;
-    uint64_t key = ((uint64_t)__float_as_uint(rec0[i].z) << 32) | (uint32_t)i;
+    int tx0 = 0, ty0 = 0, tx1 = 0, ty1 = 0;
+    uint64_t key = 0;
+    if (i < G) {
+        uint2 rc = rect[i];
+        tx0 = rc.x & 0xffff; ty0 = rc.x >> 16; tx1 = rc.y & 0xffff; ty1 = rc.y >> 16;
+        key = ((uint64_t)__float_as_uint(rec0[i].z) << 32) | (uint32_t)i;
+    }
+    if (!use_lds) {
+        for (int ty = ty0; ty < ty1; ty++)
+            for (int tx = tx0; tx < tx1; tx++) {
+                int t = ty * tiles_x + tx;
+                int64_t slot = (int64_t)tile_start[t] + atomicAdd(&tile_cursor[t], 1u);
+                if (slot < cap) keys[slot] = key; else header[1] = 1;
+            }
+        return;
+    }
+    for (int t = threadIdx.x; t < T; t += 256) cnt[t] = 0u;
+    __syncthreads();
+    for (int ty = ty0; ty < ty1; ty++)
+        for (int tx = tx0; tx < tx1; tx++) atomicAdd(&cnt[ty * tiles_x + tx], 1u);
+    __syncthreads();
+    for (int t = threadIdx.x; t < T; t += 256) {
+        uint32_t c = cnt[t];
+        if (c) { base[t] = tile_start[t] + atomicAdd(&tile_cursor[t], c); cnt[t] = 0u; }
+    }
+    __syncthreads();
     for (int ty = ty0; ty < ty1; ty++)
         for (int tx = tx0; tx < tx1; tx++) {
             int t = ty * tiles_x + tx;
-            int64_t slot = (int64_t)tile_start[t] + atomicAdd(&tile_cursor[t], 1u);
+            int64_t slot = (int64_t)base[t] + atomicAdd(&cnt[t], 1u);
             if (slot < cap) keys[slot] = key; else header[1] = 1;
         }
 }
@@ -722,10 +760,11 @@ int dwg_raster_forward_bin(const dwg_raster_settings* cfg, int32_t G, const floa
     int T = p.tiles_x * p.tiles_y;
     if (hipMemsetAsync(ws + L.tile_count, 0, L.tile_start - L.tile_count, stream) != hipSuccess) return DWG_E_LAUNCH;
     if (G > 0) {
-        DWG_LAUNCH("raster_preprocess", k_preprocess, dim3(dwg_cdiv(G, 256)), dim3(256), 0, stream, p, means3D, shs, colors_precomp,
-                           opacities, scales, rotations, cov3D_precomp, radii, (float4*)(ws + L.rec0),
-                           (float4*)(ws + L.rec1), (float4*)(ws + L.rec2), (uint2*)(ws + L.rect),
-                           (uint32_t*)(ws + L.tile_count));
+        const int use_lds_hist = T <= 16384;
+        DWG_LAUNCH("raster_preprocess", k_preprocess, dim3(dwg_cdiv(G, 256)), dim3(256), use_lds_hist ? (size_t)T * 4 : 0, stream, p,
+                   means3D, shs, colors_precomp, opacities, scales, rotations, cov3D_precomp, radii, (float4*)(ws + L.rec0),
+                   (float4*)(ws + L.rec1), (float4*)(ws + L.rec2), (uint2*)(ws + L.rect), (uint32_t*)(ws + L.tile_count),
+                   use_lds_hist);
     }
     DWG_LAUNCH("raster_scan_tiles", k_scan_tiles, dim3(1), dim3(1024), 0, stream, T, (const uint32_t*)(ws + L.tile_count),
                        (uint32_t*)(ws + L.tile_start), (int32_t*)(ws + L.header));
@@ -750,16 +789,25 @@ int dwg_raster_forward_render(const dwg_raster_settings* cfg, int32_t G, void* w
     uint32_t* sorted = (uint32_t*)(wp + PL.sorted);
     const uint32_t* tile_start = (const uint32_t*)(ws + L.tile_start);
     if (G > 0) {
-        DWG_LAUNCH("raster_scatter", k_scatter, dim3(dwg_cdiv(G, 256)), dim3(256), 0, stream, G, p.tiles_x,
-                           (const float4*)(ws + L.rec0), (const uint2*)(ws + L.rect), tile_start,
-                           (uint32_t*)(ws + L.tile_cursor), keys, pair_capacity, (int32_t*)(ws + L.header));
+        const int use_lds = T <= 8192;
+        DWG_LAUNCH("raster_scatter", k_scatter, dim3(dwg_cdiv(G, 256)), dim3(256), use_lds ? (size_t)T * 8 : 0, stream, G, p.tiles_x, T,
+                   (const float4*)(ws + L.rec0), (const uint2*)(ws + L.rect), tile_start, (uint32_t*)(ws + L.tile_cursor), keys,
+                   pair_capacity, (int32_t*)(ws + L.header), use_lds);
         // three size classes: (1,2048] in 16 KiB LDS, (2048,8192] in 64 KiB LDS, >8192 in global memory
         DWG_LAUNCH("raster_tile_sort", (k_tile_sort<2048, false>), dim3(T), dim3(256), 2048 * 8, stream, tile_start, keys, sorted, 0,
                            pair_capacity);
         DWG_LAUNCH("raster_tile_sort_l", (k_tile_sort<8192, false>), dim3(T), dim3(256), 8192 * 8, stream, tile_start, keys, sorted, 2048,
                            pair_capacity);
-        DWG_LAUNCH("raster_tile_sort_g", (k_tile_sort<0, true>), dim3(T), dim3(256), 0, stream, tile_start, keys, sorted, 8192,
-                           pair_capacity);
+        static bool attr_set = false;
+        if (!attr_set) {
+            hipFuncSetAttribute(reinterpret_cast<const void*>(&k_tile_sort<16384, false>), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                16384 * 8);
+            attr_set = true;
+        }
+        DWG_LAUNCH("raster_tile_sort_xl", (k_tile_sort<16384, false>), dim3(T), dim3(256), 16384 * 8, stream, tile_start, keys, sorted,
+                   8192, pair_capacity);
+        DWG_LAUNCH("raster_tile_sort_g", (k_tile_sort<0, true>), dim3(T), dim3(256), 0, stream, tile_start, keys, sorted, 16384,
+                   pair_capacity);
     }
     DWG_LAUNCH("raster_render_fwd", k_render_fwd, dim3(T), dim3(256), 0, stream, p, tile_start, (const uint32_t*)sorted,
                        (const float4*)(ws + L.rec0), (const float4*)(ws + L.rec1), (const float4*)(ws + L.rec2),

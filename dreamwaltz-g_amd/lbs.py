@@ -81,21 +81,29 @@ def joint_chain(pose, joints, parents, transl=None, return_rot_mats=False, joint
     return (A, R) if return_rot_mats else A
 
 
-def vertex_transform(vertex_indices, vertex_coords, A, lbs_weights, shapedirs=None, shape_coeffs=None, posedirs=None,
-                     rot_mats=None):
-    """transform_V (compose(V_shape_offset, V_pose_offset, V_pose_rigid, transl)) applied to a vertex subset."""
-    Vp = vertex_indices.shape[0]
-    V, J = lbs_weights.shape
+def gather_vertex_subset(vertex_indices, lbs_weights, shapedirs=None, posedirs=None):
+    """One-off gather of the body-model rows a fixed vertex subset needs, into the vertex-major layouts of
+    dwg_lbs_vertex_transform: (lbs_weights_sub [Vp,J], shapedirs_sub [Vp,3,S] | None, posedirs_sub [Vp,3,F] | None)."""
+    vi = vertex_indices.long()
+    w_sub = lbs_weights[vi].contiguous().float()
+    sd = None if shapedirs is None else shapedirs[vi].contiguous().float()
+    pd = None
+    if posedirs is not None:
+        Fp, V3 = posedirs.shape
+        pd = posedirs.view(Fp, V3 // 3, 3)[:, vi, :].permute(1, 2, 0).contiguous().float()
+    return w_sub, sd, pd
+
+
+def vertex_transform(vertex_coords, A, subset, shape_coeffs=None, rot_mats=None):
+    """transform_V (compose(V_shape_offset, V_pose_offset, V_pose_rigid, transl)) applied to a fixed vertex subset;
+    `subset` comes from gather_vertex_subset()."""
+    w_sub, sd, pd = subset
+    Vp, J = w_sub.shape
     out = torch.empty(Vp, 3, device=vertex_coords.device)
-    n_shape = 0 if shapedirs is None else shapedirs.shape[-1]
-    n_pf = 0 if posedirs is None else posedirs.shape[0]
     p = _lib.ptr
-    vi = vertex_indices.to(torch.int32).contiguous()
     _lib.check(_lib.lib().dwg_lbs_vertex_transform(
-        Vp, V, J, n_shape, n_pf, p(vi), p(vertex_coords.contiguous().float()), p(A.contiguous().float()),
-        p(lbs_weights.contiguous().float()), p(None if shapedirs is None else shapedirs.contiguous().float()),
-        p(None if shape_coeffs is None else shape_coeffs.reshape(-1).contiguous().float()),
-        p(None if posedirs is None else posedirs.contiguous().float()),
-        p(None if rot_mats is None else rot_mats.contiguous().float()), p(out), _st(vertex_coords)),
+        Vp, J, 0 if sd is None else sd.shape[-1], 0 if pd is None else pd.shape[-1], p(vertex_coords.contiguous().float()),
+        p(A.contiguous().float()), p(w_sub), p(sd), p(None if shape_coeffs is None else shape_coeffs.reshape(-1).contiguous().float()),
+        p(pd), p(None if rot_mats is None else rot_mats.contiguous().float()), p(out), _st(vertex_coords)),
         "dwg_lbs_vertex_transform")
     return out

@@ -79,13 +79,18 @@ class SDSStep:
         cnl = {k: v.to(self.device) for k, v in cnl.items()}
         mesh = None
         if M > 0:
+            # "hands": two local vertex clusters, triangles = a vertex and its two nearest neighbours (cm-sized faces, as on the
+            # SMPL-X hand/face meshes the reference binds to)
             Vp, Fp = 1200, M // 6
-            vi = torch.randperm(body["v_template"].shape[0], generator=gen)[:Vp]
-            # small triangles: pick a vertex and two of its near neighbours in index space of a spatially sorted subset
-            order = torch.argsort(body["v_template"][vi.to(self.device), 1].cpu())
-            a = torch.randint(0, Vp - 3, (Fp,), generator=gen)
-            tri = torch.stack([order[a], order[a + 1], order[a + 2]], dim=1)
-            mesh = {"hands": av.MeshBindingGaussianModel(body["v_template"][vi.to(self.device)].cpu(), tri, vi)}
+            vt = body["v_template"].cpu()
+            centres = torch.tensor([[0.35, 0.2, 0.0], [-0.35, 0.2, 0.0]])
+            d2 = ((vt[:, None, :] - centres[None]) ** 2).sum(-1)                      # [V, 2]
+            vi = torch.cat([torch.topk(d2[:, 0], Vp // 2, largest=False).indices, torch.topk(d2[:, 1], Vp // 2, largest=False).indices])
+            sub = vt[vi]
+            nn = torch.topk(torch.cdist(sub, sub), 3, largest=False).indices          # self + 2 nearest
+            a = torch.randint(0, Vp, (Fp,), generator=gen)
+            tri = nn[a]
+            mesh = {"hands": av.MeshBindingGaussianModel(sub, tri, vi)}
         self.avatar = av.DreamWaltzG(glbs, g["positions"], g["scales"], g["quaternions"], lbs_w, cnl, mesh).to(self.device)
         self.renderer = rd.GaussianRenderer(bg_color=(0.5, 0.5, 0.5))
         cam = camera.make_camera(radius=2.0, azimuth=45.0 * rank, elevation=80.0, fovy=55.0, height=res, width=res, device=self.device)

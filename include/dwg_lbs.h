@@ -41,14 +41,14 @@ int dwg_lbs_blend_backward(int32_t N, const float* T12 /*[N,12] from forward*/, 
                            const float* g_points_out, const float* g_quats_out, float* g_points, float* g_quats,
                            dwg_stream_t stream);
 
-/* transform_V applied to a vertex subset (mesh-bound Gaussians, avatar.py:1570-1576):
- *   out_t = T_rigid(v_t) * (x_t + shapedirs[v_t] . shape + posedirs[:, v_t] . (rot_mats[1:] - I)),  v_t = vertex_indices[t]
- * with T_rigid(v) = sum_j lbs_weights[v,j] A_j (A already carries the translation).  shapedirs [V,3,n_shape] and/or
- * posedirs [n_posefeat, 3V] may be NULL to skip that offset. */
-int dwg_lbs_vertex_transform(int32_t Vp, int32_t V, int32_t J, int32_t n_shape, int32_t n_posefeat,
-                             const int32_t* vertex_indices, const float* vertex_coords /*[Vp,3]*/, const float* A,
-                             const float* lbs_weights /*[V,J]*/, const float* shapedirs, const float* shape_coeffs,
-                             const float* posedirs, const float* rot_mats /*[J,9]*/, float* out /*[Vp,3]*/,
+/* transform_V applied to a FIXED vertex subset (mesh-bound Gaussians, avatar.py:1570-1576):
+ *   out_t = T_rigid(t) * (x_t + shapedirs_sub[t] . shape + posedirs_sub[t] . (rot_mats[1:] - I))
+ * with T_rigid(t) = sum_j lbs_weights_sub[t,j] A_j (A already carries the translation).  The *_sub arrays are the rows of the
+ * body model's shapedirs [V,3,S] / posedirs [F,3V] / lbs_weights [V,J] gathered once for the subset into vertex-major
+ * [Vp,3,S] / [Vp,3,F] / [Vp,J]; either direction array may be NULL to skip that offset. */
+int dwg_lbs_vertex_transform(int32_t Vp, int32_t J, int32_t n_shape, int32_t n_posefeat, const float* vertex_coords /*[Vp,3]*/,
+                             const float* A, const float* lbs_weights_sub, const float* shapedirs_sub, const float* shape_coeffs,
+                             const float* posedirs_sub, const float* rot_mats /*[J,9]*/, float* out /*[Vp,3]*/,
                              dwg_stream_t stream);
 
 #ifdef __cplusplus

@@ -91,8 +91,8 @@ def test_vertex_transform_matches_transform_V():
     joints = torch.einsum('ik,ji->jk', v_shaped, body.J_regressor)
     A, R = lbs.joint_chain(full_pose.view(55, 3).cuda(), joints.cuda(), torch.from_numpy(body.parents), inp["transl"][0].cuda(),
                            return_rot_mats=True)
-    out = lbs.vertex_transform(vi.cuda(), x.cuda(), A, body.lbs_weights.cuda(), shapedirs.cuda(), full_shape.cuda(),
-                               body.posedirs.cuda(), R)
+    subset = lbs.gather_vertex_subset(vi.cuda(), body.lbs_weights.cuda(), shapedirs.cuda(), body.posedirs.cuda())
+    out = lbs.vertex_transform(x.cuda(), A, subset, full_shape.cuda(), R)
     assert (out.cpu() - ref).abs().max() < 2e-5
 
 
