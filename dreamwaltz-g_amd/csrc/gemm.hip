@@ -15,6 +15,7 @@
 #include "dwg_common.h"
 #include "dwg_prof_internal.h"
 #include "../../include/dwg_gemm.h"
+#include <cstdlib>
 
 namespace {
 
@@ -425,10 +426,18 @@ __global__ __launch_bounds__(256) void k_gemm_glds(GemmP p) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];     // [2][A tile | B tile], rows of 128 B
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wm = wave / WN, wn = wave % WN;
-    const int m0 = blockIdx.x * BM;
-    const int ntn = (p.N + BN - 1) / BN;
-    const int n0 = (blockIdx.y % ntn) * BN;
-    const int ks_id = blockIdx.y / ntn;
+    // XCD-aware tile order: the dispatcher hands consecutive workgroup ids to the 8 XCDs round-robin, each with a private
+    // L2.  Remap so that every XCD owns a CONTIGUOUS run of tiles, n fastest: the n-tiles of one A panel (and, for wide N,
+    // neighbouring B panels) are then co-resident on one L2 instead of being fetched from HBM / Infinity Cache by 8 of them.
+    const int gm = (p.M + BM - 1) / BM, ntn = (p.N + BN - 1) / BN;
+    const int nwg = gridDim.x;
+    int id = blockIdx.x;
+    {
+        const int q = nwg / 8, r = nwg % 8, xcd = id % 8, loc = id / 8;
+        id = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + loc;     // bijective for any nwg
+    }
+    const int tile = id % (gm * ntn), ks_id = id / (gm * ntn);
+    const int m0 = (tile / ntn) * BM, n0 = (tile % ntn) * BN;
     const int z = blockIdx.z, z1 = z / p.nb2, z2 = z - z1 * p.nb2;
     const __bf16* A = reinterpret_cast<const __bf16*>(p.A) + z1 * p.bA1 + z2 * p.bA2;
     const __bf16* B = reinterpret_cast<const __bf16*>(p.B) + z1 * p.bB1 + z2 * p.bB2;
@@ -481,7 +490,7 @@ __global__ __launch_bounds__(256) void k_gemm_glds(GemmP p) {
 template <int BN, bool CONV>
 static void launch_glds(const GemmP& p, int batch, hipStream_t stream, const char* name) {
     size_t lds = (size_t)2 * (128 + BN) * 128;
-    dim3 grid((p.M + 127) / 128, ((p.N + BN - 1) / BN) * (p.splitk > 1 ? p.splitk : 1), batch);
+    dim3 grid(((p.M + 127) / 128) * ((p.N + BN - 1) / BN) * (p.splitk > 1 ? p.splitk : 1), 1, batch);
     DWG_LAUNCH(name, (k_gemm_glds<BN, CONV>), grid, dim3(256), lds, stream, p);
     if (p.splitk > 1 && p.ws) {
         long long n = (long long)p.M * p.N;
@@ -523,13 +532,23 @@ static void dispatch_a(const GemmP& p, int amode, int bmode, int batch, hipStrea
     else dispatch_b<T, BN, MODE_SCALAR>(p, bmode, batch, s, name);
 }
 
+static int batch_of(const dwg_gemm_desc* d) { return d->batch1 * d->batch2; }
+static int tile_bn(const dwg_gemm_desc* d) {
+    if (d->N <= 64) return 64;
+    if (d->dtype == DWG_DTYPE_BF16) {
+        long long blocks128 = (long long)((d->M + 127) / 128) * ((d->N + 127) / 128) * batch_of(d);
+        if (blocks128 < 256 && getenv("DWG_GEMM_NO_NARROW") == nullptr) return 64;
+    }
+    return 128;
+}
+
 // split-K factor for shapes that cannot fill 256 CUs with 128 x BN output tiles (small-M layers: 8x8 / 16x16 latents)
 static int auto_splitk(int M, int N, int K, int bn, int bk) {
     long long blocks = (long long)((M + 127) / 128) * ((N + bn - 1) / bn);
-    if (blocks >= 192 || K < 8 * bk) return 1;
+    if (blocks >= 384 || K < 16 * bk) return 1;
     if (2.0 * M * N * K < 4.0e8) return 1;      // tiny products are launch-bound: a second (reduce) launch costs more than it buys
-    long long sk = 256 / blocks;
-    long long kmax = K / (4 * bk);
+    long long sk = 512 / blocks;                // aim at ~2 workgroups per CU
+    long long kmax = K / (8 * bk);              // keep >= 8 k-steps per slice
     if (sk > kmax) sk = kmax;
     if (sk > 16) sk = 16;
     return sk >= 2 ? (int)sk : 1;
@@ -551,7 +570,7 @@ extern "C" {
 
 size_t dwg_gemm_workspace_bytes(const dwg_gemm_desc* d) {
     if (!d || d->batch1 * d->batch2 != 1 || d->M <= 0 || d->N <= 0) return 0;
-    const int bn = d->N <= 64 ? 64 : 128, bk = d->dtype == DWG_DTYPE_BF16 ? TT<__bf16>::BK : TT<float>::BK;
+    const int bn = tile_bn(d), bk = d->dtype == DWG_DTYPE_BF16 ? TT<__bf16>::BK : TT<float>::BK;
     int sk = d->splitk > 1 ? d->splitk : (d->splitk == 0 ? auto_splitk(d->M, d->N, d->K, bn, bk) : 1);
     return sk > 1 ? (size_t)sk * d->M * d->N * sizeof(float) : 0;
 }
@@ -576,7 +595,7 @@ int dwg_gemm(const dwg_gemm_desc* d, dwg_stream_t stream_) {
     p.bias_per_row = d->bias_per_row; p.splitk = d->splitk > 1 ? d->splitk : 1; p.accumulate = d->accumulate;
     p.ws = nullptr;
     {
-        const int bn = d->N <= 64 ? 64 : 128, bk = d->dtype == DWG_DTYPE_BF16 ? TT<__bf16>::BK : TT<float>::BK;
+        const int bn = tile_bn(d), bk = d->dtype == DWG_DTYPE_BF16 ? TT<__bf16>::BK : TT<float>::BK;
         if (d->workspace && d->batch1 * d->batch2 == 1) {
             int sk = d->splitk > 1 ? d->splitk : (d->splitk == 0 ? auto_splitk(d->M, d->N, d->K, bn, bk) : 1);
             while (sk > 1 && (size_t)sk * d->M * d->N * sizeof(float) > d->workspace_bytes) sk--;
@@ -594,7 +613,13 @@ int dwg_gemm(const dwg_gemm_desc* d, dwg_stream_t stream_) {
     const int batch = d->batch1 * d->batch2;
     hipStream_t stream = (hipStream_t)stream_;
     const char* name = d->name ? d->name : (d->conv_enabled ? "conv_igemm" : "gemm");
-    const bool narrow = d->N <= 64;
+    bool narrow = d->N <= 64;
+    if (d->dtype == DWG_DTYPE_BF16 && !narrow) {
+        // mid-size layers (e.g. 64x64 latents, N = 320): 128x128 tiles give < 1 workgroup per CU and waste the last n-tile;
+        // 128x64 tiles double the workgroup count (3 resident per CU) -- latency hiding beats operand reuse there
+        long long blocks128 = (long long)((d->M + 127) / 128) * ((d->N + 127) / 128) * batch_of(d);
+        if (blocks128 < 256 && getenv("DWG_GEMM_NO_NARROW") == nullptr) narrow = true;
+    }
     if (d->dtype == DWG_DTYPE_BF16) {
         typedef __bf16 T;
         int amode, bmode;
