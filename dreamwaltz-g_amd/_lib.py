@@ -46,7 +46,7 @@ SIGNATURES = {
     "dwg_grid_encode_forward": (ctypes.c_int, [_vp, _vp, _vp, _vp, _u32, _u32, _u32, _u32, _f32, _u32, _vp, _u32, _u32, _u32,
                                                _u32, _vp]),
     "dwg_grid_encode_backward": (ctypes.c_int, [_vp, _vp, _vp, _vp, _vp, _u32, _u32, _u32, _u32, _f32, _u32, _vp, _vp, _u32,
-                                                _u32, _u32, _u32, _vp]),
+                                                _u32, _u32, _u32, _vp, _vp]),
     # include/dwg_gemm.h
     "dwg_gemm": (ctypes.c_int, [_vp, _vp]),
     "dwg_gemm_workspace_bytes": (_sz, [_vp]),
@@ -54,8 +54,9 @@ SIGNATURES = {
     "dwg_act_backward_colsum": (ctypes.c_int, [_i32, _i32, _i32, _vp, _vp, _vp, _vp, _vp]),
     "dwg_adam_step": (ctypes.c_int, [_i64, _vp, _vp, _vp, _vp, _f32, _f32, _f32, _f32, _i32, _f32, _vp]),
     # include/dwg_nn.h
-    "dwg_groupnorm_forward": (ctypes.c_int, [_i32, _i32, _i32, _i32, _vp, _vp, _vp, _f32, _i32, _vp, _vp, _vp]),
-    "dwg_groupnorm_backward": (ctypes.c_int, [_i32, _i32, _i32, _i32, _vp, _vp, _vp, _vp, _vp, _f32, _i32, _vp, _vp, _vp]),
+    "dwg_groupnorm_forward": (ctypes.c_int, [_i32, _i32, _i32, _i32, _vp, _vp, _vp, _f32, _i32, _vp, _vp, _vp, _vp]),
+    "dwg_groupnorm_backward": (ctypes.c_int, [_i32, _i32, _i32, _i32, _vp, _vp, _vp, _vp, _vp, _f32, _i32, _vp, _vp, _vp, _vp]),
+    "dwg_groupnorm_workspace_floats": (_sz, [_i32, _i32]),
     "dwg_layernorm_forward": (ctypes.c_int, [_i32, _i32, _vp, _vp, _vp, _f32, _vp, _vp]),
     "dwg_geglu_forward": (ctypes.c_int, [_i64, _i32, _vp, _vp, _vp]),
     "dwg_attention_forward": (ctypes.c_int, [_i32, _i32, _i32, _i32, _i32, _vp, _i64, _i64, _vp, _i64, _i64, _vp, _i64, _i64,

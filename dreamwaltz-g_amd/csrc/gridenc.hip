@@ -114,7 +114,7 @@ __global__ __launch_bounds__(256) void k_grid_fwd(GridP p, const float* __restri
 // grad_table += w * grad (atomics), and grad_x[b,d] = sum_{l,c} grad[b,l,c] * dy_dx[b,l,d,c]
 __global__ __launch_bounds__(256) void k_grid_bwd(GridP p, const float* __restrict__ grad, const float* __restrict__ x,
                                                   const int* __restrict__ offsets, float* __restrict__ grad_table,
-                                                  const float* __restrict__ dy_dx, float* __restrict__ grad_x) {
+                                                  const float* __restrict__ dy_dx, float* __restrict__ grad_x, uint32_t first_table_level) {
     const uint32_t t = blockIdx.x * 256u + threadIdx.x;
     const uint32_t b = t / p.L, level = t - b * p.L;
     const bool live = b < p.B;
@@ -126,7 +126,7 @@ __global__ __launch_bounds__(256) void k_grid_bwd(GridP p, const float* __restri
         const float x0 = x[3 * b], x1 = x[3 * b + 1], x2 = x[3 * b + 2];
         Cell c = locate(p, offsets, level, x0, x1, x2);
         if (!c.oob) {
-            if (grad_table) {
+            if (grad_table && level >= first_table_level) {
                 float* gt = grad_table + (size_t)(uint32_t)offsets[level] * 2;
 #pragma unroll
                 for (int idx = 0; idx < 8; idx++) {
@@ -161,6 +161,35 @@ __global__ __launch_bounds__(256) void k_grid_bwd(GridP p, const float* __restri
     }
 }
 
+// Coarse levels (a few thousand cells, hundreds of points per cell): the whole level table is privatised in LDS so the
+// same-address contention stays on chip; one global atomic per (workgroup, touched entry) afterwards.
+__global__ __launch_bounds__(256) void k_grid_bwd_coarse(GridP p, uint32_t level, uint32_t points_per_block,
+                                                         const float* __restrict__ grad, const float* __restrict__ x,
+                                                         const int* __restrict__ offsets, float* __restrict__ grad_table) {
+    extern __shared__ float tab[];          // [hsize * 2]
+    const uint32_t hsize = (uint32_t)(offsets[level + 1] - offsets[level]);
+    for (uint32_t e = threadIdx.x; e < hsize * 2; e += 256) tab[e] = 0.f;
+    __syncthreads();
+    const uint32_t b0 = blockIdx.x * points_per_block, b1 = min(p.B, b0 + points_per_block);
+    for (uint32_t b = b0 + threadIdx.x; b < b1; b += 256) {
+        const float* gsrc = p.layout ? grad + (size_t)b * p.L * 2 + level * 2 : grad + ((size_t)level * p.B + b) * 2;
+        const float g0 = gsrc[0], g1 = gsrc[1];
+        Cell c = locate(p, offsets, level, x[3 * b], x[3 * b + 1], x[3 * b + 2]);
+        if (c.oob) continue;
+#pragma unroll
+        for (int idx = 0; idx < 8; idx++) {
+            uint32_t cx = c.g[0] + (idx & 1), cy = c.g[1] + ((idx >> 1) & 1), cz = c.g[2] + ((idx >> 2) & 1);
+            float w = ((idx & 1) ? c.w[0] : 1.f - c.w[0]) * ((idx & 2) ? c.w[1] : 1.f - c.w[1]) * ((idx & 4) ? c.w[2] : 1.f - c.w[2]);
+            uint32_t index = grid_index(p.gridtype, p.align_corners, c.hsize, c.res, cx, cy, cz);
+            atomicAdd(&tab[index], w * g0);
+            atomicAdd(&tab[index + 1], w * g1);
+        }
+    }
+    __syncthreads();
+    float* gt = grad_table + (size_t)(uint32_t)offsets[level] * 2;
+    for (uint32_t e = threadIdx.x; e < hsize * 2; e += 256) { float v = tab[e]; if (v != 0.f) atomicAdd(gt + e, v); }
+}
+
 static int check(uint32_t B, uint32_t D, uint32_t C, uint32_t L) {
     if (D != 3 || C != 2 || L == 0 || L > 32) return DWG_E_ARG;  // the avatar's encoder: D=3, C=2, L=16
     if ((uint64_t)B * L > 0xffffff00ull) return DWG_E_ARG;
@@ -190,7 +219,7 @@ int dwg_grid_encode_forward(const float* inputs, const float* embeddings, const 
 int dwg_grid_encode_backward(const float* grad, const float* inputs, const float* embeddings, const int32_t* offsets,
                              float* grad_embeddings, uint32_t B, uint32_t D, uint32_t C, uint32_t L, float S, uint32_t H,
                              const float* dy_dx, float* grad_inputs, uint32_t gridtype, uint32_t align_corners,
-                             uint32_t interp, uint32_t grad_layout, dwg_stream_t stream) {
+                             uint32_t interp, uint32_t grad_layout, const int32_t* host_offsets, dwg_stream_t stream) {
     int rc = check(B, D, C, L);
     if (rc) return rc;
     if (B == 0) return DWG_OK;
@@ -202,8 +231,25 @@ int dwg_grid_encode_backward(const float* grad, const float* inputs, const float
     if (grad_inputs && L != 16) {
         if (hipMemsetAsync(grad_inputs, 0, (size_t)B * 3 * sizeof(float), (hipStream_t)stream) != hipSuccess) return DWG_E_LAUNCH;
     }
+    // levels whose table fits LDS (<= 19 000 entries) and that are heavily shared (B >> entries) take the privatised path
+    uint32_t first_table_level = 0;
+    if (grad_embeddings && host_offsets && B >= 16384) {
+        static bool attr_set = false;
+        if (!attr_set) {
+            hipFuncSetAttribute(reinterpret_cast<const void*>(&k_grid_bwd_coarse), hipFuncAttributeMaxDynamicSharedMemorySize, 152 * 1024);
+            attr_set = true;
+        }
+        while (first_table_level < L) {
+            uint32_t hs = (uint32_t)(host_offsets[first_table_level + 1] - host_offsets[first_table_level]);
+            if ((size_t)hs * 8 > 152 * 1024 || (uint64_t)B * 8 < (uint64_t)hs * 16) break;
+            uint32_t ppb = hs * 8 > 64 * 1024 ? 8192 : 2048;
+            DWG_LAUNCH("grid_bwd_coarse", k_grid_bwd_coarse, dim3((B + ppb - 1) / ppb), dim3(256), (size_t)hs * 8, (hipStream_t)stream, p,
+                       first_table_level, ppb, grad, inputs, offsets, grad_embeddings);
+            first_table_level++;
+        }
+    }
     DWG_LAUNCH("grid_bwd", k_grid_bwd, dim3((n + 255) / 256), dim3(256), 0, (hipStream_t)stream, p, grad, inputs, offsets,
-                       grad_embeddings, dy_dx, grad_inputs);
+                       grad_embeddings, dy_dx, grad_inputs, first_table_level);
     DWG_RETURN_IF_LAUNCH_FAILED();
     return DWG_OK;
 }

@@ -91,7 +91,20 @@ __global__ __launch_bounds__(256) void k_gn_reduce(int HW, int C, int G, int pix
         }
         __syncthreads();
     }
-    if (tid < 2 * G) atomicAdd(&sums[(size_t)b * G * 2 + tid], gacc[tid]);
+    // per-block partial sums, reduced in a FIXED order by k_gn_finalize: deterministic, no global atomics, no memset
+    if (tid < 2 * G) sums[((size_t)b * gridDim.x + blockIdx.x) * G * 2 + tid] = gacc[tid];
+}
+
+// stats[b][g][0..1] = sum over the chunk partials, in a FIXED order: 8 interleaved strands per output, then a fixed tree
+__global__ __launch_bounds__(512) void k_gn_finalize(int chunks, int G, const float* __restrict__ partials, float* __restrict__ stats) {
+    __shared__ float part[8][128];
+    const int b = blockIdx.x, o = threadIdx.x & 127, strand = threadIdx.x >> 7;   // 128 outputs max (2G <= 128), 4 strands
+    float s = 0.f;
+    if (o < 2 * G)
+        for (int c = strand; c < chunks; c += 4) s += partials[((size_t)b * chunks + c) * G * 2 + o];
+    part[strand][o] = s;
+    __syncthreads();
+    if (strand == 0 && o < 2 * G) stats[(size_t)b * G * 2 + o] = (part[0][o] + part[1][o]) + (part[2][o] + part[3][o]);
 }
 
 // forward apply: y = silu?((x - mean) * rstd * gamma + beta)
@@ -258,21 +271,33 @@ static int gn_geometry(int HW, int C, int G, int* pix_per_block, int* chunks, si
     *lds = (size_t)256 * 8 * 2 * sizeof(float);
     return DWG_OK;
 }
+// reduction pass: ~64K elements per workgroup, at most GN_MAX_CHUNKS partials per image
+#define GN_MAX_CHUNKS 512
+static void gn_reduce_geometry(int HW, int C, int* pix_per_block, int* chunks) {
+    long long ppb = 16384 / C; if (ppb < 8) ppb = 8;
+    int ch = (int)((HW + ppb - 1) / ppb);
+    if (ch > GN_MAX_CHUNKS) { ch = GN_MAX_CHUNKS; ppb = (HW + ch - 1) / ch; ch = (int)((HW + ppb - 1) / ppb); }
+    *pix_per_block = (int)ppb; *chunks = ch;
+}
 
 }  // namespace
 
 extern "C" {
 
+size_t dwg_groupnorm_workspace_floats(int32_t B, int32_t G) { return (size_t)(B > 0 ? B : 1) * GN_MAX_CHUNKS * (G > 0 ? G : 1) * 2; }
+
 int dwg_groupnorm_forward(int32_t B, int32_t HW, int32_t C, int32_t G, const void* x, const float* gamma, const float* beta,
-                          float eps, int32_t fuse_silu, void* y, float* stats, dwg_stream_t stream_) {
-    if (B <= 0 || HW <= 0 || !x || !gamma || !beta || !y || !stats) return DWG_E_ARG;
+                          float eps, int32_t fuse_silu, void* y, float* stats, float* workspace, dwg_stream_t stream_) {
+    if (B <= 0 || HW <= 0 || !x || !gamma || !beta || !y || !stats || !workspace) return DWG_E_ARG;
     int ppb, chunks; size_t lds;
     int rc = gn_geometry(HW, C, G, &ppb, &chunks, &lds);
     if (rc) return rc;
+    int rppb, rchunks;
+    gn_reduce_geometry(HW, C, &rppb, &rchunks);
     hipStream_t stream = (hipStream_t)stream_;
-    if (hipMemsetAsync(stats, 0, (size_t)B * G * 2 * sizeof(float), stream) != hipSuccess) return DWG_E_LAUNCH;
-    DWG_LAUNCH("gn_stats", (k_gn_reduce<false>), dim3(chunks, B), dim3(256), lds, stream, HW, C, G, ppb, (const __bf16*)x,
-               (const __bf16*)nullptr, (const float*)nullptr, gamma, beta, 0, eps, stats);
+    DWG_LAUNCH("gn_stats", (k_gn_reduce<false>), dim3(rchunks, B), dim3(256), lds, stream, HW, C, G, rppb, (const __bf16*)x,
+               (const __bf16*)nullptr, (const float*)nullptr, gamma, beta, 0, eps, workspace);
+    DWG_LAUNCH("gn_finalize", k_gn_finalize, dim3(B), dim3(512), 0, stream, rchunks, G, (const float*)workspace, stats);
     DWG_LAUNCH("gn_apply", (k_gn_apply<false>), dim3(chunks, B), dim3(256), 0, stream, HW, C, G, ppb, (const __bf16*)x,
                (const __bf16*)nullptr, (const float*)stats, (const float*)nullptr, gamma, beta, fuse_silu, eps, (__bf16*)y);
     DWG_RETURN_IF_LAUNCH_FAILED();
@@ -281,15 +306,17 @@ int dwg_groupnorm_forward(int32_t B, int32_t HW, int32_t C, int32_t G, const voi
 
 int dwg_groupnorm_backward(int32_t B, int32_t HW, int32_t C, int32_t G, const void* x, const void* dy, const float* stats,
                            const float* gamma, const float* beta, float eps, int32_t fuse_silu, void* dx, float* scratch,
-                           dwg_stream_t stream_) {
-    if (B <= 0 || HW <= 0 || !x || !dy || !stats || !gamma || !beta || !dx || !scratch) return DWG_E_ARG;
+                           float* workspace, dwg_stream_t stream_) {
+    if (B <= 0 || HW <= 0 || !x || !dy || !stats || !gamma || !beta || !dx || !scratch || !workspace) return DWG_E_ARG;
     int ppb, chunks; size_t lds;
     int rc = gn_geometry(HW, C, G, &ppb, &chunks, &lds);
     if (rc) return rc;
+    int rppb, rchunks;
+    gn_reduce_geometry(HW, C, &rppb, &rchunks);
     hipStream_t stream = (hipStream_t)stream_;
-    if (hipMemsetAsync(scratch, 0, (size_t)B * G * 2 * sizeof(float), stream) != hipSuccess) return DWG_E_LAUNCH;
-    DWG_LAUNCH("gn_bwd_stats", (k_gn_reduce<true>), dim3(chunks, B), dim3(256), lds, stream, HW, C, G, ppb, (const __bf16*)x,
-               (const __bf16*)dy, stats, gamma, beta, fuse_silu, eps, scratch);
+    DWG_LAUNCH("gn_bwd_stats", (k_gn_reduce<true>), dim3(rchunks, B), dim3(256), lds, stream, HW, C, G, rppb, (const __bf16*)x,
+               (const __bf16*)dy, stats, gamma, beta, fuse_silu, eps, workspace);
+    DWG_LAUNCH("gn_finalize", k_gn_finalize, dim3(B), dim3(512), 0, stream, rchunks, G, (const float*)workspace, scratch);
     DWG_LAUNCH("gn_bwd_apply", (k_gn_apply<true>), dim3(chunks, B), dim3(256), 0, stream, HW, C, G, ppb, (const __bf16*)x,
                (const __bf16*)dy, stats, (const float*)scratch, gamma, beta, fuse_silu, eps, (__bf16*)dx);
     DWG_RETURN_IF_LAUNCH_FAILED();

@@ -38,13 +38,27 @@ def grid_encode_forward(inputs, embeddings, offsets, outputs, B, D, C, L, S, H, 
                                                   interp, out_layout, _st(inputs)), "dwg_grid_encode_forward")
 
 
+_host_offsets = {}
+
+
+def _host_offsets_of(offsets):
+    """HOST copy of the (constant) level offset table, cached per tensor: lets the library size its LDS-privatised path."""
+    key = (offsets.data_ptr(), int(offsets.numel()))
+    if key not in _host_offsets:
+        arr = (ctypes.c_int32 * offsets.numel())(*[int(v) for v in offsets.cpu().tolist()])
+        _host_offsets[key] = arr
+    return _host_offsets[key]
+
+
 def grid_encode_backward(grad, inputs, embeddings, offsets, grad_embeddings, B, D, C, L, S, H, dy_dx, grad_inputs,
                          gridtype, align_corners, interp, grad_layout=0):
     _need_cuda(inputs)
     p = _lib.ptr
+    ho = _host_offsets_of(offsets)
     _lib.check(_lib.lib().dwg_grid_encode_backward(p(grad), p(inputs), p(embeddings), p(offsets), p(grad_embeddings), B, D,
                                                    C, L, ctypes.c_float(S), H, p(dy_dx), p(grad_inputs), gridtype,
-                                                   int(bool(align_corners)), interp, grad_layout, _st(inputs)),
+                                                   int(bool(align_corners)), interp, grad_layout,
+                                                   ctypes.cast(ho, ctypes.c_void_p), _st(inputs)),
                "dwg_grid_encode_backward")
 
 

@@ -23,9 +23,10 @@ def groupnorm(x, gamma, beta, groups=32, eps=1e-5, silu=False, out=None, stats=N
     HW = x.numel() // (B * C)
     y = torch.empty_like(x) if out is None else out
     stats = torch.empty(B, groups, 2, device=x.device, dtype=torch.float32) if stats is None else stats
+    ws = torch.empty(_lib.lib().dwg_groupnorm_workspace_floats(B, groups), device=x.device, dtype=torch.float32)
     p = _lib.ptr
-    _lib.check(_lib.lib().dwg_groupnorm_forward(B, HW, C, groups, p(x), p(gamma), p(beta), eps, int(silu), p(y), p(stats), _st(x)),
-               "dwg_groupnorm_forward")
+    _lib.check(_lib.lib().dwg_groupnorm_forward(B, HW, C, groups, p(x), p(gamma), p(beta), eps, int(silu), p(y), p(stats), p(ws),
+                                                _st(x)), "dwg_groupnorm_forward")
     return y, stats
 
 
@@ -35,9 +36,10 @@ def groupnorm_backward(x, dy, stats, gamma, beta, groups=32, eps=1e-5, silu=Fals
     HW = x.numel() // (B * C)
     dx = torch.empty_like(x)
     scratch = torch.empty(B, groups, 2, device=x.device, dtype=torch.float32)
+    ws = torch.empty(_lib.lib().dwg_groupnorm_workspace_floats(B, groups), device=x.device, dtype=torch.float32)
     p = _lib.ptr
     _lib.check(_lib.lib().dwg_groupnorm_backward(B, HW, C, groups, p(x), p(dy), p(stats), p(gamma), p(beta), eps, int(silu), p(dx),
-                                                 p(scratch), _st(x)), "dwg_groupnorm_backward")
+                                                 p(scratch), p(ws), _st(x)), "dwg_groupnorm_backward")
     return dx
 
 

@@ -396,6 +396,15 @@ class Builder:
         return y
 
     # -- norms / activations ------------------------------------------------------------------------------------
+    def _gn_ws(self, B):
+        """One partial-sum scratch per plan: GroupNorm calls are sequential on the plan's stream."""
+        need = int(self.L.dwg_groupnorm_workspace_floats(B, self.groups))
+        ws = getattr(self.p, "_gn_workspace", None)
+        if ws is None or ws.numel() < need:
+            ws = self.p.buf(need, dtype=torch.float32)
+            self.p._gn_workspace = ws
+        return ws
+
     def groupnorm(self, x, name, eps, silu, keep_stats=False):
         B, C = x.shape[0], x.shape[-1]
         HW = x.numel() // (B * C)
@@ -403,7 +412,7 @@ class Builder:
         stats = self.p.buf(B, self.groups, 2, dtype=torch.float32)
         pp = lambda t: ctypes.c_void_p(t.data_ptr())  # noqa: E731
         self.p.add_call(self.L.dwg_groupnorm_forward, B, HW, C, self.groups, pp(x), pp(self.w.f32(name + ".weight")),
-                        pp(self.w.f32(name + ".bias")), eps, int(silu), pp(y), pp(stats))
+                        pp(self.w.f32(name + ".bias")), eps, int(silu), pp(y), pp(stats), pp(self._gn_ws(B)))
         return (y, stats) if keep_stats else y
 
     def groupnorm_bwd(self, x, dy, stats, name, eps, silu):
@@ -413,7 +422,8 @@ class Builder:
         scratch = self.p.buf(B, self.groups, 2, dtype=torch.float32)
         pp = lambda t: ctypes.c_void_p(t.data_ptr())  # noqa: E731
         self.p.add_call(self.L.dwg_groupnorm_backward, B, HW, C, self.groups, pp(x), pp(dy), pp(stats),
-                        pp(self.w.f32(name + ".weight")), pp(self.w.f32(name + ".bias")), eps, int(silu), pp(dx), pp(scratch))
+                        pp(self.w.f32(name + ".weight")), pp(self.w.f32(name + ".bias")), eps, int(silu), pp(dx), pp(scratch),
+                        pp(self._gn_ws(B)))
         return dx
 
     def layernorm(self, x, name):

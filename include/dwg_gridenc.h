@@ -30,7 +30,10 @@ int dwg_grid_encode_backward(const float* grad, const float* inputs, const float
                              float* grad_embeddings /*[sO,C] accumulated, may be NULL*/, uint32_t B, uint32_t D, uint32_t C,
                              uint32_t L, float S, uint32_t H, const float* dy_dx /*or NULL*/,
                              float* grad_inputs /*[B,D] or NULL (iff dy_dx NULL)*/, uint32_t gridtype,
-                             uint32_t align_corners, uint32_t interp, uint32_t grad_layout, dwg_stream_t stream);
+                             uint32_t align_corners, uint32_t interp, uint32_t grad_layout,
+                             const int32_t* host_offsets /*[L+1] HOST copy of `offsets` or NULL: enables the LDS-privatised
+                                                           table-gradient path for the coarse levels*/,
+                             dwg_stream_t stream);
 
 #ifdef __cplusplus
 }
