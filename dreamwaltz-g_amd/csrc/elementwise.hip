@@ -71,6 +71,58 @@ __global__ __launch_bounds__(256) void k_adam(size_t n, float* __restrict__ p, c
     }
 }
 
+// dW[n][k] = sum_m dz[m][n] * x[m][k]  for the per-Gaussian MLPs (N, K <= 64, M ~ 1e5): every workgroup reduces a slab of
+// rows into a 64x64 register tile (4x4 per thread) from LDS-staged 64-row chunks and writes ONE partial tile; a second
+// pass sums the partial tiles in a fixed order (deterministic, no atomics).
+__global__ __launch_bounds__(256) void k_mlp_wgrad_partial(int M, int N, int K, const float* __restrict__ dz, int lddz,
+                                                           const float* __restrict__ x, int ldx, int rows_per_block,
+                                                           float* __restrict__ partial /*[blocks][64][64]*/) {
+    __shared__ float sdz[64][65];
+    __shared__ float sx[64][65];
+    const int tid = threadIdx.x, tn = (tid >> 4) * 4, tk = (tid & 15) * 4;
+    const int r0 = blockIdx.x * rows_per_block, r1 = min(M, r0 + rows_per_block);
+    float acc[4][4];
+#pragma unroll
+    for (int a = 0; a < 4; a++)
+#pragma unroll
+        for (int b = 0; b < 4; b++) acc[a][b] = 0.f;
+    for (int base = r0; base < r1; base += 64) {
+        __syncthreads();
+        for (int e = tid; e < 64 * 64; e += 256) {
+            int r = e >> 6, c = e & 63, m = base + r;
+            sdz[r][c] = (m < r1 && c < N) ? dz[(size_t)m * lddz + c] : 0.f;
+            sx[r][c] = (m < r1 && c < K) ? x[(size_t)m * ldx + c] : 0.f;
+        }
+        __syncthreads();
+#pragma unroll 8
+        for (int r = 0; r < 64; r++) {
+            float a[4], b[4];
+#pragma unroll
+            for (int q = 0; q < 4; q++) { a[q] = sdz[r][tn + q]; b[q] = sx[r][tk + q]; }
+#pragma unroll
+            for (int q = 0; q < 4; q++)
+#pragma unroll
+                for (int u = 0; u < 4; u++) acc[q][u] += a[q] * b[u];
+        }
+    }
+    float* dst = partial + (size_t)blockIdx.x * 4096;
+#pragma unroll
+    for (int q = 0; q < 4; q++)
+#pragma unroll
+        for (int u = 0; u < 4; u++) dst[(tn + q) * 64 + tk + u] = acc[q][u];
+}
+
+__global__ __launch_bounds__(256) void k_mlp_wgrad_final(int blocks, int N, int K, const float* __restrict__ partial,
+                                                         float* __restrict__ dw, int lddw) {
+    const int e = blockIdx.x * 256 + threadIdx.x;
+    if (e >= 4096) return;
+    const int n = e >> 6, k = e & 63;
+    if (n >= N || k >= K) return;
+    float s = 0.f;
+    for (int b = 0; b < blocks; b++) s += partial[(size_t)b * 4096 + e];
+    dw[(size_t)n * lddw + k] = s;
+}
+
 typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8_t;
 
 // out[r][0:Ca] = a[r], out[r][Ca:Ca+Cb] = b[r]   (channel concat of two NHWC bf16 tensors; Ca, Cb multiples of 8)
@@ -106,6 +158,25 @@ static int grid_for(long long n) { long long b = (n + 255) / 256; if (b < 1) b =
 }  // namespace
 
 extern "C" {
+
+size_t dwg_mlp_wgrad_workspace_floats(int32_t M) {
+    int rpb = 1024, blocks = dwg_cdiv(M > 0 ? M : 1, rpb);
+    return (size_t)blocks * 4096;
+}
+
+int dwg_mlp_wgrad(int32_t M, int32_t N, int32_t K, const float* dz, int32_t lddz, const float* x, int32_t ldx, float* dw,
+                  int32_t lddw, float* workspace, dwg_stream_t stream) {
+    if (M < 0 || N <= 0 || N > 64 || K <= 0 || K > 64 || !dz || !x || !dw || !workspace) return DWG_E_ARG;
+    if (M == 0) {
+        return DWG_OK;
+    }
+    const int rpb = 1024, blocks = dwg_cdiv(M, rpb);
+    DWG_LAUNCH("mlp_wgrad", k_mlp_wgrad_partial, dim3(blocks), dim3(256), 0, (hipStream_t)stream, M, N, K, dz, lddz, x, ldx, rpb, workspace);
+    DWG_LAUNCH("mlp_wgrad_final", k_mlp_wgrad_final, dim3(16), dim3(256), 0, (hipStream_t)stream, blocks, N, K, (const float*)workspace,
+               dw, lddw);
+    DWG_RETURN_IF_LAUNCH_FAILED();
+    return DWG_OK;
+}
 
 int dwg_concat_channels(int64_t rows, int32_t Ca, int32_t Cb, const void* a, const void* b, void* out, dwg_stream_t stream) {
     if (rows < 0 || Ca <= 0 || Cb <= 0 || Ca % 8 || Cb % 8 || !a || !b || !out) return DWG_E_ARG;

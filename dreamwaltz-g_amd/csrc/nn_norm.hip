@@ -92,19 +92,20 @@ __global__ __launch_bounds__(256) void k_gn_reduce(int HW, int C, int G, int pix
         __syncthreads();
     }
     // per-block partial sums, reduced in a FIXED order by k_gn_finalize: deterministic, no global atomics, no memset
-    if (tid < 2 * G) sums[((size_t)b * gridDim.x + blockIdx.x) * G * 2 + tid] = gacc[tid];
+    if (tid < 2 * G) sums[((size_t)b * 2 * G + tid) * gridDim.x + blockIdx.x] = gacc[tid];
 }
 
-// stats[b][g][0..1] = sum over the chunk partials, in a FIXED order: 8 interleaved strands per output, then a fixed tree
-__global__ __launch_bounds__(512) void k_gn_finalize(int chunks, int G, const float* __restrict__ partials, float* __restrict__ stats) {
-    __shared__ float part[8][128];
-    const int b = blockIdx.x, o = threadIdx.x & 127, strand = threadIdx.x >> 7;   // 128 outputs max (2G <= 128), 4 strands
-    float s = 0.f;
-    if (o < 2 * G)
-        for (int c = strand; c < chunks; c += 4) s += partials[((size_t)b * chunks + c) * G * 2 + o];
-    part[strand][o] = s;
-    __syncthreads();
-    if (strand == 0 && o < 2 * G) stats[(size_t)b * G * 2 + o] = (part[0][o] + part[1][o]) + (part[2][o] + part[3][o]);
+// stats[b][o] = sum over the chunk partials [b][o][chunk], in a FIXED order: one wave per output, lane-strided loads
+// (all chunks of an output are in flight at once) + a DPP tree -> deterministic and latency-flat.
+__global__ __launch_bounds__(1024) void k_gn_finalize(int chunks, int G, const float* __restrict__ partials, float* __restrict__ stats) {
+    const int b = blockIdx.x, wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    for (int o = wave; o < 2 * G; o += 16) {
+        const float* src = partials + ((size_t)b * 2 * G + o) * chunks;
+        float s = 0.f;
+        for (int c = lane; c < chunks; c += 64) s += src[c];
+        s = dwg_wave_sum_to_lane63(s);
+        if (lane == 63) stats[(size_t)b * G * 2 + o] = s;
+    }
 }
 
 // forward apply: y = silu?((x - mean) * rstd * gamma + beta)
@@ -297,7 +298,7 @@ int dwg_groupnorm_forward(int32_t B, int32_t HW, int32_t C, int32_t G, const voi
     hipStream_t stream = (hipStream_t)stream_;
     DWG_LAUNCH("gn_stats", (k_gn_reduce<false>), dim3(rchunks, B), dim3(256), lds, stream, HW, C, G, rppb, (const __bf16*)x,
                (const __bf16*)nullptr, (const float*)nullptr, gamma, beta, 0, eps, workspace);
-    DWG_LAUNCH("gn_finalize", k_gn_finalize, dim3(B), dim3(512), 0, stream, rchunks, G, (const float*)workspace, stats);
+    DWG_LAUNCH("gn_finalize", k_gn_finalize, dim3(B), dim3(1024), 0, stream, rchunks, G, (const float*)workspace, stats);
     DWG_LAUNCH("gn_apply", (k_gn_apply<false>), dim3(chunks, B), dim3(256), 0, stream, HW, C, G, ppb, (const __bf16*)x,
                (const __bf16*)nullptr, (const float*)stats, (const float*)nullptr, gamma, beta, fuse_silu, eps, (__bf16*)y);
     DWG_RETURN_IF_LAUNCH_FAILED();
@@ -316,7 +317,7 @@ int dwg_groupnorm_backward(int32_t B, int32_t HW, int32_t C, int32_t G, const vo
     hipStream_t stream = (hipStream_t)stream_;
     DWG_LAUNCH("gn_bwd_stats", (k_gn_reduce<true>), dim3(rchunks, B), dim3(256), lds, stream, HW, C, G, rppb, (const __bf16*)x,
                (const __bf16*)dy, stats, gamma, beta, fuse_silu, eps, workspace);
-    DWG_LAUNCH("gn_finalize", k_gn_finalize, dim3(B), dim3(512), 0, stream, rchunks, G, (const float*)workspace, scratch);
+    DWG_LAUNCH("gn_finalize", k_gn_finalize, dim3(B), dim3(1024), 0, stream, rchunks, G, (const float*)workspace, scratch);
     DWG_LAUNCH("gn_bwd_apply", (k_gn_apply<true>), dim3(chunks, B), dim3(256), 0, stream, HW, C, G, ppb, (const __bf16*)x,
                (const __bf16*)dy, stats, (const float*)scratch, gamma, beta, fuse_silu, eps, (__bf16*)dx);
     DWG_RETURN_IF_LAUNCH_FAILED();

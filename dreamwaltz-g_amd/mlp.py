@@ -60,8 +60,13 @@ class _Linear(torch.autograd.Function):
         _lib.check(_lib.lib().dwg_act_backward_colsum(M, N, gemm.ACT[ctx.act], p(dy), p(y) if ctx.act else None,
                                                       p(dz) if ctx.act else None, p(colsum), _st(x)), "dwg_act_backward_colsum")
         dw = torch.zeros_like(w)
-        # dW[:, :Kx] = dz^T x   (contraction over the M rows: both operands row-major -> split-K with atomics)
-        gemm.gemm_raw(dz, x, dw, N, Kx, M, (1, N), (1, Kx), w.shape[1], splitk=_splitk(M), name="mlp_wgrad")
+        # dW[:, :Kx] = dz^T x   (contraction over the M rows of two row-major operands)
+        if N <= 64 and Kx <= 64:
+            L = _lib.lib()
+            ws = torch.empty(L.dwg_mlp_wgrad_workspace_floats(M), device=x.device, dtype=torch.float32)
+            _lib.check(L.dwg_mlp_wgrad(M, N, Kx, p(dz), N, p(x), Kx, p(dw), w.shape[1], p(ws), _st(x)), "dwg_mlp_wgrad")
+        else:
+            gemm.gemm_raw(dz, x, dw, N, Kx, M, (1, N), (1, Kx), w.shape[1], splitk=_splitk(M), name="mlp_wgrad")
         if extra is not None:
             dw[:, Kx:] = colsum[:, None] * extra.reshape(1, -1)
         dx = None

@@ -20,6 +20,13 @@ extern "C" {
 int dwg_act_backward_colsum(int32_t M, int32_t N, int32_t act, const float* dy, const float* y, float* dz, float* colsum,
                             dwg_stream_t stream);
 
+/* Weight gradient of one Linear layer of the per-Gaussian MLPs: dw[n][k] = sum_m dz[m][n] * x[m][k], N, K <= 64, written to
+ * dw with row stride lddw (only the [N,K] block is touched).  Deterministic two-pass reduction; workspace holds
+ * dwg_mlp_wgrad_workspace_floats(M) floats. */
+size_t dwg_mlp_wgrad_workspace_floats(int32_t M);
+int dwg_mlp_wgrad(int32_t M, int32_t N, int32_t K, const float* dz, int32_t lddz, const float* x, int32_t ldx, float* dw,
+                  int32_t lddw, float* workspace, dwg_stream_t stream);
+
 /* torch.optim.Adam update (amsgrad=False, weight_decay=0) on n contiguous floats, step >= 1 is the 1-based step count;
  * grad is multiplied by grad_scale first (1/world_size after a sum all-reduce).  Buffers must be 16-byte aligned. */
 int dwg_adam_step(int64_t n, float* param, const float* grad, float* exp_avg, float* exp_avg_sq, float lr, float beta1,
