@@ -77,8 +77,8 @@ __global__ __launch_bounds__(256) void k_adam(size_t n, float* __restrict__ p, c
 __global__ __launch_bounds__(256) void k_mlp_wgrad_partial(int M, int N, int K, const float* __restrict__ dz, int lddz,
                                                            const float* __restrict__ x, int ldx, int rows_per_block,
                                                            float* __restrict__ partial /*[blocks][64][64]*/) {
-    __shared__ float sdz[64][65];
-    __shared__ float sx[64][65];
+    __shared__ __attribute__((aligned(16))) float sdz[64][68];
+    __shared__ __attribute__((aligned(16))) float sx[64][68];
     const int tid = threadIdx.x, tn = (tid >> 4) * 4, tk = (tid & 15) * 4;
     const int r0 = blockIdx.x * rows_per_block, r1 = min(M, r0 + rows_per_block);
     float acc[4][4];
@@ -96,9 +96,9 @@ __global__ __launch_bounds__(256) void k_mlp_wgrad_partial(int M, int N, int K, 
         __syncthreads();
 #pragma unroll 8
         for (int r = 0; r < 64; r++) {
-            float a[4], b[4];
-#pragma unroll
-            for (int q = 0; q < 4; q++) { a[q] = sdz[r][tn + q]; b[q] = sx[r][tk + q]; }
+            const float4 av = *reinterpret_cast<const float4*>(&sdz[r][tn]);
+            const float4 bv = *reinterpret_cast<const float4*>(&sx[r][tk]);
+            const float a[4] = {av.x, av.y, av.z, av.w}, b[4] = {bv.x, bv.y, bv.z, bv.w};
 #pragma unroll
             for (int q = 0; q < 4; q++)
 #pragma unroll
@@ -114,13 +114,18 @@ __global__ __launch_bounds__(256) void k_mlp_wgrad_partial(int M, int N, int K, 
 
 __global__ __launch_bounds__(256) void k_mlp_wgrad_final(int blocks, int N, int K, const float* __restrict__ partial,
                                                          float* __restrict__ dw, int lddw) {
-    const int e = blockIdx.x * 256 + threadIdx.x;
-    if (e >= 4096) return;
-    const int n = e >> 6, k = e & 63;
-    if (n >= N || k >= K) return;
+    // 64 outputs per workgroup x 4 strands over the partial tiles; fixed combination order
+    __shared__ float part[4][64];
+    const int o = threadIdx.x & 63, strand = threadIdx.x >> 6;
+    const int e = blockIdx.x * 64 + o;
     float s = 0.f;
-    for (int b = 0; b < blocks; b++) s += partial[(size_t)b * 4096 + e];
-    dw[(size_t)n * lddw + k] = s;
+    for (int b = strand; b < blocks; b += 4) s += partial[(size_t)b * 4096 + e];
+    part[strand][o] = s;
+    __syncthreads();
+    if (strand == 0) {
+        const int n = e >> 6, k = e & 63;
+        if (n < N && k < K) dw[(size_t)n * lddw + k] = (part[0][o] + part[1][o]) + (part[2][o] + part[3][o]);
+    }
 }
 
 typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8_t;
@@ -160,7 +165,7 @@ static int grid_for(long long n) { long long b = (n + 255) / 256; if (b < 1) b =
 extern "C" {
 
 size_t dwg_mlp_wgrad_workspace_floats(int32_t M) {
-    int rpb = 1024, blocks = dwg_cdiv(M > 0 ? M : 1, rpb);
+    int rpb = 256, blocks = dwg_cdiv(M > 0 ? M : 1, rpb);
     return (size_t)blocks * 4096;
 }
 
@@ -170,9 +175,9 @@ int dwg_mlp_wgrad(int32_t M, int32_t N, int32_t K, const float* dz, int32_t lddz
     if (M == 0) {
         return DWG_OK;
     }
-    const int rpb = 1024, blocks = dwg_cdiv(M, rpb);
+    const int rpb = 256, blocks = dwg_cdiv(M, rpb);
     DWG_LAUNCH("mlp_wgrad", k_mlp_wgrad_partial, dim3(blocks), dim3(256), 0, (hipStream_t)stream, M, N, K, dz, lddz, x, ldx, rpb, workspace);
-    DWG_LAUNCH("mlp_wgrad_final", k_mlp_wgrad_final, dim3(16), dim3(256), 0, (hipStream_t)stream, blocks, N, K, (const float*)workspace,
+    DWG_LAUNCH("mlp_wgrad_final", k_mlp_wgrad_final, dim3(64), dim3(256), 0, (hipStream_t)stream, blocks, N, K, (const float*)workspace,
                dw, lddw);
     DWG_RETURN_IF_LAUNCH_FAILED();
     return DWG_OK;
