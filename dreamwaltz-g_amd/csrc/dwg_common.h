@@ -9,10 +9,11 @@
 #define DWG_TILE 16
 #define DWG_WAVE 64
 
+int& dwg_launch_failed_flag();
 #define DWG_RETURN_IF_LAUNCH_FAILED()                    \
     do {                                                 \
-        hipError_t e__ = hipGetLastError();              \
-        if (e__ != hipSuccess) return DWG_E_LAUNCH;      \
+        int& f__ = dwg_launch_failed_flag();             \
+        if (f__) { f__ = 0; return DWG_E_LAUNCH; }       \
     } while (0)
 
 static inline size_t dwg_align_up(size_t x, size_t a) { return (x + a - 1) / a * a; }

@@ -25,6 +25,11 @@ void clear_locked() {
 
 bool dwg_prof_on() { return g_on; }
 
+int& dwg_launch_failed_flag() {
+    static thread_local int flag = 0;
+    return flag;
+}
+
 void dwg_prof_begin(const char* name, hipStream_t stream, void** token) {
     *token = nullptr;
     if (!g_on) return;
