@@ -129,7 +129,7 @@ def main():
     }
     out["roofline"] = step.roofline(prof, HBM_PEAK_GBS, BF16_PEAK_TFLOPS)
     out["raster_mpix_per_s"] = args.res * args.res * views_per_step * args.steps / dt / 1e6
-    out["kernel_ms_per_step"] = {k: v[1] / prof_steps for k, v in sorted(prof.items(), key=lambda kv: -kv[1][1])[:20]}
+    out["kernel_ms_per_step"] = {k: round(v[1] / prof_steps, 4) for k, v in sorted(prof.items(), key=lambda kv: -kv[1][1])[:40]}
     out["launch_mode"] = "eager" if args.eager else "hipGraph replay of denoiser/VAE plans; kernel timers from an eager replay after the timed region"
     if not args.no_cpu_baseline and world == 1:
         out["cpu_baseline"] = cpu_baseline(args, info)

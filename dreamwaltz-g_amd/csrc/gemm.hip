@@ -242,6 +242,30 @@ template <int TM, int TN>
 __device__ __forceinline__ void tile_epilogue(const GemmP& p, f32x16 (&acc)[TM][TN], int m0, int n0, int wm, int wn, int lane,
                                               int ks_id, int z1, int z2) {
     const long long coff = z1 * p.bC1 + z2 * p.bC2, roff = z1 * p.bR1 + z2 * p.bR2;
+    if (p.act == 6) {
+        // GEGLU pair epilogue (diffusers GEGLU: hidden, gate = proj(x).chunk(2); hidden * gelu(gate)).  The projection rows are
+        // pre-interleaved in blocks of 32 so that accumulator tile j=0 holds `hidden` and j=1 the matching `gate` columns:
+        // the product is formed in registers and only the half-width result is stored (no [M, 8C] round trip).
+        const int colp = n0 + wn * 64 + (lane & 31);                 // column of the hidden half inside the interleaved layout
+        if (colp + 32 < p.N + 0 && colp < p.N) {
+            const int ocol = (n0 + wn * 64) / 2 + (lane & 31);
+            const float* bias = reinterpret_cast<const float*>(p.bias);
+            const float ba = bias ? bias[colp] : 0.f, bg = bias ? bias[colp + 32] : 0.f;
+#pragma unroll
+            for (int i = 0; i < TM; i++)
+#pragma unroll
+                for (int r = 0; r < 16; r++) {
+                    const int row = m0 + (wm * TM + i) * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+                    if (row >= p.M) continue;
+                    const float a = acc[i][0][r] * p.alpha + ba, g = acc[i][1][r] * p.alpha + bg;
+                    const float v = a * 0.5f * g * (1.f + erff(g * 0.70710678118654752f));
+                    const long long ci = coff + (long long)row * p.ldc + ocol;
+                    if (p.out_bf16) reinterpret_cast<__bf16*>(p.C)[ci] = f2bf(v);
+                    else reinterpret_cast<float*>(p.C)[ci] = v;
+                }
+        }
+        return;
+    }
 #pragma unroll
     for (int i = 0; i < TM; i++)
 #pragma unroll
@@ -713,7 +737,7 @@ extern "C" {
 size_t dwg_gemm_workspace_bytes(const dwg_gemm_desc* d) {
     if (!d || d->batch1 * d->batch2 != 1 || d->M <= 0 || d->N <= 0) return 0;
     const int bn = tile_bn(d), bk = d->dtype == DWG_DTYPE_BF16 ? TT<__bf16>::BK : TT<float>::BK;
-    int sk = d->splitk > 1 ? d->splitk : (d->splitk == 0 ? auto_splitk(d->M, d->N, d->K, bn, bk) : 1);
+    int sk = d->splitk > 1 ? d->splitk : (d->splitk == 0 && d->act != DWG_ACT_GEGLU_PAIR ? auto_splitk(d->M, d->N, d->K, bn, bk) : 1);
     return sk > 1 ? (size_t)sk * d->M * d->N * sizeof(float) : 0;
 }
 
@@ -724,6 +748,7 @@ int dwg_gemm(const dwg_gemm_desc* d, dwg_stream_t stream_) {
     if (d->dtype != DWG_DTYPE_F32 && d->dtype != DWG_DTYPE_BF16) return DWG_E_ARG;
     if (d->splitk > 1 && !d->workspace && (d->out_dtype != DWG_DTYPE_F32 || d->bias || d->residual || d->act)) return DWG_E_ARG;
     if (d->accumulate && d->out_dtype != DWG_DTYPE_F32) return DWG_E_ARG;
+    if (d->act == DWG_ACT_GEGLU_PAIR && (d->N % 64 != 0 || d->residual || d->splitk > 1 || d->bias_per_row || d->bias_row_div)) return DWG_E_ARG;
     GemmP p;
     p.A = d->A; p.B = d->B; p.C = d->C; p.bias = d->bias; p.residual = d->residual;
     p.M = d->M; p.N = d->N; p.K = d->K;
@@ -739,7 +764,7 @@ int dwg_gemm(const dwg_gemm_desc* d, dwg_stream_t stream_) {
     {
         const int bn = tile_bn(d), bk = d->dtype == DWG_DTYPE_BF16 ? TT<__bf16>::BK : TT<float>::BK;
         if (d->workspace && d->batch1 * d->batch2 == 1) {
-            int sk = d->splitk > 1 ? d->splitk : (d->splitk == 0 ? auto_splitk(d->M, d->N, d->K, bn, bk) : 1);
+            int sk = d->splitk > 1 ? d->splitk : (d->splitk == 0 && d->act != DWG_ACT_GEGLU_PAIR ? auto_splitk(d->M, d->N, d->K, bn, bk) : 1);
             while (sk > 1 && (size_t)sk * d->M * d->N * sizeof(float) > d->workspace_bytes) sk--;
             p.splitk = sk;
             if (sk > 1) p.ws = reinterpret_cast<float*>(d->workspace);

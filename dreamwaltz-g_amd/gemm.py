@@ -6,7 +6,7 @@ import torch
 from . import _lib
 
 F32, BF16 = 0, 1
-ACT = {None: 0, "none": 0, "relu": 1, "leaky_relu": 2, "silu": 3, "gelu": 4, "sigmoid": 5}
+ACT = {None: 0, "none": 0, "relu": 1, "leaky_relu": 2, "silu": 3, "gelu": 4, "sigmoid": 5, "geglu_pair": 6}
 
 
 class GemmDesc(ctypes.Structure):

@@ -330,6 +330,18 @@ class Weights:
                                          for n in names], 0).to(self.device, BF16).contiguous()
         return self.cache[key]
 
+    def lin_geglu(self, name):
+        """GEGLU projection [8C, C] (rows: hidden | gate) re-ordered in 32-row blocks [hidden_q | gate_q] for the fused
+        GEGLU-pair epilogue of dwg_gemm; returns (weight bf16, bias fp32) in that order."""
+        key = ("geglu", name)
+        if key not in self.cache:
+            w = self.sd[name + ".weight"].float(); b = self.sd[name + ".bias"].float()
+            F = w.shape[0] // 2
+            idx = torch.arange(F).view(-1, 32)
+            perm = torch.cat([idx, idx + F], dim=1).reshape(-1)          # [q*64 + 0..31] = hidden, [q*64 + 32..63] = gate
+            self.cache[key] = (w[perm].to(self.device, BF16).contiguous(), b[perm].to(self.device).contiguous())
+        return self.cache[key]
+
     def f32(self, name):
         if name not in self.cache:
             self.cache[name] = self.sd[name].float().to(self.device).contiguous()
@@ -343,11 +355,17 @@ class Weights:
 
 
 class Builder:
-    def __init__(self, plan: Plan, w: Weights, groups=32):
-        self.p, self.w, self.groups = plan, w, groups
+    def __init__(self, plan: Plan, w: Weights, groups=32, prefix="net"):
+        self.p, self.w, self.groups, self.prefix = plan, w, groups, prefix
         self.L = _lib.lib()
 
     # -- contractions -------------------------------------------------------------------------------------------
+    def _conv_tag(self, tag, KH, Ho, stride, dil):
+        if tag:
+            return tag
+        base = "conv3x3" if KH == 3 else "conv1x1"
+        return "%s%s_%s_r%d" % (base, "s2" if stride == 2 else ("T" if dil > 1 else ""), self.prefix, Ho)
+
     def conv(self, x, name, stride=1, pad=1, act=None, residual=None, upsample=1, bias_img=None, out_dtype=BF16, out_hw=None,
              pad_tl=None, r_batch_bcast=False, weight=None, bias=True, in_dilation=1, tag=None):
         """x [B,H,W,C] NHWC bf16. bias_img: (tensor [B, ld] fp32, ld) per-image channel bias replacing the conv bias."""
@@ -372,7 +390,7 @@ class Builder:
         if r_batch_bcast:   # residual is [1,Ho,Wo,Cout] broadcast over the batch: run as a batched GEMM, one image per batch
             d = gemm.gemm_raw(x, wt, y, Ho * Wo, Cout, K, (0, 1), (K, 1), Cout, bias=b, residual=residual, ldr=Cout, act=act,
                               batch=(B, 1), a_batch=(H * W * C, 0), c_batch=(Ho * Wo * Cout, 0), r_batch=(0, 0), conv=conv,
-                              conv_upsample=upsample, name=tag or "conv3x3" if KH == 3 else "conv1x1", run=False)
+                              conv_upsample=upsample, name=self._conv_tag(tag, KH, Ho, stride, in_dilation), run=False)
         else:
             kw = {}
             if bias_img is not None:
@@ -381,7 +399,7 @@ class Builder:
                 kw = dict(bias=b)
             d = gemm.gemm_raw(x, wt, y, B * Ho * Wo, Cout, K, (0, 1), (K, 1), Cout, residual=residual,
                               ldr=Cout if residual is not None else 0, act=act, conv=conv, conv_upsample=upsample,
-                              name=tag or ("conv3x3" if KH == 3 else "conv1x1"), run=False, **kw)
+                              name=self._conv_tag(tag, KH, Ho, stride, in_dilation), run=False, **kw)
         self.p.add_gemm(d)
         return y
 
@@ -389,9 +407,10 @@ class Builder:
         K = x.shape[-1]
         M = x.numel() // K
         N = wt.shape[0]
-        y = self.p.buf(*x.shape[:-1], N, dtype=out_dtype)
-        d = gemm.gemm_raw(x, wt, y, M, N, K, (K, 1), (wt.stride(0), 1), N, bias=bias, residual=residual,
-                          ldr=N if residual is not None else 0, act=act, name=tag, run=False)
+        Nout = N // 2 if act == "geglu_pair" else N
+        y = self.p.buf(*x.shape[:-1], Nout, dtype=out_dtype)
+        d = gemm.gemm_raw(x, wt, y, M, N, K, (K, 1), (wt.stride(0), 1), Nout, bias=bias, residual=residual,
+                          ldr=Nout if residual is not None else 0, act=act, name=tag, run=False)
         self.p.add_gemm(d)
         return y
 
@@ -496,8 +515,8 @@ class Builder:
         a = self.attention(q, kv[..., :C], kv[..., C:], heads)
         h = self.linear(a, self.w.lin(t + ".attn2.to_out.0"), bias=self.w.f32(t + ".attn2.to_out.0.bias"), residual=h, tag="attn_out")
         l3 = self.layernorm(h, t + ".norm3")
-        f = self.linear(l3, self.w.lin(t + ".ff.net.0.proj"), bias=self.w.f32(t + ".ff.net.0.proj.bias"), tag="ff_in")
-        g = self.geglu(f)
+        wg, bg = self.w.lin_geglu(t + ".ff.net.0.proj")
+        g = self.linear(l3, wg, bias=bg, act="geglu_pair", tag="ff_in")       # GEGLU fused into the projection's epilogue
         h = self.linear(g, self.w.lin(t + ".ff.net.2"), bias=self.w.f32(t + ".ff.net.2.bias"), residual=h, tag="ff_out")
         return self.conv(h.view(B, H, W, C), pre + ".proj_out", pad=0, residual=x)
 
@@ -576,7 +595,7 @@ class DenoiserPlan:
         p = self.plan
         wu, wc = Weights(unet_sd, device), Weights(cn_sd, device)
         self.weights = (wu, wc)     # kernel-layout weight tensors must outlive the plan that points at them
-        bu, bc = Builder(p, wu, cfg.groups), Builder(p, wc, cfg.groups)
+        bu, bc = Builder(p, wu, cfg.groups, "unet"), Builder(p, wc, cfg.groups, "cnet")
         B, hw = batch, latent_hw
         self.latents = p.buf(B, hw, hw, _pad8(cfg.in_channels), zero=True)
         self.text = p.buf(B, text_len, cfg.cross_dim)
@@ -638,7 +657,7 @@ class VAEEncoderPlan:
         self.fwd, self.bwd = Plan(device), Plan(device)
         w = Weights(sd, device)
         self.weights = w            # kernel-layout weight tensors must outlive the plans that point at them
-        f, r = Builder(self.fwd, w, cfg.groups), Builder(self.bwd, w, cfg.groups)
+        f, r = Builder(self.fwd, w, cfg.groups, "vaef"), Builder(self.bwd, w, cfg.groups, "vaeb")
         self.x = self.fwd.buf(1, image_hw, image_hw, 8, zero=True)
         boc = cfg.block_out_channels
         tape = []      # closures that extend the backward plan, replayed in reverse order

@@ -173,6 +173,16 @@ class SDSStep:
         if not prof:
             return None
         flops = self.flops_by_kernel()
+        # per-resolution conv labels (conv3x3_<net>_r<H>) are one kernel family: merge them for the roofline entry
+        merged, mflops = {}, {}
+        for k, (c, ms) in prof.items():
+            fam = "conv3x3" if k.startswith("conv3x3") else ("conv1x1" if k.startswith("conv1x1") else k)
+            c0, m0 = merged.get(fam, (0, 0.0))
+            merged[fam] = (c0 + c, m0 + ms)
+        for k, v in flops.items():
+            fam = "conv3x3" if k.startswith("conv3x3") else ("conv1x1" if k.startswith("conv1x1") else k)
+            mflops[fam] = mflops.get(fam, 0.0) + v
+        prof, flops = merged, mflops
         name, (count, total_ms) = max(prof.items(), key=lambda kv: kv[1][1])
         steps = max(1, self.step_idx and 1)
         G, K, P = self.G, self.num_pairs, self.res * self.res
@@ -197,7 +207,7 @@ class SDSStep:
                 out = {"kernel": name, "bound": "hbm", "achieved": None, "peak": hbm_peak_gbs, "unit": "GB/s", "frac": None,
                        "traffic": None, "avg_launch_ms": avg_ms, "launches": count}
         # the rasterizer's own HBM roofline is part of the headline metric: always report it next to the dominant kernel
-        rf = sum(prof[k][1] for k in prof if k.startswith("raster_") and not k.endswith("_bwd"))
+        rf = sum(prof[k][1] for k in prof if k.startswith("raster_") and not k.endswith("_bwd"))  # noqa
         rb = sum(prof[k][1] for k in prof if k.startswith("raster_") and k.endswith("_bwd"))
         n = max(1, prof.get("raster_render_fwd", (1, 0))[0])
         if rf > 0:

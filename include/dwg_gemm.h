@@ -34,6 +34,8 @@ extern "C" {
 #define DWG_ACT_SILU 3
 #define DWG_ACT_GELU 4       /* exact erf form */
 #define DWG_ACT_SIGMOID 5
+#define DWG_ACT_GEGLU_PAIR 6  /* C[m][f] = (acc[f] + b[f]) * gelu(acc[f+32] + b[f+32]) on a 32-interleaved [hidden|gate] projection;
+                                 C has N/2 columns (ldc counts those), N % 64 == 0, no residual / split-K */
 
 typedef struct dwg_gemm_desc {
     const void* A; const void* B; void* C;

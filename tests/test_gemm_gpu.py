@@ -143,3 +143,22 @@ def test_bf16_splitk_slab_epilogue_small_m():
     d.workspace, d.workspace_bytes = ws.data_ptr(), need
     gemm.run_desc(d, ctypes.c_void_p(torch.cuda.current_stream().cuda_stream))
     assert _rel(y.cpu(), ref) < 1.2e-2
+
+
+def test_bf16_geglu_pair_epilogue():
+    """Fused GEGLU: hidden * gelu(gate) formed in the projection's epilogue from a 32-interleaved [hidden|gate] weight."""
+    from dreamwaltz_g_amd import gemm
+    g = torch.Generator().manual_seed(8)
+    M, C = 1000, 320
+    x = torch.randn(M, C, generator=g).bfloat16()
+    w = (torch.randn(8 * C, C, generator=g) / C ** 0.5).bfloat16(); b = torch.randn(8 * C, generator=g) * 0.1
+    h = x.double() @ w.double().t() + b.double()
+    hid, gate = h.chunk(2, dim=-1)
+    ref = hid * torch.nn.functional.gelu(gate)
+    F_ = 4 * C
+    idx = torch.arange(F_).view(-1, 32)
+    perm = torch.cat([idx, idx + F_], dim=1).reshape(-1)
+    wp, bp = w[perm].contiguous().cuda(), b[perm].contiguous().cuda()
+    y = torch.empty(M, F_, device="cuda", dtype=torch.bfloat16)
+    gemm.gemm_raw(x.cuda(), wp, y, M, 8 * C, C, (C, 1), (C, 1), F_, bias=bp, act="geglu_pair")
+    assert _rel(y.cpu(), ref) < 1.2e-2
