@@ -114,6 +114,7 @@ def main():
             step.run()
         torch.cuda.synchronize()
     prof = _lib.prof_table()
+    prof_sym = _lib.prof_symbols()
     _lib.prof_enable(False)
     if rank != 0:
         return
@@ -127,7 +128,7 @@ def main():
         "scaling": "weak", "vs_baseline": None, "dtype": info["dtype"], "data": "synthetic",
         "config": info["config"],
     }
-    out["roofline"] = step.roofline(prof, HBM_PEAK_GBS, BF16_PEAK_TFLOPS)
+    out["roofline"] = step.roofline(prof, HBM_PEAK_GBS, BF16_PEAK_TFLOPS, prof_sym)
     out["raster_mpix_per_s"] = args.res * args.res * views_per_step * args.steps / dt / 1e6
     out["kernel_ms_per_step"] = {k: round(v[1] / prof_steps, 4) for k, v in sorted(prof.items(), key=lambda kv: -kv[1][1])[:40]}
     out["launch_mode"] = "eager" if args.eager else "hipGraph replay of denoiser/VAE plans; kernel timers from an eager replay after the timed region"

@@ -77,6 +77,7 @@ SIGNATURES = {
     "dwg_prof_enable": (ctypes.c_int, [_i32]),
     "dwg_prof_query": (ctypes.c_int, [ctypes.c_char_p, ctypes.POINTER(_i64), ctypes.POINTER(ctypes.c_double)]),
     "dwg_prof_dump": (_i64, [ctypes.c_char_p, _i64]),
+    "dwg_prof_dump_symbols": (_i64, [ctypes.c_char_p, _i64]),
 }
 
 
@@ -120,4 +121,17 @@ def prof_table():
     for line in buf.value.decode().splitlines():
         n, c, ms = line.split()
         out[n] = (int(c), float(ms))
+    return out
+
+
+def prof_symbols():
+    """{kernel symbol (as rocprofv3 lists it): (launches, total_ms, algorithmic work)} since prof_enable(True)."""
+    L = lib()
+    need = L.dwg_prof_dump_symbols(None, 0)
+    buf = ctypes.create_string_buffer(int(need) + 16)
+    L.dwg_prof_dump_symbols(buf, len(buf))
+    out = {}
+    for line in buf.value.decode().splitlines():
+        n, c, ms, w = line.split("\t")
+        out[n] = (int(c), float(ms), float(w))
     return out

@@ -362,26 +362,32 @@ __global__ __launch_bounds__(256) void k_splitk_epilogue(GemmP p) {
 // ---------------------------------------------------------------------------------------------------------------------
 // bf16 fast path: operands go HBM/L2 -> LDS directly (global_load_lds_dwordx4, no VGPR staging, no ds_write pass).
 // The LDS image of a tile is lane-linear per wave-instruction (8 rows x 128 B), so bank conflicts are avoided by an XOR
-// swizzle applied on the SOURCE side: LDS slot (row, c) holds logical 16-byte chunk c ^ (row & 7); readers apply the same XOR.
+// swizzle applied on the SOURCE side: LDS slot (row, c) holds logical 16-byte chunk c ^ swz(row), swz(row) = (row >> 1) & 7;
+// readers apply the same XOR.  ds_read_b128 is serviced in 16-lane groups ({0-3,12-15,20-27}, {4-11,16-19,28-31}, +32) over
+// 64 banks: a group's 16 fragment rows cover every residue mod 16, and (row & 1, swz(row)) then selects 16 distinct
+// 16-byte bank slots -> conflict-free (row & 7 as the XOR would pair them up 2-way).
 // Halo / out-of-range chunks are sourced from a 16-byte zero page.
 // ---------------------------------------------------------------------------------------------------------------------
 __device__ __attribute__((aligned(16))) unsigned char g_zero16[16];
 
 template <int ROWS, bool CONV>
 struct GldsLoader {
-    static constexpr int NJ = ROWS / 32;       // wave-instructions per wave per tile (each covers 8 rows)
+    static constexpr int NJ = ROWS / 32;       // wave-instructions per wave per tile (each covers 8 rows); even
     const __bf16* rowptr[CONV ? 1 : NJ];
     int iy0[CONV ? NJ : 1], ix0[CONV ? NJ : 1];
     long long pix0[CONV ? NJ : 1];
     bool rok[CONV ? NJ : 1];
     const __bf16* base;
-    int kcur, kend, ci, ky, kx;
+    // Two k-positions per lane: the logical chunk a lane fetches is slot ^ swz(row) with swz(row) = (row >> 1) & 7, and
+    // row = (wave*NJ + j)*8 + sub, so it depends on the parity of j (bit 2 of the XOR) -- [0] even j, [1] odd j.
+    int kc[2], kend, ci[2], ky[2], kx[2];
 
     __device__ __forceinline__ void init(const __bf16* base_, long long srow, int nrows, int r0, int kbeg, int kend_, const ConvP& cv) {
+        static_assert(NJ % 2 == 0, "row-block parity must equal j parity");
         base = base_; kend = kend_;
         const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, sub = lane >> 3;
-        const int logical = (lane & 7) ^ sub;              // row & 7 == sub for every row this lane loads
-        kcur = kbeg + logical * 8;
+        const int lg0 = (lane & 7) ^ (sub >> 1);
+        kc[0] = kbeg + lg0 * 8; kc[1] = kbeg + (lg0 ^ 4) * 8;
         if (!CONV) {
 #pragma unroll
             for (int j = 0; j < NJ; j++) {
@@ -400,40 +406,51 @@ struct GldsLoader {
                 iy0[j] = oy * cv.stride - cv.pad_t; ix0[j] = ox * cv.stride - cv.pad_l;
                 pix0[j] = (long long)img * cv.Hin * cv.Win;
             }
-            int tap = kcur / cv.Cin;
-            ci = kcur - tap * cv.Cin; ky = tap / cv.KW; kx = tap - ky * cv.KW;
+#pragma unroll
+            for (int q = 0; q < 2; q++) {
+                int tap = kc[q] / cv.Cin;
+                ci[q] = kc[q] - tap * cv.Cin; ky[q] = tap / cv.KW; kx[q] = tap - ky[q] * cv.KW;
+            }
         }
     }
     __device__ __forceinline__ void advance(const ConvP& cv) {
-        kcur += 64;
+        kc[0] += 64; kc[1] += 64;
         if (CONV) {
-            ci += 64;
-            while (ci >= cv.Cin) { ci -= cv.Cin; if (++kx == cv.KW) { kx = 0; ++ky; } }
+#pragma unroll
+            for (int q = 0; q < 2; q++) {
+                ci[q] += 64;
+                while (ci[q] >= cv.Cin) { ci[q] -= cv.Cin; if (++kx[q] == cv.KW) { kx[q] = 0; ++ky[q]; } }
+            }
         }
     }
     // lds_tile: byte address of this operand's tile in LDS (workgroup-uniform)
     __device__ __forceinline__ void issue(unsigned char* lds_tile, const ConvP& cv) {
         const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-        const bool kok = kcur < kend;
         const __bf16* zero = reinterpret_cast<const __bf16*>(g_zero16);
-        const __bf16* src0 = base; int cs = 0, co = 0;
-        if (CONV) {
-            src0 = ci < cv.cin1 ? base : reinterpret_cast<const __bf16*>(cv.A2);
-            cs = ci < cv.cin1 ? cv.cin1 : (cv.Cin - cv.cin1);
-            co = ci < cv.cin1 ? ci : ci - cv.cin1;
+        const __bf16* src0[2] = {base, base}; int cs[2] = {0, 0}, co[2] = {0, 0};
+        bool kok[2];
+#pragma unroll
+        for (int q = 0; q < 2; q++) {
+            kok[q] = kc[q] < kend;
+            if (CONV) {
+                src0[q] = ci[q] < cv.cin1 ? base : reinterpret_cast<const __bf16*>(cv.A2);
+                cs[q] = ci[q] < cv.cin1 ? cv.cin1 : (cv.Cin - cv.cin1);
+                co[q] = ci[q] < cv.cin1 ? ci[q] : ci[q] - cv.cin1;
+            }
         }
 #pragma unroll
         for (int j = 0; j < NJ; j++) {
+            const int q = j & 1;
             const __bf16* src;
             if (!CONV) {
-                src = (kok && rowptr[j]) ? rowptr[j] + kcur : zero;
+                src = (kok[q] && rowptr[j]) ? rowptr[j] + kc[q] : zero;
             } else {
-                int iy = iy0[j] + ky, ix = ix0[j] + kx;
-                bool ok = kok && rok[j] && iy >= 0 && ix >= 0;
+                int iy = iy0[j] + ky[q], ix = ix0[j] + kx[q];
+                bool ok = kok[q] && rok[j] && iy >= 0 && ix >= 0;
                 if (cv.dil > 1) { ok = ok && (iy % cv.dil == 0) && (ix % cv.dil == 0); iy /= cv.dil; ix /= cv.dil; }
                 if (cv.up > 1) { iy >>= 1; ix >>= 1; }
                 ok = ok && iy < cv.Hin && ix < cv.Win;
-                src = ok ? src0 + (pix0[j] + (long long)iy * cv.Win + ix) * cs + co : zero;
+                src = ok ? src0[q] + (pix0[j] + (long long)iy * cv.Win + ix) * cs[q] + co[q] : zero;
             }
             unsigned char* dst = lds_tile + ((wave * NJ + j) * 8) * 128;
             __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
@@ -442,7 +459,16 @@ struct GldsLoader {
     }
 };
 
-template <int BN, bool CONV>
+// s_waitcnt vmcnt(N) only (expcnt / lgkmcnt unconstrained): gfx9 encoding vmcnt = simm16[15:14] : simm16[3:0]
+template <int N>
+__device__ __forceinline__ void wait_vmcnt() {
+    __builtin_amdgcn_s_waitcnt((N & 15) | ((N >> 4) << 14) | (7 << 4) | (15 << 8));
+}
+
+// S-stage software pipeline: S-1 k-tiles are in flight (direct-to-LDS loads) while one is being multiplied; one barrier per
+// k-step.  Tiles past kend are still issued (from a 16-byte zero line) so that the outstanding-load count the s_waitcnt
+// relies on is a compile-time constant.
+template <int BN, bool CONV, int S>
 __global__ __launch_bounds__(256) void k_gemm_glds(GemmP p) {
     constexpr int BM = 128;
     constexpr int WN = BN / 64, WM = 4 / WN, TM = BM / WM / 32, TN = 2;
@@ -482,16 +508,20 @@ __global__ __launch_bounds__(256) void k_gemm_glds(GemmP p) {
     la.init(A, p.sam, p.M, m0, kbeg, kend, p.conv);
     lb.init(B, p.sbn, p.N, n0, kbeg, kend, p.conv);
     const int nk = kend > kbeg ? (kend - kbeg + 63) / 64 : 0;
-    if (nk > 0) { la.issue(smem_raw, p.conv); lb.issue(smem_raw + ABYTES, p.conv); }
-    // fragment addressing: row r, logical chunk cl -> byte r*128 + ((cl ^ (r & 7)) << 4); here r & 7 == lane & 7
-    const int frow = lane & 31, fx = lane & 7, fh = lane >> 5;
+    constexpr int LPT = (BM + BN) * 128 / (256 * 16);   // direct-to-LDS loads per thread per stage
+#pragma unroll
+    for (int s = 0; s < S - 1; s++) {
+        la.issue(smem_raw + s * STAGE, p.conv); lb.issue(smem_raw + s * STAGE + ABYTES, p.conv);
+        la.advance(p.conv); lb.advance(p.conv);
+    }
+    // fragment addressing: row r, logical chunk cl -> byte r*128 + ((cl ^ swz(r)) << 4); here swz(r) == (lane >> 1) & 7
+    const int frow = lane & 31, fx = (lane >> 1) & 7, fh = lane >> 5;
+    int cur = 0, nxt = S - 1;
     for (int kt = 0; kt < nk; kt++) {
-        const int cur = kt & 1;
-        __syncthreads();                    // tile kt has landed (vmcnt(0) + barrier); buffer cur^1 is free again
-        if (kt + 1 < nk) {
-            la.advance(p.conv); lb.advance(p.conv);
-            la.issue(smem_raw + (cur ^ 1) * STAGE, p.conv); lb.issue(smem_raw + (cur ^ 1) * STAGE + ABYTES, p.conv);
-        }
+        wait_vmcnt<(S - 2) * LPT>();        // this thread's loads of tile kt have landed ...
+        __builtin_amdgcn_s_barrier();       // ... and everybody's; everybody is also done reading the buffer refilled next
+        la.issue(smem_raw + nxt * STAGE, p.conv); lb.issue(smem_raw + nxt * STAGE + ABYTES, p.conv);
+        la.advance(p.conv); lb.advance(p.conv);
         const unsigned char* ta = smem_raw + cur * STAGE + (wm * TM * 32 + frow) * 128;
         const unsigned char* tb = smem_raw + cur * STAGE + ABYTES + (wn * 64 + frow) * 128;
 #pragma unroll
@@ -507,20 +537,50 @@ __global__ __launch_bounds__(256) void k_gemm_glds(GemmP p) {
 #pragma unroll
                 for (int j = 0; j < TN; j++) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[i], bf[j], acc[i][j], 0, 0, 0);
         }
+        cur = cur + 1 == S ? 0 : cur + 1; nxt = nxt + 1 == S ? 0 : nxt + 1;
     }
+    wait_vmcnt<0>();                        // drain the zero-line tail loads before LDS is handed back
     tile_epilogue<TM, TN>(p, acc, m0, n0, wm, wn, lane, ks_id, z1, z2);
 }
 
-template <int BN, bool CONV>
-static void launch_glds(const GemmP& p, int batch, hipStream_t stream, const char* name) {
-    size_t lds = (size_t)2 * (128 + BN) * 128;
+// Algorithmic flops of one launch for the profiler table: 2*M*N*K, with the zero taps of an input-dilated (strided-conv
+// dgrad) convolution not counted.
+static double gemm_flops(const GemmP& p, int batch) {
+    double f = 2.0 * p.M * p.N * p.K * batch;
+    if (p.conv.enabled && p.conv.dil > 1) f /= (double)(p.conv.dil * p.conv.dil);
+    return f;
+}
+
+template <int BN, bool CONV, int S>
+static void launch_glds_s(const GemmP& p, int batch, hipStream_t stream, const char* name) {
+    size_t lds = (size_t)S * (128 + BN) * 128;
+    static bool attr_set = false;
+    if (!attr_set) {
+        hipFuncSetAttribute(reinterpret_cast<const void*>(&k_gemm_glds<BN, CONV, S>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        attr_set = true;
+    }
     dim3 grid(((p.M + 127) / 128) * ((p.N + BN - 1) / BN) * (p.splitk > 1 ? p.splitk : 1), 1, batch);
-    DWG_LAUNCH(name, (k_gemm_glds<BN, CONV>), grid, dim3(256), lds, stream, p);
+    DWG_LAUNCH_W(name, (BN == 64 ? (CONV ? "k_gemm_glds<64,true>" : "k_gemm_glds<64,false>") : (CONV ? "k_gemm_glds<128,true>" : "k_gemm_glds<128,false>")),
+                 gemm_flops(p, batch), (k_gemm_glds<BN, CONV, S>), grid, dim3(256), lds, stream, p);
     if (p.splitk > 1 && p.ws) {
         long long n = (long long)p.M * p.N;
         int blocks = (int)((n + 255) / 256); if (blocks > 2048) blocks = 2048;
         DWG_LAUNCH("splitk_epilogue", k_splitk_epilogue, dim3(blocks), dim3(256), 0, stream, p);
     }
+}
+
+// Pipeline depth.  Measured on MI355X (tools/bench_gemm.py, DWG_GEMM_STAGES=2|3|4): deeper pipelines LOSE on every SDS
+// shape -- the extra LDS halves the resident workgroups per CU, and occupancy hides the global->LDS latency better than
+// run-ahead does (e.g. 512x1280x11520 split-K: 47 us at 2 stages, 76 us at 4).  2 stages stay the default; the deeper
+// instantiations are kept for experiments through the environment variable.
+template <int BN, bool CONV>
+static void launch_glds(const GemmP& p, int batch, hipStream_t stream, const char* name) {
+    static const int forced = getenv("DWG_GEMM_STAGES") ? atoi(getenv("DWG_GEMM_STAGES")) : 0;
+    const long long blocks = (long long)((p.M + 127) / 128) * ((p.N + BN - 1) / BN) * (p.splitk > 1 ? p.splitk : 1) * batch;
+    int S = forced ? forced : 2; (void)blocks;
+    if (S >= 4) launch_glds_s<BN, CONV, 4>(p, batch, stream, name);
+    else if (S == 3) launch_glds_s<BN, CONV, 3>(p, batch, stream, name);
+    else launch_glds_s<BN, CONV, 2>(p, batch, stream, name);
 }
 
 // ---------------------------------------------------------------------------------------------------------------------
@@ -557,7 +617,7 @@ __global__ __launch_bounds__(256) void k_conv3x3_patch(GemmP p) {
     const __bf16* X = reinterpret_cast<const __bf16*>(p.A) + (long long)img * cv.Hin * cv.Win * cv.Cin;
     const __bf16* Wt = reinterpret_cast<const __bf16*>(p.B);
     const __bf16* zero = reinterpret_cast<const __bf16*>(g_zero16);
-    const int sub = lane >> 3, logical = (lane & 7) ^ sub;
+    const int sub = lane >> 3, lg0 = (lane & 7) ^ (sub >> 1);      // logical chunk of an even 8-row block; odd: ^ 4
 
     // patch loader state: this wave issues patch instructions wave, wave+4, ... ; lane -> patch pixel (inst*8 + sub)
     auto issue_patch = [&](int cc, unsigned char* dst) {
@@ -567,6 +627,7 @@ __global__ __launch_bounds__(256) void k_conv3x3_patch(GemmP p) {
             const int py = pi / WP, px = pi - py * WP;
             const int iy = y0 - 1 + py, ix = x0 - 1 + px;
             const bool ok = pi < NPIX && iy >= 0 && iy < cv.Hin && ix >= 0 && ix < cv.Win;
+            const int logical = lg0 ^ ((inst & 1) << 2);
             const __bf16* src = ok ? X + ((long long)iy * cv.Win + ix) * cv.Cin + cc * 64 + logical * 8 : zero;
             __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
                                              (__attribute__((address_space(3))) void*)(dst + inst * 8 * 128), 16, 0, 0);
@@ -576,11 +637,11 @@ __global__ __launch_bounds__(256) void k_conv3x3_patch(GemmP p) {
     auto issue_w = [&](int cc, int tap, unsigned char* dst) {
         const int wv = __builtin_amdgcn_readfirstlane(wave);
         constexpr int NJ = BN / 32;
-        const long long kofs = (long long)tap * cv.Cin + cc * 64 + logical * 8;
+        const long long kofs = (long long)tap * cv.Cin + cc * 64;
 #pragma unroll
         for (int j = 0; j < NJ; j++) {
             const int r = n0 + (wv * NJ + j) * 8 + sub;
-            const __bf16* src = r < p.N ? Wt + (long long)r * p.sbn + kofs : zero;
+            const __bf16* src = r < p.N ? Wt + (long long)r * p.sbn + kofs + (lg0 ^ ((j & 1) << 2)) * 8 : zero;
             __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
                                              (__attribute__((address_space(3))) void*)(dst + (wv * NJ + j) * 8 * 128), 16, 0, 0);
         }
@@ -600,7 +661,7 @@ __global__ __launch_bounds__(256) void k_conv3x3_patch(GemmP p) {
         pbase[i] = (r >> 4) * WP + (r & 15);
     }
     const int ncc = cv.Cin / 64, nsteps = ncc * 9;
-    const int frow = lane & 31, fx = lane & 7, fh = lane >> 5;
+    const int frow = lane & 31, fx = (lane >> 1) & 7, fh = lane >> 5;
     issue_patch(0, sP);
     issue_w(0, 0, sB);
     for (int st = 0; st < nsteps; st++) {
@@ -621,7 +682,7 @@ __global__ __launch_bounds__(256) void k_conv3x3_patch(GemmP p) {
 #pragma unroll
             for (int i = 0; i < TM; i++) {
                 const int pi = pbase[i] + toff;
-                af[i] = *reinterpret_cast<const bf16x8*>(pa + pi * 128 + ((cl ^ (pi & 7)) << 4));
+                af[i] = *reinterpret_cast<const bf16x8*>(pa + pi * 128 + ((cl ^ ((pi >> 1) & 7)) << 4));
             }
 #pragma unroll
             for (int j = 0; j < TN; j++) bf[j] = *reinterpret_cast<const bf16x8*>(tb + j * 32 * 128 + ((cl ^ fx) << 4));
@@ -662,7 +723,8 @@ static void launch_conv3x3_patch(const GemmP& p, hipStream_t stream, const char*
         hipFuncSetAttribute(reinterpret_cast<const void*>(&k_conv3x3_patch<BN>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         attr_set = true;
     }
-    DWG_LAUNCH(name, (k_conv3x3_patch<BN>), grid, dim3(256), lds, stream, p);
+    DWG_LAUNCH_W(name, (BN == 64 ? "k_conv3x3_patch<64>" : "k_conv3x3_patch<128>"), gemm_flops(p, 1), (k_conv3x3_patch<BN>), grid,
+                 dim3(256), lds, stream, p);
 }
 
 template <typename T, int BN, int AMODE, int BMODE>
@@ -676,7 +738,8 @@ static void launch(const GemmP& p, int batch, hipStream_t stream, const char* na
                             (int)lds);
         attr_set = true;
     }
-    DWG_LAUNCH(name, (k_gemm<T, BN, AMODE, BMODE>), grid, dim3(256), lds, stream, p);
+    DWG_LAUNCH_W(name, (sizeof(T) == 2 ? "k_gemm<bf16>" : "k_gemm<f32>"), gemm_flops(p, batch), (k_gemm<T, BN, AMODE, BMODE>), grid,
+                 dim3(256), lds, stream, p);
     if (p.splitk > 1 && p.ws) {
         long long n = (long long)p.M * p.N;
         int blocks = (int)((n + 255) / 256); if (blocks > 2048) blocks = 2048;

@@ -11,7 +11,7 @@
 #include <cstring>
 
 namespace {
-struct Sample { hipEvent_t a, b; };
+struct Sample { hipEvent_t a, b; std::string symbol; double work; };
 std::mutex g_mu;
 bool g_on = false;
 std::map<std::string, std::vector<Sample>> g_samples;
@@ -30,10 +30,11 @@ int& dwg_launch_failed_flag() {
     return flag;
 }
 
-void dwg_prof_begin(const char* name, hipStream_t stream, void** token) {
+void dwg_prof_begin(const char* name, const char* symbol, double work, hipStream_t stream, void** token) {
     *token = nullptr;
     if (!g_on) return;
     Sample s;
+    s.symbol = symbol ? symbol : name; s.work = work;
     if (hipEventCreate(&s.a) != hipSuccess || hipEventCreate(&s.b) != hipSuccess) return;
     hipEventRecord(s.a, stream);
     std::lock_guard<std::mutex> lk(g_mu);
@@ -86,6 +87,33 @@ int64_t dwg_prof_dump(char* buf, int64_t cap) {
         dwg_prof_query(n.c_str(), &c, &ms);
         char line[256];
         snprintf(line, sizeof(line), "%s %lld %.6f\n", n.c_str(), (long long)c, ms);
+        out += line;
+    }
+    if (buf && cap > 0) {
+        size_t n = out.size() < (size_t)(cap - 1) ? out.size() : (size_t)(cap - 1);
+        memcpy(buf, out.data(), n); buf[n] = 0;
+    }
+    return (int64_t)out.size() + 1;
+}
+
+int64_t dwg_prof_dump_symbols(char* buf, int64_t cap) {
+    struct Agg { long long n = 0; double ms = 0.0, work = 0.0; };
+    std::map<std::string, Agg> agg;
+    {
+        std::lock_guard<std::mutex> lk(g_mu);
+        for (auto& kv : g_samples)
+            for (auto& s : kv.second) {
+                if (hipEventSynchronize(s.b) != hipSuccess) continue;
+                float ms = 0.f;
+                if (hipEventElapsedTime(&ms, s.a, s.b) != hipSuccess) continue;
+                Agg& a = agg[s.symbol];
+                a.n += 1; a.ms += ms; a.work += s.work;
+            }
+    }
+    std::string out;
+    for (auto& kv : agg) {
+        char line[384];
+        snprintf(line, sizeof(line), "%s\t%lld\t%.6f\t%.6e\n", kv.first.c_str(), kv.second.n, kv.second.ms, kv.second.work);
         out += line;
     }
     if (buf && cap > 0) {

@@ -168,44 +168,34 @@ class SDSStep:
                 tot[k] = tot.get(k, 0.0) + v
         return tot
 
-    def roofline(self, prof, hbm_peak_gbs, bf16_peak_tflops):
-        """Roofline entry for the dominant kernel (largest total time in the timed region)."""
+    def roofline(self, prof, hbm_peak_gbs, bf16_peak_tflops, symbols=None):
+        """Roofline entry for the dominant kernel = the kernel SYMBOL (as rocprofv3 --kernel-trace names it) with the
+        largest total time in the profiled region.  `symbols` = _lib.prof_symbols(): per-symbol launches, summed HIP-event
+        duration and summed algorithmic flops (2*M*N*K per launch), so achieved = flops per launch / average launch
+        duration, directly comparable with the AverageNs column of profiles/*_kernel_stats.csv."""
         if not prof:
             return None
-        flops = self.flops_by_kernel()
-        # per-resolution conv labels (conv3x3_<net>_r<H>) are one kernel family: merge them for the roofline entry
-        merged, mflops = {}, {}
-        for k, (c, ms) in prof.items():
-            fam = "conv3x3" if k.startswith("conv3x3") else ("conv1x1" if k.startswith("conv1x1") else k)
-            c0, m0 = merged.get(fam, (0, 0.0))
-            merged[fam] = (c0 + c, m0 + ms)
-        for k, v in flops.items():
-            fam = "conv3x3" if k.startswith("conv3x3") else ("conv1x1" if k.startswith("conv1x1") else k)
-            mflops[fam] = mflops.get(fam, 0.0) + v
-        prof, flops = merged, mflops
-        name, (count, total_ms) = max(prof.items(), key=lambda kv: kv[1][1])
-        steps = max(1, self.step_idx and 1)
         G, K, P = self.G, self.num_pairs, self.res * self.res
         out = {}
-        if name in flops and total_ms > 0:
-            launches_per_step = None
-            per_step_flops = flops[name]
-            # prof covers `steps_timed` steps; count launches -> per-launch average
-            avg_ms = total_ms / count
-            per_launch_flops = per_step_flops / (count / max(1, self._steps_timed(prof)))
-            ach = per_launch_flops / (avg_ms * 1e-3) / 1e12
-            out = {"kernel": name, "bound": "mfma", "achieved": ach, "peak": bf16_peak_tflops, "unit": "TFLOP/s",
-                   "frac": ach / bf16_peak_tflops, "traffic": None, "avg_launch_ms": avg_ms, "launches": count}
-        else:
-            avg_ms = total_ms / count
-            bytes_ = {"raster_render_fwd": 56 * G + 44 * K + 20 * P, "raster_render_bwd": 80 * K + 20 * P + 152 * G}.get(name)
-            if bytes_ is not None:
-                ach = bytes_ / (avg_ms * 1e-3) / 1e9
-                out = {"kernel": name, "bound": "hbm", "achieved": ach, "peak": hbm_peak_gbs, "unit": "GB/s", "frac": ach / hbm_peak_gbs,
-                       "traffic": None, "avg_launch_ms": avg_ms, "launches": count}
+        if symbols:
+            name, (count, total_ms, work) = max(symbols.items(), key=lambda kv: kv[1][1])
+            avg_ms = total_ms / max(1, count)
+            if work > 0:
+                ach = work / count / (avg_ms * 1e-3) / 1e12
+                out = {"kernel": name, "bound": "mfma", "achieved": ach, "peak": bf16_peak_tflops, "unit": "TFLOP/s",
+                       "frac": ach / bf16_peak_tflops, "traffic": None, "avg_launch_ms": avg_ms, "launches": count,
+                       "flops_per_launch": work / count}
             else:
                 out = {"kernel": name, "bound": "hbm", "achieved": None, "peak": hbm_peak_gbs, "unit": "GB/s", "frac": None,
                        "traffic": None, "avg_launch_ms": avg_ms, "launches": count}
+            # every MFMA kernel symbol, same formula (the conv / linear / attention products of the denoiser and the VAE)
+            out["mfma_kernels"] = {k: {"launches": c, "avg_launch_ms": ms / c, "tflops": w / (ms * 1e-3) / 1e12,
+                                       "frac": w / (ms * 1e-3) / 1e12 / bf16_peak_tflops}
+                                   for k, (c, ms, w) in sorted(symbols.items(), key=lambda kv: -kv[1][1]) if w > 0 and ms > 0}
+            tw = sum(w for (_, _, w) in symbols.values()); tms = sum(ms for (_, ms, w) in symbols.values() if w > 0)
+            if tms > 0:
+                out["mfma_all"] = {"tflops": tw / (tms * 1e-3) / 1e12, "frac": tw / (tms * 1e-3) / 1e12 / bf16_peak_tflops,
+                                   "flops_per_step": tw / self._steps_timed(prof)}
         # the rasterizer's own HBM roofline is part of the headline metric: always report it next to the dominant kernel
         rf = sum(prof[k][1] for k in prof if k.startswith("raster_") and not k.endswith("_bwd"))  # noqa
         rb = sum(prof[k][1] for k in prof if k.startswith("raster_") and k.endswith("_bwd"))

@@ -17,6 +17,10 @@ int dwg_prof_enable(int32_t enable);
 int dwg_prof_query(const char* name, int64_t* count, double* total_ms);
 /* Writes up to `cap` bytes of a newline-separated "name count total_ms" table; returns bytes needed. */
 int64_t dwg_prof_dump(char* buf, int64_t cap);
+/* Same samples aggregated by KERNEL SYMBOL (the name rocprofv3 --kernel-trace lists, e.g. "k_conv3x3_patch<128>"):
+ * newline-separated "symbol<TAB>count<TAB>total_ms<TAB>work", where work is the summed algorithmic flops of those
+ * launches (2*M*N*K for the GEMM / conv kernels, 0 where the caller computes bytes itself).  Returns bytes needed. */
+int64_t dwg_prof_dump_symbols(char* buf, int64_t cap);
 #ifdef __cplusplus
 }
 #endif
