@@ -68,6 +68,10 @@ SIGNATURES = {
     "dwg_concat_channels": (ctypes.c_int, [_i64, _i32, _i32, _vp, _vp, _vp, _vp]),
     "dwg_add_bf16": (ctypes.c_int, [_i64, _vp, _vp, _vp, _vp]),
     "dwg_cast_f32_to_bf16": (ctypes.c_int, [_i64, _vp, _vp, _vp]),
+    # include/dwg_meshbind.h
+    "dwg_mesh_vertex_normals": (ctypes.c_int, [_i32, _i32, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
+    "dwg_meshbind_forward": (ctypes.c_int, [_i32, _i32, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
+    "dwg_meshbind_backward": (ctypes.c_int, [_i32, _i32, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
     # include/dwg_graph.h
     "dwg_graph_begin_capture": (ctypes.c_int, [_vp]),
     "dwg_graph_end_capture": (ctypes.c_int, [_vp, ctypes.POINTER(_vp)]),

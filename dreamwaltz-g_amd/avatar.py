@@ -16,6 +16,7 @@ import torch.nn as nn
 import torch.nn.functional as F
 
 from . import lbs as lbs_ops
+from . import meshbind as mb_ops
 from .gridencoder import GridEncoder
 from .mlp import MLP, DeformNetwork
 
@@ -180,6 +181,19 @@ class MeshBindingGaussianModel(nn.Module):
         self._scales = nn.Parameter(torch.ones(Fp * n_per_triangle, 3) * init_scale_ratio)
         p2t = torch.arange(Fp)[:, None].expand(-1, n_per_triangle).reshape(-1)
         self.register_buffer("points_to_vertices", self.triangles[p2t])
+        # native path (csrc/meshbind.hip): int32 topology + the static vertex -> face adjacency for the normal gather
+        self.register_buffer("triangles_i32", self.triangles.to(torch.int32).contiguous())
+        off, faces = mb_ops.build_vertex_face_csr(self.triangles, vertex_coords.shape[0])
+        self.register_buffer("vf_offsets", off)
+        self.register_buffer("vf_faces", faces)
+
+    def forward(self, canonical_vertex_coords, observed_vertex_coords):
+        """get_positions (canonical + observed) and get_scales_and_quaternions (observed) in one forward / one backward
+        launch -> (canonical positions, positions, scales, quaternions).  The torch-op methods below are the same math,
+        kept as the reference-named entry points."""
+        vn = mb_ops.vertex_normals(observed_vertex_coords, self.triangles_i32, self.vf_offsets, self.vf_faces)
+        return mb_ops.meshbind(self._bary_coords, self._scales, canonical_vertex_coords, observed_vertex_coords, vn,
+                               self.triangles_i32, self._n_points_per_triangle)
 
     def get_positions(self, vertex_coords):
         bary = self._bary_coords / self._bary_coords.sum(dim=-1, keepdim=True)
@@ -231,6 +245,7 @@ class DreamWaltzG(nn.Module):
         self.nerf_scale_and_quaternion_net = DeformNetwork(xyz_input_ch=32, D=4, W=64)
         self.mesh_binding_gaussians = nn.ModuleDict(mesh_binding_gaussians or {})
         self._canonical_cache = None
+        self._canonical_vertices = {}
 
     # -- avatar.py:913-918
     def get_lbs_weights(self):
@@ -270,12 +285,12 @@ class DreamWaltzG(nn.Module):
         parts = [gaussians]
         for _name, gm in self.mesh_binding_gaussians.items():
             vc = gm._vertex_coords
-            cvc = self.lbs_model.transform_vertices(ctr, gm.predefined_vertex_indices, vc)
-            cpos = gm.get_positions(cvc)
+            cvc = self._canonical_vertices.get(_name)
+            if cvc is None:                          # canonical pose and the bound vertices are fixed: transform once
+                cvc = self._canonical_vertices[_name] = self.lbs_model.transform_vertices(ctr, gm.predefined_vertex_indices, vc)
+            ovc = self.lbs_model.transform_vertices(otr, gm.predefined_vertex_indices, vc)
+            cpos, pos_m, sc_m, q_m = gm(cvc, ovc)    # one HIP launch each way (csrc/meshbind.hip)
             enc_m = self.nerf_encoder(cpos, bound=self.nerf_bound)
             col_m, op_m = self.static_mlp_forward(enc_m, fix_opacities=True)
-            ovc = self.lbs_model.transform_vertices(otr, gm.predefined_vertex_indices, vc)
-            pos_m = gm.get_positions(ovc)
-            sc_m, q_m = gm.get_scales_and_quaternions(ovc, pos_m)
             parts.append(GaussianOutput(positions=pos_m, opacities=op_m, colors=col_m, quaternions=q_m, scales=sc_m))
         return merge_gaussians(*parts)

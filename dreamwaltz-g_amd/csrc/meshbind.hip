@@ -1,0 +1,147 @@
+// meshbind.hip -- mesh-bound Gaussians (hands / face): vertex normals + per-point position / tangent frame / extents,
+// forward and backward (include/dwg_meshbind.h; reference avatar.py:1016-1079, utils/mesh.py:34-94).
+// ~10^4 points: the work is tiny and latency-bound, the win is ONE launch instead of the reference's ~150 op kernels
+// per direction.  One lane per point / vertex / face; all per-point arithmetic lives in meshbind_math.h.
+#include "dwg_common.h"
+#include "dwg_prof_internal.h"
+#include "meshbind_math.h"
+#include "../../include/dwg_meshbind.h"
+
+namespace {
+
+__global__ __launch_bounds__(256) void k_face_normals(int Fp, const float* __restrict__ verts, const int* __restrict__ tri,
+                                                      float* __restrict__ fn) {
+    const int f = blockIdx.x * 256 + threadIdx.x;
+    if (f >= Fp) return;
+    const float* a = verts + 3 * (size_t)tri[3 * f];
+    const float* b = verts + 3 * (size_t)tri[3 * f + 1];
+    const float* c = verts + 3 * (size_t)tri[3 * f + 2];
+    float e1[3] = {b[0] - a[0], b[1] - a[1], b[2] - a[2]}, e2[3] = {c[0] - a[0], c[1] - a[1], c[2] - a[2]}, n[3];
+    dwg_mb_cross(e1, e2, n);
+    const float inv = 1.f / sqrtf(fmaxf(dwg_mb_dot(n, n), 1e-20f));      // safe_normalize
+    fn[3 * f] = n[0] * inv; fn[3 * f + 1] = n[1] * inv; fn[3 * f + 2] = n[2] * inv;
+}
+
+__global__ __launch_bounds__(256) void k_vertex_normals(int Vp, const float* __restrict__ fn, const int* __restrict__ vf_off,
+                                                        const int* __restrict__ vf_faces, float* __restrict__ vn) {
+    const int v = blockIdx.x * 256 + threadIdx.x;
+    if (v >= Vp) return;
+    float n[3] = {0.f, 0.f, 0.f};
+    for (int e = vf_off[v]; e < vf_off[v + 1]; e++) {
+        const float* f = fn + 3 * (size_t)vf_faces[e];
+        n[0] += f[0]; n[1] += f[1]; n[2] += f[2];
+    }
+    if (!(dwg_mb_dot(n, n) > 1e-20f)) { n[0] = 0.f; n[1] = 0.f; n[2] = 1.f; }
+    const float inv = 1.f / sqrtf(fmaxf(dwg_mb_dot(n, n), 1e-20f));
+    vn[3 * v] = n[0] * inv; vn[3 * v + 1] = n[1] * inv; vn[3 * v + 2] = n[2] * inv;
+}
+
+__device__ __forceinline__ void gather3(const float* __restrict__ src, const int* __restrict__ t, float out[3][3]) {
+#pragma unroll
+    for (int v = 0; v < 3; v++) {
+        const float* p = src + 3 * (size_t)t[v];
+        out[v][0] = p[0]; out[v][1] = p[1]; out[v][2] = p[2];
+    }
+}
+
+__global__ __launch_bounds__(256) void k_meshbind_fwd(int M, int n_per, const float* __restrict__ bary, const float* __restrict__ sc,
+                                                      const float* __restrict__ vc, const float* __restrict__ vo,
+                                                      const float* __restrict__ vn, const int* __restrict__ tri,
+                                                      float* __restrict__ pos_c, float* __restrict__ pos, float* __restrict__ scl,
+                                                      float* __restrict__ quat) {
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= M) return;
+    const int* t = tri + 3 * (size_t)(i / n_per);
+    const float b[3] = {bary[3 * (size_t)i], bary[3 * (size_t)i + 1], bary[3 * (size_t)i + 2]};
+    const float s[3] = {sc[3 * (size_t)i], sc[3 * (size_t)i + 1], sc[3 * (size_t)i + 2]};
+    float P[3][3], N[3][3], po[3], so[3], qo[4];
+    gather3(vo, t, P); gather3(vn, t, N);
+    dwg_meshbind_point(b, s, P, N, (float)n_per, po, so, qo);
+#pragma unroll
+    for (int c = 0; c < 3; c++) { pos[3 * (size_t)i + c] = po[c]; scl[3 * (size_t)i + c] = so[c]; }
+#pragma unroll
+    for (int c = 0; c < 4; c++) quat[4 * (size_t)i + c] = qo[c];
+    if (vc && pos_c) {
+        gather3(vc, t, P);
+        dwg_meshbind_position(b, P, po);
+#pragma unroll
+        for (int c = 0; c < 3; c++) pos_c[3 * (size_t)i + c] = po[c];
+    }
+}
+
+__global__ __launch_bounds__(256) void k_meshbind_bwd(int M, int n_per, const float* __restrict__ bary, const float* __restrict__ sc,
+                                                      const float* __restrict__ vc, const float* __restrict__ vo,
+                                                      const float* __restrict__ vn, const int* __restrict__ tri,
+                                                      const float* __restrict__ g_pos_c, const float* __restrict__ g_pos,
+                                                      const float* __restrict__ g_scl, const float* __restrict__ g_quat,
+                                                      float* __restrict__ g_bary, float* __restrict__ g_sc) {
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= M) return;
+    const int* t = tri + 3 * (size_t)(i / n_per);
+    const float b[3] = {bary[3 * (size_t)i], bary[3 * (size_t)i + 1], bary[3 * (size_t)i + 2]};
+    const float s[3] = {sc[3 * (size_t)i], sc[3 * (size_t)i + 1], sc[3 * (size_t)i + 2]};
+    float P[3][3], N[3][3];
+    gather3(vo, t, P); gather3(vn, t, N);
+    float gp[3] = {0.f, 0.f, 0.f}, gs[3] = {0.f, 0.f, 0.f}, gq[4] = {0.f, 0.f, 0.f, 0.f};
+    if (g_pos) { gp[0] = g_pos[3 * (size_t)i]; gp[1] = g_pos[3 * (size_t)i + 1]; gp[2] = g_pos[3 * (size_t)i + 2]; }
+    if (g_scl) { gs[0] = g_scl[3 * (size_t)i]; gs[1] = g_scl[3 * (size_t)i + 1]; gs[2] = g_scl[3 * (size_t)i + 2]; }
+    if (g_quat) { gq[0] = g_quat[4 * (size_t)i]; gq[1] = g_quat[4 * (size_t)i + 1]; gq[2] = g_quat[4 * (size_t)i + 2]; gq[3] = g_quat[4 * (size_t)i + 3]; }
+    float gb[3] = {0.f, 0.f, 0.f}, gsc[3];
+    dwg_meshbind_point_bwd(b, s, P, N, (float)n_per, gp, gs, gq, gb, gsc);
+    if (vc && g_pos_c) {
+        gather3(vc, t, P);
+        const float gc[3] = {g_pos_c[3 * (size_t)i], g_pos_c[3 * (size_t)i + 1], g_pos_c[3 * (size_t)i + 2]};
+        dwg_meshbind_position_bwd(b, P, gc, gb);
+    }
+#pragma unroll
+    for (int c = 0; c < 3; c++) { g_bary[3 * (size_t)i + c] = gb[c]; g_sc[3 * (size_t)i + c] = gsc[c]; }
+}
+
+}  // namespace
+
+extern "C" {
+
+int dwg_mesh_vertex_normals(int32_t Vp, int32_t Fp, const float* verts, const int32_t* triangles, const int32_t* vf_offsets,
+                            const int32_t* vf_faces, float* face_normals, float* vertex_normals, dwg_stream_t stream_) {
+    if (Vp < 0 || Fp < 0) return DWG_E_ARG;
+    if (Vp == 0) return DWG_OK;
+    if (!verts || !vf_offsets || !vertex_normals || (Fp > 0 && (!triangles || !vf_faces || !face_normals))) return DWG_E_ARG;
+    hipStream_t stream = (hipStream_t)stream_;
+    if (Fp > 0)
+        DWG_LAUNCH("mesh_face_normals", k_face_normals, dim3(dwg_cdiv(Fp, 256)), dim3(256), 0, stream, Fp, verts, triangles, face_normals);
+    DWG_LAUNCH("mesh_vertex_normals", k_vertex_normals, dim3(dwg_cdiv(Vp, 256)), dim3(256), 0, stream, Vp, (const float*)face_normals,
+               vf_offsets, vf_faces, vertex_normals);
+    DWG_RETURN_IF_LAUNCH_FAILED();
+    return DWG_OK;
+}
+
+int dwg_meshbind_forward(int32_t Fp, int32_t n_per_tri, const float* bary, const float* scale_params, const float* verts_cnl,
+                         const float* verts_obs, const float* vnormals_obs, const int32_t* triangles, float* pos_cnl_out,
+                         float* pos_out, float* scales_out, float* quats_out, dwg_stream_t stream_) {
+    if (Fp < 0 || n_per_tri <= 0) return DWG_E_ARG;
+    if (Fp == 0) return DWG_OK;
+    if (!bary || !scale_params || !verts_obs || !vnormals_obs || !triangles || !pos_out || !scales_out || !quats_out) return DWG_E_ARG;
+    if ((verts_cnl == nullptr) != (pos_cnl_out == nullptr)) return DWG_E_ARG;
+    const int M = Fp * n_per_tri;
+    DWG_LAUNCH("meshbind_fwd", k_meshbind_fwd, dim3(dwg_cdiv(M, 256)), dim3(256), 0, (hipStream_t)stream_, M, n_per_tri, bary, scale_params,
+               verts_cnl, verts_obs, vnormals_obs, triangles, pos_cnl_out, pos_out, scales_out, quats_out);
+    DWG_RETURN_IF_LAUNCH_FAILED();
+    return DWG_OK;
+}
+
+int dwg_meshbind_backward(int32_t Fp, int32_t n_per_tri, const float* bary, const float* scale_params, const float* verts_cnl,
+                          const float* verts_obs, const float* vnormals_obs, const int32_t* triangles, const float* g_pos_cnl,
+                          const float* g_pos, const float* g_scales, const float* g_quats, float* g_bary, float* g_scale_params,
+                          dwg_stream_t stream_) {
+    if (Fp < 0 || n_per_tri <= 0) return DWG_E_ARG;
+    if (Fp == 0) return DWG_OK;
+    if (!bary || !scale_params || !verts_obs || !vnormals_obs || !triangles || !g_bary || !g_scale_params) return DWG_E_ARG;
+    if (g_pos_cnl && !verts_cnl) return DWG_E_ARG;
+    const int M = Fp * n_per_tri;
+    DWG_LAUNCH("meshbind_bwd", k_meshbind_bwd, dim3(dwg_cdiv(M, 256)), dim3(256), 0, (hipStream_t)stream_, M, n_per_tri, bary, scale_params,
+               verts_cnl, verts_obs, vnormals_obs, triangles, g_pos_cnl, g_pos, g_scales, g_quats, g_bary, g_scale_params);
+    DWG_RETURN_IF_LAUNCH_FAILED();
+    return DWG_OK;
+}
+
+}  // extern "C"

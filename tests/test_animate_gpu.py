@@ -231,3 +231,40 @@ def test_animate_matches_oracle_forward_and_backward(with_mesh):
     for name, got, want in pairs:
         assert got is not None, name
         assert _rel_l2(got, want) < 2e-3, (name, _rel_l2(got, want))
+
+
+def test_meshbind_kernels_match_oracle():
+    """csrc/meshbind.hip through the C-ABI vs oracle/animate.py (compute_normal, mesh_positions, mesh_scales_and_quaternions)."""
+    from dreamwaltz_g_amd import meshbind as mb
+    g = torch.Generator().manual_seed(5)
+    V, n_per = 500, 6
+    verts_o = torch.randn(V, 3, generator=g) * 0.2
+    verts_c = torch.randn(V, 3, generator=g) * 0.2
+    tri = torch.randint(0, V, (700, 3), generator=g)
+    tri = tri[(tri[:, 0] != tri[:, 1]) & (tri[:, 1] != tri[:, 2]) & (tri[:, 0] != tri[:, 2])]
+    Fp = tri.shape[0]
+    base = torch.tensor([[2 / 3, 1 / 6, 1 / 6], [1 / 6, 2 / 3, 1 / 6], [1 / 6, 1 / 6, 2 / 3], [1 / 6, 5 / 12, 5 / 12],
+                         [5 / 12, 1 / 6, 5 / 12], [5 / 12, 5 / 12, 1 / 6]])
+    bary = base.expand(Fp, -1, -1) * (1 + 0.3 * torch.rand(Fp, 6, 3, generator=g))
+    scales = torch.rand(Fp * n_per, 3, generator=g) * 2.5
+    b64 = bary.double().requires_grad_(True); s64 = scales.double().requires_grad_(True)
+    vn_ref, _ = oa.compute_normal(verts_o.double(), tri)
+    cpos_ref = oa.mesh_positions(b64, verts_c.double(), tri)
+    pos_ref = oa.mesh_positions(b64, verts_o.double(), tri)
+    scl_ref, q_ref = oa.mesh_scales_and_quaternions(b64, s64, verts_o.double(), tri, pos_ref, n_per)
+    off, faces = mb.build_vertex_face_csr(tri, V)
+    tri32 = tri.to(torch.int32).cuda()
+    vn = mb.vertex_normals(verts_o.cuda(), tri32, off.cuda(), faces.cuda())
+    assert (vn.cpu().double() - vn_ref).abs().max() < 2e-6
+    bg = bary.cuda().requires_grad_(True); sg = scales.cuda().requires_grad_(True)
+    cpos, pos, scl, q = mb.meshbind(bg, sg, verts_c.cuda(), verts_o.cuda(), vn, tri32, n_per)
+    for got, ref, tol in ((cpos, cpos_ref, 1e-6), (pos, pos_ref, 1e-6), (scl, scl_ref, 1e-6), (q, q_ref, 3e-5)):
+        assert (got.detach().cpu().double() - ref.detach()).abs().max() < tol
+    ws = [torch.randn(t.shape, generator=g, dtype=torch.float64) for t in (cpos_ref, pos_ref, scl_ref, q_ref)]
+    sum((t * w).sum() for t, w in zip((cpos_ref, pos_ref, scl_ref, q_ref), ws)).backward()
+    sum((t * w.float().cuda()).sum() for t, w in zip((cpos, pos, scl, q), ws)).backward()
+    assert _rel_l2(bg.grad, b64.grad) < 2e-4, _rel_l2(bg.grad, b64.grad)
+    assert _rel_l2(sg.grad, s64.grad) < 1e-5
+    # observed pass only (no canonical vertices): canonical output is empty and carries no gradient
+    c2, p2, s2, q2 = mb.meshbind(bg, sg, None, verts_o.cuda(), vn, tri32, n_per)
+    assert c2.numel() == 0 and torch.equal(p2, pos) and torch.equal(q2, q)
