@@ -77,6 +77,9 @@ SIGNATURES = {
     "dwg_graph_end_capture": (ctypes.c_int, [_vp, ctypes.POINTER(_vp)]),
     "dwg_graph_launch": (ctypes.c_int, [_vp, _vp]),
     "dwg_graph_destroy": (ctypes.c_int, [_vp]),
+    "dwg_stream_create": (ctypes.c_int, [ctypes.POINTER(_vp)]),
+    "dwg_stream_destroy": (ctypes.c_int, [_vp]),
+    "dwg_stream_fork": (ctypes.c_int, [_vp, _vp]),
     # include/dwg_prof.h
     "dwg_prof_enable": (ctypes.c_int, [_i32]),
     "dwg_prof_query": (ctypes.c_int, [ctypes.c_char_p, ctypes.POINTER(_i64), ctypes.POINTER(ctypes.c_double)]),

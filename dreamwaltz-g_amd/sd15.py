@@ -215,6 +215,46 @@ class Plan:
         self.has_py_ops = False
         self.flops = {}         # algorithmic flops per kernel label (2*M*N*K*batch), for the roofline report
         self._lib = _lib.lib()
+        self.branch = 0         # ops are tagged with the branch (stream) they run on; 0 = the caller's stream
+        self._side = {}         # branch id -> library-owned side stream
+
+    # -- independent branches (run concurrently on side streams; parallel paths of the captured graph) -------------------
+    def fork(self, b):
+        """Branch b starts here: it is ordered after everything recorded on branch 0 so far."""
+        self.ops.append(("fork", 0, b))
+
+    def join(self, b):
+        """Branch 0 continues only after everything recorded on branch b."""
+        self.ops.append(("fork", b, 0))
+
+    def on_branch(self, b):
+        plan = self
+
+        class _Ctx:
+            def __enter__(self):
+                self.prev, plan.branch = plan.branch, b
+
+            def __exit__(self, *exc):
+                plan.branch = self.prev
+        return _Ctx()
+
+    def _stream_of(self, b, main):
+        if b == 0:
+            return main
+        if b not in self._side:
+            h = ctypes.c_void_p()
+            _lib.check(self._lib.dwg_stream_create(ctypes.byref(h)), "dwg_stream_create")
+            self._side[b] = h
+        return self._side[b]
+
+    def _issue(self, main):
+        for op in self.ops:
+            if op[0] == "fork":
+                rc = self._lib.dwg_stream_fork(self._stream_of(op[1], main), self._stream_of(op[2], main))
+            else:
+                rc = op[1](self._stream_of(op[0], main))
+            if rc:
+                raise RuntimeError("plan op failed with DWG error %s" % rc)
 
     def buf(self, *shape, dtype=BF16, zero=False):
         import os
@@ -237,21 +277,17 @@ class Plan:
         label = desc.name.decode() if desc.name else ("conv_igemm" if desc.conv_enabled else "gemm")
         self.flops[label] = self.flops.get(label, 0.0) + 2.0 * desc.M * desc.N * desc.K * desc.batch1 * desc.batch2
         fn, ref = self._lib.dwg_gemm, ctypes.byref(desc)
-        self.ops.append(lambda s, fn=fn, ref=ref: fn(ref, s))
+        self.ops.append((self.branch, lambda s, fn=fn, ref=ref: fn(ref, s)))
 
     def add_call(self, fn, *args):
-        self.ops.append(lambda s, fn=fn, args=args: fn(*args, s))
+        self.ops.append((self.branch, lambda s, fn=fn, args=args: fn(*args, s)))
 
     def add_py(self, f):
         self.has_py_ops = True
-        self.ops.append(lambda s, f=f: (f(), 0)[1])
+        self.ops.append((self.branch, lambda s, f=f: (f(), 0)[1]))
 
     def run_eager(self):
-        s = ctypes.c_void_p(torch.cuda.current_stream(self.device).cuda_stream)
-        for op in self.ops:
-            rc = op(s)
-            if rc:
-                raise RuntimeError("plan op failed with DWG error %s" % rc)
+        self._issue(ctypes.c_void_p(torch.cuda.current_stream(self.device).cuda_stream))
 
     def capture(self):
         """Record the whole plan into one hipGraph (launch-bound inner loop -> a single hipGraphLaunch per step).  The plan
@@ -266,10 +302,7 @@ class Plan:
         s = ctypes.c_void_p(self._cap_stream.cuda_stream)
         _lib.check(self._lib.dwg_graph_begin_capture(s), "dwg_graph_begin_capture")
         try:
-            for op in self.ops:
-                rc = op(s)
-                if rc:
-                    raise RuntimeError("plan op failed during capture with DWG error %s" % rc)
+            self._issue(s)
         finally:
             h = ctypes.c_void_p()
             rc = self._lib.dwg_graph_end_capture(s, ctypes.byref(h))
@@ -294,7 +327,7 @@ class Plan:
         s = ctypes.c_void_p(torch.cuda.current_stream(self.device).cuda_stream)
         bufs = [t for t in self.keep if torch.is_tensor(t) and t.is_floating_point()]
         for i, op in enumerate(self.ops):
-            rc = op(s)
+            rc = 0 if op[0] == "fork" else op[1](s)
             torch.cuda.synchronize()
             bad = [tuple(t.shape) for t in bufs if not torch.isfinite(t.float()).all()]
             if rc or bad:
@@ -418,10 +451,11 @@ class Builder:
     def _gn_ws(self, B):
         """One partial-sum scratch per plan: GroupNorm calls are sequential on the plan's stream."""
         need = int(self.L.dwg_groupnorm_workspace_floats(B, self.groups))
-        ws = getattr(self.p, "_gn_workspace", None)
+        pool = self.p.__dict__.setdefault("_gn_workspace", {})      # one per branch: branches run concurrently
+        ws = pool.get(self.p.branch)
         if ws is None or ws.numel() < need:
             ws = self.p.buf(need, dtype=torch.float32)
-            self.p._gn_workspace = ws
+            pool[self.p.branch] = ws
         return ws
 
     def groupnorm(self, x, name, eps, silu, keep_stats=False):
@@ -606,17 +640,26 @@ class DenoiserPlan:
         for i in range(len(cfg.block_out_channels)):
             for j in range(cfg.layers_per_block + 1):
                 up_names.append("up_blocks.%d.resnets.%d" % (i, j))
+        # ---- ControlNet body on branch 1: hint embedding (batch 1) + its own encoder.  It only shares INPUTS with the UNet
+        # encoder, and below 64x64 neither fills the chip alone, so the two run as parallel paths (side stream / graph branch).
+        import os
+        par = os.environ.get("DWG_SERIAL_DENOISER") != "1"
+        if par:
+            p.fork(1)
+        with p.on_branch(1 if par else 0):
+            self.temb_c = _TimeEmbed(bc, wc, cfg, B, _encoder_resnet_names(cfg))
+            e = "controlnet_cond_embedding"
+            hnt = bc.conv(self.cond, e + ".conv_in", act="silu")
+            nblk = 2 * (len(cfg.cond_channels) - 1)
+            for k in range(nblk):
+                hnt = bc.conv(hnt, "%s.blocks.%d" % (e, k), stride=2 if k % 2 == 1 else 1, act="silu")
+            hnt = bc.conv(hnt, e + ".conv_out")
+            cskips, cmid = _build_encoder(bc, cfg, self.latents, self.temb_c, self.text, hint=hnt)
         self.temb_u = _TimeEmbed(bu, wu, cfg, B, _encoder_resnet_names(cfg) + up_names)
-        self.temb_c = _TimeEmbed(bc, wc, cfg, B, _encoder_resnet_names(cfg))
         skips, mid = _build_encoder(bu, cfg, self.latents, self.temb_u, self.text)
-        # ---- ControlNet: hint embedding (batch 1), own encoder, zero convs whose epilogue adds the UNet skip it feeds
-        e = "controlnet_cond_embedding"
-        hnt = bc.conv(self.cond, e + ".conv_in", act="silu")
-        nblk = 2 * (len(cfg.cond_channels) - 1)
-        for k in range(nblk):
-            hnt = bc.conv(hnt, "%s.blocks.%d" % (e, k), stride=2 if k % 2 == 1 else 1, act="silu")
-        hnt = bc.conv(hnt, e + ".conv_out")
-        cskips, cmid = _build_encoder(bc, cfg, self.latents, self.temb_c, self.text, hint=hnt)
+        if par:
+            p.join(1)
+        # ---- zero convs whose epilogue adds the UNet skip they feed
         skips = [bc.conv(cs, "controlnet_down_blocks.%d" % k, pad=0, residual=skips[k]) for k, cs in enumerate(cskips)]
         h = bc.conv(cmid, "controlnet_mid_block", pad=0, residual=mid)
         # ---- UNet decoder
