@@ -112,9 +112,24 @@ __global__ __launch_bounds__(256) void k_grid_fwd(GridP p, const float* __restri
 }
 
 // grad_table += w * grad (atomics), and grad_x[b,d] = sum_{l,c} grad[b,l,c] * dy_dx[b,l,d,c]
+// XCD-private accumulation (XCD = true): device-scope float atomics are executed at the memory side on this chip (the 8 XCD L2s
+// are not coherent with each other): one fabric transaction per atomic, ~13 G atomics/s measured.  Instead every XCD adds into
+// ITS OWN copy of the table gradient with workgroup-scope atomics, which the XCD's L2 executes in cache (all CUs of an XCD share
+// that L2, and a wave never leaves its XCD: HW_REG_XCC_ID is where it physically runs).  The copies are summed (and cleared) by
+// k_xcd_reduce_clear afterwards.  Which copy a contribution lands in changes only the summation order.
+__device__ __forceinline__ uint32_t xcc_id() { return __builtin_amdgcn_s_getreg(20 | (0 << 6) | (3 << 11)) & 7u; }   // HW_REG_XCC_ID[3:0]
+
+template <bool XCD>
+__device__ __forceinline__ void table_add(float* p, float v) {
+    if (XCD) __hip_atomic_fetch_add(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+    else atomicAdd(p, v);
+}
+
+template <bool XCD>
 __global__ __launch_bounds__(256) void k_grid_bwd(GridP p, const float* __restrict__ grad, const float* __restrict__ x,
                                                   const int* __restrict__ offsets, float* __restrict__ grad_table,
-                                                  const float* __restrict__ dy_dx, float* __restrict__ grad_x, uint32_t first_table_level) {
+                                                  const float* __restrict__ dy_dx, float* __restrict__ grad_x, uint32_t first_table_level,
+                                                  size_t xcd_stride) {
     const uint32_t t = blockIdx.x * 256u + threadIdx.x;
     const uint32_t b = t / p.L, level = t - b * p.L;
     const bool live = b < p.B;
@@ -127,15 +142,15 @@ __global__ __launch_bounds__(256) void k_grid_bwd(GridP p, const float* __restri
         Cell c = locate(p, offsets, level, x0, x1, x2);
         if (!c.oob) {
             if (grad_table && level >= first_table_level) {
-                float* gt = grad_table + (size_t)(uint32_t)offsets[level] * 2;
+                float* gt = grad_table + (size_t)(uint32_t)offsets[level] * 2 + (XCD ? xcc_id() * xcd_stride : (size_t)0);
 #pragma unroll
                 for (int idx = 0; idx < 8; idx++) {
                     uint32_t cx = c.g[0] + (idx & 1), cy = c.g[1] + ((idx >> 1) & 1), cz = c.g[2] + ((idx >> 2) & 1);
                     float w = ((idx & 1) ? c.w[0] : 1.f - c.w[0]) * ((idx & 2) ? c.w[1] : 1.f - c.w[1]) *
                               ((idx & 4) ? c.w[2] : 1.f - c.w[2]);
                     uint32_t index = grid_index(p.gridtype, p.align_corners, c.hsize, c.res, cx, cy, cz);
-                    atomicAdd(gt + index, w * g0);
-                    atomicAdd(gt + index + 1, w * g1);
+                    table_add<XCD>(gt + index, w * g0);
+                    table_add<XCD>(gt + index + 1, w * g1);
                 }
             }
             if (dy_dx && grad_x) {
@@ -190,6 +205,21 @@ __global__ __launch_bounds__(256) void k_grid_bwd_coarse(GridP p, uint32_t level
     for (uint32_t e = threadIdx.x; e < hsize * 2; e += 256) { float v = tab[e]; if (v != 0.f) atomicAdd(gt + e, v); }
 }
 
+// dst[i] += sum over the 8 XCD-private copies, which are cleared for the next use (one pass: 8 reads + 8 zero writes + 1 RMW)
+__global__ __launch_bounds__(256) void k_xcd_reduce_clear(size_t n4, float4* __restrict__ scratch, size_t stride4, float4* __restrict__ dst) {
+    const float4 z = make_float4(0.f, 0.f, 0.f, 0.f);
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n4; i += (size_t)gridDim.x * 256) {
+        float4 a = dst[i];
+#pragma unroll
+        for (int x = 0; x < 8; x++) {
+            float4 v = scratch[x * stride4 + i];
+            a.x += v.x; a.y += v.y; a.z += v.z; a.w += v.w;
+            scratch[x * stride4 + i] = z;
+        }
+        dst[i] = a;
+    }
+}
+
 static int check(uint32_t B, uint32_t D, uint32_t C, uint32_t L) {
     if (D != 3 || C != 2 || L == 0 || L > 32) return DWG_E_ARG;  // the avatar's encoder: D=3, C=2, L=16
     if ((uint64_t)B * L > 0xffffff00ull) return DWG_E_ARG;
@@ -216,10 +246,10 @@ int dwg_grid_encode_forward(const float* inputs, const float* embeddings, const 
     return DWG_OK;
 }
 
-int dwg_grid_encode_backward(const float* grad, const float* inputs, const float* embeddings, const int32_t* offsets,
-                             float* grad_embeddings, uint32_t B, uint32_t D, uint32_t C, uint32_t L, float S, uint32_t H,
-                             const float* dy_dx, float* grad_inputs, uint32_t gridtype, uint32_t align_corners,
-                             uint32_t interp, uint32_t grad_layout, const int32_t* host_offsets, dwg_stream_t stream) {
+static int grid_backward(const float* grad, const float* inputs, const float* embeddings, const int32_t* offsets,
+                         float* grad_embeddings, uint32_t B, uint32_t D, uint32_t C, uint32_t L, float S, uint32_t H,
+                         const float* dy_dx, float* grad_inputs, uint32_t gridtype, uint32_t align_corners,
+                         uint32_t interp, uint32_t grad_layout, const int32_t* host_offsets, float* xcd_scratch, dwg_stream_t stream) {
     int rc = check(B, D, C, L);
     if (rc) return rc;
     if (B == 0) return DWG_OK;
@@ -248,10 +278,40 @@ int dwg_grid_encode_backward(const float* grad, const float* inputs, const float
             first_table_level++;
         }
     }
-    DWG_LAUNCH("grid_bwd", k_grid_bwd, dim3((n + 255) / 256), dim3(256), 0, (hipStream_t)stream, p, grad, inputs, offsets,
-                       grad_embeddings, dy_dx, grad_inputs, first_table_level);
+    if (xcd_scratch && grad_embeddings && host_offsets && first_table_level < L) {
+        const size_t total = (size_t)(uint32_t)host_offsets[L] * 2;                    // floats per table copy (multiple of 16)
+        DWG_LAUNCH("grid_bwd", (k_grid_bwd<true>), dim3((n + 255) / 256), dim3(256), 0, (hipStream_t)stream, p, grad, inputs, offsets,
+                   xcd_scratch, dy_dx, grad_inputs, first_table_level, total);
+        const size_t lo = (size_t)(uint32_t)host_offsets[first_table_level] * 2;       // coarse levels went through LDS straight to dst
+        const size_t n4 = (total - lo) / 4;
+        size_t blocks = (n4 + 255) / 256; if (blocks > 4096) blocks = 4096;
+        DWG_LAUNCH("grid_bwd_xcd_reduce", k_xcd_reduce_clear, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, n4,
+                   reinterpret_cast<float4*>(xcd_scratch + lo), total / 4, reinterpret_cast<float4*>(grad_embeddings + lo));
+    } else {
+        DWG_LAUNCH("grid_bwd", (k_grid_bwd<false>), dim3((n + 255) / 256), dim3(256), 0, (hipStream_t)stream, p, grad, inputs, offsets,
+                   grad_embeddings, dy_dx, grad_inputs, first_table_level, (size_t)0);
+    }
     DWG_RETURN_IF_LAUNCH_FAILED();
     return DWG_OK;
+}
+
+int dwg_grid_encode_backward(const float* grad, const float* inputs, const float* embeddings, const int32_t* offsets,
+                             float* grad_embeddings, uint32_t B, uint32_t D, uint32_t C, uint32_t L, float S, uint32_t H,
+                             const float* dy_dx, float* grad_inputs, uint32_t gridtype, uint32_t align_corners,
+                             uint32_t interp, uint32_t grad_layout, const int32_t* host_offsets, dwg_stream_t stream) {
+    return grid_backward(grad, inputs, embeddings, offsets, grad_embeddings, B, D, C, L, S, H, dy_dx, grad_inputs, gridtype,
+                         align_corners, interp, grad_layout, host_offsets, nullptr, stream);
+}
+
+int dwg_grid_encode_backward_xcd(const float* grad, const float* inputs, const float* embeddings, const int32_t* offsets,
+                                 float* grad_embeddings, uint32_t B, uint32_t D, uint32_t C, uint32_t L, float S, uint32_t H,
+                                 const float* dy_dx, float* grad_inputs, uint32_t gridtype, uint32_t align_corners,
+                                 uint32_t interp, uint32_t grad_layout, const int32_t* host_offsets, float* xcd_scratch,
+                                 dwg_stream_t stream) {
+    if (!xcd_scratch || !host_offsets || ((uintptr_t)xcd_scratch % 16) || (grad_embeddings && ((uintptr_t)grad_embeddings % 16)))
+        return DWG_E_ARG;
+    return grid_backward(grad, inputs, embeddings, offsets, grad_embeddings, B, D, C, L, S, H, dy_dx, grad_inputs, gridtype,
+                         align_corners, interp, grad_layout, host_offsets, xcd_scratch, stream);
 }
 
 }  // extern "C"

@@ -50,11 +50,29 @@ def _host_offsets_of(offsets):
     return _host_offsets[key]
 
 
+_xcd_scratch = {}
+
+
+def xcd_scratch_for(embeddings):
+    """8 XCD-private copies of the table gradient (zero between calls), one allocation per (device, table size)."""
+    key = (embeddings.device, embeddings.numel())
+    if key not in _xcd_scratch:
+        _xcd_scratch[key] = torch.zeros(8, embeddings.numel(), device=embeddings.device, dtype=torch.float32)
+    return _xcd_scratch[key]
+
+
 def grid_encode_backward(grad, inputs, embeddings, offsets, grad_embeddings, B, D, C, L, S, H, dy_dx, grad_inputs,
-                         gridtype, align_corners, interp, grad_layout=0):
+                         gridtype, align_corners, interp, grad_layout=0, xcd_scratch=None):
     _need_cuda(inputs)
     p = _lib.ptr
     ho = _host_offsets_of(offsets)
+    if xcd_scratch is not None:
+        _lib.check(_lib.lib().dwg_grid_encode_backward_xcd(p(grad), p(inputs), p(embeddings), p(offsets), p(grad_embeddings), B, D,
+                                                           C, L, ctypes.c_float(S), H, p(dy_dx), p(grad_inputs), gridtype,
+                                                           int(bool(align_corners)), interp, grad_layout,
+                                                           ctypes.cast(ho, ctypes.c_void_p), p(xcd_scratch), _st(inputs)),
+                   "dwg_grid_encode_backward_xcd")
+        return
     _lib.check(_lib.lib().dwg_grid_encode_backward(p(grad), p(inputs), p(embeddings), p(offsets), p(grad_embeddings), B, D,
                                                    C, L, ctypes.c_float(S), H, p(dy_dx), p(grad_inputs), gridtype,
                                                    int(bool(align_corners)), interp, grad_layout,
@@ -89,8 +107,11 @@ class _grid_encode(Function):
         grad = grad.contiguous().float()
         grad_embeddings = torch.zeros_like(embeddings)
         grad_inputs = torch.empty_like(inputs) if dy_dx is not None else None
+        # big batches: XCD-private accumulation of the table gradient (8 copies + one reduce pass beat memory-side atomics)
+        import os
+        scratch = xcd_scratch_for(embeddings) if (B >= 16384 and os.environ.get("DWG_GRID_NO_XCD") != "1") else None
         grid_encode_backward(grad, inputs, embeddings, offsets, grad_embeddings, B, D, C, L, S, H, dy_dx, grad_inputs,
-                             gridtype, ctx.align_corners, interpolation, grad_layout=1)
+                             gridtype, ctx.align_corners, interpolation, grad_layout=1, xcd_scratch=scratch)
         return grad_inputs, grad_embeddings, None, None, None, None, None, None, None
 
 

@@ -35,6 +35,17 @@ int dwg_grid_encode_backward(const float* grad, const float* inputs, const float
                                                            table-gradient path for the coarse levels*/,
                              dwg_stream_t stream);
 
+/* Same, with XCD-private accumulation of the table gradient (MI355X: 8 XCDs, each with its own L2).  Device-scope float
+ * atomics are executed at the memory side on this chip; here every XCD adds into its own copy of the table with L2-local
+ * (workgroup-scope) atomics and one extra pass sums the 8 copies into grad_embeddings (+=) and clears them.
+ * xcd_scratch: [8][offsets[L]*C] fp32, 16-byte aligned, ALL ZERO on entry (it is left all zero on return, so one allocation
+ * serves every call); host_offsets is required. */
+int dwg_grid_encode_backward_xcd(const float* grad, const float* inputs, const float* embeddings, const int32_t* offsets,
+                                 float* grad_embeddings, uint32_t B, uint32_t D, uint32_t C, uint32_t L, float S, uint32_t H,
+                                 const float* dy_dx, float* grad_inputs, uint32_t gridtype, uint32_t align_corners,
+                                 uint32_t interp, uint32_t grad_layout, const int32_t* host_offsets, float* xcd_scratch,
+                                 dwg_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

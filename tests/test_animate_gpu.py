@@ -107,7 +107,7 @@ def _grid_case(B, seed, gridtype=1, oob=True):
     return x, table, offsets, pls, gridtype
 
 
-@pytest.mark.parametrize("B,gridtype", [(4096, 1), (1000, 0), (1, 1), (33, 1)])
+@pytest.mark.parametrize("B,gridtype", [(4096, 1), (1000, 0), (1, 1), (33, 1), (40000, 1)])   # 40000: XCD-private table gradient + LDS coarse levels
 def test_grid_encoder_forward_backward(B, gridtype):
     from dreamwaltz_g_amd.gridencoder import grid_encode
     x, table, offsets, pls, _ = _grid_case(B, B, gridtype)
@@ -127,6 +127,14 @@ def test_grid_encoder_forward_backward(B, gridtype):
     out.backward(go.float().cuda())
     assert _rel_l2(tc.grad, gt_ref) < 1e-4
     assert _rel_l2(xc.grad, gx_ref) < 2e-3   # d/dx is scaled by up to 4095 per level: fp32 cancellation
+    if B >= 16384:
+        # the XCD-private scratch must be left all zero, and a second backward must reproduce the first
+        from dreamwaltz_g_amd import gridencoder as ge
+        assert float(ge.xcd_scratch_for(tc).abs().max()) == 0.0
+        tc.grad = None; xc.grad = None
+        out2 = grid_encode(xc, tc, torch.from_numpy(offsets).cuda(), pls, 16, True, gridtype, False, 1)
+        out2.backward(go.float().cuda())
+        assert _rel_l2(tc.grad, gt_ref) < 1e-4
 
 
 def test_grid_encoder_backend_layout_and_module():

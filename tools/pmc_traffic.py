@@ -1,0 +1,45 @@
+"""Per-kernel HBM traffic from two rocprofv3 PMC passes (FETCH_SIZE and WRITE_SIZE collected separately: the TCC block has 4
+slots, FETCH_SIZE takes 3 and WRITE_SIZE 2 -- MI355X_MICROARCH.md, rocprofv3 PMC slots).
+
+    cd /tmp && export TMPDIR=/tmp && cd <repo>
+    rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d gpurun_out/pmc_fetch -o sds -- python bench.py --steps 2 --warmup 1 --no-cpu-baseline --eager
+    rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d gpurun_out/pmc_write -o sds -- python bench.py --steps 2 --warmup 1 --no-cpu-baseline --eager
+    python tools/pmc_traffic.py gpurun_out/pmc_fetch/sds_counter_collection.csv gpurun_out/pmc_write/sds_counter_collection.csv profiles/r01_pmc_traffic.json
+
+Units / corrections (same guide, HBM section): counters are in KiB (x1024 -> bytes); on gfx950 FETCH_SIZE tallies the 128-byte
+requests of wide coalesced reads at 64 bytes, i.e. reports HALF the bytes of such streams -> the read side is doubled
+("fetch_corrected"); WRITE_SIZE is used as reported (uncalibrated).  Infinity-Cache hits are counted, not excluded."""
+import collections, csv, json, re, sys
+
+
+def short(name):
+    m = re.search(r"(k_[A-Za-z0-9_]+(?:<[^>]*>)?)", name)
+    s = m.group(1) if m else name[:60]
+    return s.replace(" ", "")
+
+
+def load(path, counter):
+    agg = collections.defaultdict(lambda: [0, 0.0])
+    for r in csv.DictReader(open(path)):
+        if r["Counter_Name"] != counter:
+            continue
+        a = agg[short(r["Kernel_Name"])]
+        a[0] += 1; a[1] += float(r["Counter_Value"])
+    return agg
+
+
+fetch, write = load(sys.argv[1], "FETCH_SIZE"), load(sys.argv[2], "WRITE_SIZE")
+out = {}
+for k in sorted(set(fetch) | set(write)):
+    nf, f = fetch.get(k, [0, 0.0]); nw, w = write.get(k, [0, 0.0])
+    n = max(nf, nw)
+    if n == 0:
+        continue
+    fb, wb = f * 1024 / max(nf, 1), w * 1024 / max(nw, 1)
+    out[k] = {"launches": n, "fetch_bytes_per_launch_raw": fb, "fetch_bytes_per_launch_corrected": 2 * fb,
+              "write_bytes_per_launch": wb, "hbm_bytes_per_launch": 2 * fb + wb}
+json.dump({"source": "rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate passes) over python bench.py --steps 2 --warmup 1 --eager",
+           "corrections": "KiB->bytes x1024; gfx950 FETCH_SIZE doubled for wide coalesced reads (MI355X_MICROARCH.md HBM section); WRITE_SIZE as reported",
+           "kernels": out}, open(sys.argv[3], "w"), indent=1)
+for k, v in sorted(out.items(), key=lambda kv: -kv[1]["hbm_bytes_per_launch"] * kv[1]["launches"])[:14]:
+    print("%-34s %5d launches  fetch(corr) %9.2f MB  write %9.2f MB" % (k, v["launches"], v["fetch_bytes_per_launch_corrected"] / 1e6, v["write_bytes_per_launch"] / 1e6))
