@@ -459,6 +459,66 @@ struct GldsLoader {
     }
 };
 
+// Convolution A-loader for the common case (Cin % 64 == 0, no input dilation / upsampling / concat): the generic loader redoes
+// the whole im2col index computation (~70 VALU instructions per MFMA in the 128x64-tile kernel, which made that kernel
+// instruction-issue-bound at ~10 % MFMA utilisation).  Here everything lane-dependent is hoisted out of the k-loop:
+//   * a 64-wide k-tile lies inside ONE tap (Cin % 64 == 0), so every lane of the workgroup fetches the same (ky, kx, ci) --
+//     the tap offset ((ky*Win + kx)*Cin + ci) is wave-uniform (scalar registers);
+//   * per row: a base pointer at (iy0, ix0) [may lie outside the image, only dereferenced when valid] that already contains the
+//     lane's swizzled chunk offset, and a KH*KW-bit validity mask (row in range, tap inside the image).
+// Per k-step and row this leaves: test one mask bit, one 64-bit add, one select.
+template <int ROWS>
+struct GldsConvFast {
+    static constexpr int NJ = ROWS / 32;
+    const unsigned char* pb[NJ];
+    unsigned int mask[NJ];
+    int kcur, kend, tap, ci, ky, kx;       // wave-uniform
+
+    __device__ __forceinline__ void init(const __bf16* base, long long, int nrows, int r0, int kbeg, int kend_, const ConvP& cv) {
+        static_assert(NJ % 2 == 0, "row-block parity must equal j parity");
+        const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, sub = lane >> 3;
+        const int lg0 = (lane & 7) ^ (sub >> 1);
+        kcur = kbeg; kend = kend_;
+        tap = kbeg / cv.Cin; ci = kbeg - tap * cv.Cin; ky = tap / cv.KW; kx = tap - ky * cv.KW;
+        const int hw = cv.Hout * cv.Wout;
+#pragma unroll
+        for (int j = 0; j < NJ; j++) {
+            const int r = r0 + (wave * NJ + j) * 8 + sub;
+            const bool rok = r < nrows;
+            const int rr = rok ? r : 0;
+            const int img = rr / hw, rem = rr - img * hw;
+            const int oy = rem / cv.Wout, ox = rem - oy * cv.Wout;
+            const int iy0 = oy * cv.stride - cv.pad_t, ix0 = ox * cv.stride - cv.pad_l;
+            unsigned int m = 0;
+            for (int t = 0, y = 0; y < cv.KH; y++)
+                for (int x = 0; x < cv.KW; x++, t++) {
+                    const int iy = iy0 + y, ix = ix0 + x;
+                    if (rok && iy >= 0 && iy < cv.Hin && ix >= 0 && ix < cv.Win) m |= 1u << t;
+                }
+            mask[j] = m;
+            const long long pix = ((long long)img * cv.Hin + iy0) * cv.Win + ix0;
+            pb[j] = reinterpret_cast<const unsigned char*>(base) + (pix * cv.Cin + (lg0 ^ ((j & 1) << 2)) * 8) * 2;
+        }
+    }
+    __device__ __forceinline__ void advance(const ConvP& cv) {
+        kcur += 64; ci += 64;
+        if (ci >= cv.Cin) { ci = 0; ++tap; if (++kx == cv.KW) { kx = 0; ++ky; } }
+    }
+    __device__ __forceinline__ void issue(unsigned char* lds_tile, const ConvP& cv) {
+        const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+        const unsigned char* zero = g_zero16;
+        const long long uoff = (((long long)ky * cv.Win + kx) * cv.Cin + ci) * 2;      // scalar
+        const unsigned int bit = kcur < kend ? (1u << tap) : 0u;                        // scalar (tiles past kend: zero page)
+#pragma unroll
+        for (int j = 0; j < NJ; j++) {
+            const unsigned char* src = (mask[j] & bit) ? pb[j] + uoff : zero;
+            unsigned char* dst = lds_tile + ((wave * NJ + j) * 8) * 128;
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
+                                             (__attribute__((address_space(3))) void*)dst, 16, 0, 0);
+        }
+    }
+};
+
 // s_waitcnt vmcnt(N) only (expcnt / lgkmcnt unconstrained): gfx9 encoding vmcnt = simm16[15:14] : simm16[3:0]
 template <int N>
 __device__ __forceinline__ void wait_vmcnt() {
@@ -468,7 +528,12 @@ __device__ __forceinline__ void wait_vmcnt() {
 // S-stage software pipeline: S-1 k-tiles are in flight (direct-to-LDS loads) while one is being multiplied; one barrier per
 // k-step.  Tiles past kend are still issued (from a 16-byte zero line) so that the outstanding-load count the s_waitcnt
 // relies on is a compile-time constant.
-template <int BN, bool CONV, int S>
+template <int BM, int AKIND> struct ALoaderOf { typedef GldsLoader<BM, false> type; };
+template <int BM> struct ALoaderOf<BM, 1> { typedef GldsLoader<BM, true> type; };
+template <int BM> struct ALoaderOf<BM, 2> { typedef GldsConvFast<BM> type; };
+
+// AKIND: 0 = plain rows (linear layers), 1 = generic implicit-GEMM convolution, 2 = convolution fast path (GldsConvFast)
+template <int BN, int AKIND, int S>
 __global__ __launch_bounds__(256) void k_gemm_glds(GemmP p) {
     constexpr int BM = 128;
     constexpr int WN = BN / 64, WM = 4 / WN, TM = BM / WM / 32, TN = 2;
@@ -503,7 +568,7 @@ __global__ __launch_bounds__(256) void k_gemm_glds(GemmP p) {
         for (int j = 0; j < TN; j++)
 #pragma unroll
             for (int r = 0; r < 16; r++) acc[i][j][r] = 0.f;
-    GldsLoader<BM, CONV> la;
+    typename ALoaderOf<BM, AKIND>::type la;
     GldsLoader<BN, false> lb;
     la.init(A, p.sam, p.M, m0, kbeg, kend, p.conv);
     lb.init(B, p.sbn, p.N, n0, kbeg, kend, p.conv);
@@ -551,17 +616,18 @@ static double gemm_flops(const GemmP& p, int batch) {
     return f;
 }
 
-template <int BN, bool CONV, int S>
+template <int BN, int AKIND, int S>
 static void launch_glds_s(const GemmP& p, int batch, hipStream_t stream, const char* name) {
     size_t lds = (size_t)S * (128 + BN) * 128;
     static bool attr_set = false;
     if (!attr_set) {
-        hipFuncSetAttribute(reinterpret_cast<const void*>(&k_gemm_glds<BN, CONV, S>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        hipFuncSetAttribute(reinterpret_cast<const void*>(&k_gemm_glds<BN, AKIND, S>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         attr_set = true;
     }
     dim3 grid(((p.M + 127) / 128) * ((p.N + BN - 1) / BN) * (p.splitk > 1 ? p.splitk : 1), 1, batch);
-    DWG_LAUNCH_W(name, (BN == 64 ? (CONV ? "k_gemm_glds<64,true>" : "k_gemm_glds<64,false>") : (CONV ? "k_gemm_glds<128,true>" : "k_gemm_glds<128,false>")),
-                 gemm_flops(p, batch), (k_gemm_glds<BN, CONV, S>), grid, dim3(256), lds, stream, p);
+    static const char* const sym[2][3] = {{"k_gemm_glds<64,rows>", "k_gemm_glds<64,conv>", "k_gemm_glds<64,convfast>"},
+                                          {"k_gemm_glds<128,rows>", "k_gemm_glds<128,conv>", "k_gemm_glds<128,convfast>"}};
+    DWG_LAUNCH_W(name, sym[BN == 128][AKIND], gemm_flops(p, batch), (k_gemm_glds<BN, AKIND, S>), grid, dim3(256), lds, stream, p);
     if (p.splitk > 1 && p.ws) {
         long long n = (long long)p.M * p.N;
         int blocks = (int)((n + 255) / 256); if (blocks > 2048) blocks = 2048;
@@ -569,18 +635,14 @@ static void launch_glds_s(const GemmP& p, int batch, hipStream_t stream, const c
     }
 }
 
-// Pipeline depth.  Measured on MI355X (tools/bench_gemm.py, DWG_GEMM_STAGES=2|3|4): deeper pipelines LOSE on every SDS
-// shape -- the extra LDS halves the resident workgroups per CU, and occupancy hides the global->LDS latency better than
-// run-ahead does (e.g. 512x1280x11520 split-K: 47 us at 2 stages, 76 us at 4).  2 stages stay the default; the deeper
-// instantiations are kept for experiments through the environment variable.
-template <int BN, bool CONV>
+// Pipeline depth.  Measured on MI355X (tools/bench_gemm.py, DWG_GEMM_STAGES=2|3): a deeper pipeline LOSES on every SDS shape --
+// the extra LDS costs resident workgroups, and occupancy hides the global->LDS latency better than run-ahead does (e.g.
+// 512x1280x11520 split-K: 47 us at 2 stages, 76 us at 4).  2 stages are the default; 3 stays selectable for experiments.
+template <int BN, int AKIND>
 static void launch_glds(const GemmP& p, int batch, hipStream_t stream, const char* name) {
     static const int forced = getenv("DWG_GEMM_STAGES") ? atoi(getenv("DWG_GEMM_STAGES")) : 0;
-    const long long blocks = (long long)((p.M + 127) / 128) * ((p.N + BN - 1) / BN) * (p.splitk > 1 ? p.splitk : 1) * batch;
-    int S = forced ? forced : 2; (void)blocks;
-    if (S >= 4) launch_glds_s<BN, CONV, 4>(p, batch, stream, name);
-    else if (S == 3) launch_glds_s<BN, CONV, 3>(p, batch, stream, name);
-    else launch_glds_s<BN, CONV, 2>(p, batch, stream, name);
+    if (forced >= 3) launch_glds_s<BN, AKIND, 3>(p, batch, stream, name);
+    else launch_glds_s<BN, AKIND, 2>(p, batch, stream, name);
 }
 
 // ---------------------------------------------------------------------------------------------------------------------
@@ -870,8 +932,19 @@ int dwg_gemm(const dwg_gemm_desc* d, dwg_stream_t stream_) {
         if (patch_ok) {
             if (narrow) launch_conv3x3_patch<64>(p, stream, name); else launch_conv3x3_patch<128>(p, stream, name);
         } else if (glds_ok) {
-            if (narrow) { if (amode == MODE_CONV) launch_glds<64, true>(p, batch, stream, name); else launch_glds<64, false>(p, batch, stream, name); }
-            else { if (amode == MODE_CONV) launch_glds<128, true>(p, batch, stream, name); else launch_glds<128, false>(p, batch, stream, name); }
+            static const bool no_fast = getenv("DWG_CONV_NO_FAST") != nullptr;
+            const int akind = amode != MODE_CONV ? 0
+                              : (d->conv_cin % 64 == 0 && p.conv.dil == 1 && p.conv.up == 1 && !d->A2 && d->conv_kh * d->conv_kw <= 32 &&
+                                 !no_fast ? 2 : 1);
+            if (narrow) {
+                if (akind == 2) launch_glds<64, 2>(p, batch, stream, name);
+                else if (akind == 1) launch_glds<64, 1>(p, batch, stream, name);
+                else launch_glds<64, 0>(p, batch, stream, name);
+            } else {
+                if (akind == 2) launch_glds<128, 2>(p, batch, stream, name);
+                else if (akind == 1) launch_glds<128, 1>(p, batch, stream, name);
+                else launch_glds<128, 0>(p, batch, stream, name);
+            }
         } else if (narrow) dispatch_a<T, 64>(p, amode, bmode, batch, stream, name);
         else dispatch_a<T, 128>(p, amode, bmode, batch, stream, name);
     } else {
