@@ -287,6 +287,146 @@ __device__ __forceinline__ void tile_epilogue(const GemmP& p, f32x16 (&acc)[TM][
         }
 }
 
+// ---------------------------------------------------------------------------------------------------------------------
+// Transposed accumulator orientation (direct-to-LDS kernels): the MFMA is issued as D' = Btile . Atile^T, so that a lane owns
+// ONE output row (lane & 31) and, per group of four accumulator registers, FOUR CONSECUTIVE output columns
+// (8*(r>>2) + 4*(lane>>5) + (r&3)).  The epilogue then moves 8-byte bf16x4 / 16-byte float4 pieces (bias, residual, store,
+// split-K slab) instead of one 2-byte element per instruction: 4x fewer epilogue instructions and memory requests, which is
+// what the small-K layers (5-20 k-steps per tile) spend most of their time on.
+// ---------------------------------------------------------------------------------------------------------------------
+struct bf16x4_t { __bf16 v[4]; };
+
+__device__ __forceinline__ bool epilogue_vec_ok(const GemmP& p, long long coff, long long roff) {
+    bool ok = (p.N & 3) == 0 && (p.ldc & 3) == 0 && (coff & 3) == 0 && ((uintptr_t)p.C & 15) == 0;
+    if (p.residual) ok = ok && (p.ldr & 3) == 0 && (roff & 3) == 0 && ((uintptr_t)p.residual & 15) == 0;
+    return ok;
+}
+
+// four consecutive columns col..col+3 of one row
+__device__ __forceinline__ void epilogue_store4(const GemmP& p, float (&v)[4], int row, int col, long long coff, long long roff, bool vec_ok) {
+    if (!vec_ok || col + 3 >= p.N) {
+#pragma unroll
+        for (int e = 0; e < 4; e++)
+            if (col + e < p.N) epilogue_store(p, v[e], row, col + e, coff, roff);
+        return;
+    }
+    if (p.bias) {
+        const float* b = reinterpret_cast<const float*>(p.bias);
+        if (p.bias_row_div > 0) {
+            b += (long long)(row / p.bias_row_div) * p.bias_ld + col;
+            v[0] += b[0]; v[1] += b[1]; v[2] += b[2]; v[3] += b[3];
+        } else if (p.bias_per_row) {
+            const float br = b[row];
+            v[0] += br; v[1] += br; v[2] += br; v[3] += br;
+        } else {
+            v[0] += b[col]; v[1] += b[col + 1]; v[2] += b[col + 2]; v[3] += b[col + 3];
+        }
+    }
+#pragma unroll
+    for (int e = 0; e < 4; e++) v[e] = apply_act(v[e], p.act);
+    if (p.residual) {
+        const long long ri = roff + (long long)row * p.ldr + col;
+        if (p.res_bf16) {
+            bf16x4_t r = *reinterpret_cast<const bf16x4_t*>(reinterpret_cast<const __bf16*>(p.residual) + ri);
+#pragma unroll
+            for (int e = 0; e < 4; e++) v[e] += bf2f(r.v[e]);
+        } else {
+            float4 r = *reinterpret_cast<const float4*>(reinterpret_cast<const float*>(p.residual) + ri);
+            v[0] += r.x; v[1] += r.y; v[2] += r.z; v[3] += r.w;
+        }
+    }
+    const long long ci = coff + (long long)row * p.ldc + col;
+    if (p.out_bf16) {
+        bf16x4_t o;
+#pragma unroll
+        for (int e = 0; e < 4; e++) o.v[e] = f2bf(v[e]);
+        *reinterpret_cast<bf16x4_t*>(reinterpret_cast<__bf16*>(p.C) + ci) = o;
+    } else {
+        float4* dst = reinterpret_cast<float4*>(reinterpret_cast<float*>(p.C) + ci);
+        float4 o = make_float4(v[0], v[1], v[2], v[3]);
+        if (p.accumulate) { float4 c = *dst; o.x += c.x; o.y += c.y; o.z += c.z; o.w += c.w; }
+        *dst = o;
+    }
+}
+
+template <int TM, int TN>
+__device__ __forceinline__ void tile_epilogue_t(const GemmP& p, f32x16 (&acc)[TM][TN], int m0, int n0, int wm, int wn, int lane,
+                                                int ks_id, int z1, int z2) {
+    const long long coff = z1 * p.bC1 + z2 * p.bC2, roff = z1 * p.bR1 + z2 * p.bR2;
+    const bool vec_ok = epilogue_vec_ok(p, coff, roff);
+    const int lrow = lane & 31, lhalf = (lane >> 5) * 4;
+    if (p.act == 6) {
+        // GEGLU pair (see tile_epilogue): tile j=0 holds `hidden`, j=1 the matching `gate` columns; N % 64 == 0
+        const float* bias = reinterpret_cast<const float*>(p.bias);
+#pragma unroll
+        for (int i = 0; i < TM; i++) {
+            const int row = m0 + (wm * TM + i) * 32 + lrow;
+            if (row >= p.M) continue;
+#pragma unroll
+            for (int r4 = 0; r4 < 4; r4++) {
+                const int cl = 8 * r4 + lhalf;
+                const int colp = n0 + wn * 64 + cl;
+                if (colp + 35 >= p.N) continue;
+                const int ocol = (n0 + wn * 64) / 2 + cl;
+                float v[4];
+#pragma unroll
+                for (int e = 0; e < 4; e++) {
+                    const float a = acc[i][0][4 * r4 + e] * p.alpha + (bias ? bias[colp + e] : 0.f);
+                    const float g = acc[i][1][4 * r4 + e] * p.alpha + (bias ? bias[colp + 32 + e] : 0.f);
+                    v[e] = a * 0.5f * g * (1.f + erff(g * 0.70710678118654752f));
+                }
+                const long long ci = coff + (long long)row * p.ldc + ocol;
+                if (p.out_bf16) {
+                    if (((p.ldc | coff) & 3) == 0 && ((uintptr_t)p.C & 7) == 0) {
+                        bf16x4_t o;
+#pragma unroll
+                        for (int e = 0; e < 4; e++) o.v[e] = f2bf(v[e]);
+                        *reinterpret_cast<bf16x4_t*>(reinterpret_cast<__bf16*>(p.C) + ci) = o;
+                    } else {
+#pragma unroll
+                        for (int e = 0; e < 4; e++) reinterpret_cast<__bf16*>(p.C)[ci + e] = f2bf(v[e]);
+                    }
+                } else {
+#pragma unroll
+                    for (int e = 0; e < 4; e++) reinterpret_cast<float*>(p.C)[ci + e] = v[e];
+                }
+            }
+        }
+        return;
+    }
+#pragma unroll
+    for (int i = 0; i < TM; i++) {
+        const int row = m0 + (wm * TM + i) * 32 + lrow;
+        if (row >= p.M) continue;
+#pragma unroll
+        for (int j = 0; j < TN; j++)
+#pragma unroll
+            for (int r4 = 0; r4 < 4; r4++) {
+                const int col = n0 + wn * 64 + j * 32 + 8 * r4 + lhalf;
+                if (col >= p.N) continue;
+                float v[4];
+#pragma unroll
+                for (int e = 0; e < 4; e++) v[e] = acc[i][j][4 * r4 + e] * p.alpha;
+                if (p.splitk > 1) {
+                    if (p.ws) {                              // slab, reduced by k_splitk_epilogue
+                        float* dst = p.ws + ((long long)ks_id * p.M + row) * p.N + col;
+                        if ((p.N & 3) == 0) *reinterpret_cast<float4*>(dst) = make_float4(v[0], v[1], v[2], v[3]);
+                        else {
+#pragma unroll
+                            for (int e = 0; e < 4; e++) if (col + e < p.N) dst[e] = v[e];
+                        }
+                    } else {
+#pragma unroll
+                        for (int e = 0; e < 4; e++)
+                            if (col + e < p.N) atomicAdd(reinterpret_cast<float*>(p.C) + coff + (long long)row * p.ldc + col + e, v[e]);
+                    }
+                    continue;
+                }
+                epilogue_store4(p, v, row, col, coff, roff, vec_ok);
+            }
+    }
+}
+
 template <typename T, int BN, int AMODE, int BMODE>
 __global__ __launch_bounds__(256) void k_gemm(GemmP p) {
     constexpr int BM = 128, BK = TT<T>::BK, LDT = BK + TT<T>::PAD;
@@ -600,12 +740,12 @@ __global__ __launch_bounds__(256) void k_gemm_glds(GemmP p) {
 #pragma unroll
             for (int i = 0; i < TM; i++)
 #pragma unroll
-                for (int j = 0; j < TN; j++) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[i], bf[j], acc[i][j], 0, 0, 0);
+                for (int j = 0; j < TN; j++) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(bf[j], af[i], acc[i][j], 0, 0, 0);   // transposed: see tile_epilogue_t
         }
         cur = cur + 1 == S ? 0 : cur + 1; nxt = nxt + 1 == S ? 0 : nxt + 1;
     }
     wait_vmcnt<0>();                        // drain the zero-line tail loads before LDS is handed back
-    tile_epilogue<TM, TN>(p, acc, m0, n0, wm, wn, lane, ks_id, z1, z2);
+    tile_epilogue_t<TM, TN>(p, acc, m0, n0, wm, wn, lane, ks_id, z1, z2);
 }
 
 // Algorithmic flops of one launch for the profiler table: 2*M*N*K, with the zero taps of an input-dilated (strided-conv
@@ -751,25 +891,29 @@ __global__ __launch_bounds__(256) void k_conv3x3_patch(GemmP p) {
 #pragma unroll
             for (int i = 0; i < TM; i++)
 #pragma unroll
-                for (int j = 0; j < TN; j++) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[i], bf[j], acc[i][j], 0, 0, 0);
+                for (int j = 0; j < TN; j++) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(bf[j], af[i], acc[i][j], 0, 0, 0);   // transposed
         }
     }
-    // epilogue: accumulator row -> output pixel -> flat NHWC row index
+    // epilogue (transposed orientation: a lane owns one output pixel and groups of four consecutive channels)
+    const bool vec_ok = epilogue_vec_ok(p, 0, 0);
 #pragma unroll
-    for (int i = 0; i < TM; i++)
+    for (int i = 0; i < TM; i++) {
+        const int rr = (wm * TM + i) * 32 + (lane & 31);
+        const int y = y0 + (rr >> 4), x = x0 + (rr & 15);
+        if (y >= cv.Hout || x >= cv.Wout) continue;
+        const int m = (img * cv.Hout + y) * cv.Wout + x;
 #pragma unroll
-        for (int j = 0; j < TN; j++) {
-            const int col = n0 + wn * 64 + j * 32 + (lane & 31);
-            if (col >= p.N) continue;
+        for (int j = 0; j < TN; j++)
 #pragma unroll
-            for (int r = 0; r < 16; r++) {
-                const int rr = (wm * TM + i) * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
-                const int y = y0 + (rr >> 4), x = x0 + (rr & 15);
-                if (y >= cv.Hout || x >= cv.Wout) continue;
-                const int m = (img * cv.Hout + y) * cv.Wout + x;
-                epilogue_store(p, acc[i][j][r] * p.alpha, m, col, 0, 0);
+            for (int r4 = 0; r4 < 4; r4++) {
+                const int col = n0 + wn * 64 + j * 32 + 8 * r4 + (lane >> 5) * 4;
+                if (col >= p.N) continue;
+                float v[4];
+#pragma unroll
+                for (int e = 0; e < 4; e++) v[e] = acc[i][j][4 * r4 + e] * p.alpha;
+                epilogue_store4(p, v, m, col, 0, 0, vec_ok);
             }
-        }
+    }
 }
 
 template <int BN>
