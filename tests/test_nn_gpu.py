@@ -13,7 +13,8 @@ def _err(a, r):
 
 
 @pytest.mark.parametrize("B,H,C,silu,eps", [(2, 64, 320, True, 1e-5), (2, 16, 1280, False, 1e-6), (1, 96, 128, True, 1e-6),
-                                            (2, 8, 2560, True, 1e-5), (1, 33, 64, False, 1e-5), (2, 32, 960, True, 1e-5)])
+                                            (2, 8, 2560, True, 1e-5), (1, 33, 64, False, 1e-5), (2, 32, 960, True, 1e-5),
+                                            (1, 128, 256, True, 1e-6)])   # 128^2 x 8 ch per group: the three-kernel path
 def test_groupnorm_forward_backward(B, H, C, silu, eps):
     from dreamwaltz_g_amd import nn_ops
     g = torch.Generator().manual_seed(C + H)
