@@ -427,6 +427,35 @@ __device__ __forceinline__ void tile_epilogue_t(const GemmP& p, f32x16 (&acc)[TM
     }
 }
 
+// sums the split-K slabs in slice order and applies the fused epilogue (batch == 1); four consecutive columns per thread
+// (float4 slab reads, 8/16-byte bias / residual / output pieces) when N % 4 == 0
+__global__ __launch_bounds__(256) void k_splitk_epilogue(GemmP p) {
+    const long long n = (long long)p.M * p.N;
+    if ((p.N & 3) == 0) {
+        const bool vec_ok = epilogue_vec_ok(p, 0, 0);
+        const long long n4 = n >> 2;
+        const int N4 = p.N >> 2;
+        for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < n4; i += (long long)gridDim.x * 256) {
+            const float4* src = reinterpret_cast<const float4*>(p.ws) + i;
+            float4 a = src[0];
+            for (int sidx = 1; sidx < p.splitk; sidx++) {
+                const float4 u = src[(long long)sidx * n4];
+                a.x += u.x; a.y += u.y; a.z += u.z; a.w += u.w;
+            }
+            const int row = (int)(i / N4), col = (int)(i - (long long)row * N4) * 4;
+            float v[4] = {a.x, a.y, a.z, a.w};
+            epilogue_store4(p, v, row, col, 0, 0, vec_ok);
+        }
+        return;
+    }
+    for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long long)gridDim.x * 256) {
+        float v = 0.f;
+        for (int s = 0; s < p.splitk; s++) v += p.ws[(long long)s * n + i];
+        int row = (int)(i / p.N), col = (int)(i - (long long)row * p.N);
+        epilogue_store(p, v, row, col, 0, 0);
+    }
+}
+
 template <typename T, int BN, int AMODE, int BMODE>
 __global__ __launch_bounds__(256) void k_gemm(GemmP p) {
     constexpr int BM = 128, BK = TT<T>::BK, LDT = BK + TT<T>::PAD;
@@ -486,17 +515,6 @@ __global__ __launch_bounds__(256) void k_gemm(GemmP p) {
         __syncthreads();
     }
     tile_epilogue<TM, TN>(p, acc, m0, n0, wm, wn, lane, ks_id, z1, z2);
-}
-
-// sums the split-K slabs and applies the fused epilogue (batch == 1)
-__global__ __launch_bounds__(256) void k_splitk_epilogue(GemmP p) {
-    const long long n = (long long)p.M * p.N;
-    for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long long)gridDim.x * 256) {
-        float v = 0.f;
-        for (int s = 0; s < p.splitk; s++) v += p.ws[(long long)s * n + i];
-        int row = (int)(i / p.N), col = (int)(i - (long long)row * p.N);
-        epilogue_store(p, v, row, col, 0, 0);
-    }
 }
 
 // ---------------------------------------------------------------------------------------------------------------------
@@ -770,6 +788,7 @@ static void launch_glds_s(const GemmP& p, int batch, hipStream_t stream, const c
     DWG_LAUNCH_W(name, sym[BN == 128][AKIND], gemm_flops(p, batch), (k_gemm_glds<BN, AKIND, S>), grid, dim3(256), lds, stream, p);
     if (p.splitk > 1 && p.ws) {
         long long n = (long long)p.M * p.N;
+        if ((p.N & 3) == 0) n >>= 2;                 // four columns per thread
         int blocks = (int)((n + 255) / 256); if (blocks > 2048) blocks = 2048;
         DWG_LAUNCH("splitk_epilogue", k_splitk_epilogue, dim3(blocks), dim3(256), 0, stream, p);
     }
@@ -794,7 +813,7 @@ static void launch_glds(const GemmP& p, int batch, hipStream_t stream, const cha
 // L2->LDS bytes per flop drop by ~40 % (A: 16 KiB/tap -> 23 KiB/9 taps).
 // ---------------------------------------------------------------------------------------------------------------------
 template <int BN>
-__global__ __launch_bounds__(256) void k_conv3x3_patch(GemmP p) {
+__global__ __launch_bounds__(256, 2) void k_conv3x3_patch(GemmP p) {   // 2 waves per SIMD: LDS allows 2 workgroups per CU anyway
     constexpr int PH = 8, PW = 16, HP = PH + 2, WP = PW + 2, NPIX = HP * WP;     // 180 patch pixels, 128 B each
     constexpr int NPI = (NPIX + 7) / 8;                                          // 23 wave-instructions per patch
     constexpr int WN = BN / 64, WM = 4 / WN, TM = 128 / WM / 32, TN = 2;
@@ -835,17 +854,26 @@ __global__ __launch_bounds__(256) void k_conv3x3_patch(GemmP p) {
                                              (__attribute__((address_space(3))) void*)(dst + inst * 8 * 128), 16, 0, 0);
         }
     };
-    // weight slab loader: rows n0 .. n0+BN of Wt[Cout][9*Cin], columns (tap*Cin + cc*64) .. +64
+    // weight slab loader: rows n0 .. n0+BN of Wt[Cout][9*Cin], columns (tap*Cin + cc*64) .. +64.  Row pointers (with the lane's
+    // swizzled chunk folded in) are fixed for the whole kernel; per step only a wave-uniform column offset is added.
+    constexpr int NJW = BN / 32;
+    const __bf16* wrow[NJW];
+    {
+        const int wv = __builtin_amdgcn_readfirstlane(wave);
+#pragma unroll
+        for (int j = 0; j < NJW; j++) {
+            const int r = n0 + (wv * NJW + j) * 8 + sub;
+            wrow[j] = r < p.N ? Wt + (long long)r * p.sbn + (lg0 ^ ((j & 1) << 2)) * 8 : nullptr;
+        }
+    }
     auto issue_w = [&](int cc, int tap, unsigned char* dst) {
         const int wv = __builtin_amdgcn_readfirstlane(wave);
-        constexpr int NJ = BN / 32;
-        const long long kofs = (long long)tap * cv.Cin + cc * 64;
+        const long long kofs = (long long)tap * cv.Cin + cc * 64;          // wave-uniform
 #pragma unroll
-        for (int j = 0; j < NJ; j++) {
-            const int r = n0 + (wv * NJ + j) * 8 + sub;
-            const __bf16* src = r < p.N ? Wt + (long long)r * p.sbn + kofs + (lg0 ^ ((j & 1) << 2)) * 8 : zero;
+        for (int j = 0; j < NJW; j++) {
+            const __bf16* src = wrow[j] ? wrow[j] + kofs : zero;
             __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
-                                             (__attribute__((address_space(3))) void*)(dst + (wv * NJ + j) * 8 * 128), 16, 0, 0);
+                                             (__attribute__((address_space(3))) void*)(dst + (wv * NJW + j) * 8 * 128), 16, 0, 0);
         }
     };
     f32x16 acc[TM][TN];
@@ -862,36 +890,38 @@ __global__ __launch_bounds__(256) void k_conv3x3_patch(GemmP p) {
         const int r = (wm * TM + i) * 32 + (lane & 31);
         pbase[i] = (r >> 4) * WP + (r & 15);
     }
-    const int ncc = cv.Cin / 64, nsteps = ncc * 9;
+    const int ncc = cv.Cin / 64;
     const int frow = lane & 31, fx = (lane >> 1) & 7, fh = lane >> 5;
     issue_patch(0, sP);
     issue_w(0, 0, sB);
-    for (int st = 0; st < nsteps; st++) {
-        const int cc = st / 9, tap = st - cc * 9;
-        __syncthreads();                                    // everything issued so far has landed; older buffers are free
-        if (st + 1 < nsteps) {
-            const int cc1 = (st + 1) / 9, tap1 = (st + 1) - cc1 * 9;
-            issue_w(cc1, tap1, sB + ((st + 1) & 1) * BBYTES);
-            if (tap == 0 && cc + 1 < ncc) issue_patch(cc + 1, sP + ((cc + 1) & 1) * PBYTES);   // a full slab ahead
-        }
+    // 9 taps unrolled: the tap's patch offset is an immediate and there is no step -> (slab, tap) division in the loop
+    for (int cc = 0; cc < ncc; cc++) {
         const unsigned char* pa = sP + (cc & 1) * PBYTES;
-        const unsigned char* tb = sB + (st & 1) * BBYTES + (wn * 64 + frow) * 128;
-        const int toff = (tap / 3) * WP + (tap % 3);
 #pragma unroll
-        for (int ks = 0; ks < 4; ks++) {
-            const int cl = ks * 2 + fh;
-            bf16x8 af[TM], bf[TN];
+        for (int tap = 0; tap < 9; tap++) {
+            const int par = (cc + tap) & 1;                     // step parity: 9 steps per slab
+            __syncthreads();                                    // everything issued so far has landed; older buffers are free
+            if (tap < 8) issue_w(cc, tap + 1, sB + (par ^ 1) * BBYTES);
+            else if (cc + 1 < ncc) issue_w(cc + 1, 0, sB + (par ^ 1) * BBYTES);
+            if (tap == 0 && cc + 1 < ncc) issue_patch(cc + 1, sP + ((cc + 1) & 1) * PBYTES);   // a full slab ahead
+            const unsigned char* tb = sB + par * BBYTES + (wn * 64 + frow) * 128;
+            const int toff = (tap / 3) * WP + (tap % 3);
 #pragma unroll
-            for (int i = 0; i < TM; i++) {
-                const int pi = pbase[i] + toff;
-                af[i] = *reinterpret_cast<const bf16x8*>(pa + pi * 128 + ((cl ^ ((pi >> 1) & 7)) << 4));
+            for (int ks = 0; ks < 4; ks++) {
+                const int cl = ks * 2 + fh;
+                bf16x8 af[TM], bf[TN];
+#pragma unroll
+                for (int i = 0; i < TM; i++) {
+                    const int pi = pbase[i] + toff;
+                    af[i] = *reinterpret_cast<const bf16x8*>(pa + pi * 128 + ((cl ^ ((pi >> 1) & 7)) << 4));
+                }
+#pragma unroll
+                for (int j = 0; j < TN; j++) bf[j] = *reinterpret_cast<const bf16x8*>(tb + j * 32 * 128 + ((cl ^ fx) << 4));
+#pragma unroll
+                for (int i = 0; i < TM; i++)
+#pragma unroll
+                    for (int j = 0; j < TN; j++) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(bf[j], af[i], acc[i][j], 0, 0, 0);   // transposed
             }
-#pragma unroll
-            for (int j = 0; j < TN; j++) bf[j] = *reinterpret_cast<const bf16x8*>(tb + j * 32 * 128 + ((cl ^ fx) << 4));
-#pragma unroll
-            for (int i = 0; i < TM; i++)
-#pragma unroll
-                for (int j = 0; j < TN; j++) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(bf[j], af[i], acc[i][j], 0, 0, 0);   // transposed
         }
     }
     // epilogue (transposed orientation: a lane owns one output pixel and groups of four consecutive channels)
@@ -948,6 +978,7 @@ static void launch(const GemmP& p, int batch, hipStream_t stream, const char* na
                  dim3(256), lds, stream, p);
     if (p.splitk > 1 && p.ws) {
         long long n = (long long)p.M * p.N;
+        if ((p.N & 3) == 0) n >>= 2;                 // four columns per thread
         int blocks = (int)((n + 255) / 256); if (blocks > 2048) blocks = 2048;
         DWG_LAUNCH("splitk_epilogue", k_splitk_epilogue, dim3(blocks), dim3(256), 0, stream, p);
     }
