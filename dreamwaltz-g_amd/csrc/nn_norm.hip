@@ -4,6 +4,7 @@
 // same math through torch.nn.functional.group_norm / layer_norm / gelu / softmax inside diffusers.
 // Access pattern: every kernel walks the tensor in 16-byte (8 x bf16) chunks, whole rows per wave, so HBM sees full lines.
 #include "dwg_common.h"
+#include <cstdlib>
 #include "dwg_prof_internal.h"
 #include "../../include/dwg_nn.h"
 
@@ -117,16 +118,38 @@ __global__ __launch_bounds__(256) void k_gn_apply(int HW, int C, int G, int pix_
                                                   const __bf16* __restrict__ dy, const float* __restrict__ stats,
                                                   const float* __restrict__ bsums, const float* __restrict__ gamma,
                                                   const float* __restrict__ beta, int silu, float eps,
-                                                  __bf16* __restrict__ out) {
+                                                  __bf16* __restrict__ out, const float* __restrict__ partials, int pchunks,
+                                                  float* __restrict__ sums_out) {
     __shared__ float gstat[64 * 4];
+    __shared__ float tot[128];
     const int b = blockIdx.y, tid = threadIdx.x;
     const int C8 = C / 8, cg = C / G;
     const float inv_n = 1.f / ((float)HW * cg);
+    if (partials) {
+        // Few chunks (small tensors): the fixed-order sum of the reduction pass's partials [b][2G][chunk] is redone by every
+        // workgroup right here -- 2G x chunks floats out of L2 -- instead of a separate finalize launch between two
+        // 10-us kernels.  4 threads per output, strided over the chunks, combined in a fixed order.
+        const int o = tid >> 2, part = tid & 3;
+        float a = 0.f;
+        if (o < 2 * G) {
+            const float* src = partials + ((size_t)b * 2 * G + o) * pchunks;
+            for (int c = part; c < pchunks; c += 4) a += src[c];
+        }
+        a += __shfl_xor(a, 1); a += __shfl_xor(a, 2);
+        if (part == 0 && o < 2 * G) {
+            tot[o] = a;
+            if (blockIdx.x == 0) sums_out[(size_t)b * 2 * G + o] = a;      // the saved statistics (forward) / scratch (backward)
+        }
+        __syncthreads();
+    }
     if (tid < G) {
-        float m = stats[((size_t)b * G + tid) * 2] * inv_n;
-        float var = stats[((size_t)b * G + tid) * 2 + 1] * inv_n - m * m;
+        const float* st = BWD ? stats : (partials ? tot : stats + (size_t)b * G * 2);
+        const float* bs = BWD ? (partials ? tot : bsums + (size_t)b * G * 2) : nullptr;
+        const float* fst = BWD ? stats + (size_t)b * G * 2 : st;
+        float m = fst[2 * tid] * inv_n;
+        float var = fst[2 * tid + 1] * inv_n - m * m;
         gstat[4 * tid] = m; gstat[4 * tid + 1] = rsqrtf(fmaxf(var, 0.f) + eps);
-        if (BWD) { gstat[4 * tid + 2] = bsums[((size_t)b * G + tid) * 2] * inv_n; gstat[4 * tid + 3] = bsums[((size_t)b * G + tid) * 2 + 1] * inv_n; }
+        if (BWD) { gstat[4 * tid + 2] = bs[2 * tid] * inv_n; gstat[4 * tid + 3] = bs[2 * tid + 1] * inv_n; }
     }
     __syncthreads();
     const int p0 = blockIdx.x * pix_per_block, p1 = min(HW, p0 + pix_per_block);
@@ -274,6 +297,7 @@ static int gn_geometry(int HW, int C, int G, int* pix_per_block, int* chunks, si
 }
 // reduction pass: ~64K elements per workgroup, at most GN_MAX_CHUNKS partials per image
 #define GN_MAX_CHUNKS 512
+#define GN_FOLD_MAX_CHUNKS 32      // up to this many partials per output the apply pass sums them itself (no finalize launch)
 static void gn_reduce_geometry(int HW, int C, int* pix_per_block, int* chunks) {
     long long ppb = 16384 / C; if (ppb < 8) ppb = 8;
     int ch = (int)((HW + ppb - 1) / ppb);
@@ -298,9 +322,12 @@ int dwg_groupnorm_forward(int32_t B, int32_t HW, int32_t C, int32_t G, const voi
     hipStream_t stream = (hipStream_t)stream_;
     DWG_LAUNCH("gn_stats", (k_gn_reduce<false>), dim3(rchunks, B), dim3(256), lds, stream, HW, C, G, rppb, (const __bf16*)x,
                (const __bf16*)nullptr, (const float*)nullptr, gamma, beta, 0, eps, workspace);
-    DWG_LAUNCH("gn_finalize", k_gn_finalize, dim3(B), dim3(1024), 0, stream, rchunks, G, (const float*)workspace, stats);
+    static const int fold_max = getenv("DWG_GN_FOLD") ? atoi(getenv("DWG_GN_FOLD")) : GN_FOLD_MAX_CHUNKS;
+    const bool fold = rchunks <= fold_max && 2 * G * 4 <= 256;     // finalize folded into the apply pass
+    if (!fold) DWG_LAUNCH("gn_finalize", k_gn_finalize, dim3(B), dim3(1024), 0, stream, rchunks, G, (const float*)workspace, stats);
     DWG_LAUNCH("gn_apply", (k_gn_apply<false>), dim3(chunks, B), dim3(256), 0, stream, HW, C, G, ppb, (const __bf16*)x,
-               (const __bf16*)nullptr, (const float*)stats, (const float*)nullptr, gamma, beta, fuse_silu, eps, (__bf16*)y);
+               (const __bf16*)nullptr, (const float*)stats, (const float*)nullptr, gamma, beta, fuse_silu, eps, (__bf16*)y,
+               fold ? (const float*)workspace : (const float*)nullptr, rchunks, stats);
     DWG_RETURN_IF_LAUNCH_FAILED();
     return DWG_OK;
 }
@@ -317,9 +344,12 @@ int dwg_groupnorm_backward(int32_t B, int32_t HW, int32_t C, int32_t G, const vo
     hipStream_t stream = (hipStream_t)stream_;
     DWG_LAUNCH("gn_bwd_stats", (k_gn_reduce<true>), dim3(rchunks, B), dim3(256), lds, stream, HW, C, G, rppb, (const __bf16*)x,
                (const __bf16*)dy, stats, gamma, beta, fuse_silu, eps, workspace);
-    DWG_LAUNCH("gn_finalize", k_gn_finalize, dim3(B), dim3(1024), 0, stream, rchunks, G, (const float*)workspace, scratch);
+    static const int fold_max = getenv("DWG_GN_FOLD") ? atoi(getenv("DWG_GN_FOLD")) : GN_FOLD_MAX_CHUNKS;
+    const bool fold = rchunks <= fold_max && 2 * G * 4 <= 256;
+    if (!fold) DWG_LAUNCH("gn_finalize", k_gn_finalize, dim3(B), dim3(1024), 0, stream, rchunks, G, (const float*)workspace, scratch);
     DWG_LAUNCH("gn_bwd_apply", (k_gn_apply<true>), dim3(chunks, B), dim3(256), 0, stream, HW, C, G, ppb, (const __bf16*)x,
-               (const __bf16*)dy, stats, (const float*)scratch, gamma, beta, fuse_silu, eps, (__bf16*)dx);
+               (const __bf16*)dy, stats, (const float*)scratch, gamma, beta, fuse_silu, eps, (__bf16*)dx,
+               fold ? (const float*)workspace : (const float*)nullptr, rchunks, scratch);
     DWG_RETURN_IF_LAUNCH_FAILED();
     return DWG_OK;
 }
