@@ -129,6 +129,14 @@ def main():
         "config": info["config"],
     }
     out["roofline"] = step.roofline(prof, HBM_PEAK_GBS, BF16_PEAK_TFLOPS, prof_sym)
+    # HBM traffic of the dominant kernel per launch: PMC counters need their own rocprofv3 passes (FETCH_SIZE and WRITE_SIZE
+    # separately), so the table is produced by tools/pmc_traffic.py from those passes and committed under profiles/.
+    tpath = os.path.join(ROOT, "profiles", "r01_pmc_traffic.json")
+    if out["roofline"] and os.path.exists(tpath):
+        tk = json.load(open(tpath))["kernels"].get(out["roofline"]["kernel"].replace(" ", ""))
+        if tk:
+            out["roofline"]["traffic"] = tk["hbm_bytes_per_launch"]
+            out["roofline"]["traffic_source"] = "profiles/r01_pmc_traffic.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes, gfx950 corrections)"
     out["raster_mpix_per_s"] = args.res * args.res * views_per_step * args.steps / dt / 1e6
     out["kernel_ms_per_step"] = {k: round(v[1] / prof_steps, 4) for k, v in sorted(prof.items(), key=lambda kv: -kv[1][1])[:40]}
     out["launch_mode"] = "eager" if args.eager else "hipGraph replay of denoiser/VAE plans; kernel timers from an eager replay after the timed region"

@@ -783,9 +783,12 @@ static void launch_glds_s(const GemmP& p, int batch, hipStream_t stream, const c
         attr_set = true;
     }
     dim3 grid(((p.M + 127) / 128) * ((p.N + BN - 1) / BN) * (p.splitk > 1 ? p.splitk : 1), 1, batch);
-    static const char* const sym[2][3] = {{"k_gemm_glds<64,rows>", "k_gemm_glds<64,conv>", "k_gemm_glds<64,convfast>"},
-                                          {"k_gemm_glds<128,rows>", "k_gemm_glds<128,conv>", "k_gemm_glds<128,convfast>"}};
-    DWG_LAUNCH_W(name, sym[BN == 128][AKIND], gemm_flops(p, batch), (k_gemm_glds<BN, AKIND, S>), grid, dim3(256), lds, stream, p);
+    // profiler symbols spelled as rocprofv3 prints the instantiation: k_gemm_glds<BN, AKIND, S>
+    static const char* const sym[2][2][3] = {{{"k_gemm_glds<64, 0, 2>", "k_gemm_glds<64, 1, 2>", "k_gemm_glds<64, 2, 2>"},
+                                              {"k_gemm_glds<64, 0, 3>", "k_gemm_glds<64, 1, 3>", "k_gemm_glds<64, 2, 3>"}},
+                                             {{"k_gemm_glds<128, 0, 2>", "k_gemm_glds<128, 1, 2>", "k_gemm_glds<128, 2, 2>"},
+                                              {"k_gemm_glds<128, 0, 3>", "k_gemm_glds<128, 1, 3>", "k_gemm_glds<128, 2, 3>"}}};
+    DWG_LAUNCH_W(name, sym[BN == 128][S == 3][AKIND], gemm_flops(p, batch), (k_gemm_glds<BN, AKIND, S>), grid, dim3(256), lds, stream, p);
     if (p.splitk > 1 && p.ws) {
         long long n = (long long)p.M * p.N;
         if ((p.N & 3) == 0) n >>= 2;                 // four columns per thread
