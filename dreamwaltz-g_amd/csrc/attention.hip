@@ -70,28 +70,60 @@ __global__ __launch_bounds__(256) void k_flash_fwd(AttnP p) {
     float m_run = -3.0e38f, l_run = 0.f;
 
     const int ntiles = (p.Nk + KT - 1) / KT;
+    // K / V staging is software-pipelined through registers: the global loads of tile t+1 are issued right after tile t has
+    // been written to LDS and complete while tile t is being multiplied (the unpipelined version exposed one L2/HBM round
+    // trip per 32-key tile -- 128 of them per workgroup at 4096 keys).
+    constexpr int NKC = (KT * (DK / 8) + 255) / 256, NVC = (KT * (DV / 8) + 255) / 256;
+    bf16x8 kreg[NKC], vreg[NVC];
+    // per-thread staging coordinates are tile-invariant: (key, dc) and the matching global / LDS addresses are computed once
+    int kkey[NKC], vkey[NVC];
+    const __bf16* kptr[NKC]; const __bf16* vptr[NVC];
+    __bf16* klds[NKC]; __bf16* vlds[NVC];
+#pragma unroll
+    for (int i = 0; i < NKC; i++) {
+        const int c = tid + i * 256;
+        const int key = c / (DK / 8), dc = (c % (DK / 8)) * 8;
+        const bool on = c < KT * (DK / 8) && dc < p.d;
+        kkey[i] = on ? key : (1 << 30);                       // disabled lanes never pass the key-range test
+        kptr[i] = K + (long long)key * p.ldk + dc;
+        klds[i] = c < KT * (DK / 8) ? &sK[key * LDK + dc] : nullptr;
+    }
+#pragma unroll
+    for (int i = 0; i < NVC; i++) {
+        const int c = tid + i * 256;
+        const int key = c % KT, dc = (c / KT) * 8;            // consecutive threads -> consecutive keys: conflict-light transposed writes
+        const bool on = c < KT * (DV / 8) && dc < p.d;
+        vkey[i] = on ? key : (1 << 30);
+        vptr[i] = V + (long long)key * p.ldv + dc;
+        vlds[i] = c < KT * (DV / 8) ? &sVt[dc * LDV + key] : nullptr;
+    }
+    auto fetch = [&](int k0) {
+        bf16x8 z;
+#pragma unroll
+        for (int e = 0; e < 8; e++) z[e] = (__bf16)0.f;
+#pragma unroll
+        for (int i = 0; i < NKC; i++)
+            kreg[i] = (long long)k0 + kkey[i] < p.Nk ? *reinterpret_cast<const bf16x8*>(kptr[i] + (long long)k0 * p.ldk) : z;
+#pragma unroll
+        for (int i = 0; i < NVC; i++)
+            vreg[i] = (long long)k0 + vkey[i] < p.Nk ? *reinterpret_cast<const bf16x8*>(vptr[i] + (long long)k0 * p.ldv) : z;
+    };
+    if (ntiles > 0) fetch(0);
     for (int t = 0; t < ntiles; t++) {
         const int k0 = t * KT;
         __syncthreads();   // previous tile fully consumed
-        // stage K tile [key][d] (zero padded) and V tile transposed [d][key]
-        for (int c = tid; c < KT * (DK / 8); c += 256) {
-            int key = c / (DK / 8), dc = (c % (DK / 8)) * 8;
-            bf16x8 v;
+        // stage K tile [key][d] (zero padded) and V tile transposed [d][key] from the prefetched registers
 #pragma unroll
-            for (int e = 0; e < 8; e++) v[e] = (__bf16)0.f;
-            if (k0 + key < p.Nk && dc < p.d) v = *reinterpret_cast<const bf16x8*>(K + (long long)(k0 + key) * p.ldk + dc);
-            *reinterpret_cast<bf16x8*>(&sK[key * LDK + dc]) = v;
-        }
-        for (int c = tid; c < KT * (DV / 8); c += 256) {
-            int key = c % KT, dc = (c / KT) * 8;      // consecutive threads -> consecutive keys: conflict-light transposed writes
-            bf16x8 v;
+        for (int i = 0; i < NKC; i++)
+            if (klds[i]) *reinterpret_cast<bf16x8*>(klds[i]) = kreg[i];
 #pragma unroll
-            for (int e = 0; e < 8; e++) v[e] = (__bf16)0.f;
-            if (k0 + key < p.Nk && dc < p.d) v = *reinterpret_cast<const bf16x8*>(V + (long long)(k0 + key) * p.ldv + dc);
+        for (int i = 0; i < NVC; i++)
+            if (vlds[i]) {
 #pragma unroll
-            for (int e = 0; e < 8; e++) sVt[(dc + e) * LDV + key] = v[e];
-        }
+                for (int e = 0; e < 8; e++) vlds[i][e * LDV] = vreg[i][e];
+            }
         __syncthreads();
+        if (t + 1 < ntiles) fetch(k0 + KT);      // in flight during the MFMA / softmax work below
         // S^T tile: rows = keys, cols = queries
         f32x16 s;
 #pragma unroll
@@ -101,27 +133,36 @@ __global__ __launch_bounds__(256) void k_flash_fwd(AttnP p) {
             bf16x8 kf = *reinterpret_cast<const bf16x8*>(&sK[ql * LDK + 16 * ks + 8 * half]);
             s = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf, qf[ks], s, 0, 0, 0);
         }
-        // online softmax for this lane's query; register r <-> key k0 + (r&3) + 8*(r>>2) + 4*half
-        float mx = -3.0e38f;
+        // online softmax for this lane's query; register r <-> key k0 + (r&3) + 8*(r>>2) + 4*half.
+        // The scale (> 0) is folded into the exponent (one fma per element); only the last, partial tile needs key masking;
+        // the accumulator rescale is skipped while no lane of the wave has seen a new maximum (the common case after the
+        // first tiles).
+        if (k0 + KT > p.Nk) {
 #pragma unroll
-        for (int r = 0; r < 16; r++) {
-            int key = k0 + (r & 3) + 8 * (r >> 2) + 4 * half;
-            s[r] = key < p.Nk ? s[r] * p.scale_log2 : -3.0e38f;
-            mx = fmaxf(mx, s[r]);
+            for (int r = 0; r < 16; r++) {
+                int key = k0 + (r & 3) + 8 * (r >> 2) + 4 * half;
+                if (key >= p.Nk) s[r] = -3.0e38f;
+            }
         }
+        float mx = s[0];
+#pragma unroll
+        for (int r = 1; r < 16; r++) mx = fmaxf(mx, s[r]);
         mx = fmaxf(mx, __shfl_xor(mx, 32));
-        const float m_new = fmaxf(m_run, mx);
-        const float alpha = exp2f(m_run - m_new);
+        const float m_new = fmaxf(m_run, mx * p.scale_log2);
         float rs = 0.f;
 #pragma unroll
-        for (int r = 0; r < 16; r++) { s[r] = exp2f(s[r] - m_new); rs += s[r]; }
+        for (int r = 0; r < 16; r++) { s[r] = __builtin_amdgcn_exp2f(fmaf(s[r], p.scale_log2, -m_new)); rs += s[r]; }   // raw v_exp_f32: arguments <= 0, underflow -> 0
         rs += __shfl_xor(rs, 32);
-        l_run = l_run * alpha + rs;
+        if (__any(m_new != m_run)) {
+            const float alpha = __builtin_amdgcn_exp2f(m_run - m_new);
+            l_run *= alpha;
+#pragma unroll
+            for (int j = 0; j < NVB; j++)
+#pragma unroll
+                for (int r = 0; r < 16; r++) acc[j][r] *= alpha;
+        }
+        l_run += rs;
         m_run = m_new;
-#pragma unroll
-        for (int j = 0; j < NVB; j++)
-#pragma unroll
-            for (int r = 0; r < 16; r++) acc[j][r] *= alpha;
         // P^T as B operand: step st uses registers 8 st .. 8 st + 7 of this lane
         bf16x8 pf[2];
 #pragma unroll

@@ -17,6 +17,21 @@ import torch
 from . import _lib, avatar as av, camera, guidance as gd, renderer as rd, rasterizer, synth
 
 
+def get_expon_lr_func(lr_init, lr_final, lr_delay_steps=0, lr_delay_mult=1.0, max_steps=1000000):
+    """Log-linear learning-rate decay with an optional eased-in start: mirror of core/optim/optim_utils.py:4-38 (host-side
+    float arithmetic; pinned against the reference's own function by tests/test_oracle_golden.py)."""
+    def helper(step):
+        if step < 0 or (lr_init == 0.0 and lr_final == 0.0):
+            return 0.0
+        if lr_delay_steps > 0:
+            delay_rate = lr_delay_mult + (1 - lr_delay_mult) * math.sin(0.5 * math.pi * min(max(step / lr_delay_steps, 0.0), 1.0))
+        else:
+            delay_rate = 1.0
+        t = min(max(step / max_steps, 0.0), 1.0)
+        return delay_rate * math.exp(math.log(lr_init) * (1 - t) + math.log(lr_final) * t)
+    return helper
+
+
 class FlatAdam:
     """All trainable parameters live in ONE flat fp32 buffer (16-byte aligned slices, grouped by learning rate), gradients
     in a second one: a single all-reduce and one fused Adam launch per group (include/dwg_elementwise.h)."""
@@ -28,7 +43,8 @@ class FlatAdam:
             start = total
             for p in g["params"]:
                 total += (p.numel() + 3) // 4 * 4
-            self.groups.append(dict(lr=g["lr"], betas=g.get("betas", betas), start=start, end=total))
+            self.groups.append(dict(lr=g["lr"], betas=g.get("betas", betas), start=start, end=total, name=g.get("name"),
+                                    schedule=g.get("schedule"), base_lr=g.get("base_lr", g["lr"])))
         self.flat = torch.zeros(total, device=device)
         self.grad = torch.zeros(total, device=device)
         self.m = torch.zeros(total, device=device)
@@ -46,6 +62,20 @@ class FlatAdam:
 
     def zero_grad(self):
         self.grad.zero_()
+
+    def update_learning_rate(self, spatial_scale, iteration=None):
+        """GaussianOptimizer.update_learning_rate (gaussian_optimizer.py:130-141): the 'positions' group follows its exponential
+        schedule times spatial_scale, the 'scales' group is its base rate times spatial_scale; every other group is constant."""
+        it = self.t if iteration is None else iteration
+        lr = 0.0
+        for g in self.groups:
+            if g["name"] == "positions" and g["schedule"] is not None:
+                lr = g["schedule"](it)
+                g["lr"] = lr * spatial_scale
+            elif g["name"] == "scales":
+                lr = g["base_lr"]
+                g["lr"] = lr * spatial_scale
+        return lr
 
     def step(self, grad_scale=1.0):
         self.t += 1
@@ -106,9 +136,12 @@ class SDSStep:
             self.wimg = torch.randn(1, res, res, 3, generator=torch.Generator().manual_seed(seed + 6)).to(self.device)
         a = self.avatar
         spatial = 2.0 * float(cam["tanfov"][0])      # spatial_scale = radius * tanfov (trainer.py:711-716)
+        iters = 10000                                # cfg.optim.iters; position_lr_max_steps = 2 * iters (avatar.py:1594-1601)
         groups = [
-            dict(params=[a._positions], lr=1.6e-4 * spatial), dict(params=[a._scales], lr=2.5e-3 * spatial),
-            dict(params=[a._quaternions], lr=1e-3),
+            dict(params=[a._positions], lr=1.6e-4 * spatial, name="positions",
+                 schedule=get_expon_lr_func(lr_init=1.6e-4, lr_final=1.6e-6, lr_delay_mult=0.01, max_steps=2 * iters)),
+            dict(params=[a._scales], lr=2.5e-3 * spatial, name="scales", base_lr=2.5e-3),
+            dict(params=[a._quaternions], lr=1e-3, name="quaternions"),
             dict(params=[a.nerf_encoder.embeddings], lr=1e-2, betas=(0.9, 0.99)),
             dict(params=list(a.nerf_opacity_and_color_net.parameters()) + list(a.nerf_scale_and_quaternion_net.parameters()),
                  lr=1e-3, betas=(0.9, 0.99)),
@@ -116,6 +149,7 @@ class SDSStep:
         for gm in a.mesh_binding_gaussians.values():
             groups.append(dict(params=[gm._bary_coords, gm._scales], lr=1e-3))
         self.opt = FlatAdam(groups, self.device)
+        self.spatial_scale = spatial
         self.step_idx = 0
         self.num_pairs = 0
         rasterizer.ASYNC[0] = True       # training loop: no host sync for the pair count (checked one frame late)
@@ -131,6 +165,7 @@ class SDSStep:
 
     def run(self):
         self.opt.zero_grad()
+        self.opt.update_learning_rate(self.spatial_scale, self.step_idx)      # trainer.py:861-866 (host-side floats)
         pose = synth.random_smpl_inputs(seed=1000 * self.rank + self.step_idx, device=self.device)
         gaussians = self.avatar.animate(pose)
         out = self.renderer.render(self.cam, gaussians)

@@ -63,3 +63,13 @@ def test_grid_offsets_match_survey_table():
     sizes = np.diff(off)
     assert list(sizes[:5]) == [4920, 15632, 42880, 125000, 373248]
     assert all(s == 524288 for s in sizes[5:]) and off[-1] == 6328848
+
+
+def test_lr_schedule_matches_reference_get_expon_lr_func():
+    """The optimizer's position schedule (dreamwaltz_g_amd.sds_step.get_expon_lr_func) against values produced by the
+    reference's core/optim/optim_utils.get_expon_lr_func (golden: lr_init 1.6e-4, lr_final 1.6e-6, delay_mult 0.01, 10000 steps)."""
+    import dwg_import  # noqa: F401
+    from dreamwaltz_g_amd.sds_step import get_expon_lr_func
+    f = get_expon_lr_func(lr_init=1.6e-4, lr_final=1.6e-6, lr_delay_mult=0.01, max_steps=10000)
+    got = np.array([f(int(s)) for s in G["lr_steps"]])
+    assert np.allclose(got, G["lr_values"], rtol=1e-12, atol=0.0)
