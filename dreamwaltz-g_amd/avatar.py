@@ -270,8 +270,24 @@ class DreamWaltzG(nn.Module):
         otr = self.lbs_model.forward(**smpl_observed_inputs)
         positions = self._positions
         canonical_positions = self.lbs_transform(positions, ctr)
-        enc = self.nerf_encoder(canonical_positions, bound=self.nerf_bound)
-        colors, opacities = self.static_mlp_forward(enc, fix_opacities=False)
+        N = positions.shape[0]
+        # mesh-bound parts first: their canonical positions go through the SAME encoder / static-MLP launches as the free
+        # Gaussians (the reference calls the two networks once per part, avatar.py:1544-1583; the maths is row-wise, so one pass
+        # over the concatenated rows gives the same values with half the launches and one table-gradient scatter)
+        mesh_parts = []
+        for _name, gm in self.mesh_binding_gaussians.items():
+            vc = gm._vertex_coords
+            cvc = self._canonical_vertices.get(_name)
+            if cvc is None:                          # canonical pose and the bound vertices are fixed: transform once
+                cvc = self._canonical_vertices[_name] = self.lbs_model.transform_vertices(ctr, gm.predefined_vertex_indices, vc)
+            ovc = self.lbs_model.transform_vertices(otr, gm.predefined_vertex_indices, vc)
+            mesh_parts.append(gm(cvc, ovc))          # (cpos, pos_m, sc_m, q_m): one HIP launch each way (csrc/meshbind.hip)
+        all_cpos = torch.cat([canonical_positions] + [mp[0] for mp in mesh_parts], dim=0) if mesh_parts else canonical_positions
+        enc_all = self.nerf_encoder(all_cpos, bound=self.nerf_bound)
+        oc_all = self.nerf_opacity_and_color_net(enc_all)                      # static_mlp_forward (avatar.py:1283-1290), all rows
+        sig = torch.sigmoid(oc_all)
+        enc = enc_all[:N]
+        colors, opacities = sig[:N, 1:], sig[:N, :1]
         body_pose = smpl_observed_inputs.get('body_pose')
         if body_pose is None:
             body_pose = torch.zeros(1, 63, device=positions.device)
@@ -283,14 +299,11 @@ class DreamWaltzG(nn.Module):
         pos, quats = self.lbs_transform(pos, otr, quats)
         gaussians = GaussianOutput(positions=pos, opacities=opacities, colors=colors, quaternions=quats, scales=scales)
         parts = [gaussians]
-        for _name, gm in self.mesh_binding_gaussians.items():
-            vc = gm._vertex_coords
-            cvc = self._canonical_vertices.get(_name)
-            if cvc is None:                          # canonical pose and the bound vertices are fixed: transform once
-                cvc = self._canonical_vertices[_name] = self.lbs_model.transform_vertices(ctr, gm.predefined_vertex_indices, vc)
-            ovc = self.lbs_model.transform_vertices(otr, gm.predefined_vertex_indices, vc)
-            cpos, pos_m, sc_m, q_m = gm(cvc, ovc)    # one HIP launch each way (csrc/meshbind.hip)
-            enc_m = self.nerf_encoder(cpos, bound=self.nerf_bound)
-            col_m, op_m = self.static_mlp_forward(enc_m, fix_opacities=True)
+        off = N
+        for (cpos, pos_m, sc_m, q_m) in mesh_parts:
+            M = cpos.shape[0]
+            col_m = sig[off:off + M, 1:]
+            op_m = torch.ones_like(sig[off:off + M, :1])                       # fix_opacities=True (avatar.py:1328-1355)
+            off += M
             parts.append(GaussianOutput(positions=pos_m, opacities=op_m, colors=col_m, quaternions=q_m, scales=sc_m))
         return merge_gaussians(*parts)
