@@ -57,7 +57,7 @@ SIGNATURES = {
     "dwg_adam_step": (ctypes.c_int, [_i64, _vp, _vp, _vp, _vp, _f32, _f32, _f32, _f32, _i32, _f32, _vp]),
     # include/dwg_nn.h
     "dwg_groupnorm_forward": (ctypes.c_int, [_i32, _i32, _i32, _i32, _vp, _vp, _vp, _f32, _i32, _vp, _vp, _vp, _vp]),
-    "dwg_groupnorm_backward": (ctypes.c_int, [_i32, _i32, _i32, _i32, _vp, _vp, _vp, _vp, _vp, _f32, _i32, _vp, _vp, _vp, _vp]),
+    "dwg_groupnorm_backward": (ctypes.c_int, [_i32, _i32, _i32, _i32, _vp, _vp, _vp, _vp, _vp, _f32, _i32, _vp, _vp, _vp, _vp, _vp]),
     "dwg_groupnorm_workspace_floats": (_sz, [_i32, _i32]),
     "dwg_layernorm_forward": (ctypes.c_int, [_i32, _i32, _vp, _vp, _vp, _f32, _vp, _vp]),
     "dwg_geglu_forward": (ctypes.c_int, [_i64, _i32, _vp, _vp, _vp]),
@@ -69,6 +69,7 @@ SIGNATURES = {
     "dwg_mlp_wgrad": (ctypes.c_int, [_i32, _i32, _i32, _vp, _i32, _vp, _i32, _vp, _i32, _vp, _vp]),
     "dwg_concat_channels": (ctypes.c_int, [_i64, _i32, _i32, _vp, _vp, _vp, _vp]),
     "dwg_add_bf16": (ctypes.c_int, [_i64, _vp, _vp, _vp, _vp]),
+    "dwg_interleave2x2": (ctypes.c_int, [_i32, _i32, _i32, _i32, _vp, _vp, _vp, _vp, _vp, _vp]),
     "dwg_cast_f32_to_bf16": (ctypes.c_int, [_i64, _vp, _vp, _vp]),
     # include/dwg_meshbind.h
     "dwg_mesh_vertex_normals": (ctypes.c_int, [_i32, _i32, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),

@@ -160,6 +160,21 @@ __global__ __launch_bounds__(256) void k_cast_f32_bf16(long long n, const float*
 
 static int grid_for(long long n) { long long b = (n + 255) / 256; if (b < 1) b = 1; if (b > 4096) b = 4096; return (int)b; }
 
+// out[b, 2i+py, 2j+px, :] = sub[py*2+px][b, i, j, :]  (16-byte pieces; C % 8 == 0)
+__global__ __launch_bounds__(256) void k_interleave2x2(int B, int Ho, int Wo, int C8, const uint4* __restrict__ s00,
+                                                       const uint4* __restrict__ s01, const uint4* __restrict__ s10,
+                                                       const uint4* __restrict__ s11, uint4* __restrict__ out) {
+    const long long n = (long long)B * Ho * Wo * C8 * 4;
+    for (long long t = (long long)blockIdx.x * 256 + threadIdx.x; t < n; t += (long long)gridDim.x * 256) {
+        const int c = (int)(t % C8);
+        long long r = t / C8;                       // output pixel index over [B][2Ho][2Wo]
+        const int x = (int)(r % (2 * Wo)); r /= 2 * Wo;
+        const int y = (int)(r % (2 * Ho)); const int b = (int)(r / (2 * Ho));
+        const uint4* src = (y & 1) ? ((x & 1) ? s11 : s10) : ((x & 1) ? s01 : s00);
+        out[t] = src[(((long long)b * Ho + (y >> 1)) * Wo + (x >> 1)) * C8 + c];
+    }
+}
+
 }  // namespace
 
 extern "C" {
@@ -233,6 +248,19 @@ int dwg_adam_step(int64_t n, float* param, const float* grad, float* exp_avg, fl
     if (blocks > 2048) blocks = 2048;
     DWG_LAUNCH("adam_step", k_adam, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, (size_t)n, param, grad, exp_avg,
                exp_avg_sq, lr, beta1, beta2, eps, bc1, bc2_sqrt, grad_scale);
+    DWG_RETURN_IF_LAUNCH_FAILED();
+    return DWG_OK;
+}
+
+int dwg_interleave2x2(int32_t B, int32_t Ho, int32_t Wo, int32_t C, const void* s00, const void* s01, const void* s10, const void* s11,
+                      void* out, dwg_stream_t stream) {
+    if (B < 0 || Ho < 0 || Wo < 0 || C <= 0 || C % 8) return DWG_E_ARG;
+    const long long n = (long long)B * Ho * Wo * (C / 8) * 4;
+    if (n == 0) return DWG_OK;
+    if (!s00 || !s01 || !s10 || !s11 || !out) return DWG_E_ARG;
+    long long blocks = (n + 255) / 256; if (blocks > 8192) blocks = 8192;
+    DWG_LAUNCH("interleave2x2", k_interleave2x2, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, B, Ho, Wo, C / 8, (const uint4*)s00,
+               (const uint4*)s01, (const uint4*)s10, (const uint4*)s11, (uint4*)out);
     DWG_RETURN_IF_LAUNCH_FAILED();
     return DWG_OK;
 }

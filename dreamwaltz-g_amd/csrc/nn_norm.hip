@@ -119,7 +119,7 @@ __global__ __launch_bounds__(256) void k_gn_apply(int HW, int C, int G, int pix_
                                                   const float* __restrict__ bsums, const float* __restrict__ gamma,
                                                   const float* __restrict__ beta, int silu, float eps,
                                                   __bf16* __restrict__ out, const float* __restrict__ partials, int pchunks,
-                                                  float* __restrict__ sums_out) {
+                                                  float* __restrict__ sums_out, const __bf16* __restrict__ residual) {
     __shared__ float gstat[64 * 4];
     __shared__ float tot[128];
     const int b = blockIdx.y, tid = threadIdx.x;
@@ -166,6 +166,7 @@ __global__ __launch_bounds__(256) void k_gn_apply(int HW, int C, int G, int pix_
         }
         const __bf16* xp = x + ((size_t)b * HW + p0 + prow) * C + (size_t)cc * 8;
         const __bf16* dp = BWD ? dy + ((size_t)b * HW + p0 + prow) * C + (size_t)cc * 8 : nullptr;
+        const __bf16* rp = (BWD && residual) ? residual + ((size_t)b * HW + p0 + prow) * C + (size_t)cc * 8 : nullptr;
         __bf16* op = out + ((size_t)b * HW + p0 + prow) * C + (size_t)cc * 8;
         const size_t step = (size_t)rows * C;
         for (int p = p0 + prow; p < p1; p += rows) {
@@ -186,6 +187,12 @@ __global__ __launch_bounds__(256) void k_gn_apply(int HW, int C, int G, int pix_
                     if (silu) gq *= silu_grad(xh * ga[e] + be[e]);
                     gq *= ga[e];
                     o[e] = (__bf16)(rs[e] * (gq - m1[e] - xh * m2[e]));
+                }
+                if (rp) {                       // skip-connection gradient added here instead of a separate add pass
+                    bf16x8 rv = *reinterpret_cast<const bf16x8*>(rp);
+#pragma unroll
+                    for (int e = 0; e < 8; e++) o[e] = (__bf16)((float)o[e] + (float)rv[e]);
+                    rp += step;
                 }
                 dp += step;
             }
@@ -327,14 +334,14 @@ int dwg_groupnorm_forward(int32_t B, int32_t HW, int32_t C, int32_t G, const voi
     if (!fold) DWG_LAUNCH("gn_finalize", k_gn_finalize, dim3(B), dim3(1024), 0, stream, rchunks, G, (const float*)workspace, stats);
     DWG_LAUNCH("gn_apply", (k_gn_apply<false>), dim3(chunks, B), dim3(256), 0, stream, HW, C, G, ppb, (const __bf16*)x,
                (const __bf16*)nullptr, (const float*)stats, (const float*)nullptr, gamma, beta, fuse_silu, eps, (__bf16*)y,
-               fold ? (const float*)workspace : (const float*)nullptr, rchunks, stats);
+               fold ? (const float*)workspace : (const float*)nullptr, rchunks, stats, (const __bf16*)nullptr);
     DWG_RETURN_IF_LAUNCH_FAILED();
     return DWG_OK;
 }
 
 int dwg_groupnorm_backward(int32_t B, int32_t HW, int32_t C, int32_t G, const void* x, const void* dy, const float* stats,
                            const float* gamma, const float* beta, float eps, int32_t fuse_silu, void* dx, float* scratch,
-                           float* workspace, dwg_stream_t stream_) {
+                           float* workspace, const void* residual, dwg_stream_t stream_) {
     if (B <= 0 || HW <= 0 || !x || !dy || !stats || !gamma || !beta || !dx || !scratch || !workspace) return DWG_E_ARG;
     int ppb, chunks; size_t lds;
     int rc = gn_geometry(HW, C, G, &ppb, &chunks, &lds);
@@ -349,7 +356,7 @@ int dwg_groupnorm_backward(int32_t B, int32_t HW, int32_t C, int32_t G, const vo
     if (!fold) DWG_LAUNCH("gn_finalize", k_gn_finalize, dim3(B), dim3(1024), 0, stream, rchunks, G, (const float*)workspace, scratch);
     DWG_LAUNCH("gn_bwd_apply", (k_gn_apply<true>), dim3(chunks, B), dim3(256), 0, stream, HW, C, G, ppb, (const __bf16*)x,
                (const __bf16*)dy, stats, (const float*)scratch, gamma, beta, fuse_silu, eps, (__bf16*)dx,
-               fold ? (const float*)workspace : (const float*)nullptr, rchunks, scratch);
+               fold ? (const float*)workspace : (const float*)nullptr, rchunks, scratch, (const __bf16*)residual);
     DWG_RETURN_IF_LAUNCH_FAILED();
     return DWG_OK;
 }

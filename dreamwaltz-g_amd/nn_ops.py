@@ -30,7 +30,7 @@ def groupnorm(x, gamma, beta, groups=32, eps=1e-5, silu=False, out=None, stats=N
     return y, stats
 
 
-def groupnorm_backward(x, dy, stats, gamma, beta, groups=32, eps=1e-5, silu=False):
+def groupnorm_backward(x, dy, stats, gamma, beta, groups=32, eps=1e-5, silu=False, residual=None):
     _chk(x); _chk(dy)
     B, C = x.shape[0], x.shape[-1]
     HW = x.numel() // (B * C)
@@ -39,7 +39,7 @@ def groupnorm_backward(x, dy, stats, gamma, beta, groups=32, eps=1e-5, silu=Fals
     ws = torch.empty(_lib.lib().dwg_groupnorm_workspace_floats(B, groups), device=x.device, dtype=torch.float32)
     p = _lib.ptr
     _lib.check(_lib.lib().dwg_groupnorm_backward(B, HW, C, groups, p(x), p(dy), p(stats), p(gamma), p(beta), eps, int(silu), p(dx),
-                                                 p(scratch), p(ws), _st(x)), "dwg_groupnorm_backward")
+                                                 p(scratch), p(ws), p(residual), _st(x)), "dwg_groupnorm_backward")
     return dx
 
 

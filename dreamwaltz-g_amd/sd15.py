@@ -10,6 +10,7 @@ pre-allocated NHWC bf16 buffers (shapes never change during SDS) -- so a step is
 stream with no allocation, no shape logic and no host synchronisation; the plan is hipGraph-capturable as is.
 """
 import ctypes
+import os
 import math
 from collections import OrderedDict
 from dataclasses import dataclass
@@ -356,6 +357,24 @@ class Weights:
             self.cache[key] = wp.to(self.device, BF16).contiguous()
         return self.cache[key]
 
+    def conv_dgrad_s2(self, name, py, px):
+        """Tap subset of a 3x3 stride-2 convolution's weights that reaches the input pixels of parity (py, px), laid out as the
+        weights [Cin_x, KH', KW', Cout_y] of the stride-1 convolution over the incoming gradient that produces them:
+        dx[2i+py, 2j+px] = sum_{ty,tx} W[ty,tx] . dy[i - pad + ty, j - pad + tx];  even parity: taps ky = (2, 0) with pad 1,
+        odd parity: tap ky = 1 with pad 0 (the forward reads x[2i+ky, 2j+kx])."""
+        key = ("dgrad_s2", name, py, px)
+        if key not in self.cache:
+            w = self.sd[name + ".weight"].float()                        # [Cout_y, Cin_x, 3, 3]
+            kmap = {0: [2, 0], 1: [1]}
+            kys, kxs = kmap[py], kmap[px]
+            cy, cx = w.shape[0], w.shape[1]
+            wp = torch.zeros(_pad8(cx), len(kys), len(kxs), _pad8(cy))
+            for ty, ky in enumerate(kys):
+                for tx, kx in enumerate(kxs):
+                    wp[:cx, ty, tx, :cy] = w[:, :, ky, kx].t()
+            self.cache[key] = wp.to(self.device, BF16).contiguous()
+        return self.cache[key]
+
     def lin(self, *names):
         key = ("lin",) + names
         if key not in self.cache:
@@ -393,10 +412,11 @@ class Builder:
         self.L = _lib.lib()
 
     # -- contractions -------------------------------------------------------------------------------------------
-    def _conv_tag(self, tag, KH, Ho, stride, dil):
+    def _conv_tag(self, tag, KH, Ho, stride, dil, KW=None):
         if tag:
             return tag
-        base = "conv3x3" if KH == 3 else "conv1x1"
+        KW = KH if KW is None else KW
+        base = "conv3x3" if KH == 3 else ("conv1x1" if KH * KW == 1 else "conv%dx%d" % (KH, KW))
         return "%s%s_%s_r%d" % (base, "s2" if stride == 2 else ("T" if dil > 1 else ""), self.prefix, Ho)
 
     def conv(self, x, name, stride=1, pad=1, act=None, residual=None, upsample=1, bias_img=None, out_dtype=BF16, out_hw=None,
@@ -423,7 +443,7 @@ class Builder:
         if r_batch_bcast:   # residual is [1,Ho,Wo,Cout] broadcast over the batch: run as a batched GEMM, one image per batch
             d = gemm.gemm_raw(x, wt, y, Ho * Wo, Cout, K, (0, 1), (K, 1), Cout, bias=b, residual=residual, ldr=Cout, act=act,
                               batch=(B, 1), a_batch=(H * W * C, 0), c_batch=(Ho * Wo * Cout, 0), r_batch=(0, 0), conv=conv,
-                              conv_upsample=upsample, name=self._conv_tag(tag, KH, Ho, stride, in_dilation), run=False)
+                              conv_upsample=upsample, name=self._conv_tag(tag, KH, Ho, stride, in_dilation, KW), run=False)
         else:
             kw = {}
             if bias_img is not None:
@@ -432,7 +452,7 @@ class Builder:
                 kw = dict(bias=b)
             d = gemm.gemm_raw(x, wt, y, B * Ho * Wo, Cout, K, (0, 1), (K, 1), Cout, residual=residual,
                               ldr=Cout if residual is not None else 0, act=act, conv=conv, conv_upsample=upsample,
-                              name=self._conv_tag(tag, KH, Ho, stride, in_dilation), run=False, **kw)
+                              name=self._conv_tag(tag, KH, Ho, stride, in_dilation, KW), run=False, **kw)
         self.p.add_gemm(d)
         return y
 
@@ -468,7 +488,7 @@ class Builder:
                         pp(self.w.f32(name + ".bias")), eps, int(silu), pp(y), pp(stats), pp(self._gn_ws(B)))
         return (y, stats) if keep_stats else y
 
-    def groupnorm_bwd(self, x, dy, stats, name, eps, silu):
+    def groupnorm_bwd(self, x, dy, stats, name, eps, silu, residual=None):
         B, C = x.shape[0], x.shape[-1]
         HW = x.numel() // (B * C)
         dx = self.p.buf(*x.shape)
@@ -476,7 +496,7 @@ class Builder:
         pp = lambda t: ctypes.c_void_p(t.data_ptr())  # noqa: E731
         self.p.add_call(self.L.dwg_groupnorm_backward, B, HW, C, self.groups, pp(x), pp(dy), pp(stats),
                         pp(self.w.f32(name + ".weight")), pp(self.w.f32(name + ".bias")), eps, int(silu), pp(dx), pp(scratch),
-                        pp(self._gn_ws(B)))
+                        pp(self._gn_ws(B)), pp(residual) if residual is not None else None)
         return dx
 
     def layernorm(self, x, name):
@@ -517,6 +537,22 @@ class Builder:
         pp = lambda t: ctypes.c_void_p(t.data_ptr())  # noqa: E731
         self.p.add_call(self.L.dwg_add_bf16, a.numel(), pp(a), pp(b), pp(y))
         return y
+
+    def conv_dgrad_s2(self, dy, name):
+        """Input gradient of `F.pad(x, (0,1,0,1)); conv(3x3, stride 2)` (diffusers Downsample2D, padding 0): four stride-1
+        convolutions of dy, one per output parity class, then one interleave pass."""
+        B, Ho, Wo, _ = dy.shape
+        subs = []
+        for py in (0, 1):
+            for px in (0, 1):
+                wt = self.w.conv_dgrad_s2(name, py, px)
+                subs.append(self.conv(dy, None, weight=wt, bias=False, stride=1, pad_tl=(wt.shape[1] - 1, wt.shape[2] - 1),
+                                      out_hw=(Ho, Wo)))
+        C = subs[0].shape[-1]
+        out = self.p.buf(B, 2 * Ho, 2 * Wo, C)
+        pp = lambda t: ctypes.c_void_p(t.data_ptr())  # noqa: E731
+        self.p.add_call(self.L.dwg_interleave2x2, B, Ho, Wo, C, pp(subs[0]), pp(subs[1]), pp(subs[2]), pp(subs[3]), pp(out))
+        return out
 
     def cast_bf16(self, x):
         y = self.p.buf(*x.shape)
@@ -722,9 +758,9 @@ class VAEEncoderPlan:
                 dn2 = r.conv(dout, None, weight=w.conv(pre + ".conv2", True), bias=False)
                 dh1 = r.groupnorm_bwd(h1, dn2, s2, pre + ".norm2", 1e-6, True)
                 dn1 = r.conv(dh1, None, weight=w.conv(pre + ".conv1", True), bias=False)
+                if C == Cout:                       # identity skip: its gradient is added inside the GroupNorm backward
+                    return r.groupnorm_bwd(xin, dn1, s1, pre + ".norm1", 1e-6, True, residual=dout)
                 dx = r.groupnorm_bwd(xin, dn1, s1, pre + ".norm1", 1e-6, True)
-                if C == Cout:
-                    return r.add(dx, dout)
                 return r.conv(dout, None, weight=w.conv(pre + ".conv_shortcut", True), pad=0, bias=False, residual=dx)
             tape.append(back)
             return out
@@ -738,8 +774,11 @@ class VAEEncoderPlan:
                 name = "encoder.down_blocks.%d.downsamplers.0.conv" % i
                 Hin = h.shape[1]
                 h = f.conv(h, name, stride=2, pad=0, out_hw=(Hin // 2, Hin // 2))      # F.pad(0,1,0,1) + conv stride 2
-                tape.append(lambda d, name=name, Hin=Hin: r.conv(d, None, weight=w.conv(name, True), bias=False, stride=1,
-                                                                 pad_tl=(2, 2), out_hw=(Hin, Hin), in_dilation=2))
+                if os.environ.get("DWG_VAE_DILATED_DGRAD") == "1":     # zero-dilated input, all 9 taps: 4x the multiply-adds
+                    tape.append(lambda d, name=name, Hin=Hin: r.conv(d, None, weight=w.conv(name, True), bias=False, stride=1,
+                                                                     pad_tl=(2, 2), out_hw=(Hin, Hin), in_dilation=2))
+                else:
+                    tape.append(lambda d, name=name: r.conv_dgrad_s2(d, name))
         h = resnet_f(h, "encoder.mid_block.resnets.0")
         h = self._attention(f, r, w, h, "encoder.mid_block.attentions.0", tape)
         h = resnet_f(h, "encoder.mid_block.resnets.1")

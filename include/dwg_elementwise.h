@@ -36,6 +36,11 @@ int dwg_adam_step(int64_t n, float* param, const float* grad, float* exp_avg, fl
 int dwg_concat_channels(int64_t rows, int32_t Ca, int32_t Cb, const void* a, const void* b, void* out, dwg_stream_t stream);
 /* out = a + b on bf16 buffers (n % 8 == 0): gradient joins of the VAE-encoder backward. */
 int dwg_add_bf16(int64_t n, const void* a, const void* b, void* out, dwg_stream_t stream);
+/* out[b, 2i+py, 2j+px, :] = s<py><px>[b, i, j, :] -- NHWC bf16, C % 8 == 0.  Assembles the input gradient of a stride-2
+ * convolution from its four output-parity classes, each of which is an ordinary stride-1 convolution of the incoming gradient
+ * with a 2x2 / 2x1 / 1x2 / 1x1 subset of the taps (no zero-dilated input, a quarter of the multiply-adds). */
+int dwg_interleave2x2(int32_t B, int32_t Ho, int32_t Wo, int32_t C, const void* s00, const void* s01, const void* s10, const void* s11,
+                      void* out, dwg_stream_t stream);
 /* fp32 -> bf16 copy. */
 int dwg_cast_f32_to_bf16(int64_t n, const float* src, void* dst, dwg_stream_t stream);
 

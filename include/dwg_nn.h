@@ -21,10 +21,11 @@ int dwg_groupnorm_forward(int32_t B, int32_t HW, int32_t C, int32_t G, const voi
  * the statistics are bit-reproducible; one buffer may be shared by all calls on a stream). */
 size_t dwg_groupnorm_workspace_floats(int32_t B, int32_t G);
 
-/* dx of the above w.r.t. x (affine parameters are frozen: basic.py:347-352). dy/dx bf16 [B,HW,C]; scratch [B,G,2] fp32. */
+/* dx of the above w.r.t. x (affine parameters are frozen: basic.py:347-352). dy/dx bf16 [B,HW,C]; scratch [B,G,2] fp32.
+ * residual (bf16 [B,HW,C] or NULL) is added to dx: the skip-connection gradient of a ResNet block, saving a separate add pass. */
 int dwg_groupnorm_backward(int32_t B, int32_t HW, int32_t C, int32_t G, const void* x, const void* dy, const float* stats,
                            const float* gamma, const float* beta, float eps, int32_t fuse_silu, void* dx, float* scratch,
-                           float* workspace, dwg_stream_t stream);
+                           float* workspace, const void* residual, dwg_stream_t stream);
 
 /* LayerNorm over the last dimension: x/y [M, C] bf16, C % 8 == 0, C <= 2048. */
 int dwg_layernorm_forward(int32_t M, int32_t C, const void* x, const float* gamma, const float* beta, float eps, void* y,

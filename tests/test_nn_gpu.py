@@ -29,8 +29,13 @@ def test_groupnorm_forward_backward(B, H, C, silu, eps):
     assert _err(y.permute(0, 3, 1, 2), ref) < 1.2e-2
     dy = torch.randn(ref.shape, generator=g).bfloat16()
     (gx,) = torch.autograd.grad(ref, xd, dy.double())
-    dx = nn_ops.groupnorm_backward(xn, dy.permute(0, 2, 3, 1).contiguous().cuda(), stats, gamma.cuda(), beta.cuda(), 32, eps, silu)
+    dyn = dy.permute(0, 2, 3, 1).contiguous().cuda()
+    dx = nn_ops.groupnorm_backward(xn, dyn, stats, gamma.cuda(), beta.cuda(), 32, eps, silu)
     assert _err(dx.permute(0, 3, 1, 2), gx) < 1.5e-2
+    # fused skip-connection gradient: dx + residual in the same pass
+    res = torch.randn(xn.shape, generator=g).bfloat16().cuda()
+    dx2 = nn_ops.groupnorm_backward(xn, dyn, stats, gamma.cuda(), beta.cuda(), 32, eps, silu, residual=res)
+    assert _err(dx2.permute(0, 3, 1, 2), gx + res.permute(0, 3, 1, 2).cpu().double()) < 1.5e-2
 
 
 @pytest.mark.parametrize("M,C", [(8192, 320), (300, 1280), (5, 640)])
