@@ -20,7 +20,7 @@ namespace {
 
 #define MAXJ 64
 
-__global__ __launch_bounds__(64) void k_joint_chain(int J, const float* __restrict__ pose /*[J,3]*/,
+__global__ __launch_bounds__(256) void k_joint_chain(int J, const float* __restrict__ pose /*[J,3]*/,
                                                     const float* __restrict__ joints /*[J,3]*/,
                                                     const int* __restrict__ parents, const float* __restrict__ transl,
                                                     const float* __restrict__ jdirs /*[J,3,S]|null*/,
@@ -31,12 +31,18 @@ __global__ __launch_bounds__(64) void k_joint_chain(int J, const float* __restri
     __shared__ float sj[MAXJ][3];
     __shared__ int par[MAXJ];
     const int t = threadIdx.x;
-    if (t < J) {
-        // rest joints of the shaped template: J = J_template + (J_regressor . shapedirs) . shape
-        for (int k = 0; k < 3; k++) {
-            float v = joints[3 * t + k];
-            if (jdirs) { const float* d = jdirs + ((size_t)t * 3 + k) * S; for (int l = 0; l < S; l++) v += d[l] * shape[l]; }
-            sj[t][k] = v;
+    {
+        // rest joints of the shaped template: J = J_template + (J_regressor . shapedirs) . shape -- 3J dot products of length S
+        // (400): one wave per dot product, lane-strided coalesced loads + a DPP reduction (the serial per-joint loop cost 130 us)
+        const int wave = t >> 6, lane = t & 63;
+        for (int idx = wave; idx < 3 * J; idx += 4) {
+            float v = 0.f;
+            if (jdirs) {
+                const float* d = jdirs + (size_t)idx * S;
+                for (int l = lane; l < S; l += 64) v += d[l] * shape[l];
+                v = dwg_wave_sum_to_lane63(v);
+            }
+            if (lane == 63) sj[idx / 3][idx % 3] = joints[idx] + v;
         }
     }
     __syncthreads();
@@ -217,7 +223,7 @@ int dwg_lbs_joint_chain(int32_t J, const float* pose, const float* joints, const
                         float* rot_mats_out, dwg_stream_t stream) {
     if (J <= 0 || J > MAXJ || !pose || !joints || !parents || !A_out) return DWG_E_ARG;
     if (joint_shape_dirs && (!shape_coeffs || n_shape <= 0)) return DWG_E_ARG;
-    DWG_LAUNCH("lbs_joint_chain", k_joint_chain, dim3(1), dim3(64), 0, (hipStream_t)stream, J, pose, joints, parents, transl,
+    DWG_LAUNCH("lbs_joint_chain", k_joint_chain, dim3(1), dim3(256), 0, (hipStream_t)stream, J, pose, joints, parents, transl,
                joint_shape_dirs, shape_coeffs, n_shape, A_out, rot_mats_out);
     DWG_RETURN_IF_LAUNCH_FAILED();
     return DWG_OK;
