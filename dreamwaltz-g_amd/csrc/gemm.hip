@@ -1013,11 +1013,14 @@ static int tile_bn(const dwg_gemm_desc* d) {
 
 // split-K factor for shapes that cannot fill 256 CUs with 128 x BN output tiles (small-M layers: 8x8 / 16x16 latents)
 static int auto_splitk(int M, int N, int K, int bn, int bk) {
+    static const int target = getenv("DWG_SPLITK_TARGET") ? atoi(getenv("DWG_SPLITK_TARGET")) : 512;
+    static const int nosplit = getenv("DWG_SPLITK_NOSPLIT") ? atoi(getenv("DWG_SPLITK_NOSPLIT")) : 384;
+    static const int minsteps = getenv("DWG_SPLITK_MINSTEPS") ? atoi(getenv("DWG_SPLITK_MINSTEPS")) : 8;
     long long blocks = (long long)((M + 127) / 128) * ((N + bn - 1) / bn);
-    if (blocks >= 384 || K < 16 * bk) return 1;
+    if (blocks >= nosplit || K < 2 * minsteps * bk) return 1;
     if (2.0 * M * N * K < 4.0e8) return 1;      // tiny products are launch-bound: a second (reduce) launch costs more than it buys
-    long long sk = 512 / blocks;                // aim at ~2 workgroups per CU
-    long long kmax = K / (8 * bk);              // keep >= 8 k-steps per slice
+    long long sk = target / blocks;             // aim at ~2 workgroups per CU
+    long long kmax = K / (minsteps * bk);       // keep >= 8 k-steps per slice
     if (sk > kmax) sk = kmax;
     if (sk > 16) sk = 16;
     return sk >= 2 ? (int)sk : 1;

@@ -1,0 +1,90 @@
+"""CPU tests of the host-side logic above the C-ABI: weight re-layouts the kernels rely on, mesh adjacency, optimizer
+bookkeeping.  No GPU, no HIP launches (the oracle here is plain torch on CPU)."""
+import torch
+import torch.nn.functional as F
+
+import dwg_import  # noqa: F401
+from dreamwaltz_g_amd import meshbind as mb
+from dreamwaltz_g_amd import sd15
+from dreamwaltz_g_amd.sds_step import FlatAdam, get_expon_lr_func
+from oracle import animate as oa
+
+
+def test_stride2_dgrad_parity_class_weights_reproduce_the_input_gradient():
+    """Weights.conv_dgrad_s2: the four tap subsets, applied as stride-1 convolutions of dy with pad (KH-1, KW-1) on the top /
+    left and interleaved by output parity, equal the autograd input gradient of F.pad(x,(0,1,0,1)) + conv3x3 stride 2
+    (diffusers Downsample2D with padding 0, as used by the VAE encoder)."""
+    g = torch.Generator().manual_seed(0)
+    B, Cx, Cy, H = 2, 16, 24, 10
+    x = torch.randn(B, Cx, H, H, generator=g, dtype=torch.float64).requires_grad_(True)
+    w = torch.randn(Cy, Cx, 3, 3, generator=g, dtype=torch.float64)
+    y = F.conv2d(F.pad(x, (0, 1, 0, 1)), w, stride=2)
+    dy = torch.randn(y.shape, generator=g, dtype=torch.float64)
+    (gx,) = torch.autograd.grad(y, x, dy)
+    W = sd15.Weights({"c.weight": w.float()}, torch.device("cpu"))
+    out = torch.zeros_like(gx)
+    for py in (0, 1):
+        for px in (0, 1):
+            ws = W.conv_dgrad_s2("c", py, px).double()                   # [Cx(pad 8), KH', KW', Cy(pad 8)]
+            assert ws.shape[0] == Cx and ws.shape[3] == Cy and ws.shape[1] == 2 - py and ws.shape[2] == 2 - px
+            wt = ws.permute(0, 3, 1, 2)                                  # conv2d layout [out=Cx, in=Cy, KH', KW']
+            d = F.pad(dy, (ws.shape[2] - 1, 0, ws.shape[1] - 1, 0))
+            out[:, :, py::2, px::2] = F.conv2d(d, wt)
+    # bf16 storage of the weights: relative error ~ 2^-9 per tap
+    assert (out - gx).abs().max() / gx.abs().max() < 2e-2
+
+
+def test_geglu_weight_interleave():
+    """Weights.lin_geglu: rows come out in blocks of 64 = [32 hidden | the matching 32 gate] rows."""
+    g = torch.Generator().manual_seed(1)
+    C = 64
+    w = torch.randn(8 * C, C, generator=g); b = torch.randn(8 * C, generator=g)
+    W = sd15.Weights({"p.weight": w, "p.bias": b}, torch.device("cpu"))
+    wi, bi = W.lin_geglu("p")
+    Fh = 4 * C
+    for q in range(Fh // 32):
+        assert torch.equal(bi[64 * q:64 * q + 32], b[32 * q:32 * q + 32])
+        assert torch.equal(bi[64 * q + 32:64 * q + 64], b[Fh + 32 * q:Fh + 32 * q + 32])
+        assert torch.equal(wi[64 * q + 32].float(), w[Fh + 32 * q].bfloat16().float())
+    # the fused epilogue computes hidden * gelu(gate) for output column 32 q + i from rows (64 q + i, 64 q + 32 + i)
+    x = torch.randn(5, C, generator=g)
+    ref = (x @ w.bfloat16().float().t() + b)                              # same bf16-rounded weights: isolates the permutation
+    ref = ref[:, :Fh] * F.gelu(ref[:, Fh:])
+    y = x @ wi.float().t() + bi
+    y = y.view(5, -1, 2, 32)
+    got = (y[:, :, 0] * F.gelu(y[:, :, 1])).reshape(5, Fh)
+    assert (got - ref).abs().max() < 1e-4
+
+
+def test_vertex_face_csr_matches_index_add_normals():
+    g = torch.Generator().manual_seed(2)
+    V = 60
+    tri = torch.randint(0, V, (150, 3), generator=g)
+    tri = tri[(tri[:, 0] != tri[:, 1]) & (tri[:, 1] != tri[:, 2]) & (tri[:, 0] != tri[:, 2])]
+    off, faces = mb.build_vertex_face_csr(tri, V)
+    assert off[0] == 0 and off[-1] == 3 * tri.shape[0] and off.dtype == torch.int32
+    verts = torch.randn(V, 3, generator=g, dtype=torch.float64)
+    vn_ref, fn = oa.compute_normal(verts, tri)
+    acc = torch.zeros(V, 3, dtype=torch.float64)
+    for v in range(V):
+        for e in range(int(off[v]), int(off[v + 1])):
+            acc[v] += fn[int(faces[e])]
+    deflt = torch.tensor([0.0, 0.0, 1.0], dtype=torch.float64)
+    acc = torch.where((acc * acc).sum(-1, keepdim=True) > 1e-20, acc, deflt)
+    assert (oa.safe_normalize(acc) - vn_ref).abs().max() < 1e-12
+
+
+def test_flat_adam_learning_rate_schedule_bookkeeping():
+    """GaussianOptimizer.update_learning_rate semantics (gaussian_optimizer.py:130-141) on the flat-buffer optimizer."""
+    a = torch.nn.Parameter(torch.zeros(10, 3)); b = torch.nn.Parameter(torch.zeros(10, 3)); c = torch.nn.Parameter(torch.zeros(7))
+    sched = get_expon_lr_func(lr_init=1.6e-4, lr_final=1.6e-6, lr_delay_mult=0.01, max_steps=20000)
+    opt = FlatAdam([dict(params=[a], lr=0.0, name="positions", schedule=sched), dict(params=[b], lr=0.0, name="scales", base_lr=2.5e-3),
+                    dict(params=[c], lr=1e-3, name="quaternions")], torch.device("cpu"))
+    lr = opt.update_learning_rate(spatial_scale=1.04, iteration=0)
+    assert abs(opt.groups[0]["lr"] - 1.6e-4 * 1.04) < 1e-12 and abs(opt.groups[1]["lr"] - 2.5e-3 * 1.04) < 1e-12
+    assert opt.groups[2]["lr"] == 1e-3 and lr == 2.5e-3                  # the reference returns the last group rate it touched
+    opt.update_learning_rate(spatial_scale=1.04, iteration=20000)
+    assert abs(opt.groups[0]["lr"] - 1.6e-6 * 1.04) < 1e-15
+    # parameters and gradients are views of the flat buffers (16-byte aligned slices)
+    assert a.data.data_ptr() == opt.flat.data_ptr() and a.grad.data_ptr() == opt.grad.data_ptr()
+    assert (b.data.data_ptr() - opt.flat.data_ptr()) % 16 == 0 and (c.data.data_ptr() - opt.flat.data_ptr()) % 16 == 0
