@@ -71,6 +71,10 @@ SIGNATURES = {
     "dwg_add_bf16": (ctypes.c_int, [_i64, _vp, _vp, _vp, _vp]),
     "dwg_interleave2x2": (ctypes.c_int, [_i32, _i32, _i32, _i32, _vp, _vp, _vp, _vp, _vp, _vp]),
     "dwg_cast_f32_to_bf16": (ctypes.c_int, [_i64, _vp, _vp, _vp]),
+    # include/dwg_gaussian.h
+    "dwg_gaussian_assemble_forward": (ctypes.c_int, [_i32, _i32, _vp, _vp, _f32, _vp, _vp, _f32, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
+    "dwg_gaussian_assemble_backward": (ctypes.c_int, [_i32, _i32, _f32, _vp, _f32, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp,
+                                                       _vp, _vp, _vp, _vp]),
     # include/dwg_meshbind.h
     "dwg_mesh_vertex_normals": (ctypes.c_int, [_i32, _i32, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
     "dwg_meshbind_forward": (ctypes.c_int, [_i32, _i32, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),

@@ -15,6 +15,7 @@ import torch
 import torch.nn as nn
 import torch.nn.functional as F
 
+from . import assemble as asm_ops
 from . import lbs as lbs_ops
 from . import meshbind as mb_ops
 from .gridencoder import GridEncoder
@@ -285,25 +286,18 @@ class DreamWaltzG(nn.Module):
         all_cpos = torch.cat([canonical_positions] + [mp[0] for mp in mesh_parts], dim=0) if mesh_parts else canonical_positions
         enc_all = self.nerf_encoder(all_cpos, bound=self.nerf_bound)
         oc_all = self.nerf_opacity_and_color_net(enc_all)                      # static_mlp_forward (avatar.py:1283-1290), all rows
-        sig = torch.sigmoid(oc_all)
         enc = enc_all[:N]
-        colors, opacities = sig[:N, 1:], sig[:N, :1]
         body_pose = smpl_observed_inputs.get('body_pose')
         if body_pose is None:
             body_pose = torch.zeros(1, 63, device=positions.device)
         offsets, mlp_scales, _mlp_quats = self.nerf_scale_and_quaternion_net(enc, body_pose)
-        # non_rigid_transform (avatar.py:1464-1498) with the defaults
-        pos = positions + offsets * self.init_offset
-        scales = torch.exp(self._scales) + mlp_scales * self.init_scale
-        quats = F.normalize(self._quaternions, dim=-1)
+        # non_rigid_transform (avatar.py:1464-1498, default flags) + the sigmoid / exp / normalize activations: one HIP launch
+        pos, scales, quats, col_all, op_all = asm_ops.assemble(positions, offsets, self._scales, mlp_scales, self._quaternions, oc_all,
+                                                               self.init_offset, self.init_scale)
         pos, quats = self.lbs_transform(pos, otr, quats)
-        gaussians = GaussianOutput(positions=pos, opacities=opacities, colors=colors, quaternions=quats, scales=scales)
-        parts = [gaussians]
-        off = N
-        for (cpos, pos_m, sc_m, q_m) in mesh_parts:
-            M = cpos.shape[0]
-            col_m = sig[off:off + M, 1:]
-            op_m = torch.ones_like(sig[off:off + M, :1])                       # fix_opacities=True (avatar.py:1328-1355)
-            off += M
-            parts.append(GaussianOutput(positions=pos_m, opacities=op_m, colors=col_m, quaternions=q_m, scales=sc_m))
-        return merge_gaussians(*parts)
+        if not mesh_parts:
+            return GaussianOutput(positions=pos, opacities=op_all, colors=col_all, quaternions=quats, scales=scales)
+        # merge_gaussians (gaussian_utils.py:56-68): colours / opacities already come out in the merged row order
+        return GaussianOutput(positions=torch.cat([pos] + [mp[1] for mp in mesh_parts], dim=0), opacities=op_all, colors=col_all,
+                              quaternions=torch.cat([quats] + [mp[3] for mp in mesh_parts], dim=0),
+                              scales=torch.cat([scales] + [mp[2] for mp in mesh_parts], dim=0))
