@@ -238,57 +238,8 @@ __device__ __forceinline__ void epilogue_store(const GemmP& p, float v, int row,
     else reinterpret_cast<float*>(p.C)[ci] = v;
 }
 
-template <int TM, int TN>
-__device__ __forceinline__ void tile_epilogue(const GemmP& p, f32x16 (&acc)[TM][TN], int m0, int n0, int wm, int wn, int lane,
-                                              int ks_id, int z1, int z2) {
-    const long long coff = z1 * p.bC1 + z2 * p.bC2, roff = z1 * p.bR1 + z2 * p.bR2;
-    if (p.act == 6) {
-        // GEGLU pair epilogue (diffusers GEGLU: hidden, gate = proj(x).chunk(2); hidden * gelu(gate)).  The projection rows are
-        // pre-interleaved in blocks of 32 so that accumulator tile j=0 holds `hidden` and j=1 the matching `gate` columns:
-        // the product is formed in registers and only the half-width result is stored (no [M, 8C] round trip).
-        const int colp = n0 + wn * 64 + (lane & 31);                 // column of the hidden half inside the interleaved layout
-        if (colp + 32 < p.N + 0 && colp < p.N) {
-            const int ocol = (n0 + wn * 64) / 2 + (lane & 31);
-            const float* bias = reinterpret_cast<const float*>(p.bias);
-            const float ba = bias ? bias[colp] : 0.f, bg = bias ? bias[colp + 32] : 0.f;
-#pragma unroll
-            for (int i = 0; i < TM; i++)
-#pragma unroll
-                for (int r = 0; r < 16; r++) {
-                    const int row = m0 + (wm * TM + i) * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
-                    if (row >= p.M) continue;
-                    const float a = acc[i][0][r] * p.alpha + ba, g = acc[i][1][r] * p.alpha + bg;
-                    const float v = a * 0.5f * g * (1.f + erff(g * 0.70710678118654752f));
-                    const long long ci = coff + (long long)row * p.ldc + ocol;
-                    if (p.out_bf16) reinterpret_cast<__bf16*>(p.C)[ci] = f2bf(v);
-                    else reinterpret_cast<float*>(p.C)[ci] = v;
-                }
-        }
-        return;
-    }
-#pragma unroll
-    for (int i = 0; i < TM; i++)
-#pragma unroll
-        for (int j = 0; j < TN; j++) {
-            const int col = n0 + wn * 64 + j * 32 + (lane & 31);
-            if (col >= p.N) continue;
-#pragma unroll
-            for (int r = 0; r < 16; r++) {
-                const int row = m0 + (wm * TM + i) * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
-                if (row >= p.M) continue;
-                float v = acc[i][j][r] * p.alpha;
-                if (p.splitk > 1) {
-                    if (p.ws) p.ws[((long long)ks_id * p.M + row) * p.N + col] = v;          // slab, reduced by k_splitk_epilogue
-                    else atomicAdd(reinterpret_cast<float*>(p.C) + coff + (long long)row * p.ldc + col, v);
-                    continue;
-                }
-                epilogue_store(p, v, row, col, coff, roff);
-            }
-        }
-}
-
 // ---------------------------------------------------------------------------------------------------------------------
-// Transposed accumulator orientation (direct-to-LDS kernels): the MFMA is issued as D' = Btile . Atile^T, so that a lane owns
+// Transposed accumulator orientation (all MFMA kernels of this file): the MFMA is issued as D' = Btile . Atile^T, so that a lane owns
 // ONE output row (lane & 31) and, per group of four accumulator registers, FOUR CONSECUTIVE output columns
 // (8*(r>>2) + 4*(lane>>5) + (r&3)).  The epilogue then moves 8-byte bf16x4 / 16-byte float4 pieces (bias, residual, store,
 // split-K slab) instead of one 2-byte element per instruction: 4x fewer epilogue instructions and memory requests, which is
@@ -356,7 +307,9 @@ __device__ __forceinline__ void tile_epilogue_t(const GemmP& p, f32x16 (&acc)[TM
     const bool vec_ok = epilogue_vec_ok(p, coff, roff);
     const int lrow = lane & 31, lhalf = (lane >> 5) * 4;
     if (p.act == 6) {
-        // GEGLU pair (see tile_epilogue): tile j=0 holds `hidden`, j=1 the matching `gate` columns; N % 64 == 0
+        // GEGLU pair epilogue (diffusers GEGLU: hidden, gate = proj(x).chunk(2); hidden * gelu(gate)).  The projection rows are
+        // pre-interleaved in blocks of 32 so that accumulator tile j=0 holds `hidden` and j=1 the matching `gate` columns: the
+        // product is formed in registers and only the half-width result is stored (no [M, 8C] round trip).  N % 64 == 0.
         const float* bias = reinterpret_cast<const float*>(p.bias);
 #pragma unroll
         for (int i = 0; i < TM; i++) {
@@ -510,11 +463,11 @@ __global__ __launch_bounds__(256) void k_gemm(GemmP p) {
 #pragma unroll
         for (int i = 0; i < TM; i++)
 #pragma unroll
-            for (int j = 0; j < TN; j++) mma_tile<T>(a + i * 32 * LDT, b + j * 32 * LDT, lane, acc[i][j]);
+            for (int j = 0; j < TN; j++) mma_tile<T>(b + j * 32 * LDT, a + i * 32 * LDT, lane, acc[i][j]);   // transposed: see tile_epilogue_t
         if (kt + 1 < nk) { la.store(sA + (cur ^ 1) * BM * LDT); lb.store(sB + (cur ^ 1) * BN * LDT); }
         __syncthreads();
     }
-    tile_epilogue<TM, TN>(p, acc, m0, n0, wm, wn, lane, ks_id, z1, z2);
+    tile_epilogue_t<TM, TN>(p, acc, m0, n0, wm, wn, lane, ks_id, z1, z2);
 }
 
 // ---------------------------------------------------------------------------------------------------------------------
