@@ -46,7 +46,7 @@ def cpu_baseline(args, workload):
     from oracle import animate as oa
     from tests import raster_cases as rc
     torch.set_num_threads(1)
-    G = min(args.gaussians, 40000)
+    G = min(args.gaussians, 100000)      # the full headline size (about 8 s on the GPU box host, 20 s on a slow core)
     body = oa.SyntheticBody(seed=0)
     nets = oa.init_avatar_networks(seed=0)
     g = torch.Generator().manual_seed(1)
