@@ -72,44 +72,53 @@ __global__ __launch_bounds__(256) void k_adam(size_t n, float* __restrict__ p, c
 }
 
 // dW[n][k] = sum_m dz[m][n] * x[m][k]  for the per-Gaussian MLPs (N, K <= 64, M ~ 1e5): every workgroup reduces a slab of
-// rows into a 64x64 register tile (4x4 per thread) from LDS-staged 64-row chunks and writes ONE partial tile; a second
+// rows into a 64x64 tile (exact-f32 MFMA, one 32x32 quadrant per wave) from LDS-staged 64-row chunks and writes ONE partial tile; a second
 // pass sums the partial tiles in a fixed order (deterministic, no atomics).
 __global__ __launch_bounds__(256) void k_mlp_wgrad_partial(int M, int N, int K, const float* __restrict__ dz, int lddz,
                                                            const float* __restrict__ x, int ldx, int rows_per_block,
                                                            float* __restrict__ partial /*[blocks][64][64]*/) {
     __shared__ __attribute__((aligned(16))) float sdz[64][68];
     __shared__ __attribute__((aligned(16))) float sx[64][68];
-    const int tid = threadIdx.x, tn = (tid >> 4) * 4, tk = (tid & 15) * 4;
+    // exact-f32 MFMA (v_mfma_f32_32x32x2_f32): the 64x64 tile is 2x2 MFMA tiles, one per wave; the contraction runs over the
+    // rows of the chunk, two rows per instruction.  A = dz^T (lane: n = l & 31, row parity = l >> 5), B = x (lane: k = l & 31).
+    typedef __attribute__((ext_vector_type(16))) float f32x16_t;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int tn = (wave >> 1) * 32, tk = (wave & 1) * 32;
     const int r0 = blockIdx.x * rows_per_block, r1 = min(M, r0 + rows_per_block);
-    float acc[4][4];
+    f32x16_t acc;
 #pragma unroll
-    for (int a = 0; a < 4; a++)
+    for (int r = 0; r < 16; r++) acc[r] = 0.f;
+    // chunk staging is register-prefetched one chunk ahead (thread t owns column t & 63 of rows (t >> 6) + 4 i): the global
+    // loads of chunk c+1 are in flight while chunk c is multiplied
+    const int sc = tid & 63, sr = tid >> 6;
+    float rdz[16], rx[16];
+    auto fetch = [&](int base) {
 #pragma unroll
-        for (int b = 0; b < 4; b++) acc[a][b] = 0.f;
+        for (int i = 0; i < 16; i++) {
+            const int m = base + sr + 4 * i;
+            rdz[i] = (m < r1 && sc < N) ? dz[(size_t)m * lddz + sc] : 0.f;
+            rx[i] = (m < r1 && sc < K) ? x[(size_t)m * ldx + sc] : 0.f;
+        }
+    };
+    if (r0 < r1) fetch(r0);
     for (int base = r0; base < r1; base += 64) {
         __syncthreads();
-        for (int e = tid; e < 64 * 64; e += 256) {
-            int r = e >> 6, c = e & 63, m = base + r;
-            sdz[r][c] = (m < r1 && c < N) ? dz[(size_t)m * lddz + c] : 0.f;
-            sx[r][c] = (m < r1 && c < K) ? x[(size_t)m * ldx + c] : 0.f;
-        }
+#pragma unroll
+        for (int i = 0; i < 16; i++) { sdz[sr + 4 * i][sc] = rdz[i]; sx[sr + 4 * i][sc] = rx[i]; }
         __syncthreads();
+        if (base + 64 < r1) fetch(base + 64);
+        const float* pa = &sdz[lane >> 5][tn + (lane & 31)];
+        const float* pb = &sx[lane >> 5][tk + (lane & 31)];
 #pragma unroll 8
-        for (int r = 0; r < 64; r++) {
-            const float4 av = *reinterpret_cast<const float4*>(&sdz[r][tn]);
-            const float4 bv = *reinterpret_cast<const float4*>(&sx[r][tk]);
-            const float a[4] = {av.x, av.y, av.z, av.w}, b[4] = {bv.x, bv.y, bv.z, bv.w};
-#pragma unroll
-            for (int q = 0; q < 4; q++)
-#pragma unroll
-                for (int u = 0; u < 4; u++) acc[q][u] += a[q] * b[u];
-        }
+        for (int st = 0; st < 32; st++)
+            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(pa[st * 2 * 68], pb[st * 2 * 68], acc, 0, 0, 0);
     }
     float* dst = partial + (size_t)blockIdx.x * 4096;
 #pragma unroll
-    for (int q = 0; q < 4; q++)
-#pragma unroll
-        for (int u = 0; u < 4; u++) dst[(tn + q) * 64 + tk + u] = acc[q][u];
+    for (int r = 0; r < 16; r++) {
+        const int n = tn + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+        dst[n * 64 + tk + (lane & 31)] = acc[r];
+    }
 }
 
 __global__ __launch_bounds__(256) void k_mlp_wgrad_final(int blocks, int N, int K, const float* __restrict__ partial,
