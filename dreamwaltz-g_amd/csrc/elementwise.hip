@@ -237,7 +237,7 @@ int dwg_act_backward_colsum(int32_t M, int32_t N, int32_t act, const float* dy, 
                             dwg_stream_t stream) {
     if (M < 0 || N <= 0 || N > 256 || !dy) return DWG_E_ARG;
     if (M == 0) return DWG_OK;
-    int rows_per_block = 512;
+    int rows_per_block = 128;      // ~800 workgroups at 1e5 rows: the pass is a pure stream, it needs the whole chip
     DWG_LAUNCH("act_bwd_colsum", k_act_bwd_colsum, dim3(dwg_cdiv(M, rows_per_block)), dim3(256), 0, (hipStream_t)stream, M, N,
                act, dy, y, dz, colsum, rows_per_block);
     DWG_RETURN_IF_LAUNCH_FAILED();
