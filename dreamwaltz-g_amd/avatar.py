@@ -248,6 +248,35 @@ class DreamWaltzG(nn.Module):
         self._canonical_cache = None
         self._canonical_vertices = {}
 
+    # -- checkpoints ------------------------------------------------------------------------------------------------
+    def load_reference_state_dict(self, state_dict, prefix="avatar."):
+        """Loads the avatar part of a reference checkpoint's `model` entry (trainer.py:238-259 saves {'train_step',
+        'checkpoints', 'model': Scene.state_dict()}; the avatar sits under `avatar.` and, duplicated, `avatars.0.`).
+        Per-Gaussian parameters are first resized to the checkpoint's Gaussian count exactly like
+        GaussianModel.reset_by_state_dict (gaussian_model.py:58-85, avatar.py:1254-1281); parameter names match the reference,
+        so everything else is a plain copy.  Returns (loaded keys, checkpoint keys with no counterpart here, our keys the
+        checkpoint does not carry).  Call it BEFORE the parameters are re-homed into a FlatAdam buffer when the count changes."""
+        sd = {k[len(prefix):]: v for k, v in state_dict.items() if k.startswith(prefix)}
+        if "_positions" in sd:
+            n = sd["_positions"].shape[0]
+            for name in ("_positions", "_scales", "_quaternions", "_lbs_weights"):
+                cur = getattr(self, name, None)
+                if cur is not None and name in sd and cur.shape[0] != n:
+                    new = torch.empty(n, *cur.shape[1:], dtype=cur.dtype, device=cur.device)
+                    setattr(self, name, nn.Parameter(new, requires_grad=cur.requires_grad))
+        own = self.state_dict()
+        loaded, unknown = [], []
+        for k, v in sd.items():
+            if k in own and tuple(own[k].shape) == tuple(v.shape):
+                own[k].copy_(v.to(own[k].dtype))
+                loaded.append(k)
+            else:
+                unknown.append(k)
+        missing = [k for k in own if k not in sd]
+        self._canonical_cache = None
+        self._canonical_vertices = {}
+        return loaded, unknown, missing
+
     # -- avatar.py:913-918
     def get_lbs_weights(self):
         return self._lbs_weights

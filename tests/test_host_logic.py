@@ -88,3 +88,38 @@ def test_flat_adam_learning_rate_schedule_bookkeeping():
     # parameters and gradients are views of the flat buffers (16-byte aligned slices)
     assert a.data.data_ptr() == opt.flat.data_ptr() and a.grad.data_ptr() == opt.grad.data_ptr()
     assert (b.data.data_ptr() - opt.flat.data_ptr()) % 16 == 0 and (c.data.data_ptr() - opt.flat.data_ptr()) % 16 == 0
+
+
+def test_reference_checkpoint_keys_load_into_the_native_avatar():
+    """A reference-shaped `model` state dict (Scene.state_dict(): avatar under `avatar.` and `avatars.0.`, trainer.py:238-259)
+    with a DIFFERENT Gaussian count loads into dreamwaltz_g_amd.avatar.DreamWaltzG: per-Gaussian parameters are resized
+    (gaussian_model.py:58-85) and every network / mesh-binding tensor is copied by name."""
+    from dreamwaltz_g_amd import avatar as av, synth
+    g = torch.Generator().manual_seed(3)
+    body = synth.synthetic_body(seed=0)
+    glbs = av.GeneralLinearBlendSkinning(body)
+    N0, N1 = 50, 80
+    mk = lambda n: dict(p=torch.randn(n, 3, generator=g) * 0.3, s=torch.rand(n, 3, generator=g) * 0.01 + 0.002,  # noqa: E731
+                        q=torch.randn(n, 4, generator=g), w=torch.softmax(torch.randn(n, 55, generator=g), -1))
+    a0 = mk(N0)
+    vi = torch.arange(30); tri = torch.tensor([[0, 1, 2], [3, 4, 5], [6, 7, 8], [9, 10, 11]])
+    mesh = {"hands": av.MeshBindingGaussianModel(body["v_template"][vi], tri, vi)}
+    cnl = dict(body_pose=torch.zeros(1, 63), global_orient=torch.zeros(1, 3), left_hand_pose=torch.zeros(1, 45),
+               right_hand_pose=torch.zeros(1, 45), expression=torch.zeros(1, 100))
+    a = av.DreamWaltzG(glbs, a0["p"], a0["s"], a0["q"], a0["w"], cnl, mesh)
+    # reference-shaped checkpoint: same names, other Gaussian count, plus keys the native module has no use for
+    src = {k: torch.randn(v.shape, generator=g) for k, v in a.state_dict().items() if v.is_floating_point()}
+    b1 = mk(N1)
+    src.update({"_positions": b1["p"], "_scales": torch.log(b1["s"]), "_quaternions": b1["q"], "_lbs_weights": b1["w"]})
+    ckpt = {"avatar." + k: v for k, v in src.items()}
+    ckpt.update({"avatars.0." + k: v for k, v in src.items()})
+    ckpt["avatar.nearest_triangles_buffer"] = torch.zeros(N1, dtype=torch.long)
+    ckpt["background.some_weight"] = torch.zeros(3)
+    loaded, unknown, missing = a.load_reference_state_dict(ckpt)
+    assert a._positions.shape == (N1, 3) and a._lbs_weights.shape == (N1, 55) and not a._lbs_weights.requires_grad
+    assert torch.equal(a._positions.data, b1["p"]) and torch.equal(a._scales.data, torch.log(b1["s"]))
+    assert torch.equal(a.nerf_encoder.embeddings.data, src["nerf_encoder.embeddings"])
+    assert torch.equal(a.mesh_binding_gaussians["hands"]._bary_coords.data, src["mesh_binding_gaussians.hands._bary_coords"])
+    assert unknown == ["nearest_triangles_buffer"]
+    assert "nerf_opacity_and_color_net.net.0.weight" in loaded and "nerf_scale_and_quaternion_net.gaussian_warp.weight" in loaded
+    assert all(not k.startswith("_") for k in missing)      # only (integer) buffers of the native module may be absent
