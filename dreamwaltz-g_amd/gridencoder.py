@@ -39,6 +39,15 @@ def grid_encode_forward(inputs, embeddings, offsets, outputs, B, D, C, L, S, H, 
 
 
 _host_offsets = {}
+_host_arrays = {}
+
+
+def _host_array(values):
+    """ctypes int32 array for a tuple of level offsets (cached by CONTENT)."""
+    if values not in _host_arrays:
+        _host_arrays[values] = (ctypes.c_int32 * len(values))(*values)
+    return _host_arrays[values]
+
 
 
 def _host_offsets_of(offsets):
@@ -62,10 +71,10 @@ def xcd_scratch_for(embeddings):
 
 
 def grid_encode_backward(grad, inputs, embeddings, offsets, grad_embeddings, B, D, C, L, S, H, dy_dx, grad_inputs,
-                         gridtype, align_corners, interp, grad_layout=0, xcd_scratch=None):
+                         gridtype, align_corners, interp, grad_layout=0, xcd_scratch=None, host_offsets=None):
     _need_cuda(inputs)
     p = _lib.ptr
-    ho = _host_offsets_of(offsets)
+    ho = host_offsets if host_offsets is not None else _host_offsets_of(offsets)
     if xcd_scratch is not None:
         _lib.check(_lib.lib().dwg_grid_encode_backward_xcd(p(grad), p(inputs), p(embeddings), p(offsets), p(grad_embeddings), B, D,
                                                            C, L, ctypes.c_float(S), H, p(dy_dx), p(grad_inputs), gridtype,
@@ -83,7 +92,9 @@ def grid_encode_backward(grad, inputs, embeddings, offsets, grad_embeddings, B, 
 class _grid_encode(Function):
     @staticmethod
     def forward(ctx, inputs, embeddings, offsets, per_level_scale, base_resolution, calc_grad_inputs=False, gridtype=0,
-                align_corners=False, interpolation=0):
+                align_corners=False, interpolation=0, host_offsets=None):
+        """host_offsets: ctypes int32 array holding the same values as `offsets` (the GridEncoder module keeps one: it builds
+        the table on the host).  Without it the backward falls back to a per-tensor cache keyed by the device address."""
         inputs = inputs.contiguous().float()
         embeddings = embeddings.contiguous().float()
         B, D = inputs.shape
@@ -98,6 +109,7 @@ class _grid_encode(Function):
         ctx.save_for_backward(inputs, embeddings, offsets, dy_dx)
         ctx.dims = [B, D, C, L, S, H, gridtype, interpolation]
         ctx.align_corners = align_corners
+        ctx.host_offsets = host_offsets
         return outputs
 
     @staticmethod
@@ -111,11 +123,16 @@ class _grid_encode(Function):
         import os
         scratch = xcd_scratch_for(embeddings) if (B >= 16384 and os.environ.get("DWG_GRID_NO_XCD") != "1") else None
         grid_encode_backward(grad, inputs, embeddings, offsets, grad_embeddings, B, D, C, L, S, H, dy_dx, grad_inputs,
-                             gridtype, ctx.align_corners, interpolation, grad_layout=1, xcd_scratch=scratch)
-        return grad_inputs, grad_embeddings, None, None, None, None, None, None, None
+                             gridtype, ctx.align_corners, interpolation, grad_layout=1, xcd_scratch=scratch,
+                             host_offsets=ctx.host_offsets)
+        return grad_inputs, grad_embeddings, None, None, None, None, None, None, None, None
 
 
-grid_encode = _grid_encode.apply
+def grid_encode(inputs, embeddings, offsets, per_level_scale, base_resolution, calc_grad_inputs=False, gridtype=0,
+                align_corners=False, interpolation=0, host_offsets=None):
+    """Same positional signature as the reference's `grid_encode = _grid_encode.apply` (grid.py:96), plus the optional host copy."""
+    return _grid_encode.apply(inputs, embeddings, offsets, per_level_scale, base_resolution, calc_grad_inputs, gridtype,
+                              align_corners, interpolation, host_offsets)
 
 
 class GridEncoder(nn.Module):
@@ -143,6 +160,7 @@ class GridEncoder(nn.Module):
             offset += params_in_level
         offsets.append(offset)
         self.register_buffer('offsets', torch.from_numpy(np.array(offsets, dtype=np.int32)))
+        self._host_offsets_py = tuple(int(o) for o in offsets)     # host copy for the library's LDS-path sizing
         self.n_params = offsets[-1] * level_dim
         self.embeddings = nn.Parameter(torch.empty(offset, level_dim))
         self.reset_parameters()
@@ -150,10 +168,17 @@ class GridEncoder(nn.Module):
     def reset_parameters(self):
         self.embeddings.data.uniform_(-1e-4, 1e-4)
 
+    def _load_from_state_dict(self, *args, **kwargs):
+        super()._load_from_state_dict(*args, **kwargs)
+        self._host_offsets_py = None       # `offsets` may have been replaced: re-read it once on the next forward
+
     def forward(self, inputs, bound=1):
         inputs = (inputs + bound) / (2 * bound)
         prefix_shape = list(inputs.shape[:-1])
         inputs = inputs.view(-1, self.input_dim)
+        if self._host_offsets_py is None:
+            self._host_offsets_py = tuple(int(o) for o in self.offsets.cpu().tolist())
         outputs = grid_encode(inputs, self.embeddings, self.offsets, self.per_level_scale, self.base_resolution,
-                              inputs.requires_grad, self.gridtype_id, self.align_corners, self.interp_id)
+                              inputs.requires_grad, self.gridtype_id, self.align_corners, self.interp_id,
+                              _host_array(self._host_offsets_py))
         return outputs.view(prefix_shape + [self.output_dim])
