@@ -156,6 +156,48 @@ def transform_quaternions_flip(SE3, quaternions, weights):
     return matrix_to_quaternion(rot)
 
 
+def transform_quaternions(SE3, quaternions, indices=None, weights=None, rotation_mode='quaternion', flip_rotation_axis=False):
+    """inverse_lbs.py:212-251, all three branches."""
+    R = SE3[..., :3, :3]
+    if indices is not None:
+        R = R[indices]
+    if weights is not None:
+        R = torch.einsum('nj,jkl->nkl', weights, SE3[..., :3, :3])
+    if flip_rotation_axis:
+        flip = torch.tensor([1.0, -1.0, -1.0], dtype=R.dtype)[None, :, None]
+        return matrix_to_quaternion((R @ (quaternion_to_matrix(quaternions) * flip)) * flip)
+    if rotation_mode == 'matrix':
+        return matrix_to_quaternion(R @ quaternion_to_matrix(quaternions))
+    return quaternion_multiply(matrix_to_quaternion(R), quaternions)
+
+
+def se3_inverse(SE3):
+    """inverse_lbs.py:102-138: [R^T, -R^T t]; the last row of the INPUT is overwritten with (0,0,0,1) in place (checklist Q7)."""
+    SE3[..., 3, :] = torch.tensor([0, 0, 0, 1], dtype=SE3.dtype)
+    Rt = SE3[..., :3, :3].transpose(-1, -2)
+    out = torch.zeros_like(SE3)
+    out[..., :3, :3] = Rt
+    out[..., :3, 3] = -torch.matmul(Rt, SE3[..., :3, 3].unsqueeze(-1)).squeeze(-1)
+    out[..., 3, 3] = 1.0
+    return out
+
+
+def se3_weight(SE3, weights):
+    """inverse_lbs.py:174-180 (qr_correct=False): blends the whole 4x4."""
+    return torch.einsum('nj,jkl->nkl', weights, SE3)
+
+
+def inverse_transform_points(points, R, T):
+    """inverse_lbs.py:187-188: general 3x3 inverse (checklist Q8)."""
+    return torch.matmul(torch.inverse(R), (points - T).unsqueeze(-1))[..., :, 0]
+
+
+def inverse_lbs_transform(positions, transforms, lbs_weights):
+    """avatar.py:1377-1424 with use_*_offsets False: inverse of the BLENDED (non-rigid) matrix per point."""
+    jt = se3_weight(se3_compose(transforms["J_pose_rigid"], transforms["G_transl_offset"])[0], lbs_weights)
+    return inverse_transform_points(positions, jt[..., :3, :3], jt[..., :3, 3])
+
+
 # ----------------------------------------------------------------------------------------------------------------
 # synthetic SMPL-X-shaped body model (SURVEY 8c: the licensed model file is absent)
 # ----------------------------------------------------------------------------------------------------------------
@@ -443,10 +485,42 @@ def lbs_transform(positions, transforms, lbs_weights, quaternions=None):
     return p, transform_quaternions_flip(jt, quaternions, lbs_weights)
 
 
+def non_rigid_transform(positions, offsets, mlp_scales, mlp_quats, _scales, _quaternions, init_offset=0.01, init_scale=0.001,
+                        max_scale=0.01, use_non_rigid_offsets=True, use_non_rigid_scales=True, use_non_rigid_rotations=False,
+                        non_rigid_rotation_mode='add', learn_scale=True, learn_quaternions=True):
+    """avatar.py:1464-1498, every branch that does not assert.  NB the scale branch is selected by non_rigid_ROTATION_mode
+    (checklist Q4)."""
+    if use_non_rigid_offsets:
+        positions = positions + offsets * init_offset
+    if use_non_rigid_scales:
+        if learn_scale:
+            if non_rigid_rotation_mode == 'add':
+                scales = torch.exp(_scales) + mlp_scales * init_scale
+            else:
+                scales = torch.exp(_scales) * (1.0 + mlp_scales * init_scale)
+        else:
+            scales = (torch.exp(mlp_scales) * init_scale).clamp(max=max_scale)
+    else:
+        scales = torch.exp(_scales)
+    if use_non_rigid_rotations:
+        if learn_quaternions:
+            if non_rigid_rotation_mode == 'add':
+                quats = F.normalize(_quaternions, dim=-1) + mlp_quats
+            else:
+                quats = quaternion_multiply(F.normalize(mlp_quats, dim=-1), F.normalize(_quaternions, dim=-1))
+        else:
+            quats = F.normalize(mlp_quats, dim=-1)
+    else:
+        quats = F.normalize(_quaternions, dim=-1)
+    return positions, scales, quats
+
+
 def animate(params: Dict[str, torch.Tensor], nets: dict, body: SyntheticBody, smpl_observed: dict, smpl_canonical: dict,
-            mesh: Optional[dict] = None, nerf_bound=2.0, init_offset=0.01, init_scale=0.001):
+            mesh: Optional[dict] = None, nerf_bound=2.0, init_offset=0.01, init_scale=0.001, extra_betas=None):
     """params: _positions [N,3], _scales [N,3] (log), _quaternions [N,4], _lbs_weights [N,55].
     mesh (optional): dict(vertex_indices [Vp], triangles [Fp,3] (local), vertex_coords [Vp,3], bary [Fp,n,3], scales [M,3]).
+    extra_betas (optional, [1,300]): `learn_hand_betas` -- the mesh-bound vertices go through a second pair of skeleton passes with
+    `extra_betas=_betas` (avatar.py:1551-1565); the free Gaussians keep the un-shaped skeleton.
     Returns dict positions/opacities/colors/quaternions/scales in the reference's GaussianOutput layout."""
     _, cV, ctr = glbs_forward(body, **smpl_canonical)
     _, oV, otr = glbs_forward(body, **smpl_observed)
@@ -458,13 +532,15 @@ def animate(params: Dict[str, torch.Tensor], nets: dict, body: SyntheticBody, sm
     oc = mlp_forward(enc, nets["static_w"], nets["static_b"])
     colors = torch.sigmoid(oc[:, 1:]); opacities = torch.sigmoid(oc[:, :1])
     body_pose = smpl_observed.get("body_pose", torch.zeros(1, 63, dtype=positions.dtype))
-    offsets, mlp_scales, _mlp_quats = deform_forward(enc, body_pose, nets["deform"])
-    pos = positions + offsets * init_offset
-    scales = torch.exp(params["_scales"]) + mlp_scales * init_scale          # avatar.py:1471-1472 (checklist Q4)
-    quats = F.normalize(params["_quaternions"], dim=-1)                     # use_non_rigid_rotations=False
+    offsets, mlp_scales, mlp_quats = deform_forward(enc, body_pose, nets["deform"])
+    pos, scales, quats = non_rigid_transform(positions, offsets, mlp_scales, mlp_quats, params["_scales"], params["_quaternions"],
+                                             init_offset=init_offset, init_scale=init_scale)
     pos, quats = lbs_transform(pos, otr, w, quats)
     out = dict(positions=pos, opacities=opacities, colors=colors, quaternions=quats, scales=scales)
     if mesh is not None:
+        if extra_betas is not None:
+            _, cV, _ = glbs_forward(body, **smpl_canonical, extra_betas=extra_betas)
+            _, oV, _ = glbs_forward(body, **smpl_observed, extra_betas=extra_betas)
         vi = mesh["vertex_indices"]
         cvc = transform_points(cV[0], mesh["vertex_coords"], indices=vi)
         cpos = mesh_positions(mesh["bary"], cvc, mesh["triangles"])
