@@ -32,6 +32,7 @@ SIGNATURES = {
     "dwg_raster_workspace_sizes": (ctypes.c_int, [_i32, _i32, _i32, _i64, ctypes.POINTER(_sz), ctypes.POINTER(_sz),
                                                   ctypes.POINTER(_sz)]),
     "dwg_raster_num_pairs_ptr": (_vp, [_vp]),
+    "dwg_raster_camera_setup": (ctypes.c_int, [_vp, _vp, _vp, _vp, _vp]),
     "dwg_raster_forward_bin": (ctypes.c_int, [ctypes.POINTER(RasterSettingsC), _i32] + [_vp] * 9 + [_vp]),
     "dwg_raster_forward_render": (ctypes.c_int, [ctypes.POINTER(RasterSettingsC), _i32, _vp, _vp, _i64, _vp, _vp, _vp,
                                                  _vp, _vp]),
@@ -42,6 +43,7 @@ SIGNATURES = {
     "dwg_lbs_blend_forward": (ctypes.c_int, [_i32, _i32, _i32] + [_vp] * 7 + [_vp]),
     "dwg_lbs_blend_backward": (ctypes.c_int, [_i32] + [_vp] * 7 + [_vp]),
     "dwg_lbs_vertex_transform": (ctypes.c_int, [_i32] * 4 + [_vp] * 8 + [_vp]),
+    "dwg_lbs_vertex_transform_backward_shape": (ctypes.c_int, [_i32] * 3 + [_vp] * 9 + [_vp]),
     # include/dwg_gridenc.h
     "dwg_grid_encode_forward": (ctypes.c_int, [_vp, _vp, _vp, _vp, _u32, _u32, _u32, _u32, _f32, _u32, _vp, _u32, _u32, _u32,
                                                _u32, _vp]),
@@ -79,6 +81,8 @@ SIGNATURES = {
     "dwg_mesh_vertex_normals": (ctypes.c_int, [_i32, _i32, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
     "dwg_meshbind_forward": (ctypes.c_int, [_i32, _i32, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
     "dwg_meshbind_backward": (ctypes.c_int, [_i32, _i32, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
+    "dwg_meshbind_backward_verts": (ctypes.c_int, [_i32, _i32] + [_vp] * 15 + [_vp]),
+    "dwg_mesh_vertex_normals_backward": (ctypes.c_int, [_i32, _i32] + [_vp] * 8 + [_vp]),
     # include/dwg_graph.h
     "dwg_graph_begin_capture": (ctypes.c_int, [_vp]),
     "dwg_graph_end_capture": (ctypes.c_int, [_vp, ctypes.POINTER(_vp)]),

@@ -1,25 +1,27 @@
-"""MI355X-native mirror of the reference's avatar hot path.
+"""MI355X-native mirror of the reference's avatar hot path (boundary B3/B5).
 
   GaussianOutput / merge_gaussians   /root/reference/core/gaussian/gaussian_utils.py:20-68
-  GeneralLinearBlendSkinning         /root/reference/core/human/inverse_lbs.py:517-784   (forward only, frozen skeleton)
-  MeshBindingGaussianModel           /root/reference/core/system/avatar.py:921-1079
-  DreamWaltzG (.animate, .lbs_transform, .non_rigid_transform, get_*_gaussians)  avatar.py:1097-1588 with the default
-                                     flags (configs/__init__.py:117-126,194-205)
-Heavy arithmetic = HIP kernels through the C-ABI (lbs.hip, gridenc.hip, gemm.hip); the glue between them is thin torch
-element-wise code on the same stream.  Parameter names match the reference so its checkpoints map one to one.
+  GeneralLinearBlendSkinning         /root/reference/core/human/inverse_lbs.py:517-784
+        .forward(**smpl_inputs) -> (transform_J, transform_V, transforms)   -- the reference's triple of RigidTransform objects
+  MeshBindingGaussianModel           /root/reference/core/system/avatar.py:921-1096
+  DreamWaltzG (.animate, .lbs_transform, .inverse_lbs_transform, .non_rigid_transform, .get_optimizer, ...)  avatar.py:1097-1635
+Heavy arithmetic = HIP kernels through the C-ABI (lbs.hip, gridenc.hip, gemm.hip, assemble.hip, meshbind.hip); what the
+reference materialises densely per step (transform_V [V,4,4], the three vertex offsets) is kept LAZY here and only computed
+for the vertex subset a caller asks for.  Parameter names match the reference so its checkpoints map one to one.
 """
 from dataclasses import dataclass, fields
 from typing import Dict, Optional
 
 import torch
 import torch.nn as nn
-import torch.nn.functional as F
 
 from . import assemble as asm_ops
 from . import lbs as lbs_ops
 from . import meshbind as mb_ops
+from . import optim
 from .gridencoder import GridEncoder
 from .mlp import MLP, DeformNetwork
+from .rigid import (RigidTransform, matrix_to_quaternion, quaternion_multiply, standardize_quaternion)  # noqa: F401  (re-exported)
 
 
 @dataclass
@@ -55,44 +57,73 @@ def merge_gaussians(*gaussians: GaussianOutput) -> GaussianOutput:
 
 
 # ----------------------------------------------------------------------------------------------------------------------
-# quaternion helpers (pytorch3d.transforms restatements used outside the fused LBS kernel: mesh-bound frames only)
-# ----------------------------------------------------------------------------------------------------------------------
-def _sqrt_positive_part(x):
-    return torch.where(x > 0, torch.sqrt(torch.clamp(x, min=1e-38)), torch.zeros_like(x))
-
-
-def matrix_to_quaternion(matrix):
-    m = matrix.reshape(matrix.shape[:-2] + (9,))
-    m00, m01, m02, m10, m11, m12, m20, m21, m22 = torch.unbind(m, -1)
-    q_abs = _sqrt_positive_part(torch.stack([1.0 + m00 + m11 + m22, 1.0 + m00 - m11 - m22, 1.0 - m00 + m11 - m22,
-                                             1.0 - m00 - m11 + m22], dim=-1))
-    quat_by_rijk = torch.stack([
-        torch.stack([q_abs[..., 0] ** 2, m21 - m12, m02 - m20, m10 - m01], dim=-1),
-        torch.stack([m21 - m12, q_abs[..., 1] ** 2, m10 + m01, m02 + m20], dim=-1),
-        torch.stack([m02 - m20, m10 + m01, q_abs[..., 2] ** 2, m12 + m21], dim=-1),
-        torch.stack([m10 - m01, m20 + m02, m21 + m12, q_abs[..., 3] ** 2], dim=-1)], dim=-2)
-    cand = quat_by_rijk / (2.0 * q_abs[..., None].clamp_min(0.1))
-    idx = q_abs.argmax(dim=-1)
-    return torch.gather(cand, -2, idx[..., None, None].expand(idx.shape + (1, 4))).squeeze(-2)
-
-
-def standardize_quaternion(q):
-    return torch.where(q[..., 0:1] < 0, -q, q)
-
-
-# ----------------------------------------------------------------------------------------------------------------------
 # skeleton
 # ----------------------------------------------------------------------------------------------------------------------
-@dataclass
-class LBSTransforms:
-    """What DreamWaltzG needs from lbs_model.forward(): `A` = compose(J_pose_rigid, G_transl_offset) [J,4,4]."""
-    A: torch.Tensor
-    rot_mats: torch.Tensor
-    full_shape: torch.Tensor
+class _LazyRigidTransform(RigidTransform):
+    """A RigidTransform whose SE3 is only built when somebody reads it (.SE3 / .R / .T or any algebra on it)."""
+
+    def __init__(self, thunk):
+        self.__dict__["_thunk"] = thunk
+
+    def _materialise(self):
+        SE3 = self.__dict__.pop("_thunk")()
+        self.SE3, self.R, self.T = SE3, SE3[..., :3, :3], SE3[..., :3, 3]
+
+    def __getattr__(self, name):
+        if name in ("SE3", "R", "T") and "_thunk" in self.__dict__:
+            self._materialise()
+            return self.__dict__[name]
+        raise AttributeError(name)
+
+    def squeeze(self, dim=0):
+        if "_thunk" in self.__dict__:
+            inner = self.__dict__["_thunk"]
+            self.__dict__["_thunk"] = lambda: inner().squeeze(dim)
+            return self
+        return super().squeeze(dim)
+
+
+class _VertexTransform(_LazyRigidTransform):
+    """transform_V = compose(V_shape_offset, V_pose_offset, V_pose_rigid[, transl]) (inverse_lbs.py:758-772).  The one call the
+    hot path makes on it, `.transform_points(vertex_coords, indices=predefined_vertex_indices)` (avatar.py:1570,1577), runs on the
+    vertex SUBSET in one HIP launch (lbs.hip k_vertex_transform) and is differentiable w.r.t. the shape coefficients (betas)."""
+
+    def __init__(self, model, ctx, thunk):
+        super().__init__(thunk)
+        self.__dict__["_model"], self.__dict__["_ctx"] = model, ctx
+
+    def transform_points(self, points, indices=None, weights=None):
+        if indices is not None and weights is None and "_thunk" in self.__dict__ and points.is_cuda:
+            return self._model._transform_vertex_subset(self._ctx, indices, points)
+        return super().transform_points(points, indices=indices, weights=weights)
+
+
+class LBSTransforms(dict):
+    """The `transforms` dict of GeneralLinearBlendSkinning.forward: keys V_shape_offset, V_pose_offset, V_pose_rigid,
+    J_shape_offset, J_pose_rigid, G_transl_offset -> RigidTransform, every one built on first access.  The fused kernels read the
+    attributes instead: A [J,4,4] = compose(J_pose_rigid, G_transl_offset) as ONE tensor straight from k_joint_chain."""
+    KEYS = ("V_shape_offset", "V_pose_offset", "V_pose_rigid", "J_shape_offset", "J_pose_rigid", "G_transl_offset")
+
+    def __init__(self, model, A, rot_mats, full_shape, transl, full_pose):
+        super().__init__()
+        self.model, self.A, self.rot_mats, self.full_shape, self.transl, self.full_pose = model, A, rot_mats, full_shape, transl, full_pose
+
+    def __missing__(self, key):
+        if key not in self.KEYS:
+            raise KeyError(key)
+        v = self.model._build_transform(self, key)
+        self[key] = v
+        return v
+
+    def __contains__(self, key):
+        return key in self.KEYS
+
+    def keys(self):
+        return list(self.KEYS)
 
 
 class GeneralLinearBlendSkinning(nn.Module):
-    """Forward-only mirror of inverse_lbs.py:517-784 for a frozen SMPL-X(-shaped) model given as tensors."""
+    """Mirror of inverse_lbs.py:517-784 for a frozen SMPL-X(-shaped) model given as tensors."""
 
     def __init__(self, body: Dict[str, torch.Tensor]):
         super().__init__()
@@ -107,9 +138,11 @@ class GeneralLinearBlendSkinning(nn.Module):
         self.register_buffer("joint_shape_dirs", torch.einsum('jv,vcl->jcl', self.J_regressor, shapedirs).contiguous())
         self.num_joints = self.J_regressor.shape[0]
         self.NUM_BODY_JOINTS = 21
-        self._subsets = {}
+        self.use_smplx = True
+        self._subsets = []          # [(index tensor kept alive, its version, gathered rows)]
 
-    def get_full_shape(self, betas=None, expression=None, extra_betas=None):
+    def get_full_shape(self, betas=None, expression=None, batch_size=None, extra_betas=None):
+        """inverse_lbs.py:570-589."""
         betas = self.betas if betas is None else betas
         if extra_betas is not None:
             betas = betas + extra_betas
@@ -129,98 +162,150 @@ class GeneralLinearBlendSkinning(nn.Module):
                           right_hand_pose.reshape(-1, 3)], dim=0).to(dev)
         return full + self.pose_mean.reshape(-1, 3)
 
-    @torch.no_grad()
     def forward(self, betas=None, body_pose=None, global_orient=None, left_hand_pose=None, right_hand_pose=None,
-                jaw_pose=None, leye_pose=None, reye_pose=None, expression=None, transl=None, extra_betas=None, **_unused):
+                jaw_pose=None, leye_pose=None, reye_pose=None, expression=None, transl=None, flame_betas=None,
+                flame_expression=None, extra_betas=None):
+        """-> (transform_J, transform_V, transforms), inverse_lbs.py:719-784.  One launch (k_joint_chain); the dense per-vertex
+        transforms are built only if read."""
         full_shape = self.get_full_shape(betas=betas, expression=expression, extra_betas=extra_betas)
-        full_pose = self.get_full_pose(body_pose, global_orient, left_hand_pose, right_hand_pose, jaw_pose, leye_pose, reye_pose)
-        A, R = lbs_ops.joint_chain(full_pose, self.J_template, self.parents, transl=transl, return_rot_mats=True,
-                                   joint_shape_dirs=self.joint_shape_dirs, shape_coeffs=full_shape)
-        return LBSTransforms(A=A, rot_mats=R, full_shape=full_shape)
+        with torch.no_grad():
+            full_pose = self.get_full_pose(body_pose, global_orient, left_hand_pose, right_hand_pose, jaw_pose, leye_pose, reye_pose)
+            A, R = lbs_ops.joint_chain(full_pose, self.J_template, self.parents, transl=transl, return_rot_mats=True,
+                                       joint_shape_dirs=self.joint_shape_dirs, shape_coeffs=full_shape.detach())
+        tr = LBSTransforms(self, A, R, full_shape, transl, full_pose)
+        transform_V = _VertexTransform(self, tr, lambda: self._dense_transform_V(tr))
+        transform_J = _LazyRigidTransform(lambda: self._dense_transform_J(tr))
+        return transform_J, transform_V, tr
 
-    @torch.no_grad()
+    # -- lazily built dense pieces (not on the hot path) -----------------------------------------------------------------
+    def _joints(self, tr):
+        return self.J_template + torch.einsum('jcl,l->jc', self.joint_shape_dirs, tr.full_shape.reshape(-1))
+
+    def _build_transform(self, tr, key):
+        dev = self.v_template.device
+        if key == "G_transl_offset":
+            if tr.transl is not None:
+                return RigidTransform(T=tr.transl.reshape(1, 3).float())
+            return RigidTransform(SE3=torch.eye(4, device=dev).expand(1, 4, 4))
+        if key == "J_pose_rigid":
+            SE3 = tr.A.clone()
+            if tr.transl is not None:
+                SE3[:, :3, 3] = SE3[:, :3, 3] - tr.transl.reshape(3)
+            return RigidTransform(SE3=SE3[None])
+        if key == "J_shape_offset":
+            return RigidTransform(T=(self._joints(tr) - self.J_template)[None])
+        if key == "V_shape_offset":
+            return RigidTransform(T=torch.einsum('vcl,l->vc', self.shapedirs_all, tr.full_shape.reshape(-1))[None])
+        if key == "V_pose_offset":
+            feat = (tr.rot_mats[1:] - torch.eye(3, device=dev)).reshape(1, -1)
+            return RigidTransform(T=(feat @ self.posedirs).view(1, -1, 3))
+        if key == "V_pose_rigid":
+            A = tr["J_pose_rigid"].SE3[0]
+            return RigidTransform(SE3=torch.einsum('vj,jkl->vkl', self.lbs_weights, A)[None])
+        raise KeyError(key)
+
+    def _dense_transform_V(self, tr):
+        t = tr["V_shape_offset"].compose(tr["V_pose_offset"], tr["V_pose_rigid"])
+        return (t.compose(tr["G_transl_offset"]) if tr.transl is not None else t).SE3
+
+    def _dense_transform_J(self, tr):
+        t = tr["J_shape_offset"].compose(tr["J_pose_rigid"])
+        return (t.compose(tr["G_transl_offset"]) if tr.transl is not None else t).SE3
+
+    # -- vertex subset (mesh-bound Gaussians) --------------------------------------------------------------------------
+    def _subset_rows(self, vertex_indices):
+        """Blend-shape / pose-corrective / skinning rows of a vertex subset, gathered once per index tensor.  The cache holds
+        the index tensor itself (so its storage cannot be recycled under a stale entry) and its version counter."""
+        for ref, ver, rows in self._subsets:
+            if ref is vertex_indices or (ref.data_ptr() == vertex_indices.data_ptr() and ref.shape == vertex_indices.shape and
+                                         ref.device == vertex_indices.device):
+                if ref._version == ver and vertex_indices._version == ver:
+                    return rows
+        rows = lbs_ops.gather_vertex_subset(vertex_indices.to(self.v_template.device), self.lbs_weights, self.shapedirs_all, self.posedirs)
+        self._subsets = [e for e in self._subsets if e[0] is not vertex_indices][-7:] + [(vertex_indices, vertex_indices._version, rows)]
+        return rows
+
+    def _transform_vertex_subset(self, tr, vertex_indices, vertex_coords):
+        rows = self._subset_rows(vertex_indices)
+        return lbs_ops.vertex_transform(vertex_coords, tr.A, rows, tr.full_shape, tr.rot_mats, joint_chain_ctx=(
+            self.parents, self.joint_shape_dirs, self.J_template), pose=tr.full_pose)
+
     def transform_vertices(self, tr: LBSTransforms, vertex_indices, vertex_coords):
-        """transform_V.transform_points(vertex_coords, indices=...) (avatar.py:1570,1577).  The subset's blend-shape rows are
-        gathered once per distinct index tensor."""
-        key = (vertex_indices.data_ptr(), int(vertex_indices.numel()))
-        if key not in self._subsets:
-            self._subsets[key] = lbs_ops.gather_vertex_subset(vertex_indices, self.lbs_weights, self.shapedirs_all, self.posedirs)
-        return lbs_ops.vertex_transform(vertex_coords, tr.A, self._subsets[key], tr.full_shape, tr.rot_mats)
+        """transform_V.transform_points(vertex_coords, indices=...) (avatar.py:1570,1577)."""
+        return self._transform_vertex_subset(tr, vertex_indices, vertex_coords)
 
 
 # ----------------------------------------------------------------------------------------------------------------------
 # mesh-bound Gaussians (hands / face)
 # ----------------------------------------------------------------------------------------------------------------------
-def safe_normalize(x, eps=1e-20):
-    return x / torch.sqrt(torch.clamp((x * x).sum(-1, keepdim=True), min=eps))
-
-
-def compute_normal(vertices, faces):
-    """utils/mesh.py:34-94 (single mesh)."""
-    i0, i1, i2 = faces[:, 0], faces[:, 1], faces[:, 2]
-    v0, v1, v2 = vertices[i0], vertices[i1], vertices[i2]
-    fn = safe_normalize(torch.linalg.cross(v1 - v0, v2 - v0))
-    vn = torch.zeros_like(vertices).index_add(0, i0, fn).index_add(0, i1, fn).index_add(0, i2, fn)
-    vn = torch.where((vn * vn).sum(-1, keepdim=True) > 1e-20, vn, torch.tensor([0.0, 0.0, 1.0], device=vertices.device))
-    return safe_normalize(vn), fn
-
-
 class MeshBindingGaussianModel(nn.Module):
-    """avatar.py:921-1079: n Gaussians per triangle, learnable barycentric coordinates and tangent scales."""
+    """avatar.py:921-1096: n Gaussians per triangle, learnable barycentric coordinates and tangent scales."""
 
-    def __init__(self, vertex_coords, triangles, vertex_indices, n_per_triangle=6, init_scale_ratio=1.0):
+    def __init__(self, vertex_coords, triangles, vertex_indices, n_per_triangle=6, init_scale_ratio=1.0, learn_bary_coords=True,
+                 learn_vertex_coords=False, learn_scales=True):
         super().__init__()
+        self.learn_bary_coords, self.learn_vertex_coords, self.learn_scales = learn_bary_coords, learn_vertex_coords, learn_scales
         self.register_buffer("predefined_vertex_indices", vertex_indices.long())
         self.register_buffer("triangles", triangles.long())
         self._n_points_per_triangle = n_per_triangle
         Fp = triangles.shape[0]
+        self._n_triangles, self._n_vertices, self._n_points = Fp, vertex_coords.shape[0], Fp * n_per_triangle
         base = torch.tensor([[2 / 3, 1 / 6, 1 / 6], [1 / 6, 2 / 3, 1 / 6], [1 / 6, 1 / 6, 2 / 3], [1 / 6, 5 / 12, 5 / 12],
                              [5 / 12, 1 / 6, 5 / 12], [5 / 12, 5 / 12, 1 / 6]], dtype=torch.float32)
         assert n_per_triangle == 6, "default n_gaussians_per_triangle"
-        self._bary_coords = nn.Parameter(base.expand(Fp, -1, -1).clone())
-        self._vertex_coords = nn.Parameter(vertex_coords.float().clone(), requires_grad=False)
-        self._scales = nn.Parameter(torch.ones(Fp * n_per_triangle, 3) * init_scale_ratio)
+        self._bary_coords = nn.Parameter(base.expand(Fp, -1, -1).clone(), requires_grad=learn_bary_coords)
+        self._vertex_coords = nn.Parameter(vertex_coords.float().clone(), requires_grad=learn_vertex_coords)
+        self._scales = nn.Parameter(torch.ones(Fp * n_per_triangle, 3) * init_scale_ratio, requires_grad=learn_scales)
         p2t = torch.arange(Fp)[:, None].expand(-1, n_per_triangle).reshape(-1)
+        self.register_buffer("points_to_triangles", p2t)
         self.register_buffer("points_to_vertices", self.triangles[p2t])
-        # native path (csrc/meshbind.hip): int32 topology + the static vertex -> face adjacency for the normal gather
-        self.register_buffer("triangles_i32", self.triangles.to(torch.int32).contiguous())
-        off, faces = mb_ops.build_vertex_face_csr(self.triangles, vertex_coords.shape[0])
-        self.register_buffer("vf_offsets", off)
-        self.register_buffer("vf_faces", faces)
+        self._rebuild_topology()
+
+    def _rebuild_topology(self):
+        """Derived buffers of the native path (csrc/meshbind.hip): int32 topology + the static vertex -> face adjacency."""
+        self.register_buffer("triangles_i32", self.triangles.to(torch.int32).contiguous(), persistent=False)
+        off, faces = mb_ops.build_vertex_face_csr(self.triangles, self._vertex_coords.shape[0])
+        self.register_buffer("vf_offsets", off.to(self.triangles.device), persistent=False)
+        self.register_buffer("vf_faces", faces.to(self.triangles.device), persistent=False)
+
+    @staticmethod
+    def bary_coord_activation(bary_coords):
+        return bary_coords / bary_coords.sum(dim=-1, keepdim=True)
+
+    def get_vertex_coords(self):
+        return self._vertex_coords
 
     def forward(self, canonical_vertex_coords, observed_vertex_coords):
-        """get_positions (canonical + observed) and get_scales_and_quaternions (observed) in one forward / one backward
-        launch -> (canonical positions, positions, scales, quaternions).  The torch-op methods below are the same math,
-        kept as the reference-named entry points."""
-        vn = mb_ops.vertex_normals(observed_vertex_coords, self.triangles_i32, self.vf_offsets, self.vf_faces)
-        return mb_ops.meshbind(self._bary_coords, self._scales, canonical_vertex_coords, observed_vertex_coords, vn,
-                               self.triangles_i32, self._n_points_per_triangle)
+        """get_positions (canonical + observed) and get_scales_and_quaternions (observed) in one forward / one backward launch
+        -> (canonical positions, positions, scales, quaternions)."""
+        return mb_ops.meshbind_full(self._bary_coords, self._scales, canonical_vertex_coords, observed_vertex_coords, self.triangles_i32,
+                                    self.vf_offsets, self.vf_faces, self._n_points_per_triangle)
 
-    def get_positions(self, vertex_coords):
-        bary = self._bary_coords / self._bary_coords.sum(dim=-1, keepdim=True)
-        return torch.einsum('fnv,fvc->fnc', bary, vertex_coords[self.triangles]).reshape(-1, 3)
+    def get_positions(self, vertex_coords=None, bary_coords=None):
+        """avatar.py:1016-1025 (same HIP kernel, positions only)."""
+        if vertex_coords is None:
+            vertex_coords = self.get_vertex_coords()
+        if bary_coords is not None:
+            return torch.einsum('fnv,fvc->fnc', bary_coords, vertex_coords[self.triangles]).reshape(-1, 3)
+        return mb_ops.meshbind_full(self._bary_coords, self._scales, None, vertex_coords, self.triangles_i32, self.vf_offsets,
+                                    self.vf_faces, self._n_points_per_triangle)[1]
 
-    def get_scales_and_quaternions(self, vertex_coords, positions, eps=1e-9):
-        dot = lambda a, b: (a * b).sum(-1, keepdim=True)  # noqa: E731
-        p0 = positions
-        pv = vertex_coords[self.points_to_vertices]
-        p1, p2, p3 = pv[:, 0], pv[:, 1], pv[:, 2]
-        vn, _ = compute_normal(vertex_coords, self.triangles)
-        pn = (vn[self.points_to_vertices] * self._bary_coords.reshape(-1, 3)[:, :, None]).sum(dim=1)   # raw bary (Q5)
-        v0 = pn / (torch.linalg.vector_norm(pn, dim=-1, keepdim=True) + eps)
-        ref = torch.tensor((1.0, 0.0, 0.0), device=p0.device).expand_as(p0)
-        v1 = torch.linalg.cross(v0, ref)
-        v1 = v1 / (torch.linalg.vector_norm(v1, dim=-1, keepdim=True) + eps)
-        v2 = torch.linalg.cross(v0, v1)
-        v2 = v2 / (torch.linalg.vector_norm(v2, dim=-1, keepdim=True) + eps)
-        R = torch.stack((v0, v1, v2), dim=2) * torch.tensor([1.0, -1.0, -1.0], device=p0.device)[None, :, None]
-        n = self._n_points_per_triangle
-        s0 = torch.zeros_like(v0[:, :1])
-        s1 = (dot(p1 - p0, v1).abs() + dot(p2 - p0, v1).abs() + dot(p3 - p0, v1).abs()) / n
-        s2 = (dot(p1 - p0, v2).abs() + dot(p2 - p0, v2).abs() + dot(p3 - p0, v2).abs()) / n
-        s1 = s1 * torch.clamp(self._scales[:, 1:2], min=0.5, max=2.0)
-        s2 = s2 * torch.clamp(self._scales[:, 2:3], min=0.5, max=2.0)
-        return torch.cat((s0, s1, s2), dim=1), standardize_quaternion(matrix_to_quaternion(R))
+    def get_scales_and_quaternions(self, vertex_coords, positions=None, eps=1e-9):
+        """avatar.py:1027-1079; `positions` is recomputed inside the kernel from the same inputs."""
+        _, _, s, q = mb_ops.meshbind_full(self._bary_coords, self._scales, None, vertex_coords, self.triangles_i32, self.vf_offsets,
+                                          self.vf_faces, self._n_points_per_triangle)
+        return s, q
+
+    def get_optimizer(self, cfg, optimizer_name: str):
+        """avatar.py:1082-1096: Adam(lr=0, eps=1e-15) with groups bary_coords (position_lr_init), vertex_coords, scales (scaling_lr)."""
+        l = []
+        if self.learn_bary_coords:
+            l.append({'params': [self._bary_coords], 'lr': cfg.render.position_lr_init, 'name': "bary_coords"})
+        if self.learn_vertex_coords:
+            l.append({'params': [self._vertex_coords], 'lr': cfg.render.position_lr_init, 'name': "vertex_coords"})
+        if self.learn_scales:
+            l.append({'params': [self._scales], 'lr': cfg.render.scaling_lr, 'name': "scales"})
+        return {optimizer_name: optim.AdamSpec(l, eps=1e-15)} if l else {}
 
 
 # ----------------------------------------------------------------------------------------------------------------------
@@ -229,15 +314,38 @@ class MeshBindingGaussianModel(nn.Module):
 class DreamWaltzG(nn.Module):
     def __init__(self, lbs_model: GeneralLinearBlendSkinning, positions, scales, quaternions, lbs_weights,
                  smpl_canonical_inputs: dict, mesh_binding_gaussians: Optional[Dict[str, MeshBindingGaussianModel]] = None,
-                 nerf_bound=2.0, init_offset=0.01, init_scale=0.001):
+                 nerf_bound=2.0, init_offset=0.01, init_scale=0.001, max_scale=0.01, learn_positions=True, learn_scales=True,
+                 learn_quaternions=True, learn_lbs_weights=False, learn_hand_betas=False, learn_face_betas=False,
+                 nearest_vertex_indices=None, cfg=None):
         super().__init__()
         self.lbs_model = lbs_model
-        self._positions = nn.Parameter(positions.float().clone())
-        self._scales = nn.Parameter(torch.log(scales.float().clone()))       # scale_activation = exp
-        self._quaternions = nn.Parameter(quaternions.float().clone())
-        self._lbs_weights = nn.Parameter(lbs_weights.float().clone(), requires_grad=False)   # configs/__init__.py:197
+        self.deform_model = None
+        self._positions = nn.Parameter(positions.float().clone(), requires_grad=learn_positions)
+        self._scales = nn.Parameter(torch.log(scales.float().clone()), requires_grad=learn_scales)       # scale_activation = exp
+        self._quaternions = nn.Parameter(quaternions.float().clone(), requires_grad=learn_quaternions)
+        self._lbs_weights = nn.Parameter(lbs_weights.float().clone(), requires_grad=learn_lbs_weights)   # configs/__init__.py:197
+        self.learn_positions, self.learn_scale, self.learn_quaternions, self.learn_lbs_weights = (
+            learn_positions, learn_scales, learn_quaternions, learn_lbs_weights)
+        self.learn_hand_betas, self.learn_face_betas = learn_hand_betas, learn_face_betas
+        self.learn_betas = learn_hand_betas or learn_face_betas
+        self._betas = nn.Parameter(lbs_model.betas.data.clone(), requires_grad=self.learn_betas)          # avatar.py:1225
         self.smpl_canonical_inputs = smpl_canonical_inputs
-        self.nerf_bound, self.init_offset, self.init_scale = nerf_bound, init_offset, init_scale
+        self.register_buffer("nerf_bound", torch.tensor(float(nerf_bound)))
+        self._nerf_bound_host = float(nerf_bound)
+        self.init_offset, self.init_scale, self.max_scale = init_offset, init_scale, max_scale
+        # the default flags (configs/__init__.py:117-126); non-default combinations are rejected, not silently ignored
+        self.use_joint_shape_offsets = self.use_vertex_shape_offsets = self.use_vertex_pose_offsets = False
+        self.use_non_rigid_offsets, self.use_non_rigid_scales, self.use_non_rigid_rotations = True, True, False
+        self.non_rigid_scale_mode = self.non_rigid_rotation_mode = 'add'
+        self.render_mesh_binding_3d_gaussians_only = self.render_unconstrained_3d_gaussians_only = False
+        self.use_nerf_encoded_position = True
+        if cfg is not None:
+            for k in ("use_joint_shape_offsets", "use_vertex_shape_offsets", "use_vertex_pose_offsets", "use_non_rigid_offsets",
+                      "use_non_rigid_scales", "use_non_rigid_rotations", "non_rigid_scale_mode", "non_rigid_rotation_mode",
+                      "render_mesh_binding_3d_gaussians_only", "render_unconstrained_3d_gaussians_only", "use_nerf_encoded_position"):
+                if hasattr(cfg.render, k) and getattr(cfg.render, k) != getattr(self, k):
+                    raise NotImplementedError("cfg.render.%s = %r: only the default configuration of the shipped recipes is built "
+                                              "(configs/__init__.py:117-126)" % (k, getattr(cfg.render, k)))
         # nerf_model.py:223-232: tiledgrid encoder L=16 C=2 base 16 -> 2048*bound, smoothstep; sigma_net 32->64->64->4
         self.nerf_encoder = GridEncoder(input_dim=3, num_levels=16, level_dim=2, base_resolution=16, log2_hashmap_size=19,
                                         desired_resolution=2048 * nerf_bound, gridtype='tiled', align_corners=False,
@@ -245,25 +353,75 @@ class DreamWaltzG(nn.Module):
         self.nerf_opacity_and_color_net = MLP(32, 4, 64, 3, bias=True)
         self.nerf_scale_and_quaternion_net = DeformNetwork(xyz_input_ch=32, D=4, W=64)
         self.mesh_binding_gaussians = nn.ModuleDict(mesh_binding_gaussians or {})
+        self._n_points = self._positions.shape[0]
+        self._n_points_on_mesh = sum(m._n_points for m in self.mesh_binding_gaussians.values())
+        self.nearest_triangles_buffer = {'nearest_vertex_indices': nearest_vertex_indices}
         self._canonical_cache = None
         self._canonical_vertices = {}
 
+    @property
+    def device(self):
+        return self._positions.device
+
+    @property
+    def densification_mask(self):
+        return torch.cat([torch.ones(self._n_points, dtype=torch.bool), torch.zeros(self._n_points_on_mesh, dtype=torch.bool)])
+
+    # -- GaussianModel accessors (gaussian_model.py:25-56) -------------------------------------------------------------------
+    scale_activation = staticmethod(torch.exp)
+    scale_inverse_activation = staticmethod(torch.log)
+    color_activation = staticmethod(torch.sigmoid)
+    opacity_activation = staticmethod(torch.sigmoid)
+    rotation_activation = staticmethod(torch.nn.functional.normalize)
+
+    def get_positions(self):
+        return self._positions
+
+    def get_scales(self, return_means=False):
+        if return_means:
+            return torch.exp(self._scales.mean(dim=-1, keepdim=True).expand(-1, 3))
+        return torch.exp(self._scales)
+
+    def get_quaternions(self):
+        return torch.nn.functional.normalize(self._quaternions)
+
+    @staticmethod
+    def lbs_weight_activation(lbs_weights):
+        return lbs_weights / lbs_weights.sum(dim=-1, keepdim=True)
+
+    def get_lbs_weights(self):
+        return self.lbs_weight_activation(self._lbs_weights)
+
     # -- checkpoints ------------------------------------------------------------------------------------------------
+    def invalidate_caches(self):
+        """Everything derived from parameters / buffers that a checkpoint load or an in-place edit may have changed."""
+        self._canonical_cache = None
+        self._canonical_vertices = {}
+        self.nerf_encoder._host_offsets_py = None
+        self.lbs_model._subsets = []
+        for m in self.mesh_binding_gaussians.values():
+            m._rebuild_topology()
+
+    def reset_by_state_dict(self, state_dict, attribute_names=('_positions', '_scales', '_quaternions', '_lbs_weights')):
+        """GaussianModel.reset_by_state_dict (gaussian_model.py:58-85, avatar.py:1254-1281): resize the per-Gaussian parameters to
+        the checkpoint's Gaussian count before the plain copy."""
+        if "_positions" not in state_dict:
+            return
+        n = state_dict["_positions"].shape[0]
+        for name in attribute_names:
+            cur = getattr(self, name, None)
+            if cur is not None and name in state_dict and cur.shape[0] != n:
+                new = torch.empty(n, *cur.shape[1:], dtype=cur.dtype, device=cur.device)
+                setattr(self, name, nn.Parameter(new, requires_grad=cur.requires_grad))
+        self._n_points = n
+
     def load_reference_state_dict(self, state_dict, prefix="avatar."):
         """Loads the avatar part of a reference checkpoint's `model` entry (trainer.py:238-259 saves {'train_step',
         'checkpoints', 'model': Scene.state_dict()}; the avatar sits under `avatar.` and, duplicated, `avatars.0.`).
-        Per-Gaussian parameters are first resized to the checkpoint's Gaussian count exactly like
-        GaussianModel.reset_by_state_dict (gaussian_model.py:58-85, avatar.py:1254-1281); parameter names match the reference,
-        so everything else is a plain copy.  Returns (loaded keys, checkpoint keys with no counterpart here, our keys the
-        checkpoint does not carry).  Call it BEFORE the parameters are re-homed into a FlatAdam buffer when the count changes."""
+        Returns (loaded keys, checkpoint keys with no counterpart here, our keys the checkpoint does not carry).  Call it
+        BEFORE the parameters are re-homed into a flat optimizer buffer when the Gaussian count changes."""
         sd = {k[len(prefix):]: v for k, v in state_dict.items() if k.startswith(prefix)}
-        if "_positions" in sd:
-            n = sd["_positions"].shape[0]
-            for name in ("_positions", "_scales", "_quaternions", "_lbs_weights"):
-                cur = getattr(self, name, None)
-                if cur is not None and name in sd and cur.shape[0] != n:
-                    new = torch.empty(n, *cur.shape[1:], dtype=cur.dtype, device=cur.device)
-                    setattr(self, name, nn.Parameter(new, requires_grad=cur.requires_grad))
+        self.reset_by_state_dict(sd)
         own = self.state_dict()
         loaded, unknown = [], []
         for k, v in sd.items():
@@ -272,18 +430,32 @@ class DreamWaltzG(nn.Module):
                 loaded.append(k)
             else:
                 unknown.append(k)
+        if "nerf_bound" in sd:
+            self._nerf_bound_host = float(sd["nerf_bound"])
         missing = [k for k in own if k not in sd]
-        self._canonical_cache = None
-        self._canonical_vertices = {}
+        self.invalidate_caches()
         return loaded, unknown, missing
 
-    # -- avatar.py:913-918
-    def get_lbs_weights(self):
-        return self._lbs_weights
+    # -- LBS -----------------------------------------------------------------------------------------------------------
+    def _joint_pose_A(self, transforms):
+        """compose(J_pose_rigid, G_transl_offset).squeeze(0) (avatar.py:1441-1444) as one [J,4,4] tensor."""
+        A = getattr(transforms, "A", None)
+        if A is not None:
+            return A
+        return RigidTransform.compose(transforms['J_pose_rigid'], transforms['G_transl_offset']).SE3.reshape(-1, 4, 4)
 
-    def lbs_transform(self, positions, transforms: LBSTransforms, quaternions=None):
-        """avatar.py:1426-1462 with use_*_offsets False; the weight normalisation of get_lbs_weights is fused in."""
-        return lbs_ops.lbs_blend(transforms.A, self._lbs_weights, positions, quaternions, normalize_weights=True)
+    def lbs_transform(self, positions, transforms, lbs_weights=None, vertex_indices=None, quaternions=None):
+        """avatar.py:1426-1462 (use_*_offsets False).  `lbs_weights=None` means "the avatar's own": the raw parameter is streamed
+        once and its normalisation (get_lbs_weights, avatar.py:913-918) is fused into the kernel."""
+        A = self._joint_pose_A(transforms)
+        if lbs_weights is None:
+            return lbs_ops.lbs_blend(A, self._lbs_weights, positions, quaternions, normalize_weights=True)
+        return lbs_ops.lbs_blend(A, lbs_weights, positions, quaternions, normalize_weights=False)
+
+    def inverse_lbs_transform(self, positions, transforms):
+        """avatar.py:1377-1424, the 'Correct' branch: per-point inverse of the BLENDED matrix (checklist Q8); init-time only."""
+        jt = RigidTransform(SE3=self._joint_pose_A(transforms)).weight(self.get_lbs_weights())
+        return RigidTransform._inverse_transform_points(positions, R=jt.R, T=jt.T)
 
     def static_mlp_forward(self, enc, fix_opacities=False):
         oc = self.nerf_opacity_and_color_net(enc)
@@ -291,42 +463,100 @@ class DreamWaltzG(nn.Module):
         opacities = torch.ones_like(oc[:, :1]) if fix_opacities else torch.sigmoid(oc[:, :1])
         return colors, opacities
 
+    def dynamic_mlp_forward(self, enc, body_pose):
+        return self.nerf_scale_and_quaternion_net(enc, body_pose)
+
+    def non_rigid_transform(self, gaussians: GaussianOutput) -> GaussianOutput:
+        """avatar.py:1464-1498, default flags (element-wise torch; `animate` uses the fused kernel of assemble.hip instead)."""
+        gaussians.positions = gaussians.positions + gaussians.offsets * self.init_offset
+        gaussians.offsets = None
+        gaussians.scales = self.get_scales() + gaussians.scales * self.init_scale        # keyed by non_rigid_ROTATION_mode (Q4)
+        gaussians.quaternions = self.get_quaternions()
+        return gaussians
+
+    def forward(self):
+        return self.animate(None)
+
     def animate(self, smpl_observed_inputs: Optional[dict] = None) -> GaussianOutput:
+        """avatar.py:1500-1588."""
         if smpl_observed_inputs is None:
             smpl_observed_inputs = self.smpl_canonical_inputs
         if self._canonical_cache is None:           # canonical inputs never change: cache the skeleton pass
             self._canonical_cache = self.lbs_model.forward(**self.smpl_canonical_inputs)
-        ctr = self._canonical_cache
-        otr = self.lbs_model.forward(**smpl_observed_inputs)
+        _, cV, ctr = self._canonical_cache
+        _, oV, otr = self.lbs_model.forward(**smpl_observed_inputs)
         positions = self._positions
         canonical_positions = self.lbs_transform(positions, ctr)
         N = positions.shape[0]
+        if self.learn_betas:                         # avatar.py:1551-1553 (sub-stage 2.1: --render.learn_hand_betas True)
+            _, cVb, _ = self.lbs_model.forward(**self.smpl_canonical_inputs, extra_betas=self._betas)
+            _, oVb, _ = self.lbs_model.forward(**smpl_observed_inputs, extra_betas=self._betas)
         # mesh-bound parts first: their canonical positions go through the SAME encoder / static-MLP launches as the free
         # Gaussians (the reference calls the two networks once per part, avatar.py:1544-1583; the maths is row-wise, so one pass
         # over the concatenated rows gives the same values with half the launches and one table-gradient scatter)
         mesh_parts = []
-        for _name, gm in self.mesh_binding_gaussians.items():
-            vc = gm._vertex_coords
-            cvc = self._canonical_vertices.get(_name)
-            if cvc is None:                          # canonical pose and the bound vertices are fixed: transform once
-                cvc = self._canonical_vertices[_name] = self.lbs_model.transform_vertices(ctr, gm.predefined_vertex_indices, vc)
-            ovc = self.lbs_model.transform_vertices(otr, gm.predefined_vertex_indices, vc)
+        for name, gm in self.mesh_binding_gaussians.items():
+            vc = gm.get_vertex_coords()
+            with_betas = (name == 'hands' and self.learn_hand_betas) or (name == 'face' and self.learn_face_betas)
+            if with_betas:
+                cvc = cVb.squeeze(0).transform_points(vc, indices=gm.predefined_vertex_indices)
+                ovc = oVb.squeeze(0).transform_points(vc, indices=gm.predefined_vertex_indices)
+            else:
+                cvc = self._canonical_vertices.get(name)
+                if cvc is None:                      # canonical pose and the bound vertices are fixed: transform once
+                    cvc = self._canonical_vertices[name] = cV.squeeze(0).transform_points(vc, indices=gm.predefined_vertex_indices)
+                ovc = oV.squeeze(0).transform_points(vc, indices=gm.predefined_vertex_indices)
             mesh_parts.append(gm(cvc, ovc))          # (cpos, pos_m, sc_m, q_m): one HIP launch each way (csrc/meshbind.hip)
         all_cpos = torch.cat([canonical_positions] + [mp[0] for mp in mesh_parts], dim=0) if mesh_parts else canonical_positions
-        enc_all = self.nerf_encoder(all_cpos, bound=self.nerf_bound)
+        enc_all = self.nerf_encoder(all_cpos, bound=self._nerf_bound_host)
         oc_all = self.nerf_opacity_and_color_net(enc_all)                      # static_mlp_forward (avatar.py:1283-1290), all rows
         enc = enc_all[:N]
         body_pose = smpl_observed_inputs.get('body_pose')
         if body_pose is None:
             body_pose = torch.zeros(1, 63, device=positions.device)
-        offsets, mlp_scales, _mlp_quats = self.nerf_scale_and_quaternion_net(enc, body_pose)
+        offsets, mlp_scales, _mlp_quats = self.dynamic_mlp_forward(enc, body_pose)
         # non_rigid_transform (avatar.py:1464-1498, default flags) + the sigmoid / exp / normalize activations: one HIP launch
         pos, scales, quats, col_all, op_all = asm_ops.assemble(positions, offsets, self._scales, mlp_scales, self._quaternions, oc_all,
                                                                self.init_offset, self.init_scale)
-        pos, quats = self.lbs_transform(pos, otr, quats)
+        pos, quats = self.lbs_transform(pos, otr, quaternions=quats)
         if not mesh_parts:
             return GaussianOutput(positions=pos, opacities=op_all, colors=col_all, quaternions=quats, scales=scales)
         # merge_gaussians (gaussian_utils.py:56-68): colours / opacities already come out in the merged row order
         return GaussianOutput(positions=torch.cat([pos] + [mp[1] for mp in mesh_parts], dim=0), opacities=op_all, colors=col_all,
                               quaternions=torch.cat([quats] + [mp[3] for mp in mesh_parts], dim=0),
                               scales=torch.cat([scales] + [mp[2] for mp in mesh_parts], dim=0))
+
+    # -- optimizers (avatar.py:1590-1635) --------------------------------------------------------------------------------
+    def get_optimizer(self, cfg):
+        """Same dict of named optimizers as the reference: 'avatar' (GaussianOptimizer: positions / scales / quaternions with
+        the exponential position schedule), 'lbs' (betas / lbs weights when learned), 'nerf' (encoder 10x, both MLPs), 'mesh_<part>'.
+        Every one is a view of ONE flat fp32 parameter / gradient / moment buffer (optim.FlatAdam): the all-reduce operand of
+        the multi-view step and the operand of the fused Adam kernel."""
+        specs = {}
+        iterations = cfg.optim.iters
+        l = []
+        if self._positions.requires_grad:
+            l.append({'params': [self._positions], 'lr': cfg.render.position_lr_init, 'name': "positions"})
+        if self._scales.requires_grad:
+            l.append({'params': [self._scales], 'lr': cfg.render.scaling_lr, 'name': "scales"})
+        if self._quaternions.requires_grad:
+            l.append({'params': [self._quaternions], 'lr': cfg.render.rotation_lr, 'name': "quaternions"})
+        if l:
+            specs['avatar'] = optim.AdamSpec(l, eps=1e-15, gaussian=dict(
+                iterations=iterations, position_lr_init=cfg.render.position_lr_init, position_lr_final=cfg.render.position_lr_final,
+                position_lr_delay_mult=0.01, position_lr_max_steps=iterations * 2, scaling_lr=cfg.render.scaling_lr))
+        pl = []
+        if self.learn_lbs_weights:
+            pl.append({'params': [self._lbs_weights], 'lr': cfg.render.lbs_lr})
+        if self.learn_betas:
+            pl.append({'params': [self._betas], 'lr': cfg.render.betas_lr})
+        if pl:
+            specs['lbs'] = optim.AdamSpec(pl, eps=1e-8)                       # torch.optim.Adam defaults (avatar.py:1616)
+        nerf_lr = cfg.nerf.lr
+        specs['nerf'] = optim.AdamSpec([
+            {'params': list(self.nerf_encoder.parameters()), 'lr': nerf_lr * 10},
+            {'params': list(self.nerf_opacity_and_color_net.parameters()), 'lr': nerf_lr},
+            {'params': list(self.nerf_scale_and_quaternion_net.parameters()), 'lr': nerf_lr}], betas=(0.9, 0.99), eps=1e-15)
+        for model_name, gm in self.mesh_binding_gaussians.items():
+            specs.update(gm.get_optimizer(cfg=cfg, optimizer_name='mesh_' + model_name))
+        return optim.build_flat_optimizers(specs, self._positions.device)

@@ -47,19 +47,9 @@ __global__ __launch_bounds__(256) void k_joint_chain(int J, const float* __restr
     }
     __syncthreads();
     if (t < J) {
-        // Rodrigues with angle = |r + 1e-8| (smplx.lbs.batch_rodrigues)
-        float rx = pose[3 * t], ry = pose[3 * t + 1], rz = pose[3 * t + 2];
-        float ax = rx + 1e-8f, ay = ry + 1e-8f, az = rz + 1e-8f;
-        float angle = sqrtf(ax * ax + ay * ay + az * az);
-        float dx = rx / angle, dy = ry / angle, dz = rz / angle;
-        float s = sinf(angle), c = cosf(angle);
-        float K[9] = {0.f, -dz, dy, dz, 0.f, -dx, -dy, dx, 0.f};
         float R[9];
-        for (int r = 0; r < 3; r++)
-            for (int cc = 0; cc < 3; cc++) {
-                float kk = K[3 * r] * K[cc] + K[3 * r + 1] * K[3 + cc] + K[3 * r + 2] * K[6 + cc];
-                R[3 * r + cc] = (r == cc ? 1.f : 0.f) + s * K[3 * r + cc] + (1.f - c) * kk;
-            }
+        const float rv[3] = {pose[3 * t], pose[3 * t + 1], pose[3 * t + 2]};
+        dwg_rodrigues(rv, R);                // angle = |r + 1e-8| (smplx.lbs.batch_rodrigues)
         int p = parents[t];
         par[t] = p;
         float rel[3];
@@ -214,6 +204,86 @@ __global__ __launch_bounds__(256) void k_vertex_transform(int Vp, int J, int S, 
     }
 }
 
+// Backward of k_vertex_transform w.r.t. the shape coefficients (and the translation column of A): for a fixed pose the
+// transformed vertex is LINEAR in the coefficients,  v' = sum_j w_vj [Rg_j (x + S_v beta + P_v) + t_j(beta)],  so
+//   g_shape[l] += sum_v  S_v[:, l] . (T_v[:3,:3]^T g_v)            (this kernel, first term)
+//   g_At[j]    += sum_v  w_vj g_v                                  (this kernel; chained to beta by k_joint_chain_bwd)
+// Grid-stride over vertices, one wave per vertex; each lane keeps its coefficients' partial sums in registers, the block
+// combines its waves in LDS and issues one global atomic per coefficient.
+#define MAXS_PER_LANE 8          // S <= 512 shape coefficients
+__global__ __launch_bounds__(256) void k_vertex_transform_bwd(int Vp, int J, int S, const float* __restrict__ A,
+                                                              const float* __restrict__ w_sub, const float* __restrict__ sdirs,
+                                                              const float* __restrict__ g_out /*[Vp,3]*/,
+                                                              float* __restrict__ g_shape /*[S] accumulate*/,
+                                                              float* __restrict__ g_At /*[J,3] accumulate*/) {
+    __shared__ float sA[MAXJ * 12];
+    __shared__ float sS[512];
+    __shared__ float sT[MAXJ * 3];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    for (int k = tid; k < J * 12; k += 256) { int j = k / 12, e = k - j * 12; sA[k] = A[16 * j + e]; }
+    for (int k = tid; k < 512; k += 256) sS[k] = 0.f;
+    for (int k = tid; k < MAXJ * 3; k += 256) sT[k] = 0.f;
+    __syncthreads();
+    float acc[MAXS_PER_LANE];
+#pragma unroll
+    for (int u = 0; u < MAXS_PER_LANE; u++) acc[u] = 0.f;
+    for (int t = blockIdx.x * 4 + wave; t < Vp; t += gridDim.x * 4) {
+        float R[9];
+#pragma unroll
+        for (int e = 0; e < 9; e++) R[e] = 0.f;
+        const float* wr = w_sub + (size_t)t * J;
+        const float g0 = g_out[3 * t], g1 = g_out[3 * t + 1], g2 = g_out[3 * t + 2];
+        for (int j = lane; j < J; j += 64) {
+            const float wj = wr[j];
+#pragma unroll
+            for (int r = 0; r < 3; r++)
+#pragma unroll
+                for (int c = 0; c < 3; c++) R[3 * r + c] += wj * sA[j * 12 + 4 * r + c];
+            atomicAdd(&sT[3 * j], wj * g0); atomicAdd(&sT[3 * j + 1], wj * g1); atomicAdd(&sT[3 * j + 2], wj * g2);
+        }
+#pragma unroll
+        for (int e = 0; e < 9; e++) R[e] = dwg_wave_sum_all(R[e]);
+        const float gx0 = R[0] * g0 + R[3] * g1 + R[6] * g2, gx1 = R[1] * g0 + R[4] * g1 + R[7] * g2, gx2 = R[2] * g0 + R[5] * g1 + R[8] * g2;
+        if (sdirs) {
+            const float* sd = sdirs + (size_t)t * 3 * S;
+#pragma unroll
+            for (int u = 0; u < MAXS_PER_LANE; u++) {
+                const int l = lane + 64 * u;
+                if (l < S) acc[u] += sd[l] * gx0 + sd[S + l] * gx1 + sd[2 * S + l] * gx2;
+            }
+        }
+    }
+#pragma unroll
+    for (int u = 0; u < MAXS_PER_LANE; u++) {
+        const int l = lane + 64 * u;
+        if (l < S) atomicAdd(&sS[l], acc[u]);
+    }
+    __syncthreads();
+    for (int l = tid; l < S; l += 256) if (sS[l] != 0.f) atomicAdd(&g_shape[l], sS[l]);
+    for (int k = tid; k < J * 3; k += 256) if (sT[k] != 0.f) atomicAdd(&g_At[k], sT[k]);
+}
+
+// d loss / d A[:, :3, 3] -> d loss / d shape through the rest joints (one workgroup; the 55-joint chain is serial by nature and
+// runs on one lane, the final [3J, S]^T matvec on all of them).
+__global__ __launch_bounds__(256) void k_joint_chain_bwd(int J, const float* __restrict__ pose, const int* __restrict__ parents,
+                                                         const float* __restrict__ jdirs /*[J,3,S]*/, int S,
+                                                         const float* __restrict__ g_At /*[J,3]*/, float* __restrict__ g_shape) {
+    __shared__ float Rg[MAXJ * 9];
+    __shared__ float Gp[MAXJ * 3];
+    __shared__ float dJ[MAXJ * 3];
+    __shared__ int par[MAXJ];
+    const int tid = threadIdx.x;
+    if (tid < J) par[tid] = parents[tid];
+    __syncthreads();
+    if (tid == 0) dwg_joint_chain_rest_joint_bwd(J, pose, par, g_At, Rg, Gp, dJ);
+    __syncthreads();
+    for (int l = tid; l < S; l += 256) {
+        float v = 0.f;
+        for (int k = 0; k < 3 * J; k++) v += jdirs[(size_t)k * S + l] * dJ[k];
+        g_shape[l] += v;
+    }
+}
+
 }  // namespace
 
 extern "C" {
@@ -274,6 +344,27 @@ int dwg_lbs_vertex_transform(int32_t Vp, int32_t J, int32_t n_shape, int32_t n_p
     DWG_LAUNCH("lbs_vertex_transform", k_vertex_transform, dim3(dwg_cdiv(Vp, 4)), dim3(256), 0, (hipStream_t)stream, Vp, J, n_shape,
                posedirs_sub ? n_posefeat : 0, vertex_coords, A, lbs_weights_sub, shapedirs_sub, shape_coeffs, posedirs_sub, rot_mats,
                out);
+    DWG_RETURN_IF_LAUNCH_FAILED();
+    return DWG_OK;
+}
+
+int dwg_lbs_vertex_transform_backward_shape(int32_t Vp, int32_t J, int32_t n_shape, const float* A, const float* lbs_weights_sub,
+                                            const float* shapedirs_sub, const float* g_out, const float* pose, const int32_t* parents,
+                                            const float* joint_shape_dirs, float* g_A_transl_scratch, float* g_shape,
+                                            dwg_stream_t stream_) {
+    if (Vp < 0 || J <= 0 || J > MAXJ || n_shape <= 0 || n_shape > 64 * MAXS_PER_LANE) return DWG_E_ARG;
+    if (!A || !lbs_weights_sub || !shapedirs_sub || !g_out || !pose || !parents || !joint_shape_dirs || !g_A_transl_scratch || !g_shape)
+        return DWG_E_ARG;
+    hipStream_t stream = (hipStream_t)stream_;
+    if (hipMemsetAsync(g_shape, 0, sizeof(float) * (size_t)n_shape, stream) != hipSuccess) return DWG_E_LAUNCH;
+    if (hipMemsetAsync(g_A_transl_scratch, 0, sizeof(float) * 3 * (size_t)J, stream) != hipSuccess) return DWG_E_LAUNCH;
+    if (Vp > 0) {
+        int blocks = dwg_cdiv(Vp, 4); if (blocks > 64) blocks = 64;
+        DWG_LAUNCH("lbs_vertex_transform_bwd", k_vertex_transform_bwd, dim3(blocks), dim3(256), 0, stream, Vp, J, n_shape, A, lbs_weights_sub,
+                   shapedirs_sub, g_out, g_shape, g_A_transl_scratch);
+        DWG_LAUNCH("lbs_joint_chain_bwd", k_joint_chain_bwd, dim3(1), dim3(256), 0, stream, J, pose, parents, joint_shape_dirs, n_shape,
+                   (const float*)g_A_transl_scratch, g_shape);
+    }
     DWG_RETURN_IF_LAUNCH_FAILED();
     return DWG_OK;
 }

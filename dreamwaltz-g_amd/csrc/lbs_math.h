@@ -136,3 +136,57 @@ DWG_HD void dwg_lbs_apply_bwd(const float T12[12], const float p[3], const float
             }
     }
 }
+
+
+// ---------------------------------------------------------------------------------------------------------------------
+// Skeleton backward w.r.t. the REST joints (needed for `learn_hand_betas` / `learn_face_betas`: avatar.py:1551-1553; the joint
+// rotations do not depend on the shape coefficients, the rest joints do: J = J_template + (J_regressor . shapedirs) . betas).
+//   smplx.lbs.batch_rigid_transform:  rel_k = J_k - J_parent(k) (root: J_0);  Rg_k = Rg_parent R_k;  p_k = p_parent + Rg_parent rel_k;
+//                                     A_k = [Rg_k | p_k - Rg_k J_k]
+// Given g_t[k] = d loss / d A_k[:3, 3] this writes dJ[k] = d loss / d J_k (everything linear in J for fixed rotations).
+// ---------------------------------------------------------------------------------------------------------------------
+// Rodrigues with angle = |r + 1e-8| (smplx.lbs.batch_rodrigues)
+DWG_HD void dwg_rodrigues(const float r[3], float R[9]) {
+    float ax = r[0] + 1e-8f, ay = r[1] + 1e-8f, az = r[2] + 1e-8f;
+    float angle = sqrtf(ax * ax + ay * ay + az * az);
+    float dx = r[0] / angle, dy = r[1] / angle, dz = r[2] / angle;
+    float s = sinf(angle), c = cosf(angle);
+    float K[9] = {0.f, -dz, dy, dz, 0.f, -dx, -dy, dx, 0.f};
+    for (int a = 0; a < 3; a++)
+        for (int b = 0; b < 3; b++) {
+            float kk = K[3 * a] * K[b] + K[3 * a + 1] * K[3 + b] + K[3 * a + 2] * K[6 + b];
+            R[3 * a + b] = (a == b ? 1.f : 0.f) + s * K[3 * a + b] + (1.f - c) * kk;
+        }
+}
+
+// Rg [J][9] and Gp [J][3] are scratch.  parents[k] < k for k > 0.
+DWG_HD void dwg_joint_chain_rest_joint_bwd(int J, const float* pose /*[J,3]*/, const int* parents, const float* g_t /*[J,3]*/,
+                                           float* Rg, float* Gp, float* dJ /*[J,3]*/) {
+    for (int k = 0; k < J; k++) {
+        float R[9];
+        dwg_rodrigues(pose + 3 * k, R);
+        if (k == 0) { for (int e = 0; e < 9; e++) Rg[e] = R[e]; }
+        else {
+            const float* P = Rg + 9 * parents[k];
+            for (int a = 0; a < 3; a++)
+                for (int b = 0; b < 3; b++) Rg[9 * k + 3 * a + b] = P[3 * a] * R[b] + P[3 * a + 1] * R[3 + b] + P[3 * a + 2] * R[6 + b];
+        }
+        for (int c = 0; c < 3; c++) { Gp[3 * k + c] = g_t[3 * k + c]; dJ[3 * k + c] = 0.f; }
+    }
+    for (int k = J - 1; k > 0; k--)                      // d loss / d p_k: own term + every descendant's
+        for (int c = 0; c < 3; c++) Gp[3 * parents[k] + c] += Gp[3 * k + c];
+    for (int k = 0; k < J; k++) {
+        const float* Rk = Rg + 9 * k;
+        for (int c = 0; c < 3; c++)                      // t_k = p_k - Rg_k J_k
+            dJ[3 * k + c] -= Rk[c] * g_t[3 * k] + Rk[3 + c] * g_t[3 * k + 1] + Rk[6 + c] * g_t[3 * k + 2];
+        if (k == 0) {
+            for (int c = 0; c < 3; c++) dJ[c] += Gp[c];                      // p_0 = rel_0 = J_0
+        } else {
+            const float* P = Rg + 9 * parents[k];
+            for (int c = 0; c < 3; c++) {                // p_k = p_parent + Rg_parent (J_k - J_parent)
+                float g = P[c] * Gp[3 * k] + P[3 + c] * Gp[3 * k + 1] + P[6 + c] * Gp[3 * k + 2];
+                dJ[3 * k + c] += g; dJ[3 * parents[k] + c] -= g;
+            }
+        }
+    }
+}

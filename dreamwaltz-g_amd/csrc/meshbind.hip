@@ -74,7 +74,9 @@ __global__ __launch_bounds__(256) void k_meshbind_bwd(int M, int n_per, const fl
                                                       const float* __restrict__ vn, const int* __restrict__ tri,
                                                       const float* __restrict__ g_pos_c, const float* __restrict__ g_pos,
                                                       const float* __restrict__ g_scl, const float* __restrict__ g_quat,
-                                                      float* __restrict__ g_bary, float* __restrict__ g_sc) {
+                                                      float* __restrict__ g_bary, float* __restrict__ g_sc,
+                                                      float* __restrict__ g_vc /*[Vp,3] accumulate | null*/,
+                                                      float* __restrict__ g_vo, float* __restrict__ g_vn) {
     const int i = blockIdx.x * 256 + threadIdx.x;
     if (i >= M) return;
     const int* t = tri + 3 * (size_t)(i / n_per);
@@ -87,14 +89,72 @@ __global__ __launch_bounds__(256) void k_meshbind_bwd(int M, int n_per, const fl
     if (g_scl) { gs[0] = g_scl[3 * (size_t)i]; gs[1] = g_scl[3 * (size_t)i + 1]; gs[2] = g_scl[3 * (size_t)i + 2]; }
     if (g_quat) { gq[0] = g_quat[4 * (size_t)i]; gq[1] = g_quat[4 * (size_t)i + 1]; gq[2] = g_quat[4 * (size_t)i + 2]; gq[3] = g_quat[4 * (size_t)i + 3]; }
     float gb[3] = {0.f, 0.f, 0.f}, gsc[3];
-    dwg_meshbind_point_bwd(b, s, P, N, (float)n_per, gp, gs, gq, gb, gsc);
+    float gP[3][3] = {{0.f, 0.f, 0.f}, {0.f, 0.f, 0.f}, {0.f, 0.f, 0.f}}, gN[3][3] = {{0.f, 0.f, 0.f}, {0.f, 0.f, 0.f}, {0.f, 0.f, 0.f}};
+    const bool want_v = g_vo != nullptr;
+    dwg_meshbind_point_bwd(b, s, P, N, (float)n_per, gp, gs, gq, gb, gsc, want_v ? gP : nullptr, want_v ? gN : nullptr);
+    if (want_v) {
+#pragma unroll
+        for (int v = 0; v < 3; v++)
+#pragma unroll
+            for (int c = 0; c < 3; c++) {
+                atomicAdd(g_vo + 3 * (size_t)t[v] + c, gP[v][c]);
+                atomicAdd(g_vn + 3 * (size_t)t[v] + c, gN[v][c]);
+            }
+    }
     if (vc && g_pos_c) {
         gather3(vc, t, P);
         const float gc[3] = {g_pos_c[3 * (size_t)i], g_pos_c[3 * (size_t)i + 1], g_pos_c[3 * (size_t)i + 2]};
-        dwg_meshbind_position_bwd(b, P, gc, gb);
+        float gPc[3][3] = {{0.f, 0.f, 0.f}, {0.f, 0.f, 0.f}, {0.f, 0.f, 0.f}};
+        dwg_meshbind_position_bwd(b, P, gc, gb, g_vc ? gPc : nullptr);
+        if (g_vc) {
+#pragma unroll
+            for (int v = 0; v < 3; v++)
+#pragma unroll
+                for (int c = 0; c < 3; c++) atomicAdd(g_vc + 3 * (size_t)t[v] + c, gPc[v][c]);
+        }
     }
 #pragma unroll
     for (int c = 0; c < 3; c++) { g_bary[3 * (size_t)i + c] = gb[c]; g_sc[3 * (size_t)i + c] = gsc[c]; }
+}
+
+// Backward of k_vertex_normals / k_face_normals: g_vn [Vp,3] -> gradient of the summed face normals per vertex (g_s), then per
+// face the sum over its corners, the face-normal chain and a scatter to the three corner positions.
+__global__ __launch_bounds__(256) void k_vertex_normals_bwd_sum(int Vp, const float* __restrict__ fn, const int* __restrict__ vf_off,
+                                                                const int* __restrict__ vf_faces, const float* __restrict__ g_vn,
+                                                                float* __restrict__ g_s) {
+    const int v = blockIdx.x * 256 + threadIdx.x;
+    if (v >= Vp) return;
+    float n[3] = {0.f, 0.f, 0.f};
+    for (int e = vf_off[v]; e < vf_off[v + 1]; e++) {
+        const float* f = fn + 3 * (size_t)vf_faces[e];
+        n[0] += f[0]; n[1] += f[1]; n[2] += f[2];
+    }
+    float g[3] = {0.f, 0.f, 0.f};
+    if (dwg_mb_dot(n, n) > 1e-20f) {          // otherwise the normal is the constant (0,0,1): no gradient
+        const float gy[3] = {g_vn[3 * v], g_vn[3 * v + 1], g_vn[3 * v + 2]};
+        dwg_mb_safe_normalize_bwd(n, gy, g);
+    }
+    g_s[3 * v] = g[0]; g_s[3 * v + 1] = g[1]; g_s[3 * v + 2] = g[2];
+}
+
+__global__ __launch_bounds__(256) void k_face_normals_bwd(int Fp, const float* __restrict__ verts, const int* __restrict__ tri,
+                                                          const float* __restrict__ g_s, float* __restrict__ g_verts) {
+    const int f = blockIdx.x * 256 + threadIdx.x;
+    if (f >= Fp) return;
+    const int ia = tri[3 * f], ib = tri[3 * f + 1], ic = tri[3 * f + 2];
+    const float* a = verts + 3 * (size_t)ia; const float* b = verts + 3 * (size_t)ib; const float* c = verts + 3 * (size_t)ic;
+    float gfn[3];
+#pragma unroll
+    for (int k = 0; k < 3; k++) gfn[k] = g_s[3 * (size_t)ia + k] + g_s[3 * (size_t)ib + k] + g_s[3 * (size_t)ic + k];
+    float ga[3], gb[3], gc[3];
+    const float av[3] = {a[0], a[1], a[2]}, bv[3] = {b[0], b[1], b[2]}, cv[3] = {c[0], c[1], c[2]};
+    dwg_mb_face_normal_bwd(av, bv, cv, gfn, ga, gb, gc);
+#pragma unroll
+    for (int k = 0; k < 3; k++) {
+        atomicAdd(g_verts + 3 * (size_t)ia + k, ga[k]);
+        atomicAdd(g_verts + 3 * (size_t)ib + k, gb[k]);
+        atomicAdd(g_verts + 3 * (size_t)ic + k, gc[k]);
+    }
 }
 
 }  // namespace
@@ -139,7 +199,42 @@ int dwg_meshbind_backward(int32_t Fp, int32_t n_per_tri, const float* bary, cons
     if (g_pos_cnl && !verts_cnl) return DWG_E_ARG;
     const int M = Fp * n_per_tri;
     DWG_LAUNCH("meshbind_bwd", k_meshbind_bwd, dim3(dwg_cdiv(M, 256)), dim3(256), 0, (hipStream_t)stream_, M, n_per_tri, bary, scale_params,
-               verts_cnl, verts_obs, vnormals_obs, triangles, g_pos_cnl, g_pos, g_scales, g_quats, g_bary, g_scale_params);
+               verts_cnl, verts_obs, vnormals_obs, triangles, g_pos_cnl, g_pos, g_scales, g_quats, g_bary, g_scale_params,
+               (float*)nullptr, (float*)nullptr, (float*)nullptr);
+    DWG_RETURN_IF_LAUNCH_FAILED();
+    return DWG_OK;
+}
+
+int dwg_meshbind_backward_verts(int32_t Fp, int32_t n_per_tri, const float* bary, const float* scale_params, const float* verts_cnl,
+                                const float* verts_obs, const float* vnormals_obs, const int32_t* triangles, const float* g_pos_cnl,
+                                const float* g_pos, const float* g_scales, const float* g_quats, float* g_bary, float* g_scale_params,
+                                float* g_verts_cnl, float* g_verts_obs, float* g_vnormals_obs, dwg_stream_t stream_) {
+    if (Fp < 0 || n_per_tri <= 0) return DWG_E_ARG;
+    if (Fp == 0) return DWG_OK;
+    if (!bary || !scale_params || !verts_obs || !vnormals_obs || !triangles || !g_bary || !g_scale_params) return DWG_E_ARG;
+    if (!g_verts_obs || !g_vnormals_obs) return DWG_E_ARG;
+    if (g_pos_cnl && !verts_cnl) return DWG_E_ARG;
+    const int M = Fp * n_per_tri;
+    DWG_LAUNCH("meshbind_bwd", k_meshbind_bwd, dim3(dwg_cdiv(M, 256)), dim3(256), 0, (hipStream_t)stream_, M, n_per_tri, bary, scale_params,
+               verts_cnl, verts_obs, vnormals_obs, triangles, g_pos_cnl, g_pos, g_scales, g_quats, g_bary, g_scale_params, g_verts_cnl,
+               g_verts_obs, g_vnormals_obs);
+    DWG_RETURN_IF_LAUNCH_FAILED();
+    return DWG_OK;
+}
+
+int dwg_mesh_vertex_normals_backward(int32_t Vp, int32_t Fp, const float* verts, const int32_t* triangles, const int32_t* vf_offsets,
+                                     const int32_t* vf_faces, const float* g_vertex_normals, float* face_normals_scratch,
+                                     float* g_sum_scratch, float* g_verts, dwg_stream_t stream_) {
+    if (Vp < 0 || Fp < 0) return DWG_E_ARG;
+    if (Vp == 0 || Fp == 0) return DWG_OK;
+    if (!verts || !triangles || !vf_offsets || !vf_faces || !g_vertex_normals || !face_normals_scratch || !g_sum_scratch || !g_verts)
+        return DWG_E_ARG;
+    hipStream_t stream = (hipStream_t)stream_;
+    DWG_LAUNCH("mesh_face_normals", k_face_normals, dim3(dwg_cdiv(Fp, 256)), dim3(256), 0, stream, Fp, verts, triangles, face_normals_scratch);
+    DWG_LAUNCH("mesh_vertex_normals_bwd", k_vertex_normals_bwd_sum, dim3(dwg_cdiv(Vp, 256)), dim3(256), 0, stream, Vp,
+               (const float*)face_normals_scratch, vf_offsets, vf_faces, g_vertex_normals, g_sum_scratch);
+    DWG_LAUNCH("mesh_face_normals_bwd", k_face_normals_bwd, dim3(dwg_cdiv(Fp, 256)), dim3(256), 0, stream, Fp, verts, triangles,
+               (const float*)g_sum_scratch, g_verts);
     DWG_RETURN_IF_LAUNCH_FAILED();
     return DWG_OK;
 }

@@ -76,20 +76,23 @@ DWG_HD void dwg_meshbind_position(const float b[3], const float P[3][3], float p
     const float S = b[0] + b[1] + b[2];
     for (int i = 0; i < 3; i++) pos[i] = (b[0] / S) * P[0][i] + (b[1] / S) * P[1][i] + (b[2] / S) * P[2][i];
 }
-// adds the gradient of dwg_meshbind_position w.r.t. b into gb
-DWG_HD void dwg_meshbind_position_bwd(const float b[3], const float P[3][3], const float gpos[3], float gb[3]) {
+// adds the gradient of dwg_meshbind_position w.r.t. b into gb and, when gP is given, w.r.t. the three vertices into gP
+DWG_HD void dwg_meshbind_position_bwd(const float b[3], const float P[3][3], const float gpos[3], float gb[3], float (*gP)[3]) {
     const float S = b[0] + b[1] + b[2];
     float gbn[3], mix = 0.f;
     for (int v = 0; v < 3; v++) { gbn[v] = dwg_mb_dot(gpos, P[v]); mix += gbn[v] * (b[v] / S); }
     for (int v = 0; v < 3; v++) gb[v] += (gbn[v] - mix) / S;
+    if (gP) for (int v = 0; v < 3; v++) for (int i = 0; i < 3; i++) gP[v][i] += (b[v] / S) * gpos[i];
 }
 
 DWG_HD float dwg_mb_sign(float x) { return x > 0.f ? 1.f : (x < 0.f ? -1.f : 0.f); }
 
-// Backward of dwg_meshbind_point w.r.t. b and sc (the vertices / normals are produced under no_grad: avatar.py:1570-1577).
-// gb is ACCUMULATED into (the canonical-position gradient shares it); gsc is written.
+// Backward of dwg_meshbind_point w.r.t. b and sc and -- when gP / gN are given (learn_*_betas: the posed vertices then depend
+// on a learnable parameter, avatar.py:1551-1577) -- w.r.t. the triangle's vertices and vertex normals.
+// gb, gP, gN are ACCUMULATED into (the canonical-position gradient shares gb); gsc is written.
 DWG_HD void dwg_meshbind_point_bwd(const float b[3], const float sc[3], const float P[3][3], const float Nv[3][3], float n_per_tri,
-                                   const float gpos_in[3], const float gscl[3], const float gquat[4], float gb[3], float gsc[3]) {
+                                   const float gpos_in[3], const float gscl[3], const float gquat[4], float gb[3], float gsc[3],
+                                   float (*gP)[3], float (*gN)[3]) {
     const float ref[3] = {1.f, 0.f, 0.f};
     const float sg[3] = {1.f, -1.f, -1.f};
     const float S = b[0] + b[1] + b[2];
@@ -117,6 +120,7 @@ DWG_HD void dwg_meshbind_point_bwd(const float b[3], const float sc[3], const fl
         for (int i = 0; i < 3; i++) {
             gv1[i] += s1 * d[i]; gv2[i] += s2 * d[i];
             gpos[i] -= s1 * f.v1[i] + s2 * f.v2[i];
+            if (gP) gP[k][i] += s1 * f.v1[i] + s2 * f.v2[i];
         }
     }
     gsc[0] = 0.f;
@@ -131,5 +135,31 @@ DWG_HD void dwg_meshbind_point_bwd(const float b[3], const float sc[3], const fl
     dwg_mb_cross(ref, gc1, t); for (int i = 0; i < 3; i++) gv0[i] += t[i];
     dwg_mb_unit_bwd(f.pn, f.n0, gv0, gpn);
     for (int v = 0; v < 3; v++) gb[v] += dwg_mb_dot(gpn, Nv[v]);
-    dwg_meshbind_position_bwd(b, P, gpos, gb);
+    if (gN) for (int v = 0; v < 3; v++) for (int i = 0; i < 3; i++) gN[v][i] += b[v] * gpn[i];
+    dwg_meshbind_position_bwd(b, P, gpos, gb, gP);
+}
+
+// ---- vertex normals (utils/mesh.py:34-94) backward pieces ----
+// y = x / sqrt(max(x.x, 1e-20)) (safe_normalize): gx from gy
+DWG_HD void dwg_mb_safe_normalize_bwd(const float x[3], const float gy[3], float gx[3]) {
+    const float n2 = dwg_mb_dot(x, x);
+    if (n2 > 1e-20f) {
+        const float inv = 1.f / sqrtf(n2);
+        const float y[3] = {x[0] * inv, x[1] * inv, x[2] * inv};
+        const float d = dwg_mb_dot(y, gy);
+        for (int i = 0; i < 3; i++) gx[i] = (gy[i] - y[i] * d) * inv;
+    } else {
+        for (int i = 0; i < 3; i++) gx[i] = gy[i] * 1e10f;          // clamp active: d/dx (x / 1e-10)
+    }
+}
+// face normal fn = safe_normalize((b - a) x (c - a)): gradient w.r.t. the three corners from g_fn
+DWG_HD void dwg_mb_face_normal_bwd(const float a[3], const float b[3], const float c[3], const float gfn[3], float ga[3], float gb_[3],
+                                   float gc[3]) {
+    const float e1[3] = {b[0] - a[0], b[1] - a[1], b[2] - a[2]}, e2[3] = {c[0] - a[0], c[1] - a[1], c[2] - a[2]};
+    float n[3], gn[3], ge1[3], ge2[3];
+    dwg_mb_cross(e1, e2, n);
+    dwg_mb_safe_normalize_bwd(n, gfn, gn);
+    dwg_mb_cross(e2, gn, ge1);        // d/da (a x b) . g = b x g
+    dwg_mb_cross(gn, e1, ge2);        // d/db (a x b) . g = g x a
+    for (int i = 0; i < 3; i++) { ga[i] = -(ge1[i] + ge2[i]); gb_[i] = ge1[i]; gc[i] = ge2[i]; }
 }

@@ -2,29 +2,46 @@
 //
 // Replaces the third-party CUDA extension the reference calls at
 //   /root/reference/core/gaussian/gaussian_renderer.py:186-195 (forward) and its autograd backward
-// (boundary B1).  Written from the algorithm, not from the CUDA sources:
+// (boundary B1).  Written from the algorithm, not from the CUDA sources.
 //
-//   stage A  k_preprocess      1 thread / Gaussian: project, EWA covariance, 3-sigma radius, tile rect,
-//                              48-byte splat record (3 x float4, 16-B aligned gathers), per-tile histogram
-//            k_scan_tiles      one workgroup: exclusive scan of the <= few-thousand tile counters
-//   stage B  k_scatter         1 thread / Gaussian: (depth|id) 64-bit key into its tiles' segments
-//            k_tile_sort       1 workgroup / tile: ascending-only bitonic network on the tile's keys in LDS
-//                              (no global radix sort: keys never leave the chip between read and write)
-//            k_render_fwd      1 workgroup (4 x wave64) / 16x16 tile, splat records staged through LDS
-//   backward k_render_bwd      back-to-front replay; per-splat partial gradients are reduced across the
-//                              wavefront with DPP adds, across the 4 waves in LDS, then ONE global atomic per
-//                              (splat,tile,component)
+// Semantics are the reference's: a pixel composites, in (depth, id) order, every Gaussian whose 3-sigma square touches the
+// pixel's 16x16 screen tile.  The WORK decomposition is not the reference's:
+//
+//   * one wave64 owns one 8x8 pixel block (a quarter of a reference tile): per-block lists are ~2x shorter than per-tile
+//     lists, the forward needs no barrier, and the backward reduces per-splat partials with DPP adds inside ONE wave;
+//   * exact pair culling: a (Gaussian, block) pair is only emitted if some pixel of the block can reach alpha >= 1/255
+//     (minimum of the conic's quadratic form over the block rectangle against 2 ln(255 opacity), with a safety margin far
+//     above fp32 rounding) -- pairs the per-pixel test would reject for all 64 pixels never exist, results are unchanged;
+//   * per-block depth sort: ascending-only bitonic network on 64-bit (depth bits, id) keys in LDS, dispatched by size class
+//     (one wave per block up to 1024 pairs, one 256-thread workgroup up to 4096, one 1024-thread workgroup up to 16384);
+//   * the forward checkpoints the per-pixel compositing state every SEG splats; the backward then runs one wave per
+//     (block, segment) FRONT-TO-BACK from its checkpoint -- perfectly balanced, no serial chain over a long list -- using
+//     "sum over later splats" = (final sum) - (prefix sum);
+//   * blocks are rendered longest-list-first (bucketed by log2 of the list length).
+//
+//   stage A  k_preprocess      1 thread / Gaussian: project, EWA covariance, 3-sigma radius, tile rect, 48-byte splat record
+//                              (3 x float4, 16-B aligned gathers), exact-culled per-block histogram (LDS-privatised)
+//            k_scan_tiles      one workgroup: exclusive scans (pairs, segments), size-class lists, render order
+//   stage B  k_scatter         1 thread / Gaussian: (depth|id) 64-bit key into its blocks' ranges
+//            k_tile_sort       bitonic network per block, by size class
+//            k_render_fwd      1 wave / block, records staged through LDS, next batch prefetched into registers
+//   backward k_render_bwd      1 wave / (block, segment), one global atomic per (splat, block, component)
 //            k_preprocess_bwd  1 thread / Gaussian: conic -> cov2D -> cov3D -> (scale, quaternion), mean chain
-//
-// Compositing order inside a tile: ascending (depth bits, Gaussian id) -- same tie-break as a stable sort.
 #include "dwg_common.h"
 #include "dwg_prof_internal.h"
 #include "../../include/dwg_raster.h"
 
 namespace {
 
+#define RT 16            // the reference's tile edge: decides WHICH Gaussians a pixel sees
+#define BT 8             // pixel-block edge of this implementation (one wave64)
+#define SEG 128          // splats per backward segment / forward checkpoint interval
+#define NCLASS 4         // sort size classes
+#define NBUCKET 20       // render-order buckets (log2 of the list length)
+
 struct Params {
-    int G, H, W, tiles_x, tiles_y;
+    int G, H, W, tiles_x, tiles_y;      // tiles_* count 8x8 BLOCKS
+    int rtiles_x, rtiles_y;             // reference 16x16 tiles
     float tanfovx, tanfovy, focal_x, focal_y, scale_mod;
     int sh_degree, sh_coeffs;
     const float* bg;
@@ -33,13 +50,16 @@ struct Params {
     const float* campos;
 };
 
+// header words of the geometry workspace
+enum { H_K = 0, H_OVERFLOW = 1, H_KREF = 2, H_NSEG = 3, H_CLASS0 = 4 /* .. +NCLASS */ };
+
 struct GeomLayout {
-    size_t header, rec0, rec1, rec2, rect, tile_count, tile_start, tile_cursor, total;
+    size_t header, rec0, rec1, rec2, rect, tile_count, tile_cursor, tile_start, seg_start, tile_neff, order, cls, total;
 };
 
 static GeomLayout geom_layout(int G, int H, int W) {
     GeomLayout L;
-    size_t T = (size_t)dwg_cdiv(W, DWG_TILE) * dwg_cdiv(H, DWG_TILE);
+    size_t T = (size_t)dwg_cdiv(W, BT) * dwg_cdiv(H, BT);
     size_t g = (size_t)(G > 0 ? G : 1);
     size_t o = 0;
     L.header = o; o += 256;
@@ -47,23 +67,35 @@ static GeomLayout geom_layout(int G, int H, int W) {
     L.rec1 = o; o = dwg_align_up(o + g * sizeof(float4), 256);
     L.rec2 = o; o = dwg_align_up(o + g * sizeof(float4), 256);
     L.rect = o; o = dwg_align_up(o + g * sizeof(uint2), 256);
-    L.tile_count = o; o = dwg_align_up(o + T * 4, 256);
+    L.tile_count = o; o = dwg_align_up(o + T * 4, 256);      // tile_count and tile_cursor are cleared together
     L.tile_cursor = o; o = dwg_align_up(o + T * 4, 256);
     L.tile_start = o; o = dwg_align_up(o + (T + 1) * 4, 256);
+    L.seg_start = o; o = dwg_align_up(o + (T + 1) * 4, 256);
+    L.tile_neff = o; o = dwg_align_up(o + T * 4, 256);
+    L.order = o; o = dwg_align_up(o + T * 4, 256);
+    L.cls = o; o = dwg_align_up(o + (size_t)NCLASS * T * 4, 256);
     L.total = o;
     return L;
 }
 
-struct PairLayout { size_t keys, sorted, total; };
-static PairLayout pair_layout(int64_t cap) {
+static int64_t seg_capacity(int64_t cap, int H, int W) {
+    return cap / SEG + (int64_t)dwg_cdiv(W, BT) * dwg_cdiv(H, BT) + 1;
+}
+struct PairLayout { size_t keys, sorted, seg_tile, ckpt, total; };
+static PairLayout pair_layout(int64_t cap, int H, int W) {
     PairLayout L; size_t c = (size_t)(cap > 0 ? cap : 1);
-    L.keys = 0; L.sorted = dwg_align_up(c * 8, 256); L.total = dwg_align_up(L.sorted + c * 4, 256);
+    size_t ns = (size_t)seg_capacity((int64_t)c, H, W);
+    L.keys = 0; L.sorted = dwg_align_up(c * 8, 256);
+    L.seg_tile = dwg_align_up(L.sorted + c * 4, 256);
+    L.ckpt = dwg_align_up(L.seg_tile + ns * 4, 256);
+    L.total = dwg_align_up(L.ckpt + ns * 6 * 64 * sizeof(float), 256);
     return L;
 }
-struct ImageLayout { size_t final_T, n_contrib, total; };
+struct ImageLayout { size_t final_T, n_contrib, craw, total; };
 static ImageLayout image_layout(int H, int W) {
     ImageLayout L; size_t P = (size_t)H * W;
-    L.final_T = 0; L.n_contrib = dwg_align_up(P * 4, 256); L.total = dwg_align_up(L.n_contrib + P * 4, 256);
+    L.final_T = 0; L.n_contrib = dwg_align_up(P * 4, 256); L.craw = dwg_align_up(L.n_contrib + P * 4, 256);
+    L.total = dwg_align_up(L.craw + 5 * P * 4, 256);      // un-composited C (3), D, A totals
     return L;
 }
 
@@ -194,6 +226,31 @@ __device__ float3 sh_color(int deg, int M, const float* sh, float3 pos, const fl
 }
 
 // ------------------------------------------------------------------------------------------------
+// exact (Gaussian, block) culling
+// ------------------------------------------------------------------------------------------------
+// A splat contributes to a pixel iff power <= 0 and min(0.99, opacity * exp(power)) >= 1/255, i.e. iff the conic's quadratic form
+// q(d) = a dx^2 + 2 b dx dy + c dy^2 is <= 2 ln(255 opacity).  The margin (1e-4 relative + 1e-3 absolute on q, i.e. 5e-4 relative
+// on alpha) is hundreds of times the fp32 rounding of the per-pixel evaluation, so no contributing pair is ever dropped.
+__device__ __forceinline__ float cull_threshold(float opacity) {
+    return 2.f * logf(255.f * opacity) * (1.f + 1e-4f) + 1e-3f;      // NaN for opacity <= 0: every comparison below then keeps the pair
+}
+// minimum of q over the rectangle of pixel centres of block (bx, by), compared with thr; true = keep the pair
+__device__ __forceinline__ bool block_touch(float gx, float gy, float ca, float cb, float cc, float thr, int bx, int by) {
+    if (!(ca > 0.f) || !(cc > 0.f) || !(ca * cc - cb * cb > 0.f)) return true;      // not positive definite: no culling
+    const float x0 = (float)(bx * BT) - gx, x1 = x0 + (float)(BT - 1), y0 = (float)(by * BT) - gy, y1 = y0 + (float)(BT - 1);
+    if (x0 <= 0.f && x1 >= 0.f && y0 <= 0.f && y1 >= 0.f) return !(0.f > thr);
+    float qm = 3.0e38f;
+    const float ky = -cb / cc, kx = -cb / ca;
+    {
+        float y = fminf(y1, fmaxf(y0, ky * x0)); qm = fminf(qm, ca * x0 * x0 + 2.f * cb * x0 * y + cc * y * y);
+        y = fminf(y1, fmaxf(y0, ky * x1));       qm = fminf(qm, ca * x1 * x1 + 2.f * cb * x1 * y + cc * y * y);
+        float x = fminf(x1, fmaxf(x0, kx * y0)); qm = fminf(qm, ca * x * x + 2.f * cb * x * y0 + cc * y0 * y0);
+        x = fminf(x1, fmaxf(x0, kx * y1));       qm = fminf(qm, ca * x * x + 2.f * cb * x * y1 + cc * y1 * y1);
+    }
+    return !(qm > thr);
+}
+
+// ------------------------------------------------------------------------------------------------
 // stage A
 // ------------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void k_preprocess(Params p, const float* __restrict__ means3D,
@@ -202,9 +259,10 @@ __global__ __launch_bounds__(256) void k_preprocess(Params p, const float* __res
                                                     const float* __restrict__ rots, const float* __restrict__ cov3Dp,
                                                     int* __restrict__ radii, float4* __restrict__ rec0,
                                                     float4* __restrict__ rec1, float4* __restrict__ rec2,
-                                                    uint2* __restrict__ rect, uint32_t* __restrict__ tile_count, int use_lds_hist) {
+                                                    uint2* __restrict__ rect, uint32_t* __restrict__ tile_count,
+                                                    int32_t* __restrict__ header, int use_lds_hist) {
     __shared__ float cam[32];
-    extern __shared__ uint32_t hist[];      // [T] block-private tile histogram (hot tiles: one global atomic per block, not per splat)
+    extern __shared__ uint32_t hist[];      // [T] block-private histogram (hot blocks: one global atomic per workgroup, not per splat)
     const int T = p.tiles_x * p.tiles_y;
     if (threadIdx.x < 16) cam[threadIdx.x] = p.view[threadIdx.x];
     else if (threadIdx.x < 32) cam[threadIdx.x] = p.proj[threadIdx.x - 16];
@@ -218,6 +276,7 @@ __global__ __launch_bounds__(256) void k_preprocess(Params p, const float* __res
     int radius = 0;
     uint2 rc = make_uint2(0u, 0u);
     float4 r0 = make_float4(0.f, 0.f, 0.f, 0.f), r1 = r0, r2 = r0;
+    float kref = 0.f;
     float3 pv = xform43(view, pos);
     if (live_thread && pv.z > 0.2f) {
         float4 ph = xform44(proj, pos);
@@ -235,23 +294,28 @@ __global__ __launch_bounds__(256) void k_preprocess(Params p, const float* __res
             int rad = (int)ceilf(3.f * sqrtf(lm));
             float px = ((ndcx + 1.f) * p.W - 1.f) * 0.5f;
             float py = ((ndcy + 1.f) * p.H - 1.f) * 0.5f;
-            int tx0 = min(p.tiles_x, max(0, (int)((px - rad) / DWG_TILE)));
-            int ty0 = min(p.tiles_y, max(0, (int)((py - rad) / DWG_TILE)));
-            int tx1 = min(p.tiles_x, max(0, (int)((px + rad + DWG_TILE - 1) / DWG_TILE)));
-            int ty1 = min(p.tiles_y, max(0, (int)((py + rad + DWG_TILE - 1) / DWG_TILE)));
+            int tx0 = min(p.rtiles_x, max(0, (int)((px - rad) / RT)));
+            int ty0 = min(p.rtiles_y, max(0, (int)((py - rad) / RT)));
+            int tx1 = min(p.rtiles_x, max(0, (int)((px + rad + RT - 1) / RT)));
+            int ty1 = min(p.rtiles_y, max(0, (int)((py + rad + RT - 1) / RT)));
             if ((tx1 - tx0) * (ty1 - ty0) > 0) {
                 radius = rad;
                 rc = make_uint2((unsigned)tx0 | ((unsigned)ty0 << 16), (unsigned)tx1 | ((unsigned)ty1 << 16));
+                kref = (float)((tx1 - tx0) * (ty1 - ty0));
                 float3 col; unsigned cb = 0;
                 if (colors) col = make_float3(colors[3 * i], colors[3 * i + 1], colors[3 * i + 2]);
                 else col = sh_color(p.sh_degree, p.sh_coeffs, shs + (size_t)i * p.sh_coeffs * 3, pos, p.campos, &cb);
-                r0 = make_float4(px, py, pv.z, opac[i]);
+                const float op = opac[i];
+                r0 = make_float4(px, py, pv.z, op);
                 r1 = make_float4(e.c * di, -e.b * di, e.a * di, 0.f);
                 r2 = make_float4(col.x, col.y, col.z, __uint_as_float(cb));
-                for (int ty = ty0; ty < ty1; ty++)
-                    for (int tx = tx0; tx < tx1; tx++) {
-                        if (use_lds_hist) atomicAdd(&hist[ty * p.tiles_x + tx], 1u);
-                        else atomicAdd(&tile_count[ty * p.tiles_x + tx], 1u);
+                const float thr = cull_threshold(op);
+                const int bx1 = min(2 * tx1, p.tiles_x), by1 = min(2 * ty1, p.tiles_y);
+                for (int by = 2 * ty0; by < by1; by++)
+                    for (int bx = 2 * tx0; bx < bx1; bx++) {
+                        if (!block_touch(px, py, r1.x, r1.y, r1.z, thr, bx, by)) continue;
+                        if (use_lds_hist) atomicAdd(&hist[by * p.tiles_x + bx], 1u);
+                        else atomicAdd(&tile_count[by * p.tiles_x + bx], 1u);
                     }
             }
         }
@@ -261,77 +325,113 @@ __global__ __launch_bounds__(256) void k_preprocess(Params p, const float* __res
         rect[i] = rc;
         rec0[i] = r0; rec1[i] = r1; rec2[i] = r2;
     }
+    kref = dwg_wave_sum_to_lane63(kref);
+    if ((threadIdx.x & 63) == 63 && kref > 0.f) atomicAdd(&header[H_KREF], (int32_t)kref);
     if (use_lds_hist) {
         __syncthreads();
         for (int t = threadIdx.x; t < T; t += 256) { uint32_t c = hist[t]; if (c) atomicAdd(&tile_count[t], c); }
     }
 }
 
-// one workgroup of 1024 threads: exclusive scan of T tile counters
-__global__ __launch_bounds__(1024) void k_scan_tiles(int T, const uint32_t* __restrict__ tile_count,
-                                                     uint32_t* __restrict__ tile_start, int32_t* __restrict__ header) {
-    __shared__ uint32_t part[1024];
-    int tid = threadIdx.x;
-    int chunk = (T + 1023) / 1024;
-    int lo = tid * chunk, hi = min(T, lo + chunk);
-    uint32_t s = 0;
-    for (int t = lo; t < hi; t++) s += tile_count[t];
-    part[tid] = s;
+__device__ __forceinline__ int sort_class_of(uint32_t n) { return n <= 1024u ? 0 : (n <= 4096u ? 1 : (n <= 16384u ? 2 : 3)); }
+
+// one workgroup of 1024 threads: exclusive scans of the pair and segment counts, size-class lists, render order
+__global__ __launch_bounds__(1024) void k_scan_tiles(int T, const uint32_t* __restrict__ tile_count, uint32_t* __restrict__ tile_start,
+                                                     uint32_t* __restrict__ seg_start, uint32_t* __restrict__ cls,
+                                                     uint32_t* __restrict__ order, int32_t* __restrict__ header) {
+    __shared__ uint32_t part[1024], parts[1024];
+    __shared__ uint32_t cls_cnt[NCLASS], bkt_cnt[NBUCKET], bkt_base[NBUCKET];
+    const int tid = threadIdx.x;
+    if (tid < NCLASS) cls_cnt[tid] = 0u;
+    if (tid < NBUCKET) bkt_cnt[tid] = 0u;
+    const int chunk = (T + 1023) / 1024;
+    const int lo = tid * chunk, hi = min(T, lo + chunk);
+    uint32_t s = 0, ss = 0;
+    for (int t = lo; t < hi; t++) { uint32_t n = tile_count[t]; s += n; ss += (n + SEG - 1) / SEG; }
+    part[tid] = s; parts[tid] = ss;
     __syncthreads();
     for (int off = 1; off < 1024; off <<= 1) {
-        uint32_t v = tid >= off ? part[tid - off] : 0u;
+        uint32_t v = tid >= off ? part[tid - off] : 0u, vs = tid >= off ? parts[tid - off] : 0u;
         __syncthreads();
-        part[tid] += v;
+        part[tid] += v; parts[tid] += vs;
         __syncthreads();
     }
-    uint32_t run = part[tid] - s;  // exclusive prefix of this chunk
-    for (int t = lo; t < hi; t++) { tile_start[t] = run; run += tile_count[t]; }
-    if (tid == 1023) { tile_start[T] = part[1023]; header[0] = (int32_t)part[1023]; header[1] = 0; }
+    uint32_t run = part[tid] - s, runs = parts[tid] - ss;
+    for (int t = lo; t < hi; t++) {
+        const uint32_t n = tile_count[t];
+        tile_start[t] = run; seg_start[t] = runs;
+        run += n; runs += (n + SEG - 1) / SEG;
+        if (n) { const int c = sort_class_of(n); cls[(size_t)c * T + atomicAdd(&cls_cnt[c], 1u)] = (uint32_t)t; }
+        atomicAdd(&bkt_cnt[n ? min(NBUCKET - 1, 32 - __clz((int)n)) : 0], 1u);
+    }
+    if (tid == 1023) {
+        tile_start[T] = part[1023]; seg_start[T] = parts[1023];
+        header[H_K] = (int32_t)part[1023]; header[H_OVERFLOW] = 0; header[H_NSEG] = (int32_t)parts[1023];
+    }
+    __syncthreads();
+    if (tid == 0) {
+        uint32_t b = 0;
+        for (int k = NBUCKET - 1; k >= 0; k--) { bkt_base[k] = b; b += bkt_cnt[k]; bkt_cnt[k] = 0u; }     // longest lists first
+        for (int c = 0; c < NCLASS; c++) header[H_CLASS0 + c] = (int32_t)cls_cnt[c];
+    }
+    __syncthreads();
+    for (int t = lo; t < hi; t++) {
+        const uint32_t n = tile_count[t];
+        const int k = n ? min(NBUCKET - 1, 32 - __clz((int)n)) : 0;
+        order[bkt_base[k] + atomicAdd(&bkt_cnt[k], 1u)] = (uint32_t)t;
+    }
 }
 
 // ------------------------------------------------------------------------------------------------
 // stage B
 // ------------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void k_scatter(int G, int tiles_x, int T, const float4* __restrict__ rec0,
+__global__ __launch_bounds__(256) void k_scatter(Params p, const float4* __restrict__ rec0, const float4* __restrict__ rec1,
                                                  const uint2* __restrict__ rect, const uint32_t* __restrict__ tile_start,
                                                  uint32_t* __restrict__ tile_cursor, uint64_t* __restrict__ keys,
                                                  int64_t cap, int32_t* __restrict__ header, int use_lds) {
-    // Two sweeps over this block's splats: (1) count per tile in LDS, reserve ONE contiguous range per (block, tile) with a
-    // single returning global atomic; (2) hand out slots inside the reserved ranges with LDS atomics.
-    extern __shared__ uint32_t sm[];        // [T] counts / running local rank, [T] reserved base
-    uint32_t* cnt = sm; uint32_t* base = sm + T;
+    // Two sweeps over this workgroup's splats: (1) count per block in LDS, reserve ONE contiguous range per (workgroup, block) with
+    // a single returning global atomic; (2) hand out slots inside the reserved ranges with LDS atomics (the counter then holds
+    // the absolute running slot).
+    extern __shared__ uint32_t cnt[];       // [T]
+    const int T = p.tiles_x * p.tiles_y, G = p.G;
     int i = blockIdx.x * 256 + threadIdx.x;
-    int tx0 = 0, ty0 = 0, tx1 = 0, ty1 = 0;
+    int bx0 = 0, by0 = 0, bx1 = 0, by1 = 0;
     uint64_t key = 0;
+    float gx = 0.f, gy = 0.f, ca = 0.f, cb = 0.f, cc = 0.f, thr = 0.f;
     if (i < G) {
         uint2 rc = rect[i];
-        tx0 = rc.x & 0xffff; ty0 = rc.x >> 16; tx1 = rc.y & 0xffff; ty1 = rc.y >> 16;
-        key = ((uint64_t)__float_as_uint(rec0[i].z) << 32) | (uint32_t)i;
+        bx0 = 2 * (int)(rc.x & 0xffff); by0 = 2 * (int)(rc.x >> 16);
+        bx1 = min(2 * (int)(rc.y & 0xffff), p.tiles_x); by1 = min(2 * (int)(rc.y >> 16), p.tiles_y);
+        const float4 a = rec0[i], b = rec1[i];
+        gx = a.x; gy = a.y; ca = b.x; cb = b.y; cc = b.z; thr = cull_threshold(a.w);
+        key = ((uint64_t)__float_as_uint(a.z) << 32) | (uint32_t)i;
     }
     if (!use_lds) {
-        for (int ty = ty0; ty < ty1; ty++)
-            for (int tx = tx0; tx < tx1; tx++) {
-                int t = ty * tiles_x + tx;
+        for (int by = by0; by < by1; by++)
+            for (int bx = bx0; bx < bx1; bx++) {
+                if (!block_touch(gx, gy, ca, cb, cc, thr, bx, by)) continue;
+                const int t = by * p.tiles_x + bx;
                 int64_t slot = (int64_t)tile_start[t] + atomicAdd(&tile_cursor[t], 1u);
-                if (slot < cap) keys[slot] = key; else header[1] = 1;
+                if (slot < cap) keys[slot] = key; else header[H_OVERFLOW] = 1;
             }
         return;
     }
     for (int t = threadIdx.x; t < T; t += 256) cnt[t] = 0u;
     __syncthreads();
-    for (int ty = ty0; ty < ty1; ty++)
-        for (int tx = tx0; tx < tx1; tx++) atomicAdd(&cnt[ty * tiles_x + tx], 1u);
+    for (int by = by0; by < by1; by++)
+        for (int bx = bx0; bx < bx1; bx++)
+            if (block_touch(gx, gy, ca, cb, cc, thr, bx, by)) atomicAdd(&cnt[by * p.tiles_x + bx], 1u);
     __syncthreads();
     for (int t = threadIdx.x; t < T; t += 256) {
-        uint32_t c = cnt[t];
-        if (c) { base[t] = tile_start[t] + atomicAdd(&tile_cursor[t], c); cnt[t] = 0u; }
+        const uint32_t c = cnt[t];
+        if (c) cnt[t] = tile_start[t] + atomicAdd(&tile_cursor[t], c);
     }
     __syncthreads();
-    for (int ty = ty0; ty < ty1; ty++)
-        for (int tx = tx0; tx < tx1; tx++) {
-            int t = ty * tiles_x + tx;
-            int64_t slot = (int64_t)base[t] + atomicAdd(&cnt[t], 1u);
-            if (slot < cap) keys[slot] = key; else header[1] = 1;
+    for (int by = by0; by < by1; by++)
+        for (int bx = bx0; bx < bx1; bx++) {
+            if (!block_touch(gx, gy, ca, cb, cc, thr, bx, by)) continue;
+            const int64_t slot = (int64_t)atomicAdd(&cnt[by * p.tiles_x + bx], 1u);
+            if (slot < cap) keys[slot] = key; else header[H_OVERFLOW] = 1;
         }
 }
 
@@ -360,81 +460,104 @@ __device__ __forceinline__ void bitonic_network(Mem& m, int n, int npad) {
 struct LdsMem { uint64_t* p; __device__ uint64_t get(int i) const { return p[i]; } __device__ void set(int i, uint64_t v) { p[i] = v; } };
 struct GlbMem { volatile uint64_t* p; __device__ uint64_t get(int i) const { return p[i]; } __device__ void set(int i, uint64_t v) { p[i] = v; } };
 
-// One workgroup per tile. Handles tiles whose pair count n satisfies lo < n <= CAP (LDS) or n > lo (GLOBAL).
-template <int CAP, bool GLOBAL>
-__global__ __launch_bounds__(256) void k_tile_sort(const uint32_t* __restrict__ tile_start, uint64_t* __restrict__ keys,
-                                                   uint32_t* __restrict__ sorted, int lo, int64_t cap) {
+// One workgroup per block of size class CLS (list compacted by k_scan_tiles); workgroups beyond the class count exit.
+template <int CLS, int THREADS, bool GLOBAL>
+__global__ __launch_bounds__(THREADS) void k_tile_sort(int T, const uint32_t* __restrict__ cls, const int32_t* __restrict__ header,
+                                                       const uint32_t* __restrict__ tile_start, uint64_t* __restrict__ keys,
+                                                       uint32_t* __restrict__ sorted, int64_t cap) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
-    int tile = blockIdx.x;
+    if ((int)blockIdx.x >= header[H_CLASS0 + CLS]) return;
+    const int tile = (int)cls[(size_t)CLS * T + blockIdx.x];
     int64_t s = tile_start[tile], e = tile_start[tile + 1];
     if (s > cap) s = cap; if (e > cap) e = cap;
-    int n = (int)(e - s);
-    if (n <= lo) return;
-    if (!GLOBAL && n > CAP) return;
+    const int n = (int)(e - s);
+    if (n <= 0) return;
     int npad = 2; while (npad < n) npad <<= 1;
     if (!GLOBAL) {
         uint64_t* sk = reinterpret_cast<uint64_t*>(smem_raw);
-        for (int i = threadIdx.x; i < n; i += 256) sk[i] = keys[s + i];
+        for (int i = threadIdx.x; i < n; i += THREADS) sk[i] = keys[s + i];
         __syncthreads();
         LdsMem m{sk};
-        bitonic_network(m, n, npad);
-        for (int i = threadIdx.x; i < n; i += 256) sorted[s + i] = (uint32_t)sk[i];
+        if (n > 1) bitonic_network(m, n, npad);
+        for (int i = threadIdx.x; i < n; i += THREADS) sorted[s + i] = (uint32_t)sk[i];
     } else {
         GlbMem m{keys + s};
         __syncthreads();
         bitonic_network(m, n, npad);
-        for (int i = threadIdx.x; i < n; i += 256) sorted[s + i] = (uint32_t)m.get(i);
+        for (int i = threadIdx.x; i < n; i += THREADS) sorted[s + i] = (uint32_t)m.get(i);
     }
 }
 
-__global__ __launch_bounds__(256) void k_render_fwd(Params p, const uint32_t* __restrict__ tile_start,
-                                                    const uint32_t* __restrict__ sorted, const float4* __restrict__ rec0,
-                                                    const float4* __restrict__ rec1, const float4* __restrict__ rec2,
-                                                    int64_t cap, float* __restrict__ final_T, int* __restrict__ n_contrib,
-                                                    float* __restrict__ out_color, float* __restrict__ out_depth,
-                                                    float* __restrict__ out_alpha) {
-    __shared__ float4 s0[256], s1[256], s2[256];
-    const int tile = blockIdx.x;
+// One wave64 per 8x8 pixel block, longest list first.  Splat records of the current batch of 64 live in LDS (broadcast reads);
+// the next batch's records are gathered into registers while the current one is composited.
+__global__ __launch_bounds__(64) void k_render_fwd(Params p, const uint32_t* __restrict__ order, const uint32_t* __restrict__ tile_start,
+                                                   const uint32_t* __restrict__ seg_start, const uint32_t* __restrict__ sorted,
+                                                   const float4* __restrict__ rec0, const float4* __restrict__ rec1,
+                                                   const float4* __restrict__ rec2, int64_t cap, int64_t cap_segs,
+                                                   uint32_t* __restrict__ seg_tile, float* __restrict__ ckpt,
+                                                   uint32_t* __restrict__ tile_neff, float* __restrict__ final_T,
+                                                   int* __restrict__ n_contrib, float* __restrict__ craw,
+                                                   float* __restrict__ out_color, float* __restrict__ out_depth,
+                                                   float* __restrict__ out_alpha) {
+    __shared__ float4 s0[64], s1[64], s2[64];
+    const int tile = (int)order[blockIdx.x];
     const int tx = tile % p.tiles_x, ty = tile / p.tiles_x;
-    const int tid = threadIdx.x;
-    const int px = tx * DWG_TILE + (tid & 15), py = ty * DWG_TILE + (tid >> 4);
+    const int lane = threadIdx.x;
+    const int px = tx * BT + (lane & 7), py = ty * BT + (lane >> 3);
     const bool inside = px < p.W && py < p.H;
     int64_t rs = tile_start[tile], re = tile_start[tile + 1];
     if (rs > cap) rs = cap; if (re > cap) re = cap;
     const int n = (int)(re - rs);
+    const int64_t sbase = seg_start[tile];
+    for (int s = lane; s < (n + SEG - 1) / SEG; s += 64) if (sbase + s < cap_segs) seg_tile[sbase + s] = (uint32_t)tile;
     const float fx = (float)px, fy = (float)py;
     float T = 1.f, C0 = 0.f, C1 = 0.f, C2 = 0.f, D = 0.f, A = 0.f;
     int last = 0;
     bool done = !inside;
-    for (int base = 0; base < n; base += 256) {
-        if (__syncthreads_and(done)) break;
-        int k = base + tid;
-        if (k < n) {
-            uint32_t g = sorted[rs + k];
-            s0[tid] = rec0[g]; s1[tid] = rec1[g]; s2[tid] = rec2[g];
+    float4 r0 = make_float4(0.f, 0.f, 0.f, 0.f), r1 = r0, r2 = r0;
+    if (lane < n) { const uint32_t g = sorted[rs + lane]; r0 = rec0[g]; r1 = rec1[g]; r2 = rec2[g]; }
+    for (int base = 0; base < n; base += 64) {
+        if (!__any(!done)) break;
+        if (ckpt && (base % SEG) == 0) {
+            const int64_t seg = sbase + base / SEG;
+            if (seg < cap_segs) {
+                float* c = ckpt + (size_t)seg * 6 * 64 + lane;
+                c[0] = T; c[64] = C0; c[128] = C1; c[192] = C2; c[256] = D; c[320] = A;
+            }
         }
+        s0[lane] = r0; s1[lane] = r1; s2[lane] = r2;
+        const int nb = base + 64 + lane;
+        if (nb < n) { const uint32_t g = sorted[rs + nb]; r0 = rec0[g]; r1 = rec1[g]; r2 = rec2[g]; }
         __syncthreads();
-        int cnt = min(256, n - base);
+        const int cnt = min(64, n - base);
         if (!done) {
             for (int j = 0; j < cnt; j++) {
-                float4 a = s0[j]; float4 b = s1[j];
-                float dx = a.x - fx, dy = a.y - fy;
-                float power = splat_power(b.x, b.y, b.z, dx, dy);
+                const float4 a = s0[j]; const float4 b = s1[j];
+                const float dx = a.x - fx, dy = a.y - fy;
+                const float power = splat_power(b.x, b.y, b.z, dx, dy);
                 if (power > 0.f) continue;
-                float alpha = fminf(0.99f, a.w * expf(power));
+                const float alpha = fminf(0.99f, a.w * expf(power));
                 if (alpha < (1.f / 255.f)) continue;
-                float test_T = T * (1.f - alpha);
+                const float test_T = __fmul_rn(T, 1.f - alpha);
                 if (test_T < 0.0001f) { done = true; break; }
-                float w = alpha * T;
-                float4 c = s2[j];
-                C0 += c.x * w; C1 += c.y * w; C2 += c.z * w; D += a.z * w; A += w;
+                const float w = __fmul_rn(alpha, T);
+                const float4 c = s2[j];
+                C0 = __fmaf_rn(c.x, w, C0); C1 = __fmaf_rn(c.y, w, C1); C2 = __fmaf_rn(c.z, w, C2);
+                D = __fmaf_rn(a.z, w, D); A += w;
                 T = test_T; last = base + j + 1;
             }
         }
+        __syncthreads();
     }
+    // deepest contributor of the block: nothing behind it matters to the backward
+    int mx = last;
+#pragma unroll
+    for (int off = 32; off >= 1; off >>= 1) mx = max(mx, __shfl_xor(mx, off));
+    if (lane == 0) tile_neff[tile] = (uint32_t)mx;
     if (inside) {
-        size_t P = (size_t)p.H * p.W, pix = (size_t)py * p.W + px;
+        const size_t P = (size_t)p.H * p.W, pix = (size_t)py * p.W + px;
         final_T[pix] = T; n_contrib[pix] = last;
+        craw[pix] = C0; craw[P + pix] = C1; craw[2 * P + pix] = C2; craw[3 * P + pix] = D; craw[4 * P + pix] = A;
         out_color[pix] = C0 + T * p.bg[0];
         out_color[P + pix] = C1 + T * p.bg[1];
         out_color[2 * P + pix] = C2 + T * p.bg[2];
@@ -448,98 +571,104 @@ __global__ __launch_bounds__(256) void k_render_fwd(Params p, const uint32_t* __
 #define NGRAD 10  // g2d.x g2d.y | conic a, b(half), c | opacity | r g b | depth   (row stride 12 floats)
 #define GSTRIDE 12
 
-__global__ __launch_bounds__(256) void k_render_bwd(Params p, const uint32_t* __restrict__ tile_start,
-                                                    const uint32_t* __restrict__ sorted, const float4* __restrict__ rec0,
-                                                    const float4* __restrict__ rec1, const float4* __restrict__ rec2,
-                                                    int64_t cap, const float* __restrict__ final_T,
-                                                    const int* __restrict__ n_contrib, const float* __restrict__ g_color,
-                                                    const float* __restrict__ g_depth, const float* __restrict__ g_alpha,
-                                                    float* __restrict__ gacc /* [G][GSTRIDE] */) {
-    __shared__ float4 s0[256], s1[256], s2[256];
-    __shared__ uint32_t sgid[256];
-    __shared__ float acc[256 * NGRAD];
-    __shared__ int smax;
-    const int tile = blockIdx.x;
-    const int tx = tile % p.tiles_x, ty = tile / p.tiles_x;
-    const int tid = threadIdx.x, lane = tid & 63;
-    const int px = tx * DWG_TILE + (tid & 15), py = ty * DWG_TILE + (tid >> 4);
-    const bool inside = px < p.W && py < p.H;
+// One wave64 per (block, segment of SEG splats), front to back from the forward's checkpoint.  For splat i of a pixel:
+//   w_i = alpha_i T_i,   sum over LATER splats of c_j w_j = (final sum) - (prefix sum including i)
+//   dL/dalpha_i = sum_ch (c_i T_i - later_ch / (1 - alpha_i)) g_ch - T_final / (1 - alpha_i) (bg . g_rgb)
+// T_i follows the forward's own recurrence from the checkpoint, bit for bit.
+__global__ __launch_bounds__(64) void k_render_bwd(Params p, const int32_t* __restrict__ header, int64_t cap_segs,
+                                                   const uint32_t* __restrict__ seg_tile, const uint32_t* __restrict__ seg_start,
+                                                   const uint32_t* __restrict__ tile_start, const uint32_t* __restrict__ tile_neff,
+                                                   const uint32_t* __restrict__ sorted, const float4* __restrict__ rec0,
+                                                   const float4* __restrict__ rec1, const float4* __restrict__ rec2,
+                                                   int64_t cap, const float* __restrict__ ckpt, const float* __restrict__ final_T,
+                                                   const int* __restrict__ n_contrib, const float* __restrict__ craw,
+                                                   const float* __restrict__ g_color, const float* __restrict__ g_depth,
+                                                   const float* __restrict__ g_alpha, float* __restrict__ gacc /* [G][GSTRIDE] */) {
+    __shared__ float4 s0[64], s1[64], s2[64];
+    __shared__ float sacc[NGRAD * 64];
+    const int64_t seg = blockIdx.x;
+    if (seg >= (int64_t)header[H_NSEG] || seg >= cap_segs || header[H_OVERFLOW]) return;    // a truncated frame is redone by the caller
+    const int tile = (int)seg_tile[seg];
+    if ((unsigned)tile >= (unsigned)(p.tiles_x * p.tiles_y)) return;
+    const int sidx = (int)(seg - (int64_t)seg_start[tile]);
     int64_t rs = tile_start[tile], re = tile_start[tile + 1];
     if (rs > cap) rs = cap; if (re > cap) re = cap;
+    const int lo = sidx * SEG;
+    const int hi = min(min((int)(re - rs), (int)tile_neff[tile]), lo + SEG);
+    if (lo >= hi) return;
+    const int tx = tile % p.tiles_x, ty = tile / p.tiles_x;
+    const int lane = threadIdx.x;
+    const int px = tx * BT + (lane & 7), py = ty * BT + (lane >> 3);
+    const bool inside = px < p.W && py < p.H;
     const float fx = (float)px, fy = (float)py;
     const size_t P = (size_t)p.H * p.W, pix = (size_t)py * p.W + px;
-    const float T_final = inside ? final_T[pix] : 0.f;
-    const int last = inside ? n_contrib[pix] : 0;
+    float T_final = 0.f, t0 = 0.f, t1 = 0.f, t2 = 0.f, td = 0.f, ta = 0.f;     // totals of the forward
+    int last = 0;
     float gp0 = 0.f, gp1 = 0.f, gp2 = 0.f, gpd = 0.f, gpa = 0.f;
     if (inside) {
+        T_final = final_T[pix]; last = n_contrib[pix];
+        t0 = craw[pix]; t1 = craw[P + pix]; t2 = craw[2 * P + pix]; td = craw[3 * P + pix]; ta = craw[4 * P + pix];
         gp0 = g_color[pix]; gp1 = g_color[P + pix]; gp2 = g_color[2 * P + pix];
         if (g_depth) gpd = g_depth[pix];
         if (g_alpha) gpa = g_alpha[pix];
     }
     const float bgdot = p.bg[0] * gp0 + p.bg[1] * gp1 + p.bg[2] * gp2;
-    if (tid == 0) smax = 0;
-    __syncthreads();
-    atomicMax(&smax, last);
-    __syncthreads();
-    const int n = min((int)(re - rs), smax);  // nothing beyond the deepest contributor matters
-    float T = T_final;
-    float a0 = 0.f, a1 = 0.f, a2 = 0.f, ad = 0.f, aa = 0.f;  // sum over later splats of value*w
+    const float* ck = ckpt + (size_t)seg * 6 * 64 + lane;
+    float T = ck[0], P0 = ck[64], P1 = ck[128], P2 = ck[192], Pd = ck[256], Pa = ck[320];
     const float ddelx = 0.5f * p.W, ddely = 0.5f * p.H;
-    for (int hi = n; hi > 0; hi -= 256) {
-        const int lo = max(0, hi - 256), cnt = hi - lo;
-        __syncthreads();  // previous flush done before acc/s* are reused
-        if (tid < cnt) {
-            uint32_t g = sorted[rs + (hi - 1 - tid)];
-            sgid[tid] = g; s0[tid] = rec0[g]; s1[tid] = rec1[g]; s2[tid] = rec2[g];
-        }
 #pragma unroll
-        for (int c = 0; c < NGRAD; c++) acc[c * 256 + tid] = 0.f;
+    for (int c = 0; c < NGRAD; c++) sacc[c * 64 + lane] = 0.f;
+    for (int base = lo; base < hi; base += 64) {
+        const int cnt = min(64, hi - base);
+        uint32_t gid = 0;
+        __syncthreads();
+        if (lane < cnt) { gid = sorted[rs + base + lane]; s0[lane] = rec0[gid]; s1[lane] = rec1[gid]; s2[lane] = rec2[gid]; }
         __syncthreads();
         for (int j = 0; j < cnt; j++) {
-            const int pos = hi - 1 - j;
-            bool valid = pos < last;
-            float4 a = s0[j]; float4 b = s1[j];
-            float dx = a.x - fx, dy = a.y - fy;
-            float power = splat_power(b.x, b.y, b.z, dx, dy);
-            float Gv = expf(power);
-            float alpha = fminf(0.99f, a.w * Gv);
-            valid = valid && (power <= 0.f) && (alpha >= (1.f / 255.f));
+            const float4 a = s0[j]; const float4 b = s1[j];
+            const float dx = a.x - fx, dy = a.y - fy;
+            const float power = splat_power(b.x, b.y, b.z, dx, dy);
+            const float Gv = expf(power);
+            const float alpha = fminf(0.99f, a.w * Gv);
+            const bool valid = (base + j < last) && (power <= 0.f) && (alpha >= (1.f / 255.f));
             if (!__any(valid)) continue;  // wave-uniform skip
             float v[NGRAD];
 #pragma unroll
             for (int c = 0; c < NGRAD; c++) v[c] = 0.f;
             if (valid) {
-                float4 col = s2[j];
-                float inv1a = 1.f / (1.f - alpha);
-                T = T * inv1a;
-                float w = alpha * T;
-                float dL_dalpha = (col.x * T - a0 * inv1a) * gp0 + (col.y * T - a1 * inv1a) * gp1 +
-                                  (col.z * T - a2 * inv1a) * gp2 + (a.z * T - ad * inv1a) * gpd +
-                                  (T - aa * inv1a) * gpa - T_final * inv1a * bgdot;
-                a0 += col.x * w; a1 += col.y * w; a2 += col.z * w; ad += a.z * w; aa += w;
-                float dL_dG = a.w * dL_dalpha;
-                float gdx = b.x * dx + b.y * dy, gdy = b.z * dy + b.y * dx;
+                const float4 col = s2[j];
+                const float om = 1.f - alpha;
+                const float inv1a = 1.f / om;
+                const float w = __fmul_rn(alpha, T);
+                P0 = __fmaf_rn(col.x, w, P0); P1 = __fmaf_rn(col.y, w, P1); P2 = __fmaf_rn(col.z, w, P2);
+                Pd = __fmaf_rn(a.z, w, Pd); Pa += w;
+                const float dL_dalpha = (col.x * T - (t0 - P0) * inv1a) * gp0 + (col.y * T - (t1 - P1) * inv1a) * gp1 +
+                                        (col.z * T - (t2 - P2) * inv1a) * gp2 + (a.z * T - (td - Pd) * inv1a) * gpd +
+                                        (T - (ta - Pa) * inv1a) * gpa - T_final * inv1a * bgdot;
+                const float dL_dG = a.w * dL_dalpha;
+                const float gdx = b.x * dx + b.y * dy, gdy = b.z * dy + b.y * dx;
                 v[0] = -dL_dG * Gv * gdx * ddelx;
                 v[1] = -dL_dG * Gv * gdy * ddely;
-                float h = -0.5f * Gv * dL_dG;
+                const float h = -0.5f * Gv * dL_dG;
                 v[2] = h * dx * dx; v[3] = h * dx * dy; v[4] = h * dy * dy;
                 v[5] = Gv * dL_dalpha;
                 v[6] = w * gp0; v[7] = w * gp1; v[8] = w * gp2; v[9] = w * gpd;
+                T = __fmul_rn(T, om);
             }
 #pragma unroll
             for (int c = 0; c < NGRAD; c++) v[c] = dwg_wave_sum_to_lane63(v[c]);
             if (lane == 63) {
 #pragma unroll
-                for (int c = 0; c < NGRAD; c++) atomicAdd(&acc[c * 256 + j], v[c]);
+                for (int c = 0; c < NGRAD; c++) sacc[c * 64 + j] += v[c];
             }
         }
         __syncthreads();
-        if (tid < cnt) {
-            float* dst = gacc + (size_t)sgid[tid] * GSTRIDE;
+        if (lane < cnt) {
+            float* dst = gacc + (size_t)gid * GSTRIDE;
 #pragma unroll
             for (int c = 0; c < NGRAD; c++) {
-                float x = acc[c * 256 + tid];
-                if (x != 0.f) atomicAdd(dst + c, x);
+                const float x = sacc[c * 64 + lane];
+                if (x != 0.f) { atomicAdd(dst + c, x); sacc[c * 64 + lane] = 0.f; }
             }
         }
     }
@@ -710,12 +839,30 @@ __global__ __launch_bounds__(256) void k_preprocess_bwd(Params p, const float* _
     }
 }
 
+// viewmatrix = extrinsic^T, projmatrix = viewmatrix @ projection^T, campos = c2w[:3, 3] (gaussian_renderer.py:38-41): one launch
+// instead of a transpose, a library 4x4 GEMM and a slice
+__global__ void k_camera_setup(const float* __restrict__ extrinsic, const float* __restrict__ projection,
+                               const float* __restrict__ c2w, float* __restrict__ out /*[16 + 16 + 3]*/) {
+    const int t = threadIdx.x;
+    if (t < 16) {
+        const int r = t >> 2, c = t & 3;
+        out[t] = extrinsic[4 * c + r];
+        float v = 0.f;
+#pragma unroll
+        for (int k = 0; k < 4; k++) v += extrinsic[4 * k + r] * projection[4 * c + k];     // sum_k E^T[r,k] P^T[k,c]
+        out[16 + t] = v;
+    } else if (t < 19) {
+        out[32 + (t - 16)] = c2w[4 * (t - 16) + 3];
+    }
+}
+
 static int make_params(const dwg_raster_settings* cfg, int G, Params* p) {
     if (!cfg || G < 0 || cfg->image_height <= 0 || cfg->image_width <= 0) return DWG_E_ARG;
     if (!cfg->bg || !cfg->viewmatrix || !cfg->projmatrix) return DWG_E_ARG;
     p->G = G; p->H = cfg->image_height; p->W = cfg->image_width;
-    p->tiles_x = dwg_cdiv(p->W, DWG_TILE); p->tiles_y = dwg_cdiv(p->H, DWG_TILE);
-    if (p->tiles_x > 0xffff || p->tiles_y > 0xffff) return DWG_E_ARG;
+    p->tiles_x = dwg_cdiv(p->W, BT); p->tiles_y = dwg_cdiv(p->H, BT);
+    p->rtiles_x = dwg_cdiv(p->W, RT); p->rtiles_y = dwg_cdiv(p->H, RT);
+    if (p->rtiles_x > 0x7fff || p->rtiles_y > 0x7fff) return DWG_E_ARG;
     p->tanfovx = cfg->tanfovx; p->tanfovy = cfg->tanfovy;
     p->focal_x = p->W / (2.f * cfg->tanfovx); p->focal_y = p->H / (2.f * cfg->tanfovy);
     p->scale_mod = cfg->scale_modifier;
@@ -732,12 +879,19 @@ int dwg_raster_workspace_sizes(int32_t G, int32_t H, int32_t W, int64_t pair_cap
                                size_t* pairs_bytes, size_t* image_bytes) {
     if (G < 0 || H <= 0 || W <= 0 || pair_capacity < 0) return DWG_E_ARG;
     if (geom_bytes) *geom_bytes = geom_layout(G, H, W).total;
-    if (pairs_bytes) *pairs_bytes = pair_layout(pair_capacity).total;
+    if (pairs_bytes) *pairs_bytes = pair_layout(pair_capacity, H, W).total;
     if (image_bytes) *image_bytes = image_layout(H, W).total;
     return DWG_OK;
 }
 
 const int32_t* dwg_raster_num_pairs_ptr(const void* ws_geom) { return reinterpret_cast<const int32_t*>(ws_geom); }
+
+int dwg_raster_camera_setup(const float* extrinsic, const float* projection, const float* c2w, float* out35, dwg_stream_t stream_) {
+    if (!extrinsic || !projection || !c2w || !out35) return DWG_E_ARG;
+    DWG_LAUNCH("raster_camera_setup", k_camera_setup, dim3(1), dim3(64), 0, (hipStream_t)stream_, extrinsic, projection, c2w, out35);
+    DWG_RETURN_IF_LAUNCH_FAILED();
+    return DWG_OK;
+}
 
 int dwg_raster_forward_bin(const dwg_raster_settings* cfg, int32_t G, const float* means3D, const float* shs,
                            const float* colors_precomp, const float* opacities, const float* scales,
@@ -758,16 +912,18 @@ int dwg_raster_forward_bin(const dwg_raster_settings* cfg, int32_t G, const floa
     GeomLayout L = geom_layout(G, p.H, p.W);
     char* ws = (char*)ws_geom;
     int T = p.tiles_x * p.tiles_y;
+    if (hipMemsetAsync(ws + L.header, 0, 256, stream) != hipSuccess) return DWG_E_LAUNCH;
     if (hipMemsetAsync(ws + L.tile_count, 0, L.tile_start - L.tile_count, stream) != hipSuccess) return DWG_E_LAUNCH;
     if (G > 0) {
         const int use_lds_hist = T <= 16384;
         DWG_LAUNCH("raster_preprocess", k_preprocess, dim3(dwg_cdiv(G, 256)), dim3(256), use_lds_hist ? (size_t)T * 4 : 0, stream, p,
                    means3D, shs, colors_precomp, opacities, scales, rotations, cov3D_precomp, radii, (float4*)(ws + L.rec0),
                    (float4*)(ws + L.rec1), (float4*)(ws + L.rec2), (uint2*)(ws + L.rect), (uint32_t*)(ws + L.tile_count),
-                   use_lds_hist);
+                   (int32_t*)(ws + L.header), use_lds_hist);
     }
     DWG_LAUNCH("raster_scan_tiles", k_scan_tiles, dim3(1), dim3(1024), 0, stream, T, (const uint32_t*)(ws + L.tile_count),
-                       (uint32_t*)(ws + L.tile_start), (int32_t*)(ws + L.header));
+               (uint32_t*)(ws + L.tile_start), (uint32_t*)(ws + L.seg_start), (uint32_t*)(ws + L.cls), (uint32_t*)(ws + L.order),
+               (int32_t*)(ws + L.header));
     DWG_RETURN_IF_LAUNCH_FAILED();
     return DWG_OK;
 }
@@ -781,38 +937,47 @@ int dwg_raster_forward_render(const dwg_raster_settings* cfg, int32_t G, void* w
     if (!ws_geom || !ws_pairs || !ws_image || !out_color || !out_depth || !out_alpha || pair_capacity < 0) return DWG_E_ARG;
     hipStream_t stream = (hipStream_t)stream_;
     GeomLayout L = geom_layout(G, p.H, p.W);
-    PairLayout PL = pair_layout(pair_capacity);
+    PairLayout PL = pair_layout(pair_capacity, p.H, p.W);
     ImageLayout IL = image_layout(p.H, p.W);
+    const int64_t cap_segs = seg_capacity(pair_capacity > 0 ? pair_capacity : 1, p.H, p.W);
     char* ws = (char*)ws_geom; char* wp = (char*)ws_pairs; char* wi = (char*)ws_image;
     int T = p.tiles_x * p.tiles_y;
     uint64_t* keys = (uint64_t*)(wp + PL.keys);
     uint32_t* sorted = (uint32_t*)(wp + PL.sorted);
     const uint32_t* tile_start = (const uint32_t*)(ws + L.tile_start);
+    const uint32_t* cls = (const uint32_t*)(ws + L.cls);
+    const int32_t* header = (const int32_t*)(ws + L.header);
     if (G > 0) {
-        const int use_lds = T <= 8192;
-        DWG_LAUNCH("raster_scatter", k_scatter, dim3(dwg_cdiv(G, 256)), dim3(256), use_lds ? (size_t)T * 8 : 0, stream, G, p.tiles_x, T,
-                   (const float4*)(ws + L.rec0), (const uint2*)(ws + L.rect), tile_start, (uint32_t*)(ws + L.tile_cursor), keys,
-                   pair_capacity, (int32_t*)(ws + L.header), use_lds);
-        // three size classes: (1,2048] in 16 KiB LDS, (2048,8192] in 64 KiB LDS, >8192 in global memory
-        DWG_LAUNCH("raster_tile_sort", (k_tile_sort<2048, false>), dim3(T), dim3(256), 2048 * 8, stream, tile_start, keys, sorted, 0,
-                           pair_capacity);
-        DWG_LAUNCH("raster_tile_sort_l", (k_tile_sort<8192, false>), dim3(T), dim3(256), 8192 * 8, stream, tile_start, keys, sorted, 2048,
-                           pair_capacity);
+        const int use_lds = T <= 16384;
+        DWG_LAUNCH("raster_scatter", k_scatter, dim3(dwg_cdiv(G, 256)), dim3(256), use_lds ? (size_t)T * 4 : 0, stream, p,
+                   (const float4*)(ws + L.rec0), (const float4*)(ws + L.rec1), (const uint2*)(ws + L.rect), tile_start,
+                   (uint32_t*)(ws + L.tile_cursor), keys, pair_capacity, (int32_t*)(ws + L.header), use_lds);
+        // size classes (lists compacted by k_scan_tiles; surplus workgroups exit on their first instruction):
+        //   <= 1024 pairs: one wave, 8 KiB LDS | <= 4096: 256 threads, 32 KiB | <= 16384: 1024 threads, 128 KiB | larger: in global memory
         static bool attr_set = false;
         if (!attr_set) {
-            hipFuncSetAttribute(reinterpret_cast<const void*>(&k_tile_sort<16384, false>), hipFuncAttributeMaxDynamicSharedMemorySize,
+            hipFuncSetAttribute(reinterpret_cast<const void*>(&k_tile_sort<2, 1024, false>), hipFuncAttributeMaxDynamicSharedMemorySize,
                                 16384 * 8);
             attr_set = true;
         }
-        DWG_LAUNCH("raster_tile_sort_xl", (k_tile_sort<16384, false>), dim3(T), dim3(256), 16384 * 8, stream, tile_start, keys, sorted,
-                   8192, pair_capacity);
-        DWG_LAUNCH("raster_tile_sort_g", (k_tile_sort<0, true>), dim3(T), dim3(256), 0, stream, tile_start, keys, sorted, 16384,
-                   pair_capacity);
+        // the long classes first: they are the critical path, the short ones fill in behind them
+        // (a block of class c holds more than {0, 1024, 4096, 16384} pairs, so at most capacity / that many such blocks exist)
+        const int nD = (int)min((int64_t)T, pair_capacity / 16384 + 1), nC = (int)min((int64_t)T, pair_capacity / 4096 + 1),
+                  nB = (int)min((int64_t)T, pair_capacity / 1024 + 1);
+        DWG_LAUNCH("raster_tile_sort_g", (k_tile_sort<3, 1024, true>), dim3(nD), dim3(1024), 0, stream, T, cls, header, tile_start,
+                   keys, sorted, pair_capacity);
+        DWG_LAUNCH("raster_tile_sort_xl", (k_tile_sort<2, 1024, false>), dim3(nC), dim3(1024), 16384 * 8, stream, T, cls, header, tile_start,
+                   keys, sorted, pair_capacity);
+        DWG_LAUNCH("raster_tile_sort_l", (k_tile_sort<1, 256, false>), dim3(nB), dim3(256), 4096 * 8, stream, T, cls, header, tile_start,
+                   keys, sorted, pair_capacity);
+        DWG_LAUNCH("raster_tile_sort", (k_tile_sort<0, 64, false>), dim3(T), dim3(64), 1024 * 8, stream, T, cls, header, tile_start,
+                   keys, sorted, pair_capacity);
     }
-    DWG_LAUNCH("raster_render_fwd", k_render_fwd, dim3(T), dim3(256), 0, stream, p, tile_start, (const uint32_t*)sorted,
-                       (const float4*)(ws + L.rec0), (const float4*)(ws + L.rec1), (const float4*)(ws + L.rec2),
-                       pair_capacity, (float*)(wi + IL.final_T), (int*)(wi + IL.n_contrib), out_color, out_depth,
-                       out_alpha);
+    DWG_LAUNCH("raster_render_fwd", k_render_fwd, dim3(T), dim3(64), 0, stream, p, (const uint32_t*)(ws + L.order), tile_start,
+               (const uint32_t*)(ws + L.seg_start), (const uint32_t*)sorted, (const float4*)(ws + L.rec0), (const float4*)(ws + L.rec1),
+               (const float4*)(ws + L.rec2), pair_capacity, cap_segs, (uint32_t*)(wp + PL.seg_tile), (float*)(wp + PL.ckpt),
+               (uint32_t*)(ws + L.tile_neff), (float*)(wi + IL.final_T), (int*)(wi + IL.n_contrib), (float*)(wi + IL.craw), out_color,
+               out_depth, out_alpha);
     DWG_RETURN_IF_LAUNCH_FAILED();
     return DWG_OK;
 }
@@ -821,8 +986,7 @@ int dwg_raster_backward(const dwg_raster_settings* cfg, int32_t G, const float* 
                         const float* colors_precomp, const float* opacities, const float* scales,
                         const float* rotations, const float* cov3D_precomp, const void* ws_geom, const void* ws_pairs,
                         int64_t pair_capacity, const void* ws_image, void* ws_grad, const float* dL_dout_color,
-                        const float* dL_dout_depth, const float* dL_dout_alpha, float* dL_dmeans3D,
-                        float* dL_dmeans2D, float* dL_dshs, float* dL_dcolors, float* dL_dopacities,
+                        const float* dL_dout_depth, const float* dL_dout_alpha, float* dL_dmeans3D, float* dL_dmeans2D, float* dL_dshs, float* dL_dcolors, float* dL_dopacities,
                         float* dL_dscales, float* dL_drotations, float* dL_dcov3D, dwg_stream_t stream_) {
     Params p;
     int rc = make_params(cfg, G, &p);
@@ -835,19 +999,21 @@ int dwg_raster_backward(const dwg_raster_settings* cfg, int32_t G, const float* 
     if (((scales == nullptr) || (rotations == nullptr)) == (cov3D_precomp == nullptr)) return DWG_E_ARG;
     hipStream_t stream = (hipStream_t)stream_;
     GeomLayout L = geom_layout(G, p.H, p.W);
-    PairLayout PL = pair_layout(pair_capacity);
+    PairLayout PL = pair_layout(pair_capacity, p.H, p.W);
     ImageLayout IL = image_layout(p.H, p.W);
+    const int64_t cap_segs = seg_capacity(pair_capacity > 0 ? pair_capacity : 1, p.H, p.W);
     const char* ws = (const char*)ws_geom; const char* wp = (const char*)ws_pairs; const char* wi = (const char*)ws_image;
-    int T = p.tiles_x * p.tiles_y;
     if (hipMemsetAsync(ws_grad, 0, (size_t)G * GSTRIDE * sizeof(float), stream) != hipSuccess) return DWG_E_LAUNCH;
-    DWG_LAUNCH("raster_render_bwd", k_render_bwd, dim3(T), dim3(256), 0, stream, p, (const uint32_t*)(ws + L.tile_start),
-                       (const uint32_t*)(wp + PL.sorted), (const float4*)(ws + L.rec0), (const float4*)(ws + L.rec1),
-                       (const float4*)(ws + L.rec2), pair_capacity, (const float*)(wi + IL.final_T),
-                       (const int*)(wi + IL.n_contrib), dL_dout_color, dL_dout_depth, dL_dout_alpha, (float*)ws_grad);
+    DWG_LAUNCH("raster_render_bwd", k_render_bwd, dim3((unsigned)cap_segs), dim3(64), 0, stream, p, (const int32_t*)(ws + L.header), cap_segs,
+               (const uint32_t*)(wp + PL.seg_tile), (const uint32_t*)(ws + L.seg_start), (const uint32_t*)(ws + L.tile_start),
+               (const uint32_t*)(ws + L.tile_neff), (const uint32_t*)(wp + PL.sorted), (const float4*)(ws + L.rec0),
+               (const float4*)(ws + L.rec1), (const float4*)(ws + L.rec2), pair_capacity, (const float*)(wp + PL.ckpt),
+               (const float*)(wi + IL.final_T), (const int*)(wi + IL.n_contrib), (const float*)(wi + IL.craw),
+               dL_dout_color, dL_dout_depth, dL_dout_alpha, (float*)ws_grad);
     DWG_LAUNCH("raster_preprocess_bwd", k_preprocess_bwd, dim3(dwg_cdiv(G, 256)), dim3(256), 0, stream, p, means3D, shs, colors_precomp,
-                       scales, rotations, cov3D_precomp, (const uint2*)(ws + L.rect), (const float4*)(ws + L.rec2),
-                       (const float*)ws_grad, dL_dmeans3D, dL_dmeans2D, dL_dshs, dL_dcolors, dL_dopacities, dL_dscales,
-                       dL_drotations, dL_dcov3D);
+               scales, rotations, cov3D_precomp, (const uint2*)(ws + L.rect), (const float4*)(ws + L.rec2),
+               (const float*)ws_grad, dL_dmeans3D, dL_dmeans2D, dL_dshs, dL_dcolors, dL_dopacities, dL_dscales,
+               dL_drotations, dL_dcov3D);
     DWG_RETURN_IF_LAUNCH_FAILED();
     return DWG_OK;
 }

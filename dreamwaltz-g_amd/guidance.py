@@ -1,18 +1,29 @@
-"""Mirror of the reference's SDS guidance seam on the HIP denoiser (boundary B4/B5, SURVEY.md section 8a rows G2-G7).
+"""Mirror of the reference's SDS guidance seam on the HIP denoiser (boundary B4/B5, SURVEY.md section 8a rows G2-G8).
 
-  ControlNetScoreDistillation.__call__      /root/reference/core/guidance/basic.py:778-917 (default branch: loss_type 'sds',
-                                            CFG with negative text, weight_type 'sjc', guidance_scale 50)
-  ._predict(latents, text, cond)            /root/reference/core/guidance/controlnet.py:83-114
+  ControlNetScoreDistillation.__call__(inputs, text_embeds_dict, train_step, max_iteration, add_noise, grad_viz, **kwargs)
+                                            /root/reference/core/guidance/basic.py:778-917 (default branch: loss_type 'sds', CFG
+                                            with negative text, weight_type 'sjc', guidance_scale 50)
+  .preprocess / .prepare_latents            basic.py:354-383,420-438
+  .calc_gradients                           basic.py:546-663
+  ._predict(latents, text, cond_inputs)     /root/reference/core/guidance/controlnet.py:83-114 (reads self.timestep)
+  .prepare_image / .prepare_condition       controlnet.py:33-72 (PIL -> LANCZOS resize -> float/255 -> NCHW -> repeat)
   .encode_images(images)  (differentiable)  /root/reference/core/guidance/vae.py:34-40
-  SpecifyGradient                           /root/reference/core/guidance/basic.py:213-226
-  TimePrioritizedScheduler ('uniform')      /root/reference/core/guidance/time_prior.py:321-352
-Device RNG draw order per call is the reference's (checklist Q12): VAE posterior noise -> timestep -> latent noise.
+  SpecifyGradient                           basic.py:213-226
+  TimePrioritizedScheduler.get_timestep     /root/reference/core/guidance/time_prior.py:321-352 ('uniform' / 'constant' / 'linear')
+Attributes other code reads (basic.py:334-335,453): scheduler.scale_model_input, alphas_cumprod, vae_scale_factor,
+pipe.unet.config.sample_size.  Device RNG draw order per call is the reference's (checklist Q12): VAE posterior noise -> timestep ->
+latent noise.  Test-only keyword extensions: noise=, posterior_noise= (fixed draws for parity tests).
 """
-from typing import Dict, Optional
+import types
+from typing import Dict, List, Optional, Union
 
+import numpy as np
 import torch
+import torch.nn.functional as F
 
 from . import sd15
+from .configs import GuideConfig
+from .pgc import build_grad_hook_func, build_pgc_hook_func
 
 
 class SpecifyGradient(torch.autograd.Function):
@@ -45,11 +56,19 @@ def sd15_alphas_cumprod(device, n=1000, beta_start=0.00085, beta_end=0.012):
     return torch.cumprod(1.0 - betas, dim=0).to(device)
 
 
+def C(value, current_step=None, max_iteration=None) -> float:
+    """time_prior.py:17-33 for plain numbers (the schedule-string forms are not used by the shipped recipes)."""
+    if isinstance(value, (int, float)):
+        return float(value)
+    raise NotImplementedError("scheduled min/max timestep strings")
+
+
 class ControlNetScoreDistillation:
     def __init__(self, device, unet_cfg: Optional[sd15.UNetConfig] = None, vae_cfg: Optional[sd15.VAEConfig] = None,
-                 unet_sd=None, controlnet_sd=None, vae_sd=None, image_hw=512, guidance_scale=50.0, min_timestep=0.02,
-                 max_timestep=0.98, seed=0):
-        self.device = device
+                 unet_sd=None, controlnet_sd=None, vae_sd=None, image_hw=512, guidance_scale=None, min_timestep=None,
+                 max_timestep=None, seed=0, cfg: Optional[GuideConfig] = None):
+        self.device = torch.device(device)
+        self.cfg = cfg if cfg is not None else GuideConfig()
         self.unet_cfg = unet_cfg or sd15.UNetConfig()
         self.vae_cfg = vae_cfg or sd15.VAEConfig()
         if unet_sd is None:        # random-init weights of the SD-1.5 architecture (no checkpoints offline)
@@ -61,16 +80,34 @@ class ControlNetScoreDistillation:
         self.image_hw = image_hw
         down = 2 ** (len(self.vae_cfg.block_out_channels) - 1)
         self.latent_hw = image_hw // down
-        self.denoiser = sd15.DenoiserPlan(self.unet_cfg, unet_sd, controlnet_sd, device, batch=2, latent_hw=self.latent_hw)
-        self.vae = sd15.VAEEncoderPlan(self.vae_cfg, vae_sd, device, image_hw=image_hw)
-        self.alphas_cumprod = sd15_alphas_cumprod(device)
-        self.num_train_timesteps = 1000
-        self.guidance_scale = guidance_scale
-        self.min_step = int(self.num_train_timesteps * min_timestep)
-        self.max_step = int(self.num_train_timesteps * max_timestep)
+        self.denoiser = sd15.DenoiserPlan(self.unet_cfg, unet_sd, controlnet_sd, self.device, batch=2, latent_hw=self.latent_hw)
+        self.vae = sd15.VAEEncoderPlan(self.vae_cfg, vae_sd, self.device, image_hw=image_hw)
+        # BasicStableDiffusion.__init__ (basic.py:229-267)
+        self.loss_type, self.weight_type = self.cfg.sds_loss_type, self.cfg.sds_weight_type
+        if self.loss_type != 'sds' or self.weight_type not in ('sjc', 'dreamfusion', 'latent-nerf', 'ism'):
+            raise NotImplementedError("only the score-based 'sds' loss of the shipped recipes is on the hot path")
+        self.initial_guidance_scale = self.cfg.guidance_scale if guidance_scale is None else guidance_scale
+        self.guidance_adjust = self.cfg.guidance_adjust
+        self.do_classifier_free_guidance = self.initial_guidance_scale > 1.0
+        self.use_negative_text = self.cfg.use_negative_text
+        self.input_interpolate = self.cfg.input_interpolate
+        self.conditioning_scale = self.cfg.controlnet_scale
+        if self.conditioning_scale != 1.0:
+            raise NotImplementedError("controlnet_scale != 1")
         self.vae_scale_factor = down
         self.scaling_factor = self.vae_cfg.scaling_factor
+        self.default_latent_size = self.latent_hw
+        self.default_image_size = self.default_latent_size * self.vae_scale_factor
+        self.pipe = types.SimpleNamespace(unet=types.SimpleNamespace(config=types.SimpleNamespace(sample_size=self.latent_hw)))
+        self.scheduler = types.SimpleNamespace(scale_model_input=lambda sample, timestep=None: sample)   # DDPM / PNDM: identity
+        self.alphas_cumprod = sd15_alphas_cumprod(self.device)
+        self.num_train_timesteps = 1000
+        self.time_sampling = self.cfg.time_sampling
+        self.min_step_cfg = self.cfg.min_timestep if min_timestep is None else min_timestep
+        self.max_step_cfg = self.cfg.max_timestep if max_timestep is None else max_timestep
+        self.timestep, self.guidance_scale = None, self.initial_guidance_scale
 
+    # -- plans ---------------------------------------------------------------------------------------------------------
     def plans(self):
         return (self.denoiser.plan, self.vae.fwd, self.vae.bwd)
 
@@ -82,7 +119,45 @@ class ControlNetScoreDistillation:
         for p in self.plans():
             p.use_graph = bool(on)
 
-    # -- vae.py:34-40
+    # -- time_prior.py:292-352 ------------------------------------------------------------------------------------------
+    @property
+    def min_step(self):
+        return int(self.num_train_timesteps * C(self.min_step_cfg))
+
+    @property
+    def max_step(self):
+        return int(self.num_train_timesteps * C(self.max_step_cfg))
+
+    def get_timestep(self, batch_size=1, train_step=None, max_iteration=None):
+        if self.time_sampling == 'uniform':
+            return torch.randint(self.min_step, self.max_step + 1, [batch_size], dtype=torch.long, device=self.device)   # RNG draw #2
+        if self.time_sampling == 'constant':
+            mid = (self.min_step + self.max_step) // 2
+            return torch.randint(mid, mid + 1, [batch_size], dtype=torch.long, device=self.device)
+        if self.time_sampling == 'linear':
+            delta = (self.max_step - self.min_step) / (max_iteration - 1)
+            return torch.ones([batch_size], dtype=torch.long, device=self.device) * int(self.max_step - (train_step - 1) * delta)
+        raise NotImplementedError(self.time_sampling)
+
+    def add_noise(self, latents, noise, timestep):
+        """DDPMScheduler.add_noise [3P-memory]: sqrt(acp_t) x + sqrt(1 - acp_t) eps."""
+        a = self.alphas_cumprod[timestep].reshape(-1, 1, 1, 1)
+        return a.sqrt() * latents + (1 - a).sqrt() * noise
+
+    def get_guidance_scale(self, train_step, max_iteration):
+        """basic.py:404-418."""
+        s0 = self.initial_guidance_scale
+        if self.guidance_adjust == 'constant':
+            return s0
+        if self.guidance_adjust == 'uniform':
+            return np.random.uniform(7.5, s0)
+        if self.guidance_adjust == 'linear':
+            return s0 - (train_step - 1) * (s0 - 7.5) / (max_iteration - 1)
+        if self.guidance_adjust == 'linear_reverse':
+            return 7.5 + (train_step - 1) * (s0 - 7.5) / (max_iteration - 1)
+        raise NotImplementedError
+
+    # -- vae.py:34-40 ----------------------------------------------------------------------------------------------------
     def encode_images(self, images: torch.Tensor, posterior_noise: Optional[torch.Tensor] = None) -> torch.Tensor:
         moments = _VAEEncode.apply(images, self.vae)
         mean, logvar = moments.chunk(2, dim=1)
@@ -91,34 +166,120 @@ class ControlNetScoreDistillation:
             posterior_noise = torch.randn(mean.shape, device=mean.device, dtype=mean.dtype)      # RNG draw #1
         return (mean + std * posterior_noise) * self.scaling_factor
 
-    # -- controlnet.py:83-114
+    def prepare_latents(self, inputs: torch.Tensor, posterior_noise=None):
+        """basic.py:354-383 (RGB inputs)."""
+        if inputs.size(1) != 3:
+            raise NotImplementedError("latent-space inputs")
+        default_size = (self.default_image_size, self.default_image_size)
+        if self.input_interpolate and tuple(inputs.shape[-2:]) != default_size:
+            inputs = F.interpolate(inputs, default_size, mode='bilinear', align_corners=False)
+        assert tuple(inputs.shape[-2:]) == default_size, inputs.shape
+        return self.encode_images(inputs, posterior_noise), inputs
+
+    def preprocess(self, inputs, train_step, max_iteration, posterior_noise=None, **kwargs):
+        """basic.py:420-438."""
+        batch_size = inputs.size(0)
+        latents, inputs = self.prepare_latents(inputs, posterior_noise)
+        self.guidance_scale = kwargs.pop('guidance_scale') if 'guidance_scale' in kwargs else self.get_guidance_scale(train_step, max_iteration)
+        self.timestep = kwargs.pop('timestep') if 'timestep' in kwargs else self.get_timestep(batch_size, train_step, max_iteration)
+        return latents, inputs, kwargs
+
+    # -- controlnet.py:33-72 ---------------------------------------------------------------------------------------------
+    def prepare_image(self, image, width, height, batch_size, num_images_per_prompt, device, dtype) -> torch.Tensor:
+        from PIL import Image
+        if isinstance(image, Image.Image):
+            image = [image]
+        if not isinstance(image, torch.Tensor):
+            if isinstance(image[0], Image.Image):
+                image = [np.array(i.resize((width, height), resample=Image.Resampling.LANCZOS))[None, :] for i in image]
+                image = np.concatenate(image, axis=0)
+                image = np.array(image).astype(np.float32) / 255.0
+                image = torch.from_numpy(image.transpose(0, 3, 1, 2))
+            elif isinstance(image[0], torch.Tensor):
+                image = torch.cat(image, dim=0)
+        repeat_by = batch_size if image.shape[0] == 1 else num_images_per_prompt
+        image = image.repeat_interleave(repeat_by, dim=0)
+        return image.to(device=device, dtype=dtype)
+
+    def prepare_condition(self, cond_inputs, cond_width, cond_height, batch_size, dtype) -> torch.Tensor:
+        return self.prepare_image(cond_inputs, width=cond_width, height=cond_height, batch_size=batch_size, num_images_per_prompt=1,
+                                  device=self.device, dtype=dtype)
+
+    # -- controlnet.py:83-114 --------------------------------------------------------------------------------------------
     @torch.no_grad()
-    def _predict(self, latents_model_input, text_embeddings, cond_inputs, timestep):
-        """latents [2,4,h,w], text [2,77,768], cond [1,3,8h,8w] float in [0,1] (the PIL->tensor conversion of
-        controlnet.py:33-55 belongs to the data layer)."""
-        self.denoiser.set_inputs(latents_model_input, timestep, text_embeddings, cond_inputs)
+    def _predict(self, latents_model_input, text_embeddings, cond_inputs):
+        """latents [2,4,h,w], text [2,77,768], cond_inputs: list[PIL] | PIL | tensor [1 or 2,3,8h,8w] in [0,1].  The timestep is
+        self.timestep, as in the reference."""
+        _, _, lh, lw = latents_model_input.shape
+        cond = self.prepare_condition(cond_inputs, cond_height=lh * self.vae_scale_factor, cond_width=lw * self.vae_scale_factor,
+                                      batch_size=latents_model_input.size(0), dtype=torch.float32)
+        # the repeated condition rows are identical (controlnet.py:50-54): the hint embedding is computed once and broadcast
+        self.denoiser.set_inputs(latents_model_input, self.timestep, text_embeddings, cond[:1])
         return self.denoiser.run()
 
-    def get_timestep(self):
-        return torch.randint(self.min_step, self.max_step + 1, (1,), dtype=torch.long, device=self.device)   # RNG draw #2
+    def prepare_text_embeddings(self, text_embeds_dict: dict, text_keys: tuple):
+        return torch.concat([text_embeds_dict[k] for k in text_keys], dim=0)
 
-    def __call__(self, inputs: torch.Tensor, text_embeds_dict: Dict[str, torch.Tensor], train_step: int = 0,
-                 max_iteration: int = 1, cond_inputs=None, timestep=None, noise=None, posterior_noise=None, **_unused):
+    def calc_gradients(self, latents_noisy, text_embeds_dict, noise, guidance_rescale: float = 0.0, train_step=None, max_iteration=None,
+                       **kwargs):
+        """basic.py:546-663, the 'sds' branch."""
+        if self.do_classifier_free_guidance:
+            text_keys = ('neg', 'text') if self.use_negative_text else ('null', 'text')
+            text_embeddings = self.prepare_text_embeddings(text_embeds_dict, text_keys)
+            latents_model_input = torch.cat([latents_noisy] * 2, dim=0)
+        else:
+            raise NotImplementedError("guidance_scale <= 1 (no classifier-free guidance): the plans are built for the CFG batch of 2")
+        latents_model_input = self.scheduler.scale_model_input(latents_model_input, self.timestep)
+        noise_pred = self._predict(latents_model_input, text_embeddings, **kwargs)
+        noise_pred_uncond, noise_pred_text = noise_pred.chunk(2)
+        noise_pred = noise_pred_uncond + self.guidance_scale * (noise_pred_text - noise_pred_uncond)
+        if guidance_rescale > 0.0:
+            raise NotImplementedError("guidance_rescale")
+        gradients = noise_pred - noise
+        if self.weight_type is not None:
+            alphas = self.alphas_cumprod[self.timestep]
+            if self.weight_type == 'dreamfusion':
+                w = 1 - alphas
+            elif self.weight_type == 'latent-nerf':
+                w = (1 - alphas) * (alphas ** 0.5)
+            elif self.weight_type == 'ism':
+                w = ((1 - alphas) / alphas) ** 0.5
+            else:                                  # 'sjc'
+                w = None
+            if w is not None:
+                gradients = gradients * w.reshape(-1, 1, 1, 1)
+        if self.cfg.grad_latent_clip:
+            gs = gradients.nan_to_num(0.0, 0.0, 0.0)
+            std = ((gs ** 2).sum() / gs.count_nonzero()) ** 0.5 * self.cfg.grad_latent_clip_scale
+            gradients = torch.minimum(torch.maximum(gradients, -std), std).nan_to_num(0.0)
+        if self.cfg.grad_latent_norm:
+            gradients = torch.nn.functional.normalize(gradients.nan_to_num(0.0, 0.0, 0.0), p=2, dim=(1, 2, 3))
+        if self.cfg.grad_latent_nan_to_num:
+            gradients = torch.nan_to_num(gradients)
+        return gradients, noise_pred, text_embeddings
+
+    def __call__(self, inputs: torch.Tensor, text_embeds_dict: Dict[str, torch.Tensor], train_step: int = 0, max_iteration: int = 1,
+                 add_noise: bool = True, grad_viz: bool = False, noise=None, posterior_noise=None, **kwargs):
         """inputs [1,3,H,W] rendered image in [0,1] (requires grad).  Returns the reference's result dict."""
-        if inputs.shape[-1] != self.image_hw or inputs.shape[-2] != self.image_hw:
-            inputs = torch.nn.functional.interpolate(inputs, (self.image_hw, self.image_hw), mode="bilinear", align_corners=False)
-        latents = self.encode_images(inputs, posterior_noise)
-        t = self.get_timestep() if timestep is None else timestep
+        if inputs.size(1) == 3:                                            # pixel-wise gradient operations (basic.py:795-817)
+            if self.cfg.pgc_clip_rgb >= 0:
+                inputs.register_hook(build_pgc_hook_func(self.cfg.pgc_clip_rgb, self.cfg.pgc_suppress_type, kwargs.get('scaler')))
+            elif self.cfg.grad_rgb_clip or self.cfg.grad_rgb_norm:
+                mask = kwargs.pop('mask_inputs') if 'mask_inputs' in kwargs else None
+                inputs.register_hook(build_grad_hook_func(self.cfg.grad_rgb_clip, self.cfg.grad_rgb_norm, self.cfg.grad_rgb_clip_scale,
+                                                          scaler=kwargs.get('scaler'), mask=mask))
+        kwargs.pop('scaler', None)
+        latents, inputs, kwargs = self.preprocess(inputs, train_step, max_iteration, posterior_noise=posterior_noise, **kwargs)
         with torch.no_grad():
             if noise is None:
                 noise = torch.randn_like(latents)                                                  # RNG draw #3
-            a = self.alphas_cumprod[t].reshape(-1, 1, 1, 1)
-            latents_noisy = a.sqrt() * latents + (1 - a).sqrt() * noise
-            text = torch.cat([text_embeds_dict['neg'], text_embeds_dict['text']], dim=0)         # ('neg','text') basic.py:546-600
-            pred = self._predict(torch.cat([latents_noisy] * 2), text, cond_inputs, t)
-            noise_pred_uncond, noise_pred_text = pred.chunk(2)
-            noise_pred = noise_pred_uncond + self.guidance_scale * (noise_pred_text - noise_pred_uncond)
-            gradients = noise_pred - noise                                                         # weight_type 'sjc': w = 1
-        loss = SpecifyGradient.apply(latents, gradients)
-        return {"diffusion_loss": loss, "gradients": gradients, "timestep": t, "latents": latents, "sources": latents_noisy,
-                "targets": noise_pred}
+            latents_noisy = self.add_noise(latents, noise, self.timestep) if add_noise else latents
+        outputs = {'latents': latents, 'timestep': self.timestep}
+        with torch.no_grad():
+            gradients, noise_pred, _ = self.calc_gradients(latents_noisy=latents_noisy, text_embeds_dict=text_embeds_dict, noise=noise,
+                                                           train_step=train_step, max_iteration=max_iteration, **kwargs)
+            sources = latents
+            targets = (sources - gradients).detach()
+        outputs['sources'], outputs['targets'], outputs['gradients'] = sources, targets, gradients
+        outputs['diffusion_loss'] = SpecifyGradient.apply(sources, gradients)
+        return outputs

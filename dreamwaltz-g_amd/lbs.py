@@ -62,6 +62,13 @@ def lbs_blend(A, weights, points, quats=None, normalize_weights=False):
     return _LbsBlend.apply(A, weights, points, quats, normalize_weights)
 
 
+def lbs_blend_quaternions(A, weights, quats, normalize_weights=False):
+    """RigidTransform.transform_quaternions(q, weights=, flip_rotation_axis=True) on its own (inverse_lbs.py:234-242): the same
+    kernel with a zero point set (the weight rows dominate the traffic either way)."""
+    pts = torch.zeros(quats.shape[0], 3, device=quats.device, dtype=torch.float32)
+    return _LbsBlend.apply(A, weights, pts, quats, normalize_weights)[1]
+
+
 def joint_chain(pose, joints, parents, transl=None, return_rot_mats=False, joint_shape_dirs=None, shape_coeffs=None):
     """pose [J,3] axis-angle, joints [J,3], parents int32 [J] -> A [J,4,4] (= compose(J_pose_rigid, G_transl_offset))."""
     if not pose.is_cuda:
@@ -94,16 +101,52 @@ def gather_vertex_subset(vertex_indices, lbs_weights, shapedirs=None, posedirs=N
     return w_sub, sd, pd
 
 
-def vertex_transform(vertex_coords, A, subset, shape_coeffs=None, rot_mats=None):
+class _VertexTransformFn(torch.autograd.Function):
+    """out = transform_V[subset](vertex_coords); differentiable w.r.t. the shape coefficients (see dwg_lbs.h)."""
+
+    @staticmethod
+    def forward(ctx, vertex_coords, shape_coeffs, A, w_sub, sd, pd, rot_mats, pose, parents, joint_shape_dirs):
+        Vp, J = w_sub.shape
+        x = vertex_coords.detach().contiguous().float()
+        A = A.contiguous().float()
+        sc = None if shape_coeffs is None else shape_coeffs.detach().reshape(-1).contiguous().float()
+        out = torch.empty(Vp, 3, device=x.device)
+        p = _lib.ptr
+        _lib.check(_lib.lib().dwg_lbs_vertex_transform(
+            Vp, J, 0 if sd is None else sd.shape[-1], 0 if pd is None else pd.shape[-1], p(x), p(A), p(w_sub), p(sd), p(sc), p(pd),
+            p(None if rot_mats is None else rot_mats.contiguous().float()), p(out), _st(x)), "dwg_lbs_vertex_transform")
+        ctx.save_for_backward(A, w_sub, sd, pose, parents, joint_shape_dirs)
+        ctx.shape_shape = None if shape_coeffs is None else shape_coeffs.shape
+        return out
+
+    @staticmethod
+    def backward(ctx, g_out):
+        A, w_sub, sd, pose, parents, jdirs = ctx.saved_tensors
+        if ctx.shape_shape is None or not ctx.needs_input_grad[1]:
+            return (None,) * 10
+        if sd is None or pose is None or jdirs is None:
+            raise RuntimeError("gradient w.r.t. the shape coefficients needs shapedirs and the joint-chain inputs (pose, parents, "
+                               "joint_shape_dirs)")
+        Vp, J = w_sub.shape
+        S = sd.shape[-1]
+        g_shape = torch.empty(S, device=A.device)
+        scratch = torch.empty(J, 3, device=A.device)
+        p = _lib.ptr
+        _lib.check(_lib.lib().dwg_lbs_vertex_transform_backward_shape(
+            Vp, J, S, p(A), p(w_sub), p(sd), p(g_out.contiguous().float()), p(pose), p(parents), p(jdirs), p(scratch), p(g_shape),
+            _st(A)), "dwg_lbs_vertex_transform_backward_shape")
+        return None, g_shape.reshape(ctx.shape_shape), None, None, None, None, None, None, None, None
+
+
+def vertex_transform(vertex_coords, A, subset, shape_coeffs=None, rot_mats=None, joint_chain_ctx=None, pose=None):
     """transform_V (compose(V_shape_offset, V_pose_offset, V_pose_rigid, transl)) applied to a fixed vertex subset;
-    `subset` comes from gather_vertex_subset()."""
+    `subset` comes from gather_vertex_subset().  With joint_chain_ctx = (parents int32 [J], joint_shape_dirs [J,3,S], J_template)
+    and pose [J,3] the result is differentiable w.r.t. shape_coeffs (both the vertex offsets and the rest joints inside A)."""
     w_sub, sd, pd = subset
-    Vp, J = w_sub.shape
-    out = torch.empty(Vp, 3, device=vertex_coords.device)
-    p = _lib.ptr
-    _lib.check(_lib.lib().dwg_lbs_vertex_transform(
-        Vp, J, 0 if sd is None else sd.shape[-1], 0 if pd is None else pd.shape[-1], p(vertex_coords.contiguous().float()),
-        p(A.contiguous().float()), p(w_sub), p(sd), p(None if shape_coeffs is None else shape_coeffs.reshape(-1).contiguous().float()),
-        p(pd), p(None if rot_mats is None else rot_mats.contiguous().float()), p(out), _st(vertex_coords)),
-        "dwg_lbs_vertex_transform")
-    return out
+    if not vertex_coords.is_cuda:
+        raise RuntimeError("dreamwaltz_g_amd LBS runs on the GPU only (HIP kernels)")
+    parents = jdirs = None
+    if joint_chain_ctx is not None:
+        parents, jdirs = joint_chain_ctx[0].to(torch.int32).contiguous(), joint_chain_ctx[1].contiguous().float()
+    pose = None if pose is None else pose.detach().reshape(-1, 3).contiguous().float()
+    return _VertexTransformFn.apply(vertex_coords, shape_coeffs, A, w_sub, sd, pd, rot_mats, pose, parents, jdirs)

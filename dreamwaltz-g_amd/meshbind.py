@@ -88,3 +88,63 @@ class _MeshBind(torch.autograd.Function):
 def meshbind(bary, scales, verts_cnl, verts_obs, vnormals, triangles_i32, n_per_tri):
     """-> (canonical positions [M,3] (empty when verts_cnl is None), positions [M,3], scales [M,3], quaternions [M,4])."""
     return _MeshBind.apply(bary, scales, verts_cnl, verts_obs, vnormals, triangles_i32, n_per_tri)
+
+
+class _MeshBindFull(torch.autograd.Function):
+    """vertex normals + meshbind in one autograd node, with gradients to the (canonical / posed) vertices when they require them
+    (learn_hand_betas / learn_face_betas: the vertices then depend on `_betas`, avatar.py:1551-1577)."""
+
+    @staticmethod
+    def forward(ctx, bary, scales, verts_cnl, verts_obs, triangles_i32, vf_offsets, vf_faces, n_per_tri):
+        _need_cuda(bary, scales, verts_cnl, verts_obs, triangles_i32)
+        bary_c, scales_c = bary.detach().contiguous().float(), scales.detach().contiguous().float()
+        vc = None if verts_cnl is None else verts_cnl.detach().contiguous().float()
+        vo = verts_obs.detach().contiguous().float()
+        vn = vertex_normals(vo, triangles_i32, vf_offsets, vf_faces)
+        Fp = triangles_i32.shape[0]
+        M = Fp * n_per_tri
+        dev = bary.device
+        pos_c = torch.empty(M, 3, device=dev) if vc is not None else None
+        pos, scl, quat = torch.empty(M, 3, device=dev), torch.empty(M, 3, device=dev), torch.empty(M, 4, device=dev)
+        p = _lib.ptr
+        _lib.check(_lib.lib().dwg_meshbind_forward(Fp, n_per_tri, p(bary_c), p(scales_c), p(vc), p(vo), p(vn), p(triangles_i32),
+                                                   p(pos_c), p(pos), p(scl), p(quat), _st(bary)), "dwg_meshbind_forward")
+        ctx.save_for_backward(bary_c, scales_c, vc, vo, vn, triangles_i32, vf_offsets, vf_faces)
+        ctx.n_per_tri = n_per_tri
+        ctx.bary_shape = bary.shape
+        if pos_c is None:
+            pos_c = pos.new_empty(0, 3)
+            ctx.mark_non_differentiable(pos_c)
+        return pos_c, pos, scl, quat
+
+    @staticmethod
+    def backward(ctx, g_pos_c, g_pos, g_scl, g_quat):
+        bary_c, scales_c, vc, vo, vn, tri, vf_off, vf_faces = ctx.saved_tensors
+        Fp, Vp = tri.shape[0], vo.shape[0]
+        cg = lambda g: None if g is None else g.contiguous().float()  # noqa: E731
+        g_pos_c = cg(g_pos_c) if vc is not None else None
+        g_bary, g_sc = torch.empty_like(bary_c), torch.empty_like(scales_c)
+        p = _lib.ptr
+        L = _lib.lib()
+        want_v = ctx.needs_input_grad[3] or (vc is not None and ctx.needs_input_grad[2])
+        if not want_v:
+            _lib.check(L.dwg_meshbind_backward(Fp, ctx.n_per_tri, p(bary_c), p(scales_c), p(vc), p(vo), p(vn), p(tri), p(g_pos_c),
+                                               p(cg(g_pos)), p(cg(g_scl)), p(cg(g_quat)), p(g_bary), p(g_sc), _st(bary_c)),
+                       "dwg_meshbind_backward")
+            return g_bary.reshape(ctx.bary_shape), g_sc, None, None, None, None, None, None
+        g_vc = torch.zeros_like(vc) if vc is not None else None
+        g_vo, g_vn = torch.zeros_like(vo), torch.zeros_like(vo)
+        _lib.check(L.dwg_meshbind_backward_verts(Fp, ctx.n_per_tri, p(bary_c), p(scales_c), p(vc), p(vo), p(vn), p(tri), p(g_pos_c),
+                                                 p(cg(g_pos)), p(cg(g_scl)), p(cg(g_quat)), p(g_bary), p(g_sc), p(g_vc), p(g_vo), p(g_vn),
+                                                 _st(bary_c)), "dwg_meshbind_backward_verts")
+        fn = torch.empty(max(Fp, 1), 3, device=vo.device)
+        gs = torch.empty(Vp, 3, device=vo.device)
+        _lib.check(L.dwg_mesh_vertex_normals_backward(Vp, Fp, p(vo), p(tri), p(vf_off), p(vf_faces), p(g_vn), p(fn), p(gs), p(g_vo),
+                                                      _st(bary_c)), "dwg_mesh_vertex_normals_backward")
+        return g_bary.reshape(ctx.bary_shape), g_sc, g_vc, g_vo, None, None, None, None
+
+
+def meshbind_full(bary, scales, verts_cnl, verts_obs, triangles_i32, vf_offsets, vf_faces, n_per_tri):
+    """compute_normal + get_positions (canonical, observed) + get_scales_and_quaternions
+    -> (canonical positions [M,3] (empty when verts_cnl is None), positions [M,3], scales [M,3], quaternions [M,4])."""
+    return _MeshBindFull.apply(bary, scales, verts_cnl, verts_obs, triangles_i32, vf_offsets, vf_faces, n_per_tri)

@@ -1,0 +1,162 @@
+"""Optimizers of the SDS step behind the reference's seam.
+
+The reference builds a dict of named optimizers (`avatar.get_optimizer(cfg)`, /root/reference/core/system/avatar.py:1590-1635):
+  'avatar'     GaussianOptimizer (core/gaussian/gaussian_optimizer.py:49-141): Adam(lr=0, eps=1e-15) with groups positions / scales /
+               quaternions and `update_learning_rate(spatial_scale, iteration)` (exponential position schedule x spatial_scale,
+               scaling_lr x spatial_scale)
+  'lbs'        torch.optim.Adam (default eps 1e-8) over _lbs_weights / _betas when learned
+  'nerf'       Adam(betas=(0.9, 0.99), eps=1e-15): encoder lr 10 x nerf.lr, both MLPs nerf.lr
+  'mesh_<part>' Adam(lr=0, eps=1e-15): bary_coords (position_lr_init), scales (scaling_lr)
+and the trainer loops `optimizer.zero_grad()`, `optimizer.update_learning_rate(...)` (when present), `scaler.step(optimizer)` over
+them (core/trainer.py:861-890).  Here every one of those objects is a VIEW of one flat fp32 parameter buffer with flat gradient /
+first-moment / second-moment buffers next to it: the multi-view step all-reduces ONE tensor over RCCL, and each view's `step()` is
+a fused Adam launch per learning-rate group (csrc/elementwise.hip k_adam through include/dwg_elementwise.h).
+"""
+import ctypes
+import math
+from typing import Dict, List, Optional
+
+import torch
+
+from . import _lib
+
+
+def get_expon_lr_func(lr_init, lr_final, lr_delay_steps=0, lr_delay_mult=1.0, max_steps=1000000):
+    """Log-linear learning-rate decay with an optional eased-in start: mirror of core/optim/optim_utils.py:4-38 (host-side
+    float arithmetic; pinned against the reference's own function by tests/test_oracle_golden.py)."""
+    def helper(step):
+        if step < 0 or (lr_init == 0.0 and lr_final == 0.0):
+            return 0.0
+        if lr_delay_steps > 0:
+            delay_rate = lr_delay_mult + (1 - lr_delay_mult) * math.sin(0.5 * math.pi * min(max(step / lr_delay_steps, 0.0), 1.0))
+        else:
+            delay_rate = 1.0
+        t = min(max(step / max_steps, 0.0), 1.0)
+        return delay_rate * math.exp(math.log(lr_init) * (1 - t) + math.log(lr_final) * t)
+    return helper
+
+
+class AdamSpec:
+    """What one of the reference's optimizers is made of: param groups (+ Adam hyper-parameters); `gaussian` = the
+    OptimizationParams of a GaussianOptimizer (adds update_learning_rate)."""
+
+    def __init__(self, groups: List[dict], betas=(0.9, 0.999), eps=1e-8, gaussian: Optional[dict] = None):
+        self.groups, self.betas, self.eps, self.gaussian = groups, betas, eps, gaussian
+
+
+class FlatBuffers:
+    """ONE flat fp32 buffer each for parameters, gradients and the two Adam moments (16-byte aligned slices).  The nn.Parameters
+    are re-homed into the flat buffers (`.data` and `.grad` become views)."""
+
+    def __init__(self, params: List[torch.nn.Parameter], device):
+        total, self.slices = 0, []
+        for p in params:
+            self.slices.append((total, p.numel()))
+            total += (p.numel() + 3) // 4 * 4
+        self.flat = torch.zeros(total, device=device)
+        self.grad = torch.zeros(total, device=device)
+        self.m = torch.zeros(total, device=device)
+        self.v = torch.zeros(total, device=device)
+        for p, (off, n) in zip(params, self.slices):
+            self.flat[off:off + n].copy_(p.data.reshape(-1))
+            p.data = self.flat[off:off + n].view_as(p.data)
+            p.grad = self.grad[off:off + n].view_as(p.data)
+        self.total = total
+
+
+class FlatOptimizer:
+    """One of the named optimizers, as a view [start, end) of the flat buffers: same surface the trainer uses on the reference's
+    objects (param_groups, zero_grad, step, state_dict / load_state_dict, and update_learning_rate for 'avatar')."""
+
+    def __init__(self, name, buf: FlatBuffers, spec: AdamSpec, ranges):
+        self.name, self.buf, self.spec = name, buf, spec
+        self.param_groups = []
+        for g, (start, end) in zip(spec.groups, ranges):
+            pg = dict(g)
+            pg.update(betas=g.get('betas', spec.betas), eps=g.get('eps', spec.eps), start=start, end=end)
+            self.param_groups.append(pg)
+        self.start = min(r[0] for r in ranges)
+        self.end = max(r[1] for r in ranges)
+        self.t = 0
+        self.current_iteration = 0
+        self.grad_scale = 1.0        # 1 / world size for the multi-view step (mean of the all-reduced sum)
+        if spec.gaussian is not None:
+            ga = spec.gaussian
+            self.num_iterations = ga["iterations"]
+            self.default_scaling_lr = ga["scaling_lr"]
+            self.position_sheduler_func = get_expon_lr_func(lr_init=ga["position_lr_init"], lr_final=ga["position_lr_final"],
+                                                            lr_delay_mult=ga["position_lr_delay_mult"],
+                                                            max_steps=ga["position_lr_max_steps"])
+            self.update_learning_rate = self._update_learning_rate
+
+    def _update_learning_rate(self, spatial_scale: float, iteration: Optional[int] = None):
+        """GaussianOptimizer.update_learning_rate (gaussian_optimizer.py:130-141)."""
+        if iteration is None:
+            iteration = self.current_iteration
+        lr = 0.
+        for pg in self.param_groups:
+            if pg.get('name') == "positions":
+                lr = self.position_sheduler_func(iteration)
+                pg['lr'] = lr * spatial_scale
+            elif pg.get('name') == "scales":
+                lr = self.default_scaling_lr
+                pg['lr'] = lr * spatial_scale
+        return lr
+
+    def zero_grad(self, set_to_none: bool = False):
+        self.buf.grad[self.start:self.end].zero_()
+
+    def step(self):
+        self.t += 1
+        self.current_iteration += 1
+        L = _lib.lib()
+        b = self.buf
+        st = ctypes.c_void_p(torch.cuda.current_stream(b.flat.device).cuda_stream)
+        for pg in self.param_groups:
+            n, o = pg["end"] - pg["start"], pg["start"] * 4
+            _lib.check(L.dwg_adam_step(n, ctypes.c_void_p(b.flat.data_ptr() + o), ctypes.c_void_p(b.grad.data_ptr() + o),
+                                       ctypes.c_void_p(b.m.data_ptr() + o), ctypes.c_void_p(b.v.data_ptr() + o), float(pg["lr"]),
+                                       float(pg["betas"][0]), float(pg["betas"][1]), float(pg["eps"]), self.t, float(self.grad_scale), st),
+                       "dwg_adam_step")
+
+    def state_dict(self):
+        """Same information a torch Adam state_dict carries, flat: step count, per-group hyper-parameters and the two moments."""
+        return {"t": self.t, "current_iteration": self.current_iteration,
+                "param_groups": [{k: v for k, v in pg.items() if k != 'params'} for pg in self.param_groups],
+                "exp_avg": self.buf.m[self.start:self.end].clone(), "exp_avg_sq": self.buf.v[self.start:self.end].clone()}
+
+    def load_state_dict(self, sd):
+        self.t, self.current_iteration = int(sd["t"]), int(sd.get("current_iteration", sd["t"]))
+        for pg, s in zip(self.param_groups, sd["param_groups"]):
+            pg["lr"] = s["lr"]
+        self.buf.m[self.start:self.end].copy_(sd["exp_avg"]); self.buf.v[self.start:self.end].copy_(sd["exp_avg_sq"])
+
+
+class FlatOptimizerDict(dict):
+    """The dict `avatar.get_optimizer(cfg)` returns; `.buffers` is the shared flat storage (all-reduce operand)."""
+    buffers: FlatBuffers
+
+    def all_grads(self):
+        return self.buffers.grad
+
+    def set_grad_scale(self, s: float):
+        for o in self.values():
+            o.grad_scale = s
+
+
+def build_flat_optimizers(specs: Dict[str, AdamSpec], device) -> FlatOptimizerDict:
+    params = [p for spec in specs.values() for g in spec.groups for p in g['params']]
+    buf = FlatBuffers(params, device)
+    out = FlatOptimizerDict()
+    out.buffers = buf
+    i = 0
+    for name, spec in specs.items():
+        ranges = []
+        for g in spec.groups:
+            start = buf.slices[i][0]
+            for _ in g['params']:
+                off, n = buf.slices[i]
+                i += 1
+            ranges.append((start, (off + n + 3) // 4 * 4))
+        out[name] = FlatOptimizer(name, buf, spec, ranges)
+    return out

@@ -31,9 +31,44 @@ class GaussianRasterizationSettings(NamedTuple):
     debug: bool
 
 
-ASYNC = [False]        # True: no per-frame host sync (pair-buffer capacity from the previous frame; bench / training loop)
-_async_state = {}
-LAST_NUM_PAIRS = [0]   # (Gaussian, tile) pair count of the most recent forward (bench.py's roofline bytes)
+class PairCapacity:
+    """Sizing of the (Gaussian, block) pair workspace WITHOUT a per-frame host synchronisation (opt-in; the default path reads
+    the 4-byte pair count back like the reference's extension does).  One object per renderer and (device, H, W) -- no module
+    state.  The pair buffers of frame t are sized from the counts seen so far (with head-room; the workspace only costs memory,
+    288 GB of HBM make a generous bound free); frame t's real count and overflow flag come back through a pinned 16-byte copy
+    that `resolve()` waits on -- called from the backward of the same frame (by then the GPU is far past the forward, so
+    the wait is free) or at the next forward.  An overflow (stage B found fewer slots than pairs: the frame was truncated) is
+    LATCHED in `overflow`; the owner of the training step re-renders that frame before any optimizer step (`consume_overflow`)."""
+
+    def __init__(self, min_pairs=1 << 20, headroom=4.0):
+        self.cap = 0
+        self.min_pairs, self.headroom = int(min_pairs), float(headroom)
+        self.host = None
+        self.event = None
+        self.pending = False
+        self.overflow = False
+        self.last_num_pairs = 0          # pairs after exact culling (what the buffers hold)
+        self.last_num_pairs_ref = 0      # sum of 16x16 reference tiles touched (the K of SURVEY 8d's byte formula)
+
+    def seed(self, K):
+        self.cap = max(self.cap, int(K * self.headroom), self.min_pairs)
+
+    def resolve(self):
+        if not self.pending:
+            return
+        self.event.synchronize()
+        self.pending = False
+        K, ovf, Kref = int(self.host[0]), int(self.host[1]), int(self.host[2])
+        self.last_num_pairs, self.last_num_pairs_ref = K, Kref
+        if ovf:
+            self.overflow = True
+        if ovf or K * 2 > self.cap:
+            self.cap = max(self.cap, int(K * self.headroom))
+
+    def consume_overflow(self):
+        self.resolve()
+        o, self.overflow = self.overflow, False
+        return o
 
 
 def _f32c(t: Optional[torch.Tensor]) -> Optional[torch.Tensor]:
@@ -63,7 +98,7 @@ def _stream(device):
 class _RasterizeGaussians(torch.autograd.Function):
     @staticmethod
     def forward(ctx, means3D, means2D, sh, colors_precomp, opacities, scales, rotations, cov3Ds_precomp,
-                raster_settings: GaussianRasterizationSettings):
+                raster_settings: GaussianRasterizationSettings, pair_state: Optional[PairCapacity], info: dict):
         if not means3D.is_cuda:
             raise RuntimeError("dreamwaltz_g_amd rasterizer runs on the GPU only (HIP kernels); got a CPU tensor")
         L = _lib.lib()
@@ -92,32 +127,23 @@ class _RasterizeGaussians(torch.autograd.Function):
         radii = torch.zeros(G, dtype=torch.int32, device=device)
         st = _stream(device)
         p = _lib.ptr
+        if pair_state is not None:
+            pair_state.resolve()        # the previous frame's count (long complete): keeps `cap` current, latches an overflow
         _lib.check(L.dwg_raster_forward_bin(ctypes.byref(cfg), G, p(means3D), p(sh), p(colors_precomp), p(opac),
                                             p(scales), p(rotations), p(cov3D), p(radii), p(ws_geom), st),
                    "dwg_raster_forward_bin")
-        if ASYNC[0] and _async_state.get("cap", 0) > 0:
-            # no host synchronisation: size the pair buffers from the previous frames' pair count (with head-room) and
-            # check the recorded count / overflow flag of the PREVIOUS call, which has long completed
-            ast = _async_state
-            if ast.get("event") is not None:
-                ast["event"].synchronize()
-                kprev, ovf = int(ast["host"][0]), int(ast["host"][1])
-                LAST_NUM_PAIRS[0] = kprev
-                if ovf or kprev * 5 > ast["cap"] * 4:
-                    ast["cap"] = max(ast["cap"], int(kprev * 2))
-                    if ovf:
-                        import warnings
-                        warnings.warn("dreamwaltz_g_amd rasterizer: pair capacity overflow in the previous frame; capacity grown")
-            cap = ast["cap"]
-            K = -1
+        if pair_state is not None and pair_state.cap > 0:
+            cap = pair_state.cap        # no host synchronisation
         else:
-            # one 4-byte read-back sizes the pair buffers (the reference's extension does the same D2H copy)
-            K = int(ws_geom[:4].view(torch.int32).item())
-            LAST_NUM_PAIRS[0] = K
+            # one 16-byte read-back sizes the pair buffers exactly (the reference's extension does the same D2H copy)
+            hdr = ws_geom[:16].view(torch.int32).cpu()
+            K = int(hdr[0])
+            info["num_pairs"], info["num_pairs_ref"] = K, int(hdr[2])
             cap = max(K, 1)
-            if ASYNC[0]:
-                _async_state["cap"] = max(int(K * 2), 1024)
-                _async_state["host"] = torch.zeros(2, dtype=torch.int32).pin_memory()
+            if pair_state is not None:
+                pair_state.seed(K)
+                pair_state.last_num_pairs, pair_state.last_num_pairs_ref = K, int(hdr[2])
+                cap = pair_state.cap
         _lib.check(L.dwg_raster_workspace_sizes(G, H, W, cap, ctypes.byref(gb), ctypes.byref(pb), ctypes.byref(ib)),
                    "dwg_raster_workspace_sizes")
         ws_pairs = torch.empty(pb.value, dtype=torch.uint8, device=device)
@@ -126,14 +152,15 @@ class _RasterizeGaussians(torch.autograd.Function):
         alpha = torch.empty(1, H, W, dtype=torch.float32, device=device)
         _lib.check(L.dwg_raster_forward_render(ctypes.byref(cfg), G, p(ws_geom), p(ws_pairs), cap, p(ws_image),
                                                p(color), p(depth), p(alpha), st), "dwg_raster_forward_render")
-        if ASYNC[0]:
-            st2 = _async_state
-            st2["host"].copy_(ws_geom[:8].view(torch.int32), non_blocking=True)
+        if pair_state is not None:
+            if pair_state.host is None:
+                pair_state.host = torch.zeros(4, dtype=torch.int32).pin_memory()
+            pair_state.host.copy_(ws_geom[:16].view(torch.int32), non_blocking=True)
             ev = torch.cuda.Event(); ev.record(torch.cuda.current_stream(device))
-            st2["event"] = ev
+            pair_state.event, pair_state.pending = ev, True
         ctx.raster_settings = raster_settings
         ctx.cap = cap
-        ctx.num_pairs = K
+        ctx.pair_state = pair_state
         ctx.has = (sh is not None, colors_precomp is not None, scales is not None, cov3D is not None)
         ctx.save_for_backward(means3D, sh, colors_precomp, opac, scales, rotations, cov3D, ws_geom, ws_pairs, ws_image)
         ctx.mark_non_differentiable(radii)
@@ -146,6 +173,8 @@ class _RasterizeGaussians(torch.autograd.Function):
         rs = ctx.raster_settings
         device = means3D.device
         G = int(means3D.shape[0])
+        if ctx.pair_state is not None:
+            ctx.pair_state.resolve()     # this frame's forward finished long ago: free, and latches a capacity overflow
         keep = []
         M = int(sh.shape[1]) if sh is not None else 0
         cfg = _settings_struct(rs, device, M, keep)
@@ -168,19 +197,21 @@ class _RasterizeGaussians(torch.autograd.Function):
                                          p(ws_grad), p(g_color), p(g_depth), p(g_alpha), p(d_means3D), p(d_means2D),
                                          p(d_sh), p(d_colors), p(d_opac), p(d_scales), p(d_rots), p(d_cov),
                                          _stream(device)), "dwg_raster_backward")
-        return d_means3D, d_means2D, d_sh, d_colors, d_opac, d_scales, d_rots, d_cov, None
+        return d_means3D, d_means2D, d_sh, d_colors, d_opac, d_scales, d_rots, d_cov, None, None, None
 
 
 def rasterize_gaussians(means3D, means2D, sh, colors_precomp, opacities, scales, rotations, cov3Ds_precomp,
-                        raster_settings):
+                        raster_settings, pair_state=None, info=None):
     return _RasterizeGaussians.apply(means3D, means2D, sh, colors_precomp, opacities, scales, rotations,
-                                     cov3Ds_precomp, raster_settings)
+                                     cov3Ds_precomp, raster_settings, pair_state, {} if info is None else info)
 
 
 class GaussianRasterizer(torch.nn.Module):
-    def __init__(self, raster_settings: GaussianRasterizationSettings):
+    def __init__(self, raster_settings: GaussianRasterizationSettings, pair_state: Optional[PairCapacity] = None):
         super().__init__()
         self.raster_settings = raster_settings
+        self.pair_state = pair_state        # None: exact sizing through a 16-byte read-back per frame (the reference's behaviour)
+        self.info = {}                      # num_pairs / num_pairs_ref of the last synchronous forward
 
     def markVisible(self, positions: torch.Tensor) -> torch.Tensor:
         """Frustum test used by some callers of the original package: p_view.z > 0.2."""
@@ -198,4 +229,12 @@ class GaussianRasterizer(torch.nn.Module):
                 (scales is not None or rotations is not None) and cov3D_precomp is not None):
             raise Exception("Please provide exactly one of either scale/rotation pair or precomputed 3D covariance!")
         return rasterize_gaussians(means3D, means2D, shs, colors_precomp, opacities, scales, rotations, cov3D_precomp,
-                                   rs)
+                                   rs, self.pair_state, self.info)
+
+    @property
+    def last_num_pairs(self):
+        """(pairs after exact culling, pairs by the reference's 3-sigma tile count) of the most recent resolved forward."""
+        if self.pair_state is not None:
+            self.pair_state.resolve()
+            return self.pair_state.last_num_pairs, self.pair_state.last_num_pairs_ref
+        return self.info.get("num_pairs", 0), self.info.get("num_pairs_ref", 0)

@@ -1,57 +1,157 @@
-"""Mirror of GaussianRenderer (/root/reference/core/gaussian/gaussian_renderer.py:9-224): same constructor, same
-`build_gaussian_rasterizer(data)` / `render(data, gaussians, return_2d_radii, rasterizer)` contract and output dict,
-bound to the HIP rasterizer (rasterizer.py) instead of the CUDA package."""
+"""Mirror of GaussianRenderer (/root/reference/core/gaussian/gaussian_renderer.py:9-224):
+same constructor, same `build_gaussian_rasterizer(data)` / `compute_colors` / `compute_3d_covariance` /
+`render(data, gaussians, return_2d_radii, rasterizer)` contract and output dict, bound to the HIP rasterizer (rasterizer.py)
+instead of the CUDA package."""
+import ctypes
 from typing import Optional
 
 import torch
 
-from .rasterizer import GaussianRasterizationSettings, GaussianRasterizer
+from . import _lib
+from .rasterizer import GaussianRasterizationSettings, GaussianRasterizer, PairCapacity
+from .rigid import mm4, quaternion_to_matrix
+
+# real spherical harmonics, degree <= 3 (core/gaussian/spherical_harmonics.py:5-40,117-172)
+C0 = 0.28209479177387814
+C1 = 0.4886025119029199
+C2 = [1.0925484305920792, -1.0925484305920792, 0.31539156525252005, -1.0925484305920792, 0.5462742152960396]
+C3 = [-0.5900435899266435, 2.890611442640554, -0.4570457994644658, 0.3731763325901154, -0.4570457994644658, 1.445305721320277,
+      -0.5900435899266435]
+
+
+def eval_sh(deg: int, sh: torch.Tensor, dirs: torch.Tensor) -> torch.Tensor:
+    """sh [..., C, (deg+1)^2], dirs [..., 3] unit -> [..., C] (degree <= 3: what the rasterizer supports; the Python-side colour
+    path exists for `compute_color_in_rasterizer=False` and the sh_levels=1 background of scene.py:123-132)."""
+    assert 0 <= deg <= 3, "SH degree 0..3"
+    result = C0 * sh[..., 0]
+    if deg > 0:
+        x, y, z = dirs[..., 0:1], dirs[..., 1:2], dirs[..., 2:3]
+        result = result - C1 * y * sh[..., 1] + C1 * z * sh[..., 2] - C1 * x * sh[..., 3]
+        if deg > 1:
+            xx, yy, zz = x * x, y * y, z * z
+            xy, yz, xz = x * y, y * z, x * z
+            result = (result + C2[0] * xy * sh[..., 4] + C2[1] * yz * sh[..., 5] + C2[2] * (2.0 * zz - xx - yy) * sh[..., 6] +
+                      C2[3] * xz * sh[..., 7] + C2[4] * (xx - yy) * sh[..., 8])
+            if deg > 2:
+                result = (result + C3[0] * y * (3 * xx - yy) * sh[..., 9] + C3[1] * xy * z * sh[..., 10] +
+                          C3[2] * y * (4 * zz - xx - yy) * sh[..., 11] + C3[3] * z * (2 * zz - 3 * xx - 3 * yy) * sh[..., 12] +
+                          C3[4] * x * (4 * zz - xx - yy) * sh[..., 13] + C3[5] * z * (xx - yy) * sh[..., 14] +
+                          C3[6] * x * (xx - 3 * yy) * sh[..., 15])
+    return result
+
+
+def get_colors(sh_features, directions, sh_levels):
+    """core/gaussian/gaussian_utils.py:12-17."""
+    sh_features = sh_features[:, :sh_levels ** 2]
+    shs_view = sh_features.transpose(-1, -2).reshape(-1, 3, sh_levels ** 2)
+    return torch.clamp_min(eval_sh(sh_levels - 1, shs_view, directions) + 0.5, 0.0).view(-1, 3)
 
 
 class GaussianRenderer:
     def __init__(self, sh_levels=4, bg_color=(0.0, 0.0, 0.0), compute_color_in_rasterizer=True,
-                 compute_covariance_in_rasterizer=True) -> None:
+                 compute_covariance_in_rasterizer=True, async_pair_count=False) -> None:
         self.sh_levels = sh_levels
         self.bg_color = torch.tensor(bg_color, dtype=torch.float32)
         self.compute_color_in_rasterizer = compute_color_in_rasterizer
         self.compute_covariance_in_rasterizer = compute_covariance_in_rasterizer
+        # opt-in: size the pair workspace without a host synchronisation per frame (rasterizer.PairCapacity); state lives HERE,
+        # per renderer and per (device, H, W)
+        self.async_pair_count = async_pair_count
+        self._pair_states = {}
         self._bg_dev = {}
+        self.last_rasterizer = None
+
+    # -- capacity bookkeeping of the async mode ------------------------------------------------------------------------
+    def pair_state(self, device, H, W) -> Optional[PairCapacity]:
+        if not self.async_pair_count:
+            return None
+        key = (str(device), int(H), int(W))
+        if key not in self._pair_states:
+            self._pair_states[key] = PairCapacity()
+        return self._pair_states[key]
+
+    def consume_overflow(self) -> bool:
+        """True if a frame since the last call was truncated by the pair capacity (to be re-rendered by the caller)."""
+        return any([st.consume_overflow() for st in self._pair_states.values()])
 
     def build_gaussian_rasterizer(self, data: dict, **kwargs) -> GaussianRasterizer:
-        """gaussian_renderer.py:23-70.  The reference reads tanfov with .item() (a host sync); a float already on the host
-        (data['tanfov_host']) is used when the caller provides one."""
+        """gaussian_renderer.py:23-70.  viewmatrix = extrinsic[0]^T, projmatrix = viewmatrix @ projection[0]^T, campos =
+        c2w[0,:3,3]; on the GPU the three come out of one small launch (no library GEMM for a 4x4 product)."""
         world_view_matrix = data['extrinsic'][0]
         projection_matrix = data['projection'][0]
+        image_width, image_height = data['image_width'], data['image_height']
+        tanfovy = data['tanfov'][0].item()
+        tanfovx = data['tanfov_x'][0].item() if 'tanfov_x' in data else tanfovy
         device = world_view_matrix.device
-        if 'tanfov_host' in data:
-            tanfovy = float(data['tanfov_host'])
-            tanfovx = float(data.get('tanfov_x_host', tanfovy))
+        if device.type == 'cuda':
+            out = torch.empty(35, device=device, dtype=torch.float32)
+            p = _lib.ptr
+            _lib.check(_lib.lib().dwg_raster_camera_setup(p(world_view_matrix.float().contiguous()), p(projection_matrix.float().contiguous()),
+                                                          p(data['c2w'][0].float().contiguous()), p(out),
+                                                          ctypes.c_void_p(torch.cuda.current_stream(device).cuda_stream)),
+                       "dwg_raster_camera_setup")
+            viewmatrix, projmatrix, campos = out[:16].view(4, 4), out[16:32].view(4, 4), out[32:35]
         else:
-            tanfovy = data['tanfov'][0].item()
-            tanfovx = data['tanfov_x'][0].item() if 'tanfov_x' in data else tanfovy
-        viewmatrix = world_view_matrix.transpose(0, 1)
-        projmatrix = viewmatrix @ projection_matrix.transpose(0, 1)
+            viewmatrix = world_view_matrix.transpose(0, 1)
+            projmatrix = mm4(viewmatrix, projection_matrix.transpose(0, 1))
+            campos = data['c2w'][0, :3, 3]
         if device not in self._bg_dev:
             self._bg_dev[device] = self.bg_color.to(device)
-        settings = {
-            "image_height": data['image_height'], "image_width": data['image_width'], "tanfovx": tanfovx, "tanfovy": tanfovy,
+        raster_settings = {
+            "image_height": image_height, "image_width": image_width, "tanfovx": tanfovx, "tanfovy": tanfovy,
             "bg": self._bg_dev[device], "viewmatrix": viewmatrix, "projmatrix": projmatrix, "sh_degree": self.sh_levels - 1,
-            "campos": data['c2w'][0, :3, 3],
+            "campos": campos,
         }
-        settings.update(kwargs)
-        return GaussianRasterizer(raster_settings=GaussianRasterizationSettings(**settings, scale_modifier=1.,
-                                                                                prefiltered=False, debug=False))
+        raster_settings.update(kwargs)
+        for key, value in raster_settings.items():
+            if isinstance(value, torch.Tensor):
+                raster_settings[key] = value.to(device)
+        settings = GaussianRasterizationSettings(**raster_settings, scale_modifier=1., prefiltered=False, debug=False)
+        return GaussianRasterizer(raster_settings=settings, pair_state=self.pair_state(device, image_height, image_width))
+
+    def compute_colors(self, sh_features, directions=None, positions=None, camera_positions=None, sh_levels=None, sh_rotations=None):
+        """gaussian_renderer.py:72-105."""
+        if directions is None:
+            if positions is None or camera_positions is None:
+                raise ValueError("Either directions or positions must be provided.")
+            directions = torch.nn.functional.normalize(positions - camera_positions, dim=-1)
+        if sh_rotations is not None:
+            directions = (directions.unsqueeze(1) @ sh_rotations)[..., 0, :]
+        if sh_levels is None:
+            sh_levels = self.sh_levels
+        return get_colors(sh_features=sh_features, directions=directions, sh_levels=sh_levels)
+
+    @staticmethod
+    def compute_3d_covariance(scales, quaternions):
+        """gaussian_renderer.py:107-128: R diag(s^2) R^T, upper triangle (xx, xy, xz, yy, yz, zz)."""
+        R = quaternion_to_matrix(quaternions)
+        M = R * (scales * scales).unsqueeze(-2)             # R diag(s^2)
+        cov = mm4(M, R.transpose(-1, -2))
+        return torch.stack([cov[:, 0, 0], cov[:, 0, 1], cov[:, 0, 2], cov[:, 1, 1], cov[:, 1, 2], cov[:, 2, 2]], dim=1).float()
 
     def render(self, data: dict, gaussians, return_2d_radii: bool = False,
                rasterizer: Optional[GaussianRasterizer] = None) -> dict:
+        """gaussian_renderer.py:130-224 (mutates `gaussians` like the reference: checklist Q9)."""
         if rasterizer is None:
             rasterizer = self.build_gaussian_rasterizer(data=data)
+        self.last_rasterizer = rasterizer
         if gaussians.colors is not None:
-            gaussians.sh_features = None     # checklist Q9: the argument is mutated, as in the reference
+            gaussians.sh_features = None
+        elif not self.compute_color_in_rasterizer:
+            gaussians.colors = self.compute_colors(sh_features=gaussians.sh_features, positions=gaussians.positions,
+                                                   camera_positions=data['c2w'][:, :3, 3])
+            gaussians.sh_features = None
+        if not self.compute_covariance_in_rasterizer:
+            gaussians.cov3D = self.compute_3d_covariance(scales=gaussians.scales, quaternions=gaussians.quaternions)
+            gaussians.quaternions = None
+            gaussians.scales = None
         means3D = gaussians.positions
         screenspace_points = torch.zeros(means3D.shape[0], 3, dtype=means3D.dtype, requires_grad=True, device=means3D.device)
         if return_2d_radii:
-            screenspace_points.retain_grad()
+            try:
+                screenspace_points.retain_grad()
+            except Exception:
+                print("WARNING: return_2d_radii is True, but failed to retain grad of screenspace_points!")
         image, radii, depth, alpha = rasterizer(
             means3D=means3D, means2D=screenspace_points, shs=gaussians.sh_features, colors_precomp=gaussians.colors,
             opacities=gaussians.opacities, scales=gaussians.scales, rotations=gaussians.quaternions,

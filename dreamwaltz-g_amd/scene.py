@@ -1,0 +1,103 @@
+"""Mirror of Scene (/root/reference/core/system/scene.py:15-168; SURVEY.md section 8a row R7, boundary B5): avatar_forward
+(optional per-avatar scale / translation), multi-avatar merge, the debug overrides, GaussianRenderer.render, and the background
+compositing `image + bg (1 - alpha)` for bg_mode in {black, white, gray}.  Learned / video / Gaussian backgrounds are outside the
+hot path (scene.py:123-132,158-165) and are rejected."""
+from typing import Iterable, Optional
+
+import torch
+import torch.nn as nn
+
+from .avatar import DreamWaltzG, GaussianOutput, merge_gaussians
+from .renderer import GaussianRenderer
+
+
+class PureColorBackground:
+    """core/system/background.py:14-57."""
+    COLOR_VALUE_MAPPING = {'black': 0.0, 'white': 1.0, 'gray': 0.5}
+
+    def __contains__(self, bg_mode):
+        return bg_mode in ('black', 'white', 'gray')
+
+    @staticmethod
+    def get_background_like(color: str, image: torch.Tensor) -> torch.Tensor:
+        return torch.full_like(image, PureColorBackground.COLOR_VALUE_MAPPING[color])
+
+
+def downsample_gaussians(gaussians: GaussianOutput, n: int) -> GaussianOutput:
+    """gaussian_utils.py downsample_gaussians: a random subset of n Gaussians (debug override use_fixed_n_gaussians)."""
+    total = gaussians.positions.shape[0]
+    if n >= total:
+        return gaussians
+    idx = torch.randperm(total, device=gaussians.positions.device)[:n]
+    return GaussianOutput(**{k: (gaussians[k][idx] if torch.is_tensor(gaussians[k]) else None) for k in gaussians.keys()})
+
+
+class Scene(nn.Module):
+    def __init__(self, cfg, avatar, background=None, async_pair_count=False) -> None:
+        super().__init__()
+        if background is not None:
+            raise NotImplementedError("learned / video / Gaussian backgrounds are outside the SDS hot path (scene.py:123-132,158-165)")
+        self.device = torch.device(cfg.device)
+        if isinstance(avatar, DreamWaltzG):
+            self.avatar, self.avatars = avatar, None
+        else:
+            self.avatars = nn.ModuleList(avatar)
+            self.avatar = self.avatars[0]
+        self.background = None
+        self.pure_colors = PureColorBackground()
+        self.renderer = GaussianRenderer(sh_levels=cfg.render.sh_levels, bg_color=cfg.render.bg_color, async_pair_count=async_pair_count)
+        r = cfg.render
+        self.use_zero_scales = r.use_zero_scales
+        self.use_constant_colors = r.use_constant_colors is not None
+        self.constant_colors = None if r.use_constant_colors is None else torch.tensor([r.use_constant_colors], device=self.device)
+        self.use_constant_opacities = r.use_constant_opacities is not None
+        self.constant_opacities = None if r.use_constant_opacities is None else torch.tensor([r.use_constant_opacities], device=self.device)
+        self.use_fixed_n_gaussians = r.use_fixed_n_gaussians is not None
+        self.fixed_n_gaussians = None if r.use_fixed_n_gaussians is None else int(r.use_fixed_n_gaussians)
+        self.avatar_transl = torch.tensor(eval(r.avatar_transl), device=self.device) if r.avatar_transl is not None else None
+        self.avatar_scale = torch.tensor(eval(r.avatar_scale), device=self.device) if r.avatar_scale is not None else None
+
+    def avatar_forward(self, smpl_observed_inputs: Optional[dict] = None, avatar=None, avatar_index: Optional[int] = None) -> GaussianOutput:
+        if avatar is None:
+            avatar = self.avatar
+        gaussians = avatar.forward() if smpl_observed_inputs is None else avatar.animate(smpl_observed_inputs=smpl_observed_inputs)
+        if self.avatar_scale is not None:
+            s = self.avatar_scale
+            if s.ndim == 1:
+                s = s[avatar_index]
+            gaussians.positions = gaussians.positions * s.unsqueeze(0)
+            gaussians.scales = gaussians.scales * s.unsqueeze(0)
+        if self.avatar_transl is not None:
+            t = self.avatar_transl
+            if t.ndim == 2:
+                t = t[avatar_index]
+            gaussians.positions = gaussians.positions + t.unsqueeze(0)
+        return gaussians
+
+    def forward(self, data: dict, smpl_observed_inputs: Optional[dict] = None, use_densifier: bool = True, bg_mode: Optional[str] = None,
+                **kwargs):
+        if self.avatars is None:
+            gaussians = self.avatar_forward(smpl_observed_inputs=smpl_observed_inputs)
+        else:
+            parts = []
+            batch_size = smpl_observed_inputs['body_pose'].size(0)
+            assert batch_size <= len(self.avatars), f'Assert num_smplx_inputs: {batch_size} <= num_avatars: {len(self.avatars)}'
+            for i, avatar in enumerate(self.avatars):
+                parts.append(self.avatar_forward({k: v[i:i + 1, ...] for k, v in smpl_observed_inputs.items()}, avatar=avatar, avatar_index=i))
+            gaussians = merge_gaussians(*parts)
+        if self.use_zero_scales:
+            gaussians.scales = gaussians.scales * 0.1
+        if self.use_constant_colors:
+            gaussians.colors = self.constant_colors.expand(gaussians.colors.size(0), -1)
+        if self.use_constant_opacities:
+            gaussians.opacities = self.constant_opacities.expand(gaussians.opacities.size(0), -1)
+        if self.use_fixed_n_gaussians:
+            gaussians = downsample_gaussians(gaussians, self.fixed_n_gaussians)
+        outputs = self.renderer.render(data=data, gaussians=gaussians, return_2d_radii=use_densifier)
+        if bg_mode in self.pure_colors:
+            outputs['image_bg'] = self.pure_colors.get_background_like(bg_mode, outputs['image'])
+            outputs['image_fg'] = outputs['image']
+            outputs['image'] = outputs['image'] + outputs['image_bg'] * (1 - outputs['alpha'])
+        else:
+            outputs['image_fg'] = outputs['image']
+        return outputs

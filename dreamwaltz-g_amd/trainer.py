@@ -1,0 +1,94 @@
+"""The loop body of the reference's Trainer.train() for the 3DGS stage, on the HIP path (boundary B5):
+
+  render(data, bg_mode)      /root/reference/core/trainer.py:680-709     -> Scene.forward
+  get_spatial_scale(data)    trainer.py:711-716
+  train_forward(data)        trainer.py:933-1017   render -> NCHW -> view-dependent text embedding -> diffusion(**sd_kwargs) -> loss
+  train_step(data)           trainer.py:859-890    forward; zero_grad + update_learning_rate on every optimizer; backward;
+                                                   [multi-view: ONE all-reduce of the flat gradient buffer]; step on every optimizer
+
+Method and dictionary-key names are the reference's.  What is added: the flat-buffer all-reduce of the multi-view step
+(nothing in the reference to mirror) and the same-frame recovery of a pair-capacity overflow in the sync-free mode.
+"""
+from typing import Any, Dict, Optional
+
+import torch
+
+from .text import TextAugmentation
+
+
+class SDSTrainer:
+    def __init__(self, cfg, model, diffusion, optimizers, text_embeds_dict: Optional[dict] = None, use_controlnet: bool = True,
+                 dist=None, world: int = 1, max_step: Optional[int] = None):
+        self.cfg, self.model, self.diffusion, self.optimizers = cfg, model, diffusion, optimizers
+        self.text_embeds_dict = text_embeds_dict if text_embeds_dict is not None else {}
+        self.view_prompt = TextAugmentation(cfg.guide.text, cfg.prompt) if cfg.prompt.text_augmentation else None
+        self.use_controlnet = use_controlnet
+        self.dist, self.world = dist, world
+        self.train_step_index = 0
+        self.max_step = cfg.optim.iters if max_step is None else max_step
+        self.scaler = None                          # GradScaler(enabled=False) in the fp32 recipes: pass-through
+        self.redone_frames = 0
+        if hasattr(optimizers, "set_grad_scale"):
+            optimizers.set_grad_scale(1.0 / world)  # mean of the all-reduced (summed) gradients, folded into the Adam kernel
+
+    def render(self, data, bg_mode=None):
+        if self.cfg.prompt.scene != 'canonical' or self.cfg.render.always_animate:
+            smpl_observed_inputs = data['smpl_inputs']
+        else:
+            smpl_observed_inputs = None
+        use_densifier = self.model.training and self.cfg.render.use_densifier
+        return self.model.forward(data=data, smpl_observed_inputs=smpl_observed_inputs, use_densifier=use_densifier, bg_mode=bg_mode)
+
+    def get_spatial_scale(self, data):
+        if self.cfg.render.spatial_scale is None:
+            return data['radius'].mean().item() * data['tanfov'].mean().item()
+        return self.cfg.render.spatial_scale
+
+    def train_forward(self, data: Dict[str, Any], **forced):
+        """`forced` (timestep=, noise=, posterior_noise=) pins the random draws for parity tests."""
+        render_outputs = self.render(data=data)
+        sd_inputs = render_outputs['image'].permute(0, 3, 1, 2).contiguous()
+        if self.cfg.prompt.text_augmentation and 'viewed' in self.text_embeds_dict:
+            view_index = self.view_prompt(azim=data['azimuth'], elev=data['elevation']).item()
+            self.text_embeds_dict['text'] = self.text_embeds_dict['viewed'][view_index]
+            text = self.view_prompt.texts[view_index]
+        else:
+            if 'pos' in self.text_embeds_dict:
+                self.text_embeds_dict['text'] = self.text_embeds_dict['pos']
+            text = self.cfg.guide.text
+        sd_kwargs = {'inputs': sd_inputs, 'text_embeds_dict': self.text_embeds_dict, 'train_step': self.train_step_index,
+                     'max_iteration': self.max_step, 'grad_viz': False, 'scaler': self.scaler}
+        if self.use_controlnet:
+            sd_kwargs['cond_inputs'] = data['cond_images']
+        sd_kwargs.update(forced)
+        sd_outputs = self.diffusion(**sd_kwargs)
+        diffusion_loss = sd_outputs['diffusion_loss'] * self.cfg.guide.lambda_guidance
+        render_outputs['regularizations'] = {}
+        total_loss = 0.0
+        total_loss += diffusion_loss
+        return total_loss, render_outputs, sd_outputs, text
+
+    def _forward_backward(self, data, spatial_scale, **forced):
+        loss, render_outputs, sd_outputs, text = self.train_forward(data, **forced)
+        for optimizer in self.optimizers.values():
+            optimizer.zero_grad()
+            if hasattr(optimizer, 'update_learning_rate'):
+                optimizer.update_learning_rate(iteration=self.train_step_index, spatial_scale=spatial_scale)
+        loss.backward()
+        return loss, render_outputs, sd_outputs, text
+
+    def train_step(self, data: Dict[str, Any], **forced):
+        self.train_step_index += 1
+        spatial_scale = self.get_spatial_scale(data)
+        out = self._forward_backward(data, spatial_scale, **forced)
+        # sync-free pair sizing: the rasterizer's backward has already waited for this frame's pair count; a frame whose pair
+        # workspace was too small is rendered again (capacity has grown) BEFORE anything reaches the optimizers
+        renderer = getattr(self.model, "renderer", None)
+        while renderer is not None and renderer.consume_overflow():
+            self.redone_frames += 1
+            out = self._forward_backward(data, spatial_scale, **forced)
+        if self.world > 1:
+            self.dist.all_reduce(self.optimizers.all_grads())       # RCCL over xGMI: one flat fp32 buffer
+        for optimizer in self.optimizers.values():
+            optimizer.step()
+        return out

@@ -51,6 +51,17 @@ int dwg_lbs_vertex_transform(int32_t Vp, int32_t J, int32_t n_shape, int32_t n_p
                              const float* posedirs_sub, const float* rot_mats /*[J,9]*/, float* out /*[Vp,3]*/,
                              dwg_stream_t stream);
 
+/* Gradient of dwg_lbs_vertex_transform's output w.r.t. the shape coefficients (`learn_hand_betas` / `learn_face_betas`,
+ * avatar.py:1551-1553; scripts/train_w_expr.sh:66): both dependency paths -- the per-vertex blend-shape offset and the rest
+ * joints J(beta) that enter every A_j's translation through the kinematic chain (smplx batch_rigid_transform).  The joint
+ * rotations do not depend on the coefficients, so for a fixed pose the map is linear and this is exact.
+ * g_shape [n_shape] is OVERWRITTEN; g_A_transl_scratch [J,3] is scratch; pose [J,3] / parents / joint_shape_dirs [J,3,S] are the
+ * inputs dwg_lbs_joint_chain was called with. */
+int dwg_lbs_vertex_transform_backward_shape(int32_t Vp, int32_t J, int32_t n_shape, const float* A, const float* lbs_weights_sub,
+                                            const float* shapedirs_sub, const float* g_out /*[Vp,3]*/, const float* pose,
+                                            const int32_t* parents, const float* joint_shape_dirs, float* g_A_transl_scratch,
+                                            float* g_shape, dwg_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

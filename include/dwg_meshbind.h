@@ -39,6 +39,21 @@ int dwg_meshbind_backward(int32_t Fp, int32_t n_per_tri, const float* bary, cons
                           const float* g_pos, const float* g_scales, const float* g_quats, float* g_bary /*[Fp,n,3]*/,
                           float* g_scale_params /*[M,3]*/, dwg_stream_t stream);
 
+/* Same as dwg_meshbind_backward and additionally ACCUMULATES (buffers zeroed by the caller) the gradients w.r.t. the posed
+ * vertices, their vertex normals and the canonical vertices -- needed when the vertices depend on a learnable parameter
+ * (`learn_hand_betas` / `learn_face_betas`: avatar.py:1551-1577, scripts/train_w_expr.sh:66).  g_verts_cnl may be NULL. */
+int dwg_meshbind_backward_verts(int32_t Fp, int32_t n_per_tri, const float* bary, const float* scale_params, const float* verts_cnl,
+                                const float* verts_obs, const float* vnormals_obs, const int32_t* triangles, const float* g_pos_cnl,
+                                const float* g_pos, const float* g_scales, const float* g_quats, float* g_bary, float* g_scale_params,
+                                float* g_verts_cnl /*[Vp,3]*/, float* g_verts_obs /*[Vp,3]*/, float* g_vnormals_obs /*[Vp,3]*/,
+                                dwg_stream_t stream);
+
+/* Backward of dwg_mesh_vertex_normals (autograd through compute_normal, utils/mesh.py:34-94): adds d loss / d verts into g_verts
+ * [Vp,3] given d loss / d vertex_normals.  face_normals_scratch [Fp,3] and g_sum_scratch [Vp,3] are overwritten. */
+int dwg_mesh_vertex_normals_backward(int32_t Vp, int32_t Fp, const float* verts, const int32_t* triangles, const int32_t* vf_offsets,
+                                     const int32_t* vf_faces, const float* g_vertex_normals, float* face_normals_scratch,
+                                     float* g_sum_scratch, float* g_verts, dwg_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

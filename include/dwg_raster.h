@@ -53,11 +53,20 @@ int dwg_raster_workspace_sizes(int32_t num_gaussians, int32_t image_height, int3
                                int64_t pair_capacity, size_t* geom_bytes, size_t* pairs_bytes,
                                size_t* image_bytes);
 
-/* Device address (inside the geometry workspace) of the int32 pair count K written by stage A,
- * followed by an int32 overflow flag written by stage B. */
+/* Device address (inside the geometry workspace) of the int32 header written by stage A / B:
+ *   [0] K     pairs (Gaussian, 8x8 block) after exact culling = what the pair workspace must hold
+ *   [1] overflow flag (stage B found pair_capacity < K: the frame is truncated and must be redone)
+ *   [2] K_ref  sum over Gaussians of the 16x16 reference tiles their 3-sigma square touches (the K of SURVEY 8d's byte formula)
+ *   [3] number of backward segments. */
 const int32_t* dwg_raster_num_pairs_ptr(const void* ws_geom);
 
-/* Stage A: project, build splat records, count tiles, exclusive-scan the tile histogram. */
+/* viewmatrix = extrinsic^T, projmatrix = viewmatrix @ projection^T, campos = c2w[:3,3] exactly as
+ * GaussianRenderer.build_gaussian_rasterizer forms them (gaussian_renderer.py:38-41), in one launch:
+ * out35 = [viewmatrix 16 | projmatrix 16 | campos 3].  All pointers device, row-major 4x4. */
+int dwg_raster_camera_setup(const float* extrinsic, const float* projection, const float* c2w, float* out35,
+                            dwg_stream_t stream);
+
+/* Stage A: project, build splat records, count (exact-culled) pairs per 8x8 pixel block, scan. */
 int dwg_raster_forward_bin(const dwg_raster_settings* cfg, int32_t num_gaussians,
                            const float* means3D, const float* shs, const float* colors_precomp,
                            const float* opacities, const float* scales, const float* rotations,

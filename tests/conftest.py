@@ -12,6 +12,7 @@ import dwg_import  # noqa: E402,F401  registers dreamwaltz_g_amd
 
 def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
+    config.addinivalue_line("markers", "slow: full-size parity against the CPU oracle (tens of seconds of host arithmetic)")
 
 
 def pytest_collection_modifyitems(config, items):

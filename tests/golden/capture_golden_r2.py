@@ -371,6 +371,7 @@ def main():
                 put("sd.animate.cnl." + k, v)
             for k, v in obs.items():
                 put("sd.animate.obs." + k, v)
+            OUT["sd.animate.state_dict_keys"] = np.array(sorted(a.state_dict().keys()))
             put("sd.animate.nets_seed", np.array([4])); put("sd.animate.table_std", np.array([0.3]))
             put("sd.animate.body", np.array([300, 500, 3]))
             # inverse_lbs_transform (avatar.py:1390-1424): general 3x3 inverse of the blended matrix (checklist Q8)

@@ -17,16 +17,20 @@ def _worker(rank, world, port, q):
     import sys
     sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
     import dwg_import  # noqa: F401
-    from dreamwaltz_g_amd.sds_step import FlatAdam
+    from dreamwaltz_g_amd import optim
     os.environ["MASTER_ADDR"] = "127.0.0.1"; os.environ["MASTER_PORT"] = str(port)
     dist.init_process_group("gloo", rank=rank, world_size=world)
     torch.manual_seed(0)                                   # identical parameters on every rank
     a = torch.nn.Parameter(torch.randn(7, 3)); b = torch.nn.Parameter(torch.randn(5)); c = torch.nn.Parameter(torch.randn(2, 2, 2))
-    opt = FlatAdam([dict(params=[a, b], lr=1e-3), dict(params=[c], lr=1e-2, betas=(0.9, 0.99))], torch.device("cpu"))
-    # parameters and gradients are views into the flat buffers, slices 16-byte aligned
+    opts = optim.build_flat_optimizers({"avatar": optim.AdamSpec([dict(params=[a, b], lr=1e-3)], eps=1e-15),
+                                        "nerf": optim.AdamSpec([dict(params=[c], lr=1e-2)], betas=(0.9, 0.99), eps=1e-15)}, torch.device("cpu"))
+    opt = opts.buffers
+    # parameters and gradients are views into the flat buffers, slices 16-byte aligned; the named optimizers are views of it
     assert a.data.data_ptr() == opt.flat.data_ptr() and a.grad.data_ptr() == opt.grad.data_ptr()
-    assert all(g["start"] % 4 == 0 and g["end"] % 4 == 0 for g in opt.groups)
-    opt.zero_grad()
+    assert all(pg["start"] % 4 == 0 and pg["end"] % 4 == 0 for o in opts.values() for pg in o.param_groups)
+    assert opts.all_grads() is opt.grad
+    for o in opts.values():
+        o.zero_grad()
     x = torch.full((3,), float(rank + 1))                  # distinct "view" per rank
     loss = (a @ x).sum() * (rank + 1) + (b * b).sum() + c.sum() * (10 * rank + 1)
     loss.backward()                                        # accumulates INTO the flat gradient buffer

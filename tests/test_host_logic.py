@@ -6,7 +6,7 @@ import torch.nn.functional as F
 import dwg_import  # noqa: F401
 from dreamwaltz_g_amd import meshbind as mb
 from dreamwaltz_g_amd import sd15
-from dreamwaltz_g_amd.sds_step import FlatAdam, get_expon_lr_func
+from dreamwaltz_g_amd import optim
 from oracle import animate as oa
 
 
@@ -74,20 +74,28 @@ def test_vertex_face_csr_matches_index_add_normals():
     assert (oa.safe_normalize(acc) - vn_ref).abs().max() < 1e-12
 
 
-def test_flat_adam_learning_rate_schedule_bookkeeping():
-    """GaussianOptimizer.update_learning_rate semantics (gaussian_optimizer.py:130-141) on the flat-buffer optimizer."""
+def test_flat_optimizer_learning_rate_schedule_bookkeeping():
+    """GaussianOptimizer.update_learning_rate semantics (gaussian_optimizer.py:130-141) on a view of the flat-buffer optimizer."""
     a = torch.nn.Parameter(torch.zeros(10, 3)); b = torch.nn.Parameter(torch.zeros(10, 3)); c = torch.nn.Parameter(torch.zeros(7))
-    sched = get_expon_lr_func(lr_init=1.6e-4, lr_final=1.6e-6, lr_delay_mult=0.01, max_steps=20000)
-    opt = FlatAdam([dict(params=[a], lr=0.0, name="positions", schedule=sched), dict(params=[b], lr=0.0, name="scales", base_lr=2.5e-3),
-                    dict(params=[c], lr=1e-3, name="quaternions")], torch.device("cpu"))
+    spec = optim.AdamSpec([dict(params=[a], lr=1.6e-4, name="positions"), dict(params=[b], lr=2.5e-3, name="scales"),
+                           dict(params=[c], lr=1e-3, name="quaternions")], eps=1e-15,
+                          gaussian=dict(iterations=10000, position_lr_init=1.6e-4, position_lr_final=1.6e-6, position_lr_delay_mult=0.01,
+                                        position_lr_max_steps=20000, scaling_lr=2.5e-3))
+    opts = optim.build_flat_optimizers({"avatar": spec}, torch.device("cpu"))
+    opt = opts["avatar"]
     lr = opt.update_learning_rate(spatial_scale=1.04, iteration=0)
-    assert abs(opt.groups[0]["lr"] - 1.6e-4 * 1.04) < 1e-12 and abs(opt.groups[1]["lr"] - 2.5e-3 * 1.04) < 1e-12
-    assert opt.groups[2]["lr"] == 1e-3 and lr == 2.5e-3                  # the reference returns the last group rate it touched
+    g = opt.param_groups
+    assert abs(g[0]["lr"] - 1.6e-4 * 1.04) < 1e-12 and abs(g[1]["lr"] - 2.5e-3 * 1.04) < 1e-12    # lr_delay_steps = 0: no ease-in
+    assert g[2]["lr"] == 1e-3 and lr == 2.5e-3                  # the reference returns the last group rate it touched
     opt.update_learning_rate(spatial_scale=1.04, iteration=20000)
-    assert abs(opt.groups[0]["lr"] - 1.6e-6 * 1.04) < 1e-15
+    assert abs(g[0]["lr"] - 1.6e-6 * 1.04) < 1e-15
     # parameters and gradients are views of the flat buffers (16-byte aligned slices)
-    assert a.data.data_ptr() == opt.flat.data_ptr() and a.grad.data_ptr() == opt.grad.data_ptr()
-    assert (b.data.data_ptr() - opt.flat.data_ptr()) % 16 == 0 and (c.data.data_ptr() - opt.flat.data_ptr()) % 16 == 0
+    buf = opts.buffers
+    assert a.data.data_ptr() == buf.flat.data_ptr() and a.grad.data_ptr() == buf.grad.data_ptr()
+    assert (b.data.data_ptr() - buf.flat.data_ptr()) % 16 == 0 and (c.data.data_ptr() - buf.flat.data_ptr()) % 16 == 0
+    sd = opt.state_dict()
+    opt.load_state_dict(sd)
+    assert sd["exp_avg"].numel() == opt.end - opt.start
 
 
 def test_reference_checkpoint_keys_load_into_the_native_avatar():
@@ -123,3 +131,13 @@ def test_reference_checkpoint_keys_load_into_the_native_avatar():
     assert unknown == ["nearest_triangles_buffer"]
     assert "nerf_opacity_and_color_net.net.0.weight" in loaded and "nerf_scale_and_quaternion_net.gaussian_warp.weight" in loaded
     assert all(not k.startswith("_") for k in missing)      # only (integer) buffers of the native module may be absent
+    # derived state is rebuilt after a load: encoder host offsets, skeleton subset cache, canonical caches
+    assert a.nerf_encoder._host_offsets_py is None and a.lbs_model._subsets == [] and a._canonical_cache is None
+    # the key names of the REFERENCE classes (state_dict of a reference DreamWaltzG built by tests/golden/capture_golden_r2.py):
+    # every one has a counterpart here, except the integer index buffers we rebuild and `lbs_model.*` tensors we name differently
+    import numpy as np, os
+    G = np.load(os.path.join(os.path.dirname(__file__), "golden", "reference_golden_r2.npz"))
+    own = set(a.state_dict().keys())
+    rename = {"lbs_model.shapedirs": "lbs_model.shapedirs_all", "lbs_model.expr_dirs": "lbs_model.shapedirs_all"}
+    absent = [k for k in (str(x) for x in G["sd.animate.state_dict_keys"]) if rename.get(k, k) not in own]
+    assert all(k.startswith("lbs_model.") or k.endswith("points_to_triangles") for k in absent), absent

@@ -66,3 +66,23 @@ def test_lbs_apply_forward_and_backward_match_autograd():
     x = torch.stack([1 + M[:, 0, 0] + M[:, 1, 1] + M[:, 2, 2], 1 + M[:, 0, 0] - M[:, 1, 1] - M[:, 2, 2],
                      1 - M[:, 0, 0] + M[:, 1, 1] - M[:, 2, 2], 1 - M[:, 0, 0] - M[:, 1, 1] + M[:, 2, 2]], -1)
     assert set(x.argmax(-1).tolist()) == {0, 1, 2, 3}
+
+
+def test_joint_chain_rest_joint_backward_matches_autograd():
+    """d loss / d (rest joints) of A[:, :3, 3] through smplx batch_rigid_transform (the `learn_*_betas` path, avatar.py:1551-1553):
+    hand-derived chain (csrc/lbs_math.h) vs autograd through the oracle."""
+    L = _hostlib()
+    g = torch.Generator().manual_seed(4)
+    J = 55
+    pose = torch.randn(J, 3, generator=g, dtype=torch.float64) * 0.5
+    joints = (torch.randn(J, 3, generator=g, dtype=torch.float64) * 0.3).requires_grad_(True)
+    parents = np.array([-1] + [int(torch.randint(0, i, (1,), generator=g)) for i in range(1, J)], dtype=np.int64)
+    R = oa.batch_rodrigues(pose)
+    _, A = oa.batch_rigid_transform(R[None], joints[None], parents)
+    g_t = torch.randn(J, 3, generator=g, dtype=torch.float64)
+    (ref,) = torch.autograd.grad(A[0, :, :3, 3], joints, g_t)
+    dJ = np.zeros((J, 3), np.float32)
+    L.host_joint_chain_rest_joint_bwd(J, _p(pose.float().numpy().copy()), _p(parents.astype(np.int32).copy()),
+                                      _p(g_t.float().numpy().copy()), _p(dJ))
+    err = np.linalg.norm(dJ - ref.numpy()) / np.linalg.norm(ref.numpy())
+    assert err < 1e-5, err

@@ -50,7 +50,11 @@ def test_meshbind_point_forward_and_backward_match_autograd():
     gpos = torch.randn(pos.shape, generator=g, dtype=torch.float64)
     gscl = torch.randn(scl.shape, generator=g, dtype=torch.float64)
     gquat = torch.randn(quat.shape, generator=g, dtype=torch.float64)
-    gb_ref, gs_ref = torch.autograd.grad([pos, scl, quat], [bary, scales], [gpos, gscl, gquat])
+    verts.requires_grad_(True)
+    pos = oa.mesh_positions(bary, verts, tri)
+    scl, quat = oa.mesh_scales_and_quaternions(bary, scales, verts, tri, pos, n_per)
+    gb_ref, gs_ref, gv_ref = torch.autograd.grad([pos, scl, quat], [bary, scales, verts], [gpos, gscl, gquat])
+    verts = verts.detach()
     vn, _ = oa.compute_normal(verts, tri)
     M = Fp * n_per
     p2t = torch.arange(Fp)[:, None].expand(-1, n_per).reshape(-1)
@@ -64,7 +68,16 @@ def test_meshbind_point_forward_and_backward_match_autograd():
     assert np.abs(o_q - quat.detach().numpy()).max() < 2e-5
     assert (o_scl[:, 0] == 0).all()
     gb = np.zeros((M, 3), np.float32); gs = np.zeros((M, 3), np.float32)
+    gP = np.zeros((M, 3, 3), np.float32); gN = np.zeros((M, 3, 3), np.float32)
     L.host_meshbind_backward(M, ctypes.c_float(n_per), _p(b32), _p(s32), _p(P), _p(Nv), _p(gpos.float().numpy().copy()),
-                             _p(gscl.float().numpy().copy()), _p(gquat.float().numpy().copy()), _p(gb), _p(gs))
+                             _p(gscl.float().numpy().copy()), _p(gquat.float().numpy().copy()), _p(gb), _p(gs), _p(gP), _p(gN))
     assert _rel(gb, gb_ref.reshape(M, 3).numpy()) < 1e-4, _rel(gb, gb_ref.reshape(M, 3).numpy())
     assert _rel(gs, gs_ref.numpy()) < 1e-5, _rel(gs, gs_ref.numpy())
+    # gradient w.r.t. the posed vertices (learn_*_betas): per-point vertex / normal gradients scattered to the mesh, then the
+    # vertex-normal chain (compute_normal) back to the vertices -- against autograd through the whole oracle expression
+    idx = tri[p2t].numpy()                                   # [M,3]
+    g_vo = np.zeros((V, 3), np.float32); g_vn = np.zeros((V, 3), np.float32)
+    np.add.at(g_vo, idx.reshape(-1), gP.reshape(-1, 3)); np.add.at(g_vn, idx.reshape(-1), gN.reshape(-1, 3))
+    v32 = verts.float().numpy().copy(); t32 = tri.numpy().astype(np.int32).copy()
+    L.host_vertex_normals_backward(V, Fp, _p(v32), _p(t32), _p(g_vn), _p(g_vo))
+    assert _rel(g_vo, gv_ref.numpy()) < 2e-4, _rel(g_vo, gv_ref.numpy())

@@ -1,0 +1,179 @@
+"""-m gpu parity of the bf16/MFMA SD-1.5 stack AT SD-1.5 WIDTHS against the fp32 PyTorch-CPU oracle (oracle/sd15.py) with the
+same seeded random weights: single blocks at the production shapes (every attention head size d = 40 / 80 / 160, the LDS-patch
+convolutions, the Cin % 64 fast loader at 320 / 640 / 1280 channels, the production split-K choices), then the whole
+ControlNet + UNet CFG pass and the whole VAE encoder (forward + input gradient) at 64x64 latents / 512x512 pixels.
+
+Stated tolerances (bf16 storage with fp32 accumulation vs the fp32 oracle; the measured values of the last GPU run are in
+DESIGN.md section 2 and gpurun_out/parity_full_width.json; each bound below is about 2x its measured value):"""
+import json
+import os
+
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+_REPORT = {}
+
+
+def _rel(a, r):
+    a = a.detach().double().cpu(); r = r.detach().double().cpu()
+    return float((a - r).norm() / r.norm().clamp_min(1e-30))
+
+
+def _cos(a, r):
+    a = a.detach().double().cpu().reshape(-1); r = r.detach().double().cpu().reshape(-1)
+    return float((a @ r) / (a.norm() * r.norm()).clamp_min(1e-30))
+
+
+def _note(name, **kw):
+    _REPORT[name] = kw
+    os.makedirs(os.path.join(ROOT, "gpurun_out"), exist_ok=True)
+    with open(os.path.join(ROOT, "gpurun_out", "parity_full_width.json"), "w") as f:
+        json.dump(_REPORT, f, indent=1)
+    print("[parity]", name, kw)
+
+
+def _nhwc(x):
+    return x.permute(0, 2, 3, 1).contiguous()
+
+
+def _block_plan(sd):
+    from dreamwaltz_g_amd import sd15
+    dev = torch.device("cuda")
+    plan = sd15.Plan(dev)
+    w = sd15.Weights(sd, dev)
+    return plan, w, sd15.Builder(plan, w, 32, "t")
+
+
+@pytest.mark.parametrize("cin,cout,hw,bound", [(1280, 1280, 8, 2e-2), (320, 320, 64, 2e-2), (640, 320, 64, 2e-2), (2560, 1280, 16, 2e-2)])
+def test_resnet_block_at_sd15_width(cin, cout, hw, bound):
+    """One UNet ResnetBlock2D (GroupNorm+SiLU -> conv3x3 + time-embedding bias -> GroupNorm+SiLU -> conv3x3 + skip, 1x1 shortcut
+    when cin != cout) at batch 2."""
+    from dreamwaltz_g_amd import sd15
+    from oracle import sd15 as osd
+    sh = {}
+    sd15._resnet_shapes(sh, "r", cin, cout, 1280)
+    sd = sd15.random_state_dict(sh, seed=cin + hw)
+    g = torch.Generator().manual_seed(1)
+    x = torch.randn(2, cin, hw, hw, generator=g)
+    temb = torch.randn(2, 1280, generator=g)
+    ref = osd.resnet(x, sd, "r", temb, 32, 1e-5)
+    plan, w, b = _block_plan(sd)
+    xin = plan.buf(2, hw, hw, cin)
+    tb = (torch.nn.functional.linear(torch.nn.functional.silu(temb), sd["r.time_emb_proj.weight"], sd["r.time_emb_proj.bias"])
+          + sd["r.conv1.bias"]).cuda().contiguous()
+    y = b.resnet(xin, "r", (tb, cout))
+    xin.copy_(_nhwc(x))
+    plan.run_eager()
+    got = y.float().permute(0, 3, 1, 2)
+    e = _rel(got, ref)
+    _note("resnet_%dto%d_r%d" % (cin, cout, hw), rel_l2=e)
+    assert e < bound, e
+
+
+@pytest.mark.parametrize("c,hw,bound", [(320, 64, 2e-2), (640, 32, 2e-2), (1280, 16, 2e-2), (1280, 8, 2e-2)])
+def test_transformer_block_at_sd15_width(c, hw, bound):
+    """One Transformer2DModel block (GroupNorm, proj_in, self-attention, cross-attention over 77 text tokens, GEGLU feed-forward,
+    proj_out + skip) with 8 heads: head sizes 40 (padded tile path), 80, 160."""
+    from dreamwaltz_g_amd import sd15
+    from oracle import sd15 as osd
+    sh = {}
+    sd15._transformer_shapes(sh, "a", c, 768)
+    sd = sd15.random_state_dict(sh, seed=c + hw)
+    g = torch.Generator().manual_seed(2)
+    x = torch.randn(2, c, hw, hw, generator=g)
+    text = torch.randn(2, 77, 768, generator=g)
+    ref = osd.transformer(x, sd, "a", text, 8, 32)
+    plan, w, b = _block_plan(sd)
+    xin = plan.buf(2, hw, hw, c)
+    tin = plan.buf(2, 77, 768)
+    y = b.transformer(xin, "a", tin, 8)
+    xin.copy_(_nhwc(x)); tin.copy_(text)
+    plan.run_eager()
+    got = y.float().permute(0, 3, 1, 2)
+    e = _rel(got, ref)
+    _note("transformer_c%d_r%d" % (c, hw), rel_l2=e, head_dim=c // 8, tokens=hw * hw)
+    assert e < bound, e
+
+
+def test_vae_down_block_at_sd15_width():
+    """First VAE encoder level at 512x512: ResnetBlock2D 128 -> 128 (eps 1e-6, no time embedding) and the stride-2
+    Downsample2D with its (0,1,0,1) padding."""
+    from dreamwaltz_g_amd import sd15
+    from oracle import sd15 as osd
+    import torch.nn.functional as F
+    sh = {}
+    sd15._resnet_shapes(sh, "r", 128, 128, 0)
+    sh["d.weight"] = (128, 128, 3, 3); sh["d.bias"] = (128,)
+    sd = sd15.random_state_dict(sh, seed=9)
+    g = torch.Generator().manual_seed(3)
+    x = torch.randn(1, 128, 512, 512, generator=g)
+    r = osd.resnet(x, sd, "r", None, 32, 1e-6)
+    ref = F.conv2d(F.pad(r, (0, 1, 0, 1)), sd["d.weight"], sd["d.bias"], stride=2)
+    plan, w, b = _block_plan(sd)
+    xin = plan.buf(1, 512, 512, 128)
+    y = b.resnet(xin, "r", None, eps=1e-6)
+    z = b.conv(y, "d", stride=2, pad=0, out_hw=(256, 256))
+    xin.copy_(_nhwc(x))
+    plan.run_eager()
+    e1 = _rel(y.float().permute(0, 3, 1, 2), r)
+    e2 = _rel(z.float().permute(0, 3, 1, 2), ref)
+    _note("vae_down_block_r512", rel_l2_resnet=e1, rel_l2_downsample=e2)
+    assert e1 < 2e-2 and e2 < 2e-2, (e1, e2)
+
+
+@pytest.mark.slow
+def test_full_width_denoiser_and_sds_gradient():
+    """The whole ControlNet + UNet CFG pass at SD-1.5 width (859.5 M + 361.3 M parameters, 64x64 latents, batch 2) against the fp32
+    CPU oracle, and what SDS makes of it: gradients = eps_neg + 50 (eps_text - eps_neg) - noise.  Reports rel-L2 and cosine."""
+    from dreamwaltz_g_amd import sd15
+    from oracle import sd15 as osd
+    torch.set_num_threads(max(1, os.cpu_count() or 1))
+    ucfg = sd15.UNetConfig()
+    usd = sd15.random_state_dict(sd15.unet_param_shapes(ucfg), seed=0)
+    csd = sd15.random_state_dict(sd15.controlnet_param_shapes(ucfg), seed=1)
+    g = torch.Generator().manual_seed(5)
+    lat = torch.randn(1, 4, 64, 64, generator=g).repeat(2, 1, 1, 1)
+    text = torch.randn(2, 77, 768, generator=g)
+    cond = torch.rand(1, 3, 512, 512, generator=g)
+    noise = torch.randn(1, 4, 64, 64, generator=g)
+    t = torch.tensor([500])
+    with torch.no_grad():
+        ref = osd.predict_noise(ucfg, usd, csd, lat, t, text, cond.repeat(2, 1, 1, 1))
+    plan = sd15.DenoiserPlan(ucfg, usd, csd, torch.device("cuda"), batch=2, latent_hw=64)
+    plan.set_inputs(lat.cuda(), t.cuda(), text.cuda(), cond.cuda())
+    got = plan.run().float().cpu()
+    e = _rel(got, ref)
+    d_got, d_ref = got[1] - got[0], ref[1] - ref[0]
+    e_d = _rel(d_got, d_ref)
+    g_got = got[0] + 50.0 * d_got - noise[0]; g_ref = ref[0] + 50.0 * d_ref - noise[0]
+    e_g, c_g = _rel(g_got, g_ref), _cos(g_got, g_ref)
+    _note("denoiser_full_width", rel_l2_eps=e, rel_l2_cfg_difference=e_d, rel_l2_sds_gradients=e_g, cosine_sds_gradients=c_g,
+          cfg_difference_over_eps=float(d_ref.norm() / ref[0].norm()))
+    assert e < 2e-2, e
+    assert e_g < 0.3 and c_g > 0.95, (e_g, c_g)
+
+
+@pytest.mark.slow
+def test_full_width_vae_encoder_forward_and_input_gradient():
+    """AutoencoderKL encoder + quant_conv at 512x512 (34.2 M parameters): moments and d(sum(moments * w)) / d image."""
+    from dreamwaltz_g_amd import sd15
+    from oracle import sd15 as osd
+    torch.set_num_threads(max(1, os.cpu_count() or 1))
+    vcfg = sd15.VAEConfig()
+    sd = sd15.random_state_dict(sd15.vae_encoder_param_shapes(vcfg), seed=2)
+    g = torch.Generator().manual_seed(6)
+    img = torch.rand(1, 3, 512, 512, generator=g)
+    imgr = img.clone().requires_grad_(True)
+    ref = osd.vae_encode_moments(vcfg, sd, imgr)
+    gm = torch.randn(ref.shape, generator=g)
+    (gref,) = torch.autograd.grad(ref, imgr, gm)
+    plan = sd15.VAEEncoderPlan(vcfg, sd, torch.device("cuda"), image_hw=512)
+    got = plan.encode(img.cuda()).float().cpu()
+    gimg = plan.backward(gm.cuda()).float().cpu()
+    e_f, e_b, c_b = _rel(got, ref), _rel(gimg, gref), _cos(gimg, gref)
+    _note("vae_encoder_full_width", rel_l2_moments=e_f, rel_l2_image_grad=e_b, cosine_image_grad=c_b)
+    assert e_f < 3e-2, e_f
+    assert e_b < 1e-1 and c_b > 0.99, (e_b, c_b)
