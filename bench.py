@@ -1,11 +1,15 @@
 """bench.py -- headline benchmark of the SDS render-and-distill hot path on MI355X.
 
     python bench.py --gpus N --steps K --warmup W         (N > 1: launched by torch.distributed.run, one rank per GPU)
+    python bench.py --config c2|c5                         (the other single-GPU BASELINE.json configurations; not the headline)
 
 Prints ONE JSON line (rank 0) following the driver contract: metric / value / unit / n_gpus / steps / warmup /
 ms_per_step / higher_is_better / scaling / vs_baseline / dtype / data / config + roofline + cpu_baseline.
 A "step" is one pass of the hot path over one batch of synthetic input; see
 dreamwaltz-g_amd/sds_step.py for exactly which stages run.  Inputs are resident in HBM before the timed region.
+  c3 (default)  full SDS step, 100k Gaussians, 512^2, SD-1.5 + ControlNet      -> SDS steps/s            (the headline)
+  c2            50k Gaussians + LBS/encoder/MLPs, 512^2 raster fwd+bwd, no guidance -> steps/s + raster ms / Mpix/s / GB/s
+  c5            300k Gaussians, 1024^2, per-frame animate + raster forward (inference) -> frames/s
 """
 import argparse
 import json
@@ -23,6 +27,7 @@ from dreamwaltz_g_amd import sds_step  # noqa: E402
 
 HBM_PEAK_GBS = 8000.0      # MI355X_MICROARCH.md: 8 TB/s spec
 BF16_PEAK_TFLOPS = 2500.0  # dense bf16 MFMA peak
+TRAFFIC_JSON = os.path.join(ROOT, "profiles", "r02_pmc_traffic.json")
 
 
 def parse():
@@ -30,58 +35,154 @@ def parse():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
-    ap.add_argument("--gaussians", type=int, default=100000)
-    ap.add_argument("--res", type=int, default=512)
+    ap.add_argument("--config", choices=["c2", "c3", "c5"], default="c3")
+    ap.add_argument("--gaussians", type=int, default=None)
+    ap.add_argument("--res", type=int, default=None)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-guidance", action="store_true", help="raster+LBS sub-path only (not the headline workload)")
     ap.add_argument("--eager", action="store_true", help="launch every kernel eagerly (no hipGraph replay of the denoiser/VAE plans)")
+    ap.add_argument("--sync-pairs", action="store_true", help="exact pair-buffer sizing through a 16-byte read-back per frame")
     return ap.parse_args()
 
 
-def cpu_baseline(args, workload):
-    """Oracle (CPU restatement, ONE core) timed on a bounded sample of the same workload: `animate` (LBS x2 + grid encoder +
-    both MLPs, forward + backward through autograd) and the tile rasterizer forward + backward.  The reference has no CPU
-    diffusion path, so the diffusion half of the step has no CPU counterpart and is NOT in this number."""
+def cpu_baseline(args, G, res):
+    """The oracle (CPU restatement of the reference's PyTorch LBS / encoder / MLP path + the tile rasterizer) timed on ALL host cores
+    (torch.set_num_threads(os.cpu_count())) on the SAME kind of workload the GPU step renders: 90 % free
+    Gaussians with 4 non-zero skinning weights per row + 10 % mesh-bound Gaussians, `animate` forward + backward through autograd and
+    the rasterizer forward + backward.  The reference has no CPU diffusion path, so the diffusion half of the step
+    has no CPU counterpart and is NOT in this number.  (The C rasterizer oracle is single-threaded; the torch part uses every core.)"""
     import numpy as np
     from oracle import animate as oa
     from tests import raster_cases as rc
-    torch.set_num_threads(1)
-    G = min(args.gaussians, 100000)      # the full headline size (about 8 s on the GPU box host, 20 s on a slow core)
+    cores = os.cpu_count() or 1
+    torch.set_num_threads(cores)
+    M = (G // 10) // 6 * 6
+    N = G - M
     body = oa.SyntheticBody(seed=0)
     nets = oa.init_avatar_networks(seed=0)
     g = torch.Generator().manual_seed(1)
-    params = dict(_positions=((torch.rand(G, 3, generator=g) * 2 - 1) * torch.tensor([0.4, 0.9, 0.2])).requires_grad_(True),
-                  _scales=torch.log(torch.rand(G, 3, generator=g) * 0.018 + 0.002).requires_grad_(True),
-                  _quaternions=torch.randn(G, 4, generator=g).requires_grad_(True),
-                  _lbs_weights=torch.softmax(torch.randn(G, 55, generator=g), -1))
+    logits = torch.full((N, 55), -1e9)
+    logits.scatter_(1, torch.randint(0, 55, (N, 4), generator=g), torch.randn(N, 4, generator=g))
+    params = dict(_positions=((torch.rand(N, 3, generator=g) * 2 - 1) * torch.tensor([0.4, 0.9, 0.2])).requires_grad_(True),
+                  _scales=torch.log(torch.rand(N, 3, generator=g) * 0.018 + 0.002).requires_grad_(True),
+                  _quaternions=torch.randn(N, 4, generator=g).requires_grad_(True), _lbs_weights=torch.softmax(logits, -1))
     nets["table"].requires_grad_(True)
+    Vp, Fp = 1200, M // 6
+    vi = torch.randperm(body.V, generator=g)[:Vp]
+    tri = torch.stack([torch.randint(0, Vp, (Fp,), generator=g) for _ in range(3)], 1)
+    tri[:, 1] = (tri[:, 0] + 1 + tri[:, 1] % (Vp // 2 - 1)) % Vp; tri[:, 2] = (tri[:, 0] + Vp // 2 + tri[:, 2] % (Vp // 2)) % Vp    # distinct corners
+    base = torch.tensor([[2 / 3, 1 / 6, 1 / 6], [1 / 6, 2 / 3, 1 / 6], [1 / 6, 1 / 6, 2 / 3], [1 / 6, 5 / 12, 5 / 12],
+                         [5 / 12, 1 / 6, 5 / 12], [5 / 12, 5 / 12, 1 / 6]])
+    mesh = dict(vertex_indices=vi, triangles=tri, vertex_coords=body.v_template[vi], bary=base.expand(Fp, -1, -1).clone().requires_grad_(True),
+                scales=torch.ones(Fp * 6, 3).requires_grad_(True)) if M > 0 else None
     cnl = dict(body_pose=torch.zeros(1, 63), global_orient=torch.zeros(1, 3), left_hand_pose=torch.zeros(1, 45),
                right_hand_pose=torch.zeros(1, 45), expression=torch.zeros(1, 100))
     obs = oa.random_smpl_inputs(seed=3)
-    sc = rc.make_scene(G, args.res, args.res, seed=0)
-    wc = np.random.RandomState(0).randn(3, args.res, args.res).astype(np.float32)
+    sc = rc.make_scene(G, res, res, seed=0)
+    wc = np.random.RandomState(0).randn(3, res, res).astype(np.float32)
     # repeated passes (median) until about 10 s of CPU work have been spent, at most 5
     ta, tr, spent = [], [], 0.0
     while len(ta) < 5 and (spent < 10.0 or len(ta) < 2):
-        for v in list(params.values()) + [nets["table"]]:
+        for v in list(params.values()) + [nets["table"]] + ([mesh["bary"], mesh["scales"]] if mesh else []):
             v.grad = None
         t0 = time.perf_counter()
-        out = oa.animate(params, nets, body, obs, cnl)
+        out = oa.animate(params, nets, body, obs, cnl, mesh=mesh)
         sum(v.sum() for v in out.values()).backward()
         t1 = time.perf_counter()
         rc.oracle_forward(sc)
         rc.oracle_backward(sc, wc, None, None, dtype=np.float32)
         t2 = time.perf_counter()
         ta.append(t1 - t0); tr.append(t2 - t1); spent += t2 - t0
-    t0, t1 = 0.0, float(np.median(ta))
-    t2 = t1 + float(np.median(tr))
-    dt = t2 - t0
-    scale = args.gaussians / G          # per-Gaussian extrapolation to the full workload size (flagged in `sample`)
-    return {"value": 1.0 / (dt * scale), "unit": "steps/s (animate + rasterizer, fwd+bwd, no diffusion)", "cores": 1,
+    t_an, t_ra = float(np.median(ta)), float(np.median(tr))
+    return {"value": 1.0 / (t_an + t_ra), "unit": "steps/s (animate + rasterizer, fwd+bwd, no diffusion)", "cores": cores,
             "kind": "port",
-            "sample": "median of %d passes on 1 core (%.0f s of CPU work): oracle animate fwd+bwd (%.1f s) + tile raster fwd+bwd "
-                      "(%.1f s) of %d Gaussians @%dx%d, scaled x%.1f per-Gaussian to %d"
-                      % (len(ta), spent, t1 - t0, t2 - t1, G, args.res, args.res, scale, args.gaussians)}
+            "sample": "median of %d passes (%.0f s of CPU work, %d torch threads; the C rasterizer oracle is one thread): oracle animate "
+                      "fwd+bwd %.2f s (%d free Gaussians with 4 non-zero skinning weights + %d mesh-bound) + tile raster fwd+bwd %.2f s "
+                      "(%d Gaussians @%dx%d)" % (len(ta), spent, cores, t_an, N, M, t_ra, G, res, res)}
+
+
+def raster_report(prof, G, Kref, K, P, steps):
+    """Rasterizer against the HBM roofline with SURVEY 8d's byte formula (K = reference tile-pair count; sort traffic not counted)."""
+    rf = sum(v[1] for k, v in prof.items() if k.startswith("raster_") and not k.endswith("_bwd")) / steps
+    rb = sum(v[1] for k, v in prof.items() if k.startswith("raster_") and k.endswith("_bwd")) / steps
+    out = {}
+    if rf > 0:
+        b = 56 * G + 44 * Kref + 20 * P
+        out["raster_forward"] = {"bytes": b, "pairs_reference": Kref, "pairs_after_exact_culling": K, "ms": rf, "mpix_per_s": P / (rf * 1e-3) / 1e6,
+                                 "achieved_GBps": b / (rf * 1e-3) / 1e9, "frac_of_hbm_peak": b / (rf * 1e-3) / 1e9 / HBM_PEAK_GBS}
+    if rb > 0:
+        b = 80 * Kref + 20 * P + 152 * G
+        out["raster_backward"] = {"bytes": b, "ms": rb, "achieved_GBps": b / (rb * 1e-3) / 1e9,
+                                  "frac_of_hbm_peak": b / (rb * 1e-3) / 1e9 / HBM_PEAK_GBS}
+    return out
+
+
+def roofline(prof, prof_sym, prof_steps, G, Kref, K, P):
+    """Roofline entry for the dominant kernel = the kernel SYMBOL (as rocprofv3 --kernel-trace names it) with the largest total time
+    in the profiled region; achieved = algorithmic work per launch / average launch duration (HIP events on the launch stream)."""
+    out = {}
+    if prof_sym:
+        name, (count, total_ms, work) = max(prof_sym.items(), key=lambda kv: kv[1][1])
+        avg_ms = total_ms / max(1, count)
+        if work > 0:
+            ach = work / count / (avg_ms * 1e-3) / 1e12
+            out = {"kernel": name, "bound": "mfma", "achieved": ach, "peak": BF16_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": ach / BF16_PEAK_TFLOPS,
+                   "traffic": None, "avg_launch_ms": avg_ms, "launches": count, "flops_per_launch": work / count}
+        else:
+            out = {"kernel": name, "bound": "hbm", "achieved": None, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": None, "traffic": None,
+                   "avg_launch_ms": avg_ms, "launches": count}
+        out["mfma_kernels"] = {k: {"launches": c, "avg_launch_ms": ms / c, "tflops": w / (ms * 1e-3) / 1e12,
+                                   "frac": w / (ms * 1e-3) / 1e12 / BF16_PEAK_TFLOPS}
+                               for k, (c, ms, w) in sorted(prof_sym.items(), key=lambda kv: -kv[1][1]) if w > 0 and ms > 0}
+        tw = sum(w for (_, _, w) in prof_sym.values()); tms = sum(ms for (_, ms, w) in prof_sym.values() if w > 0)
+        if tms > 0:
+            out["mfma_all"] = {"tflops": tw / (tms * 1e-3) / 1e12, "frac": tw / (tms * 1e-3) / 1e12 / BF16_PEAK_TFLOPS,
+                               "flops_per_step": tw / prof_steps}
+        if os.path.exists(TRAFFIC_JSON) and out.get("kernel"):
+            tk = json.load(open(TRAFFIC_JSON))["kernels"].get(out["kernel"].replace(" ", ""))
+            if tk:
+                out["traffic"] = tk["hbm_bytes_per_launch"]
+                out["traffic_source"] = "profiles/r02_pmc_traffic.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes, gfx950 corrections)"
+    out.update(raster_report(prof, G, Kref, K, P, prof_steps))
+    return out
+
+
+def run_c5(args, dev):
+    """Config c5: 300k-Gaussian avatar, per-frame animate (LBS + encoder + MLPs + mesh binding) + raster forward at 1024^2, inference."""
+    G, res = args.gaussians or 300000, args.res or 1024
+    from dreamwaltz_g_amd import camera, configs, scene as sc, synth
+    cfg = configs.TrainConfig(); cfg.device = str(dev); cfg.render.bg_color = (0.5, 0.5, 0.5)
+    avatar, N, M = sds_step.build_synthetic_avatar(G, dev, seed=0)
+    scene = sc.Scene(cfg, avatar, async_pair_count=not args.sync_pairs).to(dev).eval()
+    data = camera.make_camera(radius=2.0, azimuth=0.0, elevation=80.0, fovy=55.0, height=res, width=res, device=dev)
+    poses = [synth.random_smpl_inputs(seed=i, device=dev) for i in range(240)]        # 240 pose frames (SURVEY 8d c5)
+
+    def frame(i):
+        with torch.inference_mode():
+            return scene.forward(data, smpl_observed_inputs=poses[i % 240], use_densifier=False, bg_mode=None)
+    for i in range(args.warmup):
+        frame(i)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for i in range(args.steps):
+        frame(i)
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    _lib.prof_enable(True)
+    ps = min(args.steps, 5)
+    for i in range(ps):
+        frame(i)
+    torch.cuda.synchronize()
+    prof = _lib.prof_table(); _lib.prof_enable(False)
+    K, Kref = scene.renderer.last_rasterizer.last_num_pairs
+    out = {"metric": "AIST++-style animation inference (config c5): frames/s, %dk-Gaussian avatar, per-frame LBS+raster at %d^2" % (G // 1000, res),
+           "value": args.steps / dt, "unit": "frames/s", "n_gpus": 1, "steps": args.steps, "warmup": args.warmup, "ms_per_step": dt / args.steps * 1e3,
+           "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+           "config": {"workload": "c5: animate (LBS x2, grid encoder, MLPs, %d free + %d mesh-bound Gaussians) + raster forward %dx%d, "
+                                  "inference_mode, 240 seeded random pose frames" % (N, M, res, res), "gaussians": G, "resolution": res},
+           "roofline": raster_report(prof, G, Kref, K, res * res, ps),
+           "kernel_ms_per_step": {k: round(v[1] / ps, 4) for k, v in sorted(prof.items(), key=lambda kv: -kv[1][1])[:20]}}
+    print(json.dumps(out))
 
 
 def main():
@@ -97,8 +198,13 @@ def main():
         dist.init_process_group("nccl", device_id=torch.device("cuda", local))
     dev = torch.device("cuda", local)
     torch.cuda.set_stream(torch.cuda.Stream(device=dev))   # one real (non-default) HIP stream for the whole step: graph-safe
-    step = sds_step.SDSStep(n_gaussians=args.gaussians, res=args.res, device=dev, rank=rank, world=world,
-                            guidance=not args.no_guidance, dist=dist)
+    if args.config == "c5":
+        return run_c5(args, dev)
+    guidance = not args.no_guidance and args.config == "c3"
+    G = args.gaussians or (50000 if args.config == "c2" else 100000)
+    res = args.res or 512
+    step = sds_step.SDSStep(n_gaussians=G, res=res, device=dev, rank=rank, world=world, guidance=guidance, dist=dist,
+                            async_pair_count=not args.sync_pairs)
     if not args.eager:
         step.capture_graphs()       # denoiser / VAE plans replay as hipGraphs (identical kernels, one launch each)
     for _ in range(args.warmup):
@@ -138,27 +244,24 @@ def main():
     info = step.describe()
     ms = dt / args.steps * 1e3
     views_per_step = world  # one view per rank per step (weak scaling)
+    K, Kref = step.num_pairs
+    headline = args.config == "c3" and guidance
     out = {
-        "metric": "SDS steps/sec @512^2, 100k Gaussians, SD1.5+ControlNet; raster Mpix/s vs HBM roofline",
-        "value": views_per_step * args.steps / dt, "unit": "SDS steps/s (one view each; whole job)",
+        "metric": "SDS steps/sec @512^2, 100k Gaussians, SD1.5+ControlNet; raster Mpix/s vs HBM roofline" if headline else
+                  "config %s sub-path (NOT the headline): animate + raster fwd+bwd + Adam steps/s, %dk Gaussians @%d^2, no guidance" % (args.config, G // 1000, res),
+        "value": views_per_step * args.steps / dt, "unit": "SDS steps/s (one view each; whole job)" if headline else "steps/s",
         "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": ms, "higher_is_better": True,
         "scaling": "weak", "vs_baseline": None, "dtype": info["dtype"], "data": "synthetic",
         "config": info["config"],
     }
-    out["roofline"] = step.roofline(prof, HBM_PEAK_GBS, BF16_PEAK_TFLOPS, prof_sym)
-    # HBM traffic of the dominant kernel per launch: PMC counters need their own rocprofv3 passes (FETCH_SIZE and WRITE_SIZE
-    # separately), so the table is produced by tools/pmc_traffic.py from those passes and committed under profiles/.
-    tpath = os.path.join(ROOT, "profiles", "r01_pmc_traffic.json")
-    if out["roofline"] and os.path.exists(tpath):
-        tk = json.load(open(tpath))["kernels"].get(out["roofline"]["kernel"].replace(" ", ""))
-        if tk:
-            out["roofline"]["traffic"] = tk["hbm_bytes_per_launch"]
-            out["roofline"]["traffic_source"] = "profiles/r01_pmc_traffic.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes, gfx950 corrections)"
-    out["raster_mpix_per_s"] = args.res * args.res * views_per_step * args.steps / dt / 1e6
+    out["roofline"] = roofline(prof, prof_sym, prof_steps, step.G, Kref, K, res * res)
+    rf = out["roofline"].get("raster_forward")
+    out["raster_mpix_per_s"] = rf["mpix_per_s"] if rf else None      # the rasterizer's own forward rate (pixels / forward-chain time)
+    out["redone_frames"] = step.trainer.redone_frames
     out["kernel_ms_per_step"] = {k: round(v[1] / prof_steps, 4) for k, v in sorted(prof.items(), key=lambda kv: -kv[1][1])[:40]}
     out["launch_mode"] = "eager" if args.eager else "hipGraph replay of denoiser/VAE plans; kernel timers from an eager replay after the timed region"
     if not args.no_cpu_baseline and world == 1:
-        out["cpu_baseline"] = cpu_baseline(args, info)
+        out["cpu_baseline"] = cpu_baseline(args, G, res)
     print(json.dumps(out))
 
 

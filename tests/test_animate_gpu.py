@@ -276,3 +276,63 @@ def test_meshbind_kernels_match_oracle():
     # observed pass only (no canonical vertices): canonical output is empty and carries no gradient
     c2, p2, s2, q2 = mb.meshbind(bg, sg, None, verts_o.cuda(), vn, tri32, n_per)
     assert c2.numel() == 0 and torch.equal(p2, pos) and torch.equal(q2, q)
+
+
+def test_gridencoder_dropin_backend_fp32_and_half_buffers():
+    """dropin/_gridencoder.py as the reference's grid.py drives it (backend contract of src/bindings.cpp:5-9, [L,B,C] layout):
+    fp32 buffers, and the HALF buffers grid.py allocates under autocast (embeddings / outputs / dy_dx / grad / grad_embeddings /
+    grad_inputs in fp16, inputs fp32: grid.py:44-58,79-86) -- every buffer is written in its own dtype, nothing is reinterpreted."""
+    import os, sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    sys.path.insert(0, os.path.join(root, "dropin"))
+    import _gridencoder as backend
+    B, D, C, L = 3000, 3, 2, 16
+    x, table, offsets, pls, _ = _grid_case(B, 11)
+    S, H = float(np.log2(pls)), 16
+    off = torch.from_numpy(offsets).cuda()
+    ref = oa.grid_encode(x.double(), table.double(), offsets, pls)
+    go = torch.randn(L, B, C, generator=torch.Generator().manual_seed(2))
+    xd = x.double().requires_grad_(True); td = table.double().requires_grad_(True)
+    refd = oa.grid_encode(xd, td, offsets, pls)
+    gx_ref, gt_ref = torch.autograd.grad(refd, [xd, td], go.permute(1, 0, 2).reshape(B, L * C).double())
+    for dt, tol_o, tol_g in ((torch.float32, 7e-5, 1e-4), (torch.float16, 2e-3, 2e-2)):
+        emb = table.cuda().to(dt)
+        out = torch.full((L, B, C), float("nan"), device="cuda", dtype=dt)
+        dy = torch.empty(B, L * D * C, device="cuda", dtype=dt)
+        guard = torch.full((1024,), 7.0, device="cuda", dtype=dt)       # a neighbour in the allocator: must stay untouched
+        backend.grid_encode_forward(x.cuda(), emb, off, out, B, D, C, L, S, H, dy, 1, False, 1)
+        got = out.float().permute(1, 0, 2).reshape(B, L * C).cpu().double()
+        assert (got - ref).abs().max() < tol_o, (dt, float((got - ref).abs().max()))
+        ge = torch.zeros_like(emb)
+        gi = torch.zeros(B, D, device="cuda", dtype=dt)
+        backend.grid_encode_backward(go.cuda().to(dt), x.cuda(), emb, off, ge, B, D, C, L, S, H, dy, gi, 1, False, 1)
+        assert ge.dtype == dt and gi.dtype == dt and torch.isfinite(ge.float()).all() and torch.isfinite(gi.float()).all()
+        assert _rel_l2(ge.float(), gt_ref) < tol_g, (dt, _rel_l2(ge.float(), gt_ref))
+        assert _rel_l2(gi.float(), gx_ref) < max(tol_g, 5e-3), (dt, _rel_l2(gi.float(), gx_ref))
+        assert bool((guard == 7.0).all())
+    with pytest.raises(RuntimeError):
+        backend.grid_encode_forward(x, table.cuda(), off, torch.empty(L, B, C, device="cuda"), B, D, C, L, S, H, None, 1, False, 1)   # CPU inputs
+    with pytest.raises(RuntimeError):
+        backend.grid_encode_forward(x.cuda(), table.cuda(), off, torch.empty(L, B + 1, C, device="cuda"), B, D, C, L, S, H, None, 1, False, 1)
+
+
+def test_rasterizer_dropin_package_imports_and_renders():
+    """dropin/diff_gaussian_rasterization: the names gaussian_renderer.py:5 imports, bound to the HIP rasterizer."""
+    import os, sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    sys.path.insert(0, os.path.join(root, "dropin"))
+    import diff_gaussian_rasterization as dgr
+    from tests import raster_cases as rc
+    sc = rc.make_scene(500, 64, 64, seed=4)
+    t = {k: (v.cuda() if torch.is_tensor(v) else v) for k, v in sc.items()}
+    rs = dgr.GaussianRasterizationSettings(image_height=64, image_width=64, tanfovx=sc["tanfovx"], tanfovy=sc["tanfovy"], bg=t["bg"],
+                                           scale_modifier=1.0, viewmatrix=t["viewmatrix"], projmatrix=t["projmatrix"], sh_degree=3,
+                                           campos=t["campos"], prefiltered=False, debug=False)
+    img, radii, depth, alpha = dgr.GaussianRasterizer(raster_settings=rs)(
+        means3D=t["means3D"], means2D=torch.zeros_like(t["means3D"]), shs=None, colors_precomp=t["colors"], opacities=t["opacities"],
+        scales=t["scales"], rotations=t["rotations"], cov3D_precomp=None)
+    ref = rc.oracle_forward(sc)
+    assert img.shape == (3, 64, 64) and radii.dtype == torch.int32 and depth.shape == (1, 64, 64) and alpha.shape == (1, 64, 64)
+    assert float((img.cpu() - torch.from_numpy(ref["color"])).abs().max()) < 1e-4
+    with pytest.raises(Exception):
+        dgr.GaussianRasterizer(raster_settings=rs)(means3D=t["means3D"], means2D=None, opacities=t["opacities"])   # neither SHs nor colours

@@ -1,0 +1,160 @@
+"""-m gpu: the PRODUCT (HIP kernels behind the reference-shaped API) against golden outputs of the reference's own code
+(tests/golden/capture_golden_r2.py): DreamWaltzG.animate incl. the learned-betas variant and every parameter gradient,
+Scene.forward, inverse_lbs_transform, the RigidTransform kernel paths, and the guidance call on reduced-width networks."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import animate as oa
+
+pytestmark = pytest.mark.gpu
+G = np.load(os.path.join(os.path.dirname(__file__), "golden", "reference_golden_r2.npz"))
+G1 = np.load(os.path.join(os.path.dirname(__file__), "golden", "reference_golden.npz"))
+
+
+def T(key):
+    return torch.from_numpy(np.asarray(G[key]))
+
+
+def _rel(a, r):
+    a = a.detach().double().cpu().reshape(-1); r = r.detach().double().cpu().reshape(-1)
+    return float((a - r).norm() / r.norm().clamp_min(1e-30))
+
+
+def _golden_avatar(learn_hand_betas=False):
+    from dreamwaltz_g_amd import avatar as av
+    V, F_, seed = (int(x) for x in G["sd.animate.body"])
+    body = oa.SyntheticBody(V=V, F_=F_, seed=seed)
+    nets = oa.init_avatar_networks(seed=int(G["sd.animate.nets_seed"][0]), table_std=float(G["sd.animate.table_std"][0]))
+    bd = {k: getattr(body, k) for k in ("v_template", "shapedirs", "expr_dirs", "posedirs", "J_regressor", "lbs_weights", "betas",
+                                        "expression", "pose_mean", "jaw_pose", "leye_pose", "reye_pose")}
+    bd["parents"] = torch.from_numpy(body.parents)
+    glbs = av.GeneralLinearBlendSkinning(bd)
+    m = av.MeshBindingGaussianModel(T("sd.animate.mesh.vertex_coords"), T("sd.animate.mesh.triangles"), T("sd.animate.mesh.vertex_indices"))
+    m._bary_coords.data.copy_(T("sd.animate.mesh.bary")); m._scales.data.copy_(T("sd.animate.mesh.scales"))
+    cnl = {k[len("sd.animate.cnl."):]: T(k).cuda() for k in G.files if k.startswith("sd.animate.cnl.")}
+    a = av.DreamWaltzG(glbs, T("sd.animate.param._positions"), torch.exp(T("sd.animate.param._scales")), T("sd.animate.param._quaternions"),
+                       T("sd.animate.param._lbs_weights"), cnl, {"hands": m}, learn_hand_betas=learn_hand_betas)
+    a._betas.data.copy_(T("sd.animate.param._betas"))
+    a.nerf_encoder.embeddings.data.copy_(nets["table"])
+    for l in range(3):
+        a.nerf_opacity_and_color_net.net[l].weight.data.copy_(nets["static_w"][l])
+        a.nerf_opacity_and_color_net.net[l].bias.data.copy_(nets["static_b"][l])
+    a.nerf_scale_and_quaternion_net.load_state_dict({k[len("sd.animate.deform."):]: T(k) for k in G.files if k.startswith("sd.animate.deform.")})
+    obs = {k[len("sd.animate.obs."):]: T(k).cuda() for k in G.files if k.startswith("sd.animate.obs.")}
+    return a.cuda(), obs
+
+
+@pytest.mark.parametrize("tag,lhb", [("animate", False), ("animate_betas", True)])
+def test_animate_matches_the_reference_animate(tag, lhb):
+    """Outputs and every parameter gradient of the reference's DreamWaltzG.animate (avatar.py:1500-1588), default flags and the
+    learned-hand-betas variant of sub-stage 2.1 (incl. d loss / d _betas through vertices, vertex normals and the joint chain)."""
+    a, obs = _golden_avatar(lhb)
+    out = a.animate(obs)
+    pre = "sd.%s." % tag
+    tol = dict(positions=5e-5, opacities=2e-5, colors=2e-5, quaternions=2e-4, scales=2e-5)
+    for f, t in tol.items():
+        err = float((out[f].detach().cpu() - T(pre + "out." + f)).abs().max())
+        assert err < t, (f, err)
+    loss = sum((out[f] * T(pre + "lossw." + f).cuda()).sum() for f in tol)
+    loss.backward()
+    gm = a.mesh_binding_gaussians["hands"]
+    pairs = [("_positions", a._positions.grad), ("_scales", a._scales.grad), ("_quaternions", a._quaternions.grad),
+             ("table", a.nerf_encoder.embeddings.grad), ("bary", gm._bary_coords.grad), ("mesh_scales", gm._scales.grad)]
+    if lhb:
+        pairs.append(("_betas", a._betas.grad))
+    for name, got in pairs:
+        assert got is not None, name
+        e = _rel(got, T(pre + "grad." + name))
+        assert e < 3e-3, (name, e)
+
+
+def test_reference_shaped_lbs_seam_on_the_kernels():
+    """lbs_model.forward(**smpl_inputs) -> (transform_J, transform_V, transforms) used the way the REFERENCE's DreamWaltzG.lbs_transform
+    and animate use it (avatar.py:1426-1462,1570-1577): compose / squeeze / transform_points(weights=|indices=) /
+    transform_quaternions(weights=, flip_rotation_axis=True), and .SE3 of the lazily built dense transforms."""
+    from dreamwaltz_g_amd.rigid import RigidTransform
+    a, obs = _golden_avatar(False)
+    tJ, tV, tr = a.lbs_model.forward(**obs)
+    body = oa.SyntheticBody(V=300, F_=500, seed=3)
+    otJ, otV, otr = oa.glbs_forward(body, **{k: v.cpu() for k, v in obs.items()})
+    for k in ("V_shape_offset", "V_pose_offset", "V_pose_rigid", "J_shape_offset", "J_pose_rigid", "G_transl_offset"):
+        assert (tr[k].SE3.cpu() - otr[k]).abs().max() < 2e-5, k
+    assert (tV.SE3.cpu() - otV).abs().max() < 2e-5 and (tJ.SE3.cpu() - otJ).abs().max() < 2e-5
+    w = a.get_lbs_weights()
+    jt = RigidTransform.compose(tr['J_pose_rigid'], tr['G_transl_offset']).squeeze(0)
+    p = a._positions.detach()
+    q = a._quaternions.detach()
+    ojt = oa.se3_compose(otr["J_pose_rigid"], otr["G_transl_offset"])[0]
+    assert (jt.transform_points(p, weights=w).cpu() - oa.transform_points(ojt, p.cpu(), weights=w.cpu())).abs().max() < 2e-5
+    assert (jt.transform_quaternions(q, weights=w, flip_rotation_axis=True).cpu() -
+            oa.transform_quaternions_flip(ojt, q.cpu(), w.cpu())).abs().max() < 1e-4
+    gm = a.mesh_binding_gaussians["hands"]
+    _, tV2, _ = a.lbs_model.forward(**obs)
+    got = tV2.squeeze(0).transform_points(gm._vertex_coords, indices=gm.predefined_vertex_indices)
+    ref = oa.transform_points(otV[0], gm._vertex_coords.cpu(), indices=gm.predefined_vertex_indices.cpu())
+    assert (got.cpu() - ref).abs().max() < 2e-5
+    # golden of the reference's own inverse_lbs_transform
+    _, _, ctr = a.lbs_model.forward(**a.smpl_canonical_inputs)
+    inv = a.inverse_lbs_transform(T("sd.invlbs.in").cuda(), ctr)
+    assert (inv.cpu() - T("sd.invlbs.out")).abs().max() < 2e-5
+
+
+def test_scene_forward_matches_the_reference_scene_forward():
+    """Scene.forward (scene.py:96-168) -> GaussianRenderer.render -> HIP rasterizer vs the reference's own Scene / GaussianRenderer code
+    run on the CPU raster oracle: output dict keys, layouts, radii, bg_mode compositing, avatar_scale / avatar_transl."""
+    from dreamwaltz_g_amd import configs, scene as sc
+    a, obs = _golden_avatar(False)
+    cfg = configs.TrainConfig(); cfg.device = "cuda"
+    s = sc.Scene(cfg, a).cuda()
+    data = dict(extrinsic=T("sd.scene.data.extrinsic").cuda(), projection=T("sd.scene.data.projection").cuda(), c2w=T("sd.scene.data.c2w").cuda(),
+                tanfov=T("sd.scene.data.tanfov"), image_height=64, image_width=64)
+    with torch.no_grad():
+        o = s.forward(data, smpl_observed_inputs=obs, use_densifier=True, bg_mode=None)
+    assert sorted(o.keys()) == [str(k) for k in G["sd.scene.none.keys"]]
+    for k in ("image", "depth", "alpha", "image_fg"):
+        assert o[k].shape == tuple(G["sd.scene.none." + k].shape)
+        err = (o[k].cpu() - T("sd.scene.none." + k)).abs()
+        assert float(torch.quantile(err.reshape(-1), 0.999)) < 2e-4, (k, float(err.max()))
+    assert float((o["radii"].cpu() != T("sd.scene.none.radii")).float().mean()) < 2e-3       # fp32 animate differences move a few radii by 1
+    with torch.no_grad():
+        o = s.forward(data, smpl_observed_inputs=obs, use_densifier=False, bg_mode='white')
+    assert sorted(o.keys()) == [str(k) for k in G["sd.scene.white.keys"]]
+    for k in ("image", "image_fg", "image_bg", "alpha"):
+        err = (o[k].cpu() - T("sd.scene.white." + k)).abs()
+        assert float(torch.quantile(err.reshape(-1), 0.999)) < 2e-4, (k, float(err.max()))
+    s.avatar_transl = torch.tensor([0.05, -0.02, 0.1], device="cuda"); s.avatar_scale = torch.tensor(1.2, device="cuda")
+    with torch.no_grad():
+        o = s.forward(data, smpl_observed_inputs=obs, use_densifier=False, bg_mode='gray')
+    for k in ("image", "image_bg", "depth"):
+        err = (o[k].cpu() - T("sd.scene.transl_scale_gray." + k)).abs()
+        assert float(torch.quantile(err.reshape(-1), 0.999)) < 3e-4, (k, float(err.max()))
+
+
+def test_guidance_call_matches_the_reference_call_on_reduced_width_networks():
+    """ControlNetScoreDistillation.__call__ (bf16 HIP plans) vs the reference's BasicScoreDistillation.__call__ / calc_gradients run on
+    the fp32 oracle networks (golden sd.sds.*): result keys, latents, sources / targets, loss == 1, gradients, d loss / d image."""
+    from dreamwaltz_g_amd import guidance, sd15
+    c = [int(x) for x in G["sd.sds.cfg"]]
+    ucfg = sd15.UNetConfig(block_out_channels=(c[0], c[1]), layers_per_block=c[2], heads=c[3], cross_dim=c[4], groups=c[5],
+                           attn_blocks=(True, False), cond_channels=(c[6], c[7]))
+    vcfg = sd15.VAEConfig(block_out_channels=(c[8], c[9]), layers_per_block=c[10], groups=c[11])
+    usd = sd15.random_state_dict(sd15.unet_param_shapes(ucfg), seed=0)
+    csd = sd15.random_state_dict(sd15.controlnet_param_shapes(ucfg), seed=1)
+    vsd = sd15.random_state_dict(sd15.vae_encoder_param_shapes(vcfg), seed=2)
+    dev = torch.device("cuda")
+    hw = int(G["sd.sds.call.image"].shape[-1])
+    gd = guidance.ControlNetScoreDistillation(dev, ucfg, vcfg, usd, csd, vsd, image_hw=hw)
+    text = {k: T("sd.sds.text." + k).cuda() for k in ("null", "text", "neg")}
+    img = T("sd.sds.call.image").cuda().requires_grad_(True)
+    res = gd(img, text, train_step=10, max_iteration=100, cond_inputs=T("sd.sds.cond").cuda(), timestep=T("sd.sds.timestep").cuda(),
+             noise=T("sd.sds.call.noise").cuda(), posterior_noise=T("sd.sds.call.vae_noise").cuda())
+    assert sorted(res.keys()) == [str(k) for k in G["sd.sds.call.keys"]]
+    assert float(res["diffusion_loss"]) == float(G["sd.sds.call.diffusion_loss"][0]) == 1.0
+    assert _rel(res["latents"], T("sd.sds.call.latents")) < 3e-2
+    assert _rel(res["gradients"], T("sd.sds.call.gradients")) < 2e-1
+    assert torch.allclose(res["targets"], res["sources"] - res["gradients"])
+    (res["diffusion_loss"] * 1.0).backward()
+    assert _rel(img.grad, T("sd.sds.call.image_grad")) < 3e-1

@@ -30,10 +30,10 @@ def phase(name, fn):
     return out
 
 
-st.opt.zero_grad()
+[o.zero_grad() for o in st.opt.values()]
 pose = phase("pose", lambda: synth.random_smpl_inputs(seed=5, device=st.device))
 g = phase("animate", lambda: st.avatar.animate(pose))
-out = phase("render", lambda: st.renderer.render(st.cam, g))
-res = phase("guidance", lambda: st.guidance(out["image"].permute(0, 3, 1, 2), st.text, cond_inputs=st.cond))
+out = phase("render", lambda: st.renderer.render(st.data, g))
+res = phase("guidance", lambda: st.guidance(out["image"].permute(0, 3, 1, 2), dict(st.text, text=st.text["pos"]), cond_inputs=st.data["cond_images"]))
 phase("backward", lambda: (res["diffusion_loss"] * 1.0).backward())
-phase("adam", lambda: st.opt.step(grad_scale=1.0))
+phase("adam", lambda: [o.step() for o in st.opt.values()])

@@ -32,13 +32,13 @@ N = 10
 for it in range(N):
     marks.clear()
     mark("start")
-    st.opt.zero_grad()
+    [o.zero_grad() for o in st.opt.values()]
     pose = synth.random_smpl_inputs(seed=it, device=st.device)
     gs = st.avatar.animate(pose); mark("animate_fwd")
-    out = st.renderer.render(st.cam, gs)
-    res = st.guidance(out["image"].permute(0, 3, 1, 2), st.text, cond_inputs=st.cond); mark("sds_tail")
+    out = st.renderer.render(st.data, gs)
+    res = st.guidance(out["image"].permute(0, 3, 1, 2), dict(st.text, text=st.text["pos"]), cond_inputs=st.data["cond_images"]); mark("sds_tail")
     (res["diffusion_loss"] * 1.0).backward(); mark("backward(vae_bwd+raster_bwd+animate_bwd)")
-    st.opt.step(grad_scale=1.0); mark("adam")
+    [o.step() for o in st.opt.values()]; mark("adam")
     torch.cuda.synchronize()
     for (n0, e0), (n1, e1) in zip(marks[:-1], marks[1:]):
         acc[n1] = acc.get(n1, 0.0) + e0.elapsed_time(e1)
