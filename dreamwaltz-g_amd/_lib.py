@@ -51,6 +51,8 @@ SIGNATURES = {
                                                 _u32, _u32, _u32, _vp, _vp]),
     "dwg_grid_encode_backward_xcd": (ctypes.c_int, [_vp, _vp, _vp, _vp, _vp, _u32, _u32, _u32, _u32, _f32, _u32, _vp, _vp, _u32,
                                                     _u32, _u32, _u32, _vp, _vp, _vp]),
+    "dwg_grid_encode_backward_owner": (ctypes.c_int, [_vp, _vp, _vp, _vp, _vp, _u32, _u32, _u32, _u32, _f32, _u32, _vp, _vp, _u32,
+                                                      _u32, _u32, _u32, _vp, _vp, _vp]),
     # include/dwg_gemm.h
     "dwg_gemm": (ctypes.c_int, [_vp, _vp]),
     "dwg_gemm_workspace_bytes": (_sz, [_vp]),

@@ -40,4 +40,15 @@ __device__ __forceinline__ float dwg_wave_sum_all(float v) {
     return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), 63));
 }
 __device__ __forceinline__ int dwg_lane() { return (int)(threadIdx.x & 63); }
+// erf for the GELU epilogues of the bf16 layers: Abramowitz-Stegun 7.1.26, branch-free, one exp + one rcp + 6 fma.  Absolute
+// error 6e-7 in fp32 (libm's erff costs ~3x the instructions with both branches executed under divergence); the results are
+// rounded to bf16 (relative 4e-3) right after, and the fp32 MLPs of the avatar do not use GELU.
+__device__ __forceinline__ float dwg_erf_fast(float x) {
+    const float ax = fabsf(x);
+    const float t = __frcp_rn(fmaf(0.3275911f, ax, 1.f));
+    float p = fmaf(1.061405429f, t, -1.453152027f);
+    p = fmaf(p, t, 1.421413741f); p = fmaf(p, t, -0.284496736f); p = fmaf(p, t, 0.254829592f);
+    const float y = 1.f - p * t * __expf(-ax * ax);
+    return copysignf(y, x);
+}
 #endif

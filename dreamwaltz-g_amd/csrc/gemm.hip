@@ -51,7 +51,7 @@ __device__ __forceinline__ float apply_act(float v, int act) {
         case 1: return v > 0.f ? v : 0.f;
         case 2: return v > 0.f ? v : 0.01f * v;
         case 3: return v / (1.f + __expf(-v));
-        case 4: return 0.5f * v * (1.f + erff(v * 0.70710678118654752f));
+        case 4: return 0.5f * v * (1.f + dwg_erf_fast(v * 0.70710678118654752f));
         case 5: return 1.f / (1.f + __expf(-v));
         default: return v;
     }
@@ -326,7 +326,7 @@ __device__ __forceinline__ void tile_epilogue_t(const GemmP& p, f32x16 (&acc)[TM
                 for (int e = 0; e < 4; e++) {
                     const float a = acc[i][0][4 * r4 + e] * p.alpha + (bias ? bias[colp + e] : 0.f);
                     const float g = acc[i][1][4 * r4 + e] * p.alpha + (bias ? bias[colp + 32 + e] : 0.f);
-                    v[e] = a * 0.5f * g * (1.f + erff(g * 0.70710678118654752f));
+                    v[e] = a * 0.5f * g * (1.f + dwg_erf_fast(g * 0.70710678118654752f));
                 }
                 const long long ci = coff + (long long)row * p.ldc + ocol;
                 if (p.out_bf16) {

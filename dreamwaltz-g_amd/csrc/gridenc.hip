@@ -176,6 +176,72 @@ __global__ __launch_bounds__(256) void k_grid_bwd(GridP p, const float* __restri
     }
 }
 
+// XCD-OWNED table slabs: every 128-byte line of the table gradient belongs to ONE XCD (owner = line index mod 8).  Each chunk of
+// 256 (point, level) lanes is visited by a workgroup on EVERY XCD; a workgroup evaluates all 8 corners but only adds to the entries
+// its own XCD owns -- with workgroup-scope atomics, which that XCD's L2 executes in cache.  No line is ever cached by two XCDs, so
+// there are no private copies to allocate, reduce or clear (the 8-copy variant above moved 4.9x the algorithmic traffic), and an
+// XCD's share of the table (1/8 = 6.3 MB) mostly stays in its 4 MiB L2 / the Infinity Cache.  The redundant index arithmetic
+// (8x) is a few tens of microseconds of VALU.  Work is handed out per PHYSICAL XCD (HW_REG_XCC_ID) through 8 counters, so
+// correctness does not depend on how workgroups are placed -- only on every XCD running at least one of them (checked: `done`).
+__global__ __launch_bounds__(256) void k_grid_bwd_owner(GridP p, uint32_t nchunks, const float* __restrict__ grad, const float* __restrict__ x,
+                                                        const int* __restrict__ offsets, float* __restrict__ grad_table,
+                                                        const float* __restrict__ dy_dx, float* __restrict__ grad_x,
+                                                        uint32_t first_table_level, uint32_t* __restrict__ counters /*[8] next chunk, [8..15] done*/) {
+    __shared__ uint32_t s_chunk;
+    const uint32_t my = xcc_id();
+    for (;;) {
+        if (threadIdx.x == 0) s_chunk = atomicAdd(&counters[my], 1u);
+        __syncthreads();
+        const uint32_t chunk = s_chunk;
+        __syncthreads();
+        if (chunk >= nchunks) break;
+        const uint32_t t = chunk * 256u + threadIdx.x;
+        const uint32_t b = t / p.L, level = t - b * p.L;
+        const bool live = b < p.B;
+        const bool do_x = dy_dx && grad_x && ((chunk & 7u) == my);      // exactly one of the 8 visits of a chunk
+        float gx[3] = {0.f, 0.f, 0.f};
+        if (live) {
+            const float* gsrc = p.layout ? grad + (size_t)b * p.L * 2 + level * 2 : grad + ((size_t)level * p.B + b) * 2;
+            const float g0 = gsrc[0], g1 = gsrc[1];
+            Cell c = locate(p, offsets, level, x[3 * b], x[3 * b + 1], x[3 * b + 2]);
+            if (!c.oob) {
+                if (level >= first_table_level) {
+                    const uint32_t lvl_off = (uint32_t)offsets[level] * 2u;
+#pragma unroll
+                    for (int idx = 0; idx < 8; idx++) {
+                        uint32_t cx = c.g[0] + (idx & 1), cy = c.g[1] + ((idx >> 1) & 1), cz = c.g[2] + ((idx >> 2) & 1);
+                        const uint32_t index = lvl_off + grid_index(p.gridtype, p.align_corners, c.hsize, c.res, cx, cy, cz);
+                        if (((index >> 5) & 7u) != my) continue;        // 32 floats = one 128-byte line
+                        float w = ((idx & 1) ? c.w[0] : 1.f - c.w[0]) * ((idx & 2) ? c.w[1] : 1.f - c.w[1]) *
+                                  ((idx & 4) ? c.w[2] : 1.f - c.w[2]);
+                        table_add<true>(grad_table + index, w * g0);
+                        table_add<true>(grad_table + index + 1, w * g1);
+                    }
+                }
+                if (do_x) {
+                    const float* dd = dy_dx + ((size_t)b * p.L + level) * 6;
+#pragma unroll
+                    for (int d = 0; d < 3; d++) gx[d] = g0 * dd[2 * d] + g1 * dd[2 * d + 1];
+                }
+            }
+        }
+        if (do_x) {
+            if (p.L == 16) {
+#pragma unroll
+                for (int d = 0; d < 3; d++) {
+                    float v = gx[d];
+                    v += __shfl_xor(v, 1); v += __shfl_xor(v, 2); v += __shfl_xor(v, 4); v += __shfl_xor(v, 8);
+                    gx[d] = v;
+                }
+                if (live && level == 0) { grad_x[3 * b] = gx[0]; grad_x[3 * b + 1] = gx[1]; grad_x[3 * b + 2] = gx[2]; }
+            } else if (live) {
+                atomicAdd(&grad_x[3 * b], gx[0]); atomicAdd(&grad_x[3 * b + 1], gx[1]); atomicAdd(&grad_x[3 * b + 2], gx[2]);
+            }
+        }
+    }
+    if (threadIdx.x == 0) atomicMax(&counters[8 + my], 1u);             // this XCD took part
+}
+
 // Coarse levels (a few thousand cells, hundreds of points per cell): the whole level table is privatised in LDS so the
 // same-address contention stays on chip; one global atomic per (workgroup, touched entry) afterwards.
 __global__ __launch_bounds__(256) void k_grid_bwd_coarse(GridP p, uint32_t level, uint32_t points_per_block,
@@ -291,6 +357,48 @@ static int grid_backward(const float* grad, const float* inputs, const float* em
         DWG_LAUNCH("grid_bwd", (k_grid_bwd<false>), dim3((n + 255) / 256), dim3(256), 0, (hipStream_t)stream, p, grad, inputs, offsets,
                    grad_embeddings, dy_dx, grad_inputs, first_table_level, (size_t)0);
     }
+    DWG_RETURN_IF_LAUNCH_FAILED();
+    return DWG_OK;
+}
+
+int dwg_grid_encode_backward_owner(const float* grad, const float* inputs, const float* embeddings, const int32_t* offsets,
+                                   float* grad_embeddings, uint32_t B, uint32_t D, uint32_t C, uint32_t L, float S, uint32_t H,
+                                   const float* dy_dx, float* grad_inputs, uint32_t gridtype, uint32_t align_corners,
+                                   uint32_t interp, uint32_t grad_layout, const int32_t* host_offsets, uint32_t* xcd_counters,
+                                   dwg_stream_t stream) {
+    int rc = check(B, D, C, L);
+    if (rc) return rc;
+    if (B == 0) return DWG_OK;
+    (void)embeddings;
+    if (!grad || !inputs || !offsets || !grad_embeddings || !host_offsets || !xcd_counters) return DWG_E_ARG;
+    if (((uintptr_t)grad_embeddings % 128) != 0) return DWG_E_ARG;          // line ownership assumes a line-aligned table
+    if ((dy_dx == nullptr) != (grad_inputs == nullptr)) return DWG_E_ARG;
+    GridP p{B, L, S, H, gridtype, align_corners, interp, grad_layout};
+    if (grad_inputs && L != 16) {
+        if (hipMemsetAsync(grad_inputs, 0, (size_t)B * 3 * sizeof(float), (hipStream_t)stream) != hipSuccess) return DWG_E_LAUNCH;
+    }
+    if (hipMemsetAsync(xcd_counters, 0, 16 * sizeof(uint32_t), (hipStream_t)stream) != hipSuccess) return DWG_E_LAUNCH;
+    uint32_t first_table_level = 0;
+    if (B >= 16384) {
+        static bool attr_set = false;
+        if (!attr_set) {
+            hipFuncSetAttribute(reinterpret_cast<const void*>(&k_grid_bwd_coarse), hipFuncAttributeMaxDynamicSharedMemorySize, 152 * 1024);
+            attr_set = true;
+        }
+        while (first_table_level < L) {
+            uint32_t hs = (uint32_t)(host_offsets[first_table_level + 1] - host_offsets[first_table_level]);
+            if ((size_t)hs * 8 > 152 * 1024 || (uint64_t)B * 8 < (uint64_t)hs * 16) break;
+            uint32_t ppb = hs * 8 > 64 * 1024 ? 8192 : 2048;
+            DWG_LAUNCH("grid_bwd_coarse", k_grid_bwd_coarse, dim3((B + ppb - 1) / ppb), dim3(256), (size_t)hs * 8, (hipStream_t)stream, p,
+                       first_table_level, ppb, grad, inputs, offsets, grad_embeddings);
+            first_table_level++;
+        }
+    }
+    const uint32_t nchunks = (uint32_t)(((uint64_t)B * L + 255) / 256);
+    uint32_t blocks = nchunks * 8u; if (blocks > 2048u) blocks = 2048u;       // persistent: 8 per CU, chunks pulled per physical XCD
+    if (blocks < 64u) blocks = 64u;                                          // enough that every XCD receives workgroups
+    DWG_LAUNCH("grid_bwd", k_grid_bwd_owner, dim3(blocks), dim3(256), 0, (hipStream_t)stream, p, nchunks, grad, inputs, offsets,
+               grad_embeddings, dy_dx, grad_inputs, first_table_level, xcd_counters);
     DWG_RETURN_IF_LAUNCH_FAILED();
     return DWG_OK;
 }

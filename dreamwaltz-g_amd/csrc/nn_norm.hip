@@ -258,7 +258,7 @@ __global__ __launch_bounds__(256) void k_geglu(long long M, int F, const __bf16*
 #pragma unroll
         for (int e = 0; e < 8; e++) {
             float gv = (float)g[e];
-            o[e] = (__bf16)((float)a[e] * 0.5f * gv * (1.f + erff(gv * 0.70710678118654752f)));
+            o[e] = (__bf16)((float)a[e] * 0.5f * gv * (1.f + dwg_erf_fast(gv * 0.70710678118654752f)));
         }
         *reinterpret_cast<bf16x8*>(out + m * F + (size_t)fc * 8) = o;
     }

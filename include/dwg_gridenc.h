@@ -46,6 +46,18 @@ int dwg_grid_encode_backward_xcd(const float* grad, const float* inputs, const f
                                  uint32_t interp, uint32_t grad_layout, const int32_t* host_offsets, float* xcd_scratch,
                                  dwg_stream_t stream);
 
+/* Same result through XCD-OWNED table slabs (the default for large batches): each 128-byte line of grad_embeddings belongs to
+ * one XCD (line index mod 8); every chunk of 256 (point, level) lanes is visited once per XCD and a workgroup only adds to the
+ * lines its own XCD (HW_REG_XCC_ID) owns, with L2-local (workgroup-scope) atomics.  No private copies, no reduce pass: the
+ * traffic is the table lines actually touched.  grad_embeddings must be 128-byte aligned and is accumulated into;
+ * xcd_counters: 16 uint32 of scratch (cleared inside: [0..7] work hand-out per XCD, [8..15] set to 1 by every XCD that took
+ * part -- all eight must be 1 afterwards, which the Python binding verifies in its self-test); host_offsets is required. */
+int dwg_grid_encode_backward_owner(const float* grad, const float* inputs, const float* embeddings, const int32_t* offsets,
+                                   float* grad_embeddings, uint32_t B, uint32_t D, uint32_t C, uint32_t L, float S, uint32_t H,
+                                   const float* dy_dx, float* grad_inputs, uint32_t gridtype, uint32_t align_corners,
+                                   uint32_t interp, uint32_t grad_layout, const int32_t* host_offsets, uint32_t* xcd_counters,
+                                   dwg_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

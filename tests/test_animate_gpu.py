@@ -128,13 +128,22 @@ def test_grid_encoder_forward_backward(B, gridtype):
     assert _rel_l2(tc.grad, gt_ref) < 1e-4
     assert _rel_l2(xc.grad, gx_ref) < 2e-3   # d/dx is scaled by up to 4095 per level: fp32 cancellation
     if B >= 16384:
-        # the XCD-private scratch must be left all zero, and a second backward must reproduce the first
+        # the three table-gradient paths (XCD-owned lines [default], 8 XCD-private copies, device-scope atomics) agree, a second
+        # backward reproduces the first, and the private-copy scratch is left all zero
+        import os
         from dreamwaltz_g_amd import gridencoder as ge
+        assert ge.xcd_path_ok(tc.device)
+        for mode in ("copies", "owner", "device"):
+            os.environ["DWG_GRID_XCD_MODE"] = mode
+            try:
+                tc.grad = None; xc.grad = None
+                out2 = grid_encode(xc, tc, torch.from_numpy(offsets).cuda(), pls, 16, True, gridtype, False, 1)
+                out2.backward(go.float().cuda())
+            finally:
+                os.environ.pop("DWG_GRID_XCD_MODE", None)
+            assert _rel_l2(tc.grad, gt_ref) < 1e-4, mode
+            assert _rel_l2(xc.grad, gx_ref) < 2e-3, mode
         assert float(ge.xcd_scratch_for(tc).abs().max()) == 0.0
-        tc.grad = None; xc.grad = None
-        out2 = grid_encode(xc, tc, torch.from_numpy(offsets).cuda(), pls, 16, True, gridtype, False, 1)
-        out2.backward(go.float().cuda())
-        assert _rel_l2(tc.grad, gt_ref) < 1e-4
 
 
 def test_grid_encoder_backend_layout_and_module():
