@@ -101,3 +101,34 @@ class Scene(nn.Module):
         else:
             outputs['image_fg'] = outputs['image']
         return outputs
+
+    # -- checkpoints (scene.py:170-208) ---------------------------------------------------------------------------------------
+    @staticmethod
+    def organize_state_dict(state_dict):
+        by_module = {}
+        for k, v in state_dict.items():
+            module_name = k.split('.')[0]
+            by_module.setdefault(module_name, {})[k.replace(f'{module_name}.', '', 1)] = v
+        return by_module
+
+    def state_dict(self, *args, **kwargs):
+        """Scene.state_dict() of the reference: the avatar under `avatar.` (and `avatars.<i>.` for a multi-avatar scene)."""
+        return super().state_dict(*args, **kwargs)
+
+    def load_state_dict(self, state_dict, strict: bool = True):
+        """scene.py:196-200: resize the per-Gaussian parameters to the checkpoint's count (reset_by_state_dict), then a plain
+        load; derived caches / topology of the native path are rebuilt afterwards."""
+        by_module = self.organize_state_dict(state_dict)
+        if 'avatar' in by_module:
+            self.avatar.reset_by_state_dict(by_module['avatar'])
+        own = set(super().state_dict().keys())
+        filtered = {k: v for k, v in state_dict.items() if k in own}
+        res = super().load_state_dict(filtered, strict=False)
+        if 'avatar.nerf_bound' in state_dict:
+            self.avatar._nerf_bound_host = float(state_dict['avatar.nerf_bound'])
+        for a in ([self.avatar] if self.avatars is None else list(self.avatars)):
+            a.invalidate_caches()
+        unexpected = [k for k in state_dict.keys() if k not in own]
+        if strict and (res.missing_keys or unexpected):
+            raise RuntimeError("Scene.load_state_dict: missing %s unexpected %s" % (res.missing_keys, unexpected))
+        return res

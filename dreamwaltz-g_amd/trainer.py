@@ -28,8 +28,47 @@ class SDSTrainer:
         self.max_step = cfg.optim.iters if max_step is None else max_step
         self.scaler = None                          # GradScaler(enabled=False) in the fp32 recipes: pass-through
         self.redone_frames = 0
+        self.past_checkpoints = []
         if hasattr(optimizers, "set_grad_scale"):
             optimizers.set_grad_scale(1.0 / world)  # mean of the all-reduced (summed) gradients, folded into the Adam kernel
+
+    # -- checkpoints (trainer.py:188-259): {'train_step', 'checkpoints', 'model': Scene.state_dict()[, 'optimizers', 'scaler']} ------
+    def save_checkpoint(self, ckpt_dir, full: bool = False, max_keep_ckpts: int = 2):
+        """File name step_{train_step:06d}.pth, rolling window of `max_keep_ckpts` files, as the reference writes them; `full` adds
+        the optimizer states (here: step counts, learning rates and the flat Adam moments of every named optimizer)."""
+        import os
+        os.makedirs(ckpt_dir, exist_ok=True)
+        state = {'train_step': self.train_step_index, 'checkpoints': self.past_checkpoints}
+        if full:
+            state['optimizers'] = [optimizer.state_dict() for optimizer in self.optimizers.values()]
+            state['scaler'] = {}
+        state['model'] = {k: v.detach().clone() for k, v in self.model.state_dict().items()}
+        file_path = f"step_{self.train_step_index:06d}.pth"
+        if len(self.past_checkpoints) == 0 or file_path != self.past_checkpoints[-1]:
+            self.past_checkpoints.append(file_path)
+        if len(self.past_checkpoints) > max_keep_ckpts:
+            old = os.path.join(ckpt_dir, self.past_checkpoints.pop(0))
+            if os.path.exists(old):
+                os.unlink(old)
+        torch.save(state, os.path.join(ckpt_dir, file_path))
+        return os.path.join(ckpt_dir, file_path)
+
+    def load_checkpoint(self, checkpoint, model_only: bool = False, resume: bool = True):
+        """trainer.py:188-236.  NB the parameters live in the optimizers' flat buffer: a checkpoint with a DIFFERENT Gaussian count must
+        be loaded into the model before `get_optimizer` is called (the reference rebuilds its optimizers the same way)."""
+        d = torch.load(checkpoint, map_location=self.model.device, weights_only=False)
+        if 'model' not in d:
+            self.model.load_state_dict(d)
+            return
+        self.model.load_state_dict(d['model'], strict=False)
+        self.past_checkpoints = d['checkpoints']
+        if resume:
+            self.train_step_index = d['train_step']
+        if model_only:
+            return
+        if self.optimizers is not None and 'optimizers' in d:
+            for optimizer, sd in zip(self.optimizers.values(), d['optimizers']):
+                optimizer.load_state_dict(sd)
 
     def render(self, data, bg_mode=None):
         if self.cfg.prompt.scene != 'canonical' or self.cfg.render.always_animate:

@@ -141,3 +141,49 @@ def test_reference_checkpoint_keys_load_into_the_native_avatar():
     rename = {"lbs_model.shapedirs": "lbs_model.shapedirs_all", "lbs_model.expr_dirs": "lbs_model.shapedirs_all"}
     absent = [k for k in (str(x) for x in G["sd.animate.state_dict_keys"]) if rename.get(k, k) not in own]
     assert all(k.startswith("lbs_model.") or k.endswith("points_to_triangles") for k in absent), absent
+
+
+def test_trainer_checkpoint_round_trip_has_the_reference_layout(tmp_path):
+    """SDSTrainer.save_checkpoint / load_checkpoint (mirror of trainer.py:188-259): file name, top-level keys, the avatar under
+    `avatar.` with the reference's parameter names, optimizer state, rolling window, resize on load."""
+    from dreamwaltz_g_amd import avatar as av, configs, scene as sc, synth, trainer as tr
+    body = synth.synthetic_body(V=64, J=55, seed=0)
+    g = torch.Generator().manual_seed(0)
+
+    def make(n):
+        glbs = av.GeneralLinearBlendSkinning(body)
+        vi = torch.arange(12); tri = torch.tensor([[0, 1, 2], [3, 4, 5]])
+        mesh = {"hands": av.MeshBindingGaussianModel(body["v_template"][vi], tri, vi)}
+        return av.DreamWaltzG(glbs, torch.rand(n, 3, generator=g), torch.rand(n, 3, generator=g) + 0.1, torch.randn(n, 4, generator=g),
+                              torch.rand(n, 55, generator=g), {}, mesh)
+    cfg = configs.TrainConfig(); cfg.device = "cpu"
+    a = make(9)
+    opts = a.get_optimizer(cfg)
+    t = tr.SDSTrainer(cfg, sc.Scene(cfg, a), None, opts)
+    t.train_step_index = 7
+    opts["avatar"].t = 7; opts.buffers.m.fill_(0.25)
+    path = t.save_checkpoint(str(tmp_path), full=True)
+    assert path.endswith("step_000007.pth")
+    d = torch.load(path, weights_only=False)
+    assert set(d.keys()) == {"train_step", "checkpoints", "optimizers", "scaler", "model"} and d["train_step"] == 7
+    assert d["checkpoints"] == ["step_000007.pth"] and len(d["optimizers"]) == len(opts)
+    assert {"avatar._positions", "avatar._scales", "avatar._quaternions", "avatar._lbs_weights", "avatar._betas", "avatar.nerf_bound",
+            "avatar.nerf_encoder.embeddings", "avatar.mesh_binding_gaussians.hands._bary_coords"} <= set(d["model"].keys())
+    # load into a scene with another Gaussian count: per-Gaussian parameters are resized first (gaussian_model.py:58-85)
+    b = make(5)
+    t2 = tr.SDSTrainer(cfg, sc.Scene(cfg, b), None, None)
+    t2.load_checkpoint(path, model_only=True)
+    assert b._positions.shape == (9, 3) and torch.equal(b._positions.data, d["model"]["avatar._positions"]) and t2.train_step_index == 7
+    # same count: optimizer state comes back too
+    c = make(9)
+    o3 = c.get_optimizer(cfg)
+    t3 = tr.SDSTrainer(cfg, sc.Scene(cfg, c), None, o3)
+    t3.load_checkpoint(path)
+    assert o3["avatar"].t == 7 and float(o3.buffers.m[:27].min()) == 0.25
+    assert torch.equal(c._positions.data, d["model"]["avatar._positions"])
+    # rolling window of checkpoint files
+    for step in (8, 9):
+        t.train_step_index = step
+        t.save_checkpoint(str(tmp_path), full=False, max_keep_ckpts=2)
+    import os
+    assert sorted(os.listdir(tmp_path)) == ["step_000008.pth", "step_000009.pth"]
