@@ -788,6 +788,8 @@ __global__ __launch_bounds__(256, 2) void k_conv3x3_patch(GemmP p) {   // 2 wave
         const int nwg = gridDim.x, q = nwg / 8, r = nwg % 8, xcd = id % 8, loc = id / 8;
         id = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + loc;
     }
+    const int ks_id = id / (gm * ntn);                    // split-K slice: a contiguous range of 64-channel slabs
+    id -= ks_id * gm * ntn;
     const int mt = id / ntn, n0 = (id % ntn) * BN;
     const int img = mt / (tiles_y * tiles_x), trem = mt % (tiles_y * tiles_x);
     const int y0 = (trem / tiles_x) * PH, x0 = (trem % tiles_x) * PW;
@@ -846,12 +848,15 @@ __global__ __launch_bounds__(256, 2) void k_conv3x3_patch(GemmP p) {   // 2 wave
         const int r = (wm * TM + i) * 32 + (lane & 31);
         pbase[i] = (r >> 4) * WP + (r & 15);
     }
-    const int ncc = cv.Cin / 64;
+    int cc0 = 0, ncc = cv.Cin / 64;
+    if (p.splitk > 1) {
+        const int per = (ncc + p.splitk - 1) / p.splitk;
+        cc0 = ks_id * per; ncc = min(ncc, cc0 + per);
+    }
     const int frow = lane & 31, fx = (lane >> 1) & 7, fh = lane >> 5;
-    issue_patch(0, sP);
-    issue_w(0, 0, sB);
+    if (cc0 < ncc) { issue_patch(cc0, sP + (cc0 & 1) * PBYTES); issue_w(cc0, 0, sB + ((cc0 & 1) ? BBYTES : 0)); }
     // 9 taps unrolled: the tap's patch offset is an immediate and there is no step -> (slab, tap) division in the loop
-    for (int cc = 0; cc < ncc; cc++) {
+    for (int cc = cc0; cc < ncc; cc++) {
         const unsigned char* pa = sP + (cc & 1) * PBYTES;
 #pragma unroll
         for (int tap = 0; tap < 9; tap++) {
@@ -897,6 +902,15 @@ __global__ __launch_bounds__(256, 2) void k_conv3x3_patch(GemmP p) {   // 2 wave
                 float v[4];
 #pragma unroll
                 for (int e = 0; e < 4; e++) v[e] = acc[i][j][4 * r4 + e] * p.alpha;
+                if (p.splitk > 1) {                          // fp32 slab, reduced in slice order by k_splitk_epilogue
+                    float* dst = p.ws + ((long long)ks_id * p.M + m) * p.N + col;
+                    if ((p.N & 3) == 0) *reinterpret_cast<float4*>(dst) = make_float4(v[0], v[1], v[2], v[3]);
+                    else {
+#pragma unroll
+                        for (int e = 0; e < 4; e++) if (col + e < p.N) dst[e] = v[e];
+                    }
+                    continue;
+                }
                 epilogue_store4(p, v, m, col, 0, 0, vec_ok);
             }
     }
@@ -909,7 +923,7 @@ static void launch_conv3x3_patch(const GemmP& p, hipStream_t stream, const char*
     const ConvP& cv = p.conv;
     const int nimg = p.M / (cv.Hout * cv.Wout);
     const int gm = nimg * ((cv.Hout + 7) / 8) * ((cv.Wout + 15) / 16);
-    dim3 grid(gm * ((p.N + BN - 1) / BN));
+    dim3 grid(gm * ((p.N + BN - 1) / BN) * (p.splitk > 1 ? p.splitk : 1));
     static bool attr_set = false;
     if (!attr_set) {
         hipFuncSetAttribute(reinterpret_cast<const void*>(&k_conv3x3_patch<BN>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
@@ -917,6 +931,12 @@ static void launch_conv3x3_patch(const GemmP& p, hipStream_t stream, const char*
     }
     DWG_LAUNCH_W(name, (BN == 64 ? "k_conv3x3_patch<64>" : "k_conv3x3_patch<128>"), gemm_flops(p, 1), (k_conv3x3_patch<BN>), grid,
                  dim3(256), lds, stream, p);
+    if (p.splitk > 1 && p.ws) {
+        long long n = (long long)p.M * p.N;
+        if ((p.N & 3) == 0) n >>= 2;
+        int blocks = (int)((n + 255) / 256); if (blocks > 2048) blocks = 2048;
+        DWG_LAUNCH("splitk_epilogue", k_splitk_epilogue, dim3(blocks), dim3(256), 0, stream, p);
+    }
 }
 
 template <typename T, int BN, int AMODE, int BMODE>
@@ -1059,10 +1079,25 @@ int dwg_gemm(const dwg_gemm_desc* d, dwg_stream_t stream_) {
         } else amode = pick_mode<T>(p.A, p.sam, p.sak, p.M, p.K, ao, 2);
         bmode = pick_mode<T>(p.B, p.sbn, p.sbk, p.N, p.K, bo, 2);
         const bool glds_ok = bmode == MODE_KVEC && (amode == MODE_KVEC || amode == MODE_CONV) && !d->force_register_staging;
-        const bool patch_ok = glds_ok && amode == MODE_CONV && batch == 1 && p.splitk == 1 && d->conv_kh == 3 && d->conv_kw == 3 &&
-                              d->conv_stride == 1 && p.conv.dil == 1 && p.conv.up == 1 && d->conv_pad_t == 1 && d->conv_pad_l == 1 &&
-                              !d->A2 && d->conv_cin % 64 == 0 && d->conv_hout == d->conv_hin && d->conv_wout == d->conv_win &&
-                              d->conv_wout >= 16 && d->conv_hout >= 8 && d->M >= 8192 && getenv("DWG_CONV_NO_PATCH") == nullptr;
+        // LDS-patch convolution: the halo patch of a 64-channel slab is loaded once for all nine taps (2.3x less L2 -> LDS traffic
+        // per flop than the im2col loader, which is what bounds these layers).  Below 64x64 latents it needs split-K over the
+        // channel slabs to fill the chip; DWG_CONV_PATCH_MINM = smallest M it is used for (experiment switch).
+        const int patch_min_m = getenv("DWG_CONV_PATCH_MINM") ? atoi(getenv("DWG_CONV_PATCH_MINM")) : 8192;
+        bool patch_ok = glds_ok && amode == MODE_CONV && batch == 1 && d->conv_kh == 3 && d->conv_kw == 3 &&
+                        d->conv_stride == 1 && p.conv.dil == 1 && p.conv.up == 1 && d->conv_pad_t == 1 && d->conv_pad_l == 1 &&
+                        !d->A2 && d->conv_cin % 64 == 0 && d->conv_hout == d->conv_hin && d->conv_wout == d->conv_win &&
+                        d->conv_wout >= 16 && d->conv_hout >= 8 && d->M >= patch_min_m && getenv("DWG_CONV_NO_PATCH") == nullptr;
+        if (patch_ok && p.splitk > 1) {
+            // re-derive the slice count for this kernel's tiling: (8x16 pixel tiles) x (N / BN) workgroups, >= 2 slabs per slice
+            const int gm = (d->M / (d->conv_hout * d->conv_wout)) * ((d->conv_hout + 7) / 8) * ((d->conv_wout + 15) / 16);
+            const int blocks = gm * ((d->N + (narrow ? 64 : 128) - 1) / (narrow ? 64 : 128));
+            int sk = blocks >= 256 ? 1 : (384 + blocks - 1) / blocks;
+            const int ncc = d->conv_cin / 64;
+            if (sk > ncc / 2) sk = ncc / 2;
+            if (sk > p.splitk) sk = p.splitk;             // the workspace was sized for p.splitk slabs
+            if (sk < 2) { sk = 1; p.ws = nullptr; }
+            p.splitk = sk;
+        }
         if (patch_ok) {
             if (narrow) launch_conv3x3_patch<64>(p, stream, name); else launch_conv3x3_patch<128>(p, stream, name);
         } else if (glds_ok) {

@@ -162,3 +162,40 @@ def test_bf16_geglu_pair_epilogue():
     y = torch.empty(M, F_, device="cuda", dtype=torch.bfloat16)
     gemm.gemm_raw(x.cuda(), wp, y, M, 8 * C, C, (C, 1), (C, 1), F_, bias=bp, act="geglu_pair")
     assert _rel(y.cpu(), ref) < 1.2e-2
+
+
+@pytest.mark.parametrize("C,H,patch_min_m", [(640, 32, 512), (1280, 16, 512), (640, 32, 8192), (320, 64, 512)])
+def test_bf16_conv3x3_small_latents_splitk_paths(C, H, patch_min_m):
+    """3x3 / stride 1 / pad 1 convolutions of the 32x32 and 16x16 latent levels with the library-chosen split-K: through the
+    LDS-patch kernel with split-K over the 64-channel slabs (DWG_CONV_PATCH_MINM=512) and through the im2col loader (default)."""
+    import ctypes
+    import os
+    from dreamwaltz_g_amd import gemm, _lib
+    g = torch.Generator().manual_seed(C + H)
+    Bn = 2
+    x = torch.randn(Bn, C, H, H, generator=g).bfloat16(); w = (torch.randn(C, C, 3, 3, generator=g) / (C * 9) ** 0.5).bfloat16()
+    b = torch.randn(C, generator=g); r = torch.randn(Bn, H, H, C, generator=g).bfloat16()
+    ref = torch.nn.functional.conv2d(x.double(), w.double(), b.double(), padding=1).permute(0, 2, 3, 1) + r.double()
+    xc, wc = x.permute(0, 2, 3, 1).contiguous().cuda(), w.permute(0, 2, 3, 1).contiguous().cuda()
+    y = torch.empty(Bn, H, H, C, device="cuda", dtype=torch.bfloat16)
+    M, K = Bn * H * H, 9 * C
+    os.environ["DWG_CONV_PATCH_MINM"] = str(patch_min_m)
+    try:
+        d = gemm.gemm_raw(xc, wc, y, M, C, K, (0, 1), (K, 1), C, bias=b.cuda(), residual=r.cuda(), ldr=C,
+                          conv=(C, H, H, H, H, 3, 3, 1, 1, 1, 1), run=False)
+        d.splitk = 0
+        need = _lib.lib().dwg_gemm_workspace_bytes(ctypes.byref(d))
+        ws = torch.empty(max(need, 16) // 4, device="cuda")
+        if need > 0:
+            d.workspace, d.workspace_bytes = ws.data_ptr(), need
+        else:
+            d.splitk = 1
+        _lib.prof_enable(True)
+        gemm.run_desc(d, ctypes.c_void_p(torch.cuda.current_stream().cuda_stream))
+        torch.cuda.synchronize()
+        syms = _lib.prof_symbols(); _lib.prof_enable(False)
+    finally:
+        os.environ.pop("DWG_CONV_PATCH_MINM", None)
+    used_patch = any(k.startswith("k_conv3x3_patch") for k in syms)
+    assert used_patch == (M >= patch_min_m), (syms.keys(), M, patch_min_m)
+    assert _rel(y.cpu(), ref) < 1.2e-2
