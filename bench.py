@@ -54,7 +54,9 @@ def cpu_baseline(args, G, res):
     import numpy as np
     from oracle import animate as oa
     from tests import raster_cases as rc
-    cores = os.cpu_count() or 1
+    # every host core up to 32: beyond that the oracle's element-wise torch ops on 1e5-row tensors only get slower (measured on the
+    # 256-core GPU box: the same pass takes minutes with 256 OpenMP threads)
+    cores = min(os.cpu_count() or 1, 32)
     torch.set_num_threads(cores)
     M = (G // 10) // 6 * 6
     N = G - M
@@ -96,6 +98,7 @@ def cpu_baseline(args, G, res):
     t_an, t_ra = float(np.median(ta)), float(np.median(tr))
     return {"value": 1.0 / (t_an + t_ra), "unit": "steps/s (animate + rasterizer, fwd+bwd, no diffusion)", "cores": cores,
             "kind": "port",
+            "host_cores": os.cpu_count(),
             "sample": "median of %d passes (%.0f s of CPU work, %d torch threads; the C rasterizer oracle is one thread): oracle animate "
                       "fwd+bwd %.2f s (%d free Gaussians with 4 non-zero skinning weights + %d mesh-bound) + tile raster fwd+bwd %.2f s "
                       "(%d Gaussians @%dx%d)" % (len(ta), spent, cores, t_an, N, M, t_ra, G, res, res)}

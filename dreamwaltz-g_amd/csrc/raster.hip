@@ -229,25 +229,50 @@ __device__ float3 sh_color(int deg, int M, const float* sh, float3 pos, const fl
 // exact (Gaussian, block) culling
 // ------------------------------------------------------------------------------------------------
 // A splat contributes to a pixel iff power <= 0 and min(0.99, opacity * exp(power)) >= 1/255, i.e. iff the conic's quadratic form
-// q(d) = a dx^2 + 2 b dx dy + c dy^2 is <= 2 ln(255 opacity).  The margin (1e-4 relative + 1e-3 absolute on q, i.e. 5e-4 relative
-// on alpha) is hundreds of times the fp32 rounding of the per-pixel evaluation, so no contributing pair is ever dropped.
-__device__ __forceinline__ float cull_threshold(float opacity) {
-    return 2.f * logf(255.f * opacity) * (1.f + 1e-4f) + 1e-3f;      // NaN for opacity <= 0: every comparison below then keeps the pair
-}
-// minimum of q over the rectangle of pixel centres of block (bx, by), compared with thr; true = keep the pair
-__device__ __forceinline__ bool block_touch(float gx, float gy, float ca, float cb, float cc, float thr, int bx, int by) {
-    if (!(ca > 0.f) || !(cc > 0.f) || !(ca * cc - cb * cb > 0.f)) return true;      // not positive definite: no culling
-    const float x0 = (float)(bx * BT) - gx, x1 = x0 + (float)(BT - 1), y0 = (float)(by * BT) - gy, y1 = y0 + (float)(BT - 1);
-    if (x0 <= 0.f && x1 >= 0.f && y0 <= 0.f && y1 >= 0.f) return !(0.f > thr);
-    float qm = 3.0e38f;
-    const float ky = -cb / cc, kx = -cb / ca;
-    {
-        float y = fminf(y1, fmaxf(y0, ky * x0)); qm = fminf(qm, ca * x0 * x0 + 2.f * cb * x0 * y + cc * y * y);
-        y = fminf(y1, fmaxf(y0, ky * x1));       qm = fminf(qm, ca * x1 * x1 + 2.f * cb * x1 * y + cc * y * y);
-        float x = fminf(x1, fmaxf(x0, kx * y0)); qm = fminf(qm, ca * x * x + 2.f * cb * x * y0 + cc * y0 * y0);
-        x = fminf(x1, fmaxf(x0, kx * y1));       qm = fminf(qm, ca * x * x + 2.f * cb * x * y1 + cc * y1 * y1);
+// q(d) = a dx^2 + 2 b dx dy + c dy^2 is <= 2 ln(255 opacity) =: thr.  The margin (1e-4 relative + 1e-3 absolute on q, i.e. 5e-4
+// relative on alpha, plus 1e-3 px on every interval end) is hundreds of times the fp32 rounding of the per-pixel evaluation, so
+// no contributing pair is ever dropped.
+//
+// The blocks an ellipse {q <= thr} touches are enumerated by SCANLINE, not by testing every block of the 3-sigma square: for a
+// row of blocks (pixel-centre band y in [y0, y1] relative to the centre) the x-projection of (ellipse n band) is one interval
+// [xl, xr] -- x_r(y) = (-b y + sqrt(a thr - det y^2)) / a is concave with its maximum at the ellipse's rightmost point, x_l(y) is
+// its mirror -- so a row costs two square roots whatever its length, and a lane with a huge splat does O(rows), not O(blocks), work.
+struct BlockSpan {
+    int by0, by1;        // block rows [by0, by1)
+    int bx0, bx1;        // block columns of the reference tile rect [bx0, bx1)
+    float gx, gy, ca, cb, cc, thr, det, hy, yr;
+    bool all;            // no culling (conic not positive definite / opacity not a positive number): every block of the rect
+};
+__device__ __forceinline__ BlockSpan block_span(float gx, float gy, float ca, float cb, float cc, float opacity, int tx0, int ty0, int tx1,
+                                                int ty1, int tiles_x, int tiles_y) {
+    BlockSpan s;
+    s.gx = gx; s.gy = gy; s.ca = ca; s.cb = cb; s.cc = cc;
+    s.bx0 = 2 * tx0; s.bx1 = min(2 * tx1, tiles_x); s.by0 = 2 * ty0; s.by1 = min(2 * ty1, tiles_y);
+    s.thr = 2.f * logf(255.f * opacity) * (1.f + 1e-4f) + 1e-3f;
+    s.det = ca * cc - cb * cb;
+    s.all = !(ca > 0.f) || !(cc > 0.f) || !(s.det > 0.f) || !(s.thr == s.thr);
+    s.hy = 0.f; s.yr = 0.f;
+    if (!s.all) {
+        if (!(s.thr > 0.f)) { s.by1 = s.by0; return s; }                  // never reaches alpha 1/255
+        s.hy = sqrtf(s.thr * ca / s.det) + 1e-3f;                           // half height of the ellipse
+        s.yr = -cb / cc * sqrtf(s.thr * cc / s.det);                        // y of its rightmost point (leftmost: -yr)
+        s.by0 = max(s.by0, (int)ceilf((gy - s.hy - (float)(BT - 1)) / BT));
+        s.by1 = min(s.by1, (int)floorf((gy + s.hy) / BT) + 1);
     }
-    return !(qm > thr);
+    return s;
+}
+// columns [xa, xb) of block row `by` the splat reaches
+__device__ __forceinline__ void block_row(const BlockSpan& s, int by, int* xa, int* xb) {
+    if (s.all) { *xa = s.bx0; *xb = s.bx1; return; }
+    const float y0 = (float)(by * BT) - s.gy, y1 = y0 + (float)(BT - 1);
+    const float ya = fmaxf(y0, -s.hy), yb = fminf(y1, s.hy);
+    if (ya > yb) { *xa = 0; *xb = 0; return; }
+    const float yR = fminf(yb, fmaxf(ya, s.yr)), yL = fminf(yb, fmaxf(ya, -s.yr));
+    const float dR = fmaxf(0.f, s.ca * s.thr - s.det * yR * yR), dL = fmaxf(0.f, s.ca * s.thr - s.det * yL * yL);
+    const float xr = (-s.cb * yR + sqrtf(dR)) / s.ca + 1e-3f, xl = (-s.cb * yL - sqrtf(dL)) / s.ca - 1e-3f;
+    // block bx holds pixel centres [BT bx, BT bx + BT - 1]: it meets [xl, xr] iff BT bx <= xr + gx and BT bx + BT - 1 >= xl + gx
+    int a = (int)ceilf((xl + s.gx - (float)(BT - 1)) / BT), b = (int)floorf((xr + s.gx) / BT) + 1;
+    *xa = max(a, s.bx0); *xb = min(b, s.bx1);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -309,14 +334,15 @@ __global__ __launch_bounds__(256) void k_preprocess(Params p, const float* __res
                 r0 = make_float4(px, py, pv.z, op);
                 r1 = make_float4(e.c * di, -e.b * di, e.a * di, 0.f);
                 r2 = make_float4(col.x, col.y, col.z, __uint_as_float(cb));
-                const float thr = cull_threshold(op);
-                const int bx1 = min(2 * tx1, p.tiles_x), by1 = min(2 * ty1, p.tiles_y);
-                for (int by = 2 * ty0; by < by1; by++)
-                    for (int bx = 2 * tx0; bx < bx1; bx++) {
-                        if (!block_touch(px, py, r1.x, r1.y, r1.z, thr, bx, by)) continue;
+                const BlockSpan sp = block_span(px, py, r1.x, r1.y, r1.z, op, tx0, ty0, tx1, ty1, p.tiles_x, p.tiles_y);
+                for (int by = sp.by0; by < sp.by1; by++) {
+                    int xa, xb;
+                    block_row(sp, by, &xa, &xb);
+                    for (int bx = xa; bx < xb; bx++) {
                         if (use_lds_hist) atomicAdd(&hist[by * p.tiles_x + bx], 1u);
                         else atomicAdd(&tile_count[by * p.tiles_x + bx], 1u);
                     }
+                }
             }
         }
     }
@@ -395,44 +421,49 @@ __global__ __launch_bounds__(256) void k_scatter(Params p, const float4* __restr
     extern __shared__ uint32_t cnt[];       // [T]
     const int T = p.tiles_x * p.tiles_y, G = p.G;
     int i = blockIdx.x * 256 + threadIdx.x;
-    int bx0 = 0, by0 = 0, bx1 = 0, by1 = 0;
     uint64_t key = 0;
-    float gx = 0.f, gy = 0.f, ca = 0.f, cb = 0.f, cc = 0.f, thr = 0.f;
+    BlockSpan sp;
+    sp.by0 = sp.by1 = 0;
     if (i < G) {
-        uint2 rc = rect[i];
-        bx0 = 2 * (int)(rc.x & 0xffff); by0 = 2 * (int)(rc.x >> 16);
-        bx1 = min(2 * (int)(rc.y & 0xffff), p.tiles_x); by1 = min(2 * (int)(rc.y >> 16), p.tiles_y);
+        const uint2 rc = rect[i];
+        const int tx0 = (int)(rc.x & 0xffff), ty0 = (int)(rc.x >> 16), tx1 = (int)(rc.y & 0xffff), ty1 = (int)(rc.y >> 16);
         const float4 a = rec0[i], b = rec1[i];
-        gx = a.x; gy = a.y; ca = b.x; cb = b.y; cc = b.z; thr = cull_threshold(a.w);
         key = ((uint64_t)__float_as_uint(a.z) << 32) | (uint32_t)i;
+        if (tx1 > tx0 && ty1 > ty0) sp = block_span(a.x, a.y, b.x, b.y, b.z, a.w, tx0, ty0, tx1, ty1, p.tiles_x, p.tiles_y);
     }
     if (!use_lds) {
-        for (int by = by0; by < by1; by++)
-            for (int bx = bx0; bx < bx1; bx++) {
-                if (!block_touch(gx, gy, ca, cb, cc, thr, bx, by)) continue;
+        for (int by = sp.by0; by < sp.by1; by++) {
+            int xa, xb;
+            block_row(sp, by, &xa, &xb);
+            for (int bx = xa; bx < xb; bx++) {
                 const int t = by * p.tiles_x + bx;
                 int64_t slot = (int64_t)tile_start[t] + atomicAdd(&tile_cursor[t], 1u);
                 if (slot < cap) keys[slot] = key; else header[H_OVERFLOW] = 1;
             }
+        }
         return;
     }
     for (int t = threadIdx.x; t < T; t += 256) cnt[t] = 0u;
     __syncthreads();
-    for (int by = by0; by < by1; by++)
-        for (int bx = bx0; bx < bx1; bx++)
-            if (block_touch(gx, gy, ca, cb, cc, thr, bx, by)) atomicAdd(&cnt[by * p.tiles_x + bx], 1u);
+    for (int by = sp.by0; by < sp.by1; by++) {
+        int xa, xb;
+        block_row(sp, by, &xa, &xb);
+        for (int bx = xa; bx < xb; bx++) atomicAdd(&cnt[by * p.tiles_x + bx], 1u);
+    }
     __syncthreads();
     for (int t = threadIdx.x; t < T; t += 256) {
         const uint32_t c = cnt[t];
         if (c) cnt[t] = tile_start[t] + atomicAdd(&tile_cursor[t], c);
     }
     __syncthreads();
-    for (int by = by0; by < by1; by++)
-        for (int bx = bx0; bx < bx1; bx++) {
-            if (!block_touch(gx, gy, ca, cb, cc, thr, bx, by)) continue;
+    for (int by = sp.by0; by < sp.by1; by++) {
+        int xa, xb;
+        block_row(sp, by, &xa, &xb);
+        for (int bx = xa; bx < xb; bx++) {
             const int64_t slot = (int64_t)atomicAdd(&cnt[by * p.tiles_x + bx], 1u);
             if (slot < cap) keys[slot] = key; else header[H_OVERFLOW] = 1;
         }
+    }
 }
 
 // Ascending-only bitonic network (mirror step + half-cleaners) so that virtual +inf padding above n is legal.

@@ -3,6 +3,10 @@ import sys
 
 import pytest
 
+# the GPU boxes have hundreds of host cores: hundreds of OpenMP threads on the oracle's small tensors are slower than a dozen
+os.environ.setdefault("OMP_NUM_THREADS", "16")
+os.environ.setdefault("MKL_NUM_THREADS", "16")
+
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 if ROOT not in sys.path:
     sys.path.insert(0, ROOT)

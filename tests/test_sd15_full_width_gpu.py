@@ -28,10 +28,12 @@ def _cos(a, r):
 
 
 def _note(name, **kw):
-    _REPORT[name] = kw
-    os.makedirs(os.path.join(ROOT, "gpurun_out"), exist_ok=True)
-    with open(os.path.join(ROOT, "gpurun_out", "parity_full_width.json"), "w") as f:
-        json.dump(_REPORT, f, indent=1)
+    path = os.path.join(ROOT, "gpurun_out", "parity_full_width.json")
+    os.makedirs(os.path.dirname(path), exist_ok=True)
+    d = json.load(open(path)) if os.path.exists(path) else {}      # merged: xdist workers share the file
+    d[name] = kw
+    with open(path, "w") as f:
+        json.dump(d, f, indent=1)
     print("[parity]", name, kw)
 
 
@@ -130,7 +132,7 @@ def test_full_width_denoiser_and_sds_gradient():
     CPU oracle, and what SDS makes of it: gradients = eps_neg + 50 (eps_text - eps_neg) - noise.  Reports rel-L2 and cosine."""
     from dreamwaltz_g_amd import sd15
     from oracle import sd15 as osd
-    torch.set_num_threads(max(1, os.cpu_count() or 1))
+    torch.set_num_threads(min(64, max(1, os.cpu_count() or 1)))
     ucfg = sd15.UNetConfig()
     usd = sd15.random_state_dict(sd15.unet_param_shapes(ucfg), seed=0)
     csd = sd15.random_state_dict(sd15.controlnet_param_shapes(ucfg), seed=1)
@@ -161,7 +163,7 @@ def test_full_width_vae_encoder_forward_and_input_gradient():
     """AutoencoderKL encoder + quant_conv at 512x512 (34.2 M parameters): moments and d(sum(moments * w)) / d image."""
     from dreamwaltz_g_amd import sd15
     from oracle import sd15 as osd
-    torch.set_num_threads(max(1, os.cpu_count() or 1))
+    torch.set_num_threads(min(64, max(1, os.cpu_count() or 1)))
     vcfg = sd15.VAEConfig()
     sd = sd15.random_state_dict(sd15.vae_encoder_param_shapes(vcfg), seed=2)
     g = torch.Generator().manual_seed(6)
