@@ -102,10 +102,16 @@ static ImageLayout image_layout(int H, int W) {
 // ------------------------------------------------------------------------------------------------
 // device helpers
 // ------------------------------------------------------------------------------------------------
+// ((m0 x + m4 y) + m8 z) + m12 with every product and sum rounded once: the view depth is a SORT KEY, and near-tied depths must
+// order as in the oracle (oracle/raster_oracle.c is built with -ffp-contract=off).  The pragma is what keeps the backend from
+// fusing: HIP's __fmul_rn / __fadd_rn are plain operators and contract like any other.
+__device__ __forceinline__ float dot3p(float a, float b, float c, float d, float x, float y, float z) {
+#pragma clang fp contract(off)
+    return ((a * x + b * y) + c * z) + d;
+}
 __device__ __forceinline__ float3 xform43(const float* m, float3 p) {
-    return make_float3(m[0] * p.x + m[4] * p.y + m[8] * p.z + m[12],
-                       m[1] * p.x + m[5] * p.y + m[9] * p.z + m[13],
-                       m[2] * p.x + m[6] * p.y + m[10] * p.z + m[14]);
+    return make_float3(dot3p(m[0], m[4], m[8], m[12], p.x, p.y, p.z), dot3p(m[1], m[5], m[9], m[13], p.x, p.y, p.z),
+                       dot3p(m[2], m[6], m[10], m[14], p.x, p.y, p.z));
 }
 __device__ __forceinline__ float4 xform44(const float* m, float3 p) {
     return make_float4(m[0] * p.x + m[4] * p.y + m[8] * p.z + m[12],
@@ -904,6 +910,19 @@ static int make_params(const dwg_raster_settings* cfg, int G, Params* p) {
 
 }  // namespace
 
+// Block-private LDS histograms (one global atomic per workgroup and block instead of one per pair) up to 16384 blocks (1024^2);
+// DWG_RASTER_LDS_MAXT lowers the limit (experiment switch).
+static int lds_hist_ok(int T) {
+    static const int lds_max_t = getenv("DWG_RASTER_LDS_MAXT") ? atoi(getenv("DWG_RASTER_LDS_MAXT")) : 16384;
+    static bool attr_set = false;
+    if (!attr_set) {      // 64 KiB of histogram + the static camera words is over the 64 KiB default limit
+        hipFuncSetAttribute(reinterpret_cast<const void*>(&k_preprocess), hipFuncAttributeMaxDynamicSharedMemorySize, 16384 * 4);
+        hipFuncSetAttribute(reinterpret_cast<const void*>(&k_scatter), hipFuncAttributeMaxDynamicSharedMemorySize, 16384 * 4);
+        attr_set = true;
+    }
+    return T <= lds_max_t && T <= 16384;
+}
+
 extern "C" {
 
 int dwg_raster_workspace_sizes(int32_t G, int32_t H, int32_t W, int64_t pair_capacity, size_t* geom_bytes,
@@ -946,7 +965,7 @@ int dwg_raster_forward_bin(const dwg_raster_settings* cfg, int32_t G, const floa
     if (hipMemsetAsync(ws + L.header, 0, 256, stream) != hipSuccess) return DWG_E_LAUNCH;
     if (hipMemsetAsync(ws + L.tile_count, 0, L.tile_start - L.tile_count, stream) != hipSuccess) return DWG_E_LAUNCH;
     if (G > 0) {
-        const int use_lds_hist = T <= 16384;
+        const int use_lds_hist = lds_hist_ok(T);
         DWG_LAUNCH("raster_preprocess", k_preprocess, dim3(dwg_cdiv(G, 256)), dim3(256), use_lds_hist ? (size_t)T * 4 : 0, stream, p,
                    means3D, shs, colors_precomp, opacities, scales, rotations, cov3D_precomp, radii, (float4*)(ws + L.rec0),
                    (float4*)(ws + L.rec1), (float4*)(ws + L.rec2), (uint2*)(ws + L.rect), (uint32_t*)(ws + L.tile_count),
@@ -979,7 +998,7 @@ int dwg_raster_forward_render(const dwg_raster_settings* cfg, int32_t G, void* w
     const uint32_t* cls = (const uint32_t*)(ws + L.cls);
     const int32_t* header = (const int32_t*)(ws + L.header);
     if (G > 0) {
-        const int use_lds = T <= 16384;
+        const int use_lds = lds_hist_ok(T);
         DWG_LAUNCH("raster_scatter", k_scatter, dim3(dwg_cdiv(G, 256)), dim3(256), use_lds ? (size_t)T * 4 : 0, stream, p,
                    (const float4*)(ws + L.rec0), (const float4*)(ws + L.rec1), (const uint2*)(ws + L.rect), tile_start,
                    (uint32_t*)(ws + L.tile_cursor), keys, pair_capacity, (int32_t*)(ws + L.header), use_lds);

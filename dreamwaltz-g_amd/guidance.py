@@ -66,7 +66,7 @@ def C(value, current_step=None, max_iteration=None) -> float:
 class ControlNetScoreDistillation:
     def __init__(self, device, unet_cfg: Optional[sd15.UNetConfig] = None, vae_cfg: Optional[sd15.VAEConfig] = None,
                  unet_sd=None, controlnet_sd=None, vae_sd=None, image_hw=512, guidance_scale=None, min_timestep=None,
-                 max_timestep=None, seed=0, cfg: Optional[GuideConfig] = None):
+                 max_timestep=None, seed=0, cfg: Optional[GuideConfig] = None, text_len=77):
         self.device = torch.device(device)
         self.cfg = cfg if cfg is not None else GuideConfig()
         self.unet_cfg = unet_cfg or sd15.UNetConfig()
@@ -80,7 +80,8 @@ class ControlNetScoreDistillation:
         self.image_hw = image_hw
         down = 2 ** (len(self.vae_cfg.block_out_channels) - 1)
         self.latent_hw = image_hw // down
-        self.denoiser = sd15.DenoiserPlan(self.unet_cfg, unet_sd, controlnet_sd, self.device, batch=2, latent_hw=self.latent_hw)
+        self.denoiser = sd15.DenoiserPlan(self.unet_cfg, unet_sd, controlnet_sd, self.device, batch=2, latent_hw=self.latent_hw,
+                                          text_len=text_len)      # CLIP's 77 tokens; static (the plans are hipGraphs)
         self.vae = sd15.VAEEncoderPlan(self.vae_cfg, vae_sd, self.device, image_hw=image_hw)
         # BasicStableDiffusion.__init__ (basic.py:229-267)
         self.loss_type, self.weight_type = self.cfg.sds_loss_type, self.cfg.sds_weight_type

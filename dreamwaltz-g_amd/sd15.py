@@ -669,7 +669,8 @@ class DenoiserPlan:
         B, hw = batch, latent_hw
         self.latents = p.buf(B, hw, hw, _pad8(cfg.in_channels), zero=True)
         self.text = p.buf(B, text_len, cfg.cross_dim)
-        self.cond = p.buf(1, hw * 8, hw * 8, _pad8(cfg.cond_in_channels), zero=True)
+        self.cond_scale = 2 ** (len(cfg.cond_channels) - 1)      # one stride-2 convolution per embedding level: 8 for SD-1.5
+        self.cond = p.buf(1, hw * self.cond_scale, hw * self.cond_scale, _pad8(cfg.cond_in_channels), zero=True)
         # ---- UNet encoder (does not depend on the ControlNet)
         up_names = []
         rev_attn = list(reversed(cfg.attn_blocks))

@@ -43,7 +43,9 @@ def build_synthetic_avatar(n_gaussians, device, seed=0, learn_hand_betas=False):
         nn = torch.topk(torch.cdist(sub, sub), 3, largest=False).indices          # self + 2 nearest
         a = torch.randint(0, Vp, (Fp,), generator=gen)
         mesh = {"hands": av.MeshBindingGaussianModel(sub, nn[a], vi)}
-    avatar = av.DreamWaltzG(glbs, g["positions"], g["scales"], g["quaternions"], lbs_w, cnl, mesh, learn_hand_betas=learn_hand_betas)
+    with torch.random.fork_rng(devices=[]):      # encoder / MLP initialisation: a function of `seed` only (every rank, every instance)
+        torch.manual_seed(seed + 21)
+        avatar = av.DreamWaltzG(glbs, g["positions"], g["scales"], g["quaternions"], lbs_w, cnl, mesh, learn_hand_betas=learn_hand_betas)
     return avatar.to(device), N, M
 
 

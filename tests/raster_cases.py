@@ -72,7 +72,11 @@ def image_err_stats(hip, ref):
         e = np.abs(a - ref[k])
         out[k] = dict(max=float(e.max()) if e.size else 0.0, q999=float(np.quantile(e, 0.999)) if e.size else 0.0,
                       frac_gt_1e4=float((e > 1e-4).mean()) if e.size else 0.0)
-    out["radii_equal"] = bool(np.array_equal(hip["radii"].cpu().numpy(), ref["radii"]))
+    rh, rr = hip["radii"].cpu().numpy().astype(np.int64), np.asarray(ref["radii"]).astype(np.int64)
+    out["radii_equal"] = bool(np.array_equal(rh, rr))
+    # where they differ: how many, by how much, and whether visibility (radius > 0) itself differs
+    out["radii_diff"] = dict(n=int((rh != rr).sum()), max=int(np.abs(rh - rr).max()) if rh.size else 0,
+                             visibility=int(((rh > 0) != (rr > 0)).sum()))
     return out
 
 

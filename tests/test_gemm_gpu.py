@@ -181,7 +181,8 @@ def test_bf16_conv3x3_small_latents_splitk_paths(C, H, patch_min_m):
     M, K = Bn * H * H, 9 * C
     os.environ["DWG_CONV_PATCH_MINM"] = str(patch_min_m)
     try:
-        d = gemm.gemm_raw(xc, wc, y, M, C, K, (0, 1), (K, 1), C, bias=b.cuda(), residual=r.cuda(), ldr=C,
+        bc, rcu = b.cuda(), r.cuda()      # the descriptor holds raw pointers: these must outlive the launch
+        d = gemm.gemm_raw(xc, wc, y, M, C, K, (0, 1), (K, 1), C, bias=bc, residual=rcu, ldr=C,
                           conv=(C, H, H, H, H, 3, 3, 1, 1, 1, 1), run=False)
         d.splitk = 0
         need = _lib.lib().dwg_gemm_workspace_bytes(ctypes.byref(d))

@@ -146,7 +146,8 @@ def test_guidance_call_matches_the_reference_call_on_reduced_width_networks():
     vsd = sd15.random_state_dict(sd15.vae_encoder_param_shapes(vcfg), seed=2)
     dev = torch.device("cuda")
     hw = int(G["sd.sds.call.image"].shape[-1])
-    gd = guidance.ControlNetScoreDistillation(dev, ucfg, vcfg, usd, csd, vsd, image_hw=hw)
+    text_len = int(G["sd.sds.text.text"].shape[1])
+    gd = guidance.ControlNetScoreDistillation(dev, ucfg, vcfg, usd, csd, vsd, image_hw=hw, text_len=text_len)
     text = {k: T("sd.sds.text." + k).cuda() for k in ("null", "text", "neg")}
     img = T("sd.sds.call.image").cuda().requires_grad_(True)
     res = gd(img, text, train_step=10, max_iteration=100, cond_inputs=T("sd.sds.cond").cuda(), timestep=T("sd.sds.timestep").cuda(),
