@@ -6,7 +6,9 @@ Objects are cached by mtime under csrc/_obj/; the shared library lands next to t
 travels with the repo snapshot to the GPU box (it is git-ignored, not gpurun-ignored).
 """
 import concurrent.futures
+import json
 import os
+import re
 import subprocess
 import sys
 
@@ -39,11 +41,42 @@ def _compile(src, force):
     if (not force and os.path.exists(obj) and os.path.getmtime(obj) >= os.path.getmtime(sp)
             and os.path.getmtime(obj) >= _headers_mtime()):
         return obj, False
-    cmd = [HIPCC] + FLAGS + ["-x", "hip", "-c", sp, "-o", obj]
+    cmd = [HIPCC] + FLAGS + ["-Rpass-analysis=kernel-resource-usage", "-x", "hip", "-c", sp, "-o", obj]
     r = subprocess.run(cmd, capture_output=True, text=True)
     if r.returncode != 0:
         raise RuntimeError("hipcc failed for %s:\n%s\n%s" % (src, r.stdout, r.stderr))
+    _write_resources(src, r.stderr)
     return obj, True
+
+
+_RES = re.compile(r"remark: +(Function Name|VGPRs|AGPRs|ScratchSize \[bytes/lane\]|Occupancy \[waves/SIMD\]|SGPRs Spill|VGPRs Spill|"
+                  r"LDS Size \[bytes/block\]): +(\S+)")
+
+
+def _write_resources(src, remarks):
+    """Per-kernel registers / scratch / occupancy as the compiler reports them -> _obj/<src>.resources.json.  A kernel that
+    silently starts spilling (or whose accumulators get demoted to scratch) shows up here and in tests/test_cabi.py."""
+    kernels, cur = {}, None
+    for line in remarks.splitlines():
+        m = _RES.search(line)
+        if not m:
+            continue
+        k, v = m.group(1), m.group(2)
+        if k == "Function Name":
+            cur = kernels.setdefault(v, {})
+        elif cur is not None:
+            cur[k.split(" [")[0]] = int(v)
+    with open(os.path.join(OBJ, src + ".resources.json"), "w") as f:
+        json.dump(kernels, f, indent=1, sort_keys=True)
+
+
+def resources():
+    """{source: {mangled kernel: {VGPRs, ScratchSize, ...}}} of the last build."""
+    out = {}
+    for f in sorted(os.listdir(OBJ)) if os.path.isdir(OBJ) else []:
+        if f.endswith(".resources.json"):
+            out[f[:-len(".resources.json")]] = json.load(open(os.path.join(OBJ, f)))
+    return out
 
 
 def build(force=False, verbose=True):

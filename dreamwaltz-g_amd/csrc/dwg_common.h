@@ -45,7 +45,7 @@ __device__ __forceinline__ int dwg_lane() { return (int)(threadIdx.x & 63); }
 // rounded to bf16 (relative 4e-3) right after, and the fp32 MLPs of the avatar do not use GELU.
 __device__ __forceinline__ float dwg_erf_fast(float x) {
     const float ax = fabsf(x);
-    const float t = __frcp_rn(fmaf(0.3275911f, ax, 1.f));
+    const float t = __builtin_amdgcn_rcpf(fmaf(0.3275911f, ax, 1.f));      // v_rcp_f32 (HIP's __frcp_rn is an out-of-line call: stack + clobbers)
     float p = fmaf(1.061405429f, t, -1.453152027f);
     p = fmaf(p, t, 1.421413741f); p = fmaf(p, t, -0.284496736f); p = fmaf(p, t, 0.254829592f);
     const float y = 1.f - p * t * __expf(-ax * ax);

@@ -46,12 +46,17 @@ struct GemmP {
 __device__ __forceinline__ float bf2f(__bf16 x) { return (float)x; }
 __device__ __forceinline__ __bf16 f2bf(float x) { return (__bf16)x; }
 
+// LIGHT: only identity / SiLU are compiled in (the LDS-patch convolution's epilogue: the erf of GELU would cost it registers it
+// does not have; the dispatcher sends other activations down the generic kernels)
+template <bool LIGHT = false>
 __device__ __forceinline__ float apply_act(float v, int act) {
+    if constexpr (LIGHT) return act == 3 ? v / (1.f + __expf(-v)) : v;
     switch (act) {
         case 1: return v > 0.f ? v : 0.f;
         case 2: return v > 0.f ? v : 0.01f * v;
         case 3: return v / (1.f + __expf(-v));
-        case 4: return 0.5f * v * (1.f + dwg_erf_fast(v * 0.70710678118654752f));
+        case 4: return 0.5f * v * (1.f + erff(v * 0.70710678118654752f));    // libm erf here: the branch-free dwg_erf_fast in this switch makes
+                                                                              // LLVM unswitch the epilogue loops and demote the accumulators to scratch
         case 5: return 1.f / (1.f + __expf(-v));
         default: return v;
     }
@@ -224,11 +229,12 @@ __device__ __forceinline__ void mma_tile<float>(const float* sa, const float* sb
         acc = __builtin_amdgcn_mfma_f32_32x32x2f32(pa[ks * 2], pb[ks * 2], acc, 0, 0, 0);
 }
 
+template <bool LIGHT = false>
 __device__ __forceinline__ void epilogue_store(const GemmP& p, float v, int row, int col, long long coff, long long roff) {
     const long long ci = coff + (long long)row * p.ldc + col;
     if (p.bias) v += reinterpret_cast<const float*>(p.bias)[p.bias_row_div > 0 ? (long long)(row / p.bias_row_div) * p.bias_ld + col
                                                                              : (p.bias_per_row ? row : col)];
-    v = apply_act(v, p.act);
+    v = apply_act<LIGHT>(v, p.act);
     if (p.residual) {
         const long long ri = roff + (long long)row * p.ldr + col;
         v += p.res_bf16 ? bf2f(reinterpret_cast<const __bf16*>(p.residual)[ri]) : reinterpret_cast<const float*>(p.residual)[ri];
@@ -254,11 +260,12 @@ __device__ __forceinline__ bool epilogue_vec_ok(const GemmP& p, long long coff, 
 }
 
 // four consecutive columns col..col+3 of one row
+template <bool LIGHT = false>
 __device__ __forceinline__ void epilogue_store4(const GemmP& p, float (&v)[4], int row, int col, long long coff, long long roff, bool vec_ok) {
     if (!vec_ok || col + 3 >= p.N) {
 #pragma unroll
         for (int e = 0; e < 4; e++)
-            if (col + e < p.N) epilogue_store(p, v[e], row, col + e, coff, roff);
+            if (col + e < p.N) epilogue_store<LIGHT>(p, v[e], row, col + e, coff, roff);
         return;
     }
     if (p.bias) {
@@ -274,7 +281,7 @@ __device__ __forceinline__ void epilogue_store4(const GemmP& p, float (&v)[4], i
         }
     }
 #pragma unroll
-    for (int e = 0; e < 4; e++) v[e] = apply_act(v[e], p.act);
+    for (int e = 0; e < 4; e++) v[e] = apply_act<LIGHT>(v[e], p.act);
     if (p.residual) {
         const long long ri = roff + (long long)row * p.ldr + col;
         if (p.res_bf16) {
@@ -768,7 +775,7 @@ static void launch_glds(const GemmP& p, int batch, hipStream_t stream, const cha
 // halo / out-of-image pixels from the zero page) and forms all nine taps from it; only the weight slab streams per tap.
 // L2->LDS bytes per flop drop by ~40 % (A: 16 KiB/tap -> 23 KiB/9 taps).
 // ---------------------------------------------------------------------------------------------------------------------
-template <int BN>
+template <int BN, bool SPLIT>      // SPLIT: split-K over 64-channel slabs (its own instantiation: the plain one keeps its register budget)
 __global__ __launch_bounds__(256, 2) void k_conv3x3_patch(GemmP p) {   // 2 waves per SIMD: LDS allows 2 workgroups per CU anyway
     constexpr int PH = 8, PW = 16, HP = PH + 2, WP = PW + 2, NPIX = HP * WP;     // 180 patch pixels, 128 B each
     constexpr int NPI = (NPIX + 7) / 8;                                          // 23 wave-instructions per patch
@@ -788,8 +795,8 @@ __global__ __launch_bounds__(256, 2) void k_conv3x3_patch(GemmP p) {   // 2 wave
         const int nwg = gridDim.x, q = nwg / 8, r = nwg % 8, xcd = id % 8, loc = id / 8;
         id = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + loc;
     }
-    const int ks_id = id / (gm * ntn);                    // split-K slice: a contiguous range of 64-channel slabs
-    id -= ks_id * gm * ntn;
+    int ks_id = 0;                                        // split-K slice: a contiguous range of 64-channel slabs
+    if constexpr (SPLIT) { ks_id = id / (gm * ntn); id -= ks_id * gm * ntn; }
     const int mt = id / ntn, n0 = (id % ntn) * BN;
     const int img = mt / (tiles_y * tiles_x), trem = mt % (tiles_y * tiles_x);
     const int y0 = (trem / tiles_x) * PH, x0 = (trem % tiles_x) * PW;
@@ -849,12 +856,17 @@ __global__ __launch_bounds__(256, 2) void k_conv3x3_patch(GemmP p) {   // 2 wave
         pbase[i] = (r >> 4) * WP + (r & 15);
     }
     int cc0 = 0, ncc = cv.Cin / 64;
-    if (p.splitk > 1) {
+    if constexpr (SPLIT) {
         const int per = (ncc + p.splitk - 1) / p.splitk;
         cc0 = ks_id * per; ncc = min(ncc, cc0 + per);
     }
     const int frow = lane & 31, fx = (lane >> 1) & 7, fh = lane >> 5;
-    if (cc0 < ncc) { issue_patch(cc0, sP + (cc0 & 1) * PBYTES); issue_w(cc0, 0, sB + ((cc0 & 1) ? BBYTES : 0)); }
+    if constexpr (SPLIT) {
+        if (cc0 < ncc) { issue_patch(cc0, sP + (cc0 & 1) * PBYTES); issue_w(cc0, 0, sB + ((cc0 & 1) ? BBYTES : 0)); }
+    } else {
+        issue_patch(0, sP);
+        issue_w(0, 0, sB);
+    }
     // 9 taps unrolled: the tap's patch offset is an immediate and there is no step -> (slab, tap) division in the loop
     for (int cc = cc0; cc < ncc; cc++) {
         const unsigned char* pa = sP + (cc & 1) * PBYTES;
@@ -902,7 +914,7 @@ __global__ __launch_bounds__(256, 2) void k_conv3x3_patch(GemmP p) {   // 2 wave
                 float v[4];
 #pragma unroll
                 for (int e = 0; e < 4; e++) v[e] = acc[i][j][4 * r4 + e] * p.alpha;
-                if (p.splitk > 1) {                          // fp32 slab, reduced in slice order by k_splitk_epilogue
+                if constexpr (SPLIT) {                       // fp32 slab, reduced in slice order by k_splitk_epilogue
                     float* dst = p.ws + ((long long)ks_id * p.M + m) * p.N + col;
                     if ((p.N & 3) == 0) *reinterpret_cast<float4*>(dst) = make_float4(v[0], v[1], v[2], v[3]);
                     else {
@@ -911,7 +923,7 @@ __global__ __launch_bounds__(256, 2) void k_conv3x3_patch(GemmP p) {   // 2 wave
                     }
                     continue;
                 }
-                epilogue_store4(p, v, m, col, 0, 0, vec_ok);
+                epilogue_store4<true>(p, v, m, col, 0, 0, vec_ok);
             }
     }
 }
@@ -926,11 +938,16 @@ static void launch_conv3x3_patch(const GemmP& p, hipStream_t stream, const char*
     dim3 grid(gm * ((p.N + BN - 1) / BN) * (p.splitk > 1 ? p.splitk : 1));
     static bool attr_set = false;
     if (!attr_set) {
-        hipFuncSetAttribute(reinterpret_cast<const void*>(&k_conv3x3_patch<BN>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        hipFuncSetAttribute(reinterpret_cast<const void*>(&k_conv3x3_patch<BN, false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        hipFuncSetAttribute(reinterpret_cast<const void*>(&k_conv3x3_patch<BN, true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         attr_set = true;
     }
-    DWG_LAUNCH_W(name, (BN == 64 ? "k_conv3x3_patch<64>" : "k_conv3x3_patch<128>"), gemm_flops(p, 1), (k_conv3x3_patch<BN>), grid,
-                 dim3(256), lds, stream, p);
+    if (p.splitk > 1 && p.ws)
+        DWG_LAUNCH_W(name, (BN == 64 ? "k_conv3x3_patch<64, split>" : "k_conv3x3_patch<128, split>"), gemm_flops(p, 1),
+                     (k_conv3x3_patch<BN, true>), grid, dim3(256), lds, stream, p);
+    else
+        DWG_LAUNCH_W(name, (BN == 64 ? "k_conv3x3_patch<64>" : "k_conv3x3_patch<128>"), gemm_flops(p, 1), (k_conv3x3_patch<BN, false>), grid,
+                     dim3(256), lds, stream, p);
     if (p.splitk > 1 && p.ws) {
         long long n = (long long)p.M * p.N;
         if ((p.N & 3) == 0) n >>= 2;
@@ -1086,7 +1103,8 @@ int dwg_gemm(const dwg_gemm_desc* d, dwg_stream_t stream_) {
         bool patch_ok = glds_ok && amode == MODE_CONV && batch == 1 && d->conv_kh == 3 && d->conv_kw == 3 &&
                         d->conv_stride == 1 && p.conv.dil == 1 && p.conv.up == 1 && d->conv_pad_t == 1 && d->conv_pad_l == 1 &&
                         !d->A2 && d->conv_cin % 64 == 0 && d->conv_hout == d->conv_hin && d->conv_wout == d->conv_win &&
-                        d->conv_wout >= 16 && d->conv_hout >= 8 && d->M >= patch_min_m && getenv("DWG_CONV_NO_PATCH") == nullptr;
+                        d->conv_wout >= 16 && d->conv_hout >= 8 && d->M >= patch_min_m && (d->act == 0 || d->act == 3 || p.splitk > 1) &&
+                        getenv("DWG_CONV_NO_PATCH") == nullptr;
         if (patch_ok && p.splitk > 1) {
             // re-derive the slice count for this kernel's tiling: (8x16 pixel tiles) x (N / BN) workgroups, >= 2 slabs per slice
             const int gm = (d->M / (d->conv_hout * d->conv_wout)) * ((d->conv_hout + 7) / 8) * ((d->conv_wout + 15) / 16);

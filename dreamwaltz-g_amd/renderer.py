@@ -65,6 +65,9 @@ class GaussianRenderer:
     def pair_state(self, device, H, W) -> Optional[PairCapacity]:
         if not self.async_pair_count:
             return None
+        device = torch.device(device)
+        if device.type == "cuda" and device.index is None:          # "cuda" and "cuda:<current>" are one device, one state
+            device = torch.device("cuda", torch.cuda.current_device())
         key = (str(device), int(H), int(W))
         if key not in self._pair_states:
             self._pair_states[key] = PairCapacity()

@@ -116,9 +116,10 @@ def test_c5_lbs_plus_raster_300k_1024_forward_and_properties():
     lhs = imgs[2] - bgterm
     rhs = 0.3 * (imgs[0] - bgterm) + 0.6 * (imgs[1] - bgterm)
     assert float((lhs - rhs).abs().max()) < 2e-5
-    # permutation invariance: the Gaussian order is not part of the result (depth ties aside: none in this scene)
+    # permutation invariance: the Gaussian order is not part of the result, exact depth ties aside (the id breaks them; 300 000
+    # fp32 depths in one binade hold a few thousand tied pairs, of which the overlapping ones move a pixel by ~1e-5)
     perm = torch.randperm(G, generator=g)
     s3 = {k: (v[perm] if torch.is_tensor(v) and v.shape[:1] == (G,) else v) for k, v in sc_h.items()}
     out_p = rc.hip_render(s3)
-    assert float((out_p["color"] - out["color"]).abs().max()) < 1e-5
+    assert float((out_p["color"] - out["color"]).abs().max()) < 1e-4
     assert torch.equal(out_p["radii"].cpu(), out["radii"].cpu()[perm])

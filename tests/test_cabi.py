@@ -37,3 +37,24 @@ def test_workspace_sizes_host_only():
     assert p.value >= 5000 * 12
     assert i.value >= 512 * 512 * 8
     assert L.dwg_raster_workspace_sizes(-1, 512, 512, 0, None, None, None) != 0
+
+
+def test_no_kernel_spills_beyond_the_known_ones():
+    """The compiler's per-kernel resource report of the last build (csrc/_obj/*.resources.json, written by build.py): no kernel
+    uses scratch memory except the three listed with their bounds.  (Round 2 lost 7 ms per step to an epilogue change that
+    silently demoted the GEMM accumulators to scratch; this is the tripwire.)"""
+    from dreamwaltz_g_amd import build
+    build.build(verbose=False)
+    res = build.resources()
+    assert sum(len(v) for v in res.values()) >= 100, "resource report missing: run python dreamwaltz-g_amd/build.py --force"
+    allowed = {"k_conv3x3_patchILi128ELb0": 64, "k_conv3x3_patchILi128ELb1": 64, "k_meshbind_bwd": 128}
+    bad = []
+    for src, kernels in res.items():
+        for name, r in kernels.items():
+            scratch = r.get("ScratchSize", 0)
+            if scratch == 0:
+                continue
+            lim = [v for k, v in allowed.items() if k in name]
+            if not lim or scratch > lim[0]:
+                bad.append((src, name, scratch))
+    assert not bad, bad
