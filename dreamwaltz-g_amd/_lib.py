@@ -85,6 +85,11 @@ SIGNATURES = {
     "dwg_meshbind_backward": (ctypes.c_int, [_i32, _i32, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
     "dwg_meshbind_backward_verts": (ctypes.c_int, [_i32, _i32] + [_vp] * 15 + [_vp]),
     "dwg_mesh_vertex_normals_backward": (ctypes.c_int, [_i32, _i32] + [_vp] * 8 + [_vp]),
+    # include/dwg_condition.h
+    "dwg_condition_keypoints": (ctypes.c_int, [_i32, _vp, _vp, _vp, _i32, _vp, _i32, _vp, _vp, ctypes.c_float, ctypes.c_float,
+                                               ctypes.c_float, _i32, _vp, _vp]),
+    "dwg_condition_workspace_bytes": (_sz, [_i32, _i32]),
+    "dwg_condition_draw": (ctypes.c_int, [_i32, _i32, _vp, _i32, _vp, _vp, _vp, _vp]),
     # include/dwg_graph.h
     "dwg_graph_begin_capture": (ctypes.c_int, [_vp]),
     "dwg_graph_end_capture": (ctypes.c_int, [_vp, ctypes.POINTER(_vp)]),

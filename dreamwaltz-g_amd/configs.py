@@ -98,6 +98,14 @@ class PromptConfig:
     angle_front: float = 90.0
     angle_overhead: float = 60.0
     scene: str = 'canonical'
+    # condition image (configs/__init__.py:414,441-446)
+    smpl_type: str = 'smplx'
+    use_occlusion_culling: bool = True
+    draw_body_keypoints: bool = True
+    draw_hand_keypoints: bool = True
+    draw_face_landmarks: bool = False
+    ignore_body_self_occlusion: bool = True
+    openpose_left_right_flip: bool = False
 
 
 @dataclass

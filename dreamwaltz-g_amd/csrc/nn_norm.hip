@@ -307,6 +307,10 @@ static int gn_geometry(int HW, int C, int G, int* pix_per_block, int* chunks, si
 #define GN_FOLD_MAX_CHUNKS 32      // up to this many partials per output the apply pass sums them itself (no finalize launch)
 static void gn_reduce_geometry(int HW, int C, int* pix_per_block, int* chunks) {
     long long ppb = 16384 / C; if (ppb < 8) ppb = 8;
+    // small images (the denoiser's <= 64x64 levels): at most DWG_GN_SMALL_CHUNKS partials per image, so that the apply pass can sum
+    // them itself and the finalize launch disappears (these layers are launch-latency-bound, not bandwidth-bound)
+    static const int small_chunks = getenv("DWG_GN_SMALL_CHUNKS") ? atoi(getenv("DWG_GN_SMALL_CHUNKS")) : 0;
+    if (small_chunks > 0 && HW <= 4096 && ppb * small_chunks < HW) ppb = (HW + small_chunks - 1) / small_chunks;
     int ch = (int)((HW + ppb - 1) / ppb);
     if (ch > GN_MAX_CHUNKS) { ch = GN_MAX_CHUNKS; ppb = (HW + ch - 1) / ch; ch = (int)((HW + ppb - 1) / ppb); }
     *pix_per_block = (int)ppb; *chunks = ch;
