@@ -67,7 +67,7 @@ def test_image_from_the_reference_rows_is_bit_exact(name, flags):
     assert u8.shape == (H, W, 3) and u8.dtype == torch.uint8
     assert (ref.sum(2) > 0).mean() > 0.01
     assert np.array_equal(u8.cpu().numpy(), ref)
-    assert torch.equal(chw[0], u8.permute(2, 0, 1).float() / 255.0)
+    assert (chw[0] - u8.permute(2, 0, 1).float() / 255.0).abs().max() < 1e-7          # the same bytes / 255 (torch multiplies by 1/255)
 
 
 def test_export_pose_and_call_mirror_end_to_end():
@@ -83,7 +83,7 @@ def test_export_pose_and_call_mirror_end_to_end():
     assert out.to_pil().size == (W, H) and out.to_chw().shape == (1, 3, H, W)
     chw = c.export_pose_chw(torch.from_numpy(kp).cuda(), cd.build_ray_casting_scene(torch.from_numpy(v).cuda(), t),
                             extrinsic=torch.from_numpy(E).cuda(), intrinsics=torch.from_numpy(K).cuda(), width=W, height=H)
-    assert torch.equal(chw, out.to_chw())
+    assert (chw - out.to_chw()).abs().max() < 1e-7
     with pytest.raises(NotImplementedError):
         c(types.SimpleNamespace(vertices=None, joints=None), t, {}, "depth", H, W)
     with pytest.raises(RuntimeError):
