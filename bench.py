@@ -41,6 +41,7 @@ def parse():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-guidance", action="store_true", help="raster+LBS sub-path only (not the headline workload)")
     ap.add_argument("--eager", action="store_true", help="launch every kernel eagerly (no hipGraph replay of the denoiser/VAE plans)")
+    ap.add_argument("--no-gpu-condition", action="store_true", help="fixed condition image instead of the per-step GPU OpenPose image of the posed body")
     ap.add_argument("--sync-pairs", action="store_true", help="exact pair-buffer sizing through a 16-byte read-back per frame")
     return ap.parse_args()
 
@@ -207,7 +208,7 @@ def main():
     G = args.gaussians or (50000 if args.config == "c2" else 100000)
     res = args.res or 512
     step = sds_step.SDSStep(n_gaussians=G, res=res, device=dev, rank=rank, world=world, guidance=guidance, dist=dist,
-                            async_pair_count=not args.sync_pairs)
+                            async_pair_count=not args.sync_pairs, gpu_condition=not args.no_gpu_condition)
     if not args.eager:
         step.capture_graphs()       # denoiser / VAE plans replay as hipGraphs (identical kernels, one launch each)
     for _ in range(args.warmup):

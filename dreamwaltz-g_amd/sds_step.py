@@ -12,6 +12,7 @@ seeds for pose / noise), one flat fp32 all-reduce per step, identical Adam updat
 import torch
 
 from . import avatar as av, camera, configs, guidance as gd, scene as sc, synth, trainer as tr
+from .condition import build_ray_casting_scene as cd_build
 from .optim import get_expon_lr_func  # noqa: F401  (re-exported: tests pin it against the reference's function)
 
 
@@ -51,7 +52,7 @@ def build_synthetic_avatar(n_gaussians, device, seed=0, learn_hand_betas=False):
 
 class SDSStep:
     def __init__(self, n_gaussians=100000, res=512, device="cuda", rank=0, world=1, guidance=True, dist=None, seed=0, cfg=None,
-                 avatar=None, guidance_obj=None, async_pair_count=True, iters=10000):
+                 avatar=None, guidance_obj=None, async_pair_count=True, iters=10000, gpu_condition=True):
         self.device, self.rank, self.world, self.dist, self.res = torch.device(device), rank, world, dist, res
         self.cfg = cfg if cfg is not None else configs.TrainConfig()
         self.cfg.device = str(self.device)
@@ -78,6 +79,7 @@ class SDSStep:
             self.text = {"neg": torch.randn(1, 77, cd, generator=tg).to(self.device), "pos": torch.randn(1, 77, cd, generator=tg).to(self.device),
                          "viewed": [torch.randn(1, 77, cd, generator=tg).to(self.device) for _ in range(14)]}
             self.data["cond_images"] = (torch.randint(0, 256, (1, 3, hw, hw), generator=tg).float() / 255.0).to(self.device)
+            self.condition = self._build_condition(hw, seed) if gpu_condition else None
             diffusion = self.guidance
         else:
             self.text = {}
@@ -105,8 +107,43 @@ class SDSStep:
         if self.guidance is not None:
             self.guidance.set_use_graphs(on)
 
+    # -- the data layer's per-step condition image (smpl_condition.py:271-320), on the GPU -----------------------------------
+    def _build_condition(self, hw, seed):
+        """The reference's loader runs a full SMPL-X forward and draws the OpenPose skeleton of its 128 keypoints with occlusion
+        culling against the 20 908-triangle body every step.  Synthetic stand-ins for the licensed model's topology: triangles
+        between neighbours of a spatial ordering of the template vertices, keypoints = the 55 posed joints + 73 posed vertices."""
+        from . import condition as cd
+        lbs = self.avatar.lbs_model
+        V = int(lbs.v_template.shape[0])
+        g = torch.Generator().manual_seed(seed + 31)
+        order = torch.argsort(lbs.v_template[:, 1].cpu() * 7.0 + lbs.v_template[:, 0].cpu())
+        k = torch.randint(0, V - 2, (20908,), generator=g)
+        tri = torch.stack([order[k], order[k + 1], order[k + 2]], dim=1).to(torch.int32).to(self.device)
+        pick = torch.randint(0, V, (cd.N_KEYPOINTS - 55,), generator=g).to(self.device)
+        f = hw / (2.0 * float(self.data["tanfov"][0]))
+        intr = torch.tensor([[f, 0.0, hw / 2.0], [0.0, f, hw / 2.0], [0.0, 0.0, 1.0]], device=self.device)
+        return dict(gen=cd.SMPL2Condition(self.cfg.prompt), triangles=tri, pick=pick, intrinsics=intr, hw=hw,
+                    all_vertices=torch.arange(V, device=self.device, dtype=torch.int32))
+
+    def condition_image(self, smpl_inputs):
+        """[1,3,H,W] in [0,1]: posed body (one skeleton pass + all 10 475 vertices) -> keypoints -> culling -> OpenPose drawing."""
+        c = self.condition
+        lbs = self.avatar.lbs_model
+        with torch.no_grad():
+            _, _, tr = lbs(**smpl_inputs)
+            verts = lbs.transform_vertices(tr, c["all_vertices"], lbs.v_template)
+            A = tr.A
+            J = lbs._joints(tr)
+            joints = torch.einsum('jkl,jl->jk', A[:, :3, :3], J) + A[:, :3, 3]        # A carries the global translation
+            keypoints = torch.cat([joints, verts[c["pick"]]], dim=0)
+            scene = cd_build(verts, c["triangles"])
+            return c["gen"].export_pose_chw(keypoints, scene, extrinsic=self.data["extrinsic"][0], intrinsics=c["intrinsics"],
+                                            width=c["hw"], height=c["hw"])
+
     def run(self, **forced):
         self.data["smpl_inputs"] = synth.random_smpl_inputs(seed=1000 * self.rank + self.step_idx, device=self.device)
+        if getattr(self, "condition", None) is not None:
+            self.data["cond_images"] = self.condition_image(self.data["smpl_inputs"])
         out = self.trainer.train_step(self.data, **forced)
         self.step_idx += 1
         return out
@@ -119,7 +156,9 @@ class SDSStep:
 
     # -- reporting -----------------------------------------------------------------------------------------------
     def describe(self):
-        wl = ("full SDS step: animate(LBS+grid-encoder+MLPs, %d unconstrained + %d mesh-bound Gaussians) -> raster %dx%d fwd+bwd "
+        wl = ("full SDS step: " + ("OpenPose condition image of the posed body (skeleton pass over all vertices, 128 keypoints, culling "
+                                   "against 20908 triangles, drawing) -> " if getattr(self, "condition", None) is not None else "") +
+              "animate(LBS+grid-encoder+MLPs, %d unconstrained + %d mesh-bound Gaussians) -> raster %dx%d fwd+bwd "
               "-> VAE-encode fwd+dgrad -> ControlNet+UNet SD-1.5 CFG batch 2 @64x64 latents -> Adam" % (self.N, self.M, self.res, self.res)
               ) if self.guidance is not None else (
             "sub-path only (NOT the headline workload): animate + raster %dx%d fwd+bwd + Adam, no diffusion" % (self.res, self.res))

@@ -118,7 +118,7 @@ def test_step_with_reduced_width_guidance_matches_oracle_chain():
     vsd = sd15.random_state_dict(sd15.vae_encoder_param_shapes(vcfg), seed=3)
     gd = guidance.ControlNetScoreDistillation(dev, ucfg, vcfg, usd, csd, vsd, image_hw=res)
     a, params, nets, body, _, cnl, mesh = _avatar_pair(with_mesh=True)
-    step = sds_step.SDSStep(res=res, guidance=True, avatar=a, guidance_obj=gd, async_pair_count=False)
+    step = sds_step.SDSStep(res=res, guidance=True, avatar=a, guidance_obj=gd, async_pair_count=False, gpu_condition=False)
     obs = synth.random_smpl_inputs(seed=0)
     g = torch.Generator().manual_seed(3)
     noise = torch.randn(1, 4, res // 8, res // 8, generator=g); vnoise = torch.randn(1, 4, res // 8, res // 8, generator=g)
@@ -142,6 +142,42 @@ def test_step_with_reduced_width_guidance_matches_oracle_chain():
     _note("step_reduced_width_guidance", **rep)
     assert rep["_positions_cos"] > 0.9 and rep["_positions_rel"] < 0.5, rep
     assert rep["table_cos"] > 0.9, rep
+
+
+def test_step_draws_its_condition_image_on_the_gpu():
+    """SDSStep(gpu_condition=True): the per-step OpenPose image of the posed body (full-vertex skeleton pass, 128 keypoints, culling
+    against 20 908 triangles, drawing) equals the oracle's export_pose of the same posed geometry, changes with the pose, and is
+    what the guidance consumes."""
+    from dreamwaltz_g_amd import guidance, sd15, sds_step, synth
+    from oracle import condition as oc
+    res = 128
+    dev = torch.device("cuda")
+    ucfg = sd15.UNetConfig(block_out_channels=(64, 128, 128, 128), cross_dim=64, cond_channels=(16, 32, 32, 64))
+    vcfg = sd15.VAEConfig(block_out_channels=(32, 64, 64, 64))
+    gd = guidance.ControlNetScoreDistillation(dev, ucfg, vcfg, image_hw=res)
+    step = sds_step.SDSStep(n_gaussians=3000, res=res, guidance=True, guidance_obj=gd, async_pair_count=False)
+    assert step.condition is not None and step.condition["triangles"].shape == (20908, 3)
+    pose = synth.random_smpl_inputs(seed=5, device=dev)
+    img = step.condition_image(pose)
+    assert img.shape == (1, 3, res, res) and float(img.max()) <= 1.0 and float((img.sum(1) > 0).float().mean()) > 0.005
+    # the same posed geometry through the oracle
+    lbs = step.avatar.lbs_model
+    with torch.no_grad():
+        _, _, trf = lbs(**pose)
+        verts = lbs.transform_vertices(trf, step.condition["all_vertices"], lbs.v_template)
+        J = lbs._joints(trf)
+        joints = torch.einsum('jkl,jl->jk', trf.A[:, :3, :3], J) + trf.A[:, :3, 3]
+        kp = torch.cat([joints, verts[step.condition["pick"]]], 0)
+    cfgp = step.cfg.prompt
+    rows = oc.pose_keypoints(kp.cpu().numpy(), verts.cpu().numpy(), step.condition["triangles"].cpu().numpy(), step.data["extrinsic"][0].cpu().numpy(),
+                             step.condition["intrinsics"].cpu().numpy(), res, res, ignore_body_self_occlusion=cfgp.ignore_body_self_occlusion)
+    ref = oc.draw_poses(rows, res, res, draw_face=cfgp.draw_face_landmarks)
+    got = (img[0].permute(1, 2, 0) * 255.0).round().to(torch.uint8).cpu().numpy()
+    assert (got == ref).all(2).mean() >= 0.999
+    step.run(); c0 = step.data["cond_images"].clone()
+    step.run(); c1 = step.data["cond_images"]
+    assert c0.shape == (1, 3, res, res) and not torch.equal(c0, c1)
+    assert torch.isfinite(step.optimizers.buffers.flat).all()
 
 
 def test_c3_size_sync_vs_async_pair_sizing_and_overflow_recovery():
