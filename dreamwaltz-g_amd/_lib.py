@@ -113,6 +113,10 @@ def lib():
             raise RuntimeError(
                 "libdwg_hip.so not found at %s -- run `python dreamwaltz-g_amd/build.py` "
                 "(there is no CPU fallback for the product path)" % LIB_PATH)
+        # torch first: its wheel bundles its own libamdhip64 / libhsa-runtime64, and libdwg_hip.so (linked against /opt/rocm's
+        # libamdhip64.so.7) must bind to THAT already-loaded runtime -- loaded the other way round the process ends up with two HIP
+        # runtimes and every launch on a torch stream fails with DWG_E_LAUNCH.
+        import torch  # noqa: F401
         l = ctypes.CDLL(LIB_PATH)
         for name, (res, args) in SIGNATURES.items():
             fn = getattr(l, name)
