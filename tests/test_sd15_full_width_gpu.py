@@ -3,8 +3,10 @@ same seeded random weights: single blocks at the production shapes (every attent
 convolutions, the Cin % 64 fast loader at 320 / 640 / 1280 channels, the production split-K choices), then the whole
 ControlNet + UNet CFG pass and the whole VAE encoder (forward + input gradient) at 64x64 latents / 512x512 pixels.
 
-Stated tolerances (bf16 storage with fp32 accumulation vs the fp32 oracle; the measured values of the last GPU run are in
-DESIGN.md section 2 and gpurun_out/parity_full_width.json; each bound below is about 2x its measured value):"""
+Stated tolerances (bf16 storage with fp32 accumulation vs the fp32 oracle), each about 2x the value measured on an MI355X
+(profiles/r02_parity_full_width.json): ResNet blocks rel-L2 0.29-0.36 %, transformer blocks 0.49-0.50 %,
+VAE down block 0.32 / 0.39 %, whole denoiser eps 1.5 % and the CFG-50 SDS gradient 4.2 % (cosine 0.9991), whole VAE encoder moments
+1.2 % and its image gradient 1.6 % (cosine 0.99987)."""
 import json
 import os
 
@@ -49,7 +51,7 @@ def _block_plan(sd):
     return plan, w, sd15.Builder(plan, w, 32, "t")
 
 
-@pytest.mark.parametrize("cin,cout,hw,bound", [(1280, 1280, 8, 2e-2), (320, 320, 64, 2e-2), (640, 320, 64, 2e-2), (2560, 1280, 16, 2e-2)])
+@pytest.mark.parametrize("cin,cout,hw,bound", [(1280, 1280, 8, 7e-3), (320, 320, 64, 7e-3), (640, 320, 64, 8e-3), (2560, 1280, 16, 8e-3)])
 def test_resnet_block_at_sd15_width(cin, cout, hw, bound):
     """One UNet ResnetBlock2D (GroupNorm+SiLU -> conv3x3 + time-embedding bias -> GroupNorm+SiLU -> conv3x3 + skip, 1x1 shortcut
     when cin != cout) at batch 2."""
@@ -75,7 +77,7 @@ def test_resnet_block_at_sd15_width(cin, cout, hw, bound):
     assert e < bound, e
 
 
-@pytest.mark.parametrize("c,hw,bound", [(320, 64, 2e-2), (640, 32, 2e-2), (1280, 16, 2e-2), (1280, 8, 2e-2)])
+@pytest.mark.parametrize("c,hw,bound", [(320, 64, 1e-2), (640, 32, 1e-2), (1280, 16, 1e-2), (1280, 8, 1e-2)])
 def test_transformer_block_at_sd15_width(c, hw, bound):
     """One Transformer2DModel block (GroupNorm, proj_in, self-attention, cross-attention over 77 text tokens, GEGLU feed-forward,
     proj_out + skip) with 8 heads: head sizes 40 (padded tile path), 80, 160."""
@@ -123,7 +125,7 @@ def test_vae_down_block_at_sd15_width():
     e1 = _rel(y.float().permute(0, 3, 1, 2), r)
     e2 = _rel(z.float().permute(0, 3, 1, 2), ref)
     _note("vae_down_block_r512", rel_l2_resnet=e1, rel_l2_downsample=e2)
-    assert e1 < 2e-2 and e2 < 2e-2, (e1, e2)
+    assert e1 < 7e-3 and e2 < 8e-3, (e1, e2)
 
 
 @pytest.mark.slow
@@ -154,8 +156,8 @@ def test_full_width_denoiser_and_sds_gradient():
     e_g, c_g = _rel(g_got, g_ref), _cos(g_got, g_ref)
     _note("denoiser_full_width", rel_l2_eps=e, rel_l2_cfg_difference=e_d, rel_l2_sds_gradients=e_g, cosine_sds_gradients=c_g,
           cfg_difference_over_eps=float(d_ref.norm() / ref[0].norm()))
-    assert e < 2e-2, e
-    assert e_g < 0.3 and c_g > 0.95, (e_g, c_g)
+    assert e < 3e-2, e
+    assert e_g < 0.09 and c_g > 0.998, (e_g, c_g)
 
 
 @pytest.mark.slow
@@ -177,5 +179,5 @@ def test_full_width_vae_encoder_forward_and_input_gradient():
     gimg = plan.backward(gm.cuda()).float().cpu()
     e_f, e_b, c_b = _rel(got, ref), _rel(gimg, gref), _cos(gimg, gref)
     _note("vae_encoder_full_width", rel_l2_moments=e_f, rel_l2_image_grad=e_b, cosine_image_grad=c_b)
-    assert e_f < 3e-2, e_f
-    assert e_b < 1e-1 and c_b > 0.99, (e_b, c_b)
+    assert e_f < 2.5e-2, e_f
+    assert e_b < 3.5e-2 and c_b > 0.9995, (e_b, c_b)
