@@ -165,8 +165,15 @@ class GeneralLinearBlendSkinning(nn.Module):
     def forward(self, betas=None, body_pose=None, global_orient=None, left_hand_pose=None, right_hand_pose=None,
                 jaw_pose=None, leye_pose=None, reye_pose=None, expression=None, transl=None, flame_betas=None,
                 flame_expression=None, extra_betas=None):
-        """-> (transform_J, transform_V, transforms), inverse_lbs.py:719-784.  One launch (k_joint_chain); the dense per-vertex
-        transforms are built only if read."""
+        """-> (transform_J, transform_V, transforms), inverse_lbs.py:719-784.  Two small launches (shaped joints, chain); the dense
+        per-vertex transforms are built only if read.  The skeleton pass of the SAME input tensors (same objects, unmodified) is shared:
+        the loader's condition image and `animate` both ask for the observed pose in one step."""
+        args = (betas, body_pose, global_orient, left_hand_pose, right_hand_pose, jaw_pose, leye_pose, reye_pose, expression, transl,
+                flame_betas, flame_expression)
+        key = tuple((id(a), a._version) if torch.is_tensor(a) else a for a in args)
+        last = getattr(self, "_last_forward", None)
+        if extra_betas is None and last is not None and last[0] == key:
+            return last[2]
         full_shape = self.get_full_shape(betas=betas, expression=expression, extra_betas=extra_betas)
         with torch.no_grad():
             full_pose = self.get_full_pose(body_pose, global_orient, left_hand_pose, right_hand_pose, jaw_pose, leye_pose, reye_pose)
@@ -175,6 +182,8 @@ class GeneralLinearBlendSkinning(nn.Module):
         tr = LBSTransforms(self, A, R, full_shape, transl, full_pose)
         transform_V = _VertexTransform(self, tr, lambda: self._dense_transform_V(tr))
         transform_J = _LazyRigidTransform(lambda: self._dense_transform_J(tr))
+        if extra_betas is None:
+            self._last_forward = (key, args, (transform_J, transform_V, tr))       # `args` keeps the tensors (and their ids) alive
         return transform_J, transform_V, tr
 
     # -- lazily built dense pieces (not on the hot path) -----------------------------------------------------------------

@@ -20,31 +20,32 @@ namespace {
 
 #define MAXJ 64
 
+// rest joints of the shaped template: J = J_template + (J_regressor . shapedirs) . shape -- 3J dot products of length S (400),
+// ONE WAVE EACH across 3J/4 workgroups (lane-strided coalesced loads + a DPP reduction).  Inside the single-workgroup chain kernel
+// the 165 dot products ran 42 deep per wave on cold lines: ~100 of its 125 us.  The result is parked in the (not yet written) last
+// row of each A[j] so that no scratch buffer enters the C-ABI.
+__global__ __launch_bounds__(256) void k_shaped_joints(int J, const float* __restrict__ joints, const float* __restrict__ jdirs,
+                                                       const float* __restrict__ shape, int S, float* __restrict__ A) {
+    const int idx = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+    if (idx >= 3 * J) return;
+    const float* d = jdirs + (size_t)idx * S;
+    float v = 0.f;
+    for (int l = lane; l < S; l += 64) v += d[l] * shape[l];
+    v = dwg_wave_sum_to_lane63(v);
+    if (lane == 63) A[16 * (idx / 3) + 12 + idx % 3] = joints[idx] + v;
+}
+
 __global__ __launch_bounds__(256) void k_joint_chain(int J, const float* __restrict__ pose /*[J,3]*/,
                                                     const float* __restrict__ joints /*[J,3]*/,
                                                     const int* __restrict__ parents, const float* __restrict__ transl,
-                                                    const float* __restrict__ jdirs /*[J,3,S]|null*/,
-                                                    const float* __restrict__ shape /*[S]*/, int S,
+                                                    int shaped /* rest joints come from k_shaped_joints (parked in A) */,
                                                     float* __restrict__ A /*[J,16]*/, float* __restrict__ rot_mats /*[J,9]|null*/) {
     __shared__ float tm[MAXJ][16];
     __shared__ float ch[MAXJ][16];
     __shared__ float sj[MAXJ][3];
     __shared__ int par[MAXJ];
     const int t = threadIdx.x;
-    {
-        // rest joints of the shaped template: J = J_template + (J_regressor . shapedirs) . shape -- 3J dot products of length S
-        // (400): one wave per dot product, lane-strided coalesced loads + a DPP reduction (the serial per-joint loop cost 130 us)
-        const int wave = t >> 6, lane = t & 63;
-        for (int idx = wave; idx < 3 * J; idx += 4) {
-            float v = 0.f;
-            if (jdirs) {
-                const float* d = jdirs + (size_t)idx * S;
-                for (int l = lane; l < S; l += 64) v += d[l] * shape[l];
-                v = dwg_wave_sum_to_lane63(v);
-            }
-            if (lane == 63) sj[idx / 3][idx % 3] = joints[idx] + v;
-        }
-    }
+    if (t < 3 * J) sj[t / 3][t % 3] = shaped ? A[16 * (t / 3) + 12 + t % 3] : joints[t];
     __syncthreads();
     if (t < J) {
         float R[9];
@@ -293,8 +294,11 @@ int dwg_lbs_joint_chain(int32_t J, const float* pose, const float* joints, const
                         float* rot_mats_out, dwg_stream_t stream) {
     if (J <= 0 || J > MAXJ || !pose || !joints || !parents || !A_out) return DWG_E_ARG;
     if (joint_shape_dirs && (!shape_coeffs || n_shape <= 0)) return DWG_E_ARG;
+    if (joint_shape_dirs)
+        DWG_LAUNCH("lbs_shaped_joints", k_shaped_joints, dim3(dwg_cdiv(3 * J, 4)), dim3(256), 0, (hipStream_t)stream, J, joints,
+                   joint_shape_dirs, shape_coeffs, n_shape, A_out);
     DWG_LAUNCH("lbs_joint_chain", k_joint_chain, dim3(1), dim3(256), 0, (hipStream_t)stream, J, pose, joints, parents, transl,
-               joint_shape_dirs, shape_coeffs, n_shape, A_out, rot_mats_out);
+               joint_shape_dirs ? 1 : 0, A_out, rot_mats_out);
     DWG_RETURN_IF_LAUNCH_FAILED();
     return DWG_OK;
 }
