@@ -118,6 +118,15 @@ def raster_report(prof, G, Kref, K, P, steps):
         b = 80 * Kref + 20 * P + 152 * G
         out["raster_backward"] = {"bytes": b, "ms": rb, "achieved_GBps": b / (rb * 1e-3) / 1e9,
                                   "frac_of_hbm_peak": b / (rb * 1e-3) / 1e9 / HBM_PEAK_GBS}
+    if os.path.exists(TRAFFIC_JSON):       # HBM bytes per frame from the PMC passes: every launch of the chain's kernels, summed
+        tk = json.load(open(TRAFFIC_JSON))["kernels"]
+        fwd = ("k_preprocess", "k_scan_tiles", "k_scatter", "k_tile_sort", "k_render_fwd", "k_camera_setup")
+        bwd = ("k_render_bwd", "k_preprocess_bwd")
+        for key, names in (("raster_forward", fwd), ("raster_backward", bwd)):
+            if key in out:
+                t = sum(v["hbm_bytes_per_launch"] for k, v in tk.items() if k.split("<")[0] in names)
+                out[key]["traffic"] = t
+                out[key]["traffic_over_algorithmic"] = t / out[key]["bytes"]
     return out
 
 
