@@ -253,6 +253,7 @@ def main():
     prof_sym = _lib.prof_symbols()
     _lib.prof_enable(False)
     if rank != 0:
+        dist.destroy_process_group()
         return
     info = step.describe()
     ms = dt / args.steps * 1e3
@@ -275,7 +276,9 @@ def main():
     out["launch_mode"] = "eager" if args.eager else "hipGraph replay of denoiser/VAE plans; kernel timers from an eager replay after the timed region"
     if not args.no_cpu_baseline and world == 1:
         out["cpu_baseline"] = cpu_baseline(args, G, res)
-    print(json.dumps(out))
+    print(json.dumps(out), flush=True)
+    if dist is not None:
+        dist.destroy_process_group()
 
 
 if __name__ == "__main__":
