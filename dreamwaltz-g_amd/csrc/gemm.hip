@@ -757,13 +757,16 @@ static void launch_glds_s(const GemmP& p, int batch, hipStream_t stream, const c
     }
 }
 
-// Pipeline depth.  Measured on MI355X (tools/bench_gemm.py, DWG_GEMM_STAGES=2|3): a deeper pipeline LOSES on every SDS shape --
-// the extra LDS costs resident workgroups, and occupancy hides the global->LDS latency better than run-ahead does (e.g.
-// 512x1280x11520 split-K: 47 us at 2 stages, 76 us at 4).  2 stages are the default; 3 stays selectable for experiments.
+// Pipeline depth.  Measured on MI355X at HEAD of round 2 (bench.py, DWG_GEMM_STAGES=2|3, average launch): the 128x64 tile gains from a
+// third stage (72 KiB of LDS still leaves the 2 workgroups per CU these small-M launches have anyway): conv fast path 24.6 -> 23.5 us,
+// plain rows 17.3 -> 15.6 us; the 128x128 tile loses (96 KiB -> ONE workgroup per CU: 44 -> 59 us, 122 -> 209 us), and so does the
+// generic im2col loader (38 -> 41 us: its per-stage index arithmetic is the cost there).  Default: 3 stages for the narrow tile with
+// the plain-row / fast-conv loaders, 2 otherwise; DWG_GEMM_STAGES forces one depth everywhere.
 template <int BN, int AKIND>
 static void launch_glds(const GemmP& p, int batch, hipStream_t stream, const char* name) {
     static const int forced = getenv("DWG_GEMM_STAGES") ? atoi(getenv("DWG_GEMM_STAGES")) : 0;
-    if (forced >= 3) launch_glds_s<BN, AKIND, 3>(p, batch, stream, name);
+    const bool three = forced ? forced >= 3 : (BN == 64 && AKIND != 1);
+    if (three) launch_glds_s<BN, AKIND, 3>(p, batch, stream, name);
     else launch_glds_s<BN, AKIND, 2>(p, batch, stream, name);
 }
 
