@@ -105,7 +105,7 @@ def cpu_baseline(args, G, res):
                       "(%d Gaussians @%dx%d)" % (len(ta), spent, cores, t_an, N, M, t_ra, G, res, res)}
 
 
-def raster_report(prof, G, Kref, K, P, steps):
+def raster_report(prof, G, Kref, K, P, steps, pmc=False):
     """Rasterizer against the HBM roofline with SURVEY 8d's byte formula (K = reference tile-pair count; sort traffic not counted)."""
     rf = sum(v[1] for k, v in prof.items() if k.startswith("raster_") and not k.endswith("_bwd")) / steps
     rb = sum(v[1] for k, v in prof.items() if k.startswith("raster_") and k.endswith("_bwd")) / steps
@@ -118,7 +118,7 @@ def raster_report(prof, G, Kref, K, P, steps):
         b = 80 * Kref + 20 * P + 152 * G
         out["raster_backward"] = {"bytes": b, "ms": rb, "achieved_GBps": b / (rb * 1e-3) / 1e9,
                                   "frac_of_hbm_peak": b / (rb * 1e-3) / 1e9 / HBM_PEAK_GBS}
-    if os.path.exists(TRAFFIC_JSON):       # HBM bytes per frame from the PMC passes: every launch of the chain's kernels, summed
+    if pmc and os.path.exists(TRAFFIC_JSON):       # HBM bytes per frame from the PMC passes (taken on the default c3 workload only)
         tk = json.load(open(TRAFFIC_JSON))["kernels"]
         fwd = ("k_preprocess", "k_scan_tiles", "k_scatter", "k_tile_sort", "k_render_fwd", "k_camera_setup")
         bwd = ("k_render_bwd", "k_preprocess_bwd")
@@ -156,7 +156,7 @@ def roofline(prof, prof_sym, prof_steps, G, Kref, K, P):
             if tk:
                 out["traffic"] = tk["hbm_bytes_per_launch"]
                 out["traffic_source"] = "profiles/r02_pmc_traffic.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes, gfx950 corrections)"
-    out.update(raster_report(prof, G, Kref, K, P, prof_steps))
+    out.update(raster_report(prof, G, Kref, K, P, prof_steps, pmc=(G == 100000 and P == 512 * 512)))
     return out
 
 
