@@ -525,6 +525,106 @@ __global__ __launch_bounds__(THREADS) void k_tile_sort(int T, const uint32_t* __
     }
 }
 
+// Register-blocked bitonic sort for the two common size classes.  The LDS network above moves every key through LDS on every one
+// of its log^2 passes (55 for 1024 keys: 0.9 MB of LDS traffic per block, and the blocks of a CU share ONE 128 B/clk LDS pipe -- the
+// sorts were LDS-bandwidth-bound: 0.19 of the 0.44 ms forward chain at c3, 0.51 of 1.1 ms at c5).  Here a thread owns EPT
+// CONSECUTIVE keys in registers (key i lives in thread i / EPT, register i % EPT), so every compare-exchange with stride < EPT is
+// register-only (34 of the 55 passes at EPT = 16), strides up to 32 * EPT go lane to lane inside the wave, and only the last few
+// strides of a 4096-key block cross waves through LDS.  Padding above n is real +inf keys, so the plain network applies.
+__device__ __forceinline__ uint64_t shfl_xor_u64(uint64_t v, int m) {
+    const uint32_t lo = (uint32_t)__shfl_xor((int)(uint32_t)v, m), hi = (uint32_t)__shfl_xor((int)(uint32_t)(v >> 32), m);
+    return ((uint64_t)hi << 32) | lo;
+}
+// LDS slot of key i: one 8-byte pad per 16 keys, so that a thread's 16 consecutive keys and the lanes' strided accesses spread over banks
+__device__ __forceinline__ int sort_slot(int i) { return i + (i >> 4); }
+
+template <int THREADS, int EPT>
+__device__ __forceinline__ void block_sort_regs(const uint64_t* __restrict__ keys_in, uint32_t* __restrict__ sorted_out, int n,
+                                                uint64_t* __restrict__ lds) {
+    constexpr int N = THREADS * EPT;
+    const int tid = threadIdx.x;
+    for (int e = tid; e < N; e += THREADS) lds[sort_slot(e)] = e < n ? keys_in[e] : ~0ull;      // coalesced in, +inf above n
+    __syncthreads();
+    uint64_t v[EPT];
+#pragma unroll
+    for (int r = 0; r < EPT; r++) v[r] = lds[sort_slot(tid * EPT + r)];
+#pragma unroll
+    for (int k = 2; k <= N; k <<= 1) {
+#pragma unroll
+        for (int j = k >> 1; j >= 1; j >>= 1) {
+            if (j >= EPT) {
+                const int m = j / EPT;                         // partner thread = tid ^ m, same register
+                const bool lower = (tid & m) == 0;
+                const bool asc = ((tid * EPT) & k) == 0;       // k >= 2 j >= 2 EPT: the direction bit lies in the thread index
+                if (m < 64) {
+#pragma unroll
+                    for (int r = 0; r < EPT; r++) {
+                        const uint64_t o = shfl_xor_u64(v[r], m);
+                        const bool keep_min = lower == asc;
+                        const bool take = keep_min ? (o < v[r]) : (o > v[r]);
+                        v[r] = take ? o : v[r];
+                    }
+                } else {                                       // across waves: through LDS (a few passes of the 4096-key class only)
+                    __syncthreads();
+#pragma unroll
+                    for (int r = 0; r < EPT; r++) lds[sort_slot(tid * EPT + r)] = v[r];
+                    __syncthreads();
+#pragma unroll
+                    for (int r = 0; r < EPT; r++) {
+                        const uint64_t o = lds[sort_slot((tid ^ m) * EPT + r)];
+                        const bool keep_min = lower == asc;
+                        const bool take = keep_min ? (o < v[r]) : (o > v[r]);
+                        v[r] = take ? o : v[r];
+                    }
+                }
+            } else {
+#pragma unroll
+                for (int r = 0; r < EPT; r++) {
+                    if ((r & j) == 0) {
+                        const int r2 = r | j;
+                        const bool asc = ((tid * EPT + r) & k) == 0;
+                        const uint64_t a = v[r], b = v[r2];
+                        const bool sw = asc ? (b < a) : (a < b);
+                        v[r] = sw ? b : a; v[r2] = sw ? a : b;
+                    }
+                }
+            }
+        }
+    }
+    __syncthreads();
+#pragma unroll
+    for (int r = 0; r < EPT; r++) lds[sort_slot(tid * EPT + r)] = v[r];
+    __syncthreads();
+    for (int e = tid; e < n; e += THREADS) sorted_out[e] = (uint32_t)lds[sort_slot(e)];            // coalesced out
+}
+
+// classes 0 (<= 1024 keys, one wave; 64 / 256 / 1024-key networks by list length), 1 (<= 4096 keys, four waves) and 2 (<= 16384, sixteen)
+template <int CLS, int THREADS>
+__global__ __launch_bounds__(THREADS) void k_tile_sort_regs(int T, const uint32_t* __restrict__ cls, const int32_t* __restrict__ header,
+                                                            const uint32_t* __restrict__ tile_start, const uint64_t* __restrict__ keys,
+                                                            uint32_t* __restrict__ sorted, int64_t cap) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+    if ((int)blockIdx.x >= header[H_CLASS0 + CLS]) return;
+    const int tile = (int)cls[(size_t)CLS * T + blockIdx.x];
+    int64_t s = tile_start[tile], e = tile_start[tile + 1];
+    if (s > cap) s = cap; if (e > cap) e = cap;
+    const int n = (int)(e - s);
+    if (n <= 0) return;
+    uint64_t* lds = reinterpret_cast<uint64_t*>(smem_raw);
+    if (n == 1) { if (threadIdx.x == 0) sorted[s] = (uint32_t)keys[s]; return; }
+    if (CLS == 0) {
+        if (n <= 64) block_sort_regs<64, 1>(keys + s, sorted + s, n, lds);
+        else if (n <= 256) block_sort_regs<64, 4>(keys + s, sorted + s, n, lds);
+        else block_sort_regs<64, 16>(keys + s, sorted + s, n, lds);
+    } else if (CLS == 1) {
+        if (n <= 2048) block_sort_regs<256, 8>(keys + s, sorted + s, n, lds);
+        else block_sort_regs<256, 16>(keys + s, sorted + s, n, lds);
+    } else {
+        if (n <= 8192) block_sort_regs<1024, 8>(keys + s, sorted + s, n, lds);
+        else block_sort_regs<1024, 16>(keys + s, sorted + s, n, lds);
+    }
+}
+
 // One wave64 per 8x8 pixel block, longest list first.  Splat records of the current batch of 64 live in LDS (broadcast reads);
 // the next batch's records are gathered into registers while the current one is composited.
 __global__ __launch_bounds__(64) void k_render_fwd(Params p, const uint32_t* __restrict__ order, const uint32_t* __restrict__ tile_start,
@@ -1016,12 +1116,31 @@ int dwg_raster_forward_render(const dwg_raster_settings* cfg, int32_t G, void* w
                   nB = (int)min((int64_t)T, pair_capacity / 1024 + 1);
         DWG_LAUNCH("raster_tile_sort_g", (k_tile_sort<3, 1024, true>), dim3(nD), dim3(1024), 0, stream, T, cls, header, tile_start,
                    keys, sorted, pair_capacity);
-        DWG_LAUNCH("raster_tile_sort_xl", (k_tile_sort<2, 1024, false>), dim3(nC), dim3(1024), 16384 * 8, stream, T, cls, header, tile_start,
-                   keys, sorted, pair_capacity);
-        DWG_LAUNCH("raster_tile_sort_l", (k_tile_sort<1, 256, false>), dim3(nB), dim3(256), 4096 * 8, stream, T, cls, header, tile_start,
-                   keys, sorted, pair_capacity);
-        DWG_LAUNCH("raster_tile_sort", (k_tile_sort<0, 64, false>), dim3(T), dim3(64), 1024 * 8, stream, T, cls, header, tile_start,
-                   keys, sorted, pair_capacity);
+        static const bool lds_sort = getenv("DWG_RASTER_LDS_SORT") != nullptr;      // experiment switch: the round-1 LDS network
+        if (!lds_sort) {
+            static bool attr2 = false;
+            if (!attr2) {
+                hipFuncSetAttribute(reinterpret_cast<const void*>(&k_tile_sort_regs<2, 1024>), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                    (16384 + 1024) * 8);
+                attr2 = true;
+            }
+            DWG_LAUNCH("raster_tile_sort_xl", (k_tile_sort_regs<2, 1024>), dim3(nC), dim3(1024), (16384 + 1024) * 8, stream, T, cls, header,
+                       tile_start, (const uint64_t*)keys, sorted, pair_capacity);
+        } else {
+            DWG_LAUNCH("raster_tile_sort_xl", (k_tile_sort<2, 1024, false>), dim3(nC), dim3(1024), 16384 * 8, stream, T, cls, header, tile_start,
+                       keys, sorted, pair_capacity);
+        }
+        if (lds_sort) {
+            DWG_LAUNCH("raster_tile_sort_l", (k_tile_sort<1, 256, false>), dim3(nB), dim3(256), 4096 * 8, stream, T, cls, header, tile_start,
+                       keys, sorted, pair_capacity);
+            DWG_LAUNCH("raster_tile_sort", (k_tile_sort<0, 64, false>), dim3(T), dim3(64), 1024 * 8, stream, T, cls, header, tile_start,
+                       keys, sorted, pair_capacity);
+        } else {
+            DWG_LAUNCH("raster_tile_sort_l", (k_tile_sort_regs<1, 256>), dim3(nB), dim3(256), (4096 + 256) * 8, stream, T, cls, header,
+                       tile_start, (const uint64_t*)keys, sorted, pair_capacity);
+            DWG_LAUNCH("raster_tile_sort", (k_tile_sort_regs<0, 64>), dim3(T), dim3(64), (1024 + 64) * 8, stream, T, cls, header, tile_start,
+                       (const uint64_t*)keys, sorted, pair_capacity);
+        }
     }
     DWG_LAUNCH("raster_render_fwd", k_render_fwd, dim3(T), dim3(64), 0, stream, p, (const uint32_t*)(ws + L.order), tile_start,
                (const uint32_t*)(ws + L.seg_start), (const uint32_t*)sorted, (const float4*)(ws + L.rec0), (const float4*)(ws + L.rec1),
