@@ -123,17 +123,145 @@ __global__ __launch_bounds__(256) void k_mlp_wgrad_partial(int M, int N, int K, 
 
 __global__ __launch_bounds__(256) void k_mlp_wgrad_final(int blocks, int N, int K, const float* __restrict__ partial,
                                                          float* __restrict__ dw, int lddw) {
-    // 64 outputs per workgroup x 4 strands over the partial tiles; fixed combination order
-    __shared__ float part[4][64];
-    const int o = threadIdx.x & 63, strand = threadIdx.x >> 6;
-    const int e = blockIdx.x * 64 + o;
+    // 16 outputs per workgroup x 16 strands over the partial tiles (a strand reads ~25 tiles 16 KiB apart: with 4 strands the pass was
+    // a 100-deep chain of dependent-latency loads, 25 us for 1.6 MB); fixed combination order
+    __shared__ float part[16][17];
+    const int o = threadIdx.x & 15, strand = threadIdx.x >> 4;
+    const int e = blockIdx.x * 16 + o;
     float s = 0.f;
-    for (int b = strand; b < blocks; b += 4) s += partial[(size_t)b * 4096 + e];
+    for (int b = strand; b < blocks; b += 16) s += partial[(size_t)b * 4096 + e];
     part[strand][o] = s;
     __syncthreads();
     if (strand == 0) {
         const int n = e >> 6, k = e & 63;
-        if (n < N && k < K) dw[(size_t)n * lddw + k] = (part[0][o] + part[1][o]) + (part[2][o] + part[3][o]);
+        float t = 0.f;
+#pragma unroll
+        for (int q = 0; q < 16; q++) t += part[q][o];
+        if (n < N && k < K) dw[(size_t)n * lddw + k] = t;
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------------------------
+// Whole per-Gaussian MLP in ONE launch: y = L_n(... act(L_1(x)) ...), widths <= 64 (nerf_model.py:12-33: 32-64-64-4, ReLU;
+// deform_model.py:102-143: 32(+pose bias)-64-64-64-64-10, leaky ReLU).  Layer by layer these were 8 GEMM launches that each wrote a
+// [M, 64] fp32 activation to HBM and read it back (mlp_fwd: 0.35 ms of the 2 ms c5 frame).  Here a wave keeps ITS 32 rows of
+// activations in LDS across all layers (overwritten in place once a layer's MFMAs are done), the layer's weights are staged in LDS for
+// the four waves, and the contraction is exact-f32 MFMA (v_mfma_f32_32x32x2_f32, transposed: a lane owns one row and groups of four
+// consecutive output columns).  Hidden activations are written out only when the caller keeps them for the backward.
+// ---------------------------------------------------------------------------------------------------------------------
+#define MLPC_MAXL 6
+#define MLPC_LD 68          // row stride in floats: multiple of 4 (16-byte fragment reads)
+struct MlpChainP {
+    const float* x; int M, Kin, ldx, nlayers;
+    const float* W[MLPC_MAXL]; const float* b[MLPC_MAXL]; float* hidden[MLPC_MAXL];
+    int ldw[MLPC_MAXL], N[MLPC_MAXL], K[MLPC_MAXL], act[MLPC_MAXL];
+    float* out; int ldo;
+};
+
+__device__ __forceinline__ float mlpc_act(float v, int act) {
+    return act == 1 ? fmaxf(v, 0.f) : (act == 2 ? (v > 0.f ? v : 0.01f * v) : (act == 5 ? 1.f / (1.f + __expf(-v)) : v));
+}
+// LDS position of contraction index k of a K-wide row: the MFMA lane (row, half) consumes k = 2 ks + half for ks = 0, 1, ... -- stored
+// as [half][ks] so that four consecutive steps are ONE 16-byte read (the interleaved order costs a 4-byte read per MFMA and operand)
+__device__ __forceinline__ int mlpc_pos(int k, int K) { return (k & 1) * (K >> 1) + (k >> 1); }
+
+// PERSISTENT waves: a workgroup stages ALL layers' weights in LDS once and then every wave walks its own 32-row groups to the end of
+// the input with no workgroup barrier at all (its activations are wave-private, the weights read-only) -- restaging the weights per
+// 128-row tile with two barriers per layer left the MFMA pipe 30 % busy.
+#define MLPC_WAVES 8        // waves per workgroup sharing one LDS copy of the weights: two per SIMD hide each other's LDS / epilogue latencies
+__global__ __launch_bounds__(64 * MLPC_WAVES) void k_mlp_chain(MlpChainP p, int wfloats) {
+    typedef __attribute__((ext_vector_type(16))) float f32x16_t;
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    float* sWall = smem;                                    // per layer [Np][MLPC_LD], k permuted
+    float* sBall = smem + wfloats;                          // [nlayers][64]
+    float* sXall = sBall + MLPC_MAXL * 64;                  // [MLPC_WAVES][32][MLPC_LD]
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    {
+        int off = 0;
+        for (int l = 0; l < p.nlayers; l++) {
+            const int N = p.N[l], K = p.K[l], Np = (N + 31) & ~31;
+            for (int i = tid; i < Np * K; i += 64 * MLPC_WAVES) {
+                const int n = i / K, k = i - n * K;
+                sWall[off + n * MLPC_LD + mlpc_pos(k, K)] = n < N ? p.W[l][(size_t)n * p.ldw[l] + k] : 0.f;
+            }
+            if (tid < 64) sBall[l * 64 + tid] = (tid < N && p.b[l]) ? p.b[l][tid] : 0.f;
+            off += Np * MLPC_LD;
+        }
+    }
+    __syncthreads();
+    float* sX = sXall + wave * 32 * MLPC_LD;
+    const int m = lane & 31, half = lane >> 5;
+    const int ngroups = (p.M + 31) >> 5;
+    for (int g = blockIdx.x * MLPC_WAVES + wave; g < ngroups; g += gridDim.x * MLPC_WAVES) {
+        const int r0 = g * 32;
+        __builtin_amdgcn_wave_barrier();
+        for (int i = lane; i < 32 * p.Kin; i += 64) {       // this wave's rows -> LDS, coalesced
+            const int r = i / p.Kin, k = i - r * p.Kin;
+            sX[r * MLPC_LD + mlpc_pos(k, p.Kin)] = (r0 + r < p.M) ? p.x[(size_t)(r0 + r) * p.ldx + k] : 0.f;
+        }
+        __builtin_amdgcn_wave_barrier();
+        const int grow = r0 + m;
+        int off = 0;
+        for (int l = 0; l < p.nlayers; l++) {
+            const int N = p.N[l], K = p.K[l], Np = (N + 31) & ~31;
+            const float* sW = sWall + off;
+            const float* sB = sBall + l * 64;
+            off += Np * MLPC_LD;
+            f32x16_t acc0, acc1;
+#pragma unroll
+            for (int r = 0; r < 16; r++) { acc0[r] = 0.f; acc1[r] = 0.f; }
+            const float4* px = reinterpret_cast<const float4*>(sX + m * MLPC_LD + half * (K >> 1));
+            const float4* pw0 = reinterpret_cast<const float4*>(sW + m * MLPC_LD + half * (K >> 1));
+            const float4* pw1 = reinterpret_cast<const float4*>(sW + (32 + m) * MLPC_LD + half * (K >> 1));
+            const int nq = K >> 3;                          // 16-byte groups of four MFMA steps (K % 8 == 0)
+            if (Np == 64) {                                 // two independent accumulator chains interleaved
+#pragma unroll 2
+                for (int q = 0; q < nq; q++) {
+                    const float4 xv = px[q], w0 = pw0[q], w1 = pw1[q];
+                    acc0 = __builtin_amdgcn_mfma_f32_32x32x2f32(w0.x, xv.x, acc0, 0, 0, 0);
+                    acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(w1.x, xv.x, acc1, 0, 0, 0);
+                    acc0 = __builtin_amdgcn_mfma_f32_32x32x2f32(w0.y, xv.y, acc0, 0, 0, 0);
+                    acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(w1.y, xv.y, acc1, 0, 0, 0);
+                    acc0 = __builtin_amdgcn_mfma_f32_32x32x2f32(w0.z, xv.z, acc0, 0, 0, 0);
+                    acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(w1.z, xv.z, acc1, 0, 0, 0);
+                    acc0 = __builtin_amdgcn_mfma_f32_32x32x2f32(w0.w, xv.w, acc0, 0, 0, 0);
+                    acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(w1.w, xv.w, acc1, 0, 0, 0);
+                }
+            } else {
+#pragma unroll 2
+                for (int q = 0; q < nq; q++) {
+                    const float4 xv = px[q], w0 = pw0[q];
+                    acc0 = __builtin_amdgcn_mfma_f32_32x32x2f32(w0.x, xv.x, acc0, 0, 0, 0);
+                    acc0 = __builtin_amdgcn_mfma_f32_32x32x2f32(w0.y, xv.y, acc0, 0, 0, 0);
+                    acc0 = __builtin_amdgcn_mfma_f32_32x32x2f32(w0.z, xv.z, acc0, 0, 0, 0);
+                    acc0 = __builtin_amdgcn_mfma_f32_32x32x2f32(w0.w, xv.w, acc0, 0, 0, 0);
+                }
+            }
+            __builtin_amdgcn_wave_barrier();                // every lane's reads of this layer's input precede the in-place writes
+            const bool last = l + 1 == p.nlayers;
+#pragma unroll
+            for (int t = 0; t < 2; t++) {
+                if (t * 32 >= Np) break;
+                const f32x16_t& acc = t == 0 ? acc0 : acc1;
+#pragma unroll
+                for (int q = 0; q < 4; q++) {
+                    const int n0 = t * 32 + 8 * q + 4 * half;
+                    float v[4];
+#pragma unroll
+                    for (int e = 0; e < 4; e++) v[e] = mlpc_act(acc[4 * q + e] + sB[n0 + e], p.act[l]);
+                    if (!last) {
+#pragma unroll
+                        for (int e = 0; e < 4; e++) sX[m * MLPC_LD + mlpc_pos(n0 + e, N)] = v[e];      // next layer's input (K = N), in place
+                        if (p.hidden[l] && grow < p.M && n0 < N)
+                            *reinterpret_cast<float4*>(p.hidden[l] + (size_t)grow * N + n0) = make_float4(v[0], v[1], v[2], v[3]);
+                    } else if (grow < p.M) {
+#pragma unroll
+                        for (int e = 0; e < 4; e++) if (n0 + e < N) p.out[(size_t)grow * p.ldo + n0 + e] = v[e];
+                    }
+                }
+            }
+            __builtin_amdgcn_wave_barrier();
+        }
     }
 }
 
@@ -201,8 +329,41 @@ int dwg_mlp_wgrad(int32_t M, int32_t N, int32_t K, const float* dz, int32_t lddz
     }
     const int rpb = 256, blocks = dwg_cdiv(M, rpb);
     DWG_LAUNCH("mlp_wgrad", k_mlp_wgrad_partial, dim3(blocks), dim3(256), 0, (hipStream_t)stream, M, N, K, dz, lddz, x, ldx, rpb, workspace);
-    DWG_LAUNCH("mlp_wgrad_final", k_mlp_wgrad_final, dim3(64), dim3(256), 0, (hipStream_t)stream, blocks, N, K, (const float*)workspace,
+    DWG_LAUNCH("mlp_wgrad_final", k_mlp_wgrad_final, dim3(256), dim3(256), 0, (hipStream_t)stream, blocks, N, K, (const float*)workspace,
                dw, lddw);
+    DWG_RETURN_IF_LAUNCH_FAILED();
+    return DWG_OK;
+}
+
+int dwg_mlp_chain_forward(int32_t M, int32_t Kin, const float* x, int32_t ldx, int32_t nlayers, const float* const* weights,
+                          const int32_t* ldw, const float* const* biases, const int32_t* widths, const int32_t* acts,
+                          float* const* hidden, float* out, int32_t ldo, dwg_stream_t stream) {
+    if (M < 0 || nlayers < 1 || nlayers > MLPC_MAXL || Kin < 8 || Kin > 64 || (Kin & 7) || !x || !weights || !ldw || !widths || !acts || !out)
+        return DWG_E_ARG;
+    if (M == 0) return DWG_OK;
+    MlpChainP p;
+    p.x = x; p.M = M; p.Kin = Kin; p.ldx = ldx; p.nlayers = nlayers; p.out = out; p.ldo = ldo;
+    int k = Kin;
+    for (int l = 0; l < MLPC_MAXL; l++) {
+        const bool on = l < nlayers;
+        if (on && (widths[l] < 1 || widths[l] > 64 || !weights[l] || ldw[l] < k)) return DWG_E_ARG;
+        if (on && l + 1 < nlayers && (widths[l] & 7)) return DWG_E_ARG;       // hidden widths (the next layer's K): multiples of 8
+        if (on && acts[l] != 0 && acts[l] != 1 && acts[l] != 2 && acts[l] != 5) return DWG_E_ARG;
+        p.W[l] = on ? weights[l] : nullptr; p.b[l] = (on && biases) ? biases[l] : nullptr;
+        p.hidden[l] = (on && hidden && l + 1 < nlayers) ? hidden[l] : nullptr;
+        p.ldw[l] = on ? ldw[l] : 0; p.N[l] = on ? widths[l] : 0; p.K[l] = on ? k : 0; p.act[l] = on ? acts[l] : 0;
+        if (on) k = widths[l];
+    }
+    int wfloats = 0;
+    for (int l = 0; l < nlayers; l++) wfloats += ((widths[l] + 31) & ~31) * MLPC_LD;
+    const size_t lds = ((size_t)wfloats + MLPC_MAXL * 64 + MLPC_WAVES * 32 * MLPC_LD) * sizeof(float);       // <= 150 KiB: one workgroup per CU
+    static bool attr_set = false;
+    if (!attr_set) {
+        hipFuncSetAttribute(reinterpret_cast<const void*>(&k_mlp_chain), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        attr_set = true;
+    }
+    const int wgs = dwg_cdiv(dwg_cdiv(M, 32), MLPC_WAVES);
+    DWG_LAUNCH("mlp_chain_fwd", k_mlp_chain, dim3(wgs < 256 ? wgs : 256), dim3(64 * MLPC_WAVES), lds, (hipStream_t)stream, p, wfloats);    // persistent
     DWG_RETURN_IF_LAUNCH_FAILED();
     return DWG_OK;
 }

@@ -51,29 +51,108 @@ class _Linear(torch.autograd.Function):
     @staticmethod
     def backward(ctx, dy):
         x, w, y, extra = ctx.saved_tensors
+        dx, dw, db = _linear_backward(x, w, y, extra, ctx.act, dy, ctx.needs_input_grad[0])
+        return dx, dw, (db if ctx.has_b else None), None, None
+
+
+def _linear_backward(x, w, y, extra, act, dy, need_dx):
+    """Gradients of y = act(x @ w[:, :Kx]^T + b + w[:, Kx:] @ extra) given dy and the saved OUTPUT y -> (dx | None, dw, db)."""
+    M, Kx = x.shape
+    N = w.shape[0]
+    dy = dy.contiguous().float()
+    dz = torch.empty_like(dy) if act else dy
+    colsum = torch.zeros(N, device=x.device)
+    p = _lib.ptr
+    _lib.check(_lib.lib().dwg_act_backward_colsum(M, N, gemm.ACT[act], p(dy), p(y) if act else None,
+                                                  p(dz) if act else None, p(colsum), _st(x)), "dwg_act_backward_colsum")
+    dw = torch.zeros_like(w)
+    # dW[:, :Kx] = dz^T x   (contraction over the M rows of two row-major operands)
+    if N <= 64 and Kx <= 64:
+        L = _lib.lib()
+        ws = torch.empty(L.dwg_mlp_wgrad_workspace_floats(M), device=x.device, dtype=torch.float32)
+        _lib.check(L.dwg_mlp_wgrad(M, N, Kx, p(dz), N, p(x), Kx, p(dw), w.shape[1], p(ws), _st(x)), "dwg_mlp_wgrad")
+    else:
+        gemm.gemm_raw(dz, x, dw, N, Kx, M, (1, N), (1, Kx), w.shape[1], splitk=_splitk(M), name="mlp_wgrad")
+    if extra is not None:
+        dw[:, Kx:] = colsum[:, None] * extra.reshape(1, -1)
+    dx = None
+    if need_dx:
+        dx = torch.empty_like(x)
+        gemm.gemm_raw(dz, w, dx, M, Kx, N, (N, 1), (1, w.stride(0)), Kx, name="mlp_dgrad")
+    return dx, dw, colsum
+
+
+class _MlpChain(torch.autograd.Function):
+    """The whole MLP in one forward launch (csrc/elementwise.hip k_mlp_chain, include/dwg_elementwise.h dwg_mlp_chain_forward);
+    backward layer by layer with the kernels of _Linear.  args: x, extra (vector folded into the first bias, or None), acts (tuple of
+    names, one per layer), then w_0, b_0, w_1, b_1, ..."""
+
+    @staticmethod
+    def forward(ctx, x, extra, acts, *wb):
+        L = _lib.lib()
+        nl = len(acts)
+        ws = [wb[2 * l].contiguous().float() for l in range(nl)]
+        bs = [wb[2 * l + 1] for l in range(nl)]
+        x = x.contiguous().float()
         M, Kx = x.shape
-        N = w.shape[0]
-        dy = dy.contiguous().float()
-        dz = torch.empty_like(dy) if ctx.act else dy
-        colsum = torch.zeros(N, device=x.device)
-        p = _lib.ptr
-        _lib.check(_lib.lib().dwg_act_backward_colsum(M, N, gemm.ACT[ctx.act], p(dy), p(y) if ctx.act else None,
-                                                      p(dz) if ctx.act else None, p(colsum), _st(x)), "dwg_act_backward_colsum")
-        dw = torch.zeros_like(w)
-        # dW[:, :Kx] = dz^T x   (contraction over the M rows of two row-major operands)
-        if N <= 64 and Kx <= 64:
-            L = _lib.lib()
-            ws = torch.empty(L.dwg_mlp_wgrad_workspace_floats(M), device=x.device, dtype=torch.float32)
-            _lib.check(L.dwg_mlp_wgrad(M, N, Kx, p(dz), N, p(x), Kx, p(dw), w.shape[1], p(ws), _st(x)), "dwg_mlp_wgrad")
-        else:
-            gemm.gemm_raw(dz, x, dw, N, Kx, M, (1, N), (1, Kx), w.shape[1], splitk=_splitk(M), name="mlp_wgrad")
-        if extra is not None:
-            dw[:, Kx:] = colsum[:, None] * extra.reshape(1, -1)
-        dx = None
-        if ctx.needs_input_grad[0]:
-            dx = torch.empty_like(x)
-            gemm.gemm_raw(dz, w, dx, M, Kx, N, (N, 1), (1, w.stride(0)), Kx, name="mlp_dgrad")
-        return dx, dw, (colsum if ctx.has_b else None), None, None
+        dev = x.device
+        bias0 = bs[0].float() if bs[0] is not None else torch.zeros(ws[0].shape[0], device=dev)
+        if extra is not None:      # c = extra @ w_0[:, Kx:]^T + b_0   (1 x Ke) x (Ke x N)
+            e = extra.reshape(1, -1).contiguous().float()
+            c = torch.empty(1, ws[0].shape[0], device=dev)
+            gemm.gemm_raw(e, ws[0][:, Kx:], c, 1, ws[0].shape[0], e.shape[1], (e.shape[1], 1), (ws[0].stride(0), 1), ws[0].shape[0],
+                          bias=bias0.contiguous(), name="mlp_pose_bias")
+            bias0 = c.reshape(-1)
+        biases = [bias0.contiguous()] + [None if b is None else b.contiguous().float() for b in bs[1:]]
+        widths = [int(w.shape[0]) for w in ws]
+        keep = any(ctx.needs_input_grad)
+        hidden = [torch.empty(M, widths[l], device=dev) if keep else None for l in range(nl - 1)]
+        out = torch.empty(M, widths[-1], device=dev)
+        vp, i32 = ctypes.c_void_p * nl, ctypes.c_int32 * nl
+        pv = lambda t: None if t is None else t.data_ptr()       # noqa: E731
+        _lib.check(L.dwg_mlp_chain_forward(M, Kx, _lib.ptr(x), Kx, nl, vp(*[w.data_ptr() for w in ws]), i32(*[int(w.stride(0)) for w in ws]),
+                                           vp(*[pv(b) for b in biases]), i32(*widths), i32(*[gemm.ACT[a] for a in acts]),
+                                           vp(*[pv(h) for h in hidden] + [None]), _lib.ptr(out), widths[-1], _st(x)), "dwg_mlp_chain_forward")
+        ctx.acts, ctx.nl = acts, nl
+        ctx.has_b = [b is not None for b in bs]
+        ctx.has_extra = extra is not None
+        if keep:
+            ctx.save_for_backward(x, out, *(ws + hidden + ([extra] if extra is not None else [])))
+        return out
+
+    @staticmethod
+    def backward(ctx, dy):
+        nl = ctx.nl
+        saved = ctx.saved_tensors
+        x, out = saved[0], saved[1]
+        ws, hidden = list(saved[2:2 + nl]), list(saved[2 + nl:2 + nl + nl - 1])
+        extra = saved[-1] if ctx.has_extra else None
+        grads = [None] * (2 * nl)
+        g = dy
+        for l in range(nl - 1, -1, -1):
+            xin = x if l == 0 else hidden[l - 1]
+            y = out if l == nl - 1 else hidden[l]
+            w = ws[l]
+            wl = w if (l > 0 or extra is None) else w          # layer 0 keeps the pose columns (their gradient comes from colsum)
+            dx, dw, db = _linear_backward(xin, wl, y, extra if l == 0 else None, ctx.acts[l], g, l > 0 or ctx.needs_input_grad[0])
+            grads[2 * l] = dw
+            grads[2 * l + 1] = db if ctx.has_b[l] else None
+            g = dx
+        return (g if ctx.needs_input_grad[0] else None, None, None) + tuple(grads)
+
+
+def mlp_chain(x, layers, acts, extra=None):
+    """layers: [(weight, bias | None), ...]; acts: activation name per layer.  Falls back to the per-layer path for widths > 64."""
+    if any(w.shape[0] > 64 for w, _ in layers) or x.shape[1] > 64 or x.shape[1] % 8 or any(w.shape[0] % 8 for w, _ in layers[:-1]) \
+            or len(layers) > 6 or not x.is_cuda:
+        h = x
+        for l, ((w, b), a) in enumerate(zip(layers, acts)):
+            h = linear(h, w, b, act=a, extra=extra if l == 0 else None)
+        return h
+    flat = []
+    for w, b in layers:
+        flat += [w, b]
+    return _MlpChain.apply(x, extra, tuple(acts), *flat)
 
 
 def linear(x, w, b=None, act=None, extra=None):
@@ -90,9 +169,7 @@ class MLP(nn.Module):
         self.net = nn.ModuleList(net)
 
     def forward(self, x):
-        for l in range(self.num_layers):
-            x = linear(x, self.net[l].weight, self.net[l].bias, act="relu" if l != self.num_layers - 1 else None)
-        return x
+        return mlp_chain(x, [(m.weight, m.bias) for m in self.net], ["relu"] * (self.num_layers - 1) + [None])
 
 
 class DeformNetwork(nn.Module):
@@ -109,11 +186,8 @@ class DeformNetwork(nn.Module):
         self.gaussian_scaling = nn.Linear(W, 3)
 
     def forward(self, x, body_pose):
-        h = linear(x, self.layers[0].weight, self.layers[0].bias, act="leaky_relu", extra=body_pose)
-        for i in range(1, self.D):
-            h = linear(h, self.layers[i].weight, self.layers[i].bias, act="leaky_relu")
         # the three heads share one 64 -> 10 product (warp 3 | scaling 3 | rotation 4)
         w = torch.cat([self.gaussian_warp.weight, self.gaussian_scaling.weight, self.gaussian_rotation.weight], 0)
         b = torch.cat([self.gaussian_warp.bias, self.gaussian_scaling.bias, self.gaussian_rotation.bias], 0)
-        o = linear(h, w, b)
+        o = mlp_chain(x, [(m.weight, m.bias) for m in self.layers] + [(w, b)], ["leaky_relu"] * self.D + [None], extra=body_pose)
         return o[:, 0:3], o[:, 3:6], o[:, 6:10]

@@ -27,6 +27,16 @@ size_t dwg_mlp_wgrad_workspace_floats(int32_t M);
 int dwg_mlp_wgrad(int32_t M, int32_t N, int32_t K, const float* dz, int32_t lddz, const float* x, int32_t ldx, float* dw,
                   int32_t lddw, float* workspace, dwg_stream_t stream);
 
+/* A whole per-Gaussian MLP in one launch (nerf_model.py:28-33 / deform_model.py:111-143 forward): h_0 = x [M, Kin] (row stride ldx),
+ * h_{l+1} = act_l(h_l W_l^T + b_l) for l < nlayers, W_l [widths[l], K_l] with row stride ldw[l] (only the first K_l columns are read:
+ * the pose columns of the deformation network's first layer are folded into its bias by the caller), widths <= 64, Kin and the
+ * hidden widths multiples of 8, acts in {NONE, RELU, LEAKY_RELU, SIGMOID}.  out [M, widths[last]] with row stride ldo.  hidden (may be
+ * NULL) holds per hidden layer a [M, widths[l]] buffer that receives h_{l+1} (kept for the backward), or NULL entries.
+ * weights / ldw / biases / widths / acts / hidden are HOST arrays of length nlayers (<= 6). */
+int dwg_mlp_chain_forward(int32_t M, int32_t Kin, const float* x, int32_t ldx, int32_t nlayers, const float* const* weights,
+                          const int32_t* ldw, const float* const* biases, const int32_t* widths, const int32_t* acts,
+                          float* const* hidden, float* out, int32_t ldo, dwg_stream_t stream);
+
 /* torch.optim.Adam update (amsgrad=False, weight_decay=0) on n contiguous floats, step >= 1 is the 1-based step count;
  * grad is multiplied by grad_scale first (1/world_size after a sum all-reduce).  Buffers must be 16-byte aligned. */
 int dwg_adam_step(int64_t n, float* param, const float* grad, float* exp_avg, float* exp_avg_sq, float lr, float beta1,
