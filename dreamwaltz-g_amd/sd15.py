@@ -570,6 +570,33 @@ class Builder:
         sc = x if C == Cout else self.conv(x, pre + ".conv_shortcut", pad=0)
         return self.conv(n2, pre + ".conv2", residual=sc)
 
+    def text_kv(self, text, t):
+        """[k | v] of block `t`'s cross-attention.  The text k / v projections of ALL transformer blocks of this network read the same
+        [B, 77, 768] input and nothing else: they run as ONE GEMM against the row-concatenated weights when the first block asks (16
+        launches of ~12 us each in the UNet, 7 in the ControlNet -> 1 + 1); a block's k and v are column slices of its output."""
+        batches = self.__dict__.setdefault("_text_kv", {})
+        key = text.data_ptr()
+        if key not in batches:
+            if os.environ.get("DWG_TEXT_KV_PER_BLOCK") == "1":           # experiment switch: the round-1 schedule
+                batches[key] = None
+            else:
+                suffix = ".attn2.to_k.weight"
+                blocks = sorted(n[:-len(suffix)] for n in self.w.sd if n.endswith(suffix) and self.w.sd[n].shape[1] == text.shape[-1])
+                names = []
+                for b_ in blocks:
+                    names += [b_ + ".attn2.to_k", b_ + ".attn2.to_v"]
+                out = self.linear(text, self.w.lin(*names), tag="attn_kv")
+                offs, o = {}, 0
+                for b_ in blocks:
+                    c = int(self.w.sd[b_ + suffix].shape[0])
+                    offs[b_] = (o, c); o += 2 * c
+                batches[key] = (out, offs, text)
+        ent = batches[key]
+        if ent is None or t not in ent[1]:
+            return self.linear(text, self.w.lin(t + ".attn2.to_k", t + ".attn2.to_v"), tag="attn_kv")
+        o, c = ent[1][t]
+        return ent[0][..., o:o + 2 * c]
+
     def transformer(self, x, pre, text, heads):
         B, H, W, C = x.shape
         n = self.groupnorm(x, pre + ".norm", 1e-6, False)
@@ -581,7 +608,7 @@ class Builder:
         h = self.linear(a, self.w.lin(t + ".attn1.to_out.0"), bias=self.w.f32(t + ".attn1.to_out.0.bias"), residual=h, tag="attn_out")
         l2 = self.layernorm(h, t + ".norm2")
         q = self.linear(l2, self.w.lin(t + ".attn2.to_q"), tag="attn_q")
-        kv = self.linear(text, self.w.lin(t + ".attn2.to_k", t + ".attn2.to_v"), tag="attn_kv")
+        kv = self.text_kv(text, t)
         a = self.attention(q, kv[..., :C], kv[..., C:], heads)
         h = self.linear(a, self.w.lin(t + ".attn2.to_out.0"), bias=self.w.f32(t + ".attn2.to_out.0.bias"), residual=h, tag="attn_out")
         l3 = self.layernorm(h, t + ".norm3")
