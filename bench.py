@@ -203,12 +203,20 @@ def main():
     rank = int(os.environ.get("RANK", "0")); world = int(os.environ.get("WORLD_SIZE", "1"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
     assert torch.cuda.is_available(), "bench.py needs a GPU (HIP kernels, no CPU fallback)"
+    # Functional test of the N > 1 flow on a 1-GPU box: DWG_BENCH_SHARE_GPU=1 puts every rank on cuda:0 and DWG_BENCH_BACKEND=gloo
+    # replaces RCCL (which refuses two ranks on one device).  Never set by the driver; numbers from that mode are not a measurement.
+    if os.environ.get("DWG_BENCH_SHARE_GPU") == "1":
+        local = 0
     torch.cuda.set_device(local)
     dist = None
     if world > 1:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local))
+        backend = os.environ.get("DWG_BENCH_BACKEND", "nccl")
+        if backend == "nccl":
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local))
+        else:
+            dist.init_process_group(backend)
     dev = torch.device("cuda", local)
     torch.cuda.set_stream(torch.cuda.Stream(device=dev))   # one real (non-default) HIP stream for the whole step: graph-safe
     if args.config == "c5":
