@@ -19,13 +19,42 @@ __device__ __forceinline__ float act_grad_from_output(float y, int act) {
 __global__ __launch_bounds__(256) void k_act_bwd_colsum(int M, int N, int act, const float* __restrict__ dy,
                                                         const float* __restrict__ y, float* __restrict__ dz,
                                                         float* __restrict__ colsum, int rows_per_block) {
-    __shared__ float part[256];
+    __shared__ float part[256 * 4];
     const int tid = threadIdx.x;
+    const int r0 = blockIdx.x * rows_per_block;
+    const int r1 = min(M, r0 + rows_per_block);
+    if ((N & 3) == 0 && N <= 256) {
+        // four consecutive columns per thread: 16-byte loads / stores (the scalar version streamed 77 MB at 3 TB/s)
+        const int tpr = N >> 2, rows_par = 256 / tpr;
+        const int cq = tid % tpr, rsub = tid / tpr;
+        float s[4] = {0.f, 0.f, 0.f, 0.f};
+        if (rsub < rows_par) {
+            for (int r = r0 + rsub; r < r1; r += rows_par) {
+                const size_t i = ((size_t)r * N >> 2) + cq;
+                float4 g = reinterpret_cast<const float4*>(dy)[i];
+                if (y) {
+                    const float4 yy = reinterpret_cast<const float4*>(y)[i];
+                    g.x *= act_grad_from_output(yy.x, act); g.y *= act_grad_from_output(yy.y, act);
+                    g.z *= act_grad_from_output(yy.z, act); g.w *= act_grad_from_output(yy.w, act);
+                }
+                if (dz) reinterpret_cast<float4*>(dz)[i] = g;
+                s[0] += g.x; s[1] += g.y; s[2] += g.z; s[3] += g.w;
+            }
+        }
+#pragma unroll
+        for (int e = 0; e < 4; e++) part[tid * 4 + e] = (rsub < rows_par) ? s[e] : 0.f;
+        __syncthreads();
+        if (colsum && tid < N) {
+            const int q = tid >> 2, e = tid & 3;
+            float t = 0.f;
+            for (int k = 0; k < rows_par; k++) t += part[(k * tpr + q) * 4 + e];
+            atomicAdd(&colsum[tid], t);
+        }
+        return;
+    }
     const int tpr = N;                       // threads per row (one thread per column)
     const int rows_par = 256 / tpr;          // rows processed in parallel
     const int col = tid % tpr, rsub = tid / tpr;
-    const int r0 = blockIdx.x * rows_per_block;
-    const int r1 = min(M, r0 + rows_per_block);
     float s = 0.f;
     if (rsub < rows_par) {
         for (int r = r0 + rsub; r < r1; r += rows_par) {

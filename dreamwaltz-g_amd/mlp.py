@@ -55,17 +55,18 @@ class _Linear(torch.autograd.Function):
         return dx, dw, (db if ctx.has_b else None), None, None
 
 
-def _linear_backward(x, w, y, extra, act, dy, need_dx):
-    """Gradients of y = act(x @ w[:, :Kx]^T + b + w[:, Kx:] @ extra) given dy and the saved OUTPUT y -> (dx | None, dw, db)."""
+def _linear_backward(x, w, y, extra, act, dy, need_dx, zeros=None):
+    """Gradients of y = act(x @ w[:, :Kx]^T + b + w[:, Kx:] @ extra) given dy and the saved OUTPUT y -> (dx | None, dw, db).
+    `zeros`: optional (colsum [N], dw like w) views of a buffer the caller zero-filled once for a whole chain."""
     M, Kx = x.shape
     N = w.shape[0]
     dy = dy.contiguous().float()
     dz = torch.empty_like(dy) if act else dy
-    colsum = torch.zeros(N, device=x.device)
+    colsum = torch.zeros(N, device=x.device) if zeros is None else zeros[0]
     p = _lib.ptr
     _lib.check(_lib.lib().dwg_act_backward_colsum(M, N, gemm.ACT[act], p(dy), p(y) if act else None,
                                                   p(dz) if act else None, p(colsum), _st(x)), "dwg_act_backward_colsum")
-    dw = torch.zeros_like(w)
+    dw = torch.zeros_like(w) if zeros is None else zeros[1]
     # dW[:, :Kx] = dz^T x   (contraction over the M rows of two row-major operands)
     if N <= 64 and Kx <= 64:
         L = _lib.lib()
@@ -129,12 +130,18 @@ class _MlpChain(torch.autograd.Function):
         extra = saved[-1] if ctx.has_extra else None
         grads = [None] * (2 * nl)
         g = dy
+        # one zero fill for every layer's bias-gradient accumulator and weight-gradient tile (16 fills per step before)
+        sizes = [(int(w.shape[0]), int(w.numel())) for w in ws]
+        flat = torch.zeros(sum(a + b for a, b in sizes), device=x.device)
+        zs, o = [], 0
+        for (a, b), w in zip(sizes, ws):
+            zs.append((flat[o:o + a], flat[o + a:o + a + b].view_as(w))); o += a + b
         for l in range(nl - 1, -1, -1):
             xin = x if l == 0 else hidden[l - 1]
             y = out if l == nl - 1 else hidden[l]
             w = ws[l]
             wl = w if (l > 0 or extra is None) else w          # layer 0 keeps the pose columns (their gradient comes from colsum)
-            dx, dw, db = _linear_backward(xin, wl, y, extra if l == 0 else None, ctx.acts[l], g, l > 0 or ctx.needs_input_grad[0])
+            dx, dw, db = _linear_backward(xin, wl, y, extra if l == 0 else None, ctx.acts[l], g, l > 0 or ctx.needs_input_grad[0], zeros=zs[l])
             grads[2 * l] = dw
             grads[2 * l + 1] = db if ctx.has_b[l] else None
             g = dx
