@@ -379,26 +379,52 @@ int dwg_grid_encode_backward_owner(const float* grad, const float* inputs, const
     }
     if (hipMemsetAsync(xcd_counters, 0, 16 * sizeof(uint32_t), (hipStream_t)stream) != hipSuccess) return DWG_E_LAUNCH;
     uint32_t first_table_level = 0;
+    hipStream_t main_stream = (hipStream_t)stream, side = nullptr;
+    hipEvent_t ev_join = nullptr;
     if (B >= 16384) {
         static bool attr_set = false;
         if (!attr_set) {
             hipFuncSetAttribute(reinterpret_cast<const void*>(&k_grid_bwd_coarse), hipFuncAttributeMaxDynamicSharedMemorySize, 152 * 1024);
             attr_set = true;
         }
+        // The LDS-privatised coarse levels are a handful of fat workgroups (13 - 49 of them, up to 97 KiB of LDS each) that touch
+        // their own part of the table gradient: they run on a library-owned side stream NEXT TO the fine-level kernel instead of
+        // in front of it (0.27 ms of a 1.9 ms backward otherwise spent on a mostly idle chip).  DWG_GRID_SERIAL_COARSE=1: one stream.
+        static const bool serial = getenv("DWG_GRID_SERIAL_COARSE") != nullptr;
+        static hipStream_t side_streams[16] = {nullptr};
+        static hipEvent_t ev_forks[16] = {nullptr}, ev_joins[16] = {nullptr};
+        int dev = 0;
+        hipEvent_t ev_fork = nullptr;
+        if (!serial && hipGetDevice(&dev) == hipSuccess && dev >= 0 && dev < 16) {
+            if (!side_streams[dev]) {
+                if (hipStreamCreateWithFlags(&side_streams[dev], hipStreamNonBlocking) != hipSuccess ||
+                    hipEventCreateWithFlags(&ev_forks[dev], hipEventDisableTiming) != hipSuccess ||
+                    hipEventCreateWithFlags(&ev_joins[dev], hipEventDisableTiming) != hipSuccess) return DWG_E_LAUNCH;
+            }
+            side = side_streams[dev]; ev_fork = ev_forks[dev]; ev_join = ev_joins[dev];
+        }
+        bool forked = false;
         while (first_table_level < L) {
             uint32_t hs = (uint32_t)(host_offsets[first_table_level + 1] - host_offsets[first_table_level]);
             if ((size_t)hs * 8 > 152 * 1024 || (uint64_t)B * 8 < (uint64_t)hs * 16) break;
             uint32_t ppb = hs * 8 > 64 * 1024 ? 8192 : 2048;
-            DWG_LAUNCH("grid_bwd_coarse", k_grid_bwd_coarse, dim3((B + ppb - 1) / ppb), dim3(256), (size_t)hs * 8, (hipStream_t)stream, p,
+            if (side && !forked) {          // everything queued on the caller's stream so far (zeroed gradients, inputs) happens first
+                if (hipEventRecord(ev_fork, main_stream) != hipSuccess || hipStreamWaitEvent(side, ev_fork, 0) != hipSuccess) return DWG_E_LAUNCH;
+                forked = true;
+            }
+            DWG_LAUNCH("grid_bwd_coarse", k_grid_bwd_coarse, dim3((B + ppb - 1) / ppb), dim3(256), (size_t)hs * 8, side ? side : main_stream, p,
                        first_table_level, ppb, grad, inputs, offsets, grad_embeddings);
             first_table_level++;
         }
+        if (!forked) side = nullptr;
+        else if (hipEventRecord(ev_join, side) != hipSuccess) return DWG_E_LAUNCH;
     }
     const uint32_t nchunks = (uint32_t)(((uint64_t)B * L + 255) / 256);
     uint32_t blocks = nchunks * 8u; if (blocks > 2048u) blocks = 2048u;       // persistent: 8 per CU, chunks pulled per physical XCD
     if (blocks < 64u) blocks = 64u;                                          // enough that every XCD receives workgroups
-    DWG_LAUNCH("grid_bwd", k_grid_bwd_owner, dim3(blocks), dim3(256), 0, (hipStream_t)stream, p, nchunks, grad, inputs, offsets,
+    DWG_LAUNCH("grid_bwd", k_grid_bwd_owner, dim3(blocks), dim3(256), 0, main_stream, p, nchunks, grad, inputs, offsets,
                grad_embeddings, dy_dx, grad_inputs, first_table_level, xcd_counters);
+    if (side && hipStreamWaitEvent(main_stream, ev_join, 0) != hipSuccess) return DWG_E_LAUNCH;       // join: later work sees both
     DWG_RETURN_IF_LAUNCH_FAILED();
     return DWG_OK;
 }
