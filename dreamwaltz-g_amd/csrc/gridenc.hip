@@ -292,6 +292,162 @@ static int check(uint32_t B, uint32_t D, uint32_t C, uint32_t L) {
     return DWG_OK;
 }
 
+// ---------------------------------------------------------------------------------------------------------------------
+// SLAB-BINNED table gradient (round 2, after the PMC passes of tools/pmc_grid.sh): on this chip EVERY global float atomic is
+// forwarded to the memory side -- TCC_EA0_ATOMIC == the number of atomics issued, L2 hit or not, workgroup scope or not, and a plain
+// load of the line first does not change it -- so the 51 M adds of a 100 k-point backward run at the ~30 G/s of the fabric's atomic
+// units (1.7 ms) whatever the XCD placement.  This path issues (almost) no global atomics: the (entry, value pair) contributions are
+// BINNED by 8192-entry slab of the table (count per workgroup in LDS -> scan -> scatter 16-byte records into slab order), then one
+// workgroup per slab accumulates its records in a 64 KiB LDS image with LDS atomics and writes the slab out with plain 16-byte
+// stores.  Only slabs with more than GS_MAXREC records (the densest few levels) are split over several workgroups that add their
+// images with global atomics.  The coarse levels keep their LDS-privatised kernel.  Needs a zero-filled gradient table (the
+// untouched entries of a plain-stored slab are written as zeros again) and B * L * 8 * 16 bytes of record workspace.
+// ---------------------------------------------------------------------------------------------------------------------
+#define GS_SLAB 8192u          // table entries (float2) per slab: 64 KiB of LDS
+#define GS_NWG 256u            // workgroups of the count / scatter passes (each owns a contiguous range of (point, level) chunks)
+#define GS_MAXREC 49152u       // records one accumulate workgroup takes
+struct GsUnit { uint32_t slab, begin, end, multi; };
+
+__device__ __forceinline__ uint32_t gs_wg_chunks(uint32_t nchunks) { return (nchunks + GS_NWG - 1u) / GS_NWG; }
+
+// passes 1 and 3 share this walk: SCATTER = false counts records per slab, true writes them at the reserved positions
+template <bool SCATTER>
+__global__ __launch_bounds__(256) void k_gs_bin(GridP p, uint32_t nchunks, uint32_t nslab, uint32_t first_entry, const float* __restrict__ grad,
+                                                const float* __restrict__ x, const int* __restrict__ offsets, uint32_t first_table_level,
+                                                uint32_t* __restrict__ counts /*[GS_NWG][nslab]: counts, then prefixes*/,
+                                                const uint32_t* __restrict__ slab_start, uint4* __restrict__ records,
+                                                const float* __restrict__ dy_dx, float* __restrict__ grad_x) {
+    extern __shared__ uint32_t cur[];       // [nslab]
+    const uint32_t wg = blockIdx.x;
+    for (uint32_t s_ = threadIdx.x; s_ < nslab; s_ += 256) cur[s_] = SCATTER ? slab_start[s_] + counts[(size_t)wg * nslab + s_] : 0u;
+    __syncthreads();
+    const uint32_t cpw = gs_wg_chunks(nchunks);
+    const uint32_t c0 = wg * cpw, c1 = min(nchunks, c0 + cpw);
+    for (uint32_t chunk = c0; chunk < c1; chunk++) {
+        const uint32_t t = chunk * 256u + threadIdx.x;
+        const uint32_t b = t / p.L, level = t - b * p.L;
+        const bool live = b < p.B;
+        const bool do_x = SCATTER && dy_dx && grad_x;
+        float gx[3] = {0.f, 0.f, 0.f};
+        if (live) {
+            const float* gsrc = p.layout ? grad + (size_t)b * p.L * 2 + level * 2 : grad + ((size_t)level * p.B + b) * 2;
+            const float g0 = gsrc[0], g1 = gsrc[1];
+            Cell c = locate(p, offsets, level, x[3 * b], x[3 * b + 1], x[3 * b + 2]);
+            if (!c.oob) {
+                if (level >= first_table_level) {
+                    const uint32_t lvl_entry = (uint32_t)offsets[level] - first_entry;
+#pragma unroll
+                    for (int idx = 0; idx < 8; idx++) {
+                        uint32_t cx = c.g[0] + (idx & 1), cy = c.g[1] + ((idx >> 1) & 1), cz = c.g[2] + ((idx >> 2) & 1);
+                        const uint32_t e = lvl_entry + (grid_index(p.gridtype, p.align_corners, c.hsize, c.res, cx, cy, cz) >> 1);
+                        const uint32_t slab = e / GS_SLAB;
+                        const uint32_t pos = atomicAdd(&cur[slab], 1u);
+                        if (SCATTER) {
+                            float w = ((idx & 1) ? c.w[0] : 1.f - c.w[0]) * ((idx & 2) ? c.w[1] : 1.f - c.w[1]) *
+                                      ((idx & 4) ? c.w[2] : 1.f - c.w[2]);
+                            records[pos] = make_uint4(e - slab * GS_SLAB, __float_as_uint(w * g0), __float_as_uint(w * g1), 0u);
+                        }
+                    }
+                }
+                if (do_x) {
+                    const float* dd = dy_dx + ((size_t)b * p.L + level) * 6;
+#pragma unroll
+                    for (int d = 0; d < 3; d++) gx[d] = g0 * dd[2 * d] + g1 * dd[2 * d + 1];
+                }
+            }
+        }
+        if (do_x) {
+            if (p.L == 16) {
+#pragma unroll
+                for (int d = 0; d < 3; d++) {
+                    float v = gx[d];
+                    v += __shfl_xor(v, 1); v += __shfl_xor(v, 2); v += __shfl_xor(v, 4); v += __shfl_xor(v, 8);
+                    gx[d] = v;
+                }
+                if (live && level == 0) { grad_x[3 * b] = gx[0]; grad_x[3 * b + 1] = gx[1]; grad_x[3 * b + 2] = gx[2]; }
+            } else if (live) {
+                atomicAdd(&grad_x[3 * b], gx[0]); atomicAdd(&grad_x[3 * b + 1], gx[1]); atomicAdd(&grad_x[3 * b + 2], gx[2]);
+            }
+        }
+    }
+    if (!SCATTER) {
+        __syncthreads();
+        for (uint32_t s_ = threadIdx.x; s_ < nslab; s_ += 256) counts[(size_t)wg * nslab + s_] = cur[s_];
+    }
+}
+
+// pass 2 (one workgroup): per slab the exclusive prefix over the workgroups' counts (in place), the slab's start, and the work units
+__global__ __launch_bounds__(1024) void k_gs_scan(uint32_t nslab, uint32_t* __restrict__ counts, uint32_t* __restrict__ slab_start /*[nslab+1]*/,
+                                                  GsUnit* __restrict__ units, uint32_t* __restrict__ n_units) {
+    __shared__ uint32_t tot[1024], ucnt[1024];
+    __shared__ uint32_t carry_t, carry_u;
+    const uint32_t tid = threadIdx.x;
+    if (tid == 0) { carry_t = 0u; carry_u = 0u; }
+    __syncthreads();
+    for (uint32_t base = 0; base < nslab; base += 1024u) {
+        const uint32_t s_ = base + tid;
+        uint32_t run = 0;
+        if (s_ < nslab) {
+            for (uint32_t w0 = 0; w0 < GS_NWG; w0 += 16u) {     // 16 independent loads in flight, then their prefixes
+                uint32_t c[16];
+#pragma unroll
+                for (int i = 0; i < 16; i++) c[i] = counts[(size_t)(w0 + i) * nslab + s_];
+#pragma unroll
+                for (int i = 0; i < 16; i++) { counts[(size_t)(w0 + i) * nslab + s_] = run; run += c[i]; }
+            }
+        }
+        const uint32_t nu = s_ < nslab ? (run > GS_MAXREC ? (run + GS_MAXREC - 1u) / GS_MAXREC : 1u) : 0u;
+        tot[tid] = run; ucnt[tid] = nu;
+        __syncthreads();
+        for (uint32_t off = 1; off < 1024u; off <<= 1) {            // inclusive scans of both
+            const uint32_t a = tid >= off ? tot[tid - off] : 0u, u = tid >= off ? ucnt[tid - off] : 0u;
+            __syncthreads();
+            tot[tid] += a; ucnt[tid] += u;
+            __syncthreads();
+        }
+        const uint32_t start = carry_t + tot[tid] - run, ustart = carry_u + ucnt[tid] - nu;
+        if (s_ < nslab) {
+            slab_start[s_] = start;
+            for (uint32_t u = 0; u < nu; u++) {
+                GsUnit g;
+                g.slab = s_; g.begin = start + u * GS_MAXREC; g.end = min(start + run, g.begin + GS_MAXREC); g.multi = nu > 1u ? 1u : 0u;
+                units[ustart + u] = g;
+            }
+        }
+        __syncthreads();
+        if (tid == 1023) { carry_t += tot[1023]; carry_u += ucnt[1023]; }
+        __syncthreads();
+    }
+    if (tid == 0) { slab_start[nslab] = carry_t; *n_units = carry_u; }
+}
+
+// pass 4: one workgroup per unit
+__global__ __launch_bounds__(256) void k_gs_accumulate(uint32_t first_entry, uint32_t total_entries, const GsUnit* __restrict__ units,
+                                                       const uint32_t* __restrict__ n_units, const uint4* __restrict__ records,
+                                                       float* __restrict__ grad_table) {
+    extern __shared__ float tab[];          // [GS_SLAB * 2]
+    if (blockIdx.x >= *n_units) return;
+    const GsUnit u = units[blockIdx.x];
+    for (uint32_t e = threadIdx.x; e < GS_SLAB * 2u; e += 256) tab[e] = 0.f;
+    __syncthreads();
+    for (uint32_t r = u.begin + threadIdx.x; r < u.end; r += 256) {
+        const uint4 rec = records[r];
+        atomicAdd(&tab[2u * rec.x], __uint_as_float(rec.y));
+        atomicAdd(&tab[2u * rec.x + 1u], __uint_as_float(rec.z));
+    }
+    __syncthreads();
+    const uint32_t e0 = first_entry + u.slab * GS_SLAB;                     // first table entry of this slab
+    const uint32_t ne = min(GS_SLAB, total_entries - e0);
+    float* dst = grad_table + (size_t)e0 * 2;
+    if (!u.multi && ((uintptr_t)dst & 15) == 0) {
+        for (uint32_t q = threadIdx.x; q < ne / 2u; q += 256)               // two entries (16 bytes) per store
+            reinterpret_cast<float4*>(dst)[q] = make_float4(tab[4 * q], tab[4 * q + 1], tab[4 * q + 2], tab[4 * q + 3]);
+        if ((ne & 1u) && threadIdx.x == 0) { dst[2 * (ne - 1)] = tab[2 * (ne - 1)]; dst[2 * (ne - 1) + 1] = tab[2 * (ne - 1) + 1]; }
+    } else {
+        for (uint32_t e = threadIdx.x; e < ne * 2u; e += 256) { const float v = tab[e]; if (v != 0.f) atomicAdd(dst + e, v); }
+    }
+}
+
 }  // namespace
 
 extern "C" {
@@ -425,6 +581,79 @@ int dwg_grid_encode_backward_owner(const float* grad, const float* inputs, const
     DWG_LAUNCH("grid_bwd", k_grid_bwd_owner, dim3(blocks), dim3(256), 0, main_stream, p, nchunks, grad, inputs, offsets,
                grad_embeddings, dy_dx, grad_inputs, first_table_level, xcd_counters);
     if (side && hipStreamWaitEvent(main_stream, ev_join, 0) != hipSuccess) return DWG_E_LAUNCH;       // join: later work sees both
+    DWG_RETURN_IF_LAUNCH_FAILED();
+    return DWG_OK;
+}
+
+size_t dwg_grid_backward_slabs_workspace_bytes(uint32_t B, uint32_t L, uint32_t total_entries) {
+    const size_t nslab = (total_entries + GS_SLAB - 1u) / GS_SLAB;
+    const size_t recs = (size_t)B * L * 8;
+    const size_t max_units = nslab + recs / GS_MAXREC + 2;
+    return dwg_align_up(recs * sizeof(uint4), 256) + dwg_align_up((size_t)GS_NWG * nslab * 4, 256) + dwg_align_up((nslab + 1) * 4, 256) +
+           dwg_align_up(max_units * sizeof(GsUnit), 256) + 256;
+}
+
+int dwg_grid_encode_backward_slabs(const float* grad, const float* inputs, const float* embeddings, const int32_t* offsets,
+                                   float* grad_embeddings, uint32_t B, uint32_t D, uint32_t C, uint32_t L, float S, uint32_t H,
+                                   const float* dy_dx, float* grad_inputs, uint32_t gridtype, uint32_t align_corners,
+                                   uint32_t interp, uint32_t grad_layout, const int32_t* host_offsets, void* workspace,
+                                   size_t workspace_bytes, dwg_stream_t stream) {
+    int rc = check(B, D, C, L);
+    if (rc) return rc;
+    if (B == 0) return DWG_OK;
+    (void)embeddings;
+    if (!grad || !inputs || !offsets || !host_offsets || !grad_embeddings || !workspace) return DWG_E_ARG;
+    if ((dy_dx == nullptr) != (grad_inputs == nullptr)) return DWG_E_ARG;
+    const uint32_t total_entries = (uint32_t)host_offsets[L];
+    if (workspace_bytes < dwg_grid_backward_slabs_workspace_bytes(B, L, total_entries)) return DWG_E_CAPACITY;
+    hipStream_t st = (hipStream_t)stream;
+    GridP p{B, L, S, H, gridtype, align_corners, interp, grad_layout};
+    if (grad_inputs && L != 16) {
+        if (hipMemsetAsync(grad_inputs, 0, (size_t)B * 3 * sizeof(float), st) != hipSuccess) return DWG_E_LAUNCH;
+    }
+    // coarse levels: LDS-privatised, as in the other paths
+    uint32_t first_table_level = 0;
+    if (B >= 16384) {
+        static bool attr_set = false;
+        if (!attr_set) {
+            hipFuncSetAttribute(reinterpret_cast<const void*>(&k_grid_bwd_coarse), hipFuncAttributeMaxDynamicSharedMemorySize, 152 * 1024);
+            attr_set = true;
+        }
+        while (first_table_level < L) {
+            uint32_t hs = (uint32_t)(host_offsets[first_table_level + 1] - host_offsets[first_table_level]);
+            if ((size_t)hs * 8 > 152 * 1024 || (uint64_t)B * 8 < (uint64_t)hs * 16) break;
+            uint32_t ppb = hs * 8 > 64 * 1024 ? 8192 : 2048;
+            DWG_LAUNCH("grid_bwd_coarse", k_grid_bwd_coarse, dim3((B + ppb - 1) / ppb), dim3(256), (size_t)hs * 8, st, p, first_table_level, ppb,
+                       grad, inputs, offsets, grad_embeddings);
+            first_table_level++;
+        }
+    }
+    const uint32_t nchunks = (uint32_t)(((uint64_t)B * L + 255) / 256);
+    if (first_table_level >= L) {           // nothing left for the table pass; the input gradient still needs its walk
+        first_table_level = L;
+    }
+    const uint32_t first_entry = (uint32_t)host_offsets[first_table_level < L ? first_table_level : L];
+    const uint32_t nslab = (total_entries - first_entry + GS_SLAB - 1u) / GS_SLAB > 0 ? (total_entries - first_entry + GS_SLAB - 1u) / GS_SLAB : 1u;
+    const size_t recs = (size_t)B * L * 8;
+    const size_t max_units = (size_t)nslab + recs / GS_MAXREC + 2;
+    unsigned char* w = reinterpret_cast<unsigned char*>(workspace);
+    uint4* records = reinterpret_cast<uint4*>(w); w += dwg_align_up(recs * sizeof(uint4), 256);
+    uint32_t* counts = reinterpret_cast<uint32_t*>(w); w += dwg_align_up((size_t)GS_NWG * ((total_entries + GS_SLAB - 1u) / GS_SLAB) * 4, 256);
+    uint32_t* slab_start = reinterpret_cast<uint32_t*>(w); w += dwg_align_up(((size_t)(total_entries + GS_SLAB - 1u) / GS_SLAB + 1) * 4, 256);
+    GsUnit* units = reinterpret_cast<GsUnit*>(w); w += dwg_align_up(((size_t)(total_entries + GS_SLAB - 1u) / GS_SLAB + recs / GS_MAXREC + 2) * sizeof(GsUnit), 256);
+    uint32_t* n_units = reinterpret_cast<uint32_t*>(w);
+    static bool attr2 = false;
+    if (!attr2) {
+        hipFuncSetAttribute(reinterpret_cast<const void*>(&k_gs_accumulate), hipFuncAttributeMaxDynamicSharedMemorySize, GS_SLAB * 8);
+        attr2 = true;
+    }
+    DWG_LAUNCH("grid_bwd_count", (k_gs_bin<false>), dim3(GS_NWG), dim3(256), (size_t)nslab * 4, st, p, nchunks, nslab, first_entry, grad, inputs,
+               offsets, first_table_level, counts, (const uint32_t*)slab_start, records, dy_dx, grad_inputs);
+    DWG_LAUNCH("grid_bwd_scan", k_gs_scan, dim3(1), dim3(1024), 0, st, nslab, counts, slab_start, units, n_units);
+    DWG_LAUNCH("grid_bwd_scatter", (k_gs_bin<true>), dim3(GS_NWG), dim3(256), (size_t)nslab * 4, st, p, nchunks, nslab, first_entry, grad, inputs,
+               offsets, first_table_level, counts, (const uint32_t*)slab_start, records, dy_dx, grad_inputs);
+    DWG_LAUNCH("grid_bwd", k_gs_accumulate, dim3((unsigned)max_units), dim3(256), (size_t)GS_SLAB * 8, st, first_entry, total_entries,
+               (const GsUnit*)units, (const uint32_t*)n_units, (const uint4*)records, grad_embeddings);
     DWG_RETURN_IF_LAUNCH_FAILED();
     return DWG_OK;
 }

@@ -126,11 +126,31 @@ def xcd_counters_for(device):
     return _xcd_counters[key]
 
 
+_SLAB_WS = {}     # device -> byte workspace of the slab-binned backward (grown on demand; one backward at a time per stream order)
+
+
+def slab_workspace_for(device, B, L, total_entries):
+    need = int(_lib.lib().dwg_grid_backward_slabs_workspace_bytes(B, L, total_entries))
+    ws = _SLAB_WS.get(str(device))
+    if ws is None or ws.numel() < need:
+        ws = torch.empty(need, dtype=torch.uint8, device=device)
+        _SLAB_WS[str(device)] = ws
+    return ws
+
+
 def grid_encode_backward(grad, inputs, embeddings, offsets, grad_embeddings, B, D, C, L, S, H, dy_dx, grad_inputs,
-                         gridtype, align_corners, interp, grad_layout=0, xcd_scratch=None, host_offsets=None, xcd_counters=None):
+                         gridtype, align_corners, interp, grad_layout=0, xcd_scratch=None, host_offsets=None, xcd_counters=None,
+                         slab_workspace=None):
     _need_cuda(inputs)
     p = _lib.ptr
     ho = host_offsets if host_offsets is not None else _host_offsets_of(offsets)
+    if slab_workspace is not None:
+        _lib.check(_lib.lib().dwg_grid_encode_backward_slabs(p(grad), p(inputs), p(embeddings), p(offsets), p(grad_embeddings), B, D,
+                                                             C, L, ctypes.c_float(S), H, p(dy_dx), p(grad_inputs), gridtype,
+                                                             int(bool(align_corners)), interp, grad_layout,
+                                                             ctypes.cast(ho, ctypes.c_void_p), p(slab_workspace), slab_workspace.numel(),
+                                                             _st(inputs)), "dwg_grid_encode_backward_slabs")
+        return
     if xcd_counters is not None:
         _lib.check(_lib.lib().dwg_grid_encode_backward_owner(p(grad), p(inputs), p(embeddings), p(offsets), p(grad_embeddings), B, D,
                                                              C, L, ctypes.c_float(S), H, p(dy_dx), p(grad_inputs), gridtype,
@@ -184,13 +204,16 @@ class _grid_encode(Function):
         grad_inputs = torch.empty_like(inputs) if dy_dx is not None else None
         # big batches: XCD-private accumulation of the table gradient (8 copies + one reduce pass beat memory-side atomics)
         import os
-        mode = os.environ.get("DWG_GRID_XCD_MODE", "owner") if (B >= 16384 and xcd_path_ok(inputs.device)) else "device"
+        mode = os.environ.get("DWG_GRID_XCD_MODE", "slabs") if B >= 16384 else "device"
+        if mode in ("owner", "copies") and not xcd_path_ok(inputs.device):
+            mode = "device"
         scratch = xcd_scratch_for(embeddings) if mode == "copies" else None
         counters = xcd_counters_for(inputs.device) if (mode == "owner" and grad_embeddings.data_ptr() % 128 == 0) else None
+        slab_ws = slab_workspace_for(inputs.device, B, L, int(embeddings.shape[0])) if mode == "slabs" else None
         try:
             grid_encode_backward(grad, inputs, embeddings, offsets, grad_embeddings, B, D, C, L, S, H, dy_dx, grad_inputs,
                                  gridtype, ctx.align_corners, interpolation, grad_layout=1, xcd_scratch=scratch,
-                                 host_offsets=ctx.host_offsets, xcd_counters=counters)
+                                 host_offsets=ctx.host_offsets, xcd_counters=counters, slab_workspace=slab_ws)
         except Exception:
             if scratch is not None:
                 scratch.zero_()        # a failed launch must not leave partial sums for the next call

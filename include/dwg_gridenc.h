@@ -58,6 +58,17 @@ int dwg_grid_encode_backward_owner(const float* grad, const float* inputs, const
                                    uint32_t interp, uint32_t grad_layout, const int32_t* host_offsets, uint32_t* xcd_counters,
                                    dwg_stream_t stream);
 
+/* The same gradients with the table part BINNED instead of scattered with atomics (gridenc.hip "slab-binned"): the contributions are
+ * sorted by 8192-entry slab of the table into `workspace` (dwg_grid_backward_slabs_workspace_bytes: B * L * 8 records of 16 bytes +
+ * small tables), accumulated per slab in LDS and written with plain stores.  grad_embeddings must be ZERO on entry (it is overwritten
+ * slab-wise, not accumulated into, except for the coarse levels and the few oversubscribed slabs); host_offsets is required. */
+size_t dwg_grid_backward_slabs_workspace_bytes(uint32_t B, uint32_t L, uint32_t total_entries);
+int dwg_grid_encode_backward_slabs(const float* grad, const float* inputs, const float* embeddings, const int32_t* offsets,
+                                   float* grad_embeddings, uint32_t B, uint32_t D, uint32_t C, uint32_t L, float S, uint32_t H,
+                                   const float* dy_dx, float* grad_inputs, uint32_t gridtype, uint32_t align_corners,
+                                   uint32_t interp, uint32_t grad_layout, const int32_t* host_offsets, void* workspace,
+                                   size_t workspace_bytes, dwg_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

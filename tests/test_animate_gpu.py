@@ -128,12 +128,12 @@ def test_grid_encoder_forward_backward(B, gridtype):
     assert _rel_l2(tc.grad, gt_ref) < 1e-4
     assert _rel_l2(xc.grad, gx_ref) < 2e-3   # d/dx is scaled by up to 4095 per level: fp32 cancellation
     if B >= 16384:
-        # the three table-gradient paths (XCD-owned lines [default], 8 XCD-private copies, device-scope atomics) agree, a second
-        # backward reproduces the first, and the private-copy scratch is left all zero
+        # the four table-gradient paths (slab-binned [default], XCD-owned lines, 8 XCD-private copies, device-scope atomics) agree, a
+        # second backward reproduces the first, and the private-copy scratch is left all zero
         import os
         from dreamwaltz_g_amd import gridencoder as ge
         assert ge.xcd_path_ok(tc.device)
-        for mode in ("copies", "owner", "device"):
+        for mode in ("slabs", "copies", "owner", "device", "slabs"):
             os.environ["DWG_GRID_XCD_MODE"] = mode
             try:
                 tc.grad = None; xc.grad = None
