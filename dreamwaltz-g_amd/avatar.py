@@ -188,7 +188,7 @@ class GeneralLinearBlendSkinning(nn.Module):
 
     # -- lazily built dense pieces (not on the hot path) -----------------------------------------------------------------
     def _joints(self, tr):
-        return self.J_template + torch.einsum('jcl,l->jc', self.joint_shape_dirs, tr.full_shape.reshape(-1))
+        return self.J_template + (self.joint_shape_dirs * tr.full_shape.reshape(1, 1, -1)).sum(-1)
 
     def _build_transform(self, tr, key):
         dev = self.v_template.device

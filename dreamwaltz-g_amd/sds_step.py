@@ -134,7 +134,7 @@ class SDSStep:
             verts = lbs.transform_vertices(tr, c["all_vertices"], lbs.v_template)
             A = tr.A
             J = lbs._joints(tr)
-            joints = torch.einsum('jkl,jl->jk', A[:, :3, :3], J) + A[:, :3, 3]        # A carries the global translation
+            joints = (A[:, :3, :3] * J[:, None, :]).sum(-1) + A[:, :3, 3]         # A carries the global translation (no library GEMM for 55 3x3 products)
             keypoints = torch.cat([joints, verts[c["pick"]]], dim=0)
             scene = cd_build(verts, c["triangles"])
             return c["gen"].export_pose_chw(keypoints, scene, extrinsic=self.data["extrinsic"][0], intrinsics=c["intrinsics"],

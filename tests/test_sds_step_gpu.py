@@ -166,7 +166,7 @@ def test_step_draws_its_condition_image_on_the_gpu():
         _, _, trf = lbs(**pose)
         verts = lbs.transform_vertices(trf, step.condition["all_vertices"], lbs.v_template)
         J = lbs._joints(trf)
-        joints = torch.einsum('jkl,jl->jk', trf.A[:, :3, :3], J) + trf.A[:, :3, 3]
+        joints = (trf.A[:, :3, :3] * J[:, None, :]).sum(-1) + trf.A[:, :3, 3]
         kp = torch.cat([joints, verts[step.condition["pick"]]], 0)
     cfgp = step.cfg.prompt
     rows = oc.pose_keypoints(kp.cpu().numpy(), verts.cpu().numpy(), step.condition["triangles"].cpu().numpy(), step.data["extrinsic"][0].cpu().numpy(),
