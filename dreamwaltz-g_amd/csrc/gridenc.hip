@@ -611,9 +611,12 @@ int dwg_grid_encode_backward_slabs(const float* grad, const float* inputs, const
     if (grad_inputs && L != 16) {
         if (hipMemsetAsync(grad_inputs, 0, (size_t)B * 3 * sizeof(float), st) != hipSuccess) return DWG_E_LAUNCH;
     }
-    // coarse levels: LDS-privatised, as in the other paths
+    // ALL levels go through the slabs by default: the dense coarse levels become a few oversubscribed slabs (split into units that add
+    // their LDS images with atomics) and cost nothing extra in the accumulate pass, where their separate LDS-privatised kernel was two
+    // poorly parallel launches of 0.13 ms each (c2 404 -> 464 steps/s).  DWG_GRID_SLAB_COARSE=1 restores that kernel for them.
     uint32_t first_table_level = 0;
-    if (B >= 16384) {
+    static const bool coarse = getenv("DWG_GRID_SLAB_COARSE") != nullptr;
+    if (B >= 16384 && coarse) {
         static bool attr_set = false;
         if (!attr_set) {
             hipFuncSetAttribute(reinterpret_cast<const void*>(&k_grid_bwd_coarse), hipFuncAttributeMaxDynamicSharedMemorySize, 152 * 1024);
