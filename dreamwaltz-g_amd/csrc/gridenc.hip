@@ -297,15 +297,15 @@ static int check(uint32_t B, uint32_t D, uint32_t C, uint32_t L) {
 // forwarded to the memory side -- TCC_EA0_ATOMIC == the number of atomics issued, L2 hit or not, workgroup scope or not, and a plain
 // load of the line first does not change it -- so the 51 M adds of a 100 k-point backward run at the ~30 G/s of the fabric's atomic
 // units (1.7 ms) whatever the XCD placement.  This path issues (almost) no global atomics: the (entry, value pair) contributions are
-// BINNED by 8192-entry slab of the table (count per workgroup in LDS -> scan -> scatter 16-byte records into slab order), then one
-// workgroup per slab accumulates its records in a 64 KiB LDS image with LDS atomics and writes the slab out with plain 16-byte
+// BINNED by 4096-entry slab of the table (count per workgroup in LDS -> scan -> scatter 16-byte records into slab order), then one
+// workgroup per slab accumulates its records in a 32 KiB LDS image with LDS atomics and writes the slab out with plain 16-byte
 // stores.  Only slabs with more than GS_MAXREC records (the densest few levels) are split over several workgroups that add their
 // images with global atomics.  The coarse levels keep their LDS-privatised kernel.  Needs a zero-filled gradient table (the
 // untouched entries of a plain-stored slab are written as zeros again) and B * L * 8 * 16 bytes of record workspace.
 // ---------------------------------------------------------------------------------------------------------------------
-#define GS_SLAB 8192u          // table entries (float2) per slab: 64 KiB of LDS
+#define GS_SLAB 4096u          // table entries (float2) per slab: 32 KiB of LDS (four accumulate workgroups per CU)
 #define GS_NWG 256u            // workgroups of the count / scatter passes (each owns a contiguous range of (point, level) chunks)
-#define GS_MAXREC 49152u       // records one accumulate workgroup takes
+#define GS_MAXREC 32768u       // records one accumulate workgroup takes
 struct GsUnit { uint32_t slab, begin, end, multi; };
 
 __device__ __forceinline__ uint32_t gs_wg_chunks(uint32_t nchunks) { return (nchunks + GS_NWG - 1u) / GS_NWG; }

@@ -59,7 +59,7 @@ int dwg_grid_encode_backward_owner(const float* grad, const float* inputs, const
                                    dwg_stream_t stream);
 
 /* The same gradients with the table part BINNED instead of scattered with atomics (gridenc.hip "slab-binned"): the contributions are
- * sorted by 8192-entry slab of the table into `workspace` (dwg_grid_backward_slabs_workspace_bytes: B * L * 8 records of 16 bytes +
+ * sorted by 4096-entry slab of the table into `workspace` (dwg_grid_backward_slabs_workspace_bytes: B * L * 8 records of 16 bytes +
  * small tables), accumulated per slab in LDS and written with plain stores.  grad_embeddings must be ZERO on entry (it is overwritten
  * slab-wise, not accumulated into, except for the coarse levels and the few oversubscribed slabs); host_offsets is required. */
 size_t dwg_grid_backward_slabs_workspace_bytes(uint32_t B, uint32_t L, uint32_t total_entries);
