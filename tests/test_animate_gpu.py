@@ -287,7 +287,8 @@ def test_meshbind_kernels_match_oracle():
     assert c2.numel() == 0 and torch.equal(p2, pos) and torch.equal(q2, q)
 
 
-def test_gridencoder_dropin_backend_fp32_and_half_buffers():
+@pytest.mark.parametrize("B", [3000, 20000])          # 20000: the slab-binned table gradient behind the same contract
+def test_gridencoder_dropin_backend_fp32_and_half_buffers(B):
     """dropin/_gridencoder.py as the reference's grid.py drives it (backend contract of src/bindings.cpp:5-9, [L,B,C] layout):
     fp32 buffers, and the HALF buffers grid.py allocates under autocast (embeddings / outputs / dy_dx / grad / grad_embeddings /
     grad_inputs in fp16, inputs fp32: grid.py:44-58,79-86) -- every buffer is written in its own dtype, nothing is reinterpreted."""
@@ -295,7 +296,7 @@ def test_gridencoder_dropin_backend_fp32_and_half_buffers():
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     sys.path.insert(0, os.path.join(root, "dropin"))
     import _gridencoder as backend
-    B, D, C, L = 3000, 3, 2, 16
+    D, C, L = 3, 2, 16
     x, table, offsets, pls, _ = _grid_case(B, 11)
     S, H = float(np.log2(pls)), 16
     off = torch.from_numpy(offsets).cuda()
@@ -313,9 +314,11 @@ def test_gridencoder_dropin_backend_fp32_and_half_buffers():
         got = out.float().permute(1, 0, 2).reshape(B, L * C).cpu().double()
         assert (got - ref).abs().max() < tol_o, (dt, float((got - ref).abs().max()))
         ge = torch.zeros_like(emb)
+        ge[5, 0] = 3.0                                                    # the backend ACCUMULATES into the caller's buffer
         gi = torch.zeros(B, D, device="cuda", dtype=dt)
         backend.grid_encode_backward(go.cuda().to(dt), x.cuda(), emb, off, ge, B, D, C, L, S, H, dy, gi, 1, False, 1)
         assert ge.dtype == dt and gi.dtype == dt and torch.isfinite(ge.float()).all() and torch.isfinite(gi.float()).all()
+        ge = ge.float(); ge[5, 0] -= 3.0
         assert _rel_l2(ge.float(), gt_ref) < tol_g, (dt, _rel_l2(ge.float(), gt_ref))
         assert _rel_l2(gi.float(), gx_ref) < max(tol_g, 5e-3), (dt, _rel_l2(gi.float(), gx_ref))
         assert bool((guard == 7.0).all())
