@@ -40,6 +40,7 @@ def parse():
     ap.add_argument("--res", type=int, default=None)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-guidance", action="store_true", help="raster+LBS sub-path only (not the headline workload)")
+    ap.add_argument("--frame-graph", action="store_true", help="config c5: replay each frame as one captured hipGraph (player.GraphedAnimation)")
     ap.add_argument("--eager", action="store_true", help="launch every kernel eagerly (no hipGraph replay of the denoiser/VAE plans)")
     ap.add_argument("--no-gpu-condition", action="store_true", help="fixed condition image instead of the per-step GPU OpenPose image of the posed body")
     ap.add_argument("--sync-pairs", action="store_true", help="exact pair-buffer sizing through a 16-byte read-back per frame")
@@ -170,7 +171,14 @@ def run_c5(args, dev):
     data = camera.make_camera(radius=2.0, azimuth=0.0, elevation=80.0, fovy=55.0, height=res, width=res, device=dev)
     poses = [synth.random_smpl_inputs(seed=i, device=dev) for i in range(240)]        # 240 pose frames
 
+    player = None
+    if args.frame_graph:        # the frame as ONE captured graph replayed per pose (player.GraphedAnimation); measured: no gain, the frame is GPU-bound
+        from dreamwaltz_g_amd import player as pl
+        player = pl.GraphedAnimation(scene, data, poses[0], warmup_poses=poses[:24])
+
     def frame(i):
+        if player is not None:
+            return player.replay(poses[i % 240])
         with torch.inference_mode():
             return scene.forward(data, smpl_observed_inputs=poses[i % 240], use_densifier=False, bg_mode=None)
     for i in range(args.warmup):
@@ -181,6 +189,10 @@ def run_c5(args, dev):
         frame(i)
     torch.cuda.synchronize()
     dt = time.perf_counter() - t0
+    graphed = player is not None
+    if graphed:                 # per-kernel timers need eager launches: same kernels, same inputs, after the timed region
+        assert player.check(), "a replayed frame was truncated by the frozen pair capacity"
+        player.close(); player = None
     _lib.prof_enable(True)
     ps = min(args.steps, 5)
     for i in range(ps):
@@ -194,6 +206,7 @@ def run_c5(args, dev):
            "config": {"workload": "c5: animate (LBS x2, grid encoder, MLPs, %d free + %d mesh-bound Gaussians) + raster forward %dx%d, "
                                   "inference_mode, 240 seeded random pose frames" % (N, M, res, res), "gaussians": G, "resolution": res},
            "roofline": raster_report(prof, G, Kref, K, res * res, ps),
+           "launch_mode": "one hipGraph per frame (player.GraphedAnimation); kernel timers from eager frames after the timed region" if graphed else "eager",
            "kernel_ms_per_step": {k: round(v[1] / ps, 4) for k, v in sorted(prof.items(), key=lambda kv: -kv[1][1])[:20]}}
     print(json.dumps(out))
 

@@ -21,7 +21,7 @@ class RasterSettingsC(ctypes.Structure):
         ("sh_degree", ctypes.c_int32), ("sh_coeffs", ctypes.c_int32),
         ("prefiltered", ctypes.c_int32), ("debug", ctypes.c_int32),
         ("bg", ctypes.c_void_p), ("viewmatrix", ctypes.c_void_p), ("projmatrix", ctypes.c_void_p),
-        ("campos", ctypes.c_void_p),
+        ("campos", ctypes.c_void_p), ("visit_order", ctypes.c_void_p),
     ]
 
 

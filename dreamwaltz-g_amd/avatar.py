@@ -170,9 +170,11 @@ class GeneralLinearBlendSkinning(nn.Module):
         the loader's condition image and `animate` both ask for the observed pose in one step."""
         args = (betas, body_pose, global_orient, left_hand_pose, right_hand_pose, jaw_pose, leye_pose, reye_pose, expression, transl,
                 flame_betas, flame_expression)
-        key = tuple((id(a), a._version) if torch.is_tensor(a) else a for a in args)
+        # (inference tensors carry no version counter: calls made with them are simply not remembered)
+        cacheable = extra_betas is None and not any(torch.is_tensor(a) and a.is_inference() for a in args)
+        key = tuple((id(a), a._version) if torch.is_tensor(a) else a for a in args) if cacheable else None
         last = getattr(self, "_last_forward", None)
-        if extra_betas is None and last is not None and last[0] == key:
+        if cacheable and last is not None and last[0] == key:
             return last[2]
         full_shape = self.get_full_shape(betas=betas, expression=expression, extra_betas=extra_betas)
         with torch.no_grad():
@@ -182,7 +184,7 @@ class GeneralLinearBlendSkinning(nn.Module):
         tr = LBSTransforms(self, A, R, full_shape, transl, full_pose)
         transform_V = _VertexTransform(self, tr, lambda: self._dense_transform_V(tr))
         transform_J = _LazyRigidTransform(lambda: self._dense_transform_J(tr))
-        if extra_betas is None:
+        if cacheable:
             self._last_forward = (key, args, (transform_J, transform_V, tr))       # `args` keeps the tensors (and their ids) alive
         return transform_J, transform_V, tr
 

@@ -48,6 +48,7 @@ struct Params {
     const float* view;
     const float* proj;
     const float* campos;
+    const int32_t* visit_order;         // permutation in which the binning stages walk the Gaussians (NULL: index order)
 };
 
 // header words of the geometry workspace
@@ -302,6 +303,7 @@ __global__ __launch_bounds__(256) void k_preprocess(Params p, const float* __res
     int i = blockIdx.x * 256 + threadIdx.x;
     const bool live_thread = i < p.G;
     if (!live_thread) i = 0;
+    else if (p.visit_order) i = p.visit_order[i];
     const float* view = cam; const float* proj = cam + 16;
     float3 pos = make_float3(means3D[3 * i], means3D[3 * i + 1], means3D[3 * i + 2]);
     int radius = 0;
@@ -431,6 +433,7 @@ __global__ __launch_bounds__(256) void k_scatter(Params p, const float4* __restr
     BlockSpan sp;
     sp.by0 = sp.by1 = 0;
     if (i < G) {
+        if (p.visit_order) i = p.visit_order[i];
         const uint2 rc = rect[i];
         const int tx0 = (int)(rc.x & 0xffff), ty0 = (int)(rc.x >> 16), tx1 = (int)(rc.y & 0xffff), ty1 = (int)(rc.y >> 16);
         const float4 a = rec0[i], b = rec1[i];
@@ -1005,6 +1008,7 @@ static int make_params(const dwg_raster_settings* cfg, int G, Params* p) {
     p->scale_mod = cfg->scale_modifier;
     p->sh_degree = cfg->sh_degree; p->sh_coeffs = cfg->sh_coeffs;
     p->bg = cfg->bg; p->view = cfg->viewmatrix; p->proj = cfg->projmatrix; p->campos = cfg->campos;
+    p->visit_order = cfg->visit_order;
     return DWG_OK;
 }
 

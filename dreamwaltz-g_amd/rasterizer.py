@@ -47,6 +47,7 @@ class PairCapacity:
         self.event = None
         self.pending = False
         self.overflow = False
+        self.frozen = False              # True: fixed capacity, no events, no host waits (a frame captured into a graph, see player.py)
         self.last_num_pairs = 0          # pairs after exact culling (what the buffers hold)
         self.last_num_pairs_ref = 0      # sum of 16x16 reference tiles touched (the K of SURVEY 8d's byte formula)
 
@@ -54,7 +55,7 @@ class PairCapacity:
         self.cap = max(self.cap, int(K * self.headroom), self.min_pairs)
 
     def resolve(self):
-        if not self.pending:
+        if not self.pending or self.frozen:
             return
         self.event.synchronize()
         self.pending = False
@@ -98,7 +99,8 @@ def _stream(device):
 class _RasterizeGaussians(torch.autograd.Function):
     @staticmethod
     def forward(ctx, means3D, means2D, sh, colors_precomp, opacities, scales, rotations, cov3Ds_precomp,
-                raster_settings: GaussianRasterizationSettings, pair_state: Optional[PairCapacity], info: dict):
+                raster_settings: GaussianRasterizationSettings, pair_state: Optional[PairCapacity], info: dict,
+                visit_order: Optional[torch.Tensor] = None):
         if not means3D.is_cuda:
             raise RuntimeError("dreamwaltz_g_amd rasterizer runs on the GPU only (HIP kernels); got a CPU tensor")
         L = _lib.lib()
@@ -119,6 +121,10 @@ class _RasterizeGaussians(torch.autograd.Function):
         keep = []
         M = int(sh.shape[1]) if sh is not None else 0
         cfg = _settings_struct(raster_settings, device, M, keep)
+        if visit_order is not None:         # binning walks the Gaussians in this order (a permutation; the images do not depend on it)
+            if visit_order.dtype != torch.int32 or visit_order.device != device or visit_order.numel() != G or not visit_order.is_contiguous():
+                raise ValueError("visit_order: a contiguous int32 permutation of the %d Gaussians on %s" % (G, device))
+            cfg.visit_order = visit_order.data_ptr()
         gb, pb, ib = ctypes.c_size_t(), ctypes.c_size_t(), ctypes.c_size_t()
         _lib.check(L.dwg_raster_workspace_sizes(G, H, W, 0, ctypes.byref(gb), ctypes.byref(pb), ctypes.byref(ib)),
                    "dwg_raster_workspace_sizes")
@@ -156,8 +162,9 @@ class _RasterizeGaussians(torch.autograd.Function):
             if pair_state.host is None:
                 pair_state.host = torch.zeros(4, dtype=torch.int32).pin_memory()
             pair_state.host.copy_(ws_geom[:16].view(torch.int32), non_blocking=True)
-            ev = torch.cuda.Event(); ev.record(torch.cuda.current_stream(device))
-            pair_state.event, pair_state.pending = ev, True
+            if not pair_state.frozen:
+                ev = torch.cuda.Event(); ev.record(torch.cuda.current_stream(device))
+                pair_state.event, pair_state.pending = ev, True
         ctx.raster_settings = raster_settings
         ctx.cap = cap
         ctx.pair_state = pair_state
@@ -197,19 +204,38 @@ class _RasterizeGaussians(torch.autograd.Function):
                                          p(ws_grad), p(g_color), p(g_depth), p(g_alpha), p(d_means3D), p(d_means2D),
                                          p(d_sh), p(d_colors), p(d_opac), p(d_scales), p(d_rots), p(d_cov),
                                          _stream(device)), "dwg_raster_backward")
-        return d_means3D, d_means2D, d_sh, d_colors, d_opac, d_scales, d_rots, d_cov, None, None, None
+        return d_means3D, d_means2D, d_sh, d_colors, d_opac, d_scales, d_rots, d_cov, None, None, None, None
+
+
+def morton_order(positions: torch.Tensor, bits: int = 10) -> torch.Tensor:
+    """int32 permutation that walks `positions` [G,3] along a Z-order curve of their bounding box (3 x `bits` bits).  Gaussians that
+    are neighbours in the walk are neighbours in space, hence on screen: a workgroup of the binning stages then touches a few
+    hundred 8x8 blocks instead of thousands, and its block-private histogram merges the global atomics (include/dwg_raster.h,
+    `visit_order`).  A handful of small torch launches; callers refresh it every few dozen frames, not per frame."""
+    with torch.no_grad():
+        p = positions.detach().float()
+        lo, hi = p.amin(dim=0), p.amax(dim=0)
+        q = ((p - lo) / (hi - lo).clamp_min(1e-12) * float((1 << bits) - 1)).to(torch.int64).clamp_(0, (1 << bits) - 1)
+        if bits > 10:
+            raise ValueError("morton_order: at most 10 bits per axis")
+        for shift, mask in ((16, 0x030000FF), (8, 0x0300F00F), (4, 0x030C30C3), (2, 0x09249249)):      # spread the bits 3 apart
+            q = (q | (q << shift)) & mask
+        code = q[:, 0] | (q[:, 1] << 1) | (q[:, 2] << 2)
+        return torch.argsort(code).to(torch.int32).contiguous()
 
 
 def rasterize_gaussians(means3D, means2D, sh, colors_precomp, opacities, scales, rotations, cov3Ds_precomp,
-                        raster_settings, pair_state=None, info=None):
+                        raster_settings, pair_state=None, info=None, visit_order=None):
     return _RasterizeGaussians.apply(means3D, means2D, sh, colors_precomp, opacities, scales, rotations,
-                                     cov3Ds_precomp, raster_settings, pair_state, {} if info is None else info)
+                                     cov3Ds_precomp, raster_settings, pair_state, {} if info is None else info, visit_order)
 
 
 class GaussianRasterizer(torch.nn.Module):
-    def __init__(self, raster_settings: GaussianRasterizationSettings, pair_state: Optional[PairCapacity] = None):
+    def __init__(self, raster_settings: GaussianRasterizationSettings, pair_state: Optional[PairCapacity] = None,
+                 visit_order: Optional[torch.Tensor] = None):
         super().__init__()
         self.raster_settings = raster_settings
+        self.visit_order = visit_order      # optional int32 permutation: the order in which binning walks the Gaussians (see morton_order)
         self.pair_state = pair_state        # None: exact sizing through a 16-byte read-back per frame (the reference's behaviour)
         self.info = {}                      # num_pairs / num_pairs_ref of the last synchronous forward
 
@@ -229,7 +255,7 @@ class GaussianRasterizer(torch.nn.Module):
                 (scales is not None or rotations is not None) and cov3D_precomp is not None):
             raise Exception("Please provide exactly one of either scale/rotation pair or precomputed 3D covariance!")
         return rasterize_gaussians(means3D, means2D, shs, colors_precomp, opacities, scales, rotations, cov3D_precomp,
-                                   rs, self.pair_state, self.info)
+                                   rs, self.pair_state, self.info, self.visit_order)
 
     @property
     def last_num_pairs(self):

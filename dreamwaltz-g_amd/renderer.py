@@ -3,12 +3,13 @@ same constructor, same `build_gaussian_rasterizer(data)` / `compute_colors` / `c
 `render(data, gaussians, return_2d_radii, rasterizer)` contract and output dict, bound to the HIP rasterizer (rasterizer.py)
 instead of the CUDA package."""
 import ctypes
+import os
 from typing import Optional
 
 import torch
 
 from . import _lib
-from .rasterizer import GaussianRasterizationSettings, GaussianRasterizer, PairCapacity
+from .rasterizer import GaussianRasterizationSettings, GaussianRasterizer, PairCapacity, morton_order
 from .rigid import mm4, quaternion_to_matrix
 
 # real spherical harmonics, degree <= 3 (core/gaussian/spherical_harmonics.py:5-40,117-172)
@@ -49,7 +50,7 @@ def get_colors(sh_features, directions, sh_levels):
 
 class GaussianRenderer:
     def __init__(self, sh_levels=4, bg_color=(0.0, 0.0, 0.0), compute_color_in_rasterizer=True,
-                 compute_covariance_in_rasterizer=True, async_pair_count=False) -> None:
+                 compute_covariance_in_rasterizer=True, async_pair_count=False, reorder_every: Optional[int] = None) -> None:
         self.sh_levels = sh_levels
         self.bg_color = torch.tensor(bg_color, dtype=torch.float32)
         self.compute_color_in_rasterizer = compute_color_in_rasterizer
@@ -60,6 +61,12 @@ class GaussianRenderer:
         self._pair_states = {}
         self._bg_dev = {}
         self.last_rasterizer = None
+        # Binning order (rasterizer.morton_order): refreshed from the current positions every `reorder_every` frames per Gaussian
+        # count (0: never -- index order); the images do not depend on it.  DWG_RASTER_REORDER overrides the default of 64.
+        if reorder_every is None:
+            reorder_every = int(os.environ.get("DWG_RASTER_REORDER", "64"))
+        self.reorder_every = int(reorder_every)
+        self._visit_orders = {}
 
     # -- capacity bookkeeping of the async mode ------------------------------------------------------------------------
     def pair_state(self, device, H, W) -> Optional[PairCapacity]:
@@ -112,6 +119,14 @@ class GaussianRenderer:
         settings = GaussianRasterizationSettings(**raster_settings, scale_modifier=1., prefiltered=False, debug=False)
         return GaussianRasterizer(raster_settings=settings, pair_state=self.pair_state(device, image_height, image_width))
 
+    def _visit_order_for(self, positions: torch.Tensor) -> torch.Tensor:
+        key = (str(positions.device), int(positions.shape[0]))
+        entry = self._visit_orders.get(key)
+        if entry is None or entry[1] >= self.reorder_every:
+            entry = self._visit_orders[key] = [morton_order(positions), 0]
+        entry[1] += 1
+        return entry[0]
+
     def compute_colors(self, sh_features, directions=None, positions=None, camera_positions=None, sh_levels=None, sh_rotations=None):
         """gaussian_renderer.py:72-105."""
         if directions is None:
@@ -149,6 +164,8 @@ class GaussianRenderer:
             gaussians.quaternions = None
             gaussians.scales = None
         means3D = gaussians.positions
+        if rasterizer.visit_order is None and self.reorder_every > 0 and means3D.is_cuda and means3D.shape[0] >= 4096:
+            rasterizer.visit_order = self._visit_order_for(means3D)
         screenspace_points = torch.zeros(means3D.shape[0], 3, dtype=means3D.dtype, requires_grad=True, device=means3D.device)
         if return_2d_radii:
             try:

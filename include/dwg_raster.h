@@ -43,6 +43,10 @@ typedef struct dwg_raster_settings {
     const float* viewmatrix; /* [16] device */
     const float* projmatrix; /* [16] device */
     const float* campos;     /* [3]  device (only read for SH colours) */
+    const int32_t* visit_order; /* [G] device or NULL: a PERMUTATION of 0..G-1, the order in which the binning stages walk the
+                                 * Gaussians.  Results do not depend on it (every per-block list is sorted by (depth, index)); a
+                                 * spatially coherent order makes the Gaussians of one workgroup share blocks, which is what the
+                                 * block-private binning histograms need to merge their global atomics.  NULL = index order. */
 } dwg_raster_settings;
 
 /* Byte sizes of the three caller-owned workspaces.

@@ -37,7 +37,7 @@ def oracle_backward(sc, g_color, g_depth=None, g_alpha=None, dtype=np.float64, *
     return oraster.backward(dtype=dtype, g_color=g_color, g_depth=g_depth, g_alpha=g_alpha, **d)
 
 
-def hip_render(sc, device="cuda", requires_grad=False, use_sh=None, sh_degree=0, use_cov=None):
+def hip_render(sc, device="cuda", requires_grad=False, use_sh=None, sh_degree=0, use_cov=None, visit_order=None):
     from dreamwaltz_g_amd.rasterizer import GaussianRasterizationSettings, GaussianRasterizer
     t = {k: (v.to(device) if torch.is_tensor(v) else v) for k, v in sc.items()}
     rs = GaussianRasterizationSettings(
@@ -60,7 +60,7 @@ def hip_render(sc, device="cuda", requires_grad=False, use_sh=None, sh_degree=0,
         kw.update(cov3D_precomp=leaves["cov3D"], scales=None, rotations=None)
     else:
         kw.update(scales=leaves["scales"], rotations=leaves["rotations"], cov3D_precomp=None)
-    color, radii, depth, alpha = GaussianRasterizer(rs)(**kw)
+    color, radii, depth, alpha = GaussianRasterizer(rs, visit_order=visit_order)(**kw)
     return dict(color=color, radii=radii, depth=depth, alpha=alpha, leaves=leaves)
 
 

@@ -187,3 +187,52 @@ def test_trainer_checkpoint_round_trip_has_the_reference_layout(tmp_path):
         t.save_checkpoint(str(tmp_path), full=False, max_keep_ckpts=2)
     import os
     assert sorted(os.listdir(tmp_path)) == ["step_000008.pth", "step_000009.pth"]
+
+
+def test_morton_order_is_a_permutation_that_keeps_neighbours_together():
+    from dreamwaltz_g_amd.rasterizer import morton_order
+    g = torch.Generator().manual_seed(3)
+    p = torch.rand(5000, 3, generator=g) * torch.tensor([2.0, 0.5, 1.0]) - 1.0
+    o = morton_order(p)
+    assert o.dtype == torch.int32 and o.is_contiguous() and sorted(o.tolist()) == list(range(5000))
+    step_sorted = (p[o.long()][1:] - p[o.long()][:-1]).norm(dim=1).mean()
+    step_index = (p[1:] - p[:-1]).norm(dim=1).mean()
+    assert step_sorted < 0.25 * step_index
+    # the code is the bit interleave of the quantised coordinates (x lowest)
+    q = ((p - p.amin(0)) / (p.amax(0) - p.amin(0)) * 1023).long().clamp(0, 1023)
+    code = torch.zeros(5000, dtype=torch.long)
+    for b in range(10):
+        for a in range(3):
+            code |= ((q[:, a] >> b) & 1) << (3 * b + a)
+    assert torch.equal(code[o.long()], torch.sort(code).values)
+    assert sorted(morton_order(torch.zeros(7, 3)).tolist()) == list(range(7))            # degenerate box: still a permutation
+    try:
+        morton_order(p, bits=11)
+        assert False
+    except ValueError:
+        pass
+
+
+def test_renderer_refreshes_its_binning_order_on_schedule():
+    from dreamwaltz_g_amd.renderer import GaussianRenderer
+    r = GaussianRenderer(reorder_every=3)
+    p = torch.rand(100, 3)
+    a = r._visit_order_for(p)
+    assert r._visit_order_for(p) is a and r._visit_order_for(p) is a
+    b = r._visit_order_for(p.flip(0))                     # 4th frame: recomputed from the positions it is given
+    assert b is not a and not torch.equal(a, b)
+    c = r._visit_order_for(torch.rand(50, 3))              # another Gaussian count: its own entry
+    assert c.numel() == 50 and r._visit_order_for(p.flip(0)) is b
+    assert GaussianRenderer(reorder_every=0).reorder_every == 0
+
+
+def test_frozen_pair_capacity_never_waits():
+    from dreamwaltz_g_amd.rasterizer import PairCapacity
+    st = PairCapacity()
+    st.seed(1000)
+    cap = st.cap
+    st.frozen, st.pending, st.event = True, True, None      # a frame inside a captured graph: no event to wait on
+    st.resolve()
+    assert st.cap == cap and st.pending
+    st.frozen, st.pending = False, False
+    assert st.consume_overflow() is False

@@ -1,0 +1,61 @@
+"""player.GraphedAnimation (config c5's frame as one captured hipGraph) against the eager Scene.forward on the same poses."""
+import pytest
+import torch
+
+import dwg_import  # noqa: F401
+
+pytestmark = pytest.mark.gpu
+
+
+def _scene(G, res, dev):
+    from dreamwaltz_g_amd import camera, configs, scene as sc, sds_step
+    cfg = configs.TrainConfig(); cfg.device = str(dev); cfg.render.bg_color = (0.5, 0.5, 0.5)
+    avatar, _, _ = sds_step.build_synthetic_avatar(G, dev, seed=0)
+    scene = sc.Scene(cfg, avatar, async_pair_count=True).to(dev).eval()
+    data = camera.make_camera(radius=2.0, azimuth=20.0, elevation=80.0, fovy=55.0, height=res, width=res, device=dev)
+    return scene, data
+
+
+def test_graphed_frames_equal_eager_frames():
+    from dreamwaltz_g_amd import player, synth
+    dev = torch.device("cuda:0")
+    scene, data = _scene(20000, 256, dev)
+    poses = [synth.random_smpl_inputs(seed=i, device=dev) for i in range(6)]
+    eager = []
+    with torch.inference_mode():
+        for p in poses:
+            o = scene.forward(data, smpl_observed_inputs=p, use_densifier=False, bg_mode=None)
+            eager.append({k: o[k].clone() for k in ("image", "alpha", "depth")})
+    pl = player.GraphedAnimation(scene, data, poses[0], warmup_poses=poses[:3])
+    for p, e in zip(poses, eager):
+        o = pl.replay(p)
+        assert pl.check()
+        K, Kref = pl.last_num_pairs
+        assert K > 0 and Kref > 0
+        for k in ("image", "alpha", "depth"):
+            assert torch.equal(o[k], e[k]), k                  # same kernels, same inputs, deterministic forward
+    # a capacity too small for the frame: the replay flags it, a recapture repairs it
+    pl._state.cap = 1024
+    pl.graph, pl.outputs = None, None
+    pl._capture_frozen()
+    pl.replay(poses[4])
+    assert not pl.check()
+    pl.recapture(poses[:3])
+    o = pl.replay(poses[4])
+    assert pl.check() and torch.equal(o["image"], eager[4]["image"])
+    pl.close()
+    with torch.inference_mode():                              # the eager path works again afterwards, with its own bookkeeping
+        o = scene.forward(data, smpl_observed_inputs=poses[5], use_densifier=False, bg_mode=None)
+    assert torch.equal(o["image"], eager[5]["image"])
+    assert not scene.renderer.consume_overflow()
+
+
+def test_player_needs_the_async_pair_count():
+    from dreamwaltz_g_amd import camera, configs, player, scene as sc, sds_step, synth
+    dev = torch.device("cuda:0")
+    cfg = configs.TrainConfig(); cfg.device = str(dev)
+    avatar, _, _ = sds_step.build_synthetic_avatar(2000, dev, seed=0)
+    scene = sc.Scene(cfg, avatar, async_pair_count=False).to(dev).eval()
+    data = camera.make_camera(height=64, width=64, device=dev)
+    with pytest.raises(ValueError):
+        player.GraphedAnimation(scene, data, synth.random_smpl_inputs(seed=0, device=dev))

@@ -141,3 +141,28 @@ def test_argument_errors():
     with pytest.raises(RuntimeError):
         r(means3D=sc["means3D"], means2D=torch.zeros(4, 3), opacities=sc["opacities"], colors_precomp=sc["colors"],
           scales=sc["scales"], rotations=sc["rotations"])  # CPU tensors: no CPU fallback
+
+
+@pytest.mark.parametrize("G,H,W", [(20000, 256, 256), (3000, 72, 136)])
+def test_visit_order_does_not_change_the_result(G, H, W):
+    """The binning stages may walk the Gaussians in any permutation (include/dwg_raster.h `visit_order`): every per-block list is
+    sorted by (depth, index), so images and radii are IDENTICAL and gradients agree to the summation order of the atomics."""
+    from dreamwaltz_g_amd.rasterizer import morton_order
+    sc = rc.make_scene(G, H, W, seed=3)
+    base = rc.hip_render(sc, requires_grad=True)
+    g = torch.Generator().manual_seed(5)
+    w = torch.randn(3, H, W, generator=g).cuda()
+    (base["color"] * w).sum().backward()
+    for order in (torch.randperm(G, generator=g).to(torch.int32).cuda(), morton_order(sc["means3D"].cuda())):
+        assert sorted(order.tolist()) == list(range(G))
+        out = rc.hip_render(sc, requires_grad=True, visit_order=order)
+        for k in ("color", "depth", "alpha", "radii"):
+            assert torch.equal(out[k], base[k]), k
+        (out["color"] * w).sum().backward()
+        for name in ("means3D", "scales", "rotations", "opacities", "colors"):
+            a, b = out["leaves"][name].grad, base["leaves"][name].grad
+            assert float((a - b).norm() / b.norm().clamp_min(1e-20)) < 1e-5, name
+    with pytest.raises(ValueError):
+        rc.hip_render(sc, visit_order=torch.arange(G - 1, dtype=torch.int32).cuda())
+    with pytest.raises(ValueError):
+        rc.hip_render(sc, visit_order=torch.arange(G).cuda())          # int64

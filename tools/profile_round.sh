@@ -3,26 +3,31 @@
 # (kernel-trace / stats in their own runs, PMC counters in their own runs -- gpurun refuses the combination)
 set -u
 R=${1:-r02}
+# DWG_PROFILE_PARTS: which passes to run (default all): eager graph pmc bench
+PARTS=${DWG_PROFILE_PARTS:-"eager graph pmc bench"}
+has() { case " $PARTS " in *" $1 "*) return 0;; *) return 1;; esac; }
 REPO=$(cd "$(dirname "$0")/.." && pwd)
 OUT=$REPO/gpurun_out/prof_$R
 mkdir -p $OUT $REPO/profiles
 cd /tmp && export TMPDIR=/tmp
 B="python $REPO/bench.py --no-cpu-baseline"
-timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/eager -o sds -- $B --steps 5 --warmup 2 --eager > $OUT/eager.log 2>&1
-timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/graph -o sds -- $B --steps 5 --warmup 2 > $OUT/graph.log 2>&1
-timeout 300 rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $OUT/pmc_fetch -o sds -- $B --steps 2 --warmup 1 --eager > $OUT/pmc_fetch.log 2>&1
-timeout 300 rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d $OUT/pmc_write -o sds -- $B --steps 2 --warmup 1 --eager > $OUT/pmc_write.log 2>&1
+has eager && timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/eager -o sds -- $B --steps 5 --warmup 2 --eager > $OUT/eager.log 2>&1
+has graph && timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/graph -o sds -- $B --steps 5 --warmup 2 > $OUT/graph.log 2>&1
+has pmc && timeout 300 rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $OUT/pmc_fetch -o sds -- $B --steps 2 --warmup 1 --eager > $OUT/pmc_fetch.log 2>&1
+has pmc && timeout 300 rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d $OUT/pmc_write -o sds -- $B --steps 2 --warmup 1 --eager > $OUT/pmc_write.log 2>&1
 cd $REPO
 find $OUT -name "*kernel_stats.csv" | head
-cp $(find $OUT/eager -name "*kernel_stats.csv" | head -1) profiles/${R}_sds_step_eager_kernel_stats.csv
-cp $(find $OUT/graph -name "*kernel_stats.csv" | head -1) profiles/${R}_sds_step_graph_kernel_stats.csv
-python tools/pmc_traffic.py $(find $OUT/pmc_fetch -name "*counter_collection.csv" | head -1) $(find $OUT/pmc_write -name "*counter_collection.csv" | head -1) profiles/${R}_pmc_traffic.json > $OUT/pmc_traffic.log 2>&1
-tail -2 $OUT/pmc_traffic.log
-grep '^{"metric"' $OUT/eager.log | tail -1 > profiles/${R}_sds_step_eager_bench_line.json
+has eager && cp $(find $OUT/eager -name "*kernel_stats.csv" | head -1) profiles/${R}_sds_step_eager_kernel_stats.csv
+has graph && cp $(find $OUT/graph -name "*kernel_stats.csv" | head -1) profiles/${R}_sds_step_graph_kernel_stats.csv
+has pmc && python tools/pmc_traffic.py $(find $OUT/pmc_fetch -name "*counter_collection.csv" | head -1) $(find $OUT/pmc_write -name "*counter_collection.csv" | head -1) profiles/${R}_pmc_traffic.json > $OUT/pmc_traffic.log 2>&1
+has pmc && tail -2 $OUT/pmc_traffic.log
+has eager && grep '^{"metric"' $OUT/eager.log | tail -1 > profiles/${R}_sds_step_eager_bench_line.json
 # bench lines (the default command, then the two other BASELINE configs)
+if has bench; then
 timeout 400 python bench.py > $OUT/bench_default.log 2>&1; grep '^{"metric"' $OUT/bench_default.log | tail -1 > profiles/${R}_bench_line.json
 timeout 200 python bench.py --config c2 > $OUT/bench_c2.log 2>&1; grep '^{"metric"' $OUT/bench_c2.log | tail -1 > profiles/${R}_bench_line_c2.json
 timeout 200 python bench.py --config c5 > $OUT/bench_c5.log 2>&1; grep '^{"metric"' $OUT/bench_c5.log | tail -1 > profiles/${R}_bench_line_c5.json
+fi
 # large raw traces stay on the box
 find $OUT -name "*kernel_trace.csv" -size +8M -delete; find $OUT -name "*counter_collection.csv" -size +8M -delete; find $OUT -name "*.db" -delete
 mkdir -p gpurun_out/profiles_$R && cp profiles/${R}_* gpurun_out/profiles_$R/
