@@ -33,8 +33,8 @@ TRAFFIC_JSON = os.path.join(ROOT, "profiles", "r02_pmc_traffic.json")
 def parse():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=20)
-    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--steps", type=int, default=None, help="default: 20 (config c3); 200 for c2 / c5, whose steps take ~2 ms")
+    ap.add_argument("--warmup", type=int, default=None, help="default: 3 (c3); 20 for c2 / c5")
     ap.add_argument("--config", choices=["c2", "c3", "c5"], default="c3")
     ap.add_argument("--gaussians", type=int, default=None)
     ap.add_argument("--res", type=int, default=None)
@@ -44,7 +44,13 @@ def parse():
     ap.add_argument("--eager", action="store_true", help="launch every kernel eagerly (no hipGraph replay of the denoiser/VAE plans)")
     ap.add_argument("--no-gpu-condition", action="store_true", help="fixed condition image instead of the per-step GPU OpenPose image of the posed body")
     ap.add_argument("--sync-pairs", action="store_true", help="exact pair-buffer sizing through a 16-byte read-back per frame")
-    return ap.parse_args()
+    args = ap.parse_args()
+    short = args.config in ("c2", "c5")          # a 20-step window of 2-ms steps is 40 ms: too short to time a host-fed loop
+    if args.steps is None:
+        args.steps = 200 if short else 20
+    if args.warmup is None:
+        args.warmup = 20 if short else 3
+    return args
 
 
 def cpu_baseline(args, G, res):
