@@ -56,6 +56,8 @@ class GraphedAnimation:
         """Capture one frame at the pair capacity the state holds now."""
         state = self._state
         state.overflow, state.pending, state.frozen = False, False, True
+        for entry in self.scene.renderer._visit_orders.values():               # the renderer's periodic refresh of the binning order must not
+            entry[1] = 0                                                       # fall into the two frames below (it would be replayed per frame)
         side = torch.cuda.Stream(device=self.device)
         side.wait_stream(torch.cuda.current_stream(self.device))
         with torch.cuda.stream(side):
