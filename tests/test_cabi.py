@@ -58,3 +58,31 @@ def test_no_kernel_spills_beyond_the_known_ones():
             if not lim or scratch > lim[0]:
                 bad.append((src, name, scratch))
     assert not bad, bad
+
+
+def _c_struct_layout(header, struct, fields, tmp_path):
+    """sizeof and offsetof of `struct` as the C compiler lays it out from include/<header> (the headers are plain C)."""
+    import subprocess
+    src = tmp_path / "layout.c"
+    exe = tmp_path / "layout"
+    lines = ['#include <stdio.h>', '#include <stddef.h>', '#include "%s"' % header, 'int main(void) {',
+             '  printf("%%zu\\n", sizeof(%s));' % struct]
+    lines += ['  printf("%%zu\\n", offsetof(%s, %s));' % (struct, f) for f in fields]
+    lines += ['  return 0; }']
+    src.write_text("\n".join(lines))
+    subprocess.run(["gcc", "-std=c99", "-I", os.path.join(ROOT, "include"), str(src), "-o", str(exe)], check=True)
+    out = subprocess.run([str(exe)], check=True, capture_output=True, text=True).stdout.split()
+    return int(out[0]), [int(v) for v in out[1:]]
+
+
+def test_ctypes_structures_have_the_layout_of_the_c_headers(tmp_path):
+    """The two structs that cross the C-ABI by pointer: the ctypes mirrors must agree with include/*.h field for field."""
+    from dreamwaltz_g_amd import gemm
+    for header, struct, mirror in (("dwg_raster.h", "dwg_raster_settings", _lib.RasterSettingsC), ("dwg_gemm.h", "dwg_gemm_desc", gemm.GemmDesc)):
+        names = [f[0] for f in mirror._fields_]
+        size, offsets = _c_struct_layout(header, struct, names, tmp_path)        # a field the header lacks fails to compile
+        assert size == ctypes.sizeof(mirror), (struct, size, ctypes.sizeof(mirror))
+        assert offsets == [getattr(mirror, n).offset for n in names], struct
+        # and the header has no field the mirror lacks: the last mirrored field ends where the struct (padding aside) ends
+        last = mirror._fields_[-1]
+        assert offsets[-1] + ctypes.sizeof(last[1]) + 8 > size, struct
