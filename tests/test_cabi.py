@@ -86,3 +86,15 @@ def test_ctypes_structures_have_the_layout_of_the_c_headers(tmp_path):
         # and the header has no field the mirror lacks: the last mirrored field ends where the struct (padding aside) ends
         last = mirror._fields_[-1]
         assert offsets[-1] + ctypes.sizeof(last[1]) + 8 > size, struct
+
+
+def test_every_header_compiles_standalone_as_c_and_cxx(tmp_path):
+    """include/*.h is the binding surface for a C, C++ or FFI caller: each header must stand on its own in both languages."""
+    import subprocess
+    for h in sorted(glob.glob(os.path.join(ROOT, "include", "*.h"))):
+        for lang, cc, std in (("c", "gcc", "-std=c99"), ("c++", "g++", "-std=c++11")):
+            src = tmp_path / ("t." + ("c" if lang == "c" else "cpp"))
+            src.write_text('#include "%s"\nint main(void) { return 0; }\n' % os.path.basename(h))
+            r = subprocess.run([cc, std, "-Wall", "-Werror", "-fsyntax-only", "-I", os.path.join(ROOT, "include"), str(src)],
+                               capture_output=True, text=True)
+            assert r.returncode == 0, (h, lang, r.stderr[:2000])
