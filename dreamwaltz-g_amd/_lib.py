@@ -73,6 +73,14 @@ SIGNATURES = {
                                              _vp, _i64, _i64, _f32, _vp]),
     "dwg_softmax_rows_forward": (ctypes.c_int, [_i32, _i32, _f32, _vp, _i64, _vp, _i64, _vp]),
     "dwg_softmax_rows_backward": (ctypes.c_int, [_i32, _i32, _f32, _vp, _i64, _vp, _i64, _vp, _i64, _vp]),
+    "dwg_groupnorm_forward_dt": (ctypes.c_int, [_i32, _i32, _i32, _i32, _i32, _vp, _vp, _vp, _f32, _i32, _vp, _vp, _vp, _vp]),
+    "dwg_groupnorm_backward_dt": (ctypes.c_int, [_i32, _i32, _i32, _i32, _i32, _vp, _vp, _vp, _vp, _vp, _f32, _i32, _vp, _vp, _vp, _vp, _vp]),
+    "dwg_layernorm_forward_dt": (ctypes.c_int, [_i32, _i32, _i32, _vp, _vp, _vp, _f32, _vp, _vp]),
+    "dwg_geglu_forward_dt": (ctypes.c_int, [_i32, _i64, _i32, _vp, _vp, _vp]),
+    "dwg_softmax_rows_forward_dt": (ctypes.c_int, [_i32, _i32, _i32, _f32, _vp, _i64, _vp, _i64, _vp]),
+    "dwg_softmax_rows_backward_dt": (ctypes.c_int, [_i32, _i32, _i32, _f32, _vp, _i64, _vp, _i64, _vp, _i64, _vp]),
+    "dwg_add_dt": (ctypes.c_int, [_i32, _i64, _vp, _vp, _vp, _vp]),
+    "dwg_cast_f32_to_dt": (ctypes.c_int, [_i32, _i64, _vp, _vp, _vp]),
     "dwg_mlp_wgrad_workspace_floats": (_sz, [_i32]),
     "dwg_mlp_wgrad": (ctypes.c_int, [_i32, _i32, _i32, _vp, _i32, _vp, _i32, _vp, _i32, _vp, _vp]),
     "dwg_concat_channels": (ctypes.c_int, [_i64, _i32, _i32, _vp, _vp, _vp, _vp]),

@@ -172,7 +172,8 @@ class GeneralLinearBlendSkinning(nn.Module):
                 flame_betas, flame_expression)
         # (inference tensors carry no version counter: calls made with them are simply not remembered)
         cacheable = extra_betas is None and not any(torch.is_tensor(a) and a.is_inference() for a in args)
-        key = tuple((id(a), a._version) if torch.is_tensor(a) else a for a in args) if cacheable else None
+        own = (self.betas,) if torch.is_tensor(getattr(self, "betas", None)) else ()       # the model's own shape coefficients are part of the result
+        key = tuple((id(a), a._version) if torch.is_tensor(a) else a for a in args + own) if cacheable else None
         last = getattr(self, "_last_forward", None)
         if cacheable and last is not None and last[0] == key:
             return last[2]
@@ -255,6 +256,10 @@ class MeshBindingGaussianModel(nn.Module):
     def __init__(self, vertex_coords, triangles, vertex_indices, n_per_triangle=6, init_scale_ratio=1.0, learn_bary_coords=True,
                  learn_vertex_coords=False, learn_scales=True):
         super().__init__()
+        if learn_vertex_coords:
+            # the native vertex-transform Function has no gradient w.r.t. the bound vertex coordinates and `animate` caches the canonical
+            # vertices: accepting the flag would build an Adam group that never moves (the shipped recipes keep it off, configs:202-205)
+            raise NotImplementedError("learn_vertex_coords=True: the mesh-bound vertex coordinates are frozen on this path")
         self.learn_bary_coords, self.learn_vertex_coords, self.learn_scales = learn_bary_coords, learn_vertex_coords, learn_scales
         self.register_buffer("predefined_vertex_indices", vertex_indices.long())
         self.register_buffer("triangles", triangles.long())
@@ -410,6 +415,7 @@ class DreamWaltzG(nn.Module):
         self._canonical_vertices = {}
         self.nerf_encoder._host_offsets_py = None
         self.lbs_model._subsets = []
+        self.lbs_model._last_forward = None          # keyed on the call's tensors only: the model's own betas / buffers may have changed
         for m in self.mesh_binding_gaussians.values():
             m._rebuild_topology()
 

@@ -220,11 +220,13 @@ int dwg_attention_forward(int32_t B, int32_t H, int32_t Nq, int32_t Nk, int32_t 
             scale * 1.4426950408889634f};
     dim3 grid(dwg_cdiv(Nq, 128), B * H), block(256);
     hipStream_t stream = (hipStream_t)stream_;
-    if (d <= 32) DWG_LAUNCH("flash_attn_d32", (k_flash_fwd<32, 32>), grid, block, 0, stream, p);
-    else if (d <= 48) DWG_LAUNCH("flash_attn_d48", (k_flash_fwd<48, 64>), grid, block, 0, stream, p);
-    else if (d <= 64) DWG_LAUNCH("flash_attn_d64", (k_flash_fwd<64, 64>), grid, block, 0, stream, p);
-    else if (d <= 96) DWG_LAUNCH("flash_attn_d96", (k_flash_fwd<96, 96>), grid, block, 0, stream, p);
-    else DWG_LAUNCH("flash_attn_d160", (k_flash_fwd<160, 160>), grid, block, 0, stream, p);
+    // algorithmic flops of the launch (QK^T and PV on the logical head size; the padded tile columns are not counted)
+    const double flops = 4.0 * B * H * (double)Nq * Nk * d;
+    if (d <= 32) DWG_LAUNCH_W("flash_attn_d32", "k_flash_fwd<32, 32>", flops, (k_flash_fwd<32, 32>), grid, block, 0, stream, p);
+    else if (d <= 48) DWG_LAUNCH_W("flash_attn_d48", "k_flash_fwd<48, 64>", flops, (k_flash_fwd<48, 64>), grid, block, 0, stream, p);
+    else if (d <= 64) DWG_LAUNCH_W("flash_attn_d64", "k_flash_fwd<64, 64>", flops, (k_flash_fwd<64, 64>), grid, block, 0, stream, p);
+    else if (d <= 96) DWG_LAUNCH_W("flash_attn_d96", "k_flash_fwd<96, 96>", flops, (k_flash_fwd<96, 96>), grid, block, 0, stream, p);
+    else DWG_LAUNCH_W("flash_attn_d160", "k_flash_fwd<160, 160>", flops, (k_flash_fwd<160, 160>), grid, block, 0, stream, p);
     DWG_RETURN_IF_LAUNCH_FAILED();
     return DWG_OK;
 }

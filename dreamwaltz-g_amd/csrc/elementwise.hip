@@ -324,6 +324,22 @@ __global__ __launch_bounds__(256) void k_cast_f32_bf16(long long n, const float*
     for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long long)gridDim.x * 256) dst[i] = (__bf16)src[i];
 }
 
+// the same two passes for any activation element type (fp16 / fp32 plans)
+template <typename T>
+__global__ __launch_bounds__(256) void k_add_t(long long n8, const T* __restrict__ a, const T* __restrict__ b, T* __restrict__ out) {
+    typedef T __attribute__((ext_vector_type(8))) V;
+    for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < n8; i += (long long)gridDim.x * 256) {
+        V x = reinterpret_cast<const V*>(a)[i], y = reinterpret_cast<const V*>(b)[i], o;
+#pragma unroll
+        for (int e = 0; e < 8; e++) o[e] = (T)((float)x[e] + (float)y[e]);
+        reinterpret_cast<V*>(out)[i] = o;
+    }
+}
+template <typename T>
+__global__ __launch_bounds__(256) void k_cast_f32_t(long long n, const float* __restrict__ src, T* __restrict__ dst) {
+    for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long long)gridDim.x * 256) dst[i] = (T)src[i];
+}
+
 static int grid_for(long long n) { long long b = (n + 255) / 256; if (b < 1) b = 1; if (b > 4096) b = 4096; return (int)b; }
 
 // out[b, 2i+py, 2j+px, :] = sub[py*2+px][b, i, j, :]  (16-byte pieces; C % 8 == 0)
@@ -411,6 +427,34 @@ int dwg_add_bf16(int64_t n, const void* a, const void* b, void* out, dwg_stream_
     if (n == 0) return DWG_OK;
     DWG_LAUNCH("add_bf16", k_add_bf16, dim3(grid_for(n / 8)), dim3(256), 0, (hipStream_t)stream, (long long)(n / 8), (const __bf16*)a,
                (const __bf16*)b, (__bf16*)out);
+    DWG_RETURN_IF_LAUNCH_FAILED();
+    return DWG_OK;
+}
+
+int dwg_add_dt(int32_t dtype, int64_t n, const void* a, const void* b, void* out, dwg_stream_t stream) {
+    if (dtype == DWG_DTYPE_BF16) return dwg_add_bf16(n, a, b, out, stream);
+    if (n < 0 || n % 8 || !a || !b || !out) return DWG_E_ARG;
+    if (n == 0) return DWG_OK;
+    if (dtype == DWG_DTYPE_F16)
+        DWG_LAUNCH("add_f16", k_add_t<_Float16>, dim3(grid_for(n / 8)), dim3(256), 0, (hipStream_t)stream, (long long)(n / 8), (const _Float16*)a,
+                   (const _Float16*)b, (_Float16*)out);
+    else if (dtype == DWG_DTYPE_F32)
+        DWG_LAUNCH("add_f32", k_add_t<float>, dim3(grid_for(n / 8)), dim3(256), 0, (hipStream_t)stream, (long long)(n / 8), (const float*)a,
+                   (const float*)b, (float*)out);
+    else return DWG_E_ARG;
+    DWG_RETURN_IF_LAUNCH_FAILED();
+    return DWG_OK;
+}
+
+int dwg_cast_f32_to_dt(int32_t dtype, int64_t n, const float* src, void* dst, dwg_stream_t stream) {
+    if (dtype == DWG_DTYPE_BF16) return dwg_cast_f32_to_bf16(n, src, dst, stream);
+    if (n < 0 || !src || !dst) return DWG_E_ARG;
+    if (n == 0) return DWG_OK;
+    if (dtype == DWG_DTYPE_F16)
+        DWG_LAUNCH("cast_f32_f16", k_cast_f32_t<_Float16>, dim3(grid_for(n)), dim3(256), 0, (hipStream_t)stream, (long long)n, src, (_Float16*)dst);
+    else if (dtype == DWG_DTYPE_F32)
+        DWG_LAUNCH("cast_f32_f32", k_cast_f32_t<float>, dim3(grid_for(n)), dim3(256), 0, (hipStream_t)stream, (long long)n, src, (float*)dst);
+    else return DWG_E_ARG;
     DWG_RETURN_IF_LAUNCH_FAILED();
     return DWG_OK;
 }

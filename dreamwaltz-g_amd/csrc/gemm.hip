@@ -997,7 +997,7 @@ static void dispatch_a(const GemmP& p, int amode, int bmode, int batch, hipStrea
 static int batch_of(const dwg_gemm_desc* d) { return d->batch1 * d->batch2; }
 static int tile_bn(const dwg_gemm_desc* d) {
     if (d->N <= 64) return 64;
-    if (d->dtype == DWG_DTYPE_BF16) {
+    {
         long long blocks128 = (long long)((d->M + 127) / 128) * ((d->N + 127) / 128) * batch_of(d);
         if (blocks128 < 256 && getenv("DWG_GEMM_NO_NARROW") == nullptr) return 64;
     }
@@ -1080,7 +1080,7 @@ int dwg_gemm(const dwg_gemm_desc* d, dwg_stream_t stream_) {
     hipStream_t stream = (hipStream_t)stream_;
     const char* name = d->name ? d->name : (d->conv_enabled ? "conv_igemm" : "gemm");
     bool narrow = d->N <= 64;
-    if (d->dtype == DWG_DTYPE_BF16 && !narrow) {
+    if (!narrow) {
         // mid-size layers (e.g. 64x64 latents, N = 320): 128x128 tiles give < 1 workgroup per CU and waste the last n-tile;
         // 128x64 tiles double the workgroup count (3 resident per CU) -- latency hiding beats operand reuse there
         long long blocks128 = (long long)((d->M + 127) / 128) * ((d->N + 127) / 128) * batch_of(d);
@@ -1138,10 +1138,18 @@ int dwg_gemm(const dwg_gemm_desc* d, dwg_stream_t stream_) {
         } else if (narrow) dispatch_a<T, 64>(p, amode, bmode, batch, stream, name);
         else dispatch_a<T, 128>(p, amode, bmode, batch, stream, name);
     } else {
+        // exact-f32 path (v_mfma_f32_32x32x2_f32): the avatar's MLPs, and every layer of the fp32 denoiser / VAE plans -- the precision the
+        // reference runs the 3DGS stage in (configs/__init__.py:236,241).  Register-staged generic kernel, incl. the im2col loader.
         typedef float T;
-        if (d->conv_enabled) return DWG_E_ARG;  // convolutions run in bf16
         long long ao[2] = {p.bA1, p.bA2}, bo[2] = {p.bB1, p.bB2};
-        int amode = pick_mode<T>(p.A, p.sam, p.sak, p.M, p.K, ao, 2);
+        int amode;
+        if (d->conv_enabled) {
+            if (d->conv_cin % 4 != 0 || ((uintptr_t)d->A % 16) != 0) return DWG_E_ARG;
+            if (d->A2 && (d->conv_cin1 % 4 != 0 || d->conv_cin1 <= 0 || d->conv_cin1 >= d->conv_cin || ((uintptr_t)d->A2 % 16) != 0))
+                return DWG_E_ARG;
+            if (d->K != d->conv_kh * d->conv_kw * d->conv_cin) return DWG_E_ARG;
+            amode = MODE_CONV;
+        } else amode = pick_mode<T>(p.A, p.sam, p.sak, p.M, p.K, ao, 2);
         int bmode = pick_mode<T>(p.B, p.sbn, p.sbk, p.N, p.K, bo, 2);
         if (narrow) dispatch_a<T, 64>(p, amode, bmode, batch, stream, name);
         else dispatch_a<T, 128>(p, amode, bmode, batch, stream, name);

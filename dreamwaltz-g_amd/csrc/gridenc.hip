@@ -639,6 +639,9 @@ int dwg_grid_encode_backward_slabs(const float* grad, const float* inputs, const
     const uint32_t nslab = (total_entries - first_entry + GS_SLAB - 1u) / GS_SLAB > 0 ? (total_entries - first_entry + GS_SLAB - 1u) / GS_SLAB : 1u;
     const size_t recs = (size_t)B * L * 8;
     const size_t max_units = (size_t)nslab + recs / GS_MAXREC + 2;
+    // limits of this path (callers fall back to dwg_grid_encode_backward): the binning kernels keep one u32 counter per slab in LDS
+    // (64 KiB without an opt-in: tables up to 67 M entries) and record positions are u32
+    if ((size_t)nslab * 4 > 64 * 1024 || recs > 0xffffffffull) return DWG_E_CAPACITY;
     unsigned char* w = reinterpret_cast<unsigned char*>(workspace);
     uint4* records = reinterpret_cast<uint4*>(w); w += dwg_align_up(recs * sizeof(uint4), 256);
     uint32_t* counts = reinterpret_cast<uint32_t*>(w); w += dwg_align_up((size_t)GS_NWG * ((total_entries + GS_SLAB - 1u) / GS_SLAB) * 4, 256);

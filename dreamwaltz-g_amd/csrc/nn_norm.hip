@@ -10,7 +10,8 @@
 
 namespace {
 
-typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
+// element type T of the activations: T (default plans), _Float16 (the reference's --optim.fp16 storage), float (its GS-stage fp32)
+template <typename T> using vec8 = T __attribute__((ext_vector_type(8)));
 
 __device__ __forceinline__ float silu_f(float z) { return z / (1.f + __expf(-z)); }
 __device__ __forceinline__ float silu_grad(float z) { float s = 1.f / (1.f + __expf(-z)); return s * (1.f + z * (1.f - s)); }
@@ -19,9 +20,9 @@ __device__ __forceinline__ float silu_grad(float z) { float s = 1.f / (1.f + __e
 // GroupNorm statistics: sums[b][g] = (sum x, sum x^2)  |  backward: (sum dyh, sum dyh*xhat)
 // grid (chunks, B); each block owns a contiguous pixel range of one image and ALL channels (full-row, coalesced reads).
 // ---------------------------------------------------------------------------------------------------------------------
-template <bool BWD>
-__global__ __launch_bounds__(256) void k_gn_reduce(int HW, int C, int G, int pix_per_block, const __bf16* __restrict__ x,
-                                                   const __bf16* __restrict__ dy, const float* __restrict__ stats,
+template <typename T, bool BWD>
+__global__ __launch_bounds__(256) void k_gn_reduce(int HW, int C, int G, int pix_per_block, const T* __restrict__ x,
+                                                   const T* __restrict__ dy, const float* __restrict__ stats,
                                                    const float* __restrict__ gamma, const float* __restrict__ beta, int silu,
                                                    float eps, float* __restrict__ sums /*[B][G][2]*/) {
     extern __shared__ __attribute__((aligned(16))) float lds[];   // [rows][Cb*2] partials for the current channel pass
@@ -56,12 +57,12 @@ __global__ __launch_bounds__(256) void k_gn_reduce(int HW, int C, int G, int pix
             }
             for (int p = p0 + prow; p < p1; p += rows) {
                 size_t off = ((size_t)b * HW + p) * C + (size_t)cc * 8;
-                bf16x8 xv = *reinterpret_cast<const bf16x8*>(x + off);
+                vec8<T> xv = *reinterpret_cast<const vec8<T>*>(x + off);
                 if (!BWD) {
 #pragma unroll
                     for (int e = 0; e < 8; e++) { float v = (float)xv[e]; s1[e] += v; s2[e] += v * v; }
                 } else {
-                    bf16x8 dv = *reinterpret_cast<const bf16x8*>(dy + off);
+                    vec8<T> dv = *reinterpret_cast<const vec8<T>*>(dy + off);
 #pragma unroll
                     for (int e = 0; e < 8; e++) {
                         float xh = ((float)xv[e] - mu[e]) * rs[e];
@@ -113,13 +114,13 @@ __global__ __launch_bounds__(1024) void k_gn_finalize(int chunks, int G, const f
 // backward apply: dx = rstd * (dyh - mean(dyh) - xhat * mean(dyh * xhat)) [+ residual]
 // Same thread layout as the reduction: a thread owns ONE 8-channel chunk (its affine parameters and group statistics live
 // in registers) and walks the block's pixel range, so the inner loop is load - 8 fma - store with 32-bit index math only.
-template <bool BWD>
-__global__ __launch_bounds__(256) void k_gn_apply(int HW, int C, int G, int pix_per_block, const __bf16* __restrict__ x,
-                                                  const __bf16* __restrict__ dy, const float* __restrict__ stats,
+template <typename T, bool BWD>
+__global__ __launch_bounds__(256) void k_gn_apply(int HW, int C, int G, int pix_per_block, const T* __restrict__ x,
+                                                  const T* __restrict__ dy, const float* __restrict__ stats,
                                                   const float* __restrict__ bsums, const float* __restrict__ gamma,
                                                   const float* __restrict__ beta, int silu, float eps,
-                                                  __bf16* __restrict__ out, const float* __restrict__ partials, int pchunks,
-                                                  float* __restrict__ sums_out, const __bf16* __restrict__ residual) {
+                                                  T* __restrict__ out, const float* __restrict__ partials, int pchunks,
+                                                  float* __restrict__ sums_out, const T* __restrict__ residual) {
     __shared__ float gstat[64 * 4];
     __shared__ float tot[128];
     const int b = blockIdx.y, tid = threadIdx.x;
@@ -164,39 +165,39 @@ __global__ __launch_bounds__(256) void k_gn_apply(int HW, int C, int G, int pix_
             ga[e] = gamma[ch]; be[e] = beta[ch]; mu[e] = gstat[4 * g]; rs[e] = gstat[4 * g + 1];
             m1[e] = BWD ? gstat[4 * g + 2] : 0.f; m2[e] = BWD ? gstat[4 * g + 3] : 0.f;
         }
-        const __bf16* xp = x + ((size_t)b * HW + p0 + prow) * C + (size_t)cc * 8;
-        const __bf16* dp = BWD ? dy + ((size_t)b * HW + p0 + prow) * C + (size_t)cc * 8 : nullptr;
-        const __bf16* rp = (BWD && residual) ? residual + ((size_t)b * HW + p0 + prow) * C + (size_t)cc * 8 : nullptr;
-        __bf16* op = out + ((size_t)b * HW + p0 + prow) * C + (size_t)cc * 8;
+        const T* xp = x + ((size_t)b * HW + p0 + prow) * C + (size_t)cc * 8;
+        const T* dp = BWD ? dy + ((size_t)b * HW + p0 + prow) * C + (size_t)cc * 8 : nullptr;
+        const T* rp = (BWD && residual) ? residual + ((size_t)b * HW + p0 + prow) * C + (size_t)cc * 8 : nullptr;
+        T* op = out + ((size_t)b * HW + p0 + prow) * C + (size_t)cc * 8;
         const size_t step = (size_t)rows * C;
         for (int p = p0 + prow; p < p1; p += rows) {
-            bf16x8 xv = *reinterpret_cast<const bf16x8*>(xp);
-            bf16x8 o;
+            vec8<T> xv = *reinterpret_cast<const vec8<T>*>(xp);
+            vec8<T> o;
             if (!BWD) {
 #pragma unroll
                 for (int e = 0; e < 8; e++) {
                     float z = ((float)xv[e] - mu[e]) * rs[e] * ga[e] + be[e];
-                    o[e] = (__bf16)(silu ? silu_f(z) : z);
+                    o[e] = (T)(silu ? silu_f(z) : z);
                 }
             } else {
-                bf16x8 dv = *reinterpret_cast<const bf16x8*>(dp);
+                vec8<T> dv = *reinterpret_cast<const vec8<T>*>(dp);
 #pragma unroll
                 for (int e = 0; e < 8; e++) {
                     float xh = ((float)xv[e] - mu[e]) * rs[e];
                     float gq = (float)dv[e];
                     if (silu) gq *= silu_grad(xh * ga[e] + be[e]);
                     gq *= ga[e];
-                    o[e] = (__bf16)(rs[e] * (gq - m1[e] - xh * m2[e]));
+                    o[e] = (T)(rs[e] * (gq - m1[e] - xh * m2[e]));
                 }
                 if (rp) {                       // skip-connection gradient added here instead of a separate add pass
-                    bf16x8 rv = *reinterpret_cast<const bf16x8*>(rp);
+                    vec8<T> rv = *reinterpret_cast<const vec8<T>*>(rp);
 #pragma unroll
-                    for (int e = 0; e < 8; e++) o[e] = (__bf16)((float)o[e] + (float)rv[e]);
+                    for (int e = 0; e < 8; e++) o[e] = (T)((float)o[e] + (float)rv[e]);
                     rp += step;
                 }
                 dp += step;
             }
-            *reinterpret_cast<bf16x8*>(op) = o;
+            *reinterpret_cast<vec8<T>*>(op) = o;
             xp += step; op += step;
         }
     }
@@ -205,8 +206,9 @@ __global__ __launch_bounds__(256) void k_gn_apply(int HW, int C, int G, int pix_
 // ---------------------------------------------------------------------------------------------------------------------
 // LayerNorm over the last dim (C % 8 == 0, C <= 2048): one wave per row, values kept in registers between the passes
 // ---------------------------------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void k_layernorm(int M, int C, const __bf16* __restrict__ x, const float* __restrict__ gamma,
-                                                   const float* __restrict__ beta, float eps, __bf16* __restrict__ y) {
+template <typename T>
+__global__ __launch_bounds__(256) void k_layernorm(int M, int C, const T* __restrict__ x, const float* __restrict__ gamma,
+                                                   const float* __restrict__ beta, float eps, T* __restrict__ y) {
     const int row = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
     if (row >= M) return;
     const int C8 = C / 8;
@@ -216,7 +218,7 @@ __global__ __launch_bounds__(256) void k_layernorm(int M, int C, const __bf16* _
     for (int it = 0; it < 4; it++) {
         int cc = lane + it * 64;
         if (cc < C8) {
-            bf16x8 xv = *reinterpret_cast<const bf16x8*>(x + (size_t)row * C + (size_t)cc * 8);
+            vec8<T> xv = *reinterpret_cast<const vec8<T>*>(x + (size_t)row * C + (size_t)cc * 8);
 #pragma unroll
             for (int e = 0; e < 8; e++) { v[it][e] = (float)xv[e]; s += v[it][e]; }
         }
@@ -238,35 +240,37 @@ __global__ __launch_bounds__(256) void k_layernorm(int M, int C, const __bf16* _
     for (int it = 0; it < 4; it++) {
         int cc = lane + it * 64;
         if (cc < C8) {
-            bf16x8 o;
+            vec8<T> o;
 #pragma unroll
-            for (int e = 0; e < 8; e++) { int ch = cc * 8 + e; o[e] = (__bf16)((v[it][e] - mean) * rstd * gamma[ch] + beta[ch]); }
-            *reinterpret_cast<bf16x8*>(y + (size_t)row * C + (size_t)cc * 8) = o;
+            for (int e = 0; e < 8; e++) { int ch = cc * 8 + e; o[e] = (T)((v[it][e] - mean) * rstd * gamma[ch] + beta[ch]); }
+            *reinterpret_cast<vec8<T>*>(y + (size_t)row * C + (size_t)cc * 8) = o;
         }
     }
 }
 
 // GEGLU: out[m][f] = x[m][f] * gelu(x[m][F + f])   (diffusers GEGLU: hidden, gate = proj(x).chunk(2); hidden * gelu(gate))
-__global__ __launch_bounds__(256) void k_geglu(long long M, int F, const __bf16* __restrict__ x, __bf16* __restrict__ out) {
+template <typename T>
+__global__ __launch_bounds__(256) void k_geglu(long long M, int F, const T* __restrict__ x, T* __restrict__ out) {
     const int F8 = F / 8;
     const long long n = M * F8;
     for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long long)gridDim.x * 256) {
         long long m = i / F8; int fc = (int)(i % F8);
-        bf16x8 a = *reinterpret_cast<const bf16x8*>(x + m * 2 * F + (size_t)fc * 8);
-        bf16x8 g = *reinterpret_cast<const bf16x8*>(x + m * 2 * F + F + (size_t)fc * 8);
-        bf16x8 o;
+        vec8<T> a = *reinterpret_cast<const vec8<T>*>(x + m * 2 * F + (size_t)fc * 8);
+        vec8<T> g = *reinterpret_cast<const vec8<T>*>(x + m * 2 * F + F + (size_t)fc * 8);
+        vec8<T> o;
 #pragma unroll
         for (int e = 0; e < 8; e++) {
             float gv = (float)g[e];
-            o[e] = (__bf16)((float)a[e] * 0.5f * gv * (1.f + dwg_erf_fast(gv * 0.70710678118654752f)));
+            o[e] = (T)((float)a[e] * 0.5f * gv * (1.f + dwg_erf_fast(gv * 0.70710678118654752f)));
         }
-        *reinterpret_cast<bf16x8*>(out + m * F + (size_t)fc * 8) = o;
+        *reinterpret_cast<vec8<T>*>(out + m * F + (size_t)fc * 8) = o;
     }
 }
 
 // Row softmax of fp32 scores (one wave per row, n <= 8192): P = softmax(scale * S) stored as bf16 (row stride ldp)
+template <typename T>
 __global__ __launch_bounds__(256) void k_softmax_rows(int rows, int n, float scale, const float* __restrict__ S, long long lds_,
-                                                      __bf16* __restrict__ P, long long ldp) {
+                                                      T* __restrict__ P, long long ldp) {
     const int row = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
     if (row >= rows) return;
     const float* s = S + (size_t)row * lds_;
@@ -277,22 +281,23 @@ __global__ __launch_bounds__(256) void k_softmax_rows(int rows, int n, float sca
     for (int j = lane; j < n; j += 64) sum += __expf(s[j] * scale - mx);
     sum = dwg_wave_sum_all(sum);
     const float inv = 1.f / sum;
-    __bf16* p = P + (size_t)row * ldp;
-    for (int j = lane; j < n; j += 64) p[j] = (__bf16)(__expf(s[j] * scale - mx) * inv);
+    T* p = P + (size_t)row * ldp;
+    for (int j = lane; j < n; j += 64) p[j] = (T)(__expf(s[j] * scale - mx) * inv);
 }
 
 // dS = scale * P * (dP - sum_j dP_j P_j)   (P bf16, dP fp32) -> bf16
-__global__ __launch_bounds__(256) void k_softmax_rows_bwd(int rows, int n, float scale, const __bf16* __restrict__ P, long long ldp,
-                                                          const float* __restrict__ dP, long long lddp, __bf16* __restrict__ dS,
+template <typename T>
+__global__ __launch_bounds__(256) void k_softmax_rows_bwd(int rows, int n, float scale, const T* __restrict__ P, long long ldp,
+                                                          const float* __restrict__ dP, long long lddp, T* __restrict__ dS,
                                                           long long ldds) {
     const int row = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
     if (row >= rows) return;
-    const __bf16* p = P + (size_t)row * ldp; const float* dp = dP + (size_t)row * lddp;
+    const T* p = P + (size_t)row * ldp; const float* dp = dP + (size_t)row * lddp;
     float dot = 0.f;
     for (int j = lane; j < n; j += 64) dot += (float)p[j] * dp[j];
     dot = dwg_wave_sum_all(dot);
-    __bf16* ds = dS + (size_t)row * ldds;
-    for (int j = lane; j < n; j += 64) ds[j] = (__bf16)(scale * (float)p[j] * (dp[j] - dot));
+    T* ds = dS + (size_t)row * ldds;
+    for (int j = lane; j < n; j += 64) ds[j] = (T)(scale * (float)p[j] * (dp[j] - dot));
 }
 
 static int gn_geometry(int HW, int C, int G, int* pix_per_block, int* chunks, size_t* lds) {
@@ -318,12 +323,21 @@ static void gn_reduce_geometry(int HW, int C, int* pix_per_block, int* chunks) {
 
 }  // namespace
 
+// element-type dispatch of the entry points (DWG_DTYPE_* of include/dwg_types.h)
+#define DWG_DT_SWITCH(DT, ...)                                                           \
+    switch (DT) {                                                                        \
+        case DWG_DTYPE_BF16: { typedef __bf16 T; __VA_ARGS__; } break;                   \
+        case DWG_DTYPE_F16: { typedef _Float16 T; __VA_ARGS__; } break;                  \
+        case DWG_DTYPE_F32: { typedef float T; __VA_ARGS__; } break;                     \
+        default: return DWG_E_ARG;                                                       \
+    }
+
 extern "C" {
 
 size_t dwg_groupnorm_workspace_floats(int32_t B, int32_t G) { return (size_t)(B > 0 ? B : 1) * GN_MAX_CHUNKS * (G > 0 ? G : 1) * 2; }
 
-int dwg_groupnorm_forward(int32_t B, int32_t HW, int32_t C, int32_t G, const void* x, const float* gamma, const float* beta,
-                          float eps, int32_t fuse_silu, void* y, float* stats, float* workspace, dwg_stream_t stream_) {
+int dwg_groupnorm_forward_dt(int32_t dtype, int32_t B, int32_t HW, int32_t C, int32_t G, const void* x, const float* gamma, const float* beta,
+                             float eps, int32_t fuse_silu, void* y, float* stats, float* workspace, dwg_stream_t stream_) {
     if (B <= 0 || HW <= 0 || !x || !gamma || !beta || !y || !stats || !workspace) return DWG_E_ARG;
     int ppb, chunks; size_t lds;
     int rc = gn_geometry(HW, C, G, &ppb, &chunks, &lds);
@@ -331,21 +345,27 @@ int dwg_groupnorm_forward(int32_t B, int32_t HW, int32_t C, int32_t G, const voi
     int rppb, rchunks;
     gn_reduce_geometry(HW, C, &rppb, &rchunks);
     hipStream_t stream = (hipStream_t)stream_;
-    DWG_LAUNCH("gn_stats", (k_gn_reduce<false>), dim3(rchunks, B), dim3(256), lds, stream, HW, C, G, rppb, (const __bf16*)x,
-               (const __bf16*)nullptr, (const float*)nullptr, gamma, beta, 0, eps, workspace);
     static const int fold_max = getenv("DWG_GN_FOLD") ? atoi(getenv("DWG_GN_FOLD")) : GN_FOLD_MAX_CHUNKS;
     const bool fold = rchunks <= fold_max && 2 * G * 4 <= 256;     // finalize folded into the apply pass
-    if (!fold) DWG_LAUNCH("gn_finalize", k_gn_finalize, dim3(B), dim3(1024), 0, stream, rchunks, G, (const float*)workspace, stats);
-    DWG_LAUNCH("gn_apply", (k_gn_apply<false>), dim3(chunks, B), dim3(256), 0, stream, HW, C, G, ppb, (const __bf16*)x,
-               (const __bf16*)nullptr, (const float*)stats, (const float*)nullptr, gamma, beta, fuse_silu, eps, (__bf16*)y,
-               fold ? (const float*)workspace : (const float*)nullptr, rchunks, stats, (const __bf16*)nullptr);
+    DWG_DT_SWITCH(dtype,
+        DWG_LAUNCH("gn_stats", (k_gn_reduce<T, false>), dim3(rchunks, B), dim3(256), lds, stream, HW, C, G, rppb, (const T*)x,
+                   (const T*)nullptr, (const float*)nullptr, gamma, beta, 0, eps, workspace);
+        if (!fold) DWG_LAUNCH("gn_finalize", k_gn_finalize, dim3(B), dim3(1024), 0, stream, rchunks, G, (const float*)workspace, stats);
+        DWG_LAUNCH("gn_apply", (k_gn_apply<T, false>), dim3(chunks, B), dim3(256), 0, stream, HW, C, G, ppb, (const T*)x,
+                   (const T*)nullptr, (const float*)stats, (const float*)nullptr, gamma, beta, fuse_silu, eps, (T*)y,
+                   fold ? (const float*)workspace : (const float*)nullptr, rchunks, stats, (const T*)nullptr))
     DWG_RETURN_IF_LAUNCH_FAILED();
     return DWG_OK;
 }
 
-int dwg_groupnorm_backward(int32_t B, int32_t HW, int32_t C, int32_t G, const void* x, const void* dy, const float* stats,
-                           const float* gamma, const float* beta, float eps, int32_t fuse_silu, void* dx, float* scratch,
-                           float* workspace, const void* residual, dwg_stream_t stream_) {
+int dwg_groupnorm_forward(int32_t B, int32_t HW, int32_t C, int32_t G, const void* x, const float* gamma, const float* beta,
+                          float eps, int32_t fuse_silu, void* y, float* stats, float* workspace, dwg_stream_t stream) {
+    return dwg_groupnorm_forward_dt(DWG_DTYPE_BF16, B, HW, C, G, x, gamma, beta, eps, fuse_silu, y, stats, workspace, stream);
+}
+
+int dwg_groupnorm_backward_dt(int32_t dtype, int32_t B, int32_t HW, int32_t C, int32_t G, const void* x, const void* dy, const float* stats,
+                              const float* gamma, const float* beta, float eps, int32_t fuse_silu, void* dx, float* scratch,
+                              float* workspace, const void* residual, dwg_stream_t stream_) {
     if (B <= 0 || HW <= 0 || !x || !dy || !stats || !gamma || !beta || !dx || !scratch || !workspace) return DWG_E_ARG;
     int ppb, chunks; size_t lds;
     int rc = gn_geometry(HW, C, G, &ppb, &chunks, &lds);
@@ -353,56 +373,83 @@ int dwg_groupnorm_backward(int32_t B, int32_t HW, int32_t C, int32_t G, const vo
     int rppb, rchunks;
     gn_reduce_geometry(HW, C, &rppb, &rchunks);
     hipStream_t stream = (hipStream_t)stream_;
-    DWG_LAUNCH("gn_bwd_stats", (k_gn_reduce<true>), dim3(rchunks, B), dim3(256), lds, stream, HW, C, G, rppb, (const __bf16*)x,
-               (const __bf16*)dy, stats, gamma, beta, fuse_silu, eps, workspace);
     static const int fold_max = getenv("DWG_GN_FOLD") ? atoi(getenv("DWG_GN_FOLD")) : GN_FOLD_MAX_CHUNKS;
     const bool fold = rchunks <= fold_max && 2 * G * 4 <= 256;
-    if (!fold) DWG_LAUNCH("gn_finalize", k_gn_finalize, dim3(B), dim3(1024), 0, stream, rchunks, G, (const float*)workspace, scratch);
-    DWG_LAUNCH("gn_bwd_apply", (k_gn_apply<true>), dim3(chunks, B), dim3(256), 0, stream, HW, C, G, ppb, (const __bf16*)x,
-               (const __bf16*)dy, stats, (const float*)scratch, gamma, beta, fuse_silu, eps, (__bf16*)dx,
-               fold ? (const float*)workspace : (const float*)nullptr, rchunks, scratch, (const __bf16*)residual);
+    DWG_DT_SWITCH(dtype,
+        DWG_LAUNCH("gn_bwd_stats", (k_gn_reduce<T, true>), dim3(rchunks, B), dim3(256), lds, stream, HW, C, G, rppb, (const T*)x,
+                   (const T*)dy, stats, gamma, beta, fuse_silu, eps, workspace);
+        if (!fold) DWG_LAUNCH("gn_finalize", k_gn_finalize, dim3(B), dim3(1024), 0, stream, rchunks, G, (const float*)workspace, scratch);
+        DWG_LAUNCH("gn_bwd_apply", (k_gn_apply<T, true>), dim3(chunks, B), dim3(256), 0, stream, HW, C, G, ppb, (const T*)x,
+                   (const T*)dy, stats, (const float*)scratch, gamma, beta, fuse_silu, eps, (T*)dx,
+                   fold ? (const float*)workspace : (const float*)nullptr, rchunks, scratch, (const T*)residual))
+    DWG_RETURN_IF_LAUNCH_FAILED();
+    return DWG_OK;
+}
+
+int dwg_groupnorm_backward(int32_t B, int32_t HW, int32_t C, int32_t G, const void* x, const void* dy, const float* stats,
+                           const float* gamma, const float* beta, float eps, int32_t fuse_silu, void* dx, float* scratch,
+                           float* workspace, const void* residual, dwg_stream_t stream) {
+    return dwg_groupnorm_backward_dt(DWG_DTYPE_BF16, B, HW, C, G, x, dy, stats, gamma, beta, eps, fuse_silu, dx, scratch, workspace, residual,
+                                     stream);
+}
+
+int dwg_layernorm_forward_dt(int32_t dtype, int32_t M, int32_t C, const void* x, const float* gamma, const float* beta, float eps, void* y,
+                             dwg_stream_t stream) {
+    if (M < 0 || C <= 0 || C % 8 || C > 2048 || !x || !gamma || !beta || !y) return DWG_E_ARG;
+    if (M == 0) return DWG_OK;
+    DWG_DT_SWITCH(dtype, DWG_LAUNCH("layernorm", k_layernorm<T>, dim3(dwg_cdiv(M, 4)), dim3(256), 0, (hipStream_t)stream, M, C, (const T*)x,
+                                    gamma, beta, eps, (T*)y))
     DWG_RETURN_IF_LAUNCH_FAILED();
     return DWG_OK;
 }
 
 int dwg_layernorm_forward(int32_t M, int32_t C, const void* x, const float* gamma, const float* beta, float eps, void* y,
                           dwg_stream_t stream) {
-    if (M < 0 || C <= 0 || C % 8 || C > 2048 || !x || !gamma || !beta || !y) return DWG_E_ARG;
+    return dwg_layernorm_forward_dt(DWG_DTYPE_BF16, M, C, x, gamma, beta, eps, y, stream);
+}
+
+int dwg_geglu_forward_dt(int32_t dtype, int64_t M, int32_t F, const void* x, void* out, dwg_stream_t stream) {
+    if (M < 0 || F <= 0 || F % 8 || !x || !out) return DWG_E_ARG;
     if (M == 0) return DWG_OK;
-    DWG_LAUNCH("layernorm", k_layernorm, dim3(dwg_cdiv(M, 4)), dim3(256), 0, (hipStream_t)stream, M, C, (const __bf16*)x, gamma,
-               beta, eps, (__bf16*)y);
+    long long n = M * (F / 8);
+    int blocks = (int)((n + 255) / 256); if (blocks > 4096) blocks = 4096;
+    DWG_DT_SWITCH(dtype, DWG_LAUNCH("geglu", k_geglu<T>, dim3(blocks), dim3(256), 0, (hipStream_t)stream, (long long)M, F, (const T*)x, (T*)out))
     DWG_RETURN_IF_LAUNCH_FAILED();
     return DWG_OK;
 }
 
 int dwg_geglu_forward(int64_t M, int32_t F, const void* x, void* out, dwg_stream_t stream) {
-    if (M < 0 || F <= 0 || F % 8 || !x || !out) return DWG_E_ARG;
-    if (M == 0) return DWG_OK;
-    long long n = M * (F / 8);
-    int blocks = (int)((n + 255) / 256); if (blocks > 4096) blocks = 4096;
-    DWG_LAUNCH("geglu", k_geglu, dim3(blocks), dim3(256), 0, (hipStream_t)stream, (long long)M, F, (const __bf16*)x, (__bf16*)out);
+    return dwg_geglu_forward_dt(DWG_DTYPE_BF16, M, F, x, out, stream);
+}
+
+int dwg_softmax_rows_forward_dt(int32_t dtype, int32_t rows, int32_t n, float scale, const float* S, int64_t lds, void* P, int64_t ldp,
+                                dwg_stream_t stream) {
+    if (rows < 0 || n <= 0 || !S || !P) return DWG_E_ARG;
+    if (rows == 0) return DWG_OK;
+    DWG_DT_SWITCH(dtype, DWG_LAUNCH("softmax_rows", k_softmax_rows<T>, dim3(dwg_cdiv(rows, 4)), dim3(256), 0, (hipStream_t)stream, rows, n, scale,
+                                    S, (long long)lds, (T*)P, (long long)ldp))
     DWG_RETURN_IF_LAUNCH_FAILED();
     return DWG_OK;
 }
 
 int dwg_softmax_rows_forward(int32_t rows, int32_t n, float scale, const float* S, int64_t lds, void* P, int64_t ldp,
                              dwg_stream_t stream) {
-    if (rows < 0 || n <= 0 || !S || !P) return DWG_E_ARG;
+    return dwg_softmax_rows_forward_dt(DWG_DTYPE_BF16, rows, n, scale, S, lds, P, ldp, stream);
+}
+
+int dwg_softmax_rows_backward_dt(int32_t dtype, int32_t rows, int32_t n, float scale, const void* P, int64_t ldp, const float* dP, int64_t lddp,
+                                 void* dS, int64_t ldds, dwg_stream_t stream) {
+    if (rows < 0 || n <= 0 || !P || !dP || !dS) return DWG_E_ARG;
     if (rows == 0) return DWG_OK;
-    DWG_LAUNCH("softmax_rows", k_softmax_rows, dim3(dwg_cdiv(rows, 4)), dim3(256), 0, (hipStream_t)stream, rows, n, scale, S,
-               (long long)lds, (__bf16*)P, (long long)ldp);
+    DWG_DT_SWITCH(dtype, DWG_LAUNCH("softmax_rows_bwd", k_softmax_rows_bwd<T>, dim3(dwg_cdiv(rows, 4)), dim3(256), 0, (hipStream_t)stream, rows, n,
+                                    scale, (const T*)P, (long long)ldp, dP, (long long)lddp, (T*)dS, (long long)ldds))
     DWG_RETURN_IF_LAUNCH_FAILED();
     return DWG_OK;
 }
 
 int dwg_softmax_rows_backward(int32_t rows, int32_t n, float scale, const void* P, int64_t ldp, const float* dP, int64_t lddp,
                               void* dS, int64_t ldds, dwg_stream_t stream) {
-    if (rows < 0 || n <= 0 || !P || !dP || !dS) return DWG_E_ARG;
-    if (rows == 0) return DWG_OK;
-    DWG_LAUNCH("softmax_rows_bwd", k_softmax_rows_bwd, dim3(dwg_cdiv(rows, 4)), dim3(256), 0, (hipStream_t)stream, rows, n, scale,
-               (const __bf16*)P, (long long)ldp, dP, (long long)lddp, (__bf16*)dS, (long long)ldds);
-    DWG_RETURN_IF_LAUNCH_FAILED();
-    return DWG_OK;
+    return dwg_softmax_rows_backward_dt(DWG_DTYPE_BF16, rows, n, scale, P, ldp, dP, lddp, dS, ldds, stream);
 }
 
 }  // extern "C"

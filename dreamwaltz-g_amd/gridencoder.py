@@ -126,15 +126,23 @@ def xcd_counters_for(device):
     return _xcd_counters[key]
 
 
-_SLAB_WS = {}     # device -> byte workspace of the slab-binned backward (grown on demand; one backward at a time per stream order)
+_SLAB_WS = {}     # (device, stream) -> byte workspace of the slab-binned backward (grown on demand; backwards on one stream are ordered,
+                  # a workspace replaced by a bigger one is only released by the caching allocator in that stream's order)
+
+
+def slab_path_ok(B, L, total_entries):
+    """Limits of dwg_grid_encode_backward_slabs (it returns DWG_E_CAPACITY beyond them): one u32 LDS counter per 4096-entry slab within
+    64 KiB, u32 record positions."""
+    return (total_entries + 4095) // 4096 * 4 <= 64 * 1024 and B * L * 8 <= 0xffffffff
 
 
 def slab_workspace_for(device, B, L, total_entries):
     need = int(_lib.lib().dwg_grid_backward_slabs_workspace_bytes(B, L, total_entries))
-    ws = _SLAB_WS.get(str(device))
+    key = (str(device), torch.cuda.current_stream(device).cuda_stream)
+    ws = _SLAB_WS.get(key)
     if ws is None or ws.numel() < need:
         ws = torch.empty(need, dtype=torch.uint8, device=device)
-        _SLAB_WS[str(device)] = ws
+        _SLAB_WS[key] = ws
     return ws
 
 
@@ -206,6 +214,8 @@ class _grid_encode(Function):
         import os
         mode = os.environ.get("DWG_GRID_XCD_MODE", "slabs") if B >= 16384 else "device"
         if mode in ("owner", "copies") and not xcd_path_ok(inputs.device):
+            mode = "device"
+        if mode == "slabs" and not slab_path_ok(B, L, int(embeddings.shape[0])):
             mode = "device"
         scratch = xcd_scratch_for(embeddings) if mode == "copies" else None
         counters = xcd_counters_for(inputs.device) if (mode == "owner" and grad_embeddings.data_ptr() % 128 == 0) else None

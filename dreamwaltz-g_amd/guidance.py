@@ -66,8 +66,10 @@ def C(value, current_step=None, max_iteration=None) -> float:
 class ControlNetScoreDistillation:
     def __init__(self, device, unet_cfg: Optional[sd15.UNetConfig] = None, vae_cfg: Optional[sd15.VAEConfig] = None,
                  unet_sd=None, controlnet_sd=None, vae_sd=None, image_hw=512, guidance_scale=None, min_timestep=None,
-                 max_timestep=None, seed=0, cfg: Optional[GuideConfig] = None, text_len=77):
+                 max_timestep=None, seed=0, cfg: Optional[GuideConfig] = None, text_len=77, dtype="bf16"):
         self.device = torch.device(device)
+        self.dtype_name = sd15.dtype_name(dtype)          # storage type of the denoiser / VAE plans: "bf16" (default) | "f32" (the reference's
+                                                          # GS-stage precision, configs/__init__.py:236,241) | "f16" (its --optim.fp16 mode)
         self.cfg = cfg if cfg is not None else GuideConfig()
         self.unet_cfg = unet_cfg or sd15.UNetConfig()
         self.vae_cfg = vae_cfg or sd15.VAEConfig()
@@ -81,8 +83,8 @@ class ControlNetScoreDistillation:
         down = 2 ** (len(self.vae_cfg.block_out_channels) - 1)
         self.latent_hw = image_hw // down
         self.denoiser = sd15.DenoiserPlan(self.unet_cfg, unet_sd, controlnet_sd, self.device, batch=2, latent_hw=self.latent_hw,
-                                          text_len=text_len)      # CLIP's 77 tokens; static (the plans are hipGraphs)
-        self.vae = sd15.VAEEncoderPlan(self.vae_cfg, vae_sd, self.device, image_hw=image_hw)
+                                          text_len=text_len, dtype=self.dtype_name)      # CLIP's 77 tokens; static (the plans are hipGraphs)
+        self.vae = sd15.VAEEncoderPlan(self.vae_cfg, vae_sd, self.device, image_hw=image_hw, dtype=self.dtype_name)
         # BasicStableDiffusion.__init__ (basic.py:229-267)
         self.loss_type, self.weight_type = self.cfg.sds_loss_type, self.cfg.sds_weight_type
         if self.loss_type != 'sds' or self.weight_type not in ('sjc', 'dreamfusion', 'latent-nerf', 'ism'):

@@ -7,7 +7,7 @@ about as much: the eager loop is host-bound.  A replay costs one copy of the pos
 
 What is static in the graph: the camera, the Gaussian count and the pair-buffer capacity of the rasterizer (frozen at 1.5x the largest
 count of the warm-up frames, at least the running capacity).  A frame that needs more pairs than that is TRUNCATED by the kernels and
-flags it; `GraphedAnimation.check()` (one stream synchronisation) reports it, and `recapture()` grows the capacity.  Callers that cannot
+flags it (in the graph's OWN pair state: eager frames through the same Scene keep the renderer's); `GraphedAnimation.check()` (one stream synchronisation) reports it, and `recapture()` grows the capacity.  Callers that cannot
 tolerate a truncated frame call check() per frame -- that still skips all the per-frame host work."""
 from typing import Dict, Iterable, Optional
 
@@ -32,18 +32,27 @@ class GraphedAnimation:
         with torch.inference_mode():
             return self.scene.forward(self.data, smpl_observed_inputs=self.pose, use_densifier=False, bg_mode=self.bg_mode)
 
-    def _capture(self, warmup_poses, grow: float = 1.5):
+    def _capture(self, warmup_poses, grow: float = 1.5, min_cap: int = 0):
+        from .rasterizer import PairCapacity
         H, W = int(self.data["image_height"]), int(self.data["image_width"])
-        state = self._state = self.scene.renderer.pair_state(self.device, H, W)
-        state.frozen = False
+        shared = self.scene.renderer.pair_state(self.device, H, W)           # the renderer's own state: eager frames keep using it
         most = 0
         for pose in warmup_poses:                                             # eager frames: caches, lazy kernel attributes, pair counts
             self.set_pose(pose)
             self._frame()
-            state.resolve()
-            most = max(most, state.last_num_pairs)
-        state.cap = max(state.cap, int(most * grow), state.min_pairs)
+            shared.resolve()
+            most = max(most, shared.last_num_pairs)
+        # The graph gets its OWN frozen PairCapacity (fixed capacity, no events, own pinned count / overflow words): eager frames rendered
+        # through the same Scene while the graph is alive keep the renderer's state with overflow detection and head-room growth on.
+        own = PairCapacity()
+        own.cap = max(shared.cap, int(most * grow), shared.min_pairs, int(min_cap))
+        own.frozen = True
+        self._state, self._state_key = own, (self.scene.renderer, (str(self._dev_key()), H, W))
         self._capture_frozen()
+
+    def _dev_key(self):
+        d = torch.device(self.device)
+        return torch.device("cuda", torch.cuda.current_device()) if d.index is None else d
 
     def _forget_pose_caches(self):
         # the skeleton pass remembers its last result per input tensors and versions (avatar.GeneralLinearBlendSkinning.forward): the
@@ -56,8 +65,15 @@ class GraphedAnimation:
         """Capture one frame at the pair capacity the state holds now."""
         state = self._state
         state.overflow, state.pending, state.frozen = False, False, True
+        renderer, key = self._state_key
+        shared = renderer._pair_states.get(key)
+        renderer._pair_states[key] = state                                     # only while the two frames below are issued
         for entry in self.scene.renderer._visit_orders.values():               # the renderer's periodic refresh of the binning order must not
             entry[1] = 0                                                       # fall into the two frames below (it would be replayed per frame)
+        # The captured kernels read the binning order through its DEVICE POINTER.  Eager frames through the same renderer replace the
+        # renderer's entry every `reorder_every` calls; the graph keeps its own references so that the tensor it points at can never go
+        # back to the allocator while the graph is alive (released by close() / recapture()).
+        self._keep = None
         side = torch.cuda.Stream(device=self.device)
         side.wait_stream(torch.cuda.current_stream(self.device))
         with torch.cuda.stream(side):
@@ -68,6 +84,11 @@ class GraphedAnimation:
             with torch.cuda.graph(self.graph, stream=side):
                 self.outputs = self._frame()
             self._forget_pose_caches()                                         # nothing outside the graph may alias its pool
+        self._keep = [entry[0] for entry in self.scene.renderer._visit_orders.values()]
+        if shared is not None:
+            renderer._pair_states[key] = shared
+        else:
+            renderer._pair_states.pop(key, None)
         torch.cuda.current_stream(self.device).wait_stream(side)
 
     def set_pose(self, pose: Dict[str, torch.Tensor]):
@@ -91,13 +112,10 @@ class GraphedAnimation:
 
     def recapture(self, warmup_poses):
         """After check() returned False: capture again with a capacity grown from fresh eager frames."""
-        self.graph, self.outputs = None, None
-        self._state.cap *= 2
-        self._capture(list(warmup_poses), grow=2.0)
+        self.graph, self.outputs, self._keep = None, None, None
+        self._capture(list(warmup_poses), grow=2.0, min_cap=self._state.cap * 2)
 
     def close(self):
-        """Hand the renderer's pair state back to eager frames (events and head-room growth on again)."""
-        self.graph, self.outputs = None, None
-        if self._state is not None:
-            self._state.frozen = False
-            self._state = None
+        """Drop the graph, its frozen pair state and its references to the binning-order tensors."""
+        self.graph, self.outputs, self._keep = None, None, None
+        self._state = None

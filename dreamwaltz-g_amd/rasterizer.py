@@ -48,6 +48,9 @@ class PairCapacity:
         self.pending = False
         self.overflow = False
         self.frozen = False              # True: fixed capacity, no events, no host waits (a frame captured into a graph, see player.py)
+        self.seq = 0                     # frames rendered through this state; `pending_seq` = the frame whose count is in flight
+        self.pending_seq = 0
+        self.overflow_seq = -1           # the (latest) frame that was truncated: its backward returns zeros (see _RasterizeGaussians.backward)
         self.last_num_pairs = 0          # pairs after exact culling (what the buffers hold)
         self.last_num_pairs_ref = 0      # sum of 16x16 reference tiles touched (the K of SURVEY 8d's byte formula)
 
@@ -63,6 +66,7 @@ class PairCapacity:
         self.last_num_pairs, self.last_num_pairs_ref = K, Kref
         if ovf:
             self.overflow = True
+            self.overflow_seq = self.pending_seq
         if ovf or K * 2 > self.cap:
             self.cap = max(self.cap, int(K * self.headroom))
 
@@ -162,12 +166,14 @@ class _RasterizeGaussians(torch.autograd.Function):
             if pair_state.host is None:
                 pair_state.host = torch.zeros(4, dtype=torch.int32).pin_memory()
             pair_state.host.copy_(ws_geom[:16].view(torch.int32), non_blocking=True)
+            pair_state.seq += 1
             if not pair_state.frozen:
                 ev = torch.cuda.Event(); ev.record(torch.cuda.current_stream(device))
-                pair_state.event, pair_state.pending = ev, True
+                pair_state.event, pair_state.pending, pair_state.pending_seq = ev, True, pair_state.seq
         ctx.raster_settings = raster_settings
         ctx.cap = cap
         ctx.pair_state = pair_state
+        ctx.frame_seq = pair_state.seq if pair_state is not None else 0
         ctx.has = (sh is not None, colors_precomp is not None, scales is not None, cov3D is not None)
         ctx.save_for_backward(means3D, sh, colors_precomp, opac, scales, rotations, cov3D, ws_geom, ws_pairs, ws_image)
         ctx.mark_non_differentiable(radii)
@@ -182,6 +188,13 @@ class _RasterizeGaussians(torch.autograd.Function):
         G = int(means3D.shape[0])
         if ctx.pair_state is not None:
             ctx.pair_state.resolve()     # this frame's forward finished long ago: free, and latches a capacity overflow
+            if ctx.pair_state.overflow_seq == ctx.frame_seq:
+                # THIS frame was truncated by the pair capacity: its owner renders it again (SDSTrainer.train_step).  Its gradient is
+                # ZERO, not the truncated frame's partial one -- a multi-view step accumulates several frames into one gradient buffer
+                # before the optimizer runs, and the re-rendered frame must be the only contribution of its view.
+                z = lambda t: None if t is None else torch.zeros_like(t)     # noqa: E731
+                return (z(means3D), torch.zeros(G, 3, device=device), z(sh), z(colors_precomp), torch.zeros(G, 1, device=device),
+                        z(scales), z(rotations), z(cov3D), None, None, None, None)
         keep = []
         M = int(sh.shape[1]) if sh is not None else 0
         cfg = _settings_struct(rs, device, M, keep)

@@ -22,6 +22,24 @@ from . import _lib, gemm
 
 BF16 = torch.bfloat16
 
+# Storage element type of a plan's activations and weights (accumulation is fp32 in all of them):
+#   "bf16"  default: MFMA bf16 (v_mfma_f32_32x32x16_bf16), direct-to-LDS tiles, flash attention
+#   "f32"   the precision the reference runs the 3DGS stage in (/root/reference/configs/__init__.py:236,241; `--optim.fp16` is only passed
+#           to the NeRF stages of scripts/train_w_expr.sh): exact-f32 MFMA (v_mfma_f32_32x32x2_f32, peak 157 TFLOP/s), attention as
+#           QK^T -> row softmax -> PV.  It is the full-precision reference the bf16 plans are measured against ON THE GPU.
+#   "f16"   the reference's autocast storage type (configs/__init__.py:462): the bandwidth-bound layers are typed for it
+#           (include/dwg_nn.h *_dt), the MFMA GEMM is not -- plans refuse it.
+TORCH_DTYPE = {"bf16": torch.bfloat16, "f32": torch.float32, "f16": torch.float16}
+DT_CODE = {"f32": 0, "bf16": 1, "f16": 2}          # DWG_DTYPE_* (include/dwg_types.h)
+
+
+def dtype_name(dtype) -> str:
+    names = {"bf16": "bf16", "bfloat16": "bf16", torch.bfloat16: "bf16", "f32": "f32", "fp32": "f32", "float32": "f32", torch.float32: "f32",
+             "f16": "f16", "fp16": "f16", "float16": "f16", "half": "f16", torch.float16: "f16"}
+    if dtype not in names:
+        raise ValueError("plan dtype must be one of bf16 / f32 / f16, got %r" % (dtype,))
+    return names[dtype]
+
 
 # ----------------------------------------------------------------------------------------------------------------------
 # configuration + parameter inventory (diffusers key names / shapes)
@@ -206,8 +224,14 @@ def _pad8(c):
 class Plan:
     """Flat list of prebuilt library calls; run() is the only per-step Python work."""
 
-    def __init__(self, device):
+    def __init__(self, device, dtype="bf16"):
         self.device = device
+        self.dtype_name = dtype_name(dtype)
+        if self.dtype_name == "f16":
+            raise NotImplementedError("fp16-storage plans: the layers are typed for it (dwg_nn.h *_dt) but dwg_gemm has no f16 MFMA path; "
+                                      "use bf16 (same MFMA rate, no loss scaling) or f32")
+        self.dtype, self.dt = TORCH_DTYPE[self.dtype_name], DT_CODE[self.dtype_name]
+        self.esize = 4 if self.dtype_name == "f32" else 2
         self.ops = []
         self.keep = []          # descriptors / tensors kept alive
         self.tags = []
@@ -257,8 +281,9 @@ class Plan:
             if rc:
                 raise RuntimeError("plan op failed with DWG error %s" % rc)
 
-    def buf(self, *shape, dtype=BF16, zero=False):
+    def buf(self, *shape, dtype=None, zero=False):
         import os
+        dtype = self.dtype if dtype is None else dtype
         zero = zero or os.environ.get("DWG_PLAN_ZERO") == "1"
         t = (torch.zeros if zero else torch.empty)(*shape, device=self.device, dtype=dtype)
         self.keep.append(t)
@@ -340,10 +365,11 @@ class Weights:
     """Kernel-layout copies of a diffusers-format state_dict: conv [Cout,KH,KW,Cin(pad 8)] bf16, linear [out,in] bf16,
     biases / norm affine fp32."""
 
-    def __init__(self, sd: Dict[str, torch.Tensor], device):
+    def __init__(self, sd: Dict[str, torch.Tensor], device, dtype="bf16"):
         self.device = device
         self.sd = sd
         self.cache = {}
+        self.wdtype = TORCH_DTYPE[dtype_name(dtype)]         # storage type of the conv / linear weights (biases, norm affine: fp32)
 
     def conv(self, name, flip_for_dgrad=False):
         key = (name, flip_for_dgrad)
@@ -354,7 +380,7 @@ class Weights:
             cout, cin = w.shape[0], w.shape[1]
             wp = torch.zeros(_pad8(cout) if flip_for_dgrad else cout, w.shape[2], w.shape[3], _pad8(cin))
             wp[:cout, :, :, :cin] = w.permute(0, 2, 3, 1)
-            self.cache[key] = wp.to(self.device, BF16).contiguous()
+            self.cache[key] = wp.to(self.device, self.wdtype).contiguous()
         return self.cache[key]
 
     def conv_dgrad_s2(self, name, py, px):
@@ -372,14 +398,14 @@ class Weights:
             for ty, ky in enumerate(kys):
                 for tx, kx in enumerate(kxs):
                     wp[:cx, ty, tx, :cy] = w[:, :, ky, kx].t()
-            self.cache[key] = wp.to(self.device, BF16).contiguous()
+            self.cache[key] = wp.to(self.device, self.wdtype).contiguous()
         return self.cache[key]
 
     def lin(self, *names):
         key = ("lin",) + names
         if key not in self.cache:
             self.cache[key] = torch.cat([self.sd[n + ".weight"].float().reshape(self.sd[n + ".weight"].shape[0], -1)
-                                         for n in names], 0).to(self.device, BF16).contiguous()
+                                         for n in names], 0).to(self.device, self.wdtype).contiguous()
         return self.cache[key]
 
     def lin_geglu(self, name):
@@ -391,7 +417,7 @@ class Weights:
             F = w.shape[0] // 2
             idx = torch.arange(F).view(-1, 32)
             perm = torch.cat([idx, idx + F], dim=1).reshape(-1)          # [q*64 + 0..31] = hidden, [q*64 + 32..63] = gate
-            self.cache[key] = (w[perm].to(self.device, BF16).contiguous(), b[perm].to(self.device).contiguous())
+            self.cache[key] = (w[perm].to(self.device, self.wdtype).contiguous(), b[perm].to(self.device).contiguous())
         return self.cache[key]
 
     def f32(self, name):
@@ -419,7 +445,7 @@ class Builder:
         base = "conv3x3" if KH == 3 else ("conv1x1" if KH * KW == 1 else "conv%dx%d" % (KH, KW))
         return "%s%s_%s_r%d" % (base, "s2" if stride == 2 else ("T" if dil > 1 else ""), self.prefix, Ho)
 
-    def conv(self, x, name, stride=1, pad=1, act=None, residual=None, upsample=1, bias_img=None, out_dtype=BF16, out_hw=None,
+    def conv(self, x, name, stride=1, pad=1, act=None, residual=None, upsample=1, bias_img=None, out_dtype=None, out_hw=None,
              pad_tl=None, r_batch_bcast=False, weight=None, bias=True, in_dilation=1, tag=None):
         """x [B,H,W,C] NHWC bf16. bias_img: (tensor [B, ld] fp32, ld) per-image channel bias replacing the conv bias."""
         B, H, W, C = x.shape
@@ -456,7 +482,7 @@ class Builder:
         self.p.add_gemm(d)
         return y
 
-    def linear(self, x, wt, bias=None, act=None, residual=None, out_dtype=BF16, tag="linear"):
+    def linear(self, x, wt, bias=None, act=None, residual=None, out_dtype=None, tag="linear"):
         K = x.shape[-1]
         M = x.numel() // K
         N = wt.shape[0]
@@ -484,7 +510,7 @@ class Builder:
         y = self.p.buf(*x.shape)
         stats = self.p.buf(B, self.groups, 2, dtype=torch.float32)
         pp = lambda t: ctypes.c_void_p(t.data_ptr())  # noqa: E731
-        self.p.add_call(self.L.dwg_groupnorm_forward, B, HW, C, self.groups, pp(x), pp(self.w.f32(name + ".weight")),
+        self.p.add_call(self.L.dwg_groupnorm_forward_dt, self.p.dt, B, HW, C, self.groups, pp(x), pp(self.w.f32(name + ".weight")),
                         pp(self.w.f32(name + ".bias")), eps, int(silu), pp(y), pp(stats), pp(self._gn_ws(B)))
         return (y, stats) if keep_stats else y
 
@@ -494,7 +520,7 @@ class Builder:
         dx = self.p.buf(*x.shape)
         scratch = self.p.buf(B, self.groups, 2, dtype=torch.float32)
         pp = lambda t: ctypes.c_void_p(t.data_ptr())  # noqa: E731
-        self.p.add_call(self.L.dwg_groupnorm_backward, B, HW, C, self.groups, pp(x), pp(dy), pp(stats),
+        self.p.add_call(self.L.dwg_groupnorm_backward_dt, self.p.dt, B, HW, C, self.groups, pp(x), pp(dy), pp(stats),
                         pp(self.w.f32(name + ".weight")), pp(self.w.f32(name + ".bias")), eps, int(silu), pp(dx), pp(scratch),
                         pp(self._gn_ws(B)), pp(residual) if residual is not None else None)
         return dx
@@ -504,7 +530,7 @@ class Builder:
         M = x.numel() // C
         y = self.p.buf(*x.shape)
         pp = lambda t: ctypes.c_void_p(t.data_ptr())  # noqa: E731
-        self.p.add_call(self.L.dwg_layernorm_forward, M, C, pp(x), pp(self.w.f32(name + ".weight")), pp(self.w.f32(name + ".bias")),
+        self.p.add_call(self.L.dwg_layernorm_forward_dt, self.p.dt, M, C, pp(x), pp(self.w.f32(name + ".weight")), pp(self.w.f32(name + ".bias")),
                         1e-5, pp(y))
         return y
 
@@ -513,14 +539,35 @@ class Builder:
         M = x.numel() // F2
         y = self.p.buf(*x.shape[:-1], F2 // 2)
         pp = lambda t: ctypes.c_void_p(t.data_ptr())  # noqa: E731
-        self.p.add_call(self.L.dwg_geglu_forward, M, F2 // 2, pp(x), pp(y))
+        self.p.add_call(self.L.dwg_geglu_forward_dt, self.p.dt, M, F2 // 2, pp(x), pp(y))
         return y
+
+    def _pooled(self, tag, numel, dtype):
+        """Scratch shared by the sequential ops of one branch (score / probability matrices of the unfused attention)."""
+        pool = self.p.__dict__.setdefault("_scratch_pool", {})
+        key = (tag, self.p.branch, dtype)
+        t = pool.get(key)
+        if t is None or t.numel() < numel:
+            t = pool[key] = self.p.buf(numel, dtype=dtype)
+        return t[:numel]
 
     def attention(self, q, k, v, heads):
         B, Nq, HD = q.shape
         Nk, d = k.shape[1], HD // heads
         o = self.p.buf(B, Nq, HD)
         pp = lambda t: ctypes.c_void_p(t.data_ptr())  # noqa: E731
+        if self.p.dtype_name != "bf16":
+            # full-precision plans: S = Q K^T (batched over image x head) -> row softmax -> O = P V on the exact-f32 MFMA GEMM
+            S = self._pooled("attn_S", B * heads * Nq * Nk, torch.float32)
+            P = self._pooled("attn_P", B * heads * Nq * Nk, self.p.dtype)
+            self.p.add_gemm(gemm.gemm_raw(q, k, S, Nq, Nk, d, (q.stride(1), 1), (k.stride(1), 1), Nk, batch=(B, heads),
+                                          a_batch=(q.stride(0), d), b_batch=(k.stride(0), d), c_batch=(heads * Nq * Nk, Nq * Nk),
+                                          name="attn_qk", run=False))
+            self.p.add_call(self.L.dwg_softmax_rows_forward_dt, self.p.dt, B * heads * Nq, Nk, float(d) ** -0.5, pp(S), Nk, pp(P), Nk)
+            self.p.add_gemm(gemm.gemm_raw(P, v, o, Nq, d, Nk, (Nk, 1), (1, v.stride(1)), HD, batch=(B, heads),
+                                          a_batch=(heads * Nq * Nk, Nq * Nk), b_batch=(v.stride(0), d), c_batch=(o.stride(0), d),
+                                          name="attn_pv", run=False))
+            return o
         self.p.add_call(self.L.dwg_attention_forward, B, heads, Nq, Nk, d, pp(q), q.stride(1), q.stride(0), pp(k), k.stride(1),
                         k.stride(0), pp(v), v.stride(1), v.stride(0), pp(o), o.stride(1), o.stride(0), float(d) ** -0.5)
         return o
@@ -529,13 +576,14 @@ class Builder:
         Ca, Cb = a.shape[-1], b.shape[-1]
         y = self.p.buf(*a.shape[:-1], Ca + Cb)
         pp = lambda t: ctypes.c_void_p(t.data_ptr())  # noqa: E731
-        self.p.add_call(self.L.dwg_concat_channels, a.numel() // Ca, Ca, Cb, pp(a), pp(b), pp(y))
+        k2 = self.p.esize // 2                      # the concat kernel moves 16-byte pieces of 2-byte elements: fp32 channels count twice
+        self.p.add_call(self.L.dwg_concat_channels, a.numel() // Ca, Ca * k2, Cb * k2, pp(a), pp(b), pp(y))
         return y
 
     def add(self, a, b):
         y = self.p.buf(*a.shape)
         pp = lambda t: ctypes.c_void_p(t.data_ptr())  # noqa: E731
-        self.p.add_call(self.L.dwg_add_bf16, a.numel(), pp(a), pp(b), pp(y))
+        self.p.add_call(self.L.dwg_add_dt, self.p.dt, a.numel(), pp(a), pp(b), pp(y))
         return y
 
     def conv_dgrad_s2(self, dy, name):
@@ -551,13 +599,16 @@ class Builder:
         C = subs[0].shape[-1]
         out = self.p.buf(B, 2 * Ho, 2 * Wo, C)
         pp = lambda t: ctypes.c_void_p(t.data_ptr())  # noqa: E731
-        self.p.add_call(self.L.dwg_interleave2x2, B, Ho, Wo, C, pp(subs[0]), pp(subs[1]), pp(subs[2]), pp(subs[3]), pp(out))
+        self.p.add_call(self.L.dwg_interleave2x2, B, Ho, Wo, C * (self.p.esize // 2), pp(subs[0]), pp(subs[1]), pp(subs[2]), pp(subs[3]), pp(out))
         return out
 
     def cast_bf16(self, x):
+        """fp32 accumulator buffer -> the plan's activation type (a no-op for the fp32 plans)."""
+        if self.p.dtype == torch.float32:
+            return x
         y = self.p.buf(*x.shape)
         pp = lambda t: ctypes.c_void_p(t.data_ptr())  # noqa: E731
-        self.p.add_call(self.L.dwg_cast_f32_to_bf16, x.numel(), pp(x), pp(y))
+        self.p.add_call(self.L.dwg_cast_f32_to_dt, self.p.dt, x.numel(), pp(x), pp(y))
         return y
 
     # -- blocks ----------------------------------------------------------------------------------------------------
@@ -686,11 +737,11 @@ class DenoiserPlan:
     cond [1,8h,8w,8] (3 used; the condition image is identical for both CFG entries -- controlnet.py:60-72 repeats it --
     so its embedding is computed once and broadcast).  Output: eps [B,h,w,4] fp32."""
 
-    def __init__(self, cfg: UNetConfig, unet_sd, cn_sd, device, batch=2, latent_hw=64, text_len=77):
+    def __init__(self, cfg: UNetConfig, unet_sd, cn_sd, device, batch=2, latent_hw=64, text_len=77, dtype="bf16"):
         self.cfg, self.device, self.B, self.hw = cfg, device, batch, latent_hw
-        self.plan = Plan(device)
+        self.plan = Plan(device, dtype)
         p = self.plan
-        wu, wc = Weights(unet_sd, device), Weights(cn_sd, device)
+        wu, wc = Weights(unet_sd, device, dtype), Weights(cn_sd, device, dtype)
         self.weights = (wu, wc)     # kernel-layout weight tensors must outlive the plan that points at them
         bu, bc = Builder(p, wu, cfg.groups, "unet"), Builder(p, wc, cfg.groups, "cnet")
         B, hw = batch, latent_hw
@@ -759,10 +810,10 @@ class VAEEncoderPlan:
     but sits INSIDE the autograd graph of SDS -- basic.py:368-372).  forward: image [1,3,H,W] in [0,1] -> moments
     [1,8,H/8,W/8] (2x-1 normalisation of VaeImageProcessor fused into the input conversion).  backward: d moments -> d image."""
 
-    def __init__(self, cfg: VAEConfig, sd, device, image_hw=512):
+    def __init__(self, cfg: VAEConfig, sd, device, image_hw=512, dtype="bf16"):
         self.cfg, self.device, self.hw = cfg, device, image_hw
-        self.fwd, self.bwd = Plan(device), Plan(device)
-        w = Weights(sd, device)
+        self.fwd, self.bwd = Plan(device, dtype), Plan(device, dtype)
+        w = Weights(sd, device, dtype)
         self.weights = w            # kernel-layout weight tensors must outlive the plans that point at them
         f, r = Builder(self.fwd, w, cfg.groups, "vaef"), Builder(self.bwd, w, cfg.groups, "vaeb")
         self.x = self.fwd.buf(1, image_hw, image_hw, 8, zero=True)
@@ -839,7 +890,7 @@ class VAEEncoderPlan:
         f.p.add_gemm(gemm.gemm_raw(q, k, S, N, N, C, (C, 1), (C, 1), N, name="vae_qk", run=False))
         P = f.p.buf(N, N)
         pp = lambda t: ctypes.c_void_p(t.data_ptr())  # noqa: E731
-        f.p.add_call(f.L.dwg_softmax_rows_forward, N, N, scale, pp(S), N, pp(P), N)
+        f.p.add_call(f.L.dwg_softmax_rows_forward_dt, f.p.dt, N, N, scale, pp(S), N, pp(P), N)
         o = f.p.buf(B, N, C)
         f.p.add_gemm(gemm.gemm_raw(P, v, o, N, C, N, (N, 1), (1, C), C, name="vae_pv", run=False))
         out = f.linear(o, w.lin(pre + ".to_out.0"), bias=w.f32(pre + ".to_out.0.bias"), residual=x.view(B, N, C), tag="vae_out")
@@ -855,7 +906,7 @@ class VAEEncoderPlan:
             dv = r.p.buf(B, N, C)      # dv = P^T do
             r.p.add_gemm(gemm.gemm_raw(P, do, dv, N, C, N, (1, N), (1, C), C, name="vae_bwd_dv", run=False))
             dS = r.p.buf(N, N)
-            r.p.add_call(r.L.dwg_softmax_rows_backward, N, N, scale, pp(P), N, pp(dP), N, pp(dS), N)
+            r.p.add_call(r.L.dwg_softmax_rows_backward_dt, r.p.dt, N, N, scale, pp(P), N, pp(dP), N, pp(dS), N)
             dq = r.p.buf(B, N, C)      # dq = dS k
             r.p.add_gemm(gemm.gemm_raw(dS, k, dq, N, C, N, (N, 1), (1, C), C, name="vae_bwd_dq", run=False))
             dk = r.p.buf(B, N, C)      # dk = dS^T q

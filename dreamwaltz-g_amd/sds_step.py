@@ -6,8 +6,10 @@ end-to-end tests drive.  Everything it calls is the product's reference-shaped A
         (VAE encode in autograd -> ControlNet + UNet CFG batch 2 -> SpecifyGradient)  ->  backward  ->  [RCCL all-reduce of the flat
         gradient buffer when world > 1]  ->  fused Adam on the flat parameter buffer.
 
-Multi-GPU (config c4): rank r renders view r (azimuth 45 deg * r) of the SAME avatar (identical seeds for parameters, distinct
-seeds for pose / noise), one flat fp32 all-reduce per step, identical Adam updates on every rank.
+Multi-view (config c4): a step renders V views of the SAME avatar -- view v has its own camera (azimuth 45 deg * v), its
+own pose and its own RNG stream (VAE posterior / timestep / noise), all functions of (v, step) only -- and view v is rendered by rank
+v mod world.  Every rank accumulates its views into the flat gradient buffer, ONE flat fp32 all-reduce per step, the mean over the V
+views folded into the fused Adam, identical updates on every rank.  The default (V = world) is one view per rank.
 """
 import torch
 
@@ -52,8 +54,12 @@ def build_synthetic_avatar(n_gaussians, device, seed=0, learn_hand_betas=False):
 
 class SDSStep:
     def __init__(self, n_gaussians=100000, res=512, device="cuda", rank=0, world=1, guidance=True, dist=None, seed=0, cfg=None,
-                 avatar=None, guidance_obj=None, async_pair_count=True, iters=10000, gpu_condition=True):
+                 avatar=None, guidance_obj=None, async_pair_count=True, iters=10000, gpu_condition=True, views=None, dtype="bf16"):
         self.device, self.rank, self.world, self.dist, self.res = torch.device(device), rank, world, dist, res
+        self.views = int(views) if views is not None else world           # views per step over ALL ranks
+        if self.views < world:
+            raise ValueError("a multi-view step needs at least one view per rank (views=%d, world=%d)" % (self.views, world))
+        self.my_views = list(range(rank, self.views, world))              # view v -> rank v mod world
         self.cfg = cfg if cfg is not None else configs.TrainConfig()
         self.cfg.device = str(self.device)
         self.cfg.render.bg_color = (0.5, 0.5, 0.5)           # the GS recipes (train_w_expr.sh:68,81,94)
@@ -67,18 +73,21 @@ class SDSStep:
         self.optimizers = avatar.get_optimizer(self.cfg)                 # dict of views on ONE flat buffer
         self.scene = sc.Scene(self.cfg, avatar, async_pair_count=async_pair_count).to(self.device)
         self.scene.train()
-        cam = camera.make_camera(radius=2.0, azimuth=45.0 * rank, elevation=80.0, fovy=55.0, height=res, width=res, device=self.device)
-        self.data = dict(cam)
+        self.view_data = {v: dict(camera.make_camera(radius=2.0, azimuth=45.0 * v, elevation=80.0, fovy=55.0, height=res, width=res,
+                                                     device=self.device)) for v in self.my_views}
+        self.data = self.view_data[self.my_views[0]]
         self.guidance = guidance_obj
         tg = torch.Generator().manual_seed(seed + 5)
         if guidance and self.guidance is None:
-            self.guidance = gd.ControlNetScoreDistillation(self.device, image_hw=512, seed=seed, cfg=self.cfg.guide)
+            self.guidance = gd.ControlNetScoreDistillation(self.device, image_hw=512, seed=seed, cfg=self.cfg.guide, dtype=dtype)
         if self.guidance is not None:
             cd = self.guidance.unet_cfg.cross_dim
             hw = self.guidance.image_hw
             self.text = {"neg": torch.randn(1, 77, cd, generator=tg).to(self.device), "pos": torch.randn(1, 77, cd, generator=tg).to(self.device),
                          "viewed": [torch.randn(1, 77, cd, generator=tg).to(self.device) for _ in range(14)]}
-            self.data["cond_images"] = (torch.randint(0, 256, (1, 3, hw, hw), generator=tg).float() / 255.0).to(self.device)
+            fixed_cond = (torch.randint(0, 256, (1, 3, hw, hw), generator=tg).float() / 255.0).to(self.device)
+            for d in self.view_data.values():
+                d["cond_images"] = fixed_cond
             self.condition = self._build_condition(hw, seed) if gpu_condition else None
             diffusion = self.guidance
         else:
@@ -87,8 +96,8 @@ class SDSStep:
             diffusion = _ImageLoss(wimg)
         self.trainer = tr.SDSTrainer(self.cfg, self.scene, diffusion, self.optimizers, self.text, use_controlnet=self.guidance is not None,
                                      dist=dist, world=world, max_step=iters)
+        self.trainer.set_views(self.views)
         self.step_idx = 0
-        torch.manual_seed(1234 + rank)
 
     # kept names (bench.py / tools)
     @property
@@ -125,9 +134,10 @@ class SDSStep:
         return dict(gen=cd.SMPL2Condition(self.cfg.prompt), triangles=tri, pick=pick, intrinsics=intr, hw=hw,
                     all_vertices=torch.arange(V, device=self.device, dtype=torch.int32))
 
-    def condition_image(self, smpl_inputs):
+    def condition_image(self, smpl_inputs, data=None):
         """[1,3,H,W] in [0,1]: posed body (one skeleton pass + all 10 475 vertices) -> keypoints -> culling -> OpenPose drawing."""
         c = self.condition
+        data = self.data if data is None else data
         lbs = self.avatar.lbs_model
         with torch.no_grad():
             _, _, tr = lbs(**smpl_inputs)
@@ -137,7 +147,7 @@ class SDSStep:
             joints = (A[:, :3, :3] * J[:, None, :]).sum(-1) + A[:, :3, 3]         # A carries the global translation (no library GEMM for 55 3x3 products)
             keypoints = torch.cat([joints, verts[c["pick"]]], dim=0)
             scene = cd_build(verts, c["triangles"])
-            return c["gen"].export_pose_chw(keypoints, scene, extrinsic=self.data["extrinsic"][0], intrinsics=c["intrinsics"],
+            return c["gen"].export_pose_chw(keypoints, scene, extrinsic=data["extrinsic"][0], intrinsics=c["intrinsics"],
                                             width=c["hw"], height=c["hw"])
 
     def _upload_pose(self, cpu_inputs):
@@ -147,8 +157,9 @@ class SDSStep:
         the host is never more than one step ahead (the rasterizer's pair-count event), so a slot is free when it comes round again."""
         if self.device.type != "cuda":
             return {k: v.to(self.device) for k, v in cpu_inputs.items()}
-        slots = self.__dict__.setdefault("_pose_slots", [None] * 4)
-        i = self.step_idx % 4
+        nslot = 4 * len(self.my_views)
+        slots = self.__dict__.setdefault("_pose_slots", [None] * nslot)
+        i = self.__dict__["_pose_slot_next"] = (self.__dict__.get("_pose_slot_next", -1) + 1) % nslot
         if slots[i] is None:
             slots[i] = {k: torch.empty_like(v).pin_memory() for k, v in cpu_inputs.items()}
         out = {}
@@ -158,10 +169,15 @@ class SDSStep:
         return out
 
     def run(self, **forced):
-        self.data["smpl_inputs"] = self._upload_pose(synth.random_smpl_inputs(seed=1000 * self.rank + self.step_idx, device="cpu"))
-        if getattr(self, "condition", None) is not None:
-            self.data["cond_images"] = self.condition_image(self.data["smpl_inputs"])
-        out = self.trainer.train_step(self.data, **forced)
+        views = []
+        for v in self.my_views:
+            d = self.view_data[v]
+            d["smpl_inputs"] = self._upload_pose(synth.random_smpl_inputs(seed=1000 * v + self.step_idx, device="cpu"))
+            d["rng_seed"] = (1234 + v) * 1000003 + self.step_idx          # the view's own device-RNG stream (Q12 draw order inside it)
+            if getattr(self, "condition", None) is not None:
+                d["cond_images"] = self.condition_image(d["smpl_inputs"], d)
+            views.append(d)
+        out = self.trainer.train_step(views if len(views) > 1 else views[0], **forced)
         self.step_idx += 1
         return out
 
@@ -179,11 +195,15 @@ class SDSStep:
               "-> VAE-encode fwd+dgrad -> ControlNet+UNet SD-1.5 CFG batch 2 @64x64 latents -> Adam" % (self.N, self.M, self.res, self.res)
               ) if self.guidance is not None else (
             "sub-path only (NOT the headline workload): animate + raster %dx%d fwd+bwd + Adam, no diffusion" % (self.res, self.res))
-        return {"dtype": "bf16" if self.guidance is not None else "f32",
-                "config": {"workload": wl, "gaussians": self.G, "resolution": self.res, "views_per_step_per_gpu": 1,
+        gdt = self.guidance.dtype_name if self.guidance is not None else "f32"
+        prec = {"bf16": "denoiser+VAE bf16 storage / fp32 accumulate (MFMA bf16)", "f32": "denoiser+VAE fp32 storage and arithmetic (exact-f32 MFMA)",
+                "f16": "denoiser+VAE fp16 storage / fp32 accumulate (MFMA f16)"}[gdt]
+        return {"dtype": gdt,
+                "config": {"workload": wl, "gaussians": self.G, "resolution": self.res, "views_per_step": self.views,
+                           "views_per_step_per_gpu": len(self.my_views),
                            "weights": "seeded random init of the SD-1.5 / ControlNet / VAE architecture",
-                           "precision": "denoiser+VAE bf16 storage / fp32 accumulate; LBS, encoder, MLPs, rasterizer fp32",
-                           "parallelism": "dp%d (one view per GPU, flat-gradient all-reduce)" % self.world}}
+                           "precision": prec + "; LBS, encoder, MLPs, rasterizer fp32",
+                           "parallelism": "dp%d (view v on GPU v mod %d, flat-gradient all-reduce)" % (self.world, self.world)}}
 
     def flops_by_kernel(self):
         tot = {}

@@ -3,8 +3,9 @@
   render(data, bg_mode)      /root/reference/core/trainer.py:680-709     -> Scene.forward
   get_spatial_scale(data)    trainer.py:711-716
   train_forward(data)        trainer.py:933-1017   render -> NCHW -> view-dependent text embedding -> diffusion(**sd_kwargs) -> loss
-  train_step(data)           trainer.py:859-890    forward; zero_grad + update_learning_rate on every optimizer; backward;
-                                                   [multi-view: ONE all-reduce of the flat gradient buffer]; step on every optimizer
+  train_step(data)           trainer.py:859-890    zero_grad + update_learning_rate on every optimizer; forward; backward [x views of
+                                                   this rank, accumulated; ONE all-reduce of the flat gradient buffer]; step on every
+                                                   optimizer
 
 Method and dictionary-key names are the reference's.  What is added: the flat-buffer all-reduce of the multi-view step
 (nothing in the reference to mirror) and the same-frame recovery of a pair-capacity overflow in the sync-free mode.
@@ -29,8 +30,8 @@ class SDSTrainer:
         self.scaler = None                          # GradScaler(enabled=False) in the fp32 recipes: pass-through
         self.redone_frames = 0
         self.past_checkpoints = []
-        if hasattr(optimizers, "set_grad_scale"):
-            optimizers.set_grad_scale(1.0 / world)  # mean of the all-reduced (summed) gradients, folded into the Adam kernel
+        self.set_views(world)                       # one view per rank unless the caller says otherwise: mean of the summed gradients,
+                                                    # folded into the Adam kernel
 
     # -- checkpoints (trainer.py:188-259): {'train_step', 'checkpoints', 'model': Scene.state_dict()[, 'optimizers', 'scaler']} ------
     def save_checkpoint(self, ckpt_dir, full: bool = False, max_keep_ckpts: int = 2):
@@ -107,27 +108,55 @@ class SDSTrainer:
         total_loss += diffusion_loss
         return total_loss, render_outputs, sd_outputs, text
 
-    def _forward_backward(self, data, spatial_scale, **forced):
-        loss, render_outputs, sd_outputs, text = self.train_forward(data, **forced)
+    def _begin_step(self, spatial_scale):
+        """zero_grad + update_learning_rate on every optimizer (trainer.py:861-870).  The reference does this between the forward and the
+        backward of its one view; nothing in a forward reads a gradient, so doing it first is the same step -- and it is what lets a
+        multi-view step accumulate several backwards into the one flat gradient buffer."""
         for optimizer in self.optimizers.values():
             optimizer.zero_grad()
             if hasattr(optimizer, 'update_learning_rate'):
                 optimizer.update_learning_rate(iteration=self.train_step_index, spatial_scale=spatial_scale)
+
+    def _forward_backward(self, data, **forced):
+        loss, render_outputs, sd_outputs, text = self.train_forward(data, **forced)
         loss.backward()
         return loss, render_outputs, sd_outputs, text
 
-    def train_step(self, data: Dict[str, Any], **forced):
-        self.train_step_index += 1
-        spatial_scale = self.get_spatial_scale(data)
-        out = self._forward_backward(data, spatial_scale, **forced)
-        # sync-free pair sizing: the rasterizer's backward has already waited for this frame's pair count; a frame whose pair
-        # workspace was too small is rendered again (capacity has grown) BEFORE anything reaches the optimizers
+    def _view(self, data, **forced):
+        """Forward + backward of ONE view, accumulated into the flat gradient buffer.  Sync-free pair sizing: the rasterizer's backward
+        has already waited for this frame's pair count; a frame whose pair workspace was too small contributed a ZERO gradient
+        (rasterizer._RasterizeGaussians.backward) and is rendered again here (capacity has grown) BEFORE anything reaches the optimizers."""
+        seed = data.get('rng_seed') if isinstance(data, dict) else None
+        if seed is not None:
+            torch.manual_seed(int(seed))          # the view's own RNG stream (VAE posterior, timestep, noise): the same draws whichever rank renders it
+        out = self._forward_backward(data, **forced)
         renderer = getattr(self.model, "renderer", None)
         while renderer is not None and renderer.consume_overflow():
             self.redone_frames += 1
-            out = self._forward_backward(data, spatial_scale, **forced)
+            if seed is not None:
+                torch.manual_seed(int(seed))
+            out = self._forward_backward(data, **forced)
+        return out
+
+    def train_step(self, data, **forced):
+        """One optimizer step.  `data`: the loader's dict for the reference's single-view step, or a LIST of such dicts -- the views THIS
+        rank renders in a multi-view step (view v of V goes to rank v mod world; identical parameters everywhere).
+        Every view's gradient is accumulated into the one flat buffer, then ONE all-reduce (RCCL over xGMI) when world > 1, then the
+        fused Adam with 1 / V folded in (the mean over ALL views of the step, `set_views`)."""
+        views = list(data) if isinstance(data, (list, tuple)) else [data]
+        self.train_step_index += 1
+        self._begin_step(self.get_spatial_scale(views[0]))
+        out = None
+        for view in views:
+            out = self._view(view, **forced)
         if self.world > 1:
-            self.dist.all_reduce(self.optimizers.all_grads())       # RCCL over xGMI: one flat fp32 buffer
+            self.dist.all_reduce(self.optimizers.all_grads())       # one flat fp32 buffer
         for optimizer in self.optimizers.values():
             optimizer.step()
         return out
+
+    def set_views(self, total_views: int):
+        """Views per step over ALL ranks (default: one per rank): the optimizers see the MEAN gradient over them."""
+        self.total_views = int(total_views)
+        if hasattr(self.optimizers, "set_grad_scale"):
+            self.optimizers.set_grad_scale(1.0 / self.total_views)

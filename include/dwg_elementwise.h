@@ -53,6 +53,10 @@ int dwg_interleave2x2(int32_t B, int32_t Ho, int32_t Wo, int32_t C, const void* 
                       void* out, dwg_stream_t stream);
 /* fp32 -> bf16 copy. */
 int dwg_cast_f32_to_bf16(int64_t n, const float* src, void* dst, dwg_stream_t stream);
+/* The typed passes for the other plan element types (dtype = DWG_DTYPE_BF16 | DWG_DTYPE_F16 | DWG_DTYPE_F32, dwg_types.h).  The two byte
+ * movers above (concat, interleave) serve them as they are: pass channel counts in units of 2-byte elements (2 C for fp32). */
+int dwg_add_dt(int32_t dtype, int64_t n, const void* a, const void* b, void* out, dwg_stream_t stream);
+int dwg_cast_f32_to_dt(int32_t dtype, int64_t n, const float* src, void* dst, dwg_stream_t stream);
 
 #ifdef __cplusplus
 }

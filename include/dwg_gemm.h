@@ -25,8 +25,7 @@
 extern "C" {
 #endif
 
-#define DWG_DTYPE_F32 0
-#define DWG_DTYPE_BF16 1
+/* DWG_DTYPE_F32 / DWG_DTYPE_BF16: dwg_types.h */
 
 #define DWG_ACT_NONE 0
 #define DWG_ACT_RELU 1

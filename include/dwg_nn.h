@@ -49,6 +49,25 @@ int dwg_softmax_rows_forward(int32_t rows, int32_t n, float scale, const float* 
 int dwg_softmax_rows_backward(int32_t rows, int32_t n, float scale, const void* P, int64_t ldp, const float* dP, int64_t lddp,
                               void* dS, int64_t ldds, dwg_stream_t stream);
 
+/* The same layers for any activation element type: `dtype` = DWG_DTYPE_BF16 | DWG_DTYPE_F16 | DWG_DTYPE_F32 (dwg_types.h) of every
+ * `void*` activation argument; affine parameters, statistics and scratch stay fp32.  The un-suffixed entry points above are the
+ * DWG_DTYPE_BF16 case.  fp32 is the precision the reference runs the 3DGS stage in (/root/reference/configs/__init__.py:236,241 --
+ * `--optim.fp16` is only passed to the NeRF stages), fp16 is its autocast storage type (configs/__init__.py:462, trainer.py:844,859). */
+int dwg_groupnorm_forward_dt(int32_t dtype, int32_t B, int32_t HW, int32_t C, int32_t G, const void* x, const float* gamma,
+                             const float* beta, float eps, int32_t fuse_silu, void* y, float* stats, float* workspace,
+                             dwg_stream_t stream);
+int dwg_groupnorm_backward_dt(int32_t dtype, int32_t B, int32_t HW, int32_t C, int32_t G, const void* x, const void* dy,
+                              const float* stats, const float* gamma, const float* beta, float eps, int32_t fuse_silu, void* dx,
+                              float* scratch, float* workspace, const void* residual, dwg_stream_t stream);
+int dwg_layernorm_forward_dt(int32_t dtype, int32_t M, int32_t C, const void* x, const float* gamma, const float* beta, float eps,
+                             void* y, dwg_stream_t stream);
+int dwg_geglu_forward_dt(int32_t dtype, int64_t M, int32_t F, const void* x, void* out, dwg_stream_t stream);
+/* P / dS have element type `dtype`; S / dP stay fp32 */
+int dwg_softmax_rows_forward_dt(int32_t dtype, int32_t rows, int32_t n, float scale, const float* S, int64_t lds, void* P,
+                                int64_t ldp, dwg_stream_t stream);
+int dwg_softmax_rows_backward_dt(int32_t dtype, int32_t rows, int32_t n, float scale, const void* P, int64_t ldp, const float* dP,
+                                 int64_t lddp, void* dS, int64_t ldds, dwg_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -17,8 +17,13 @@ def build():
     subprocess.run(["make", "-C", _HERE, "-s"], check=True)
 
 
-def _lib(dtype):
+def _lib(dtype, omp=False):
+    """omp=True: the multi-threaded f32 build (bench.py's cpu_baseline only; the checker build is single-threaded and deterministic)."""
     key = "f64" if np.dtype(dtype) == np.float64 else "f32"
+    if omp:
+        if key != "f32":
+            raise ValueError("the OpenMP build of the raster oracle is f32 only")
+        key = "f32_omp"
     if key not in _libs:
         path = os.path.join(_BUILD, "liboracle_raster_%s.so" % key)
         if not os.path.exists(path):
@@ -40,9 +45,9 @@ def _prep(dtype, *arrs):
 
 def forward(means3D, opacities, viewmatrix, projmatrix, tanfovx, tanfovy, bg, H, W, colors=None, shs=None,
             sh_degree=0, campos=None, scales=None, rotations=None, cov3D=None, scale_modifier=1.0,
-            dtype=np.float32):
+            dtype=np.float32, omp=False):
     """Returns dict(color[3,H,W], depth[H,W], alpha[H,W], radii[G], final_T, n_contrib, num_pairs)."""
-    L = _lib(dtype)
+    L = _lib(dtype, omp)
     real = ctypes.c_double if np.dtype(dtype) == np.float64 else ctypes.c_float
     means3D, opacities, viewmatrix, projmatrix, bg, colors, shs, campos, scales, rotations, cov3D = _prep(
         dtype, means3D, opacities, viewmatrix, projmatrix, bg, colors, shs, campos, scales, rotations, cov3D)
@@ -62,8 +67,8 @@ def forward(means3D, opacities, viewmatrix, projmatrix, tanfovx, tanfovy, bg, H,
 
 def backward(means3D, opacities, viewmatrix, projmatrix, tanfovx, tanfovy, bg, H, W, g_color, g_depth=None,
              g_alpha=None, colors=None, shs=None, sh_degree=0, campos=None, scales=None, rotations=None, cov3D=None,
-             scale_modifier=1.0, dtype=np.float32):
-    L = _lib(dtype)
+             scale_modifier=1.0, dtype=np.float32, omp=False):
+    L = _lib(dtype, omp)
     real = ctypes.c_double if np.dtype(dtype) == np.float64 else ctypes.c_float
     (means3D, opacities, viewmatrix, projmatrix, bg, colors, shs, campos, scales, rotations, cov3D, g_color, g_depth,
      g_alpha) = _prep(dtype, means3D, opacities, viewmatrix, projmatrix, bg, colors, shs, campos, scales, rotations,

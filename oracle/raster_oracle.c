@@ -67,6 +67,15 @@ typedef struct {
     uint32_t* sorted;     /* K gaussian ids */
 } state_t;
 
+/* Two builds of this file (oracle/Makefile): the CHECKER (single-threaded, deterministic summation order: what tests/ and smoke() compare
+ * against) and the `_omp` build (-fopenmp: tiles / Gaussians across all host cores, gradient sums through atomics) that only
+ * bench.py's cpu_baseline leg times -- so that the reported host number is not a one-core number. */
+#ifdef _OPENMP
+#define DWG_ADD(x, v) _Pragma("omp atomic") (x) += (v)
+#else
+#define DWG_ADD(x, v) (x) += (v)
+#endif
+
 static uint32_t fbits(float f) { uint32_t u; memcpy(&u, &f, 4); return u; }
 
 static void quat_to_R(const REAL* q, REAL R[9]) {
@@ -162,6 +171,7 @@ static int build_state(state_t* st, int G, int H, int W, const REAL* means3D, co
     st->tile_start = (uint32_t*)calloc((size_t)ntiles + 1, sizeof(uint32_t));
     const REAL focal_x = W / (2 * tanfovx), focal_y = H / (2 * tanfovy);
     uint32_t* counts = (uint32_t*)calloc((size_t)ntiles, sizeof(uint32_t));
+#pragma omp parallel for schedule(static)
     for (int i = 0; i < G; i++) {
         splat_t* s = &st->s[i];
         s->radius = 0; if (radii) radii[i] = 0;
@@ -223,7 +233,7 @@ static int build_state(state_t* st, int G, int H, int W, const REAL* means3D, co
         s->depth = pv[2];
         s->opacity = opac[i];
         s->radius = radius; if (radii) radii[i] = radius;
-        for (int ty = s->ty0; ty < s->ty1; ty++) for (int tx = s->tx0; tx < s->tx1; tx++) counts[ty * gx + tx]++;
+        for (int ty = s->ty0; ty < s->ty1; ty++) for (int tx = s->tx0; tx < s->tx1; tx++) { DWG_ADD(counts[ty * gx + tx], 1u); }
     }
     int64_t K = 0;
     for (int t = 0; t < ntiles; t++) { st->tile_start[t] = (uint32_t)K; K += counts[t]; }
@@ -240,6 +250,7 @@ static int build_state(state_t* st, int G, int H, int W, const REAL* means3D, co
             keys[st->tile_start[t] + counts[t]++] = key;
         }
     }
+#pragma omp parallel for schedule(dynamic, 4)
     for (int t = 0; t < ntiles; t++) {
         uint32_t a = st->tile_start[t], b = st->tile_start[t + 1];
         if (b - a > 1) qsort(keys + a, b - a, sizeof(uint64_t), cmp_u64);
@@ -253,6 +264,7 @@ static int build_state(state_t* st, int G, int H, int W, const REAL* means3D, co
 static void composite_forward(const state_t* st, const REAL* bg, REAL* out_color, REAL* out_depth,
                               REAL* out_alpha, REAL* final_T, int* n_contrib) {
     int H = st->H, W = st->W;
+#pragma omp parallel for collapse(2) schedule(dynamic, 2)
     for (int ty = 0; ty < st->tiles_y; ty++) for (int tx = 0; tx < st->tiles_x; tx++) {
         int t = ty * st->tiles_x + tx;
         uint32_t a = st->tile_start[t], b = st->tile_start[t + 1];
@@ -331,6 +343,7 @@ int dwg_oracle_raster_backward(int G, int H, int W, const REAL* means3D, const R
     REAL* gcol = (REAL*)calloc((size_t)(G > 0 ? G : 1) * 3, sizeof(REAL));
     REAL* gdep = (REAL*)calloc((size_t)(G > 0 ? G : 1), sizeof(REAL));
     const REAL ddelx_dx = (REAL)0.5 * W, ddely_dy = (REAL)0.5 * H;
+#pragma omp parallel for collapse(2) schedule(dynamic, 2)
     for (int ty = 0; ty < st.tiles_y; ty++) for (int tx = 0; tx < st.tiles_x; tx++) {
         int t = ty * st.tiles_x + tx;
         uint32_t a = st.tile_start[t];
@@ -359,27 +372,28 @@ int dwg_oracle_raster_backward(int G, int H, int W, const REAL* means3D, const R
                 REAL inv1a = 1 / (1 - alpha);
                 for (int ch = 0; ch < 3; ch++) {
                     dL_dalpha += (s->rgb[ch] * T - acc[ch] * inv1a) * gp[ch];
-                    gcol[3 * gid + ch] += w * gp[ch];
+                    DWG_ADD(gcol[3 * gid + ch], w * gp[ch]);
                     acc[ch] += s->rgb[ch] * w;
                 }
                 dL_dalpha += (s->depth * T - accd * inv1a) * gpd;
-                gdep[gid] += w * gpd; accd += s->depth * w;
+                DWG_ADD(gdep[gid], w * gpd); accd += s->depth * w;
                 dL_dalpha += (T - acca * inv1a) * gpa; acca += w;
                 dL_dalpha += (-T_final * inv1a) * bgdot;
                 REAL dL_dG = s->opacity * dL_dalpha;
                 REAL gdx = s->ca * dx + s->cb * dy, gdy = s->cc * dy + s->cb * dx;
                 REAL dG_ddx = -Gv * gdx, dG_ddy = -Gv * gdy;
-                g2d[2 * gid] += dL_dG * dG_ddx * ddelx_dx;
-                g2d[2 * gid + 1] += dL_dG * dG_ddy * ddely_dy;
-                gcon[3 * gid] += (REAL)-0.5 * Gv * dx * dx * dL_dG;
-                gcon[3 * gid + 1] += (REAL)-0.5 * Gv * dx * dy * dL_dG; /* NB: b appears twice: stored as half, doubled below */
-                gcon[3 * gid + 2] += (REAL)-0.5 * Gv * dy * dy * dL_dG;
-                gop[gid] += Gv * dL_dalpha;
+                DWG_ADD(g2d[2 * gid], dL_dG * dG_ddx * ddelx_dx);
+                DWG_ADD(g2d[2 * gid + 1], dL_dG * dG_ddy * ddely_dy);
+                DWG_ADD(gcon[3 * gid], (REAL)-0.5 * Gv * dx * dx * dL_dG);
+                DWG_ADD(gcon[3 * gid + 1], (REAL)-0.5 * Gv * dx * dy * dL_dG); /* NB: b appears twice: stored as half, doubled below */
+                DWG_ADD(gcon[3 * gid + 2], (REAL)-0.5 * Gv * dy * dy * dL_dG);
+                DWG_ADD(gop[gid], Gv * dL_dalpha);
             }
         }
     }
     /* per-Gaussian chain */
     const REAL focal_x = W / (2 * tanfovx), focal_y = H / (2 * tanfovy);
+#pragma omp parallel for schedule(static)
     for (int i = 0; i < G; i++) {
         const splat_t* s = &st.s[i];
         REAL gm[3] = {0, 0, 0};

@@ -58,3 +58,115 @@ def test_flat_gradient_allreduce_gloo_world2():
     assert torch.equal(res[0][1], res[1][1])              # identical reduced gradients on both ranks
     # d/da of (a @ x).sum() * (r+1) with x = r+1  ->  (r+1)^2 per entry; summed over ranks 1 + 4 = 5
     assert torch.allclose(res[0][2], torch.full((7, 3), 5.0))
+
+
+# ---------------------------------------------------------------------------------------------------------------------------------------
+# the REAL loop body (trainer.SDSTrainer.train_step) on two gloo ranks: per-rank view accumulation, the one all-reduce, the 1 / V fold
+# into Adam, replica identity after the step, and equality with one process that accumulates the same views.  The HIP kernels cannot run
+# here, so the scene is a small differentiable stand-in and the fused Adam launch is replaced by the same arithmetic in torch.
+# ---------------------------------------------------------------------------------------------------------------------------------------
+def _cpu_adam_step(self):
+    self.t += 1
+    self.current_iteration += 1
+    b = self.buf
+    for pg in self.param_groups:
+        s = slice(pg["start"], pg["end"])
+        g = b.grad[s] * self.grad_scale
+        b1, b2 = pg["betas"]
+        b.m[s].mul_(b1).add_(g, alpha=1 - b1)
+        b.v[s].mul_(b2).addcmul_(g, g, value=1 - b2)
+        mh = b.m[s] / (1 - b1 ** self.t)
+        vh = b.v[s] / (1 - b2 ** self.t)
+        b.flat[s].sub_(pg["lr"] * mh / (vh.sqrt() + pg["eps"]))
+
+
+class _ToyScene(torch.nn.Module):
+    """Scene stand-in: image[1,H,W,3] = a smooth function of the parameters and of the view's camera scalar."""
+
+    def __init__(self):
+        super().__init__()
+        g = torch.Generator().manual_seed(0)
+        self.a = torch.nn.Parameter(torch.randn(6, 3, generator=g))
+        self.b = torch.nn.Parameter(torch.randn(5, generator=g))
+
+    def forward(self, data, smpl_observed_inputs=None, use_densifier=False, bg_mode=None):
+        az = data["azimuth"].float().reshape(())
+        pose = smpl_observed_inputs["body_pose"].float().sum() if smpl_observed_inputs is not None else 0.0
+        base = torch.linspace(0, 1, 4 * 4 * 3).reshape(1, 4, 4, 3)
+        img = torch.sin(base * self.a.sum() + az * 0.01 + pose) + (self.b ** 2).sum() * torch.cos(base * (1.0 + az * 0.003))
+        return {"image": img, "alpha": torch.ones(1, 4, 4, 1), "depth": torch.ones(1, 4, 4, 1)}
+
+
+def _toy_views(which, step):
+    views = []
+    for v in which:
+        g = torch.Generator().manual_seed(1000 * v + step)
+        views.append({"azimuth": torch.tensor([45.0 * v]), "elevation": torch.tensor([80.0]), "radius": torch.tensor([2.0]),
+                      "tanfov": torch.tensor([0.52]), "smpl_inputs": {"body_pose": torch.randn(1, 63, generator=g) * 0.1},
+                      "rng_seed": 77 + v})
+    return views
+
+
+def _toy_trainer(rank, world, views, dist_mod):
+    from dreamwaltz_g_amd import configs, optim, sds_step, trainer
+    optim.FlatOptimizer.step = _cpu_adam_step            # the fused HIP Adam, restated (this process only)
+    cfg = configs.TrainConfig(); cfg.device = "cpu"; cfg.prompt.text_augmentation = False
+    scene = _ToyScene()
+    opts = optim.build_flat_optimizers({"avatar": optim.AdamSpec([dict(params=[scene.a], lr=1e-2)], eps=1e-15),
+                                        "nerf": optim.AdamSpec([dict(params=[scene.b], lr=1e-3)], betas=(0.9, 0.99), eps=1e-15)}, torch.device("cpu"))
+    w = torch.randn(1, 4, 4, 3, generator=torch.Generator().manual_seed(9))
+    tr = trainer.SDSTrainer(cfg, scene, sds_step._ImageLoss(w), opts, {}, use_controlnet=False, dist=dist_mod, world=world, max_step=100)
+    tr.set_views(views)
+    return tr, opts
+
+
+def _trainer_worker(rank, world, port, q):
+    import sys
+    sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    import dwg_import  # noqa: F401
+    os.environ["MASTER_ADDR"] = "127.0.0.1"; os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    V = 4
+    tr, opts = _toy_trainer(rank, world, V, dist)
+    for step in range(3):
+        mine = _toy_views(range(rank, V, world), step)           # view v -> rank v mod world: two views per rank
+        tr.train_step(mine)
+    q.put((rank, opts.buffers.flat.numpy().copy(), opts.buffers.grad.numpy().copy()))      # by value (no fd passing after exit)
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_train_step_multiview_two_ranks_equal_one_process_accumulating_the_same_views():
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_trainer_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = sorted([q.get(timeout=300) for _ in range(2)], key=lambda t: t[0])
+    res = [(r, torch.from_numpy(a), torch.from_numpy(b)) for r, a, b in res]
+    for p in procs:
+        p.join(timeout=120)
+        assert p.exitcode == 0
+    assert torch.equal(res[0][1], res[1][1]) and torch.equal(res[0][2], res[1][2])      # replicas bit-identical after three steps
+    import dwg_import  # noqa: F401
+    from dreamwaltz_g_amd import optim
+    saved = optim.FlatOptimizer.step
+    try:
+        tr, opts = _toy_trainer(0, 1, 4, None)
+        for step in range(3):
+            tr.train_step(_toy_views(range(4), step))                                   # one process, all four views accumulated
+    finally:
+        optim.FlatOptimizer.step = saved
+    assert tr.total_views == 4 and opts["avatar"].grad_scale == 0.25
+    assert torch.allclose(opts.buffers.grad, res[0][2], rtol=1e-5, atol=1e-7)           # summed (not yet averaged) gradients of the last step
+    assert torch.allclose(opts.buffers.flat, res[0][1], rtol=1e-4, atol=1e-6)
+    # a single dict is still the reference's one-view step
+    tr1, opts1 = None, None
+    try:
+        tr1, opts1 = _toy_trainer(0, 1, 1, None)
+        before = opts1.buffers.flat.clone()
+        tr1.train_step(_toy_views([0], 0)[0])
+    finally:
+        optim.FlatOptimizer.step = saved
+    assert opts1["avatar"].grad_scale == 1.0 and not torch.equal(before, opts1.buffers.flat)

@@ -122,3 +122,20 @@ def test_backward_cov3d_precomp_and_sh():
     _fd_check(lambda v: _loss(ds, wc, wd, wa, shs=v), shs, g["shs"], idx, 1e-6, "shs")
     idx = [(rs.randint(0, 32), rs.randint(0, 3)) for _ in range(12)]
     _fd_check(lambda v: _loss(ds, wc, wd, wa, means3D=v), ds["means3D"], g["means3D"], idx, 1e-6, "means3D(sh)")
+
+
+def test_openmp_build_of_the_oracle_equals_the_checker_build():
+    """bench.py's cpu_baseline times the -fopenmp build (tiles / Gaussians across the host cores); the checker build stays single-threaded.
+    Same forward bit for bit; gradients equal up to the order of the fp32 sums."""
+    import numpy as np
+    from tests import raster_cases as rc
+    sc = rc.make_scene(3000, 96, 80, seed=4)
+    a, b = rc.oracle_forward(sc), rc.oracle_forward(sc, omp=True)
+    for k in ("color", "depth", "alpha", "radii", "n_contrib"):
+        assert np.array_equal(a[k], b[k]), k
+    assert a["num_pairs"] == b["num_pairs"]
+    wc = np.random.RandomState(0).randn(3, 96, 80).astype(np.float32)
+    ga = rc.oracle_backward(sc, wc, None, None, dtype=np.float32)
+    gb = rc.oracle_backward(sc, wc, None, None, dtype=np.float32, omp=True)
+    for k in ("means3D", "scales", "rotations", "opacities", "colors", "means2D"):
+        assert rc.grad_err(gb[k], ga[k])["rel_l2"] < 1e-5, k

@@ -34,6 +34,17 @@ def test_graphed_frames_equal_eager_frames():
         assert K > 0 and Kref > 0
         for k in ("image", "alpha", "depth"):
             assert torch.equal(o[k], e[k]), k                  # same kernels, same inputs, deterministic forward
+    # eager frames through the SAME Scene while the graph is alive (training between previews): the renderer replaces its binning-order
+    # tensor every `reorder_every` frames and keeps its own pair bookkeeping; the graph holds its own references and its own frozen state
+    scene.renderer.reorder_every = 2
+    with torch.inference_mode():
+        for p in poses[:5]:
+            scene.forward(data, smpl_observed_inputs=p, use_densifier=False, bg_mode=None)
+    junk = [torch.randint(0, 2 ** 31 - 1, (20000,), dtype=torch.int32, device=dev) for _ in range(8)]     # recycle freed blocks, if any
+    assert not scene.renderer.pair_state(dev, 256, 256).frozen
+    o = pl.replay(poses[2])
+    assert pl.check() and torch.equal(o["image"], eager[2]["image"])
+    del junk
     # a capacity too small for the frame: the replay flags it, a recapture repairs it
     pl._state.cap = 1024
     pl.graph, pl.outputs = None, None

@@ -1,8 +1,10 @@
 #!/bin/bash
-# Regenerates the judged profiles of a round at HEAD on a GPU box:  bash tools/profile_round.sh r02
+# Regenerates the judged profiles of a round at HEAD on a GPU box:  bash tools/profile_round.sh r03 [commit]
+# (the box has no .git: pass `git rev-parse --short HEAD` as the second argument; the PMC profile is also stamped with a hash of the kernel sources)
 # (kernel-trace / stats in their own runs, PMC counters in their own runs -- gpurun refuses the combination)
 set -u
-R=${1:-r02}
+R=${1:-r03}
+COMMIT=${2:-unknown}
 # DWG_PROFILE_PARTS: which passes to run (default all): eager graph pmc bench
 PARTS=${DWG_PROFILE_PARTS:-"eager graph pmc bench"}
 has() { case " $PARTS " in *" $1 "*) return 0;; *) return 1;; esac; }
@@ -10,7 +12,7 @@ REPO=$(cd "$(dirname "$0")/.." && pwd)
 OUT=$REPO/gpurun_out/prof_$R
 mkdir -p $OUT $REPO/profiles
 cd /tmp && export TMPDIR=/tmp
-B="python $REPO/bench.py --no-cpu-baseline"
+B="python $REPO/bench.py --headline-only --no-cpu-baseline"
 has eager && timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/eager -o sds -- $B --steps 5 --warmup 2 --eager > $OUT/eager.log 2>&1
 has graph && timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/graph -o sds -- $B --steps 5 --warmup 2 > $OUT/graph.log 2>&1
 has pmc && timeout 300 rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $OUT/pmc_fetch -o sds -- $B --steps 2 --warmup 1 --eager > $OUT/pmc_fetch.log 2>&1
@@ -19,14 +21,13 @@ cd $REPO
 find $OUT -name "*kernel_stats.csv" | head
 has eager && cp $(find $OUT/eager -name "*kernel_stats.csv" | head -1) profiles/${R}_sds_step_eager_kernel_stats.csv
 has graph && cp $(find $OUT/graph -name "*kernel_stats.csv" | head -1) profiles/${R}_sds_step_graph_kernel_stats.csv
-has pmc && python tools/pmc_traffic.py $(find $OUT/pmc_fetch -name "*counter_collection.csv" | head -1) $(find $OUT/pmc_write -name "*counter_collection.csv" | head -1) profiles/${R}_pmc_traffic.json > $OUT/pmc_traffic.log 2>&1
+has pmc && python tools/pmc_traffic.py $(find $OUT/pmc_fetch -name "*counter_collection.csv" | head -1) $(find $OUT/pmc_write -name "*counter_collection.csv" | head -1) profiles/${R}_pmc_traffic.json $COMMIT > $OUT/pmc_traffic.log 2>&1
 has pmc && tail -2 $OUT/pmc_traffic.log
 has eager && grep '^{"metric"' $OUT/eager.log | tail -1 > profiles/${R}_sds_step_eager_bench_line.json
 # bench lines (the default command, then the two other BASELINE configs)
 if has bench; then
-timeout 400 python bench.py > $OUT/bench_default.log 2>&1; grep '^{"metric"' $OUT/bench_default.log | tail -1 > profiles/${R}_bench_line.json
-timeout 200 python bench.py --config c2 > $OUT/bench_c2.log 2>&1; grep '^{"metric"' $OUT/bench_c2.log | tail -1 > profiles/${R}_bench_line_c2.json
-timeout 200 python bench.py --config c5 > $OUT/bench_c5.log 2>&1; grep '^{"metric"' $OUT/bench_c5.log | tail -1 > profiles/${R}_bench_line_c5.json
+# the default command carries c1 / c2 / c4 (8 views on one GPU) / c5 and the fp32 line as attachments
+timeout 900 python bench.py > $OUT/bench_default.log 2>&1; grep '^{"metric"' $OUT/bench_default.log | tail -1 > profiles/${R}_bench_line.json
 fi
 # large raw traces stay on the box
 find $OUT -name "*kernel_trace.csv" -size +8M -delete; find $OUT -name "*counter_collection.csv" -size +8M -delete; find $OUT -name "*.db" -delete
