@@ -141,6 +141,24 @@ class GeneralLinearBlendSkinning(nn.Module):
         self.use_smplx = True
         self._subsets = []          # [(index tensor kept alive, its version, gathered rows)]
 
+    @classmethod
+    def from_reference(cls, ref) -> "GeneralLinearBlendSkinning":
+        """Adopts the tensors of a reference `GeneralLinearBlendSkinning` (inverse_lbs.py:521-568: the copies it took of the smplx model's
+        v_template / shapedirs / expr_dirs / posedirs / J_regressor / lbs_weights / parents / betas / expression / pose_mean / jaw, eye
+        poses) -- by attribute name; the frozen `learn_*` flags of the shipped recipes are required."""
+        if not getattr(ref, "use_smplx", True):
+            raise NotImplementedError("SMPL (not SMPL-X) body models")
+        for k in ("v_template", "shapedirs", "posedirs", "J_regressor", "lbs_weights", "expr_dirs"):
+            if getattr(getattr(ref, k), "requires_grad", False):
+                raise NotImplementedError("learnable %s (cfg.render.deform_learn_*): the skeleton tensors are frozen on this path" % k)
+        t = lambda v: torch.as_tensor(v).detach()       # noqa: E731
+        body = {k: t(getattr(ref, k)) for k in ("v_template", "shapedirs", "expr_dirs", "posedirs", "J_regressor", "lbs_weights", "betas",
+                                                  "expression", "pose_mean", "jaw_pose", "leye_pose", "reye_pose")}
+        body["parents"] = t(ref.parents).long()
+        m = cls(body)
+        m.NUM_BODY_JOINTS = int(getattr(ref, "NUM_BODY_JOINTS", 21))
+        return m.to(body["v_template"].device)
+
     def get_full_shape(self, betas=None, expression=None, batch_size=None, extra_betas=None):
         """inverse_lbs.py:570-589."""
         betas = self.betas if betas is None else betas
@@ -277,6 +295,20 @@ class MeshBindingGaussianModel(nn.Module):
         self.register_buffer("points_to_vertices", self.triangles[p2t])
         self._rebuild_topology()
 
+    @classmethod
+    def from_reference(cls, ref) -> "MeshBindingGaussianModel":
+        """Adopts a reference `MeshBindingGaussianModel` (avatar.py:921-966) by attribute name: triangles (already re-indexed to the part's
+        vertices), predefined_vertex_indices, and the three parameters _bary_coords / _vertex_coords / _scales with their learn flags."""
+        n = int(ref._n_points_per_triangle)
+        m = cls(ref._vertex_coords.detach(), ref.triangles.detach(), torch.as_tensor(ref.predefined_vertex_indices), n_per_triangle=n,
+                learn_bary_coords=bool(ref.learn_bary_coords), learn_vertex_coords=bool(ref.learn_vertex_coords),
+                learn_scales=bool(ref.learn_scales))
+        with torch.no_grad():
+            m._bary_coords.copy_(ref._bary_coords.detach()); m._scales.copy_(ref._scales.detach())
+        if hasattr(ref, "predefined_triangle_indices"):
+            m.predefined_triangle_indices = torch.as_tensor(ref.predefined_triangle_indices)
+        return m.to(ref._vertex_coords.device)
+
     def _rebuild_topology(self):
         """Derived buffers of the native path (csrc/meshbind.hip): int32 topology + the static vertex -> face adjacency."""
         self.register_buffer("triangles_i32", self.triangles.to(torch.int32).contiguous(), persistent=False)
@@ -374,6 +406,66 @@ class DreamWaltzG(nn.Module):
         self.nearest_triangles_buffer = {'nearest_vertex_indices': nearest_vertex_indices}
         self._canonical_cache = None
         self._canonical_vertices = {}
+
+    @classmethod
+    def from_reference(cls, ref, cfg=None) -> "DreamWaltzG":
+        """The HIP-backed avatar for the object the reference's `build_gaussian_avatar` returned (avatar.py:1642-1714 -> DreamWaltzG.__init__
+        avatar.py:1098-1244): same Gaussians, same networks, same body -- every Parameter / buffer is adopted BY NAME from `ref`
+        (its state_dict() loads into this object key for key), the constructor-time work of the reference (NeRF point cloud, nearest
+        triangles, inverse LBS of the initial positions, LBS-weight smoothing) is NOT repeated.  dropin/dwg_bind.py calls this so that
+        main.py reaches the kernels without an edit; `cfg` defaults to `ref.cfg` (non-default render flags are rejected loudly)."""
+        cfg = cfg if cfg is not None else getattr(ref, "cfg", None)
+        if type(ref.lbs_model).__name__ != "GeneralLinearBlendSkinning":
+            raise NotImplementedError("deform_type without 'glbs' (%s)" % type(ref.lbs_model).__name__)
+        if getattr(ref, "deform_model", None) is not None:
+            raise NotImplementedError("deform_type 'non_rigid' (the reference's animate raises for it too, avatar.py:317-318)")
+        enc = ref.nerf_encoder
+        want = dict(input_dim=3, num_levels=16, level_dim=2, base_resolution=16)
+        for k, v in want.items():
+            if hasattr(enc, k) and int(getattr(enc, k)) != v:
+                raise NotImplementedError("nerf encoder %s=%r (built: %r)" % (k, getattr(enc, k), v))
+        lbs = GeneralLinearBlendSkinning.from_reference(ref.lbs_model)
+        mesh = {k: MeshBindingGaussianModel.from_reference(m) for k, m in ref.mesh_binding_gaussians.items()}
+        nvi = None
+        ntb = getattr(ref, "nearest_triangles_buffer", None)
+        if isinstance(ntb, dict):
+            nvi = ntb.get("nearest_vertex_indices")
+        av = cls(lbs, ref._positions.detach(), torch.exp(ref._scales.detach()), ref._quaternions.detach(), ref._lbs_weights.detach(),
+                 {k: v.detach() for k, v in ref.smpl_canonical_inputs.items()}, mesh, nerf_bound=float(ref.nerf_bound),
+                 init_offset=float(ref.init_offset), init_scale=float(ref.init_scale), max_scale=float(ref.max_scale),
+                 learn_positions=bool(ref._positions.requires_grad), learn_scales=bool(ref._scales.requires_grad),
+                 learn_quaternions=bool(ref._quaternions.requires_grad), learn_lbs_weights=bool(ref._lbs_weights.requires_grad),
+                 learn_hand_betas=bool(getattr(ref, "learn_hand_betas", False)), learn_face_betas=bool(getattr(ref, "learn_face_betas", False)),
+                 nearest_vertex_indices=nvi, cfg=cfg)
+        if isinstance(ntb, dict):
+            av.nearest_triangles_buffer = ntb
+        for k in ("gridtype", "interpolation", "align_corners", "log2_hashmap_size"):
+            if hasattr(enc, k) and getattr(enc, k) != getattr(av.nerf_encoder, k):
+                raise NotImplementedError("nerf encoder %s=%r (this path builds %r: nerf_model.py:223-231 defaults)"
+                                          % (k, getattr(enc, k), getattr(av.nerf_encoder, k)))
+        if hasattr(enc, "per_level_scale") and abs(float(enc.per_level_scale) - float(av.nerf_encoder.per_level_scale)) > 1e-6:
+            raise NotImplementedError("nerf encoder per_level_scale=%r (built: %r)" % (enc.per_level_scale, av.nerf_encoder.per_level_scale))
+        av = av.to(ref._positions.device)
+        loaded, unknown, missing = av.load_reference_state_dict(ref.state_dict(), prefix="")
+        # every learnable tensor of the reference must have found its place; frozen body tensors are adopted above under other names
+        need = [k for k, p in ref.named_parameters() if p.requires_grad]
+        lost = [k for k in need if k not in loaded]
+        if lost:
+            raise RuntimeError("DreamWaltzG.from_reference: trainable reference parameters with no counterpart: %s" % lost)
+        av.cfg = cfg
+        av.__dict__["reference"] = ref       # NOT a registered sub-module (no state_dict keys): construction-time attributes the trainer
+                                             # may still read (canonical_vertices, canonical_triangles, ...) resolve through __getattr__
+        return av
+
+    def __getattr__(self, name):
+        # attributes of the adopted reference avatar that this mirror does not carry (canonical_vertices, canonical_triangles, ...)
+        try:
+            return super().__getattr__(name)
+        except AttributeError:
+            ref = self.__dict__.get("reference")
+            if ref is not None and not name.startswith("_") and hasattr(ref, name):
+                return getattr(ref, name)
+            raise
 
     @property
     def device(self):

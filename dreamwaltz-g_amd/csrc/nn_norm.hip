@@ -55,7 +55,43 @@ __global__ __launch_bounds__(256) void k_gn_reduce(int HW, int C, int G, int pix
                     ga[e] = gamma[ch]; be[e] = beta[ch]; mu[e] = gstat[2 * g]; rs[e] = gstat[2 * g + 1];
                 }
             }
-            for (int p = p0 + prow; p < p1; p += rows) {
+            // Long pixel ranges (the VAE's 128^2 .. 512^2 tensors: tens of trips) keep FOUR independent 16-byte loads in flight per thread:
+            // with one load per trip the pass is bound by memory latency (~1.5 TB/s measured), not by HBM.  Short ranges (every denoiser
+            // tensor: 1-2 trips) take the plain loop below -- unrolling THAT one made all of them slower (rejected list).
+            int p = p0 + prow;
+            if (!BWD) {
+                for (; p + 3 * rows < p1; p += 4 * rows) {
+                    const T* xp = x + ((size_t)b * HW + p) * C + (size_t)cc * 8;
+                    const size_t st = (size_t)rows * C;
+                    const vec8<T> x0 = *reinterpret_cast<const vec8<T>*>(xp), x1 = *reinterpret_cast<const vec8<T>*>(xp + st),
+                                  x2 = *reinterpret_cast<const vec8<T>*>(xp + 2 * st), x3 = *reinterpret_cast<const vec8<T>*>(xp + 3 * st);
+#pragma unroll
+                    for (int e = 0; e < 8; e++) {
+                        const float a = (float)x0[e], bq = (float)x1[e], c = (float)x2[e], d = (float)x3[e];
+                        s1[e] += (a + bq) + (c + d); s2[e] += (a * a + bq * bq) + (c * c + d * d);
+                    }
+                }
+            } else if (p < p1) {
+                // backward statistics: the next trip's two loads are issued before this trip's arithmetic (software pipeline; unrolling the
+                // arithmetic itself costs 70 more registers and halves the occupancy)
+                size_t off = ((size_t)b * HW + p) * C + (size_t)cc * 8;
+                const size_t st = (size_t)rows * C;
+                vec8<T> xc = *reinterpret_cast<const vec8<T>*>(x + off), dc = *reinterpret_cast<const vec8<T>*>(dy + off);
+                for (; p < p1; p += rows) {
+                    vec8<T> xn = xc, dn = dc;
+                    if (p + rows < p1) { xn = *reinterpret_cast<const vec8<T>*>(x + off + st); dn = *reinterpret_cast<const vec8<T>*>(dy + off + st); }
+#pragma unroll
+                    for (int e = 0; e < 8; e++) {
+                        float xh = ((float)xc[e] - mu[e]) * rs[e];
+                        float g = (float)dc[e];
+                        if (silu) g *= silu_grad(xh * ga[e] + be[e]);
+                        g *= ga[e];
+                        s1[e] += g; s2[e] += g * xh;
+                    }
+                    xc = xn; dc = dn; off += st;
+                }
+            }
+            for (; p < p1; p += rows) {
                 size_t off = ((size_t)b * HW + p) * C + (size_t)cc * 8;
                 vec8<T> xv = *reinterpret_cast<const vec8<T>*>(x + off);
                 if (!BWD) {
@@ -170,7 +206,55 @@ __global__ __launch_bounds__(256) void k_gn_apply(int HW, int C, int G, int pix_
         const T* rp = (BWD && residual) ? residual + ((size_t)b * HW + p0 + prow) * C + (size_t)cc * 8 : nullptr;
         T* op = out + ((size_t)b * HW + p0 + prow) * C + (size_t)cc * 8;
         const size_t step = (size_t)rows * C;
-        for (int p = p0 + prow; p < p1; p += rows) {
+        int p = p0 + prow;
+        if (!BWD) {
+            // long pixel ranges: four independent loads in flight per thread (see k_gn_reduce)
+            for (; p + 3 * rows < p1; p += 4 * rows) {
+                vec8<T> xv[4];
+#pragma unroll
+                for (int u = 0; u < 4; u++) xv[u] = *reinterpret_cast<const vec8<T>*>(xp + u * step);
+#pragma unroll
+                for (int u = 0; u < 4; u++) {
+                    vec8<T> o;
+#pragma unroll
+                    for (int e = 0; e < 8; e++) {
+                        float z = ((float)xv[u][e] - mu[e]) * rs[e] * ga[e] + be[e];
+                        o[e] = (T)(silu ? silu_f(z) : z);
+                    }
+                    *reinterpret_cast<vec8<T>*>(op + u * step) = o;
+                }
+                xp += 4 * step; op += 4 * step;
+            }
+        } else {
+            for (; p + rows < p1; p += 2 * rows) {
+                vec8<T> xv[2], dv[2], rv[2];
+#pragma unroll
+                for (int u = 0; u < 2; u++) {
+                    xv[u] = *reinterpret_cast<const vec8<T>*>(xp + u * step); dv[u] = *reinterpret_cast<const vec8<T>*>(dp + u * step);
+                    if (rp) rv[u] = *reinterpret_cast<const vec8<T>*>(rp + u * step);
+                }
+#pragma unroll
+                for (int u = 0; u < 2; u++) {
+                    vec8<T> o;
+#pragma unroll
+                    for (int e = 0; e < 8; e++) {
+                        float xh = ((float)xv[u][e] - mu[e]) * rs[e];
+                        float gq = (float)dv[u][e];
+                        if (silu) gq *= silu_grad(xh * ga[e] + be[e]);
+                        gq *= ga[e];
+                        o[e] = (T)(rs[e] * (gq - m1[e] - xh * m2[e]));
+                    }
+                    if (rp) {
+#pragma unroll
+                        for (int e = 0; e < 8; e++) o[e] = (T)((float)o[e] + (float)rv[u][e]);
+                    }
+                    *reinterpret_cast<vec8<T>*>(op + u * step) = o;
+                }
+                xp += 2 * step; op += 2 * step; dp += 2 * step;
+                if (rp) rp += 2 * step;
+            }
+        }
+        for (; p < p1; p += rows) {
             vec8<T> xv = *reinterpret_cast<const vec8<T>*>(xp);
             vec8<T> o;
             if (!BWD) {
@@ -308,7 +392,7 @@ static int gn_geometry(int HW, int C, int G, int* pix_per_block, int* chunks, si
     return DWG_OK;
 }
 // reduction pass: ~64K elements per workgroup, at most GN_MAX_CHUNKS partials per image
-#define GN_MAX_CHUNKS 512
+#define GN_MAX_CHUNKS 2048     // 512^2 x 128-channel VAE tensors: 2048 workgroups of the statistics pass (8 per CU) keep HBM busy
 #define GN_FOLD_MAX_CHUNKS 32      // up to this many partials per output the apply pass sums them itself (no finalize launch)
 static void gn_reduce_geometry(int HW, int C, int* pix_per_block, int* chunks) {
     long long ppb = 16384 / C; if (ppb < 8) ppb = 8;

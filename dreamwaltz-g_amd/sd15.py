@@ -72,6 +72,51 @@ class VAEConfig:
     scaling_factor: float = 0.18215
 
 
+def _cfg_get(config, key, default):
+    if config is None:
+        return default
+    if isinstance(config, dict):
+        return config.get(key, default)
+    return getattr(config, key, default)
+
+
+def unet_config_from(config) -> "UNetConfig":
+    """UNetConfig from a diffusers `UNet2DConditionModel.config` (attribute or dict access; None -> the SD-1.5 defaults).  Anything that is
+    not the SD-1.x layer graph this file builds (one transformer block per attention site, heads = attention_head_dim, GEGLU, no
+    class / addition embeddings) is rejected."""
+    d = UNetConfig()
+    if config is None:
+        return d
+    boc = tuple(int(c) for c in _cfg_get(config, "block_out_channels", d.block_out_channels))
+    down = tuple(_cfg_get(config, "down_block_types", ("CrossAttnDownBlock2D",) * 3 + ("DownBlock2D",)))
+    heads = _cfg_get(config, "attention_head_dim", d.heads)
+    if isinstance(heads, (list, tuple)):
+        if len(set(heads)) != 1:
+            raise NotImplementedError("per-level attention_head_dim %r (SDXL-style UNets are outside this path)" % (heads,))
+        heads = heads[0]
+    for key, want in (("transformer_layers_per_block", 1), ("class_embed_type", None), ("addition_embed_type", None), ("use_linear_projection", False),
+                      ("only_cross_attention", False), ("dual_cross_attention", False)):
+        got = _cfg_get(config, key, want)
+        if got != want:
+            raise NotImplementedError("UNet config %s=%r (SD-1.x layer graph only)" % (key, got))
+    return UNetConfig(in_channels=int(_cfg_get(config, "in_channels", d.in_channels)), out_channels=int(_cfg_get(config, "out_channels", d.out_channels)),
+                      block_out_channels=boc, layers_per_block=int(_cfg_get(config, "layers_per_block", d.layers_per_block)), heads=int(heads),
+                      cross_dim=int(_cfg_get(config, "cross_attention_dim", d.cross_dim)), groups=int(_cfg_get(config, "norm_num_groups", d.groups)),
+                      attn_blocks=tuple(t.startswith("CrossAttn") for t in down))
+
+
+def vae_config_from(config) -> "VAEConfig":
+    """VAEConfig from a diffusers `AutoencoderKL.config` (None -> SD-1.5's)."""
+    d = VAEConfig()
+    if config is None:
+        return d
+    return VAEConfig(in_channels=int(_cfg_get(config, "in_channels", d.in_channels)),
+                     block_out_channels=tuple(int(c) for c in _cfg_get(config, "block_out_channels", d.block_out_channels)),
+                     layers_per_block=int(_cfg_get(config, "layers_per_block", d.layers_per_block)),
+                     latent_channels=int(_cfg_get(config, "latent_channels", d.latent_channels)), groups=int(_cfg_get(config, "norm_num_groups", d.groups)),
+                     scaling_factor=float(_cfg_get(config, "scaling_factor", d.scaling_factor)))
+
+
 def _resnet_shapes(sh, pre, cin, cout, temb):
     sh[pre + ".norm1.weight"] = (cin,); sh[pre + ".norm1.bias"] = (cin,)
     sh[pre + ".conv1.weight"] = (cout, cin, 3, 3); sh[pre + ".conv1.bias"] = (cout,)
