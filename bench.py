@@ -61,6 +61,8 @@ def parse():
     ap.add_argument("--eager", action="store_true", help="launch every kernel eagerly (no hipGraph replay of the denoiser/VAE plans)")
     ap.add_argument("--no-gpu-condition", action="store_true", help="fixed condition image instead of the per-step GPU OpenPose image of the posed body")
     ap.add_argument("--sync-pairs", action="store_true", help="exact pair-buffer sizing through a 16-byte read-back per frame")
+    ap.add_argument("--sequential-views", action="store_true", help="config c4: one guidance call per view (gradients accumulated) instead of one "
+                                                                    "batched VAE / denoiser pass for all the views of a rank")
     ap.add_argument("--share-gpu", action="store_true", help="every rank on cuda:0 over gloo: a functional run of the N > 1 path on a 1-GPU box, "
                                                              "NOT a measurement")
     return ap.parse_args()
@@ -153,26 +155,52 @@ def _cpu_pass(w, backward):
     return t1 - t0, t2 - t1
 
 
+_THREADS = {}
+
+
+def _pick_threads(host):
+    """torch thread count for the oracle: the faster of {all host cores, 32} on a micro-probe of what the oracle's
+    `animate` is made of -- a few dozen element-wise / reduction / small-matmul ops on [1e4, 55]-sized tensors, forward and backward.
+    (Measured on the 256-core GPU hosts, round 3: the WHOLE 10k-Gaussian oracle pass takes 0.16 s on 32 threads and 33.7 s on 256, 3.7 s
+    vs 110 s with the backward -- every small op pays the wake-up of 256 OpenMP threads; probing with the full pass cost the default
+    bench run four minutes, hence the micro-probe.)  Cached for the process."""
+    if host in _THREADS:
+        return _THREADS[host]
+    g = torch.Generator().manual_seed(0)
+    w = torch.rand(10000, 55, generator=g); A = torch.randn(55, 16, generator=g); p = torch.randn(10000, 3, generator=g)
+
+    def probe():
+        t0 = time.perf_counter()
+        for _ in range(3):
+            x = p.clone().requires_grad_(True)
+            wn = w / w.sum(-1, keepdim=True)
+            T = (wn @ A).view(-1, 4, 4)
+            y = (T[:, :3, :3] @ x[:, :, None])[..., 0] + T[:, :3, 3]
+            q = torch.nn.functional.normalize(torch.cat([y, y.norm(dim=-1, keepdim=True)], -1), dim=-1)
+            (torch.sigmoid(q).sum() + torch.exp(-y * y).sum()).backward()
+        return time.perf_counter() - t0
+    out = {}
+    for th in sorted({host, min(host, 32)}):
+        torch.set_num_threads(th)
+        probe()
+        out[th] = probe()
+    _THREADS[host] = (min(out, key=out.get), out)
+    return _THREADS[host]
+
+
 def cpu_baseline(G, res, backward=True, canonical=False, budget_s=10.0, unit="steps/s"):
     """The oracle (CPU restatement of the reference's PyTorch LBS / encoder / MLP path + the C tile rasterizer, OpenMP over tiles) timed on
     the host cores on the SAME kind of workload the GPU step renders.  Thread count: BASELINE.md section 4 prescribes
-    torch.set_num_threads(os.cpu_count()); on the 256-core GPU hosts the oracle's element-wise torch ops on 1e4..1e5-row tensors run slower
-    with every core than with 32 threads, so BOTH settings are timed on a 10k-Gaussian sample of the workload and the full-size passes use
-    the faster one (both sample times are reported).  The reference has no CPU diffusion path, so the diffusion half of a step has no CPU
+    torch.set_num_threads(os.cpu_count()); on the 256-core GPU hosts the oracle's small-tensor torch ops run far slower with every core
+    than with 32 threads, so both settings are timed on a micro-probe (`_pick_threads`) and the passes use the faster one (both probe
+    times are reported; the C rasterizer always uses every core through OpenMP).  The reference has no CPU diffusion path, so the diffusion half of a step has no CPU
     counterpart and is NOT in this number."""
     import numpy as np
     host = os.cpu_count() or 1
-    probe = _cpu_workload(min(G, 10000), min(res, 256), canonical)
-    cand = sorted({host, min(host, 32)})
-    probe_s = {}
     os.environ["OMP_NUM_THREADS"] = str(host)            # the OpenMP raster oracle reads it when its library is first loaded
-    for th in cand:
-        torch.set_num_threads(th)
-        _cpu_pass(probe, backward)                       # warm-up (thread pool, page faults)
-        probe_s[th] = sum(_cpu_pass(probe, backward))
-    best = min(probe_s, key=probe_s.get)
+    best, probe_s = _pick_threads(host)
     torch.set_num_threads(best)
-    w = _cpu_workload(G, res, canonical) if (G > 10000 or res > 256) else probe
+    w = _cpu_workload(G, res, canonical)
     ta, tr, spent = [], [], 0.0
     while len(ta) < 5 and (spent < budget_s or len(ta) < 2):            # median of the passes that fit ~budget_s of CPU work, at most 5
         a, r = _cpu_pass(w, backward)
@@ -184,7 +212,7 @@ def cpu_baseline(G, res, backward=True, canonical=False, budget_s=10.0, unit="st
             "threads_probe_s": {str(k): round(v, 3) for k, v in probe_s.items()},
             "sample": "median of %d passes (%.0f s of CPU work): oracle animate %s %.3f s on %d torch threads (%d free Gaussians with 4 non-zero "
                       "skinning weights + %d mesh-bound) + C tile rasterizer %s %.3f s (OpenMP over tiles, %d threads; %d Gaussians @%dx%d); thread "
-                      "count = the faster of {all %d cores, 32} on a 10k-Gaussian sample"
+                      "count = the faster of {all %d cores, 32} on a micro-probe of the oracle's op mix"
                       % (len(ta), spent, what, t_an, best, w["N"], w["M"], what, t_ra, host, G, res, res, host)}
 
 
@@ -298,10 +326,16 @@ class Ctx:
         self.guidance = {}          # dtype -> ControlNetScoreDistillation (plans are shared between the c3 and c4 legs)
         self.state_dicts = None
 
-    def guidance_for(self, dtype):
-        """One guidance object per plan dtype; the seeded random-init state dicts (1.22 G + 34 M parameters, generated on the host) are
-        made once and shared."""
-        if dtype not in self.guidance:
+    def guidance_for(self, dtype, views=1):
+        """One guidance object per (plan dtype, views per call); the seeded random-init state dicts (1.22 G + 34 M parameters, generated on
+        the host) are made once, and the kernel-layout weights in HBM are shared between the objects of one dtype."""
+        key = dtype if views == 1 else (dtype, views)
+        if key not in self.guidance:
+            if views > 1:
+                from dreamwaltz_g_amd import guidance as gd
+                base = self.guidance_for(dtype, 1)
+                self.guidance[key] = gd.ControlNetScoreDistillation(self.dev, image_hw=512, seed=0, dtype=dtype, views=views, share_weights_with=base)
+                return self.guidance[key]
             from dreamwaltz_g_amd import guidance as gd, sd15
             if self.state_dicts is None:
                 u, v = sd15.UNetConfig(), sd15.VAEConfig()
@@ -311,7 +345,7 @@ class Ctx:
             usd, csd, vsd = self.state_dicts
             g = gd.ControlNetScoreDistillation(self.dev, image_hw=512, seed=0, unet_sd=usd, controlnet_sd=csd, vae_sd=vsd, dtype=dtype)
             self.guidance[dtype] = g
-        return self.guidance[dtype]
+        return self.guidance[key]
 
 
 def _timed(ctx, fn, steps, warmup):
@@ -336,7 +370,7 @@ def _timed(ctx, fn, steps, warmup):
     return dt
 
 
-def run_sds(ctx, config, dtype="bf16", views=None, steps=None, warmup=None, profile=True):
+def run_sds(ctx, config, dtype="bf16", views=None, steps=None, warmup=None, profile=True, batch_views=None):
     """c2 / c3 / c4: SDSStep-based workloads.  Returns the JSON line as a dict (rank 0) or None."""
     args = ctx.args
     steps, warmup = defaults(config, steps, warmup)
@@ -347,9 +381,13 @@ def run_sds(ctx, config, dtype="bf16", views=None, steps=None, warmup=None, prof
         views = 8 if config == "c4" else ctx.world
     if views < ctx.world:
         raise SystemExit("bench.py: %d views cannot be spread over %d GPUs (at least one view per rank)" % (views, ctx.world))
+    per_rank = len(range(ctx.rank, views, ctx.world))
+    if batch_views is None:         # c4: one guidance call per step for all the views of a rank, unless --sequential-views
+        batch_views = config == "c4" and not args.sequential_views
+    batch_views = bool(batch_views and guidance and per_rank > 1 and views % ctx.world == 0)
     step = sds_step.SDSStep(n_gaussians=G, res=res, device=ctx.dev, rank=ctx.rank, world=ctx.world, guidance=guidance, dist=ctx.dist,
                             async_pair_count=not args.sync_pairs, gpu_condition=not args.no_gpu_condition, views=views, dtype=dtype,
-                            guidance_obj=ctx.guidance_for(dtype) if guidance else None)
+                            guidance_obj=ctx.guidance_for(dtype, per_rank if batch_views else 1) if guidance else None)
     if not args.eager:
         step.capture_graphs()       # denoiser / VAE plans replay as hipGraphs (identical kernels, one launch each)
     else:
@@ -524,8 +562,11 @@ def main():
             ctx.guidance.pop("f32", None)                         # free the fp32 plans (weights 5 GB, activations) before the other legs
             torch.cuda.empty_cache()
             cfgs = {}
-            c4 = run_sds(ctx, "c4", steps=3, warmup=1, profile=False)
+            c4 = run_sds(ctx, "c4", steps=3, warmup=1, profile=False)                       # 8 views through ONE VAE / denoiser pass per step
             cfgs["c4_n1"] = _brief(c4)
+            ctx.guidance.pop(("bf16", 8), None); torch.cuda.empty_cache()
+            c4s = run_sds(ctx, "c4", steps=3, warmup=1, profile=False, batch_views=False)   # the same 8 views one guidance call at a time
+            cfgs["c4_n1_sequential_views"] = _brief(c4s, ("value", "unit", "ms_per_step", "steps", "warmup", "views_per_s"))
             c2 = run_sds(ctx, "c2", steps=200, warmup=20)
             cfgs["c2"] = _brief(c2)
             c5 = run_c5(ctx, 200, 20)

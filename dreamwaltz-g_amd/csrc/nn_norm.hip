@@ -24,7 +24,7 @@ template <typename T, bool BWD>
 __global__ __launch_bounds__(256) void k_gn_reduce(int HW, int C, int G, int pix_per_block, const T* __restrict__ x,
                                                    const T* __restrict__ dy, const float* __restrict__ stats,
                                                    const float* __restrict__ gamma, const float* __restrict__ beta, int silu,
-                                                   float eps, float* __restrict__ sums /*[B][G][2]*/) {
+                                                   float eps, float* __restrict__ sums /*[B][G][2]*/, int deep) {
     extern __shared__ __attribute__((aligned(16))) float lds[];   // [rows][Cb*2] partials for the current channel pass
     __shared__ float gacc[64 * 2];
     __shared__ float gstat[64 * 2];
@@ -60,7 +60,7 @@ __global__ __launch_bounds__(256) void k_gn_reduce(int HW, int C, int G, int pix
             // tensor: 1-2 trips) take the plain loop below -- unrolling THAT one made all of them slower (rejected list).
             int p = p0 + prow;
             if (!BWD) {
-                for (; p + 3 * rows < p1; p += 4 * rows) {
+                for (; deep && p + 3 * rows < p1; p += 4 * rows) {
                     const T* xp = x + ((size_t)b * HW + p) * C + (size_t)cc * 8;
                     const size_t st = (size_t)rows * C;
                     const vec8<T> x0 = *reinterpret_cast<const vec8<T>*>(xp), x1 = *reinterpret_cast<const vec8<T>*>(xp + st),
@@ -71,7 +71,7 @@ __global__ __launch_bounds__(256) void k_gn_reduce(int HW, int C, int G, int pix
                         s1[e] += (a + bq) + (c + d); s2[e] += (a * a + bq * bq) + (c * c + d * d);
                     }
                 }
-            } else if (p < p1) {
+            } else if (deep && p < p1) {
                 // backward statistics: the next trip's two loads are issued before this trip's arithmetic (software pipeline; unrolling the
                 // arithmetic itself costs 70 more registers and halves the occupancy)
                 size_t off = ((size_t)b * HW + p) * C + (size_t)cc * 8;
@@ -156,7 +156,7 @@ __global__ __launch_bounds__(256) void k_gn_apply(int HW, int C, int G, int pix_
                                                   const float* __restrict__ bsums, const float* __restrict__ gamma,
                                                   const float* __restrict__ beta, int silu, float eps,
                                                   T* __restrict__ out, const float* __restrict__ partials, int pchunks,
-                                                  float* __restrict__ sums_out, const T* __restrict__ residual) {
+                                                  float* __restrict__ sums_out, const T* __restrict__ residual, int deep) {
     __shared__ float gstat[64 * 4];
     __shared__ float tot[128];
     const int b = blockIdx.y, tid = threadIdx.x;
@@ -209,7 +209,7 @@ __global__ __launch_bounds__(256) void k_gn_apply(int HW, int C, int G, int pix_
         int p = p0 + prow;
         if (!BWD) {
             // long pixel ranges: four independent loads in flight per thread (see k_gn_reduce)
-            for (; p + 3 * rows < p1; p += 4 * rows) {
+            for (; deep && p + 3 * rows < p1; p += 4 * rows) {
                 vec8<T> xv[4];
 #pragma unroll
                 for (int u = 0; u < 4; u++) xv[u] = *reinterpret_cast<const vec8<T>*>(xp + u * step);
@@ -226,7 +226,7 @@ __global__ __launch_bounds__(256) void k_gn_apply(int HW, int C, int G, int pix_
                 xp += 4 * step; op += 4 * step;
             }
         } else {
-            for (; p + rows < p1; p += 2 * rows) {
+            for (; deep && p + rows < p1; p += 2 * rows) {
                 vec8<T> xv[2], dv[2], rv[2];
 #pragma unroll
                 for (int u = 0; u < 2; u++) {
@@ -384,6 +384,9 @@ __global__ __launch_bounds__(256) void k_softmax_rows_bwd(int rows, int n, float
     for (int j = lane; j < n; j += 64) ds[j] = (T)(scale * (float)p[j] * (dp[j] - dot));
 }
 
+// DWG_GN_SHALLOW=1: the round-2 loops (one load in flight per thread) -- A/B switch for the long-range paths
+static int gn_deep() { static const int v = getenv("DWG_GN_SHALLOW") ? 0 : 1; return v; }
+
 static int gn_geometry(int HW, int C, int G, int* pix_per_block, int* chunks, size_t* lds) {
     if (C % 8 || G <= 0 || G > 64 || C % G) return DWG_E_ARG;
     int ppb = HW / 256; if (ppb < 16) ppb = 16; if (ppb > 256) ppb = 256;
@@ -392,7 +395,8 @@ static int gn_geometry(int HW, int C, int G, int* pix_per_block, int* chunks, si
     return DWG_OK;
 }
 // reduction pass: ~64K elements per workgroup, at most GN_MAX_CHUNKS partials per image
-#define GN_MAX_CHUNKS 2048     // 512^2 x 128-channel VAE tensors: 2048 workgroups of the statistics pass (8 per CU) keep HBM busy
+#define GN_MAX_CHUNKS_DEEP 2048     // 512^2 x 128-channel VAE tensors: 2048 workgroups of the statistics pass (8 per CU) keep HBM busy
+#define GN_MAX_CHUNKS (gn_deep() ? GN_MAX_CHUNKS_DEEP : 512)
 #define GN_FOLD_MAX_CHUNKS 32      // up to this many partials per output the apply pass sums them itself (no finalize launch)
 static void gn_reduce_geometry(int HW, int C, int* pix_per_block, int* chunks) {
     long long ppb = 16384 / C; if (ppb < 8) ppb = 8;
@@ -418,7 +422,7 @@ static void gn_reduce_geometry(int HW, int C, int* pix_per_block, int* chunks) {
 
 extern "C" {
 
-size_t dwg_groupnorm_workspace_floats(int32_t B, int32_t G) { return (size_t)(B > 0 ? B : 1) * GN_MAX_CHUNKS * (G > 0 ? G : 1) * 2; }
+size_t dwg_groupnorm_workspace_floats(int32_t B, int32_t G) { return (size_t)(B > 0 ? B : 1) * GN_MAX_CHUNKS_DEEP * (G > 0 ? G : 1) * 2; }
 
 int dwg_groupnorm_forward_dt(int32_t dtype, int32_t B, int32_t HW, int32_t C, int32_t G, const void* x, const float* gamma, const float* beta,
                              float eps, int32_t fuse_silu, void* y, float* stats, float* workspace, dwg_stream_t stream_) {
@@ -433,11 +437,11 @@ int dwg_groupnorm_forward_dt(int32_t dtype, int32_t B, int32_t HW, int32_t C, in
     const bool fold = rchunks <= fold_max && 2 * G * 4 <= 256;     // finalize folded into the apply pass
     DWG_DT_SWITCH(dtype,
         DWG_LAUNCH("gn_stats", (k_gn_reduce<T, false>), dim3(rchunks, B), dim3(256), lds, stream, HW, C, G, rppb, (const T*)x,
-                   (const T*)nullptr, (const float*)nullptr, gamma, beta, 0, eps, workspace);
+                   (const T*)nullptr, (const float*)nullptr, gamma, beta, 0, eps, workspace, gn_deep());
         if (!fold) DWG_LAUNCH("gn_finalize", k_gn_finalize, dim3(B), dim3(1024), 0, stream, rchunks, G, (const float*)workspace, stats);
         DWG_LAUNCH("gn_apply", (k_gn_apply<T, false>), dim3(chunks, B), dim3(256), 0, stream, HW, C, G, ppb, (const T*)x,
                    (const T*)nullptr, (const float*)stats, (const float*)nullptr, gamma, beta, fuse_silu, eps, (T*)y,
-                   fold ? (const float*)workspace : (const float*)nullptr, rchunks, stats, (const T*)nullptr))
+                   fold ? (const float*)workspace : (const float*)nullptr, rchunks, stats, (const T*)nullptr, gn_deep()))
     DWG_RETURN_IF_LAUNCH_FAILED();
     return DWG_OK;
 }
@@ -461,11 +465,11 @@ int dwg_groupnorm_backward_dt(int32_t dtype, int32_t B, int32_t HW, int32_t C, i
     const bool fold = rchunks <= fold_max && 2 * G * 4 <= 256;
     DWG_DT_SWITCH(dtype,
         DWG_LAUNCH("gn_bwd_stats", (k_gn_reduce<T, true>), dim3(rchunks, B), dim3(256), lds, stream, HW, C, G, rppb, (const T*)x,
-                   (const T*)dy, stats, gamma, beta, fuse_silu, eps, workspace);
+                   (const T*)dy, stats, gamma, beta, fuse_silu, eps, workspace, gn_deep());
         if (!fold) DWG_LAUNCH("gn_finalize", k_gn_finalize, dim3(B), dim3(1024), 0, stream, rchunks, G, (const float*)workspace, scratch);
         DWG_LAUNCH("gn_bwd_apply", (k_gn_apply<T, true>), dim3(chunks, B), dim3(256), 0, stream, HW, C, G, ppb, (const T*)x,
                    (const T*)dy, stats, (const float*)scratch, gamma, beta, fuse_silu, eps, (T*)dx,
-                   fold ? (const float*)workspace : (const float*)nullptr, rchunks, scratch, (const T*)residual))
+                   fold ? (const float*)workspace : (const float*)nullptr, rchunks, scratch, (const T*)residual, gn_deep()))
     DWG_RETURN_IF_LAUNCH_FAILED();
     return DWG_OK;
 }

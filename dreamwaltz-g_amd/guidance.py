@@ -66,25 +66,35 @@ def C(value, current_step=None, max_iteration=None) -> float:
 class ControlNetScoreDistillation:
     def __init__(self, device, unet_cfg: Optional[sd15.UNetConfig] = None, vae_cfg: Optional[sd15.VAEConfig] = None,
                  unet_sd=None, controlnet_sd=None, vae_sd=None, image_hw=512, guidance_scale=None, min_timestep=None,
-                 max_timestep=None, seed=0, cfg: Optional[GuideConfig] = None, text_len=77, dtype="bf16"):
+                 max_timestep=None, seed=0, cfg: Optional[GuideConfig] = None, text_len=77, dtype="bf16", views=1, share_weights_with=None):
+        """`views` > 1: ONE call distils that many rendered views at once (inputs [V,3,H,W]; the plans are built for a VAE batch of V and a
+        denoiser batch of 2 V -- nothing in the reference to mirror, its call is batch 1: checklist Q11).  `share_weights_with`: another
+        guidance object of the same dtype whose kernel-layout weights this one's plans point at (no second copy in HBM)."""
         self.device = torch.device(device)
+        self.views = int(views)
         self.dtype_name = sd15.dtype_name(dtype)          # storage type of the denoiser / VAE plans: "bf16" (default) | "f32" (the reference's
                                                           # GS-stage precision, configs/__init__.py:236,241) | "f16" (its --optim.fp16 mode)
         self.cfg = cfg if cfg is not None else GuideConfig()
         self.unet_cfg = unet_cfg or sd15.UNetConfig()
         self.vae_cfg = vae_cfg or sd15.VAEConfig()
-        if unet_sd is None:        # random-init weights of the SD-1.5 architecture (no checkpoints offline)
-            unet_sd = sd15.random_state_dict(sd15.unet_param_shapes(self.unet_cfg), seed=seed)
-        if controlnet_sd is None:
-            controlnet_sd = sd15.random_state_dict(sd15.controlnet_param_shapes(self.unet_cfg), seed=seed + 1)
-        if vae_sd is None:
-            vae_sd = sd15.random_state_dict(sd15.vae_encoder_param_shapes(self.vae_cfg), seed=seed + 2)
+        shared = share_weights_with
+        if shared is not None and shared.dtype_name != self.dtype_name:
+            raise ValueError("share_weights_with: plans of dtype %s cannot point at %s weights" % (self.dtype_name, shared.dtype_name))
+        if shared is None:
+            if unet_sd is None:        # random-init weights of the SD-1.5 architecture (no checkpoints offline)
+                unet_sd = sd15.random_state_dict(sd15.unet_param_shapes(self.unet_cfg), seed=seed)
+            if controlnet_sd is None:
+                controlnet_sd = sd15.random_state_dict(sd15.controlnet_param_shapes(self.unet_cfg), seed=seed + 1)
+            if vae_sd is None:
+                vae_sd = sd15.random_state_dict(sd15.vae_encoder_param_shapes(self.vae_cfg), seed=seed + 2)
         self.image_hw = image_hw
         down = 2 ** (len(self.vae_cfg.block_out_channels) - 1)
         self.latent_hw = image_hw // down
-        self.denoiser = sd15.DenoiserPlan(self.unet_cfg, unet_sd, controlnet_sd, self.device, batch=2, latent_hw=self.latent_hw,
-                                          text_len=text_len, dtype=self.dtype_name)      # CLIP's 77 tokens; static (the plans are hipGraphs)
-        self.vae = sd15.VAEEncoderPlan(self.vae_cfg, vae_sd, self.device, image_hw=image_hw, dtype=self.dtype_name)
+        self.denoiser = sd15.DenoiserPlan(self.unet_cfg, unet_sd, controlnet_sd, self.device, batch=2 * self.views, latent_hw=self.latent_hw,
+                                          text_len=text_len, dtype=self.dtype_name, views=self.views,
+                                          weights=shared.denoiser.weights if shared is not None else None)      # CLIP's 77 tokens; static
+        self.vae = sd15.VAEEncoderPlan(self.vae_cfg, vae_sd, self.device, image_hw=image_hw, dtype=self.dtype_name, batch=self.views,
+                                       weights=shared.vae.weights if shared is not None else None)
         # BasicStableDiffusion.__init__ (basic.py:229-267)
         self.loss_type, self.weight_type = self.cfg.sds_loss_type, self.cfg.sds_weight_type
         if self.loss_type != 'sds' or self.weight_type not in ('sjc', 'dreamfusion', 'latent-nerf', 'ism'):
@@ -131,12 +141,13 @@ class ControlNetScoreDistillation:
     def max_step(self):
         return int(self.num_train_timesteps * C(self.max_step_cfg))
 
-    def get_timestep(self, batch_size=1, train_step=None, max_iteration=None):
+    def get_timestep(self, batch_size=1, train_step=None, max_iteration=None, generator=None):
         if self.time_sampling == 'uniform':
-            return torch.randint(self.min_step, self.max_step + 1, [batch_size], dtype=torch.long, device=self.device)   # RNG draw #2
+            return torch.randint(self.min_step, self.max_step + 1, [batch_size], dtype=torch.long, device=self.device,
+                                 generator=generator)                                                                   # RNG draw #2
         if self.time_sampling == 'constant':
             mid = (self.min_step + self.max_step) // 2
-            return torch.randint(mid, mid + 1, [batch_size], dtype=torch.long, device=self.device)
+            return torch.randint(mid, mid + 1, [batch_size], dtype=torch.long, device=self.device, generator=generator)
         if self.time_sampling == 'linear':
             delta = (self.max_step - self.min_step) / (max_iteration - 1)
             return torch.ones([batch_size], dtype=torch.long, device=self.device) * int(self.max_step - (train_step - 1) * delta)
@@ -161,15 +172,15 @@ class ControlNetScoreDistillation:
         raise NotImplementedError
 
     # -- vae.py:34-40 ----------------------------------------------------------------------------------------------------
-    def encode_images(self, images: torch.Tensor, posterior_noise: Optional[torch.Tensor] = None) -> torch.Tensor:
+    def encode_images(self, images: torch.Tensor, posterior_noise: Optional[torch.Tensor] = None, generator=None) -> torch.Tensor:
         moments = _VAEEncode.apply(images, self.vae)
         mean, logvar = moments.chunk(2, dim=1)
         std = torch.exp(0.5 * torch.clamp(logvar, -30.0, 20.0))
         if posterior_noise is None:
-            posterior_noise = torch.randn(mean.shape, device=mean.device, dtype=mean.dtype)      # RNG draw #1
+            posterior_noise = torch.randn(mean.shape, device=mean.device, dtype=mean.dtype, generator=generator)      # RNG draw #1
         return (mean + std * posterior_noise) * self.scaling_factor
 
-    def prepare_latents(self, inputs: torch.Tensor, posterior_noise=None):
+    def prepare_latents(self, inputs: torch.Tensor, posterior_noise=None, generator=None):
         """basic.py:354-383 (RGB inputs)."""
         if inputs.size(1) != 3:
             raise NotImplementedError("latent-space inputs")
@@ -177,14 +188,16 @@ class ControlNetScoreDistillation:
         if self.input_interpolate and tuple(inputs.shape[-2:]) != default_size:
             inputs = F.interpolate(inputs, default_size, mode='bilinear', align_corners=False)
         assert tuple(inputs.shape[-2:]) == default_size, inputs.shape
-        return self.encode_images(inputs, posterior_noise), inputs
+        return self.encode_images(inputs, posterior_noise, generator=generator), inputs
 
-    def preprocess(self, inputs, train_step, max_iteration, posterior_noise=None, **kwargs):
-        """basic.py:420-438."""
+    def preprocess(self, inputs, train_step, max_iteration, posterior_noise=None, generator=None, **kwargs):
+        """basic.py:420-438.  `generator`: the device generator every random draw of the call comes from (None: the default one, as in
+        the reference) -- a multi-view step gives each view its own stream."""
         batch_size = inputs.size(0)
-        latents, inputs = self.prepare_latents(inputs, posterior_noise)
+        latents, inputs = self.prepare_latents(inputs, posterior_noise, generator=generator)
         self.guidance_scale = kwargs.pop('guidance_scale') if 'guidance_scale' in kwargs else self.get_guidance_scale(train_step, max_iteration)
-        self.timestep = kwargs.pop('timestep') if 'timestep' in kwargs else self.get_timestep(batch_size, train_step, max_iteration)
+        self.timestep = (kwargs.pop('timestep') if 'timestep' in kwargs
+                         else self.get_timestep(batch_size, train_step, max_iteration, generator=generator))
         return latents, inputs, kwargs
 
     # -- controlnet.py:33-72 ---------------------------------------------------------------------------------------------
@@ -216,12 +229,25 @@ class ControlNetScoreDistillation:
         _, _, lh, lw = latents_model_input.shape
         cond = self.prepare_condition(cond_inputs, cond_height=lh * self.vae_scale_factor, cond_width=lw * self.vae_scale_factor,
                                       batch_size=latents_model_input.size(0), dtype=torch.float32)
-        # the repeated condition rows are identical (controlnet.py:50-54): the hint embedding is computed once and broadcast
-        self.denoiser.set_inputs(latents_model_input, self.timestep, text_embeddings, cond[:1])
+        # the repeated condition rows are identical (controlnet.py:50-54): the hint embedding is computed once per view and broadcast
+        self.denoiser.set_inputs(latents_model_input, self.timestep, text_embeddings, cond[:self.views])
         return self.denoiser.run()
 
     def prepare_text_embeddings(self, text_embeds_dict: dict, text_keys: tuple):
-        return torch.concat([text_embeds_dict[k] for k in text_keys], dim=0)
+        embeds = [text_embeds_dict[k] for k in text_keys]
+        if self.views > 1:          # one embedding per view; a single one is shared by all views
+            embeds = [e.expand(self.views, -1, -1) if e.size(0) == 1 else e for e in embeds]
+        return torch.concat(embeds, dim=0)
+
+    def draw_view_randoms(self, generator=None, train_step=None, max_iteration=None):
+        """The three device draws of ONE view's call in the reference's order (checklist Q12): VAE posterior noise [1,4,h,w], timestep [1],
+        latent noise [1,4,h,w].  A multi-view call is fed the per-view draws stacked (posterior_noise=, timestep=, noise=), so every view
+        sees exactly the numbers its own single-view call would draw from the same generator state."""
+        shape = (1, self.vae_cfg.latent_channels, self.latent_hw, self.latent_hw)
+        pn = torch.randn(shape, device=self.device, generator=generator)
+        t = self.get_timestep(1, train_step, max_iteration, generator=generator)
+        n = torch.randn(shape, device=self.device, generator=generator)
+        return pn, t, n
 
     def calc_gradients(self, latents_noisy, text_embeds_dict, noise, guidance_rescale: float = 0.0, train_step=None, max_iteration=None,
                        **kwargs):
@@ -262,8 +288,10 @@ class ControlNetScoreDistillation:
         return gradients, noise_pred, text_embeddings
 
     def __call__(self, inputs: torch.Tensor, text_embeds_dict: Dict[str, torch.Tensor], train_step: int = 0, max_iteration: int = 1,
-                 add_noise: bool = True, grad_viz: bool = False, noise=None, posterior_noise=None, **kwargs):
-        """inputs [1,3,H,W] rendered image in [0,1] (requires grad).  Returns the reference's result dict."""
+                 add_noise: bool = True, grad_viz: bool = False, noise=None, posterior_noise=None, generator=None, **kwargs):
+        """inputs [V,3,H,W] rendered image(s) in [0,1] (requires grad; V = self.views, 1 in the reference).  Returns the reference's result dict."""
+        if inputs.size(0) != self.views:
+            raise ValueError("this guidance object's plans are built for %d view(s) per call, got a batch of %d" % (self.views, inputs.size(0)))
         if inputs.size(1) == 3:                                            # pixel-wise gradient operations (basic.py:795-817)
             if self.cfg.pgc_clip_rgb >= 0:
                 inputs.register_hook(build_pgc_hook_func(self.cfg.pgc_clip_rgb, self.cfg.pgc_suppress_type, kwargs.get('scaler')))
@@ -272,10 +300,11 @@ class ControlNetScoreDistillation:
                 inputs.register_hook(build_grad_hook_func(self.cfg.grad_rgb_clip, self.cfg.grad_rgb_norm, self.cfg.grad_rgb_clip_scale,
                                                           scaler=kwargs.get('scaler'), mask=mask))
         kwargs.pop('scaler', None)
-        latents, inputs, kwargs = self.preprocess(inputs, train_step, max_iteration, posterior_noise=posterior_noise, **kwargs)
+        latents, inputs, kwargs = self.preprocess(inputs, train_step, max_iteration, posterior_noise=posterior_noise, generator=generator,
+                                                  **kwargs)
         with torch.no_grad():
             if noise is None:
-                noise = torch.randn_like(latents)                                                  # RNG draw #3
+                noise = torch.randn(latents.shape, device=latents.device, dtype=latents.dtype, generator=generator)   # RNG draw #3
             latents_noisy = self.add_noise(latents, noise, self.timestep) if add_noise else latents
         outputs = {'latents': latents, 'timestep': self.timestep}
         with torch.no_grad():

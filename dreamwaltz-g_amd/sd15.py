@@ -511,9 +511,13 @@ class Builder:
                 b = None
         conv = (C, H, W, Ho, Wo, KH, KW, stride, pt, pl, in_dilation)
         K = KH * KW * C
-        if r_batch_bcast:   # residual is [1,Ho,Wo,Cout] broadcast over the batch: run as a batched GEMM, one image per batch
+        if r_batch_bcast:   # residual is [Vr,Ho,Wo,Cout], image b of the batch adds residual b % Vr (the ControlNet hint of view b % Vr is
+            # shared by the CFG entries of that view): a batched GEMM, one image per batch entry, batch = (B / Vr) x Vr
+            Vr = int(residual.shape[0])
+            assert B % Vr == 0, (B, Vr)
             d = gemm.gemm_raw(x, wt, y, Ho * Wo, Cout, K, (0, 1), (K, 1), Cout, bias=b, residual=residual, ldr=Cout, act=act,
-                              batch=(B, 1), a_batch=(H * W * C, 0), c_batch=(Ho * Wo * Cout, 0), r_batch=(0, 0), conv=conv,
+                              batch=(B // Vr, Vr), a_batch=(Vr * H * W * C, H * W * C), c_batch=(Vr * Ho * Wo * Cout, Ho * Wo * Cout),
+                              r_batch=(0, Ho * Wo * Cout), conv=conv,
                               conv_upsample=upsample, name=self._conv_tag(tag, KH, Ho, stride, in_dilation, KW), run=False)
         else:
             kw = {}
@@ -779,21 +783,23 @@ class DenoiserPlan:
     """ControlNet-conditioned UNet forward for a CFG batch: eps = UNet(x, t, text, ControlNet(x, t, text, cond)).
 
     Inputs (static buffers, overwritten before run()):  latents [B,h,w,8] (4 used), t_emb [B,320] x2, text [B,77,768],
-    cond [1,8h,8w,8] (3 used; the condition image is identical for both CFG entries -- controlnet.py:60-72 repeats it --
-    so its embedding is computed once and broadcast).  Output: eps [B,h,w,4] fp32."""
+    cond [V,8h,8w,8] (3 used; V = `views`, B = 2 V ordered [negative of view 0..V-1 | text of view 0..V-1]: the condition image of a
+    view is identical for its CFG entries -- controlnet.py:60-72 repeats it -- so its embedding is computed once per view and
+    broadcast).  Output: eps [B,h,w,4] fp32.  `weights`: (UNet, ControlNet) `Weights` of another plan of the same dtype to share."""
 
-    def __init__(self, cfg: UNetConfig, unet_sd, cn_sd, device, batch=2, latent_hw=64, text_len=77, dtype="bf16"):
-        self.cfg, self.device, self.B, self.hw = cfg, device, batch, latent_hw
+    def __init__(self, cfg: UNetConfig, unet_sd, cn_sd, device, batch=2, latent_hw=64, text_len=77, dtype="bf16", views=1, weights=None):
+        self.cfg, self.device, self.B, self.hw, self.views = cfg, device, batch, latent_hw, int(views)
+        assert batch % self.views == 0, (batch, views)
         self.plan = Plan(device, dtype)
         p = self.plan
-        wu, wc = Weights(unet_sd, device, dtype), Weights(cn_sd, device, dtype)
+        wu, wc = weights if weights is not None else (Weights(unet_sd, device, dtype), Weights(cn_sd, device, dtype))
         self.weights = (wu, wc)     # kernel-layout weight tensors must outlive the plan that points at them
         bu, bc = Builder(p, wu, cfg.groups, "unet"), Builder(p, wc, cfg.groups, "cnet")
         B, hw = batch, latent_hw
         self.latents = p.buf(B, hw, hw, _pad8(cfg.in_channels), zero=True)
         self.text = p.buf(B, text_len, cfg.cross_dim)
         self.cond_scale = 2 ** (len(cfg.cond_channels) - 1)      # one stride-2 convolution per embedding level: 8 for SD-1.5
-        self.cond = p.buf(1, hw * self.cond_scale, hw * self.cond_scale, _pad8(cfg.cond_in_channels), zero=True)
+        self.cond = p.buf(self.views, hw * self.cond_scale, hw * self.cond_scale, _pad8(cfg.cond_in_channels), zero=True)
         # ---- UNet encoder (does not depend on the ControlNet)
         up_names = []
         rev_attn = list(reversed(cfg.attn_blocks))
@@ -836,10 +842,15 @@ class DenoiserPlan:
         self.eps = bu.conv(n, "conv_out", out_dtype=torch.float32)
 
     def set_inputs(self, latents_nchw, t, text, cond_nchw=None):
-        """latents [B,4,h,w] fp32, t [B] or scalar tensor, text [B,77,768], cond [1,3,8h,8w] in [0,1] (optional)."""
+        """latents [B,4,h,w] fp32, t scalar / [V] (one per view, repeated over the CFG entries) / [B], text [B,77,768],
+        cond [V,3,8h,8w] in [0,1] (optional)."""
         c = latents_nchw.shape[1]
         self.latents[..., :c].copy_(latents_nchw.permute(0, 2, 3, 1))
-        te = timestep_embedding(t.reshape(-1).expand(self.B), self.cfg.block_out_channels[0])
+        t = t.reshape(-1)
+        if t.numel() not in (1, self.B):
+            assert self.B % t.numel() == 0, (self.B, t.numel())
+            t = t.repeat(self.B // t.numel())                 # [t_0..t_{V-1} | t_0..t_{V-1}]: the batch order of the CFG halves
+        te = timestep_embedding(t.expand(self.B), self.cfg.block_out_channels[0])
         self.temb_u.tin.copy_(te); self.temb_c.tin.copy_(te)
         self.text.copy_(text)
         if cond_nchw is not None:
@@ -855,13 +866,13 @@ class VAEEncoderPlan:
     but sits INSIDE the autograd graph of SDS -- basic.py:368-372).  forward: image [1,3,H,W] in [0,1] -> moments
     [1,8,H/8,W/8] (2x-1 normalisation of VaeImageProcessor fused into the input conversion).  backward: d moments -> d image."""
 
-    def __init__(self, cfg: VAEConfig, sd, device, image_hw=512, dtype="bf16"):
-        self.cfg, self.device, self.hw = cfg, device, image_hw
+    def __init__(self, cfg: VAEConfig, sd, device, image_hw=512, dtype="bf16", batch=1, weights=None):
+        self.cfg, self.device, self.hw, self.B = cfg, device, image_hw, int(batch)
         self.fwd, self.bwd = Plan(device, dtype), Plan(device, dtype)
-        w = Weights(sd, device, dtype)
+        w = weights if weights is not None else Weights(sd, device, dtype)
         self.weights = w            # kernel-layout weight tensors must outlive the plans that point at them
         f, r = Builder(self.fwd, w, cfg.groups, "vaef"), Builder(self.bwd, w, cfg.groups, "vaeb")
-        self.x = self.fwd.buf(1, image_hw, image_hw, 8, zero=True)
+        self.x = self.fwd.buf(self.B, image_hw, image_hw, 8, zero=True)
         boc = cfg.block_out_channels
         tape = []      # closures that extend the backward plan, replayed in reverse order
 
@@ -931,34 +942,43 @@ class VAEEncoderPlan:
         q = f.linear(nt, w.lin(pre + ".to_q"), bias=w.f32(pre + ".to_q.bias"), tag="vae_qkv")
         k = f.linear(nt, w.lin(pre + ".to_k"), bias=w.f32(pre + ".to_k.bias"), tag="vae_qkv")
         v = f.linear(nt, w.lin(pre + ".to_v"), bias=w.f32(pre + ".to_v.bias"), tag="vae_qkv")
-        S = f.p.buf(N, N, dtype=torch.float32)
-        f.p.add_gemm(gemm.gemm_raw(q, k, S, N, N, C, (C, 1), (C, 1), N, name="vae_qk", run=False))
-        P = f.p.buf(N, N)
+        # per image (batch1 = B): scores, probabilities and the value product are batched GEMMs over the images of the plan
+        S = f.p.buf(B, N, N, dtype=torch.float32)
+        f.p.add_gemm(gemm.gemm_raw(q, k, S, N, N, C, (C, 1), (C, 1), N, batch=(B, 1), a_batch=(N * C, 0), b_batch=(N * C, 0),
+                                   c_batch=(N * N, 0), name="vae_qk", run=False))
+        P = f.p.buf(B, N, N)
         pp = lambda t: ctypes.c_void_p(t.data_ptr())  # noqa: E731
-        f.p.add_call(f.L.dwg_softmax_rows_forward_dt, f.p.dt, N, N, scale, pp(S), N, pp(P), N)
+        f.p.add_call(f.L.dwg_softmax_rows_forward_dt, f.p.dt, B * N, N, scale, pp(S), N, pp(P), N)
         o = f.p.buf(B, N, C)
-        f.p.add_gemm(gemm.gemm_raw(P, v, o, N, C, N, (N, 1), (1, C), C, name="vae_pv", run=False))
+        f.p.add_gemm(gemm.gemm_raw(P, v, o, N, C, N, (N, 1), (1, C), C, batch=(B, 1), a_batch=(N * N, 0), b_batch=(N * C, 0),
+                                   c_batch=(N * C, 0), name="vae_pv", run=False))
         out = f.linear(o, w.lin(pre + ".to_out.0"), bias=w.f32(pre + ".to_out.0.bias"), residual=x.view(B, N, C), tag="vae_out")
         out = out.view(B, H, W, C)
 
         def back(dout):
             dt = dout.view(B, N, C)
             wo, wq, wk, wv = (w.lin(pre + s) for s in (".to_out.0", ".to_q", ".to_k", ".to_v"))
+            M = B * N
+            bk = dict(batch=(B, 1))
             do = r.p.buf(B, N, C)      # d o = dout @ Wo
-            r.p.add_gemm(gemm.gemm_raw(dt, wo, do, N, C, C, (C, 1), (1, C), C, name="vae_bwd", run=False))
-            dP = r.p.buf(N, N, dtype=torch.float32)   # dP = do v^T
-            r.p.add_gemm(gemm.gemm_raw(do, v, dP, N, N, C, (C, 1), (C, 1), N, name="vae_bwd_dp", run=False))
+            r.p.add_gemm(gemm.gemm_raw(dt, wo, do, M, C, C, (C, 1), (1, C), C, name="vae_bwd", run=False))
+            dP = r.p.buf(B, N, N, dtype=torch.float32)   # dP = do v^T
+            r.p.add_gemm(gemm.gemm_raw(do, v, dP, N, N, C, (C, 1), (C, 1), N, a_batch=(N * C, 0), b_batch=(N * C, 0), c_batch=(N * N, 0),
+                                       name="vae_bwd_dp", run=False, **bk))
             dv = r.p.buf(B, N, C)      # dv = P^T do
-            r.p.add_gemm(gemm.gemm_raw(P, do, dv, N, C, N, (1, N), (1, C), C, name="vae_bwd_dv", run=False))
-            dS = r.p.buf(N, N)
-            r.p.add_call(r.L.dwg_softmax_rows_backward_dt, r.p.dt, N, N, scale, pp(P), N, pp(dP), N, pp(dS), N)
+            r.p.add_gemm(gemm.gemm_raw(P, do, dv, N, C, N, (1, N), (1, C), C, a_batch=(N * N, 0), b_batch=(N * C, 0), c_batch=(N * C, 0),
+                                       name="vae_bwd_dv", run=False, **bk))
+            dS = r.p.buf(B, N, N)
+            r.p.add_call(r.L.dwg_softmax_rows_backward_dt, r.p.dt, B * N, N, scale, pp(P), N, pp(dP), N, pp(dS), N)
             dq = r.p.buf(B, N, C)      # dq = dS k
-            r.p.add_gemm(gemm.gemm_raw(dS, k, dq, N, C, N, (N, 1), (1, C), C, name="vae_bwd_dq", run=False))
+            r.p.add_gemm(gemm.gemm_raw(dS, k, dq, N, C, N, (N, 1), (1, C), C, a_batch=(N * N, 0), b_batch=(N * C, 0), c_batch=(N * C, 0),
+                                       name="vae_bwd_dq", run=False, **bk))
             dk = r.p.buf(B, N, C)      # dk = dS^T q
-            r.p.add_gemm(gemm.gemm_raw(dS, q, dk, N, C, N, (1, N), (1, C), C, name="vae_bwd_dk", run=False))
+            r.p.add_gemm(gemm.gemm_raw(dS, q, dk, N, C, N, (1, N), (1, C), C, a_batch=(N * N, 0), b_batch=(N * C, 0), c_batch=(N * C, 0),
+                                       name="vae_bwd_dk", run=False, **bk))
             dn = r.p.buf(B, N, C, dtype=torch.float32)   # dn = dq Wq + dk Wk + dv Wv (fp32 accumulate across the three products)
             for i, (g_, wt) in enumerate(((dq, wq), (dk, wk), (dv, wv))):
-                r.p.add_gemm(gemm.gemm_raw(g_, wt, dn, N, C, C, (C, 1), (1, C), C, accumulate=i > 0, name="vae_bwd_dn", run=False))
+                r.p.add_gemm(gemm.gemm_raw(g_, wt, dn, M, C, C, (C, 1), (1, C), C, accumulate=i > 0, name="vae_bwd_dn", run=False))
             dnb = r.cast_bf16(dn).view(B, H, W, C)
             dx = r.groupnorm_bwd(x, dnb, st, pre + ".group_norm", 1e-6, False)
             return r.add(dx, dout)
@@ -966,13 +986,13 @@ class VAEEncoderPlan:
         return out
 
     def encode(self, image_nchw):
-        """image [1,3,H,W] fp32 in [0,1] -> moments [1,8,h,w] fp32 (NCHW view)."""
+        """image [B,3,H,W] fp32 in [0,1] -> moments [B,8,h,w] fp32 (NCHW view)."""
         self.x[..., :3].copy_((image_nchw * 2.0 - 1.0).permute(0, 2, 3, 1))
         self.fwd.run()
         return self.moments.permute(0, 3, 1, 2)
 
     def backward(self, dmoments_nchw):
-        """d loss / d moments [1,8,h,w] -> d loss / d image [1,3,H,W] fp32."""
+        """d loss / d moments [B,8,h,w] -> d loss / d image [B,3,H,W] fp32."""
         self.dmoments.copy_(dmoments_nchw.permute(0, 2, 3, 1))
         self.bwd.run()
         return self.dx[..., :3].permute(0, 3, 1, 2).float() * 2.0

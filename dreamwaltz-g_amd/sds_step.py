@@ -54,7 +54,8 @@ def build_synthetic_avatar(n_gaussians, device, seed=0, learn_hand_betas=False):
 
 class SDSStep:
     def __init__(self, n_gaussians=100000, res=512, device="cuda", rank=0, world=1, guidance=True, dist=None, seed=0, cfg=None,
-                 avatar=None, guidance_obj=None, async_pair_count=True, iters=10000, gpu_condition=True, views=None, dtype="bf16"):
+                 avatar=None, guidance_obj=None, async_pair_count=True, iters=10000, gpu_condition=True, views=None, dtype="bf16",
+                 batch_views=False):
         self.device, self.rank, self.world, self.dist, self.res = torch.device(device), rank, world, dist, res
         self.views = int(views) if views is not None else world           # views per step over ALL ranks
         if self.views < world:
@@ -79,7 +80,9 @@ class SDSStep:
         self.guidance = guidance_obj
         tg = torch.Generator().manual_seed(seed + 5)
         if guidance and self.guidance is None:
-            self.guidance = gd.ControlNetScoreDistillation(self.device, image_hw=512, seed=seed, cfg=self.cfg.guide, dtype=dtype)
+            # batch_views: ONE VAE / denoiser pass per step for all the views of this rank (plans built for that batch)
+            self.guidance = gd.ControlNetScoreDistillation(self.device, image_hw=512, seed=seed, cfg=self.cfg.guide, dtype=dtype,
+                                                           views=len(self.my_views) if batch_views else 1)
         if self.guidance is not None:
             cd = self.guidance.unet_cfg.cross_dim
             hw = self.guidance.image_hw
@@ -173,7 +176,8 @@ class SDSStep:
         for v in self.my_views:
             d = self.view_data[v]
             d["smpl_inputs"] = self._upload_pose(synth.random_smpl_inputs(seed=1000 * v + self.step_idx, device="cpu"))
-            d["rng_seed"] = (1234 + v) * 1000003 + self.step_idx          # the view's own device-RNG stream (Q12 draw order inside it)
+            if self.guidance is not None:
+                d["rng_seed"] = (1234 + v) * 1000003 + self.step_idx      # the view's own device-RNG stream (Q12 draw order inside it)
             if getattr(self, "condition", None) is not None:
                 d["cond_images"] = self.condition_image(d["smpl_inputs"], d)
             views.append(d)
@@ -201,6 +205,7 @@ class SDSStep:
         return {"dtype": gdt,
                 "config": {"workload": wl, "gaussians": self.G, "resolution": self.res, "views_per_step": self.views,
                            "views_per_step_per_gpu": len(self.my_views),
+                           "views_per_guidance_call": getattr(self.guidance, "views", 1) if self.guidance is not None else None,
                            "weights": "seeded random init of the SD-1.5 / ControlNet / VAE architecture",
                            "precision": prec + "; LBS, encoder, MLPs, rasterizer fp32",
                            "parallelism": "dp%d (view v on GPU v mod %d, flat-gradient all-reduce)" % (self.world, self.world)}}

@@ -29,6 +29,7 @@ class SDSTrainer:
         self.max_step = cfg.optim.iters if max_step is None else max_step
         self.scaler = None                          # GradScaler(enabled=False) in the fp32 recipes: pass-through
         self.redone_frames = 0
+        self._view_rng = None
         self.past_checkpoints = []
         self.set_views(world)                       # one view per rank unless the caller says otherwise: mean of the summed gradients,
                                                     # folded into the Adam kernel
@@ -84,18 +85,59 @@ class SDSTrainer:
             return data['radius'].mean().item() * data['tanfov'].mean().item()
         return self.cfg.render.spatial_scale
 
+    def _select_text(self, data):
+        """View-dependent prompt selection (trainer.py:944-955): -> (embedding [1,77,d] or None, prompt string)."""
+        if self.cfg.prompt.text_augmentation and 'viewed' in self.text_embeds_dict:
+            view_index = self.view_prompt(azim=data['azimuth'], elev=data['elevation']).item()
+            return self.text_embeds_dict['viewed'][view_index], self.view_prompt.texts[view_index]
+        return self.text_embeds_dict.get('pos'), self.cfg.guide.text
+
+    def train_forward_views(self, views, **forced):
+        """The forward of `train_forward` for SEVERAL views in one guidance call (SURVEY section 7 "hard parts": multi-view batching per
+        launch): every view is rendered by its own animate + rasterizer pass, the V images go through the VAE encoder as a batch of V and
+        through ControlNet + UNet as a CFG batch of 2 V (small-M layers of the 8x8 .. 32x32 latent levels finally fill their MFMA tiles).
+        Each view keeps its own prompt embedding, condition image, and -- from its `rng_seed` -- exactly the random draws its own
+        single-view call would make (guidance.draw_view_randoms)."""
+        images, texts, names, conds, draws, outs = [], [], [], [], [], []
+        for data in views:
+            ro = self.render(data=data)
+            outs.append(ro)
+            images.append(ro['image'].permute(0, 3, 1, 2))
+            emb, name = self._select_text(data)
+            texts.append(emb); names.append(name)
+            if self.use_controlnet:
+                conds.append(data['cond_images'])
+            seed = data.get('rng_seed')
+            if seed is not None and 'noise' not in forced:
+                if self._view_rng is None:
+                    self._view_rng = torch.Generator(device=images[-1].device)
+                self._view_rng.manual_seed(int(seed))
+                draws.append(self.diffusion.draw_view_randoms(self._view_rng, self.train_step_index, self.max_step))
+        sd_inputs = torch.cat(images, dim=0).contiguous()
+        embeds = dict(self.text_embeds_dict)
+        if texts[0] is not None:
+            embeds['text'] = torch.cat(texts, dim=0)
+        sd_kwargs = {'inputs': sd_inputs, 'text_embeds_dict': embeds, 'train_step': self.train_step_index, 'max_iteration': self.max_step,
+                     'grad_viz': False, 'scaler': self.scaler}
+        if self.use_controlnet:
+            sd_kwargs['cond_inputs'] = torch.cat(conds, dim=0)
+        if draws:
+            sd_kwargs.update(posterior_noise=torch.cat([d[0] for d in draws]), timestep=torch.cat([d[1] for d in draws]),
+                             noise=torch.cat([d[2] for d in draws]))
+        sd_kwargs.update(forced)
+        sd_outputs = self.diffusion(**sd_kwargs)
+        total_loss = sd_outputs['diffusion_loss'] * self.cfg.guide.lambda_guidance
+        for ro in outs:
+            ro['regularizations'] = {}
+        return total_loss, outs, sd_outputs, names
+
     def train_forward(self, data: Dict[str, Any], **forced):
         """`forced` (timestep=, noise=, posterior_noise=) pins the random draws for parity tests."""
         render_outputs = self.render(data=data)
         sd_inputs = render_outputs['image'].permute(0, 3, 1, 2).contiguous()
-        if self.cfg.prompt.text_augmentation and 'viewed' in self.text_embeds_dict:
-            view_index = self.view_prompt(azim=data['azimuth'], elev=data['elevation']).item()
-            self.text_embeds_dict['text'] = self.text_embeds_dict['viewed'][view_index]
-            text = self.view_prompt.texts[view_index]
-        else:
-            if 'pos' in self.text_embeds_dict:
-                self.text_embeds_dict['text'] = self.text_embeds_dict['pos']
-            text = self.cfg.guide.text
+        emb, text = self._select_text(data)
+        if emb is not None:
+            self.text_embeds_dict['text'] = emb
         sd_kwargs = {'inputs': sd_inputs, 'text_embeds_dict': self.text_embeds_dict, 'train_step': self.train_step_index,
                      'max_iteration': self.max_step, 'grad_viz': False, 'scaler': self.scaler}
         if self.use_controlnet:
@@ -128,13 +170,19 @@ class SDSTrainer:
         (rasterizer._RasterizeGaussians.backward) and is rendered again here (capacity has grown) BEFORE anything reaches the optimizers."""
         seed = data.get('rng_seed') if isinstance(data, dict) else None
         if seed is not None:
-            torch.manual_seed(int(seed))          # the view's own RNG stream (VAE posterior, timestep, noise): the same draws whichever rank renders it
+            # the view's own RNG stream (VAE posterior, timestep, noise): the same draws whichever rank renders it.  A private device
+            # generator -- re-seeding the process-wide one costs the host a few hundred microseconds per step.
+            if self._view_rng is None:
+                dev = getattr(self.model, "device", None)
+                self._view_rng = torch.Generator(device=dev if dev is not None else next(self.model.parameters()).device)
+            forced = dict(forced, generator=self._view_rng)
+            self._view_rng.manual_seed(int(seed))
         out = self._forward_backward(data, **forced)
         renderer = getattr(self.model, "renderer", None)
         while renderer is not None and renderer.consume_overflow():
             self.redone_frames += 1
             if seed is not None:
-                torch.manual_seed(int(seed))
+                self._view_rng.manual_seed(int(seed))
             out = self._forward_backward(data, **forced)
         return out
 
@@ -147,8 +195,20 @@ class SDSTrainer:
         self.train_step_index += 1
         self._begin_step(self.get_spatial_scale(views[0]))
         out = None
-        for view in views:
-            out = self._view(view, **forced)
+        if len(views) > 1 and getattr(self.diffusion, "views", 1) == len(views):
+            # the guidance plans are built for this many views per call: ONE VAE / denoiser pass for all of them
+            renderer = getattr(self.model, "renderer", None)
+            while True:
+                loss, outs, sd_outputs, names = self.train_forward_views(views, **forced)
+                loss.backward()
+                if renderer is None or not renderer.consume_overflow():
+                    break
+                self.redone_frames += 1         # a truncated frame contributed zeros, the others did not: start the step's gradient over
+                self._begin_step(self.get_spatial_scale(views[0]))
+            out = (loss, outs, sd_outputs, names)
+        else:
+            for view in views:
+                out = self._view(view, **forced)
         if self.world > 1:
             self.dist.all_reduce(self.optimizers.all_grads())       # one flat fp32 buffer
         for optimizer in self.optimizers.values():

@@ -3,7 +3,7 @@
 With `<repo>/dropin` on PYTHONPATH, `import _gridencoder as _backend` (grid.py:9-16) resolves here and the
 reference's own grid.py drives the HIP kernels unchanged ([L,B,C] backend layout).
 
-dtypes: the kernels compute in fp32.  Under autocast (every shipped script passes --optim.fp16 True, trainer.py:844,859) the
+dtypes: the kernels compute in fp32.  Under autocast (--optim.fp16 True: the NeRF stages of scripts/train_w_expr.sh:28,46 -- the 3DGS stages :56-94 run fp32; trainer.py:844,859) the
 reference's grid.py hands over HALF embeddings / outputs / dy_dx / gradients (grid.py:28-93 casts with `embeddings.to(inputs.dtype)`
 and allocates with that dtype; its CUDA backend dispatches AT_DISPATCH_FLOATING_TYPES_AND_HALF).  Here every non-fp32 buffer goes
 through an fp32 temporary and is copied back into the caller's tensor in ITS dtype; nothing is ever reinterpreted.  Non-CUDA,

@@ -78,3 +78,55 @@ def test_bench_spawns_its_own_ranks(tmp_path):
     assert out["n_gpus"] == 2 and out["views_per_step"] == 4 and out["views_per_step_per_gpu"] == 2 and out["scaling"] == "strong"
     assert abs(out["views_per_s"] - 4 * out["value"]) < 1e-6 * out["views_per_s"]
     assert "shared_gpu" in out and out["steps"] == 3
+
+
+def test_one_batched_guidance_call_equals_the_views_one_at_a_time():
+    """The multi-view step in its two forms on the SAME three views (own camera / pose / condition image / RNG stream each): (a) one
+    guidance call per view, gradients accumulated; (b) ONE call: VAE batch 3, ControlNet + UNet CFG batch 6.  fp32 plans at reduced width
+    so that the comparison sees the batching, not bf16 rounding under CFG 50.  Also: the batched denoiser / VAE plans against their
+    single-view twins on the same inputs."""
+    import dwg_import  # noqa: F401
+    from dreamwaltz_g_amd import guidance, sd15, sds_step
+    dev = torch.device("cuda:0")
+    torch.cuda.set_stream(torch.cuda.Stream(device=dev))
+    res, V = 128, 3
+    ucfg = sd15.UNetConfig(block_out_channels=(64, 128, 128, 128), cross_dim=64, cond_channels=(16, 32, 32, 64))
+    vcfg = sd15.VAEConfig(block_out_channels=(32, 64, 64, 64))
+    usd = sd15.random_state_dict(sd15.unet_param_shapes(ucfg), seed=1)
+    csd = sd15.random_state_dict(sd15.controlnet_param_shapes(ucfg), seed=2)
+    vsd = sd15.random_state_dict(sd15.vae_encoder_param_shapes(vcfg), seed=3)
+    g1 = guidance.ControlNetScoreDistillation(dev, ucfg, vcfg, usd, csd, vsd, image_hw=res, dtype="f32")
+    gV = guidance.ControlNetScoreDistillation(dev, ucfg, vcfg, image_hw=res, dtype="f32", views=V, share_weights_with=g1)
+    assert gV.denoiser.weights is g1.denoiser.weights and gV.vae.weights is g1.vae.weights
+    # ---- plan level: batched == per view
+    g = torch.Generator().manual_seed(0)
+    lat = torch.randn(V, 4, res // 8, res // 8, generator=g).to(dev)
+    text = torch.randn(2 * V, 77, 64, generator=g).to(dev)
+    cond = torch.rand(V, 3, res, res, generator=g).to(dev)
+    t = torch.tensor([100, 500, 900], device=dev)
+    gV.denoiser.set_inputs(torch.cat([lat, lat]), t, text, cond)
+    eps_b = gV.denoiser.run().clone()
+    for v in range(V):
+        g1.denoiser.set_inputs(torch.cat([lat[v:v + 1]] * 2), t[v:v + 1], torch.stack([text[v], text[V + v]]), cond[v:v + 1])
+        e = g1.denoiser.run()
+        assert _rel(eps_b[v], e[0]) < 2e-5 and _rel(eps_b[V + v], e[1]) < 2e-5, v
+    img = torch.rand(V, 3, res, res, generator=g).to(dev)
+    gm = torch.randn(V, 8, res // 8, res // 8, generator=g).to(dev)
+    mom_b = gV.vae.encode(img).clone(); gi_b = gV.vae.backward(gm).clone()
+    for v in range(V):
+        m = g1.vae.encode(img[v:v + 1]); gi = g1.vae.backward(gm[v:v + 1])
+        assert _rel(mom_b[v], m[0]) < 2e-5 and _rel(gi_b[v], gi[0]) < 2e-5, v
+    # ---- step level
+    flats = []
+    for gd in (g1, gV):
+        step = sds_step.SDSStep(n_gaussians=6000, res=res, device=dev, guidance=True, guidance_obj=gd, views=V, async_pair_count=False, iters=1000)
+        assert step.my_views == [0, 1, 2]
+        step.run()
+        torch.cuda.synchronize()
+        b = step.optimizers.buffers
+        flats.append((b.grad.clone(), b.flat.clone(), step.optimizers["avatar"].grad_scale))
+    (ga, fa, sa), (gb, fb, sb) = flats
+    assert sa == sb == 1.0 / V
+    assert float(ga.abs().sum()) > 0 and _rel(gb, ga) < 2e-3, _rel(gb, ga)
+    d = (fa - fb).abs()
+    assert float((d > 1e-5).float().mean()) < 5e-3
