@@ -636,6 +636,27 @@ class DreamWaltzG(nn.Module):
                               scales=torch.cat([scales] + [mp[2] for mp in mesh_parts], dim=0))
 
     # -- optimizers (avatar.py:1590-1635) --------------------------------------------------------------------------------
+    # per-Gaussian opacity PARAMETERS do not exist on this avatar (avatar.py:1233-1244; its opacities come out of the MLP): the reference's
+    # GaussianModel accessors then fail on None (gaussian_model.py:43-47), and so do these -- the densifier's prune / reset paths need
+    # --render.densify_disable_prune / densify_disable_reset True for a DreamWaltzG avatar, there as here
+    _opacities = None
+
+    def get_opacities(self, return_ones=False):
+        return torch.sigmoid(self._opacities.view(-1, 1)) if not return_ones else torch.ones_like(self._opacities.view(-1, 1))
+
+    @staticmethod
+    def opacity_inverse_activation(x):
+        return torch.log(x / (1 - x))
+
+    def get_densifier(self, cfg, optimizer):
+        """avatar.py:230-235.  `optimizer`: the dict `get_optimizer(cfg)` returned (the flat buffers are resized as a whole), or its
+        'avatar' entry as the reference passes it (`Trainer.init_gaussian_solvers`, trainer.py:600-603) -- then the dict is found through it."""
+        from .densifier import build_densifier
+        opts = optimizer if isinstance(optimizer, dict) else getattr(optimizer, "owner", None)
+        if opts is None:
+            raise ValueError("get_densifier needs the optimizer dict of get_optimizer(cfg) (or one of its entries)")
+        return build_densifier(model=self, optimizers=opts, cfg=cfg)
+
     def get_optimizer(self, cfg):
         """Same dict of named optimizers as the reference: 'avatar' (GaussianOptimizer: positions / scales / quaternions with
         the exponential position schedule), 'lbs' (betas / lbs weights when learned), 'nerf' (encoder 10x, both MLPs), 'mesh_<part>'.

@@ -48,7 +48,15 @@ class RenderConfig:
     use_fixed_n_gaussians: Optional[int] = None
     avatar_transl: Optional[str] = None
     avatar_scale: Optional[str] = None
-    use_densifier: bool = False
+    use_densifier: bool = False                      # configs/__init__.py:159-171 (off in every shipped recipe)
+    densify_from_iter: Optional[int] = None
+    densify_until_iter: Optional[int] = None
+    densify_grad_threshold: float = 100              # 0.0002 for MSE, 100 for SDS
+    densify_disable_clone: bool = False
+    densify_disable_split: bool = False
+    densify_disable_prune: bool = False
+    densify_disable_reset: bool = True
+    enable_grad_prune: bool = False
     always_animate: bool = True
     spatial_scale: Optional[float] = None
 

@@ -135,15 +135,17 @@ __global__ __launch_bounds__(256) void k_gn_reduce(int HW, int C, int G, int pix
 
 // stats[b][o] = sum over the chunk partials [b][o][chunk], in a FIXED order: one wave per output, lane-strided loads
 // (all chunks of an output are in flight at once) + a DPP tree -> deterministic and latency-flat.
-__global__ __launch_bounds__(1024) void k_gn_finalize(int chunks, int G, const float* __restrict__ partials, float* __restrict__ stats) {
-    const int b = blockIdx.x, wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
-    for (int o = wave; o < 2 * G; o += 16) {
-        const float* src = partials + ((size_t)b * 2 * G + o) * chunks;
-        float s = 0.f;
-        for (int c = lane; c < chunks; c += 64) s += src[c];
-        s = dwg_wave_sum_to_lane63(s);
-        if (lane == 63) stats[(size_t)b * G * 2 + o] = s;
-    }
+__global__ __launch_bounds__(256) void k_gn_finalize(int chunks, int G, const float* __restrict__ partials, float* __restrict__ stats) {
+    // grid (ceil(2G / 4), B): four outputs per workgroup -- with up to 2048 partials per output (the 512^2 VAE tensors) ONE workgroup per
+    // image was a 25-us serial tail; the sum order per output is unchanged (lane-strided, then the DPP tree): still bit-reproducible
+    const int b = blockIdx.y, wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int o = blockIdx.x * 4 + wave;
+    if (o >= 2 * G) return;
+    const float* src = partials + ((size_t)b * 2 * G + o) * chunks;
+    float s = 0.f;
+    for (int c = lane; c < chunks; c += 64) s += src[c];
+    s = dwg_wave_sum_to_lane63(s);
+    if (lane == 63) stats[(size_t)b * G * 2 + o] = s;
 }
 
 // forward apply: y = silu?((x - mean) * rstd * gamma + beta)
@@ -438,7 +440,7 @@ int dwg_groupnorm_forward_dt(int32_t dtype, int32_t B, int32_t HW, int32_t C, in
     DWG_DT_SWITCH(dtype,
         DWG_LAUNCH("gn_stats", (k_gn_reduce<T, false>), dim3(rchunks, B), dim3(256), lds, stream, HW, C, G, rppb, (const T*)x,
                    (const T*)nullptr, (const float*)nullptr, gamma, beta, 0, eps, workspace, gn_deep());
-        if (!fold) DWG_LAUNCH("gn_finalize", k_gn_finalize, dim3(B), dim3(1024), 0, stream, rchunks, G, (const float*)workspace, stats);
+        if (!fold) DWG_LAUNCH("gn_finalize", k_gn_finalize, dim3((2 * G + 3) / 4, B), dim3(256), 0, stream, rchunks, G, (const float*)workspace, stats);
         DWG_LAUNCH("gn_apply", (k_gn_apply<T, false>), dim3(chunks, B), dim3(256), 0, stream, HW, C, G, ppb, (const T*)x,
                    (const T*)nullptr, (const float*)stats, (const float*)nullptr, gamma, beta, fuse_silu, eps, (T*)y,
                    fold ? (const float*)workspace : (const float*)nullptr, rchunks, stats, (const T*)nullptr, gn_deep()))
@@ -466,7 +468,7 @@ int dwg_groupnorm_backward_dt(int32_t dtype, int32_t B, int32_t HW, int32_t C, i
     DWG_DT_SWITCH(dtype,
         DWG_LAUNCH("gn_bwd_stats", (k_gn_reduce<T, true>), dim3(rchunks, B), dim3(256), lds, stream, HW, C, G, rppb, (const T*)x,
                    (const T*)dy, stats, gamma, beta, fuse_silu, eps, workspace, gn_deep());
-        if (!fold) DWG_LAUNCH("gn_finalize", k_gn_finalize, dim3(B), dim3(1024), 0, stream, rchunks, G, (const float*)workspace, scratch);
+        if (!fold) DWG_LAUNCH("gn_finalize", k_gn_finalize, dim3((2 * G + 3) / 4, B), dim3(256), 0, stream, rchunks, G, (const float*)workspace, scratch);
         DWG_LAUNCH("gn_bwd_apply", (k_gn_apply<T, true>), dim3(chunks, B), dim3(256), 0, stream, HW, C, G, ppb, (const T*)x,
                    (const T*)dy, stats, (const float*)scratch, gamma, beta, fuse_silu, eps, (T*)dx,
                    fold ? (const float*)workspace : (const float*)nullptr, rchunks, scratch, (const T*)residual, gn_deep()))

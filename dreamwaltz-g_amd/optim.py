@@ -107,17 +107,29 @@ class FlatOptimizer:
         self.buf.grad[self.start:self.end].zero_()
 
     def step(self):
+        """One Adam step of every param group.  Bias correction uses the group's OWN step count (torch.optim.Adam keeps one per parameter):
+        a group that sat a step out -- its parameter was just replaced by the densifier, `grad is None` in the reference -- does not age."""
         self.t += 1
         self.current_iteration += 1
-        L = _lib.lib()
-        b = self.buf
-        st = ctypes.c_void_p(torch.cuda.current_stream(b.flat.device).cuda_stream)
         for pg in self.param_groups:
-            n, o = pg["end"] - pg["start"], pg["start"] * 4
-            _lib.check(L.dwg_adam_step(n, ctypes.c_void_p(b.flat.data_ptr() + o), ctypes.c_void_p(b.grad.data_ptr() + o),
-                                       ctypes.c_void_p(b.m.data_ptr() + o), ctypes.c_void_p(b.v.data_ptr() + o), float(pg["lr"]),
-                                       float(pg["betas"][0]), float(pg["betas"][1]), float(pg["eps"]), self.t, float(self.grad_scale), st),
-                       "dwg_adam_step")
+            if pg.pop("skip_once", False):
+                # the densifier just replaced this group's parameter: torch.optim.Adam finds `grad is None` on the new Parameter and leaves
+                # it (and its moments) alone for this step (gaussian_densifier.py:141-161 + trainer.py:876-890)
+                continue
+            if pg["end"] <= pg["start"]:
+                continue
+            pg["t"] = pg.get("t", 0) + 1
+            self._launch(pg)
+
+    def _launch(self, pg):
+        """The fused Adam launch of one group over its slice of the flat buffers (csrc/elementwise.hip k_adam)."""
+        b = self.buf
+        n, o = pg["end"] - pg["start"], pg["start"] * 4
+        st = ctypes.c_void_p(torch.cuda.current_stream(b.flat.device).cuda_stream)
+        _lib.check(_lib.lib().dwg_adam_step(n, ctypes.c_void_p(b.flat.data_ptr() + o), ctypes.c_void_p(b.grad.data_ptr() + o),
+                                            ctypes.c_void_p(b.m.data_ptr() + o), ctypes.c_void_p(b.v.data_ptr() + o), float(pg["lr"]),
+                                            float(pg["betas"][0]), float(pg["betas"][1]), float(pg["eps"]), int(pg["t"]), float(self.grad_scale), st),
+                   "dwg_adam_step")
 
     def state_dict(self):
         """Same information a torch Adam state_dict carries, flat: step count, per-group hyper-parameters and the two moments."""
@@ -129,6 +141,7 @@ class FlatOptimizer:
         self.t, self.current_iteration = int(sd["t"]), int(sd.get("current_iteration", sd["t"]))
         for pg, s in zip(self.param_groups, sd["param_groups"]):
             pg["lr"] = s["lr"]
+            pg["t"] = int(s.get("t", sd["t"]))
         self.buf.m[self.start:self.end].copy_(sd["exp_avg"]); self.buf.v[self.start:self.end].copy_(sd["exp_avg_sq"])
 
 
@@ -144,19 +157,66 @@ class FlatOptimizerDict(dict):
             o.grad_scale = s
 
 
-def build_flat_optimizers(specs: Dict[str, AdamSpec], device) -> FlatOptimizerDict:
-    params = [p for spec in specs.values() for g in spec.groups for p in g['params']]
-    buf = FlatBuffers(params, device)
-    out = FlatOptimizerDict()
-    out.buffers = buf
-    i = 0
+def _group_ranges(specs: Dict[str, AdamSpec], buf: FlatBuffers) -> Dict[str, list]:
+    """[start, end) of every param group inside the flat buffers (16-byte aligned ends), in the order the parameters were laid out."""
+    i, out = 0, {}
     for name, spec in specs.items():
         ranges = []
         for g in spec.groups:
+            if not g['params']:
+                ranges.append((buf.slices[i][0] if i < len(buf.slices) else buf.total,) * 2)       # an empty group owns nothing
+                continue
             start = buf.slices[i][0]
             for _ in g['params']:
                 off, n = buf.slices[i]
                 i += 1
             ranges.append((start, (off + n + 3) // 4 * 4))
-        out[name] = FlatOptimizer(name, buf, spec, ranges)
+        out[name] = ranges
     return out
+
+
+def build_flat_optimizers(specs: Dict[str, AdamSpec], device) -> FlatOptimizerDict:
+    params = [p for spec in specs.values() for g in spec.groups for p in g['params']]
+    buf = FlatBuffers(params, device)
+    out = FlatOptimizerDict()
+    out.buffers, out.specs, out.params = buf, specs, params
+    for name, ranges in _group_ranges(specs, buf).items():
+        out[name] = FlatOptimizer(name, buf, specs[name], ranges)
+        out[name].owner = out                    # the dict this named optimizer is a view of (densifier: the buffers resize as a whole)
+    return out
+
+
+def resize_flat_params(opts: FlatOptimizerDict, new_values: Dict[torch.nn.Parameter, tuple]) -> None:
+    """Densification / pruning (gaussian_densifier.py:120-180): some parameters change their first dimension.  `new_values` maps a Parameter
+    to (data, exp_avg, exp_avg_sq) of its new shape (moments None = zeros).  The flat parameter / gradient / moment buffers are laid out
+    afresh -- every Parameter keeps its identity and is re-homed (`.data` / `.grad` become views of the new buffers), the moments of the
+    untouched parameters are carried over, every named optimizer gets its new ranges.  The all-reduce operand of the multi-view step is the
+    new `opts.buffers.grad`."""
+    old = opts.buffers
+    keep = {}
+    for p, (off, n) in zip(opts.params, old.slices):
+        if p in new_values:
+            data, m, v = new_values[p]
+            data = data.detach().float()
+            keep[p] = (data, torch.zeros_like(data) if m is None else m.detach().float(), torch.zeros_like(data) if v is None else v.detach().float(), None)
+        else:
+            keep[p] = (p.data.clone(), old.m[off:off + n].clone(), old.v[off:off + n].clone(), old.grad[off:off + n].clone())
+    for p in opts.params:
+        p.data = keep[p][0]
+        p.grad = None
+    buf = FlatBuffers(opts.params, old.flat.device)
+    for p, (off, n) in zip(opts.params, buf.slices):
+        buf.m[off:off + n].copy_(keep[p][1].reshape(-1)); buf.v[off:off + n].copy_(keep[p][2].reshape(-1))
+        if keep[p][3] is not None:
+            buf.grad[off:off + n].copy_(keep[p][3])
+    opts.buffers = buf
+    resized = set(new_values.keys())
+    for name, ranges in _group_ranges(opts.specs, buf).items():
+        o = opts[name]
+        o.buf = buf
+        for pg, g, (start, end) in zip(o.param_groups, o.spec.groups, ranges):
+            pg["start"], pg["end"] = start, end
+            if any(p in resized for p in g['params']):
+                pg["skip_once"] = True
+        o.start = min(r[0] for r in ranges)
+        o.end = max(r[1] for r in ranges)

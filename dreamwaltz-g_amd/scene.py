@@ -102,6 +102,18 @@ class Scene(nn.Module):
             outputs['image_fg'] = outputs['image']
         return outputs
 
+    def densify(self, densifiers: dict, render_outputs: dict, spatial_scale: float, train_step: int):
+        """scene.py:170-186: the free Gaussians' share of the screen-space gradient / radii goes to the avatar's densifier."""
+        if hasattr(self.avatar, 'densification_mask'):
+            mask = self.avatar.densification_mask.to(render_outputs['radii'].device)
+            viewspace_points = render_outputs['viewspace_points'][mask]
+            viewspace_points.grad = render_outputs['viewspace_points'].grad[mask]
+            radii = render_outputs['radii'][mask]
+        else:
+            viewspace_points = render_outputs['viewspace_points']
+            radii = render_outputs['radii']
+        densifiers['avatar'](viewspace_points=viewspace_points, radii=radii, spatial_extent=spatial_scale, train_step=train_step)
+
     # -- checkpoints (scene.py:170-208) ---------------------------------------------------------------------------------------
     @staticmethod
     def organize_state_dict(state_dict):

@@ -97,8 +97,11 @@ class SDSStep:
             self.text = {}
             wimg = torch.randn(1, res, res, 3, generator=torch.Generator().manual_seed(seed + 6)).to(self.device)
             diffusion = _ImageLoss(wimg)
+        densifiers = None
+        if self.cfg.render.use_densifier:                                # trainer.py:600-603 (off in every shipped recipe)
+            densifiers = {'avatar': avatar.get_densifier(cfg=self.cfg, optimizer=self.optimizers)}
         self.trainer = tr.SDSTrainer(self.cfg, self.scene, diffusion, self.optimizers, self.text, use_controlnet=self.guidance is not None,
-                                     dist=dist, world=world, max_step=iters)
+                                     dist=dist, world=world, max_step=iters, densifiers=densifiers)
         self.trainer.set_views(self.views)
         self.step_idx = 0
 

@@ -19,8 +19,9 @@ from .text import TextAugmentation
 
 class SDSTrainer:
     def __init__(self, cfg, model, diffusion, optimizers, text_embeds_dict: Optional[dict] = None, use_controlnet: bool = True,
-                 dist=None, world: int = 1, max_step: Optional[int] = None):
+                 dist=None, world: int = 1, max_step: Optional[int] = None, densifiers: Optional[dict] = None):
         self.cfg, self.model, self.diffusion, self.optimizers = cfg, model, diffusion, optimizers
+        self.densifiers = densifiers                # {'avatar': GaussianDensifier} when cfg.render.use_densifier (trainer.py:600-603), else None
         self.text_embeds_dict = text_embeds_dict if text_embeds_dict is not None else {}
         self.view_prompt = TextAugmentation(cfg.guide.text, cfg.prompt) if cfg.prompt.text_augmentation else None
         self.use_controlnet = use_controlnet
@@ -209,6 +210,13 @@ class SDSTrainer:
         else:
             for view in views:
                 out = self._view(view, **forced)
+        if self.densifiers is not None:
+            # trainer.py:879-886: between backward and the optimizer steps; single-view steps only (the reference's only kind) -- the
+            # accumulated statistics are per rendered frame, and replicas of a multi-GPU job would have to densify identically
+            if len(views) != 1 or self.world != 1:
+                raise NotImplementedError("densification inside a multi-view / multi-GPU step")
+            self.model.densify(densifiers=self.densifiers, render_outputs=out[1], spatial_scale=self.get_spatial_scale(views[0]),
+                               train_step=self.train_step_index)
         if self.world > 1:
             self.dist.all_reduce(self.optimizers.all_grads())       # one flat fp32 buffer
         for optimizer in self.optimizers.values():

@@ -65,19 +65,17 @@ def test_flat_gradient_allreduce_gloo_world2():
 # into Adam, replica identity after the step, and equality with one process that accumulates the same views.  The HIP kernels cannot run
 # here, so the scene is a small differentiable stand-in and the fused Adam launch is replaced by the same arithmetic in torch.
 # ---------------------------------------------------------------------------------------------------------------------------------------
-def _cpu_adam_step(self):
-    self.t += 1
-    self.current_iteration += 1
+def _cpu_adam_launch(self, pg):
+    """csrc/elementwise.hip k_adam restated in torch (FlatOptimizer._launch): one group's slice of the flat buffers."""
     b = self.buf
-    for pg in self.param_groups:
-        s = slice(pg["start"], pg["end"])
-        g = b.grad[s] * self.grad_scale
-        b1, b2 = pg["betas"]
-        b.m[s].mul_(b1).add_(g, alpha=1 - b1)
-        b.v[s].mul_(b2).addcmul_(g, g, value=1 - b2)
-        mh = b.m[s] / (1 - b1 ** self.t)
-        vh = b.v[s] / (1 - b2 ** self.t)
-        b.flat[s].sub_(pg["lr"] * mh / (vh.sqrt() + pg["eps"]))
+    s = slice(pg["start"], pg["end"])
+    g = b.grad[s] * self.grad_scale
+    b1, b2 = pg["betas"]
+    b.m[s].mul_(b1).add_(g, alpha=1 - b1)
+    b.v[s].mul_(b2).addcmul_(g, g, value=1 - b2)
+    mh = b.m[s] / (1 - b1 ** pg["t"])
+    vh = b.v[s] / (1 - b2 ** pg["t"])
+    b.flat[s].sub_(pg["lr"] * mh / (vh.sqrt() + pg["eps"]))
 
 
 class _ToyScene(torch.nn.Module):
@@ -109,7 +107,7 @@ def _toy_views(which, step):
 
 def _toy_trainer(rank, world, views, dist_mod):
     from dreamwaltz_g_amd import configs, optim, sds_step, trainer
-    optim.FlatOptimizer.step = _cpu_adam_step            # the fused HIP Adam, restated (this process only)
+    optim.FlatOptimizer._launch = _cpu_adam_launch       # the fused HIP Adam launch, restated (this process only)
     cfg = configs.TrainConfig(); cfg.device = "cpu"; cfg.prompt.text_augmentation = False
     scene = _ToyScene()
     opts = optim.build_flat_optimizers({"avatar": optim.AdamSpec([dict(params=[scene.a], lr=1e-2)], eps=1e-15),
@@ -151,13 +149,13 @@ def test_train_step_multiview_two_ranks_equal_one_process_accumulating_the_same_
     assert torch.equal(res[0][1], res[1][1]) and torch.equal(res[0][2], res[1][2])      # replicas bit-identical after three steps
     import dwg_import  # noqa: F401
     from dreamwaltz_g_amd import optim
-    saved = optim.FlatOptimizer.step
+    saved = optim.FlatOptimizer._launch
     try:
         tr, opts = _toy_trainer(0, 1, 4, None)
         for step in range(3):
             tr.train_step(_toy_views(range(4), step))                                   # one process, all four views accumulated
     finally:
-        optim.FlatOptimizer.step = saved
+        optim.FlatOptimizer._launch = saved
     assert tr.total_views == 4 and opts["avatar"].grad_scale == 0.25
     assert torch.allclose(opts.buffers.grad, res[0][2], rtol=1e-5, atol=1e-7)           # summed (not yet averaged) gradients of the last step
     assert torch.allclose(opts.buffers.flat, res[0][1], rtol=1e-4, atol=1e-6)
@@ -168,5 +166,5 @@ def test_train_step_multiview_two_ranks_equal_one_process_accumulating_the_same_
         before = opts1.buffers.flat.clone()
         tr1.train_step(_toy_views([0], 0)[0])
     finally:
-        optim.FlatOptimizer.step = saved
+        optim.FlatOptimizer._launch = saved
     assert opts1["avatar"].grad_scale == 1.0 and not torch.equal(before, opts1.buffers.flat)

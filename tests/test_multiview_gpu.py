@@ -97,7 +97,7 @@ def test_one_batched_guidance_call_equals_the_views_one_at_a_time():
     vsd = sd15.random_state_dict(sd15.vae_encoder_param_shapes(vcfg), seed=3)
     g1 = guidance.ControlNetScoreDistillation(dev, ucfg, vcfg, usd, csd, vsd, image_hw=res, dtype="f32")
     gV = guidance.ControlNetScoreDistillation(dev, ucfg, vcfg, image_hw=res, dtype="f32", views=V, share_weights_with=g1)
-    assert gV.denoiser.weights is g1.denoiser.weights and gV.vae.weights is g1.vae.weights
+    assert all(a is b for a, b in zip(gV.denoiser.weights, g1.denoiser.weights)) and gV.vae.weights is g1.vae.weights
     # ---- plan level: batched == per view
     g = torch.Generator().manual_seed(0)
     lat = torch.randn(V, 4, res // 8, res // 8, generator=g).to(dev)
