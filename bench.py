@@ -345,6 +345,8 @@ class Ctx:
             usd, csd, vsd = self.state_dicts
             g = gd.ControlNetScoreDistillation(self.dev, image_hw=512, seed=0, unet_sd=usd, controlnet_sd=csd, vae_sd=vsd, dtype=dtype)
             self.guidance[dtype] = g
+            import gc
+            gc.collect(); gc.freeze()           # the plans are ~1e5 long-lived Python objects: out of the cyclic collector's way
         return self.guidance[key]
 
 
@@ -547,9 +549,23 @@ def main():
             out["cpu_baseline"] = cpu_baseline(out["config"]["gaussians"], out["config"]["resolution"], backward=False, canonical=True, budget_s=4.0,
                                                unit="frames/s")
     else:
-        out = run_sds(ctx, args.config, dtype=args.dtype, views=args.views, steps=args.steps, warmup=args.warmup)
         full = (args.config == "c3" and ctx.world == 1 and not args.headline_only and not args.no_guidance and args.dtype == "bf16"
                 and args.gaussians is None and args.res is None and not args.eager)
+        pre_cfgs = {}
+        if full:
+            # the three host-fed configurations (2-ms steps: their rate is the host's enqueue rate) run FIRST, in the state a process of
+            # their own would have -- after the denoiser / VAE plans exist, the interpreter's heap holds ~1e5 more objects and the same
+            # loops measured 25 % slower (c2: 364 vs 516 steps/s)
+            c2 = run_sds(ctx, "c2", steps=200, warmup=20)
+            pre_cfgs["c2"] = _brief(c2)
+            c5 = run_c5(ctx, 200, 20)
+            c1 = run_c1(ctx, 200, 20)
+            if cpu_ok:
+                c1["cpu_baseline"] = cpu_baseline(10000, 256, backward=False, canonical=True, budget_s=3.0, unit="frames/s")
+                c5["cpu_baseline"] = cpu_baseline(300000, 1024, backward=False, budget_s=5.0, unit="frames/s")
+            pre_cfgs["c5"], pre_cfgs["c1"] = _brief(c5), _brief(c1)
+            torch.cuda.empty_cache()
+        out = run_sds(ctx, args.config, dtype=args.dtype, views=args.views, steps=args.steps, warmup=args.warmup)
         if full:
             # everything the other BASELINE.json configurations and the precision trade need, inside the one line the driver records
             f32 = run_sds(ctx, "c3", dtype="f32", steps=5, warmup=2)
@@ -561,20 +577,12 @@ def main():
                                        "tests/test_sd15_fp32_gpu.py"}
             ctx.guidance.pop("f32", None)                         # free the fp32 plans (weights 5 GB, activations) before the other legs
             torch.cuda.empty_cache()
-            cfgs = {}
+            cfgs = dict(pre_cfgs)
             c4 = run_sds(ctx, "c4", steps=3, warmup=1, profile=False)                       # 8 views through ONE VAE / denoiser pass per step
             cfgs["c4_n1"] = _brief(c4)
             ctx.guidance.pop(("bf16", 8), None); torch.cuda.empty_cache()
             c4s = run_sds(ctx, "c4", steps=3, warmup=1, profile=False, batch_views=False)   # the same 8 views one guidance call at a time
             cfgs["c4_n1_sequential_views"] = _brief(c4s, ("value", "unit", "ms_per_step", "steps", "warmup", "views_per_s"))
-            c2 = run_sds(ctx, "c2", steps=200, warmup=20)
-            cfgs["c2"] = _brief(c2)
-            c5 = run_c5(ctx, 200, 20)
-            c1 = run_c1(ctx, 200, 20)
-            if cpu_ok:
-                c1["cpu_baseline"] = cpu_baseline(10000, 256, backward=False, canonical=True, budget_s=3.0, unit="frames/s")
-                c5["cpu_baseline"] = cpu_baseline(300000, 1024, backward=False, budget_s=5.0, unit="frames/s")
-            cfgs["c5"], cfgs["c1"] = _brief(c5), _brief(c1)
             out["configs"] = cfgs
         if cpu_ok and ctx.rank == 0 and args.config in ("c2", "c3"):
             out["cpu_baseline"] = cpu_baseline(out["config"]["gaussians"], out["config"]["resolution"])

@@ -56,6 +56,8 @@ SIGNATURES = {
     "dwg_grid_backward_slabs_workspace_bytes": (_sz, [_u32, _u32, _u32]),
     "dwg_grid_encode_backward_slabs": (ctypes.c_int, [_vp, _vp, _vp, _vp, _vp, _u32, _u32, _u32, _u32, _f32, _u32, _vp, _vp, _u32, _u32,
                                                       _u32, _u32, _vp, _vp, _sz, _vp]),
+    "dwg_grid_encode_backward_slabs_accumulate": (ctypes.c_int, [_vp, _vp, _vp, _vp, _vp, _u32, _u32, _u32, _u32, _f32, _u32, _vp, _vp, _u32,
+                                                                 _u32, _u32, _u32, _vp, _vp, _sz, _vp]),
     # include/dwg_gemm.h
     "dwg_gemm": (ctypes.c_int, [_vp, _vp]),
     "dwg_gemm_workspace_bytes": (_sz, [_vp]),

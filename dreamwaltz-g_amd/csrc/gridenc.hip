@@ -424,7 +424,7 @@ __global__ __launch_bounds__(1024) void k_gs_scan(uint32_t nslab, uint32_t* __re
 // pass 4: one workgroup per unit
 __global__ __launch_bounds__(256) void k_gs_accumulate(uint32_t first_entry, uint32_t total_entries, const GsUnit* __restrict__ units,
                                                        const uint32_t* __restrict__ n_units, const uint4* __restrict__ records,
-                                                       float* __restrict__ grad_table) {
+                                                       float* __restrict__ grad_table, int accumulate) {
     extern __shared__ float tab[];          // [GS_SLAB * 2]
     if (blockIdx.x >= *n_units) return;
     const GsUnit u = units[blockIdx.x];
@@ -440,9 +440,17 @@ __global__ __launch_bounds__(256) void k_gs_accumulate(uint32_t first_entry, uin
     const uint32_t ne = min(GS_SLAB, total_entries - e0);
     float* dst = grad_table + (size_t)e0 * 2;
     if (!u.multi && ((uintptr_t)dst & 15) == 0) {
-        for (uint32_t q = threadIdx.x; q < ne / 2u; q += 256)               // two entries (16 bytes) per store
-            reinterpret_cast<float4*>(dst)[q] = make_float4(tab[4 * q], tab[4 * q + 1], tab[4 * q + 2], tab[4 * q + 3]);
-        if ((ne & 1u) && threadIdx.x == 0) { dst[2 * (ne - 1)] = tab[2 * (ne - 1)]; dst[2 * (ne - 1) + 1] = tab[2 * (ne - 1) + 1]; }
+        // this workgroup is the slab's only writer: plain 16-byte stores -- or, accumulating into a gradient buffer that already holds
+        // other contributions (the flat gradient buffer of a multi-view step), a plain read-add-write of the same pieces
+        for (uint32_t q = threadIdx.x; q < ne / 2u; q += 256) {             // two entries (16 bytes) per store
+            float4 v = make_float4(tab[4 * q], tab[4 * q + 1], tab[4 * q + 2], tab[4 * q + 3]);
+            if (accumulate) { const float4 o = reinterpret_cast<const float4*>(dst)[q]; v.x += o.x; v.y += o.y; v.z += o.z; v.w += o.w; }
+            reinterpret_cast<float4*>(dst)[q] = v;
+        }
+        if ((ne & 1u) && threadIdx.x == 0) {
+            const float o0 = accumulate ? dst[2 * (ne - 1)] : 0.f, o1 = accumulate ? dst[2 * (ne - 1) + 1] : 0.f;
+            dst[2 * (ne - 1)] = tab[2 * (ne - 1)] + o0; dst[2 * (ne - 1) + 1] = tab[2 * (ne - 1) + 1] + o1;
+        }
     } else {
         for (uint32_t e = threadIdx.x; e < ne * 2u; e += 256) { const float v = tab[e]; if (v != 0.f) atomicAdd(dst + e, v); }
     }
@@ -593,11 +601,11 @@ size_t dwg_grid_backward_slabs_workspace_bytes(uint32_t B, uint32_t L, uint32_t 
            dwg_align_up(max_units * sizeof(GsUnit), 256) + 256;
 }
 
-int dwg_grid_encode_backward_slabs(const float* grad, const float* inputs, const float* embeddings, const int32_t* offsets,
-                                   float* grad_embeddings, uint32_t B, uint32_t D, uint32_t C, uint32_t L, float S, uint32_t H,
-                                   const float* dy_dx, float* grad_inputs, uint32_t gridtype, uint32_t align_corners,
-                                   uint32_t interp, uint32_t grad_layout, const int32_t* host_offsets, void* workspace,
-                                   size_t workspace_bytes, dwg_stream_t stream) {
+static int grid_backward_slabs(const float* grad, const float* inputs, const float* embeddings, const int32_t* offsets,
+                               float* grad_embeddings, uint32_t B, uint32_t D, uint32_t C, uint32_t L, float S, uint32_t H,
+                               const float* dy_dx, float* grad_inputs, uint32_t gridtype, uint32_t align_corners,
+                               uint32_t interp, uint32_t grad_layout, const int32_t* host_offsets, void* workspace,
+                               size_t workspace_bytes, dwg_stream_t stream, int accumulate) {
     int rc = check(B, D, C, L);
     if (rc) return rc;
     if (B == 0) return DWG_OK;
@@ -659,9 +667,27 @@ int dwg_grid_encode_backward_slabs(const float* grad, const float* inputs, const
     DWG_LAUNCH("grid_bwd_scatter", (k_gs_bin<true>), dim3(GS_NWG), dim3(256), (size_t)nslab * 4, st, p, nchunks, nslab, first_entry, grad, inputs,
                offsets, first_table_level, counts, (const uint32_t*)slab_start, records, dy_dx, grad_inputs);
     DWG_LAUNCH("grid_bwd", k_gs_accumulate, dim3((unsigned)max_units), dim3(256), (size_t)GS_SLAB * 8, st, first_entry, total_entries,
-               (const GsUnit*)units, (const uint32_t*)n_units, (const uint4*)records, grad_embeddings);
+               (const GsUnit*)units, (const uint32_t*)n_units, (const uint4*)records, grad_embeddings, accumulate);
     DWG_RETURN_IF_LAUNCH_FAILED();
     return DWG_OK;
+}
+
+int dwg_grid_encode_backward_slabs(const float* grad, const float* inputs, const float* embeddings, const int32_t* offsets,
+                                   float* grad_embeddings, uint32_t B, uint32_t D, uint32_t C, uint32_t L, float S, uint32_t H,
+                                   const float* dy_dx, float* grad_inputs, uint32_t gridtype, uint32_t align_corners,
+                                   uint32_t interp, uint32_t grad_layout, const int32_t* host_offsets, void* workspace,
+                                   size_t workspace_bytes, dwg_stream_t stream) {
+    return grid_backward_slabs(grad, inputs, embeddings, offsets, grad_embeddings, B, D, C, L, S, H, dy_dx, grad_inputs, gridtype, align_corners,
+                               interp, grad_layout, host_offsets, workspace, workspace_bytes, stream, 0);
+}
+
+int dwg_grid_encode_backward_slabs_accumulate(const float* grad, const float* inputs, const float* embeddings, const int32_t* offsets,
+                                              float* grad_embeddings, uint32_t B, uint32_t D, uint32_t C, uint32_t L, float S, uint32_t H,
+                                              const float* dy_dx, float* grad_inputs, uint32_t gridtype, uint32_t align_corners,
+                                              uint32_t interp, uint32_t grad_layout, const int32_t* host_offsets, void* workspace,
+                                              size_t workspace_bytes, dwg_stream_t stream) {
+    return grid_backward_slabs(grad, inputs, embeddings, offsets, grad_embeddings, B, D, C, L, S, H, dy_dx, grad_inputs, gridtype, align_corners,
+                               interp, grad_layout, host_offsets, workspace, workspace_bytes, stream, 1);
 }
 
 int dwg_grid_encode_backward(const float* grad, const float* inputs, const float* embeddings, const int32_t* offsets,

@@ -81,6 +81,13 @@ class GaussianDensifier:
     def _param(self, name) -> nn.Parameter:
         return getattr(self.model, "_" + name)
 
+    def _rebind(self, renamed):
+        """update_model (:182-187): the model's attributes point at the new Parameter objects."""
+        for name in self.params_to_densify:
+            old = self._param(name)
+            if old in renamed:
+                setattr(self.model, "_" + name, renamed[old])
+
     def _moments(self, p):
         buf = self.optimizers.buffers
         i = [id(q) for q in self.optimizers.params].index(id(p))
@@ -93,7 +100,7 @@ class GaussianDensifier:
             p = self._param(name)
             m, v = self._moments(p)
             new[p] = (p.data[mask], m[mask], v[mask])
-        optim.resize_flat_params(self.optimizers, new)
+        self._rebind(optim.resize_flat_params(self.optimizers, new))
 
     def cat_tensors_to_optimizer(self, tensors_dict):
         new = {}
@@ -102,11 +109,11 @@ class GaussianDensifier:
             ext = tensors_dict[name]
             m, v = self._moments(p)
             new[p] = (torch.cat((p.data, ext), dim=0), torch.cat((m, torch.zeros_like(ext)), dim=0), torch.cat((v, torch.zeros_like(ext)), dim=0))
-        optim.resize_flat_params(self.optimizers, new)
+        self._rebind(optim.resize_flat_params(self.optimizers, new))
 
     def replace_tensor_to_optimizer(self, tensor, name):
         p = self._param(name)
-        optim.resize_flat_params(self.optimizers, {p: (tensor, None, None)})
+        self._rebind(optim.resize_flat_params(self.optimizers, {p: (tensor, None, None)}))
 
     def update_model(self):
         self.model._n_points = len(self.model._positions)

@@ -148,12 +148,13 @@ def slab_workspace_for(device, B, L, total_entries):
 
 def grid_encode_backward(grad, inputs, embeddings, offsets, grad_embeddings, B, D, C, L, S, H, dy_dx, grad_inputs,
                          gridtype, align_corners, interp, grad_layout=0, xcd_scratch=None, host_offsets=None, xcd_counters=None,
-                         slab_workspace=None):
+                         slab_workspace=None, accumulate=False):
     _need_cuda(inputs)
     p = _lib.ptr
     ho = host_offsets if host_offsets is not None else _host_offsets_of(offsets)
     if slab_workspace is not None:
-        _lib.check(_lib.lib().dwg_grid_encode_backward_slabs(p(grad), p(inputs), p(embeddings), p(offsets), p(grad_embeddings), B, D,
+        fn = _lib.lib().dwg_grid_encode_backward_slabs_accumulate if accumulate else _lib.lib().dwg_grid_encode_backward_slabs
+        _lib.check(fn(p(grad), p(inputs), p(embeddings), p(offsets), p(grad_embeddings), B, D,
                                                              C, L, ctypes.c_float(S), H, p(dy_dx), p(grad_inputs), gridtype,
                                                              int(bool(align_corners)), interp, grad_layout,
                                                              ctypes.cast(ho, ctypes.c_void_p), p(slab_workspace), slab_workspace.numel(),
@@ -208,7 +209,6 @@ class _grid_encode(Function):
         inputs, embeddings, offsets, dy_dx = ctx.saved_tensors
         B, D, C, L, S, H, gridtype, interpolation = ctx.dims
         grad = grad.contiguous().float()
-        grad_embeddings = torch.zeros_like(embeddings)
         grad_inputs = torch.empty_like(inputs) if dy_dx is not None else None
         # big batches: XCD-private accumulation of the table gradient (8 copies + one reduce pass beat memory-side atomics)
         import os
@@ -220,15 +220,22 @@ class _grid_encode(Function):
         scratch = xcd_scratch_for(embeddings) if mode == "copies" else None
         counters = xcd_counters_for(inputs.device) if (mode == "owner" and grad_embeddings.data_ptr() % 128 == 0) else None
         slab_ws = slab_workspace_for(inputs.device, B, L, int(embeddings.shape[0])) if mode == "slabs" else None
+        # The table is a leaf Parameter whose .grad is its slice of the flat gradient buffer (optim.FlatBuffers): the slab pass ADDS straight
+        # into it and autograd is handed None -- instead of a zeroed 50 MB temporary that autograd then adds to .grad (a 50 MB fill and a
+        # 150 MB add per backward).  DWG_GRID_GRAD_INPLACE=0 restores the temporary.
+        in_place = (mode == "slabs" and embeddings.is_leaf and embeddings.grad is not None and embeddings.grad.is_contiguous()
+                    and embeddings.grad.dtype == torch.float32 and embeddings.grad.shape == embeddings.shape
+                    and os.environ.get("DWG_GRID_GRAD_INPLACE", "1") != "0")
+        grad_embeddings = embeddings.grad if in_place else torch.zeros_like(embeddings)
         try:
             grid_encode_backward(grad, inputs, embeddings, offsets, grad_embeddings, B, D, C, L, S, H, dy_dx, grad_inputs,
                                  gridtype, ctx.align_corners, interpolation, grad_layout=1, xcd_scratch=scratch,
-                                 host_offsets=ctx.host_offsets, xcd_counters=counters, slab_workspace=slab_ws)
+                                 host_offsets=ctx.host_offsets, xcd_counters=counters, slab_workspace=slab_ws, accumulate=in_place)
         except Exception:
             if scratch is not None:
                 scratch.zero_()        # a failed launch must not leave partial sums for the next call
             raise
-        return grad_inputs, grad_embeddings, None, None, None, None, None, None, None, None
+        return grad_inputs, (None if in_place else grad_embeddings), None, None, None, None, None, None, None, None
 
 
 def grid_encode(inputs, embeddings, offsets, per_level_scale, base_resolution, calc_grad_inputs=False, gridtype=0,

@@ -186,21 +186,33 @@ def build_flat_optimizers(specs: Dict[str, AdamSpec], device) -> FlatOptimizerDi
     return out
 
 
-def resize_flat_params(opts: FlatOptimizerDict, new_values: Dict[torch.nn.Parameter, tuple]) -> None:
+def resize_flat_params(opts: FlatOptimizerDict, new_values: Dict[torch.nn.Parameter, tuple]) -> Dict[torch.nn.Parameter, torch.nn.Parameter]:
     """Densification / pruning (gaussian_densifier.py:120-180): some parameters change their first dimension.  `new_values` maps a Parameter
     to (data, exp_avg, exp_avg_sq) of its new shape (moments None = zeros).  The flat parameter / gradient / moment buffers are laid out
-    afresh -- every Parameter keeps its identity and is re-homed (`.data` / `.grad` become views of the new buffers), the moments of the
-    untouched parameters are carried over, every named optimizer gets its new ranges.  The all-reduce operand of the multi-view step is the
-    new `opts.buffers.grad`."""
+    afresh: the untouched Parameters keep their identity and are re-homed (`.data` / `.grad` become views of the new buffers, moments
+    carried over); a RESIZED parameter becomes a NEW nn.Parameter object, as in the reference (:131,156) -- a leaf whose `.data` changed
+    shape keeps a stale gradient accumulator for as long as anybody holds an output of an earlier step.  Returns {old: new} for the
+    resized ones (the caller re-binds its attributes); every named optimizer gets its new ranges.  The all-reduce operand of the
+    multi-view step is the new `opts.buffers.grad`."""
     old = opts.buffers
-    keep = {}
+    keep, renamed = {}, {}
     for p, (off, n) in zip(opts.params, old.slices):
         if p in new_values:
             data, m, v = new_values[p]
-            data = data.detach().float()
-            keep[p] = (data, torch.zeros_like(data) if m is None else m.detach().float(), torch.zeros_like(data) if v is None else v.detach().float(), None)
+            data = data.detach().float().clone()
+            q = torch.nn.Parameter(data, requires_grad=p.requires_grad)
+            renamed[p] = q
+            keep[q] = (data, torch.zeros_like(data) if m is None else m.detach().float(), torch.zeros_like(data) if v is None else v.detach().float(), None)
         else:
             keep[p] = (p.data.clone(), old.m[off:off + n].clone(), old.v[off:off + n].clone(), old.grad[off:off + n].clone())
+    opts.params = [renamed.get(p, p) for p in opts.params]
+    for spec in opts.specs.values():
+        for g in spec.groups:
+            g['params'] = [renamed.get(p, p) for p in g['params']]
+    for o in opts.values():
+        for pg in o.param_groups:
+            if 'params' in pg:
+                pg['params'] = [renamed.get(p, p) for p in pg['params']]
     for p in opts.params:
         p.data = keep[p][0]
         p.grad = None
@@ -210,7 +222,7 @@ def resize_flat_params(opts: FlatOptimizerDict, new_values: Dict[torch.nn.Parame
         if keep[p][3] is not None:
             buf.grad[off:off + n].copy_(keep[p][3])
     opts.buffers = buf
-    resized = set(new_values.keys())
+    resized = set(renamed.values())
     for name, ranges in _group_ranges(opts.specs, buf).items():
         o = opts[name]
         o.buf = buf
@@ -220,3 +232,4 @@ def resize_flat_params(opts: FlatOptimizerDict, new_values: Dict[torch.nn.Parame
                 pg["skip_once"] = True
         o.start = min(r[0] for r in ranges)
         o.end = max(r[1] for r in ranges)
+    return renamed

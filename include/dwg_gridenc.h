@@ -68,6 +68,14 @@ int dwg_grid_encode_backward_slabs(const float* grad, const float* inputs, const
                                    const float* dy_dx, float* grad_inputs, uint32_t gridtype, uint32_t align_corners,
                                    uint32_t interp, uint32_t grad_layout, const int32_t* host_offsets, void* workspace,
                                    size_t workspace_bytes, dwg_stream_t stream);
+/* The same pass ADDING into grad_embeddings instead of overwriting it: the caller's buffer already holds other contributions -- the table's
+ * slice of the flat gradient buffer that a multi-view step accumulates several backward passes into (no zeroed temporary, no separate
+ * add pass over the 50 MB table).  Slabs owned by one workgroup do a plain read-add-write of their 16-byte pieces. */
+int dwg_grid_encode_backward_slabs_accumulate(const float* grad, const float* inputs, const float* embeddings, const int32_t* offsets,
+                                   float* grad_embeddings, uint32_t B, uint32_t D, uint32_t C, uint32_t L, float S, uint32_t H,
+                                   const float* dy_dx, float* grad_inputs, uint32_t gridtype, uint32_t align_corners,
+                                   uint32_t interp, uint32_t grad_layout, const int32_t* host_offsets, void* workspace,
+                                   size_t workspace_bytes, dwg_stream_t stream);
 
 #ifdef __cplusplus
 }
