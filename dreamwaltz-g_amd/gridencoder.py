@@ -126,6 +126,8 @@ def xcd_counters_for(device):
     return _xcd_counters[key]
 
 
+INPLACE_TABLE_GRAD = True      # see _grid_encode.backward; a multi-stream multi-view step turns it off (concurrent read-add-writes of one buffer)
+
 _SLAB_WS = {}     # (device, stream) -> byte workspace of the slab-binned backward (grown on demand; backwards on one stream are ordered,
                   # a workspace replaced by a bigger one is only released by the caching allocator in that stream's order)
 
@@ -218,15 +220,15 @@ class _grid_encode(Function):
         if mode == "slabs" and not slab_path_ok(B, L, int(embeddings.shape[0])):
             mode = "device"
         scratch = xcd_scratch_for(embeddings) if mode == "copies" else None
-        counters = xcd_counters_for(inputs.device) if (mode == "owner" and grad_embeddings.data_ptr() % 128 == 0) else None
         slab_ws = slab_workspace_for(inputs.device, B, L, int(embeddings.shape[0])) if mode == "slabs" else None
         # The table is a leaf Parameter whose .grad is its slice of the flat gradient buffer (optim.FlatBuffers): the slab pass ADDS straight
         # into it and autograd is handed None -- instead of a zeroed 50 MB temporary that autograd then adds to .grad (a 50 MB fill and a
         # 150 MB add per backward).  DWG_GRID_GRAD_INPLACE=0 restores the temporary.
         in_place = (mode == "slabs" and embeddings.is_leaf and embeddings.grad is not None and embeddings.grad.is_contiguous()
                     and embeddings.grad.dtype == torch.float32 and embeddings.grad.shape == embeddings.shape
-                    and os.environ.get("DWG_GRID_GRAD_INPLACE", "1") != "0")
+                    and INPLACE_TABLE_GRAD and os.environ.get("DWG_GRID_GRAD_INPLACE", "1") != "0")
         grad_embeddings = embeddings.grad if in_place else torch.zeros_like(embeddings)
+        counters = xcd_counters_for(inputs.device) if (mode == "owner" and grad_embeddings.data_ptr() % 128 == 0) else None
         try:
             grid_encode_backward(grad, inputs, embeddings, offsets, grad_embeddings, B, D, C, L, S, H, dy_dx, grad_inputs,
                                  gridtype, ctx.align_corners, interpolation, grad_layout=1, xcd_scratch=scratch,

@@ -48,6 +48,10 @@ def get_colors(sh_features, directions, sh_levels):
     return torch.clamp_min(eval_sh(sh_levels - 1, shs_view, directions) + 0.5, 0.0).view(-1, 3)
 
 
+def stream_keyed(renderer) -> bool:
+    return bool(getattr(renderer, "per_stream_pair_states", False))
+
+
 class GaussianRenderer:
     def __init__(self, sh_levels=4, bg_color=(0.0, 0.0, 0.0), compute_color_in_rasterizer=True,
                  compute_covariance_in_rasterizer=True, async_pair_count=False, reorder_every: Optional[int] = None) -> None:
@@ -75,7 +79,10 @@ class GaussianRenderer:
         device = torch.device(device)
         if device.type == "cuda" and device.index is None:          # "cuda" and "cuda:<current>" are one device, one state
             device = torch.device("cuda", torch.cuda.current_device())
-        key = (str(device), int(H), int(W))
+        # one state per stream as well: a multi-view step renders its views concurrently on side streams, and a state's pinned count /
+        # overflow words belong to ONE in-flight frame
+        stream = torch.cuda.current_stream(device).cuda_stream if device.type == "cuda" else 0
+        key = (str(device), int(H), int(W)) if not stream_keyed(self) else (str(device), int(H), int(W), stream)
         if key not in self._pair_states:
             self._pair_states[key] = PairCapacity()
         return self._pair_states[key]
@@ -123,7 +130,13 @@ class GaussianRenderer:
         key = (str(positions.device), int(positions.shape[0]))
         entry = self._visit_orders.get(key)
         if entry is None or entry[1] >= self.reorder_every:
-            entry = self._visit_orders[key] = [morton_order(positions), 0]
+            order = morton_order(positions)
+            ev = None
+            if positions.is_cuda:           # frames on OTHER streams (concurrent views of a multi-view step) wait for the permutation to be complete
+                ev = torch.cuda.Event(); ev.record(torch.cuda.current_stream(positions.device))
+            entry = self._visit_orders[key] = [order, 0, ev, torch.cuda.current_stream(positions.device).cuda_stream if positions.is_cuda else 0]
+        elif entry[2] is not None and torch.cuda.current_stream(positions.device).cuda_stream != entry[3]:
+            torch.cuda.current_stream(positions.device).wait_event(entry[2])
         entry[1] += 1
         return entry[0]
 

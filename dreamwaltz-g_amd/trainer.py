@@ -10,6 +10,7 @@
 Method and dictionary-key names are the reference's.  What is added: the flat-buffer all-reduce of the multi-view step
 (nothing in the reference to mirror) and the same-frame recovery of a pair-capacity overflow in the sync-free mode.
 """
+import os
 from typing import Any, Dict, Optional
 
 import torch
@@ -31,6 +32,7 @@ class SDSTrainer:
         self.scaler = None                          # GradScaler(enabled=False) in the fp32 recipes: pass-through
         self.redone_frames = 0
         self._view_rng = None
+        self._view_streams, self._views_warm = [], False
         self.past_checkpoints = []
         self.set_views(world)                       # one view per rank unless the caller says otherwise: mean of the summed gradients,
                                                     # folded into the Adam kernel
@@ -100,10 +102,34 @@ class SDSTrainer:
         Each view keeps its own prompt embedding, condition image, and -- from its `rng_seed` -- exactly the random draws its own
         single-view call would make (guidance.draw_view_randoms)."""
         images, texts, names, conds, draws, outs = [], [], [], [], [], []
-        for data in views:
-            ro = self.render(data=data)
+        # The views' animate + rasterizer passes are independent chains of small, latency-bound launches: each runs on its OWN stream (and
+        # so does its backward: autograd replays a node on its forward's stream), so that one view's tails and dependent launches overlap
+        # with the other views' work -- "V views per launch" in effect, for the whole per-view chain and not only the rasterizer.  The
+        # first batched step runs on one stream (caches of constant canonical-pose results are filled there).  DWG_VIEW_STREAMS=0: off.
+        dev = getattr(self.model, "device", None)
+        multi = (dev is not None and torch.device(dev).type == "cuda" and self._views_warm and os.environ.get("DWG_VIEW_STREAMS", "1") != "0")
+        main = torch.cuda.current_stream(dev) if multi else None
+        if multi:
+            while len(self._view_streams) < len(views):
+                self._view_streams.append(torch.cuda.Stream(device=dev))
+            renderer = getattr(self.model, "renderer", None)
+            if renderer is not None:
+                renderer.per_stream_pair_states = True
+        from . import gridencoder as _ge
+        _ge.INPLACE_TABLE_GRAD = not multi          # concurrent backwards must not read-add-write the table's gradient slice in place
+        for i, data in enumerate(views):
+            if multi:
+                side = self._view_streams[i]
+                side.wait_stream(main)
+                with torch.cuda.stream(side):
+                    ro = self.render(data=data)
+                    img = ro['image'].permute(0, 3, 1, 2).contiguous()
+                img.record_stream(main)
+            else:
+                ro = self.render(data=data)
+                img = ro['image'].permute(0, 3, 1, 2)
             outs.append(ro)
-            images.append(ro['image'].permute(0, 3, 1, 2))
+            images.append(img)
             emb, name = self._select_text(data)
             texts.append(emb); names.append(name)
             if self.use_controlnet:
@@ -114,6 +140,10 @@ class SDSTrainer:
                     self._view_rng = torch.Generator(device=images[-1].device)
                 self._view_rng.manual_seed(int(seed))
                 draws.append(self.diffusion.draw_view_randoms(self._view_rng, self.train_step_index, self.max_step))
+        if multi:
+            for side in self._view_streams[:len(views)]:
+                main.wait_stream(side)
+        self._views_warm = True
         sd_inputs = torch.cat(images, dim=0).contiguous()
         embeds = dict(self.text_embeds_dict)
         if texts[0] is not None:
@@ -202,6 +232,8 @@ class SDSTrainer:
             while True:
                 loss, outs, sd_outputs, names = self.train_forward_views(views, **forced)
                 loss.backward()
+                from . import gridencoder as _ge
+                _ge.INPLACE_TABLE_GRAD = True
                 if renderer is None or not renderer.consume_overflow():
                     break
                 self.redone_frames += 1         # a truncated frame contributed zeros, the others did not: start the step's gradient over

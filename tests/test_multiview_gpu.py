@@ -121,7 +121,17 @@ def test_one_batched_guidance_call_equals_the_views_one_at_a_time():
     for gd in (g1, gV):
         step = sds_step.SDSStep(n_gaussians=6000, res=res, device=dev, guidance=True, guidance_obj=gd, views=V, async_pair_count=False, iters=1000)
         assert step.my_views == [0, 1, 2]
+        if gd is gV:
+            # the batched step renders its views concurrently on their own streams once the constant canonical-pose caches exist (its first
+            # step would fill them on one stream): fill them here, so that THIS step is the multi-stream one
+            from dreamwaltz_g_amd import synth
+            with torch.no_grad():
+                step.avatar.animate(synth.random_smpl_inputs(seed=99, device=dev))
+            torch.cuda.synchronize()
+            step.trainer._views_warm = True
         step.run()
+        if gd is gV:
+            assert len(step.trainer._view_streams) == V and step.scene.renderer.per_stream_pair_states
         torch.cuda.synchronize()
         b = step.optimizers.buffers
         flats.append((b.grad.clone(), b.flat.clone(), step.optimizers["avatar"].grad_scale))
