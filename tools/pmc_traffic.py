@@ -39,18 +39,23 @@ def load(path, counter):
     return agg
 
 
-fetch, write = load(sys.argv[1], "FETCH_SIZE"), load(sys.argv[2], "WRITE_SIZE")
-out = {}
-for k in sorted(set(fetch) | set(write)):
-    nf, f = fetch.get(k, [0, 0.0]); nw, w = write.get(k, [0, 0.0])
-    n = max(nf, nw)
-    if n == 0:
-        continue
-    fb, wb = f * 1024 / max(nf, 1), w * 1024 / max(nw, 1)
-    out[k] = {"launches": n, "fetch_bytes_per_launch_raw": fb, "fetch_bytes_per_launch_corrected": 2 * fb,
-              "write_bytes_per_launch": wb, "hbm_bytes_per_launch": 2 * fb + wb}
-json.dump({"sources_sha": sources_sha(), "commit": sys.argv[4] if len(sys.argv) > 4 else None, "source": "rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate passes) over python bench.py --steps 2 --warmup 1 --eager",
-           "corrections": "KiB->bytes x1024; gfx950 FETCH_SIZE doubled for wide coalesced reads (MI355X_MICROARCH.md HBM section); WRITE_SIZE as reported",
-           "kernels": out}, open(sys.argv[3], "w"), indent=1)
-for k, v in sorted(out.items(), key=lambda kv: -kv[1]["hbm_bytes_per_launch"] * kv[1]["launches"])[:14]:
-    print("%-34s %5d launches  fetch(corr) %9.2f MB  write %9.2f MB" % (k, v["launches"], v["fetch_bytes_per_launch_corrected"] / 1e6, v["write_bytes_per_launch"] / 1e6))
+def main():
+    fetch, write = load(sys.argv[1], "FETCH_SIZE"), load(sys.argv[2], "WRITE_SIZE")
+    out = {}
+    for k in sorted(set(fetch) | set(write)):
+        nf, f = fetch.get(k, [0, 0.0]); nw, w = write.get(k, [0, 0.0])
+        n = max(nf, nw)
+        if n == 0:
+            continue
+        fb, wb = f * 1024 / max(nf, 1), w * 1024 / max(nw, 1)
+        out[k] = {"launches": n, "fetch_bytes_per_launch_raw": fb, "fetch_bytes_per_launch_corrected": 2 * fb,
+                  "write_bytes_per_launch": wb, "hbm_bytes_per_launch": 2 * fb + wb}
+    json.dump({"sources_sha": sources_sha(), "commit": sys.argv[4] if len(sys.argv) > 4 else None, "source": "rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate passes) over python bench.py --steps 2 --warmup 1 --eager",
+               "corrections": "KiB->bytes x1024; gfx950 FETCH_SIZE doubled for wide coalesced reads (MI355X_MICROARCH.md HBM section); WRITE_SIZE as reported",
+               "kernels": out}, open(sys.argv[3], "w"), indent=1)
+    for k, v in sorted(out.items(), key=lambda kv: -kv[1]["hbm_bytes_per_launch"] * kv[1]["launches"])[:14]:
+        print("%-34s %5d launches  fetch(corr) %9.2f MB  write %9.2f MB" % (k, v["launches"], v["fetch_bytes_per_launch_corrected"] / 1e6, v["write_bytes_per_launch"] / 1e6))
+
+
+if __name__ == "__main__":
+    main()

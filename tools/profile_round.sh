@@ -6,7 +6,7 @@ set -u
 R=${1:-r03}
 COMMIT=${2:-unknown}
 # DWG_PROFILE_PARTS: which passes to run (default all): eager graph pmc bench
-PARTS=${DWG_PROFILE_PARTS:-"eager graph pmc bench"}
+PARTS=${DWG_PROFILE_PARTS:-"eager graph pmc sq bench"}
 has() { case " $PARTS " in *" $1 "*) return 0;; *) return 1;; esac; }
 REPO=$(cd "$(dirname "$0")/.." && pwd)
 OUT=$REPO/gpurun_out/prof_$R
@@ -17,7 +17,10 @@ has eager && timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d
 has graph && timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/graph -o sds -- $B --steps 5 --warmup 2 > $OUT/graph.log 2>&1
 has pmc && timeout 300 rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $OUT/pmc_fetch -o sds -- $B --steps 2 --warmup 1 --eager > $OUT/pmc_fetch.log 2>&1
 has pmc && timeout 300 rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d $OUT/pmc_write -o sds -- $B --steps 2 --warmup 1 --eager > $OUT/pmc_write.log 2>&1
+has sq && timeout 300 rocprofv3 --pmc SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS --kernel-trace --output-format csv -d $OUT/pmc_sq -o sds -- $B --steps 2 --warmup 1 --eager > $OUT/pmc_sq.log 2>&1
 cd $REPO
+has sq && python tools/pmc_sq.py $(find $OUT/pmc_sq -name "*counter_collection.csv" | head -1) profiles/${R}_pmc_sq.json $COMMIT > $OUT/pmc_sq_summary.log 2>&1
+has sq && tail -18 $OUT/pmc_sq_summary.log
 find $OUT -name "*kernel_stats.csv" | head
 has eager && cp $(find $OUT/eager -name "*kernel_stats.csv" | head -1) profiles/${R}_sds_step_eager_kernel_stats.csv
 has graph && cp $(find $OUT/graph -name "*kernel_stats.csv" | head -1) profiles/${R}_sds_step_graph_kernel_stats.csv
