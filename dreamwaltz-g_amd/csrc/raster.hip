@@ -658,7 +658,7 @@ __global__ __launch_bounds__(64) void k_render_fwd(Params p, const uint32_t* __r
     if (lane < n) { const uint32_t g = sorted[rs + lane]; r0 = rec0[g]; r1 = rec1[g]; r2 = rec2[g]; }
     for (int base = 0; base < n; base += 64) {
         if (!__any(!done)) break;
-        if (ckpt && (base % SEG) == 0) {
+        if (ckpt && base > 0 && (base % SEG) == 0) {          // segment 0 starts from the known state (T = 1, sums 0): neither written nor read
             const int64_t seg = sbase + base / SEG;
             if (seg < cap_segs) {
                 float* c = ckpt + (size_t)seg * 6 * 64 + lane;
@@ -670,23 +670,39 @@ __global__ __launch_bounds__(64) void k_render_fwd(Params p, const uint32_t* __r
         if (nb < n) { const uint32_t g = sorted[rs + nb]; r0 = rec0[g]; r1 = rec1[g]; r2 = rec2[g]; }
         __syncthreads();
         const int cnt = min(64, n - base);
-        if (!done) {
-            for (int j = 0; j < cnt; j++) {
-                const float4 a = s0[j]; const float4 b = s1[j];
+        // Branch-free walk over the batch (round 3; SQ counters of the nested-branch version: as many SALU as VALU instructions -- the
+        // exec-mask bookkeeping of three nested divergent ifs per splat -- and waves parked 42 % of the time on LDS reads issued one
+        // splat at a time).  A pixel that skips a splat or has terminated adds w = 0 (fma(c, 0, C) == C exactly), so the arithmetic of
+        // every contributing splat -- and with it every output bit -- is the one of the branchy loop.
+        bool alive = !done;
+        // four splats per trip: their twelve 16-byte LDS reads are issued together, the four evaluations (serial through T) run under
+        // the later reads' latency
+        for (int j = 0; j < cnt && __any(alive); j += 4) {
+            float4 ra[4], rb[4], rc[4];
+#pragma unroll
+            for (int u = 0; u < 4; u++) {
+                const int ju = min(j + u, cnt - 1);
+                ra[u] = s0[ju]; rb[u] = s1[ju]; rc[u] = s2[ju];
+            }
+#pragma unroll
+            for (int u = 0; u < 4; u++) {
+                const float4 a = ra[u], b = rb[u], c = rc[u];
                 const float dx = a.x - fx, dy = a.y - fy;
                 const float power = splat_power(b.x, b.y, b.z, dx, dy);
-                if (power > 0.f) continue;
                 const float alpha = fminf(0.99f, a.w * expf(power));
-                if (alpha < (1.f / 255.f)) continue;
+                const bool hit = alive && (j + u < cnt) && !(power > 0.f) && !(alpha < (1.f / 255.f));     // negated forms: as the skip tests treat a NaN
                 const float test_T = __fmul_rn(T, 1.f - alpha);
-                if (test_T < 0.0001f) { done = true; break; }
-                const float w = __fmul_rn(alpha, T);
-                const float4 c = s2[j];
+                const bool stop = hit && test_T < 0.0001f;
+                const bool upd = hit && !stop;
+                alive = alive && !stop;
+                const float w = upd ? __fmul_rn(alpha, T) : 0.f;
                 C0 = __fmaf_rn(c.x, w, C0); C1 = __fmaf_rn(c.y, w, C1); C2 = __fmaf_rn(c.z, w, C2);
                 D = __fmaf_rn(a.z, w, D); A += w;
-                T = test_T; last = base + j + 1;
+                T = upd ? test_T : T;
+                last = upd ? base + j + u + 1 : last;
             }
         }
+        done = !alive;
         __syncthreads();
     }
     // deepest contributor of the block: nothing behind it matters to the backward
@@ -715,6 +731,9 @@ __global__ __launch_bounds__(64) void k_render_fwd(Params p, const uint32_t* __r
 //   w_i = alpha_i T_i,   sum over LATER splats of c_j w_j = (final sum) - (prefix sum including i)
 //   dL/dalpha_i = sum_ch (c_i T_i - later_ch / (1 - alpha_i)) g_ch - T_final / (1 - alpha_i) (bg . g_rgb)
 // T_i follows the forward's own recurrence from the checkpoint, bit for bit.
+// GD: a depth-map gradient is given (component 9 of the per-splat partials is non-zero only then -- the SDS path has none, and skips its
+// six-step wave reduction, LDS add and atomic)
+template <bool GD>
 __global__ __launch_bounds__(64) void k_render_bwd(Params p, const int32_t* __restrict__ header, int64_t cap_segs,
                                                    const uint32_t* __restrict__ seg_tile, const uint32_t* __restrict__ seg_start,
                                                    const uint32_t* __restrict__ tile_start, const uint32_t* __restrict__ tile_neff,
@@ -726,6 +745,7 @@ __global__ __launch_bounds__(64) void k_render_bwd(Params p, const int32_t* __re
                                                    const float* __restrict__ g_alpha, float* __restrict__ gacc /* [G][GSTRIDE] */) {
     __shared__ float4 s0[64], s1[64], s2[64];
     __shared__ float sacc[NGRAD * 64];
+    constexpr int NG = GD ? NGRAD : NGRAD - 1;        // components actually reduced
     const int64_t seg = blockIdx.x;
     if (seg >= (int64_t)header[H_NSEG] || seg >= cap_segs || header[H_OVERFLOW]) return;    // a truncated frame is redone by the caller
     const int tile = (int)seg_tile[seg];
@@ -749,23 +769,27 @@ __global__ __launch_bounds__(64) void k_render_bwd(Params p, const int32_t* __re
         T_final = final_T[pix]; last = n_contrib[pix];
         t0 = craw[pix]; t1 = craw[P + pix]; t2 = craw[2 * P + pix]; td = craw[3 * P + pix]; ta = craw[4 * P + pix];
         gp0 = g_color[pix]; gp1 = g_color[P + pix]; gp2 = g_color[2 * P + pix];
-        if (g_depth) gpd = g_depth[pix];
+        if (GD) gpd = g_depth[pix];
         if (g_alpha) gpa = g_alpha[pix];
     }
     const float bgdot = p.bg[0] * gp0 + p.bg[1] * gp1 + p.bg[2] * gp2;
     const float* ck = ckpt + (size_t)seg * 6 * 64 + lane;
-    float T = ck[0], P0 = ck[64], P1 = ck[128], P2 = ck[192], Pd = ck[256], Pa = ck[320];
+    float T = 1.f, P0 = 0.f, P1 = 0.f, P2 = 0.f, Pd = 0.f, Pa = 0.f;
+    if (sidx > 0) { T = ck[0]; P0 = ck[64]; P1 = ck[128]; P2 = ck[192]; Pd = ck[256]; Pa = ck[320]; }
     const float ddelx = 0.5f * p.W, ddely = 0.5f * p.H;
 #pragma unroll
-    for (int c = 0; c < NGRAD; c++) sacc[c * 64 + lane] = 0.f;
+    for (int c = 0; c < NG; c++) sacc[c * 64 + lane] = 0.f;
     for (int base = lo; base < hi; base += 64) {
         const int cnt = min(64, hi - base);
         uint32_t gid = 0;
         __syncthreads();
         if (lane < cnt) { gid = sorted[rs + base + lane]; s0[lane] = rec0[gid]; s1[lane] = rec1[gid]; s2[lane] = rec2[gid]; }
         __syncthreads();
+        float4 an = s0[0], bn = s1[0], cn = s2[0];
         for (int j = 0; j < cnt; j++) {
-            const float4 a = s0[j]; const float4 b = s1[j];
+            const float4 a = an, b = bn, col = cn;
+            const int jn = min(j + 1, cnt - 1);
+            an = s0[jn]; bn = s1[jn]; cn = s2[jn];          // the next splat's records are in flight while this one is evaluated
             const float dx = a.x - fx, dy = a.y - fy;
             const float power = splat_power(b.x, b.y, b.z, dx, dy);
             const float Gv = expf(power);
@@ -776,7 +800,6 @@ __global__ __launch_bounds__(64) void k_render_bwd(Params p, const int32_t* __re
 #pragma unroll
             for (int c = 0; c < NGRAD; c++) v[c] = 0.f;
             if (valid) {
-                const float4 col = s2[j];
                 const float om = 1.f - alpha;
                 const float inv1a = 1.f / om;
                 const float w = __fmul_rn(alpha, T);
@@ -796,17 +819,17 @@ __global__ __launch_bounds__(64) void k_render_bwd(Params p, const int32_t* __re
                 T = __fmul_rn(T, om);
             }
 #pragma unroll
-            for (int c = 0; c < NGRAD; c++) v[c] = dwg_wave_sum_to_lane63(v[c]);
+            for (int c = 0; c < NG; c++) v[c] = dwg_wave_sum_to_lane63(v[c]);
             if (lane == 63) {
 #pragma unroll
-                for (int c = 0; c < NGRAD; c++) sacc[c * 64 + j] += v[c];
+                for (int c = 0; c < NG; c++) sacc[c * 64 + j] += v[c];
             }
         }
         __syncthreads();
         if (lane < cnt) {
             float* dst = gacc + (size_t)gid * GSTRIDE;
 #pragma unroll
-            for (int c = 0; c < NGRAD; c++) {
+            for (int c = 0; c < NG; c++) {
                 const float x = sacc[c * 64 + lane];
                 if (x != 0.f) { atomicAdd(dst + c, x); sacc[c * 64 + lane] = 0.f; }
             }
@@ -1177,12 +1200,13 @@ int dwg_raster_backward(const dwg_raster_settings* cfg, int32_t G, const float* 
     const int64_t cap_segs = seg_capacity(pair_capacity > 0 ? pair_capacity : 1, p.H, p.W);
     const char* ws = (const char*)ws_geom; const char* wp = (const char*)ws_pairs; const char* wi = (const char*)ws_image;
     if (hipMemsetAsync(ws_grad, 0, (size_t)G * GSTRIDE * sizeof(float), stream) != hipSuccess) return DWG_E_LAUNCH;
-    DWG_LAUNCH("raster_render_bwd", k_render_bwd, dim3((unsigned)cap_segs), dim3(64), 0, stream, p, (const int32_t*)(ws + L.header), cap_segs,
-               (const uint32_t*)(wp + PL.seg_tile), (const uint32_t*)(ws + L.seg_start), (const uint32_t*)(ws + L.tile_start),
-               (const uint32_t*)(ws + L.tile_neff), (const uint32_t*)(wp + PL.sorted), (const float4*)(ws + L.rec0),
-               (const float4*)(ws + L.rec1), (const float4*)(ws + L.rec2), pair_capacity, (const float*)(wp + PL.ckpt),
-               (const float*)(wi + IL.final_T), (const int*)(wi + IL.n_contrib), (const float*)(wi + IL.craw),
-               dL_dout_color, dL_dout_depth, dL_dout_alpha, (float*)ws_grad);
+#define DWG_BWD_ARGS p, (const int32_t*)(ws + L.header), cap_segs, (const uint32_t*)(wp + PL.seg_tile), (const uint32_t*)(ws + L.seg_start),   \
+        (const uint32_t*)(ws + L.tile_start), (const uint32_t*)(ws + L.tile_neff), (const uint32_t*)(wp + PL.sorted), (const float4*)(ws + L.rec0), \
+        (const float4*)(ws + L.rec1), (const float4*)(ws + L.rec2), pair_capacity, (const float*)(wp + PL.ckpt), (const float*)(wi + IL.final_T),  \
+        (const int*)(wi + IL.n_contrib), (const float*)(wi + IL.craw), dL_dout_color, dL_dout_depth, dL_dout_alpha, (float*)ws_grad
+    if (dL_dout_depth) DWG_LAUNCH("raster_render_bwd", k_render_bwd<true>, dim3((unsigned)cap_segs), dim3(64), 0, stream, DWG_BWD_ARGS);
+    else DWG_LAUNCH("raster_render_bwd", k_render_bwd<false>, dim3((unsigned)cap_segs), dim3(64), 0, stream, DWG_BWD_ARGS);
+#undef DWG_BWD_ARGS
     DWG_LAUNCH("raster_preprocess_bwd", k_preprocess_bwd, dim3(dwg_cdiv(G, 256)), dim3(256), 0, stream, p, means3D, shs, colors_precomp,
                scales, rotations, cov3D_precomp, (const uint2*)(ws + L.rect), (const float4*)(ws + L.rec2),
                (const float*)ws_grad, dL_dmeans3D, dL_dmeans2D, dL_dshs, dL_dcolors, dL_dopacities, dL_dscales,

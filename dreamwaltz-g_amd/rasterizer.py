@@ -171,6 +171,7 @@ class _RasterizeGaussians(torch.autograd.Function):
                 ev = torch.cuda.Event(); ev.record(torch.cuda.current_stream(device))
                 pair_state.event, pair_state.pending, pair_state.pending_seq = ev, True, pair_state.seq
         ctx.raster_settings = raster_settings
+        ctx.set_materialize_grads(False)        # an output the loss never touched (depth / alpha in the SDS path) arrives as None, not as zeros
         ctx.cap = cap
         ctx.pair_state = pair_state
         ctx.frame_seq = pair_state.seq if pair_state is not None else 0
