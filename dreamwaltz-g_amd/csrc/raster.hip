@@ -282,6 +282,20 @@ __device__ __forceinline__ void block_row(const BlockSpan& s, int by, int* xa, i
     *xa = max(a, s.bx0); *xb = min(b, s.bx1);
 }
 
+// A splat whose block rectangle is large is enumerated by the WHOLE wave (16 block rows x 4 column phases at a time) instead of by the
+// one lane that owns it: the pair counts are heavy-tailed (c5: radius median 20 px, 1 % above 82 px), and with one lane per Gaussian the
+// sum of per-wave maxima was 2.5x the mean work of the two binning stages (tools/diag_binning_balance.py).
+#define BIG_SPLAT_BLOCKS 32
+__device__ __forceinline__ BlockSpan span_from_lane(const BlockSpan& s, int src) {
+    BlockSpan o;
+    o.by0 = __shfl(s.by0, src); o.by1 = __shfl(s.by1, src); o.bx0 = __shfl(s.bx0, src); o.bx1 = __shfl(s.bx1, src);
+    o.gx = __shfl(s.gx, src); o.gy = __shfl(s.gy, src); o.ca = __shfl(s.ca, src); o.cb = __shfl(s.cb, src); o.cc = __shfl(s.cc, src);
+    o.thr = __shfl(s.thr, src); o.det = __shfl(s.det, src); o.hy = __shfl(s.hy, src); o.yr = __shfl(s.yr, src);
+    o.all = __shfl((int)s.all, src) != 0;
+    return o;
+}
+__device__ __forceinline__ bool span_is_big(const BlockSpan& s) { return (s.by1 - s.by0) * (s.bx1 - s.bx0) > BIG_SPLAT_BLOCKS; }
+
 // ------------------------------------------------------------------------------------------------
 // stage A
 // ------------------------------------------------------------------------------------------------
@@ -310,6 +324,9 @@ __global__ __launch_bounds__(256) void k_preprocess(Params p, const float* __res
     uint2 rc = make_uint2(0u, 0u);
     float4 r0 = make_float4(0.f, 0.f, 0.f, 0.f), r1 = r0, r2 = r0;
     float kref = 0.f;
+    BlockSpan sp;
+    sp.by0 = sp.by1 = sp.bx0 = sp.bx1 = 0; sp.all = false;
+    sp.gx = sp.gy = sp.ca = sp.cb = sp.cc = sp.thr = sp.det = sp.hy = sp.yr = 0.f;
     float3 pv = xform43(view, pos);
     if (live_thread && pv.z > 0.2f) {
         float4 ph = xform44(proj, pos);
@@ -342,14 +359,34 @@ __global__ __launch_bounds__(256) void k_preprocess(Params p, const float* __res
                 r0 = make_float4(px, py, pv.z, op);
                 r1 = make_float4(e.c * di, -e.b * di, e.a * di, 0.f);
                 r2 = make_float4(col.x, col.y, col.z, __uint_as_float(cb));
-                const BlockSpan sp = block_span(px, py, r1.x, r1.y, r1.z, op, tx0, ty0, tx1, ty1, p.tiles_x, p.tiles_y);
-                for (int by = sp.by0; by < sp.by1; by++) {
-                    int xa, xb;
-                    block_row(sp, by, &xa, &xb);
-                    for (int bx = xa; bx < xb; bx++) {
-                        if (use_lds_hist) atomicAdd(&hist[by * p.tiles_x + bx], 1u);
-                        else atomicAdd(&tile_count[by * p.tiles_x + bx], 1u);
-                    }
+                sp = block_span(px, py, r1.x, r1.y, r1.z, op, tx0, ty0, tx1, ty1, p.tiles_x, p.tiles_y);
+            }
+        }
+    }
+    {   // exact-culled per-block histogram: small splats by their own lane, big ones by the whole wave
+        const bool big = span_is_big(sp);
+        if (!big) {
+            for (int by = sp.by0; by < sp.by1; by++) {
+                int xa, xb;
+                block_row(sp, by, &xa, &xb);
+                for (int bx = xa; bx < xb; bx++) {
+                    if (use_lds_hist) atomicAdd(&hist[by * p.tiles_x + bx], 1u);
+                    else atomicAdd(&tile_count[by * p.tiles_x + bx], 1u);
+                }
+            }
+        }
+        unsigned long long m = __ballot(big);
+        const int lane = threadIdx.x & 63;
+        while (m) {
+            const int src = __ffsll((long long)m) - 1;
+            m &= m - 1;
+            const BlockSpan w = span_from_lane(sp, src);
+            for (int by = w.by0 + (lane >> 2); by < w.by1; by += 16) {
+                int xa, xb;
+                block_row(w, by, &xa, &xb);
+                for (int bx = xa + (lane & 3); bx < xb; bx += 4) {
+                    if (use_lds_hist) atomicAdd(&hist[by * p.tiles_x + bx], 1u);
+                    else atomicAdd(&tile_count[by * p.tiles_x + bx], 1u);
                 }
             }
         }
@@ -431,7 +468,8 @@ __global__ __launch_bounds__(256) void k_scatter(Params p, const float4* __restr
     int i = blockIdx.x * 256 + threadIdx.x;
     uint64_t key = 0;
     BlockSpan sp;
-    sp.by0 = sp.by1 = 0;
+    sp.by0 = sp.by1 = sp.bx0 = sp.bx1 = 0; sp.all = false;
+    sp.gx = sp.gy = sp.ca = sp.cb = sp.cc = sp.thr = sp.det = sp.hy = sp.yr = 0.f;
     if (i < G) {
         if (p.visit_order) i = p.visit_order[i];
         const uint2 rc = rect[i];
@@ -440,39 +478,56 @@ __global__ __launch_bounds__(256) void k_scatter(Params p, const float4* __restr
         key = ((uint64_t)__float_as_uint(a.z) << 32) | (uint32_t)i;
         if (tx1 > tx0 && ty1 > ty0) sp = block_span(a.x, a.y, b.x, b.y, b.z, a.w, tx0, ty0, tx1, ty1, p.tiles_x, p.tiles_y);
     }
+    // the SAME enumeration as k_preprocess (small splats by their lane, big ones by the whole wave: see span_is_big), three times
+    const bool big = span_is_big(sp);
+    const unsigned long long bigmask = __ballot(big);
+    const int lane = threadIdx.x & 63;
+#define DWG_FOR_EACH_BLOCK(KEYVAR, BODY)                                                        \
+    do {                                                                                        \
+        if (!big) {                                                                             \
+            const uint64_t KEYVAR = key; (void)KEYVAR;                                          \
+            for (int by = sp.by0; by < sp.by1; by++) {                                          \
+                int xa, xb;                                                                     \
+                block_row(sp, by, &xa, &xb);                                                    \
+                for (int bx = xa; bx < xb; bx++) { const int t = by * p.tiles_x + bx; BODY; }   \
+            }                                                                                   \
+        }                                                                                       \
+        unsigned long long m__ = bigmask;                                                       \
+        while (m__) {                                                                           \
+            const int src = __ffsll((long long)m__) - 1;                                        \
+            m__ &= m__ - 1;                                                                     \
+            const BlockSpan w = span_from_lane(sp, src);                                        \
+            const uint64_t KEYVAR = ((uint64_t)(uint32_t)__shfl((int)(uint32_t)(key >> 32), src) << 32) |   \
+                                    (uint32_t)__shfl((int)(uint32_t)key, src);                  \
+            (void)KEYVAR;                                                                       \
+            for (int by = w.by0 + (lane >> 2); by < w.by1; by += 16) {                          \
+                int xa, xb;                                                                     \
+                block_row(w, by, &xa, &xb);                                                     \
+                for (int bx = xa + (lane & 3); bx < xb; bx += 4) { const int t = by * p.tiles_x + bx; BODY; }   \
+            }                                                                                   \
+        }                                                                                       \
+    } while (0)
     if (!use_lds) {
-        for (int by = sp.by0; by < sp.by1; by++) {
-            int xa, xb;
-            block_row(sp, by, &xa, &xb);
-            for (int bx = xa; bx < xb; bx++) {
-                const int t = by * p.tiles_x + bx;
-                int64_t slot = (int64_t)tile_start[t] + atomicAdd(&tile_cursor[t], 1u);
-                if (slot < cap) keys[slot] = key; else header[H_OVERFLOW] = 1;
-            }
-        }
+        DWG_FOR_EACH_BLOCK(k, {
+            int64_t slot = (int64_t)tile_start[t] + atomicAdd(&tile_cursor[t], 1u);
+            if (slot < cap) keys[slot] = k; else header[H_OVERFLOW] = 1;
+        });
         return;
     }
     for (int t = threadIdx.x; t < T; t += 256) cnt[t] = 0u;
     __syncthreads();
-    for (int by = sp.by0; by < sp.by1; by++) {
-        int xa, xb;
-        block_row(sp, by, &xa, &xb);
-        for (int bx = xa; bx < xb; bx++) atomicAdd(&cnt[by * p.tiles_x + bx], 1u);
-    }
+    DWG_FOR_EACH_BLOCK(k, { atomicAdd(&cnt[t], 1u); });
     __syncthreads();
     for (int t = threadIdx.x; t < T; t += 256) {
         const uint32_t c = cnt[t];
         if (c) cnt[t] = tile_start[t] + atomicAdd(&tile_cursor[t], c);
     }
     __syncthreads();
-    for (int by = sp.by0; by < sp.by1; by++) {
-        int xa, xb;
-        block_row(sp, by, &xa, &xb);
-        for (int bx = xa; bx < xb; bx++) {
-            const int64_t slot = (int64_t)atomicAdd(&cnt[by * p.tiles_x + bx], 1u);
-            if (slot < cap) keys[slot] = key; else header[H_OVERFLOW] = 1;
-        }
-    }
+    DWG_FOR_EACH_BLOCK(k, {
+        const int64_t slot = (int64_t)atomicAdd(&cnt[t], 1u);
+        if (slot < cap) keys[slot] = k; else header[H_OVERFLOW] = 1;
+    });
+#undef DWG_FOR_EACH_BLOCK
 }
 
 // Ascending-only bitonic network (mirror step + half-cleaners) so that virtual +inf padding above n is legal.
