@@ -4,7 +4,8 @@
                                                         its own N ranks through torch.distributed.run (one process per GPU, RCCL); under
                                                         torchrun (WORLD_SIZE set) it is one of the ranks.
     python bench.py --config c1|c2|c4|c5                 one of the other BASELINE.json configurations as its own line
-    python bench.py --dtype f32                          the denoiser / VAE plans at the reference's own precision (fp32)
+    python bench.py --dtype f32 | f16                    the denoiser / VAE plans at the reference's own precision (fp32) / in its
+                                                         --optim.fp16 storage type (same kernels on _Float16 operands)
     python bench.py --gpus 2 --share-gpu                 functional run of the multi-rank path on a 1-GPU box (all ranks on cuda:0, gloo)
 
 Prints ONE JSON line (rank 0): metric / value / unit / n_gpus / steps / warmup / ms_per_step / higher_is_better / scaling / vs_baseline /
@@ -51,7 +52,7 @@ def parse():
     ap.add_argument("--warmup", type=int, default=None, help="default: 3 (c3), 1 (c4), 20 (c1 / c2 / c5)")
     ap.add_argument("--config", choices=["c1", "c2", "c3", "c4", "c5"], default="c3")
     ap.add_argument("--views", type=int, default=None, help="views per step over ALL GPUs (default: one per GPU for c3, 8 for c4)")
-    ap.add_argument("--dtype", choices=["bf16", "f32"], default="bf16", help="storage type of the denoiser / VAE plans")
+    ap.add_argument("--dtype", choices=["bf16", "f32", "f16"], default="bf16", help="storage type of the denoiser / VAE plans")
     ap.add_argument("--gaussians", type=int, default=None)
     ap.add_argument("--res", type=int, default=None)
     ap.add_argument("--headline-only", action="store_true", help="skip the attached configs / by_dtype / cpu_baseline legs")
@@ -573,9 +574,14 @@ def main():
                                "f32": _brief(f32, ("value", "unit", "ms_per_step", "steps", "warmup", "dtype")) | {"roofline": {k: f32["roofline"].get(k) for k in ("kernel", "achieved", "peak", "frac", "mfma_all")},
                                                                                                                     "config": f32["config"]},
                                "note": "same workload, same kernels outside the denoiser / VAE; f32 = the precision the reference runs this stage in "
-                                       "(configs/__init__.py:236,241), exact-f32 MFMA peak 157 TFLOP/s; parity of either against the fp32 oracle: "
-                                       "tests/test_sd15_fp32_gpu.py"}
+                                       "(configs/__init__.py:236,241), exact-f32 MFMA peak 157 TFLOP/s; f16 = its --optim.fp16 storage type "
+                                       "(the bf16 kernels compiled for _Float16 operands); parity against the fp32 oracle / fp32 plans: "
+                                       "tests/test_sd15_fp32_gpu.py, tests/test_sd15_fp16_gpu.py"}
             ctx.guidance.pop("f32", None)                         # free the fp32 plans (weights 5 GB, activations) before the other legs
+            torch.cuda.empty_cache()
+            f16 = run_sds(ctx, "c3", dtype="f16", steps=20, warmup=5, profile=False)
+            out["by_dtype"]["f16"] = _brief(f16, ("value", "unit", "ms_per_step", "steps", "warmup", "dtype")) | {"config": f16["config"]}
+            ctx.guidance.pop("f16", None)
             torch.cuda.empty_cache()
             cfgs = dict(pre_cfgs)
             c4 = run_sds(ctx, "c4", steps=3, warmup=1, profile=False)                       # 8 views through ONE VAE / denoiser pass per step

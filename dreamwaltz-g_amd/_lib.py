@@ -73,6 +73,8 @@ SIGNATURES = {
     "dwg_geglu_forward": (ctypes.c_int, [_i64, _i32, _vp, _vp, _vp]),
     "dwg_attention_forward": (ctypes.c_int, [_i32, _i32, _i32, _i32, _i32, _vp, _i64, _i64, _vp, _i64, _i64, _vp, _i64, _i64,
                                              _vp, _i64, _i64, _f32, _vp]),
+    "dwg_attention_forward_dt": (ctypes.c_int, [_i32, _i32, _i32, _i32, _i32, _i32, _vp, _i64, _i64, _vp, _i64, _i64, _vp, _i64, _i64,
+                                                _vp, _i64, _i64, _f32, _vp]),
     "dwg_softmax_rows_forward": (ctypes.c_int, [_i32, _i32, _f32, _vp, _i64, _vp, _i64, _vp]),
     "dwg_softmax_rows_backward": (ctypes.c_int, [_i32, _i32, _f32, _vp, _i64, _vp, _i64, _vp, _i64, _vp]),
     "dwg_groupnorm_forward_dt": (ctypes.c_int, [_i32, _i32, _i32, _i32, _i32, _vp, _vp, _vp, _f32, _i32, _vp, _vp, _vp, _vp]),

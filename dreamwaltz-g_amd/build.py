@@ -35,10 +35,19 @@ def _headers_mtime():
     return m
 
 
+def _src_mtime(sp):
+    """mtime of a source and of the .hip files it re-includes (gemm_f16.hip / attention_f16.hip compile their bf16 twins again with
+    DWG_*_F16_TU defined)."""
+    m = os.path.getmtime(sp)
+    for inc in re.findall(r'#include "([^"]+\.hip)"', open(sp).read()):
+        m = max(m, os.path.getmtime(os.path.join(CSRC, inc)))
+    return m
+
+
 def _compile(src, force):
     obj = os.path.join(OBJ, src + ".o")
     sp = os.path.join(CSRC, src)
-    if (not force and os.path.exists(obj) and os.path.getmtime(obj) >= os.path.getmtime(sp)
+    if (not force and os.path.exists(obj) and os.path.getmtime(obj) >= _src_mtime(sp)
             and os.path.getmtime(obj) >= _headers_mtime()):
         return obj, False
     cmd = [HIPCC] + FLAGS + ["-Rpass-analysis=kernel-resource-usage", "-x", "hip", "-c", sp, "-o", obj]

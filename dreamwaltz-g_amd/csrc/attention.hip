@@ -17,14 +17,24 @@
 #include "dwg_prof_internal.h"
 #include "../../include/dwg_nn.h"
 
+// 16-bit operand type of this translation unit: attention.hip is the bf16 unit, attention_f16.hip re-includes it with DWG_ATTN_F16_TU
+// defined (same kernels on _Float16, v_mfma_f32_32x32x16_f16) for the fp16-storage plans.
+#ifdef DWG_ATTN_F16_TU
+typedef _Float16 HT;
+#define DWG_MFMA16(a, b, c) __builtin_amdgcn_mfma_f32_32x32x16_f16(a, b, c, 0, 0, 0)
+#else
+typedef __bf16 HT;
+#define DWG_MFMA16(a, b, c) __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, c, 0, 0, 0)
+#endif
+
 namespace {
 
-typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
-typedef __attribute__((ext_vector_type(4))) __bf16 bf16x4;
+typedef __attribute__((ext_vector_type(8))) HT bf16x8;
+typedef __attribute__((ext_vector_type(4))) HT bf16x4;
 typedef __attribute__((ext_vector_type(16))) float f32x16;
 
 struct AttnP {
-    const __bf16* Q; const __bf16* K; const __bf16* V; __bf16* O;
+    const HT* Q; const HT* K; const HT* V; HT* O;
     int Nq, Nk, H, d;
     long long ldq, ldk, ldv, ldo;          // row strides (elements)
     long long bq, bk, bv, bo;              // per-image strides (elements); head h starts at column h*d
@@ -38,15 +48,15 @@ __global__ __launch_bounds__(256) void k_flash_fwd(AttnP p) {
     constexpr int LDK = DK + 8;            // K tile row stride (bf16), 16-byte aligned rows
     constexpr int LDV = KT + 8;            // V^T tile row stride
     constexpr int NKS = DK / 16, NVB = DV / 32;
-    __shared__ __attribute__((aligned(16))) __bf16 sK[KT * LDK];
-    __shared__ __attribute__((aligned(16))) __bf16 sVt[DV * LDV];
+    __shared__ __attribute__((aligned(16))) HT sK[KT * LDK];
+    __shared__ __attribute__((aligned(16))) HT sVt[DV * LDV];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, half = lane >> 5, ql = lane & 31;
     const int img = blockIdx.y / p.H, head = blockIdx.y % p.H;
     const int q0 = blockIdx.x * 128 + wave * 32;
-    const __bf16* Q = p.Q + img * p.bq + (long long)head * p.d;
-    const __bf16* K = p.K + img * p.bk + (long long)head * p.d;
-    const __bf16* V = p.V + img * p.bv + (long long)head * p.d;
-    __bf16* O = p.O + img * p.bo + (long long)head * p.d;
+    const HT* Q = p.Q + img * p.bq + (long long)head * p.d;
+    const HT* K = p.K + img * p.bk + (long long)head * p.d;
+    const HT* V = p.V + img * p.bv + (long long)head * p.d;
+    HT* O = p.O + img * p.bo + (long long)head * p.d;
 
     // this lane's query row as MFMA B-operand fragments: element e of step s = Q[q][16 s + 8 half + e]
     bf16x8 qf[NKS];
@@ -57,7 +67,7 @@ __global__ __launch_bounds__(256) void k_flash_fwd(AttnP p) {
             const int c = 16 * s + 8 * half;
             bf16x8 v;
 #pragma unroll
-            for (int e = 0; e < 8; e++) v[e] = (__bf16)0.f;
+            for (int e = 0; e < 8; e++) v[e] = (HT)0.f;
             if (q < p.Nq && c < p.d) v = *reinterpret_cast<const bf16x8*>(Q + (long long)q * p.ldq + c);   // d % 8 == 0
             qf[s] = v;
         }
@@ -77,8 +87,8 @@ __global__ __launch_bounds__(256) void k_flash_fwd(AttnP p) {
     bf16x8 kreg[NKC], vreg[NVC];
     // per-thread staging coordinates are tile-invariant: (key, dc) and the matching global / LDS addresses are computed once
     int kkey[NKC], vkey[NVC];
-    const __bf16* kptr[NKC]; const __bf16* vptr[NVC];
-    __bf16* klds[NKC]; __bf16* vlds[NVC];
+    const HT* kptr[NKC]; const HT* vptr[NVC];
+    HT* klds[NKC]; HT* vlds[NVC];
 #pragma unroll
     for (int i = 0; i < NKC; i++) {
         const int c = tid + i * 256;
@@ -100,7 +110,7 @@ __global__ __launch_bounds__(256) void k_flash_fwd(AttnP p) {
     auto fetch = [&](int k0) {
         bf16x8 z;
 #pragma unroll
-        for (int e = 0; e < 8; e++) z[e] = (__bf16)0.f;
+        for (int e = 0; e < 8; e++) z[e] = (HT)0.f;
 #pragma unroll
         for (int i = 0; i < NKC; i++)
             kreg[i] = (long long)k0 + kkey[i] < p.Nk ? *reinterpret_cast<const bf16x8*>(kptr[i] + (long long)k0 * p.ldk) : z;
@@ -131,7 +141,7 @@ __global__ __launch_bounds__(256) void k_flash_fwd(AttnP p) {
 #pragma unroll
         for (int ks = 0; ks < NKS; ks++) {
             bf16x8 kf = *reinterpret_cast<const bf16x8*>(&sK[ql * LDK + 16 * ks + 8 * half]);
-            s = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf, qf[ks], s, 0, 0, 0);
+            s = DWG_MFMA16(kf, qf[ks], s);
         }
         // online softmax for this lane's query; register r <-> key k0 + (r&3) + 8*(r>>2) + 4*half.
         // The scale (> 0) is folded into the exponent (one fma per element); only the last, partial tile needs key masking;
@@ -168,35 +178,35 @@ __global__ __launch_bounds__(256) void k_flash_fwd(AttnP p) {
 #pragma unroll
         for (int st = 0; st < 2; st++)
 #pragma unroll
-            for (int e = 0; e < 8; e++) pf[st][e] = (__bf16)s[8 * st + e];
+            for (int e = 0; e < 8; e++) pf[st][e] = (HT)s[8 * st + e];
         // O^T += V^T P^T ; A operand row = dv, elements follow the same key permutation:
         //   e in 0..3 -> key 16 st + 4 half + e ; e in 4..7 -> key 16 st + 8 + 4 half + (e - 4)
 #pragma unroll
         for (int j = 0; j < NVB; j++) {
 #pragma unroll
             for (int st = 0; st < 2; st++) {
-                const __bf16* vrow = &sVt[(32 * j + ql) * LDV + 16 * st + 4 * half];
+                const HT* vrow = &sVt[(32 * j + ql) * LDV + 16 * st + 4 * half];
                 bf16x4 lo = *reinterpret_cast<const bf16x4*>(vrow);
                 bf16x4 hi = *reinterpret_cast<const bf16x4*>(vrow + 8);
                 bf16x8 vf;
                 vf[0] = lo[0]; vf[1] = lo[1]; vf[2] = lo[2]; vf[3] = lo[3];
                 vf[4] = hi[0]; vf[5] = hi[1]; vf[6] = hi[2]; vf[7] = hi[3];
-                acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf, pf[st], acc[j], 0, 0, 0);
+                acc[j] = DWG_MFMA16(vf, pf[st], acc[j]);
             }
         }
     }
     // epilogue: O[q][dv] = acc / l ; lane owns query column ql, register r of block j <-> dv = 32 j + (r&3) + 8 (r>>2) + 4 half.
     // Stage through LDS so that rows go out as contiguous 16-byte stores.
     constexpr int LDO = DV + 8;
-    __shared__ __attribute__((aligned(16))) __bf16 sOut[4 * 32 * LDO];
+    __shared__ __attribute__((aligned(16))) HT sOut[4 * 32 * LDO];
     const float inv = l_run > 0.f ? 1.f / l_run : 0.f;
-    __bf16* myO = sOut + wave * 32 * LDO;
+    HT* myO = sOut + wave * 32 * LDO;
 #pragma unroll
     for (int j = 0; j < NVB; j++)
 #pragma unroll
         for (int r = 0; r < 16; r++) {
             int dv = 32 * j + (r & 3) + 8 * (r >> 2) + 4 * half;
-            myO[ql * LDO + dv] = (__bf16)(acc[j][r] * inv);
+            myO[ql * LDO + dv] = (HT)(acc[j][r] * inv);
         }
     __syncthreads();
     for (int c = lane; c < 32 * (p.d / 8); c += 64) {
@@ -210,13 +220,31 @@ __global__ __launch_bounds__(256) void k_flash_fwd(AttnP p) {
 
 extern "C" {
 
+#ifdef DWG_ATTN_F16_TU
+int dwg_attention_forward_f16(int32_t B, int32_t H, int32_t Nq, int32_t Nk, int32_t d, const void* Q, int64_t ldq, int64_t bq,
+                              const void* K, int64_t ldk, int64_t bk, const void* V, int64_t ldv, int64_t bv, void* O, int64_t ldo,
+                              int64_t bo, float scale, dwg_stream_t stream_) {
+#else
+int dwg_attention_forward_f16(int32_t B, int32_t H, int32_t Nq, int32_t Nk, int32_t d, const void* Q, int64_t ldq, int64_t bq,
+                              const void* K, int64_t ldk, int64_t bk, const void* V, int64_t ldv, int64_t bv, void* O, int64_t ldo,
+                              int64_t bo, float scale, dwg_stream_t stream_);         // attention_f16.hip
+
+int dwg_attention_forward_dt(int32_t dtype, int32_t B, int32_t H, int32_t Nq, int32_t Nk, int32_t d, const void* Q, int64_t ldq, int64_t bq,
+                             const void* K, int64_t ldk, int64_t bk, const void* V, int64_t ldv, int64_t bv, void* O, int64_t ldo,
+                             int64_t bo, float scale, dwg_stream_t stream) {
+    if (dtype == DWG_DTYPE_F16) return dwg_attention_forward_f16(B, H, Nq, Nk, d, Q, ldq, bq, K, ldk, bk, V, ldv, bv, O, ldo, bo, scale, stream);
+    if (dtype != DWG_DTYPE_BF16) return DWG_E_ARG;          // fp32 plans run attention as QK^T -> softmax -> PV on dwg_gemm
+    return dwg_attention_forward(B, H, Nq, Nk, d, Q, ldq, bq, K, ldk, bk, V, ldv, bv, O, ldo, bo, scale, stream);
+}
+
 int dwg_attention_forward(int32_t B, int32_t H, int32_t Nq, int32_t Nk, int32_t d, const void* Q, int64_t ldq, int64_t bq,
                           const void* K, int64_t ldk, int64_t bk, const void* V, int64_t ldv, int64_t bv, void* O, int64_t ldo,
                           int64_t bo, float scale, dwg_stream_t stream_) {
+#endif
     if (B <= 0 || H <= 0 || Nq <= 0 || Nk <= 0 || d <= 0 || d % 8 || d > 160 || !Q || !K || !V || !O) return DWG_E_ARG;
     if ((ldq | ldk | ldv | ldo | bq | bk | bv | bo) % 8) return DWG_E_ARG;   // 16-byte aligned rows
     if (((uintptr_t)Q | (uintptr_t)K | (uintptr_t)V | (uintptr_t)O) % 16) return DWG_E_ARG;
-    AttnP p{(const __bf16*)Q, (const __bf16*)K, (const __bf16*)V, (__bf16*)O, Nq, Nk, H, d, ldq, ldk, ldv, ldo, bq, bk, bv, bo,
+    AttnP p{(const HT*)Q, (const HT*)K, (const HT*)V, (HT*)O, Nq, Nk, H, d, ldq, ldk, ldv, ldo, bq, bk, bv, bo,
             scale * 1.4426950408889634f};
     dim3 grid(dwg_cdiv(Nq, 128), B * H), block(256);
     hipStream_t stream = (hipStream_t)stream_;

@@ -5,7 +5,7 @@ import torch
 
 from . import _lib
 
-F32, BF16 = 0, 1
+F32, BF16, F16 = 0, 1, 2
 ACT = {None: 0, "none": 0, "relu": 1, "leaky_relu": 2, "silu": 3, "gelu": 4, "sigmoid": 5, "geglu_pair": 6}
 
 
@@ -40,7 +40,9 @@ def _dt(t):
         return F32
     if t.dtype == torch.bfloat16:
         return BF16
-    raise TypeError("dwg gemm supports float32 and bfloat16 tensors, got %s" % t.dtype)
+    if t.dtype == torch.float16:
+        return F16
+    raise TypeError("dwg gemm supports float32, bfloat16 and float16 tensors, got %s" % t.dtype)
 
 
 def _stream(t):

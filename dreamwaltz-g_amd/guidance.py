@@ -73,7 +73,7 @@ class ControlNetScoreDistillation:
         self.device = torch.device(device)
         self.views = int(views)
         self.dtype_name = sd15.dtype_name(dtype)          # storage type of the denoiser / VAE plans: "bf16" (default) | "f32" (the reference's
-                                                          # GS-stage precision, configs/__init__.py:236,241) | "f16" (its --optim.fp16 mode)
+                                                          # GS-stage precision, configs/__init__.py:236,241) | "f16" (its --guide.dtype fp16)
         self.cfg = cfg if cfg is not None else GuideConfig()
         self.unet_cfg = unet_cfg or sd15.UNetConfig()
         self.vae_cfg = vae_cfg or sd15.VAEConfig()

@@ -64,18 +64,18 @@ def geglu(x, out=None):
 
 
 def attention(q, k, v, heads, out=None, scale=None):
-    """q [B, Nq, H*d], k/v [B, Nk, H*d] bf16 (last dim contiguous; may be column slices of a fused projection)."""
+    """q [B, Nq, H*d], k/v [B, Nk, H*d] bf16 or fp16 (last dim contiguous; may be column slices of a fused projection)."""
     B, Nq, HD = q.shape
     Nk = k.shape[1]
     d = HD // heads
     o = torch.empty(B, Nq, HD, device=q.device, dtype=q.dtype) if out is None else out
     scale = d ** -0.5 if scale is None else scale
     for t in (q, k, v, o):
-        assert t.stride(2) == 1 and t.dtype == torch.bfloat16
+        assert t.stride(2) == 1 and t.dtype == q.dtype and t.dtype in (torch.bfloat16, torch.float16)
     p = _lib.ptr
-    _lib.check(_lib.lib().dwg_attention_forward(B, heads, Nq, Nk, d, p(q), q.stride(1), q.stride(0), p(k), k.stride(1), k.stride(0),
+    _lib.check(_lib.lib().dwg_attention_forward_dt(1 if q.dtype == torch.bfloat16 else 2, B, heads, Nq, Nk, d, p(q), q.stride(1), q.stride(0), p(k), k.stride(1), k.stride(0),
                                                 p(v), v.stride(1), v.stride(0), p(o), o.stride(1), o.stride(0), scale, _st(q)),
-               "dwg_attention_forward")
+               "dwg_attention_forward_dt")
     return o
 
 

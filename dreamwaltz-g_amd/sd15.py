@@ -27,8 +27,8 @@ BF16 = torch.bfloat16
 #   "f32"   the precision the reference runs the 3DGS stage in (/root/reference/configs/__init__.py:236,241; `--optim.fp16` is only passed
 #           to the NeRF stages of scripts/train_w_expr.sh): exact-f32 MFMA (v_mfma_f32_32x32x2_f32, peak 157 TFLOP/s), attention as
 #           QK^T -> row softmax -> PV.  It is the full-precision reference the bf16 plans are measured against ON THE GPU.
-#   "f16"   the reference's autocast storage type (configs/__init__.py:462): the bandwidth-bound layers are typed for it
-#           (include/dwg_nn.h *_dt), the MFMA GEMM is not -- plans refuse it.
+#   "f16"   the reference's `--guide.dtype fp16` (core/guidance/basic.py:24-27,233) / autocast storage type (configs/__init__.py:462): the same kernels as "bf16" compiled for _Float16 operands
+#           (csrc/gemm_f16.hip, attention_f16.hip: v_mfma_f32_32x32x16_f16 -- same MFMA rate), 10 mantissa bits instead of 7, range 65504.
 TORCH_DTYPE = {"bf16": torch.bfloat16, "f32": torch.float32, "f16": torch.float16}
 DT_CODE = {"f32": 0, "bf16": 1, "f16": 2}          # DWG_DTYPE_* (include/dwg_types.h)
 
@@ -272,9 +272,6 @@ class Plan:
     def __init__(self, device, dtype="bf16"):
         self.device = device
         self.dtype_name = dtype_name(dtype)
-        if self.dtype_name == "f16":
-            raise NotImplementedError("fp16-storage plans: the layers are typed for it (dwg_nn.h *_dt) but dwg_gemm has no f16 MFMA path; "
-                                      "use bf16 (same MFMA rate, no loss scaling) or f32")
         self.dtype, self.dt = TORCH_DTYPE[self.dtype_name], DT_CODE[self.dtype_name]
         self.esize = 4 if self.dtype_name == "f32" else 2
         self.ops = []
@@ -605,7 +602,7 @@ class Builder:
         Nk, d = k.shape[1], HD // heads
         o = self.p.buf(B, Nq, HD)
         pp = lambda t: ctypes.c_void_p(t.data_ptr())  # noqa: E731
-        if self.p.dtype_name != "bf16":
+        if self.p.dtype_name == "f32":
             # full-precision plans: S = Q K^T (batched over image x head) -> row softmax -> O = P V on the exact-f32 MFMA GEMM
             S = self._pooled("attn_S", B * heads * Nq * Nk, torch.float32)
             P = self._pooled("attn_P", B * heads * Nq * Nk, self.p.dtype)
@@ -617,7 +614,7 @@ class Builder:
                                           a_batch=(heads * Nq * Nk, Nq * Nk), b_batch=(v.stride(0), d), c_batch=(o.stride(0), d),
                                           name="attn_pv", run=False))
             return o
-        self.p.add_call(self.L.dwg_attention_forward, B, heads, Nq, Nk, d, pp(q), q.stride(1), q.stride(0), pp(k), k.stride(1),
+        self.p.add_call(self.L.dwg_attention_forward_dt, self.p.dt, B, heads, Nq, Nk, d, pp(q), q.stride(1), q.stride(0), pp(k), k.stride(1),
                         k.stride(0), pp(v), v.stride(1), v.stride(0), pp(o), o.stride(1), o.stride(0), float(d) ** -0.5)
         return o
 

@@ -19,7 +19,8 @@ sit inside Trainer methods: /root/reference/core/trainer.py:446-453,529-530), so
                                              built from the loaded modules' state_dict()s.  Everything else (get_text_embeds, __call__,
                                              calc_gradients, tp_scheduler, pipe, decode_latents, isinstance checks) is the reference's own.
 
-Environment: DWG_BIND_DTYPE = bf16 (default) | f32   storage type of the denoiser / VAE plans
+Environment: DWG_BIND_DTYPE = bf16 | f32 | f16         storage type of the denoiser / VAE plans.  Unset: f16 when the reference loaded its
+                                                     pipeline in torch.float16 (`--guide.dtype fp16`, core/guidance/basic.py:24-27,233), else bf16
              DWG_BIND_KEEP_MODULES = 1               keep the diffusers UNet / ControlNet on the GPU (default: moved to the CPU once their
                                                      weights live in the plans -- the text encoder and the VAE decoder stay where they were)
 """
@@ -107,7 +108,7 @@ def bind_guidance(ref, dtype=None, keep_modules=None):
     _pkg()
     import torch
     from dreamwaltz_g_amd import guidance as gd, sd15
-    dtype = dtype or os.environ.get("DWG_BIND_DTYPE", "bf16")
+    dtype = dtype or os.environ.get("DWG_BIND_DTYPE") or ("f16" if getattr(ref, "torch_dtype", None) is torch.float16 else "bf16")
     unet, cnet, vae = ref.pipe.unet, ref.controlnet, ref.pipe.vae
     if type(cnet).__name__ == "MultiControlNetModel":
         raise NotImplementedError("MultiControlNetModel (several condition types at once)")

@@ -45,8 +45,8 @@ typedef struct dwg_gemm_desc {
     int32_t batch1, batch2;
     int64_t a_batch1_stride, a_batch2_stride, b_batch1_stride, b_batch2_stride, c_batch1_stride, c_batch2_stride,
         r_batch1_stride, r_batch2_stride;
-    int32_t dtype;            /* DWG_DTYPE_* of A and B */
-    int32_t out_dtype;        /* DWG_DTYPE_* of C */
+    int32_t dtype;            /* DWG_DTYPE_F32 | DWG_DTYPE_BF16 | DWG_DTYPE_F16 of A and B (F16: the fp16-operand unit, csrc/gemm_f16.hip) */
+    int32_t out_dtype;        /* DWG_DTYPE_F32 or the operand type */
     int32_t residual_dtype;
     int32_t act;              /* DWG_ACT_* */
     float alpha;

@@ -14,6 +14,5 @@ typedef void* dwg_stream_t; /* hipStream_t */
 /* element types of activation / weight tensors (the `dtype` argument of the *_dt entry points and of dwg_gemm_desc) */
 #define DWG_DTYPE_F32 0  /* the reference's GS-stage precision (configs/__init__.py:236,241): exact-f32 MFMA */
 #define DWG_DTYPE_BF16 1 /* default plans: bf16 storage, fp32 accumulation */
-#define DWG_DTYPE_F16 2  /* the reference's --optim.fp16 storage (configs/__init__.py:462): fp16 storage, fp32 accumulation;
-                            layers only (dwg_nn.h, dwg_elementwise.h) -- dwg_gemm has no f16 MFMA path */
+#define DWG_DTYPE_F16 2  /* the reference's --optim.fp16 storage (configs/__init__.py:462): fp16 storage, fp32 accumulation */
 #endif

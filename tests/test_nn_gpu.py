@@ -7,6 +7,13 @@ import torch.nn.functional as F
 pytestmark = pytest.mark.gpu
 
 
+@pytest.fixture(params=["bf16", "f16"])
+def half(request):
+    """The 16-bit operand types: bf16 (gemm.hip / attention.hip) and fp16 (their _f16 units: the same kernels on _Float16)."""
+    return {"bf16": torch.bfloat16, "f16": torch.float16}[request.param]
+
+
+
 def _err(a, r):
     a = a.float().cpu(); r = r.float().cpu()
     return float((a - r).abs().max() / r.abs().max().clamp_min(1e-20))
@@ -54,11 +61,11 @@ def test_layernorm_and_geglu(M, C):
 
 @pytest.mark.parametrize("B,Hh,Nq,Nk,d", [(2, 8, 4096, 4096, 40), (2, 8, 1024, 77, 80), (2, 8, 256, 256, 160), (1, 8, 64, 64, 160),
                                           (2, 4, 200, 77, 40), (1, 2, 130, 33, 16), (2, 8, 256, 77, 160)])
-def test_flash_attention(B, Hh, Nq, Nk, d):
+def test_flash_attention(B, Hh, Nq, Nk, d, half):
     from dreamwaltz_g_amd import nn_ops
     g = torch.Generator().manual_seed(Nq + Nk + d)
-    q = torch.randn(B, Nq, Hh * d, generator=g).bfloat16(); k = torch.randn(B, Nk, Hh * d, generator=g).bfloat16()
-    v = torch.randn(B, Nk, Hh * d, generator=g).bfloat16()
+    q = torch.randn(B, Nq, Hh * d, generator=g).to(half); k = torch.randn(B, Nk, Hh * d, generator=g).to(half)
+    v = torch.randn(B, Nk, Hh * d, generator=g).to(half)
     if Nq == 256 and Nk == 256:
         k[:, 5] *= 6.0   # a spiky key: forces large running-max jumps in the online softmax
     sp = lambda t, n: t.double().view(B, n, Hh, d).permute(0, 2, 1, 3)  # noqa: E731
@@ -67,13 +74,13 @@ def test_flash_attention(B, Hh, Nq, Nk, d):
     assert _err(o, ref) < 2e-2, _err(o, ref)
 
 
-def test_flash_attention_on_fused_qkv_slices():
+def test_flash_attention_on_fused_qkv_slices(half):
     """q/k/v as column slices of one [B, N, 3C] projection output (strided rows, no copies)."""
     from dreamwaltz_g_amd import nn_ops
     g = torch.Generator().manual_seed(0)
     B, N, Hh, d = 2, 512, 8, 40
     C = Hh * d
-    qkv = torch.randn(B, N, 3 * C, generator=g).bfloat16()
+    qkv = torch.randn(B, N, 3 * C, generator=g).to(half)
     sp = lambda t: t.double().view(B, N, Hh, d).permute(0, 2, 1, 3)  # noqa: E731
     ref = F.scaled_dot_product_attention(sp(qkv[..., :C]), sp(qkv[..., C:2 * C]), sp(qkv[..., 2 * C:]))
     ref = ref.permute(0, 2, 1, 3).reshape(B, N, C)

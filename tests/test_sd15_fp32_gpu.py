@@ -53,12 +53,11 @@ def _block_plan(sd, dtype="f32"):
     return plan, w, sd15.Builder(plan, w, 32, "t")
 
 
-def test_fp16_plans_are_refused_loudly():
+def test_unknown_plan_dtypes_are_refused_loudly():
     from dreamwaltz_g_amd import sd15
-    with pytest.raises(NotImplementedError):
-        sd15.Plan(torch.device("cuda"), "f16")
     with pytest.raises(ValueError):
         sd15.Plan(torch.device("cuda"), "int8")
+    assert sd15.Plan(torch.device("cuda"), "fp16").dtype == torch.float16        # tests/test_sd15_fp16_gpu.py
 
 
 @pytest.mark.parametrize("cin,cout,hw", [(1280, 1280, 8), (640, 320, 64), (2560, 1280, 16)])
