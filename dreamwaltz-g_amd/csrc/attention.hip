@@ -14,6 +14,7 @@
 //     (two 8-byte reads per fragment) instead of shuffling P between lanes.
 //   * per-query rescale of O is a per-lane scalar multiply (each lane owns one query column of O^T).
 #include "dwg_common.h"
+#include <cstdlib>
 #include "dwg_prof_internal.h"
 #include "../../include/dwg_nn.h"
 
@@ -41,9 +42,14 @@ struct AttnP {
     float scale_log2;                      // softmax scale * log2(e)
 };
 
-// DK = head dim padded to a multiple of 16 (contraction of QK^T), DV = padded to a multiple of 32 (rows of O^T)
-template <int DK, int DV>
-__global__ __launch_bounds__(256) void k_flash_fwd(AttnP p) {
+// DK = head dim padded to a multiple of 16 (contraction of QK^T), DV = padded to a multiple of 32 (rows of O^T).
+// LD > 0: the head dim is exactly LD < DV, and the padding row LD of V^T holds ONES: the PV MFMA (which multiplies the padding rows anyway)
+// then accumulates the softmax denominator l = sum_k P[q][k] in accumulator row LD -- rescaled with O for free -- and the 16 adds + the
+// cross-half exchange of the row sum leave the VALU-bound softmax segment.  (l sums the bf16-rounded P the MFMA uses, not the fp32 one.)
+template <int DK, int DV, int LD = 0>
+__global__ __launch_bounds__(256, 2) void k_flash_fwd(AttnP p) {   // 2 waves per SIMD = at most 256 registers: the compiler then keeps the O accumulators in
+                                                                       // arch VGPRs (MFMA VGPR form).  With 512 allowed it parks them in AGPRs and moves all of them out and back
+                                                                       // around the conditional rescale EVERY tile (112 v_accvgpr copies of 352 loop instructions at d = 40)
     constexpr int KT = 32;                 // keys per tile
     constexpr int LDK = DK + 8;            // K tile row stride (bf16), 16-byte aligned rows
     constexpr int LDV = KT + 8;            // V^T tile row stride
@@ -87,6 +93,7 @@ __global__ __launch_bounds__(256) void k_flash_fwd(AttnP p) {
     bf16x8 kreg[NKC], vreg[NVC];
     // per-thread staging coordinates are tile-invariant: (key, dc) and the matching global / LDS addresses are computed once
     int kkey[NKC], vkey[NVC];
+    bool vone[NVC];
     const HT* kptr[NKC]; const HT* vptr[NVC];
     HT* klds[NKC]; HT* vlds[NVC];
 #pragma unroll
@@ -104,19 +111,20 @@ __global__ __launch_bounds__(256) void k_flash_fwd(AttnP p) {
         const int key = c % KT, dc = (c / KT) * 8;            // consecutive threads -> consecutive keys: conflict-light transposed writes
         const bool on = c < KT * (DV / 8) && dc < p.d;
         vkey[i] = on ? key : (1 << 30);
+        vone[i] = LD > 0 && c < KT * (DV / 8) && dc == LD;      // the chunk whose first element is row LD of V^T
         vptr[i] = V + (long long)key * p.ldv + dc;
         vlds[i] = c < KT * (DV / 8) ? &sVt[dc * LDV + key] : nullptr;
     }
     auto fetch = [&](int k0) {
-        bf16x8 z;
+        bf16x8 z, one0;
 #pragma unroll
-        for (int e = 0; e < 8; e++) z[e] = (HT)0.f;
+        for (int e = 0; e < 8; e++) { z[e] = (HT)0.f; one0[e] = (HT)(e == 0 ? 1.f : 0.f); }
 #pragma unroll
         for (int i = 0; i < NKC; i++)
             kreg[i] = (long long)k0 + kkey[i] < p.Nk ? *reinterpret_cast<const bf16x8*>(kptr[i] + (long long)k0 * p.ldk) : z;
 #pragma unroll
         for (int i = 0; i < NVC; i++)
-            vreg[i] = (long long)k0 + vkey[i] < p.Nk ? *reinterpret_cast<const bf16x8*>(vptr[i] + (long long)k0 * p.ldv) : z;
+            vreg[i] = (long long)k0 + vkey[i] < p.Nk ? *reinterpret_cast<const bf16x8*>(vptr[i] + (long long)k0 * p.ldv) : (vone[i] ? one0 : z);
     };
     if (ntiles > 0) fetch(0);
     for (int t = 0; t < ntiles; t++) {
@@ -161,8 +169,11 @@ __global__ __launch_bounds__(256) void k_flash_fwd(AttnP p) {
         const float m_new = fmaxf(m_run, mx * p.scale_log2);
         float rs = 0.f;
 #pragma unroll
-        for (int r = 0; r < 16; r++) { s[r] = __builtin_amdgcn_exp2f(fmaf(s[r], p.scale_log2, -m_new)); rs += s[r]; }   // raw v_exp_f32: arguments <= 0, underflow -> 0
-        rs += __shfl_xor(rs, 32);
+        for (int r = 0; r < 16; r++) {
+            s[r] = __builtin_amdgcn_exp2f(fmaf(s[r], p.scale_log2, -m_new));   // raw v_exp_f32: arguments <= 0, underflow -> 0
+            if constexpr (LD == 0) rs += s[r];
+        }
+        if constexpr (LD == 0) rs += __shfl_xor(rs, 32);
         if (__any(m_new != m_run)) {
             const float alpha = __builtin_amdgcn_exp2f(m_run - m_new);
             l_run *= alpha;
@@ -199,6 +210,11 @@ __global__ __launch_bounds__(256) void k_flash_fwd(AttnP p) {
     // Stage through LDS so that rows go out as contiguous 16-byte stores.
     constexpr int LDO = DV + 8;
     __shared__ __attribute__((aligned(16))) HT sOut[4 * 32 * LDO];
+    if constexpr (LD > 0) {
+        // accumulator row LD: block LD / 32, register r with (r&3) + 8 (r>>2) + 4 half == LD % 32, held by the lanes of that half
+        constexpr int W = LD % 32, R = (W & 3) + 4 * (W >> 3), HL = (W >> 2) & 1;
+        l_run = __shfl(acc[LD / 32][R], ql + 32 * HL);
+    }
     const float inv = l_run > 0.f ? 1.f / l_run : 0.f;
     HT* myO = sOut + wave * 32 * LDO;
 #pragma unroll
@@ -250,11 +266,14 @@ int dwg_attention_forward(int32_t B, int32_t H, int32_t Nq, int32_t Nk, int32_t 
     hipStream_t stream = (hipStream_t)stream_;
     // algorithmic flops of the launch (QK^T and PV on the logical head size; the padded tile columns are not counted)
     const double flops = 4.0 * B * H * (double)Nq * Nk * d;
-    if (d <= 32) DWG_LAUNCH_W("flash_attn_d32", "k_flash_fwd<32, 32>", flops, (k_flash_fwd<32, 32>), grid, block, 0, stream, p);
-    else if (d <= 48) DWG_LAUNCH_W("flash_attn_d48", "k_flash_fwd<48, 64>", flops, (k_flash_fwd<48, 64>), grid, block, 0, stream, p);
-    else if (d <= 64) DWG_LAUNCH_W("flash_attn_d64", "k_flash_fwd<64, 64>", flops, (k_flash_fwd<64, 64>), grid, block, 0, stream, p);
-    else if (d <= 96) DWG_LAUNCH_W("flash_attn_d96", "k_flash_fwd<96, 96>", flops, (k_flash_fwd<96, 96>), grid, block, 0, stream, p);
-    else DWG_LAUNCH_W("flash_attn_d160", "k_flash_fwd<160, 160>", flops, (k_flash_fwd<160, 160>), grid, block, 0, stream, p);
+    static const bool no_lrow = getenv("DWG_ATTN_NO_LROW") != nullptr;       // A/B switch: softmax denominator summed on the VALU
+    if (d <= 32) DWG_LAUNCH_W("flash_attn_d32", "k_flash_fwd<32, 32, 0>", flops, (k_flash_fwd<32, 32>), grid, block, 0, stream, p);
+    else if (d == 40 && !no_lrow) DWG_LAUNCH_W("flash_attn_d48", "k_flash_fwd<48, 64, 40>", flops, (k_flash_fwd<48, 64, 40>), grid, block, 0, stream, p);
+    else if (d <= 48) DWG_LAUNCH_W("flash_attn_d48", "k_flash_fwd<48, 64, 0>", flops, (k_flash_fwd<48, 64>), grid, block, 0, stream, p);
+    else if (d <= 64) DWG_LAUNCH_W("flash_attn_d64", "k_flash_fwd<64, 64, 0>", flops, (k_flash_fwd<64, 64>), grid, block, 0, stream, p);
+    else if (d == 80 && !no_lrow) DWG_LAUNCH_W("flash_attn_d96", "k_flash_fwd<96, 96, 80>", flops, (k_flash_fwd<96, 96, 80>), grid, block, 0, stream, p);
+    else if (d <= 96) DWG_LAUNCH_W("flash_attn_d96", "k_flash_fwd<96, 96, 0>", flops, (k_flash_fwd<96, 96>), grid, block, 0, stream, p);
+    else DWG_LAUNCH_W("flash_attn_d160", "k_flash_fwd<160, 160, 0>", flops, (k_flash_fwd<160, 160>), grid, block, 0, stream, p);
     DWG_RETURN_IF_LAUNCH_FAILED();
     return DWG_OK;
 }

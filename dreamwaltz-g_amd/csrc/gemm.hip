@@ -53,6 +53,7 @@ struct GemmP {
     int act; float alpha;
     int out_bf16, res_bf16, bias_per_row, splitk, accumulate;
     float* ws;          // split-K slab workspace [splitk][M][N] (nullptr: atomicAdd into C)
+    int dbg;            // DWG_GEMM_DEBUG (timing experiments, results are garbage): 1 = k_gemm_glds skips LDS reads + MFMAs, 2 = skips the tile loads
     int bias_row_div;   // > 0: bias index = (row / bias_row_div) * bias_ld + col  (per-image channel bias: conv bias + time embedding)
     long long bias_ld;
     ConvP conv;
@@ -322,35 +323,68 @@ __device__ __forceinline__ void epilogue_store4(const GemmP& p, float (&v)[4], i
     }
 }
 
-template <int TM, int TN>
-__device__ __forceinline__ void tile_epilogue_t(const GemmP& p, f32x16 (&acc)[TM][TN], int m0, int n0, int wm, int wn, int lane,
-                                                int ks_id, int z1, int z2) {
-    const long long coff = z1 * p.bC1 + z2 * p.bC2, roff = z1 * p.bR1 + z2 * p.bR2;
+// ---------------------------------------------------------------------------------------------------------------------
+// Compact epilogue.  The accumulator tile goes registers -> LDS (the operand stages are dead by then) in two 64-row passes, and ONE rolled
+// loop -- a single copy of every run-time variant: slab / atomic split-K, GEGLU pair, bias forms, activation, residual, output type --
+// takes float4 pieces back out row-major, so that 16 consecutive threads write one contiguous 128- / 256-byte row segment.
+// Why: with the variants inside the fully unrolled (tile, register-group) loops every kernel of this file carried 15 000 - 36 000 static
+// instructions in ~1 600 - 3 200 basic blocks (120 - 290 KB of code against a 64 KB instruction cache) around a 70 - 115 instruction main
+// loop: a ONE-k-step, ONE-workgroup launch took 6.7 us inside a captured graph against 1.5 us for an empty kernel, i.e. ~5 us of
+// instruction fetch per launch on ~470 launches per SDS step (tools/shape_sweep.py PROBE=1, DESIGN.md "what bounds the small GEMMs").
+// ---------------------------------------------------------------------------------------------------------------------
+template <int BN> struct EpiLds { static constexpr int LDC = BN + 4, FLOATS = 64 * LDC; };   // row stride 4 (mod 32) banks: conflict-free b128 rows
+
+// RowFn: tile-local row (0..127) -> global output row, or -1 (outside the problem)
+template <int BN, int TM, int TN, bool LIGHT, typename RowFn>
+__device__ __forceinline__ void tile_epilogue_lds(const GemmP& p, f32x16 (&acc)[TM][TN], float* sC, int n0, int wm, int wn, int lane, int tid,
+                                                  int ks_id, long long coff, long long roff, RowFn row_of) {
+    constexpr int LDC = EpiLds<BN>::LDC, C4 = BN / 4;
     const bool vec_ok = epilogue_vec_ok(p, coff, roff);
     const int lrow = lane & 31, lhalf = (lane >> 5) * 4;
-    if (p.act == 6) {
-        // GEGLU pair epilogue (diffusers GEGLU: hidden, gate = proj(x).chunk(2); hidden * gelu(gate)).  The projection rows are
-        // pre-interleaved in blocks of 32 so that accumulator tile j=0 holds `hidden` and j=1 the matching `gate` columns: the
-        // product is formed in registers and only the half-width result is stored (no [M, 8C] round trip).  N % 64 == 0.
-        const float* bias = reinterpret_cast<const float*>(p.bias);
+    const bool geglu = p.act == 6;
+    const float* bias = reinterpret_cast<const float*>(p.bias);
+    const bool fast = vec_ok && !geglu && !p.accumulate && !p.bias_per_row && (p.splitk <= 1 || p.ws) &&
+                      (!bias || p.bias_row_div > 0 || ((uintptr_t)bias & 15) == 0) &&
+                      (!bias || p.bias_row_div <= 0 || (((uintptr_t)bias & 15) == 0 && (p.bias_ld & 3) == 0)) &&
+                      (p.splitk <= 1 || ((uintptr_t)p.ws & 15) == 0);
+#pragma unroll 1
+    for (int q = 0; q < 2; q++) {                       // rows [64 q, 64 q + 64) of the tile
+        __syncthreads();                                // operand tiles (q = 0) / the previous pass (q = 1) are no longer being read
 #pragma unroll
         for (int i = 0; i < TM; i++) {
-            const int row = m0 + (wm * TM + i) * 32 + lrow;
-            if (row >= p.M) continue;
+            const int rb = wm * TM + i;                 // 32-row block of this wave (wave-uniform)
+            if ((rb >> 1) != q) continue;
+            float* dst = sC + ((rb & 1) * 32 + lrow) * LDC + wn * 64 + lhalf;
 #pragma unroll
-            for (int r4 = 0; r4 < 4; r4++) {
-                const int cl = 8 * r4 + lhalf;
-                const int colp = n0 + wn * 64 + cl;
-                if (colp + 35 >= p.N) continue;
-                const int ocol = (n0 + wn * 64) / 2 + cl;
+            for (int j = 0; j < TN; j++)
+#pragma unroll
+                for (int r4 = 0; r4 < 4; r4++)
+                    *reinterpret_cast<float4*>(dst + j * 32 + 8 * r4) =
+                        make_float4(acc[i][j][4 * r4], acc[i][j][4 * r4 + 1], acc[i][j][4 * r4 + 2], acc[i][j][4 * r4 + 3]);
+        }
+        __syncthreads();
+        if (geglu) {
+            // GEGLU pair (diffusers GEGLU: hidden, gate = proj(x).chunk(2); hidden * gelu(gate)).  The projection rows are pre-interleaved in
+            // blocks of 32, so columns [64 b, 64 b + 32) of the tile hold `hidden` and [64 b + 32, 64 b + 64) the matching `gate`: the product
+            // is formed here and only the half-width result is stored (no [M, 8C] round trip).  N % 64 == 0.
+#pragma unroll 1
+            for (int idx = tid; idx < 64 * (C4 / 2); idx += 256) {
+                const int rl = idx / (C4 / 2), o4 = idx - rl * (C4 / 2);      // o4: group of four output columns of the half-width tile
+                const int row = row_of(q * 64 + rl);
+                const int b = o4 >> 3, w = (o4 & 7) * 4;
+                const int colp = n0 + b * 64 + w;
+                if (row < 0 || colp + 35 >= p.N) continue;
+                const float4 h = *reinterpret_cast<const float4*>(sC + rl * LDC + b * 64 + w);
+                const float4 g = *reinterpret_cast<const float4*>(sC + rl * LDC + b * 64 + 32 + w);
+                const float hv[4] = {h.x, h.y, h.z, h.w}, gv[4] = {g.x, g.y, g.z, g.w};
                 float v[4];
 #pragma unroll
                 for (int e = 0; e < 4; e++) {
-                    const float a = acc[i][0][4 * r4 + e] * p.alpha + (bias ? bias[colp + e] : 0.f);
-                    const float g = acc[i][1][4 * r4 + e] * p.alpha + (bias ? bias[colp + 32 + e] : 0.f);
-                    v[e] = a * 0.5f * g * (1.f + dwg_erf_fast(g * 0.70710678118654752f));
+                    const float a = hv[e] * p.alpha + (bias ? bias[colp + e] : 0.f);
+                    const float gg = gv[e] * p.alpha + (bias ? bias[colp + 32 + e] : 0.f);
+                    v[e] = a * 0.5f * gg * (1.f + dwg_erf_fast(gg * 0.70710678118654752f));
                 }
-                const long long ci = coff + (long long)row * p.ldc + ocol;
+                const long long ci = coff + (long long)row * p.ldc + (n0 + b * 64) / 2 + w;
                 if (p.out_bf16) {
                     if (((p.ldc | coff) & 3) == 0 && ((uintptr_t)p.C & 7) == 0) {
                         bf16x4_t o;
@@ -366,39 +400,91 @@ __device__ __forceinline__ void tile_epilogue_t(const GemmP& p, f32x16 (&acc)[TM
                     for (int e = 0; e < 4; e++) reinterpret_cast<float*>(p.C)[ci + e] = v[e];
                 }
             }
+            continue;
         }
-        return;
-    }
-#pragma unroll
-    for (int i = 0; i < TM; i++) {
-        const int row = m0 + (wm * TM + i) * 32 + lrow;
-        if (row >= p.M) continue;
-#pragma unroll
-        for (int j = 0; j < TN; j++)
-#pragma unroll
-            for (int r4 = 0; r4 < 4; r4++) {
-                const int col = n0 + wn * 64 + j * 32 + 8 * r4 + lhalf;
-                if (col >= p.N) continue;
-                float v[4];
-#pragma unroll
-                for (int e = 0; e < 4; e++) v[e] = acc[i][j][4 * r4 + e] * p.alpha;
-                if (p.splitk > 1) {
-                    if (p.ws) {                              // slab, reduced by k_splitk_epilogue
-                        float* dst = p.ws + ((long long)ks_id * p.M + row) * p.N + col;
-                        if ((p.N & 3) == 0) *reinterpret_cast<float4*>(dst) = make_float4(v[0], v[1], v[2], v[3]);
-                        else {
-#pragma unroll
-                            for (int e = 0; e < 4; e++) if (col + e < p.N) dst[e] = v[e];
-                        }
-                    } else {
-#pragma unroll
-                        for (int e = 0; e < 4; e++)
-                            if (col + e < p.N) atomicAdd(reinterpret_cast<float*>(p.C) + coff + (long long)row * p.ldc + col + e, v[e]);
+        if (fast) {
+            // The common layers: 16-byte pieces everywhere, N % 4 == 0, plain / slab store.  A thread keeps ONE column group for the whole
+            // tile (256 % C4 == 0), so the column bounds test, the per-column bias and every column offset are loop invariants and a piece
+            // costs ~20-45 VALU instructions instead of the ~190 of the general loop below.  This matters: with one or two waves per SIMD the
+            // prologue + epilogue instruction stream (4 cycles per wave64 VALU instruction) IS the launch time of the 5-20-k-step layers.
+            constexpr int RSTEP = 256 / C4;
+            const int c4 = tid & (C4 - 1), rl0 = tid / C4;
+            const int col = n0 + c4 * 4;
+            if (col < p.N) {
+                const bool col_bias = bias && p.bias_row_div <= 0;
+                float4 bc = make_float4(0.f, 0.f, 0.f, 0.f);
+                if (col_bias) bc = *reinterpret_cast<const float4*>(bias + col);
+                const bool slab = p.splitk > 1;
+#pragma unroll 2
+                for (int rl = rl0; rl < 64; rl += RSTEP) {
+                    const int row = row_of(q * 64 + rl);
+                    if (row < 0) continue;
+                    const float4 a = *reinterpret_cast<const float4*>(sC + rl * LDC + c4 * 4);
+                    float v[4] = {a.x * p.alpha, a.y * p.alpha, a.z * p.alpha, a.w * p.alpha};
+                    if (slab) {
+                        *reinterpret_cast<float4*>(p.ws + ((long long)ks_id * p.M + row) * p.N + col) = make_float4(v[0], v[1], v[2], v[3]);
+                        continue;
                     }
-                    continue;
+                    if (col_bias) { v[0] += bc.x; v[1] += bc.y; v[2] += bc.z; v[3] += bc.w; }
+                    else if (bias) {
+                        const float4 b = *reinterpret_cast<const float4*>(bias + (long long)(row / p.bias_row_div) * p.bias_ld + col);
+                        v[0] += b.x; v[1] += b.y; v[2] += b.z; v[3] += b.w;
+                    }
+                    if (p.act == 3) {
+#pragma unroll
+                        for (int e = 0; e < 4; e++) v[e] = v[e] / (1.f + __expf(-v[e]));
+                    } else if (p.act != 0) {
+#pragma unroll
+                        for (int e = 0; e < 4; e++) v[e] = apply_act<LIGHT>(v[e], p.act);
+                    }
+                    if (p.residual) {
+                        const long long ri = roff + (long long)row * p.ldr + col;
+                        if (p.res_bf16) {
+                            const bf16x4_t r = *reinterpret_cast<const bf16x4_t*>(reinterpret_cast<const HT*>(p.residual) + ri);
+#pragma unroll
+                            for (int e = 0; e < 4; e++) v[e] += bf2f(r.v[e]);
+                        } else {
+                            const float4 r = *reinterpret_cast<const float4*>(reinterpret_cast<const float*>(p.residual) + ri);
+                            v[0] += r.x; v[1] += r.y; v[2] += r.z; v[3] += r.w;
+                        }
+                    }
+                    const long long ci = coff + (long long)row * p.ldc + col;
+                    if (p.out_bf16) {
+                        bf16x4_t o;
+#pragma unroll
+                        for (int e = 0; e < 4; e++) o.v[e] = f2bf(v[e]);
+                        *reinterpret_cast<bf16x4_t*>(reinterpret_cast<HT*>(p.C) + ci) = o;
+                    } else {
+                        *reinterpret_cast<float4*>(reinterpret_cast<float*>(p.C) + ci) = make_float4(v[0], v[1], v[2], v[3]);
+                    }
                 }
-                epilogue_store4(p, v, row, col, coff, roff, vec_ok);
             }
+            continue;
+        }
+#pragma unroll 1
+        for (int idx = tid; idx < 64 * C4; idx += 256) {
+            const int rl = idx / C4, c4 = idx - rl * C4;
+            const int row = row_of(q * 64 + rl), col = n0 + c4 * 4;
+            if (row < 0 || col >= p.N) continue;
+            const float4 a = *reinterpret_cast<const float4*>(sC + rl * LDC + c4 * 4);
+            float v[4] = {a.x * p.alpha, a.y * p.alpha, a.z * p.alpha, a.w * p.alpha};
+            if (p.splitk > 1) {
+                if (p.ws) {                              // slab, reduced by k_splitk_epilogue
+                    float* dst = p.ws + ((long long)ks_id * p.M + row) * p.N + col;
+                    if ((p.N & 3) == 0) *reinterpret_cast<float4*>(dst) = make_float4(v[0], v[1], v[2], v[3]);
+                    else {
+#pragma unroll
+                        for (int e = 0; e < 4; e++) if (col + e < p.N) dst[e] = v[e];
+                    }
+                } else {
+#pragma unroll
+                    for (int e = 0; e < 4; e++)
+                        if (col + e < p.N) atomicAdd(reinterpret_cast<float*>(p.C) + coff + (long long)row * p.ldc + col + e, v[e]);
+                }
+                continue;
+            }
+            epilogue_store4<LIGHT>(p, v, row, col, coff, roff, vec_ok);
+        }
     }
 }
 
@@ -489,7 +575,9 @@ __global__ __launch_bounds__(256) void k_gemm(GemmP p) {
         if (kt + 1 < nk) { la.store(sA + (cur ^ 1) * BM * LDT); lb.store(sB + (cur ^ 1) * BN * LDT); }
         __syncthreads();
     }
-    tile_epilogue_t<TM, TN>(p, acc, m0, n0, wm, wn, lane, ks_id, z1, z2);
+    static_assert((size_t)2 * (BM + BN) * LDT * sizeof(T) >= (size_t)EpiLds<BN>::FLOATS * 4, "epilogue staging fits in the operand stages");
+    tile_epilogue_lds<BN, TM, TN, false>(p, acc, reinterpret_cast<float*>(smem_raw), n0, wm, wn, lane, tid, ks_id, z1 * p.bC1 + z2 * p.bC2,
+                                         z1 * p.bR1 + z2 * p.bR2, [&](int rl) { const int r = m0 + rl; return r < p.M ? r : -1; });
 }
 
 // ---------------------------------------------------------------------------------------------------------------------
@@ -718,8 +806,9 @@ __global__ __launch_bounds__(256) void k_gemm_glds(GemmP p) {
     for (int kt = 0; kt < nk; kt++) {
         wait_vmcnt<(S - 2) * LPT>();        // this thread's loads of tile kt have landed ...
         __builtin_amdgcn_s_barrier();       // ... and everybody's; everybody is also done reading the buffer refilled next
-        la.issue(smem_raw + nxt * STAGE, p.conv); lb.issue(smem_raw + nxt * STAGE + ABYTES, p.conv);
+        if (p.dbg != 2) { la.issue(smem_raw + nxt * STAGE, p.conv); lb.issue(smem_raw + nxt * STAGE + ABYTES, p.conv); }
         la.advance(p.conv); lb.advance(p.conv);
+        if (p.dbg == 1) { cur = cur + 1 == S ? 0 : cur + 1; nxt = nxt + 1 == S ? 0 : nxt + 1; continue; }
         const unsigned char* ta = smem_raw + cur * STAGE + (wm * TM * 32 + frow) * 128;
         const unsigned char* tb = smem_raw + cur * STAGE + ABYTES + (wn * 64 + frow) * 128;
 #pragma unroll
@@ -738,7 +827,9 @@ __global__ __launch_bounds__(256) void k_gemm_glds(GemmP p) {
         cur = cur + 1 == S ? 0 : cur + 1; nxt = nxt + 1 == S ? 0 : nxt + 1;
     }
     wait_vmcnt<0>();                        // drain the zero-line tail loads before LDS is handed back
-    tile_epilogue_t<TM, TN>(p, acc, m0, n0, wm, wn, lane, ks_id, z1, z2);
+    static_assert(S * STAGE >= EpiLds<BN>::FLOATS * 4, "epilogue staging fits in the operand stages");
+    tile_epilogue_lds<BN, TM, TN, false>(p, acc, reinterpret_cast<float*>(smem_raw), n0, wm, wn, lane, tid, ks_id, z1 * p.bC1 + z2 * p.bC2,
+                                         z1 * p.bR1 + z2 * p.bR2, [&](int rl) { const int r = m0 + rl; return r < p.M ? r : -1; });
 }
 
 // Algorithmic flops of one launch for the profiler table: 2*M*N*K, with the zero taps of an input-dilated (strided-conv
@@ -915,35 +1006,12 @@ __global__ __launch_bounds__(256, 2) void k_conv3x3_patch(GemmP p) {   // 2 wave
             }
         }
     }
-    // epilogue (transposed orientation: a lane owns one output pixel and groups of four consecutive channels)
-    const bool vec_ok = epilogue_vec_ok(p, 0, 0);
-#pragma unroll
-    for (int i = 0; i < TM; i++) {
-        const int rr = (wm * TM + i) * 32 + (lane & 31);
+    // epilogue: tile-local row rr <-> output pixel (y0 + rr / 16, x0 + rr % 16) of image img
+    static_assert(2 * PBYTES + 2 * BBYTES >= EpiLds<BN>::FLOATS * 4, "epilogue staging fits in the patch / weight buffers");
+    tile_epilogue_lds<BN, TM, TN, !SPLIT>(p, acc, reinterpret_cast<float*>(smem_raw), n0, wm, wn, lane, tid, ks_id, 0, 0, [&](int rr) {
         const int y = y0 + (rr >> 4), x = x0 + (rr & 15);
-        if (y >= cv.Hout || x >= cv.Wout) continue;
-        const int m = (img * cv.Hout + y) * cv.Wout + x;
-#pragma unroll
-        for (int j = 0; j < TN; j++)
-#pragma unroll
-            for (int r4 = 0; r4 < 4; r4++) {
-                const int col = n0 + wn * 64 + j * 32 + 8 * r4 + (lane >> 5) * 4;
-                if (col >= p.N) continue;
-                float v[4];
-#pragma unroll
-                for (int e = 0; e < 4; e++) v[e] = acc[i][j][4 * r4 + e] * p.alpha;
-                if constexpr (SPLIT) {                       // fp32 slab, reduced in slice order by k_splitk_epilogue
-                    float* dst = p.ws + ((long long)ks_id * p.M + m) * p.N + col;
-                    if ((p.N & 3) == 0) *reinterpret_cast<float4*>(dst) = make_float4(v[0], v[1], v[2], v[3]);
-                    else {
-#pragma unroll
-                        for (int e = 0; e < 4; e++) if (col + e < p.N) dst[e] = v[e];
-                    }
-                    continue;
-                }
-                epilogue_store4<true>(p, v, m, col, 0, 0, vec_ok);
-            }
-    }
+        return (y < cv.Hout && x < cv.Wout) ? (img * cv.Hout + y) * cv.Wout + x : -1;
+    });
 }
 
 template <int BN>
@@ -1092,6 +1160,8 @@ int DWG_GEMM_FN(const dwg_gemm_desc* d, dwg_stream_t stream_) {
     p.out_bf16 = d->out_dtype == DWG_DTYPE_HALF; p.res_bf16 = d->residual_dtype == DWG_DTYPE_HALF;
     p.bias_per_row = d->bias_per_row; p.splitk = d->splitk > 1 ? d->splitk : 1; p.accumulate = d->accumulate;
     p.ws = nullptr;
+    static const int dbg = getenv("DWG_GEMM_DEBUG") ? atoi(getenv("DWG_GEMM_DEBUG")) : 0;
+    p.dbg = dbg;
     {
         const int bn = tile_bn(d), bk = d->dtype == DWG_DTYPE_HALF ? TT<HT>::BK : TT<float>::BK;
         if (d->workspace && d->batch1 * d->batch2 == 1) {
