@@ -332,13 +332,18 @@ __device__ __forceinline__ void epilogue_store4(const GemmP& p, float (&v)[4], i
 // loop: a ONE-k-step, ONE-workgroup launch took 6.7 us inside a captured graph against 1.5 us for an empty kernel, i.e. ~5 us of
 // instruction fetch per launch on ~470 launches per SDS step (tools/shape_sweep.py PROBE=1, DESIGN.md "what bounds the small GEMMs").
 // ---------------------------------------------------------------------------------------------------------------------
-template <int BN> struct EpiLds { static constexpr int LDC = BN + 4, FLOATS = 64 * LDC; };   // row stride 4 (mod 32) banks: conflict-free b128 rows
+// row stride 4 (mod 32) banks: conflict-free b128 rows.  One pass over all 128 rows when the kernel's operand stages are large enough, else two.
+template <int BN> struct EpiLds {
+    static constexpr int LDC = BN + 4;
+    static constexpr int passes(size_t lds_bytes) { return lds_bytes >= (size_t)128 * LDC * 4 ? 1 : 2; }
+    static constexpr size_t bytes(int npass) { return (size_t)(128 / npass) * LDC * 4; }
+};
 
 // RowFn: tile-local row (0..127) -> global output row, or -1 (outside the problem)
-template <int BN, int TM, int TN, bool LIGHT, typename RowFn>
+template <int BN, int NPASS, int TM, int TN, bool LIGHT, typename RowFn>
 __device__ __forceinline__ void tile_epilogue_lds(const GemmP& p, f32x16 (&acc)[TM][TN], float* sC, int n0, int wm, int wn, int lane, int tid,
                                                   int ks_id, long long coff, long long roff, RowFn row_of) {
-    constexpr int LDC = EpiLds<BN>::LDC, C4 = BN / 4;
+    constexpr int LDC = EpiLds<BN>::LDC, C4 = BN / 4, PR = 128 / NPASS;      // PR rows per pass
     const bool vec_ok = epilogue_vec_ok(p, coff, roff);
     const int lrow = lane & 31, lhalf = (lane >> 5) * 4;
     const bool geglu = p.act == 6;
@@ -348,13 +353,13 @@ __device__ __forceinline__ void tile_epilogue_lds(const GemmP& p, f32x16 (&acc)[
                       (!bias || p.bias_row_div <= 0 || (((uintptr_t)bias & 15) == 0 && (p.bias_ld & 3) == 0)) &&
                       (p.splitk <= 1 || ((uintptr_t)p.ws & 15) == 0);
 #pragma unroll 1
-    for (int q = 0; q < 2; q++) {                       // rows [64 q, 64 q + 64) of the tile
+    for (int q = 0; q < NPASS; q++) {                   // rows [PR q, PR q + PR) of the tile
         __syncthreads();                                // operand tiles (q = 0) / the previous pass (q = 1) are no longer being read
 #pragma unroll
         for (int i = 0; i < TM; i++) {
             const int rb = wm * TM + i;                 // 32-row block of this wave (wave-uniform)
-            if ((rb >> 1) != q) continue;
-            float* dst = sC + ((rb & 1) * 32 + lrow) * LDC + wn * 64 + lhalf;
+            if (NPASS == 2 && (rb >> 1) != q) continue;
+            float* dst = sC + ((NPASS == 2 ? (rb & 1) : rb) * 32 + lrow) * LDC + wn * 64 + lhalf;
 #pragma unroll
             for (int j = 0; j < TN; j++)
 #pragma unroll
@@ -367,37 +372,47 @@ __device__ __forceinline__ void tile_epilogue_lds(const GemmP& p, f32x16 (&acc)[
             // GEGLU pair (diffusers GEGLU: hidden, gate = proj(x).chunk(2); hidden * gelu(gate)).  The projection rows are pre-interleaved in
             // blocks of 32, so columns [64 b, 64 b + 32) of the tile hold `hidden` and [64 b + 32, 64 b + 64) the matching `gate`: the product
             // is formed here and only the half-width result is stored (no [M, 8C] round trip).  N % 64 == 0.
-#pragma unroll 1
-            for (int idx = tid; idx < 64 * (C4 / 2); idx += 256) {
-                const int rl = idx / (C4 / 2), o4 = idx - rl * (C4 / 2);      // o4: group of four output columns of the half-width tile
-                const int row = row_of(q * 64 + rl);
-                const int b = o4 >> 3, w = (o4 & 7) * 4;
-                const int colp = n0 + b * 64 + w;
-                if (row < 0 || colp + 35 >= p.N) continue;
-                const float4 h = *reinterpret_cast<const float4*>(sC + rl * LDC + b * 64 + w);
-                const float4 g = *reinterpret_cast<const float4*>(sC + rl * LDC + b * 64 + 32 + w);
-                const float hv[4] = {h.x, h.y, h.z, h.w}, gv[4] = {g.x, g.y, g.z, g.w};
-                float v[4];
+            // a thread keeps ONE group of four output columns for the whole tile: the eight bias values and the column tests are loop invariants
+            constexpr int G = C4 / 2, RSTEP = 256 / G;
+            const int o4 = tid & (G - 1), rl0 = tid / G;
+            const int b = o4 >> 3, w = (o4 & 7) * 4;
+            const int colp = n0 + b * 64 + w;
+            if (colp + 35 < p.N) {
+                float bh[4] = {0.f, 0.f, 0.f, 0.f}, bg[4] = {0.f, 0.f, 0.f, 0.f};
+                if (bias) {
 #pragma unroll
-                for (int e = 0; e < 4; e++) {
-                    const float a = hv[e] * p.alpha + (bias ? bias[colp + e] : 0.f);
-                    const float gg = gv[e] * p.alpha + (bias ? bias[colp + 32 + e] : 0.f);
-                    v[e] = a * 0.5f * gg * (1.f + dwg_erf_fast(gg * 0.70710678118654752f));
+                    for (int e = 0; e < 4; e++) { bh[e] = bias[colp + e]; bg[e] = bias[colp + 32 + e]; }
                 }
-                const long long ci = coff + (long long)row * p.ldc + (n0 + b * 64) / 2 + w;
-                if (p.out_bf16) {
-                    if (((p.ldc | coff) & 3) == 0 && ((uintptr_t)p.C & 7) == 0) {
-                        bf16x4_t o;
+                const bool vec_store = ((p.ldc | coff) & 3) == 0 && ((uintptr_t)p.C & 7) == 0;
+#pragma unroll 2
+                for (int rl = rl0; rl < PR; rl += RSTEP) {
+                    const int row = row_of(q * PR + rl);
+                    if (row < 0) continue;
+                    const float4 h = *reinterpret_cast<const float4*>(sC + rl * LDC + b * 64 + w);
+                    const float4 g = *reinterpret_cast<const float4*>(sC + rl * LDC + b * 64 + 32 + w);
+                    const float hv[4] = {h.x, h.y, h.z, h.w}, gv[4] = {g.x, g.y, g.z, g.w};
+                    float v[4];
 #pragma unroll
-                        for (int e = 0; e < 4; e++) o.v[e] = f2bf(v[e]);
-                        *reinterpret_cast<bf16x4_t*>(reinterpret_cast<HT*>(p.C) + ci) = o;
+                    for (int e = 0; e < 4; e++) {
+                        const float a = fmaf(hv[e], p.alpha, bh[e]);
+                        const float gg = fmaf(gv[e], p.alpha, bg[e]);
+                        v[e] = a * 0.5f * gg * (1.f + dwg_erf_fast(gg * 0.70710678118654752f));
+                    }
+                    const long long ci = coff + (long long)row * p.ldc + (n0 + b * 64) / 2 + w;
+                    if (p.out_bf16) {
+                        if (vec_store) {
+                            bf16x4_t o;
+#pragma unroll
+                            for (int e = 0; e < 4; e++) o.v[e] = f2bf(v[e]);
+                            *reinterpret_cast<bf16x4_t*>(reinterpret_cast<HT*>(p.C) + ci) = o;
+                        } else {
+#pragma unroll
+                            for (int e = 0; e < 4; e++) reinterpret_cast<HT*>(p.C)[ci + e] = f2bf(v[e]);
+                        }
                     } else {
 #pragma unroll
-                        for (int e = 0; e < 4; e++) reinterpret_cast<HT*>(p.C)[ci + e] = f2bf(v[e]);
+                        for (int e = 0; e < 4; e++) reinterpret_cast<float*>(p.C)[ci + e] = v[e];
                     }
-                } else {
-#pragma unroll
-                    for (int e = 0; e < 4; e++) reinterpret_cast<float*>(p.C)[ci + e] = v[e];
                 }
             }
             continue;
@@ -416,8 +431,8 @@ __device__ __forceinline__ void tile_epilogue_lds(const GemmP& p, f32x16 (&acc)[
                 if (col_bias) bc = *reinterpret_cast<const float4*>(bias + col);
                 const bool slab = p.splitk > 1;
 #pragma unroll 2
-                for (int rl = rl0; rl < 64; rl += RSTEP) {
-                    const int row = row_of(q * 64 + rl);
+                for (int rl = rl0; rl < PR; rl += RSTEP) {
+                    const int row = row_of(q * PR + rl);
                     if (row < 0) continue;
                     const float4 a = *reinterpret_cast<const float4*>(sC + rl * LDC + c4 * 4);
                     float v[4] = {a.x * p.alpha, a.y * p.alpha, a.z * p.alpha, a.w * p.alpha};
@@ -462,9 +477,9 @@ __device__ __forceinline__ void tile_epilogue_lds(const GemmP& p, f32x16 (&acc)[
             continue;
         }
 #pragma unroll 1
-        for (int idx = tid; idx < 64 * C4; idx += 256) {
+        for (int idx = tid; idx < PR * C4; idx += 256) {
             const int rl = idx / C4, c4 = idx - rl * C4;
-            const int row = row_of(q * 64 + rl), col = n0 + c4 * 4;
+            const int row = row_of(q * PR + rl), col = n0 + c4 * 4;
             if (row < 0 || col >= p.N) continue;
             const float4 a = *reinterpret_cast<const float4*>(sC + rl * LDC + c4 * 4);
             float v[4] = {a.x * p.alpha, a.y * p.alpha, a.z * p.alpha, a.w * p.alpha};
@@ -575,8 +590,9 @@ __global__ __launch_bounds__(256) void k_gemm(GemmP p) {
         if (kt + 1 < nk) { la.store(sA + (cur ^ 1) * BM * LDT); lb.store(sB + (cur ^ 1) * BN * LDT); }
         __syncthreads();
     }
-    static_assert((size_t)2 * (BM + BN) * LDT * sizeof(T) >= (size_t)EpiLds<BN>::FLOATS * 4, "epilogue staging fits in the operand stages");
-    tile_epilogue_lds<BN, TM, TN, false>(p, acc, reinterpret_cast<float*>(smem_raw), n0, wm, wn, lane, tid, ks_id, z1 * p.bC1 + z2 * p.bC2,
+    constexpr int NPASS = EpiLds<BN>::passes((size_t)2 * (BM + BN) * LDT * sizeof(T));
+    static_assert((size_t)2 * (BM + BN) * LDT * sizeof(T) >= EpiLds<BN>::bytes(NPASS), "epilogue staging fits in the operand stages");
+    tile_epilogue_lds<BN, NPASS, TM, TN, false>(p, acc, reinterpret_cast<float*>(smem_raw), n0, wm, wn, lane, tid, ks_id, z1 * p.bC1 + z2 * p.bC2,
                                          z1 * p.bR1 + z2 * p.bR2, [&](int rl) { const int r = m0 + rl; return r < p.M ? r : -1; });
 }
 
@@ -827,8 +843,9 @@ __global__ __launch_bounds__(256) void k_gemm_glds(GemmP p) {
         cur = cur + 1 == S ? 0 : cur + 1; nxt = nxt + 1 == S ? 0 : nxt + 1;
     }
     wait_vmcnt<0>();                        // drain the zero-line tail loads before LDS is handed back
-    static_assert(S * STAGE >= EpiLds<BN>::FLOATS * 4, "epilogue staging fits in the operand stages");
-    tile_epilogue_lds<BN, TM, TN, false>(p, acc, reinterpret_cast<float*>(smem_raw), n0, wm, wn, lane, tid, ks_id, z1 * p.bC1 + z2 * p.bC2,
+    constexpr int NPASS = EpiLds<BN>::passes((size_t)S * STAGE);
+    static_assert((size_t)S * STAGE >= EpiLds<BN>::bytes(NPASS), "epilogue staging fits in the operand stages");
+    tile_epilogue_lds<BN, NPASS, TM, TN, false>(p, acc, reinterpret_cast<float*>(smem_raw), n0, wm, wn, lane, tid, ks_id, z1 * p.bC1 + z2 * p.bC2,
                                          z1 * p.bR1 + z2 * p.bR2, [&](int rl) { const int r = m0 + rl; return r < p.M ? r : -1; });
 }
 
@@ -1007,8 +1024,9 @@ __global__ __launch_bounds__(256, 2) void k_conv3x3_patch(GemmP p) {   // 2 wave
         }
     }
     // epilogue: tile-local row rr <-> output pixel (y0 + rr / 16, x0 + rr % 16) of image img
-    static_assert(2 * PBYTES + 2 * BBYTES >= EpiLds<BN>::FLOATS * 4, "epilogue staging fits in the patch / weight buffers");
-    tile_epilogue_lds<BN, TM, TN, !SPLIT>(p, acc, reinterpret_cast<float*>(smem_raw), n0, wm, wn, lane, tid, ks_id, 0, 0, [&](int rr) {
+    constexpr int NPASS = EpiLds<BN>::passes((size_t)2 * PBYTES + 2 * BBYTES);
+    static_assert((size_t)2 * PBYTES + 2 * BBYTES >= EpiLds<BN>::bytes(NPASS), "epilogue staging fits in the patch / weight buffers");
+    tile_epilogue_lds<BN, NPASS, TM, TN, !SPLIT>(p, acc, reinterpret_cast<float*>(smem_raw), n0, wm, wn, lane, tid, ks_id, 0, 0, [&](int rr) {
         const int y = y0 + (rr >> 4), x = x0 + (rr & 15);
         return (y < cv.Hout && x < cv.Wout) ? (img * cv.Hout + y) * cv.Wout + x : -1;
     });
