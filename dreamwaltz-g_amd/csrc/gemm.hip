@@ -509,16 +509,19 @@ __global__ __launch_bounds__(256) void k_splitk_epilogue(GemmP p) {
     const long long n = (long long)p.M * p.N;
     if ((p.N & 3) == 0) {
         const bool vec_ok = epilogue_vec_ok(p, 0, 0);
-        const long long n4 = n >> 2;
         const int N4 = p.N >> 2;
+        const long long n4 = n >> 2;
+        // one launch per split-K GEMM and usually ONE piece per thread: the index arithmetic is the kernel -- a 32-bit (row, column group)
+        // division instead of the 64-bit one.
         for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < n4; i += (long long)gridDim.x * 256) {
+            const unsigned iu = (unsigned)i;                        // M * N / 4 < 2^32 for every shape on the path (checked on the host)
+            const int row = (int)(iu / (unsigned)N4), col = (int)(iu - (unsigned)row * (unsigned)N4) * 4;
             const float4* src = reinterpret_cast<const float4*>(p.ws) + i;
             float4 a = src[0];
             for (int sidx = 1; sidx < p.splitk; sidx++) {
                 const float4 u = src[(long long)sidx * n4];
                 a.x += u.x; a.y += u.y; a.z += u.z; a.w += u.w;
             }
-            const int row = (int)(i / N4), col = (int)(i - (long long)row * N4) * 4;
             float v[4] = {a.x, a.y, a.z, a.w};
             epilogue_store4(p, v, row, col, 0, 0, vec_ok);
         }
@@ -1150,6 +1153,7 @@ size_t DWG_GEMM_WS_FN(const dwg_gemm_desc* d) {
     if (d && d->dtype == DWG_DTYPE_F16) return dwg_gemm_workspace_bytes_f16(d);
 #endif
     if (!d || d->batch1 * d->batch2 != 1 || d->M <= 0 || d->N <= 0) return 0;
+    if ((long long)d->M * d->N >= (1LL << 33)) return 0;       // k_splitk_epilogue indexes the float4 pieces of C with 32 bits
     const int bn = tile_bn(d), bk = d->dtype == DWG_DTYPE_HALF ? TT<HT>::BK : TT<float>::BK;
     int sk = d->splitk > 1 ? d->splitk : (d->splitk == 0 && d->act != DWG_ACT_GEGLU_PAIR ? auto_splitk(d->M, d->N, d->K, bn, bk) : 1);
     return sk > 1 ? (size_t)sk * d->M * d->N * sizeof(float) : 0;
@@ -1182,7 +1186,7 @@ int DWG_GEMM_FN(const dwg_gemm_desc* d, dwg_stream_t stream_) {
     p.dbg = dbg;
     {
         const int bn = tile_bn(d), bk = d->dtype == DWG_DTYPE_HALF ? TT<HT>::BK : TT<float>::BK;
-        if (d->workspace && d->batch1 * d->batch2 == 1) {
+        if (d->workspace && d->batch1 * d->batch2 == 1 && (long long)d->M * d->N < (1LL << 33)) {
             int sk = d->splitk > 1 ? d->splitk : (d->splitk == 0 && d->act != DWG_ACT_GEGLU_PAIR ? auto_splitk(d->M, d->N, d->K, bn, bk) : 1);
             while (sk > 1 && (size_t)sk * d->M * d->N * sizeof(float) > d->workspace_bytes) sk--;
             p.splitk = sk;
