@@ -357,6 +357,38 @@ __global__ __launch_bounds__(256) void k_interleave2x2(int B, int Ho, int Wo, in
     }
 }
 
+
+// out[b][c][r] = in[b][r][c] for 2-byte elements: 64 x 64 tiles through LDS, 16-byte reads along c and 16-byte writes along r.
+// The LDS tile is [64 rows][64 + 2] halves: a thread's 8 column reads for one output piece step by 33 dwords -> distinct banks.
+__global__ __launch_bounds__(256) void k_transpose16(int R, int C, const unsigned short* __restrict__ in, long long ld_in, long long bs_in,
+                                                     unsigned short* __restrict__ out, long long ld_out, long long bs_out) {
+    __shared__ unsigned short tile[64][66];
+    const int tid = threadIdx.x;
+    const int r0 = blockIdx.y * 64, c0 = blockIdx.x * 64;
+    in += (long long)blockIdx.z * bs_in; out += (long long)blockIdx.z * bs_out;
+#pragma unroll
+    for (int i = 0; i < 2; i++) {
+        const int idx = tid + i * 256, r = idx >> 3, ch = (idx & 7) * 8;
+        uint4 v = make_uint4(0u, 0u, 0u, 0u);
+        if (r0 + r < R && c0 + ch < C) v = *reinterpret_cast<const uint4*>(in + (long long)(r0 + r) * ld_in + c0 + ch);   // C % 8 == 0
+        unsigned* d = reinterpret_cast<unsigned*>(&tile[r][ch]);
+        d[0] = v.x; d[1] = v.y; d[2] = v.z; d[3] = v.w;
+    }
+    __syncthreads();
+#pragma unroll
+    for (int i = 0; i < 2; i++) {
+        const int idx = tid + i * 256, c = idx >> 3, rh = (idx & 7) * 8;
+        if (c0 + c >= C || r0 + rh >= R) continue;                       // R % 8 == 0
+        unsigned short e[8];
+#pragma unroll
+        for (int k = 0; k < 8; k++) e[k] = tile[rh + k][c];
+        uint4 v;
+        v.x = e[0] | ((unsigned)e[1] << 16); v.y = e[2] | ((unsigned)e[3] << 16);
+        v.z = e[4] | ((unsigned)e[5] << 16); v.w = e[6] | ((unsigned)e[7] << 16);
+        *reinterpret_cast<uint4*>(out + (long long)(c0 + c) * ld_out + r0 + rh) = v;
+    }
+}
+
 }  // namespace
 
 extern "C" {
@@ -504,6 +536,18 @@ int dwg_interleave2x2(int32_t B, int32_t Ho, int32_t Wo, int32_t C, const void* 
     long long blocks = (n + 255) / 256; if (blocks > 8192) blocks = 8192;
     DWG_LAUNCH("interleave2x2", k_interleave2x2, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, B, Ho, Wo, C / 8, (const uint4*)s00,
                (const uint4*)s01, (const uint4*)s10, (const uint4*)s11, (uint4*)out);
+    DWG_RETURN_IF_LAUNCH_FAILED();
+    return DWG_OK;
+}
+
+int dwg_transpose_2byte(int32_t batch, int32_t R, int32_t C, const void* in, int64_t ld_in, int64_t batch_stride_in, void* out, int64_t ld_out,
+                        int64_t batch_stride_out, dwg_stream_t stream) {
+    if (batch < 0 || R < 0 || C < 0 || R % 8 || C % 8 || ld_in % 8 || ld_out % 8 || batch_stride_in % 8 || batch_stride_out % 8) return DWG_E_ARG;
+    if (batch == 0 || R == 0 || C == 0) return DWG_OK;
+    if (!in || !out || ((uintptr_t)in | (uintptr_t)out) % 16) return DWG_E_ARG;
+    DWG_LAUNCH("transpose", k_transpose16, dim3((C + 63) / 64, (R + 63) / 64, batch), dim3(256), 0, (hipStream_t)stream, R, C,
+               (const unsigned short*)in, (long long)ld_in, (long long)batch_stride_in, (unsigned short*)out, (long long)ld_out,
+               (long long)batch_stride_out);
     DWG_RETURN_IF_LAUNCH_FAILED();
     return DWG_OK;
 }

@@ -450,6 +450,13 @@ class Weights:
                                          for n in names], 0).to(self.device, self.wdtype).contiguous()
         return self.cache[key]
 
+    def lin_t(self, name):
+        """The transposed copy [in, out] of a linear weight: the backward product dy @ W as a K-contiguous GEMM (B(n, k) = W^T[n][k])."""
+        key = ("lin_t", name)
+        if key not in self.cache:
+            self.cache[key] = self.lin(name).t().contiguous()
+        return self.cache[key]
+
     def lin_geglu(self, name):
         """GEGLU projection [8C, C] (rows: hidden | gate) re-ordered in 32-row blocks [hidden_q | gate_q] for the fused
         GEGLU-pair epilogue of dwg_gemm; returns (weight bf16, bias fp32) in that order."""
@@ -647,6 +654,14 @@ class Builder:
         pp = lambda t: ctypes.c_void_p(t.data_ptr())  # noqa: E731
         self.p.add_call(self.L.dwg_interleave2x2, B, Ho, Wo, C * (self.p.esize // 2), pp(subs[0]), pp(subs[1]), pp(subs[2]), pp(subs[3]), pp(out))
         return out
+
+    def transpose(self, x):
+        """[B, R, C] -> [B, C, R] (2-byte element plans): operands of the VAE attention made K-contiguous for the direct-to-LDS GEMM kernels."""
+        B, R, C = x.shape
+        y = self.p.buf(B, C, R)
+        pp = lambda t: ctypes.c_void_p(t.data_ptr())  # noqa: E731
+        self.p.add_call(self.L.dwg_transpose_2byte, B, R, C, pp(x), x.stride(1), x.stride(0), pp(y), R, C * R)
+        return y
 
     def cast_bf16(self, x):
         """fp32 accumulator buffer -> the plan's activation type (a no-op for the fp32 plans)."""
@@ -947,35 +962,62 @@ class VAEEncoderPlan:
         pp = lambda t: ctypes.c_void_p(t.data_ptr())  # noqa: E731
         f.p.add_call(f.L.dwg_softmax_rows_forward_dt, f.p.dt, B * N, N, scale, pp(S), N, pp(P), N)
         o = f.p.buf(B, N, C)
-        f.p.add_gemm(gemm.gemm_raw(P, v, o, N, C, N, (N, 1), (1, C), C, batch=(B, 1), a_batch=(N * N, 0), b_batch=(N * C, 0),
-                                   c_batch=(N * C, 0), name="vae_pv", run=False))
+        # 2-byte plans: every product below runs with BOTH operands K-contiguous (the direct-to-LDS MFMA kernels: 3-4x the rate of the
+        # register-staged strided loader) -- v, do, k, q, P and dS are transposed once each (dwg_transpose_2byte: 4 / 32 MB, ~3 / ~15 us)
+        # and the backward uses transposed copies of the four projection weights.  The fp32 plans keep the strided products.
+        kc = f.p.esize == 2
+        if kc:
+            vT = f.transpose(v)
+            f.p.add_gemm(gemm.gemm_raw(P, vT, o, N, C, N, (N, 1), (N, 1), C, batch=(B, 1), a_batch=(N * N, 0), b_batch=(N * C, 0),
+                                       c_batch=(N * C, 0), name="vae_pv", run=False))
+        else:
+            f.p.add_gemm(gemm.gemm_raw(P, v, o, N, C, N, (N, 1), (1, C), C, batch=(B, 1), a_batch=(N * N, 0), b_batch=(N * C, 0),
+                                       c_batch=(N * C, 0), name="vae_pv", run=False))
         out = f.linear(o, w.lin(pre + ".to_out.0"), bias=w.f32(pre + ".to_out.0.bias"), residual=x.view(B, N, C), tag="vae_out")
         out = out.view(B, H, W, C)
 
         def back(dout):
             dt = dout.view(B, N, C)
-            wo, wq, wk, wv = (w.lin(pre + s) for s in (".to_out.0", ".to_q", ".to_k", ".to_v"))
+            wo = w.lin(pre + ".to_out.0")
             M = B * N
             bk = dict(batch=(B, 1))
             do = r.p.buf(B, N, C)      # d o = dout @ Wo
-            r.p.add_gemm(gemm.gemm_raw(dt, wo, do, M, C, C, (C, 1), (1, C), C, name="vae_bwd", run=False))
+            if kc:
+                r.p.add_gemm(gemm.gemm_raw(dt, w.lin_t(pre + ".to_out.0"), do, M, C, C, (C, 1), (C, 1), C, name="vae_bwd", run=False))
+            else:
+                r.p.add_gemm(gemm.gemm_raw(dt, wo, do, M, C, C, (C, 1), (1, C), C, name="vae_bwd", run=False))
             dP = r.p.buf(B, N, N, dtype=torch.float32)   # dP = do v^T
             r.p.add_gemm(gemm.gemm_raw(do, v, dP, N, N, C, (C, 1), (C, 1), N, a_batch=(N * C, 0), b_batch=(N * C, 0), c_batch=(N * N, 0),
                                        name="vae_bwd_dp", run=False, **bk))
             dv = r.p.buf(B, N, C)      # dv = P^T do
-            r.p.add_gemm(gemm.gemm_raw(P, do, dv, N, C, N, (1, N), (1, C), C, a_batch=(N * N, 0), b_batch=(N * C, 0), c_batch=(N * C, 0),
-                                       name="vae_bwd_dv", run=False, **bk))
+            if kc:
+                PT, doT = r.transpose(P), r.transpose(do)
+                r.p.add_gemm(gemm.gemm_raw(PT, doT, dv, N, C, N, (N, 1), (N, 1), C, a_batch=(N * N, 0), b_batch=(N * C, 0), c_batch=(N * C, 0),
+                                           name="vae_bwd_dv", run=False, **bk))
+            else:
+                r.p.add_gemm(gemm.gemm_raw(P, do, dv, N, C, N, (1, N), (1, C), C, a_batch=(N * N, 0), b_batch=(N * C, 0), c_batch=(N * C, 0),
+                                           name="vae_bwd_dv", run=False, **bk))
             dS = r.p.buf(B, N, N)
             r.p.add_call(r.L.dwg_softmax_rows_backward_dt, r.p.dt, B * N, N, scale, pp(P), N, pp(dP), N, pp(dS), N)
             dq = r.p.buf(B, N, C)      # dq = dS k
-            r.p.add_gemm(gemm.gemm_raw(dS, k, dq, N, C, N, (N, 1), (1, C), C, a_batch=(N * N, 0), b_batch=(N * C, 0), c_batch=(N * C, 0),
-                                       name="vae_bwd_dq", run=False, **bk))
             dk = r.p.buf(B, N, C)      # dk = dS^T q
-            r.p.add_gemm(gemm.gemm_raw(dS, q, dk, N, C, N, (1, N), (1, C), C, a_batch=(N * N, 0), b_batch=(N * C, 0), c_batch=(N * C, 0),
-                                       name="vae_bwd_dk", run=False, **bk))
+            if kc:
+                kT, qT, dST = r.transpose(k), r.transpose(q), r.transpose(dS)
+                r.p.add_gemm(gemm.gemm_raw(dS, kT, dq, N, C, N, (N, 1), (N, 1), C, a_batch=(N * N, 0), b_batch=(N * C, 0), c_batch=(N * C, 0),
+                                           name="vae_bwd_dq", run=False, **bk))
+                r.p.add_gemm(gemm.gemm_raw(dST, qT, dk, N, C, N, (N, 1), (N, 1), C, a_batch=(N * N, 0), b_batch=(N * C, 0), c_batch=(N * C, 0),
+                                           name="vae_bwd_dk", run=False, **bk))
+            else:
+                r.p.add_gemm(gemm.gemm_raw(dS, k, dq, N, C, N, (N, 1), (1, C), C, a_batch=(N * N, 0), b_batch=(N * C, 0), c_batch=(N * C, 0),
+                                           name="vae_bwd_dq", run=False, **bk))
+                r.p.add_gemm(gemm.gemm_raw(dS, q, dk, N, C, N, (1, N), (1, C), C, a_batch=(N * N, 0), b_batch=(N * C, 0), c_batch=(N * C, 0),
+                                           name="vae_bwd_dk", run=False, **bk))
             dn = r.p.buf(B, N, C, dtype=torch.float32)   # dn = dq Wq + dk Wk + dv Wv (fp32 accumulate across the three products)
-            for i, (g_, wt) in enumerate(((dq, wq), (dk, wk), (dv, wv))):
-                r.p.add_gemm(gemm.gemm_raw(g_, wt, dn, M, C, C, (C, 1), (1, C), C, accumulate=i > 0, name="vae_bwd_dn", run=False))
+            for i, (g_, wn) in enumerate(((dq, ".to_q"), (dk, ".to_k"), (dv, ".to_v"))):
+                if kc:
+                    r.p.add_gemm(gemm.gemm_raw(g_, w.lin_t(pre + wn), dn, M, C, C, (C, 1), (C, 1), C, accumulate=i > 0, name="vae_bwd_dn", run=False))
+                else:
+                    r.p.add_gemm(gemm.gemm_raw(g_, w.lin(pre + wn), dn, M, C, C, (C, 1), (1, C), C, accumulate=i > 0, name="vae_bwd_dn", run=False))
             dnb = r.cast_bf16(dn).view(B, H, W, C)
             dx = r.groupnorm_bwd(x, dnb, st, pre + ".group_norm", 1e-6, False)
             return r.add(dx, dout)

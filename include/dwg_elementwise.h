@@ -58,6 +58,12 @@ int dwg_cast_f32_to_bf16(int64_t n, const float* src, void* dst, dwg_stream_t st
 int dwg_add_dt(int32_t dtype, int64_t n, const void* a, const void* b, void* out, dwg_stream_t stream);
 int dwg_cast_f32_to_dt(int32_t dtype, int64_t n, const float* src, void* dst, dwg_stream_t stream);
 
+/* out[b][c][r] = in[b][r][c] for 2-byte elements (bf16 / fp16): R, C and the strides (elements) multiples of 8, 16-byte aligned bases.
+ * The VAE mid-block attention (N = 4096, d = 512) transposes P, dS and the [N, C] projections with it so that every product of its forward
+ * and backward is a K-contiguous GEMM (the direct-to-LDS MFMA kernels) instead of a strided one. */
+int dwg_transpose_2byte(int32_t batch, int32_t R, int32_t C, const void* in, int64_t ld_in, int64_t batch_stride_in, void* out, int64_t ld_out,
+                        int64_t batch_stride_out, dwg_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -101,3 +101,17 @@ def test_softmax_rows_forward_backward():
     (gS,) = torch.autograd.grad(ref, Sd, dP.double())
     dS = nn_ops.softmax_rows_backward(P, dP.cuda(), 0.044)
     assert _err(dS, gS) < 2e-2
+
+
+@pytest.mark.parametrize("B,R,C", [(1, 4096, 512), (2, 72, 200), (3, 8, 8), (1, 512, 4096)])
+def test_transpose_2byte(B, R, C, half):
+    """out[b][c][r] = in[b][r][c] on 2-byte elements, bit-exact, incl. ragged 64 x 64 tiles and a strided (row-sliced) source."""
+    import ctypes
+    from dreamwaltz_g_amd import _lib
+    g = torch.Generator().manual_seed(R + C)
+    x = torch.randn(B, R, C + 8, generator=g).to(half).cuda()
+    src = x[..., :C]                                   # row stride C + 8
+    out = torch.empty(B, C, R, device="cuda", dtype=half)
+    st = ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+    _lib.check(_lib.lib().dwg_transpose_2byte(B, R, C, _lib.ptr(src), src.stride(1), src.stride(0), _lib.ptr(out), R, C * R, st), "dwg_transpose_2byte")
+    assert torch.equal(out, src.transpose(1, 2).contiguous())
