@@ -536,7 +536,8 @@ __global__ __launch_bounds__(256) void k_splitk_epilogue(GemmP p) {
 }
 
 template <typename T, int BN, int AMODE, int BMODE>
-__global__ __launch_bounds__(256) void k_gemm(GemmP p) {
+__global__ __launch_bounds__(256, (sizeof(T) == 4 || BN == 64) ? 2 : 1) void k_gemm(GemmP p) {   // <= 256 registers where they suffice: accumulators
+                                                     // in arch VGPRs (see k_gemm_glds); the register-staged 16-bit 128 x 128 tile needs more
     constexpr int BM = 128, BK = TT<T>::BK, LDT = BK + TT<T>::PAD;
     constexpr int WN = BN / 64;            // waves along N (2 for BN=128, 1 for BN=64)
     constexpr int WM = 4 / WN;             // waves along M
@@ -774,7 +775,8 @@ template <int BM> struct ALoaderOf<BM, 2> { typedef GldsConvFast<BM> type; };
 
 // AKIND: 0 = plain rows (linear layers), 1 = generic implicit-GEMM convolution, 2 = convolution fast path (GldsConvFast)
 template <int BN, int AKIND, int S>
-__global__ __launch_bounds__(256) void k_gemm_glds(GemmP p) {
+__global__ __launch_bounds__(256, 2) void k_gemm_glds(GemmP p) {     // 2 waves / SIMD = the LDS-bound occupancy anyway; with <= 256 registers the
+                                                                      // accumulators stay in arch VGPRs (no v_accvgpr copies in prologue / epilogue)
     constexpr int BM = 128;
     constexpr int WN = BN / 64, WM = 4 / WN, TM = BM / WM / 32, TN = 2;
     constexpr int ABYTES = BM * 128, BBYTES = BN * 128, STAGE = ABYTES + BBYTES;
