@@ -148,6 +148,115 @@ __global__ __launch_bounds__(256) void k_gn_finalize(int chunks, int G, const fl
     if (lane == 63) stats[(size_t)b * G * 2 + o] = s;
 }
 
+// Small tensors (the denoiser's 8x8 / 16x16 / 32x32 levels): the WHOLE layer in one launch.  grid (G / gb, B): a workgroup owns gb whole
+// groups of one image -- gb * (C / G) channels, a multiple of 8, i.e. whole 16-byte chunks -- and walks that channel bundle over all pixels
+// twice (the second time out of L2): column sums -> fixed-order tree -> mean / rstd -> normalise.  Replaces statistics + (finalize) + apply,
+// three dependent ~5 us launches whose data would fit in one CU's registers.  Few workgroups (16-64) on purpose: the work is latency, not
+// bandwidth.  Bit-reproducible (no atomics, fixed summation order); not bit-identical to the three-launch path (another order).
+template <typename T>
+__global__ __launch_bounds__(256) void k_gn_small(int HW, int C, int G, int gb, const T* __restrict__ x, const float* __restrict__ gamma,
+                                                  const float* __restrict__ beta, int silu, float eps, T* __restrict__ y,
+                                                  float* __restrict__ stats_out) {
+    extern __shared__ __attribute__((aligned(16))) float lds[];   // [2][tp][nb] per-lane column partials | [2][nb] column sums
+    __shared__ float gsum[16], gstat[16];
+    const int b = blockIdx.y, g0 = blockIdx.x * gb, tid = threadIdx.x;
+    const int cg = C / G, nb = gb * cg, nc = nb / 8, tp = 256 / nc;
+    const int pl = tid / nc, ci = tid - pl * nc;
+    const bool active = pl < tp;
+    const size_t base = (size_t)b * HW * C + (size_t)g0 * cg + ci * 8;
+    const T* xb = x + base;
+    const long long st = (long long)tp * C;                       // element stride of one trip
+    float s[8], q[8];
+#pragma unroll
+    for (int e = 0; e < 8; e++) { s[e] = 0.f; q[e] = 0.f; }
+    if (active) {
+        int p = pl;
+        const T* xp = xb + (size_t)p * C;
+        for (; p + 3 * tp < HW; p += 4 * tp, xp += 4 * st) {       // four independent loads in flight
+            const vec8<T> x0 = *reinterpret_cast<const vec8<T>*>(xp), x1 = *reinterpret_cast<const vec8<T>*>(xp + st),
+                          x2 = *reinterpret_cast<const vec8<T>*>(xp + 2 * st), x3 = *reinterpret_cast<const vec8<T>*>(xp + 3 * st);
+#pragma unroll
+            for (int e = 0; e < 8; e++) {
+                const float a0 = (float)x0[e], a1 = (float)x1[e], a2 = (float)x2[e], a3 = (float)x3[e];
+                s[e] += (a0 + a1) + (a2 + a3);
+                q[e] += (a0 * a0 + a1 * a1) + (a2 * a2 + a3 * a3);
+            }
+        }
+        for (; p < HW; p += tp, xp += st) {
+            const vec8<T> xv = *reinterpret_cast<const vec8<T>*>(xp);
+#pragma unroll
+            for (int e = 0; e < 8; e++) { const float a = (float)xv[e]; s[e] += a; q[e] = fmaf(a, a, q[e]); }
+        }
+    }
+    float* cs = lds; float* cq = lds + tp * nb; float* col = lds + 2 * tp * nb;
+    if (active) {
+#pragma unroll
+        for (int e = 0; e < 8; e++) { cs[pl * nb + ci * 8 + e] = s[e]; cq[pl * nb + ci * 8 + e] = q[e]; }
+    }
+    __syncthreads();
+    for (int t = tid; t < 2 * nb; t += 256) {                      // column sums over the tp pixel lanes, in lane order
+        const int stt = t >= nb, c = t - stt * nb;
+        const float* src = (stt ? cq : cs) + c;
+        float a = 0.f;
+        for (int r = 0; r < tp; r++) a += src[r * nb];
+        col[t] = a;
+    }
+    __syncthreads();
+    if (tid < 2 * gb) {                                            // group sums over the group's columns, in channel order
+        const int stt = tid >= gb, gl = tid - stt * gb;
+        const float* src = col + stt * nb + gl * cg;
+        float a = 0.f;
+        for (int c = 0; c < cg; c++) a += src[c];
+        gsum[tid] = a;
+        stats_out[((size_t)b * G + g0 + gl) * 2 + stt] = a;
+    }
+    __syncthreads();
+    if (tid < gb) {
+        const float inv_n = 1.f / ((float)HW * cg);
+        const float m = gsum[tid] * inv_n, var = gsum[gb + tid] * inv_n - m * m;
+        gstat[2 * tid] = m; gstat[2 * tid + 1] = rsqrtf(fmaxf(var, 0.f) + eps);
+    }
+    __syncthreads();
+    if (!active) return;
+    float sc[8], sh[8];
+#pragma unroll
+    for (int e = 0; e < 8; e++) {
+        const int cl = ci * 8 + e, gl = cl / cg, ch = g0 * cg + cl;
+        const float rs = gstat[2 * gl + 1];
+        sc[e] = gamma[ch] * rs; sh[e] = beta[ch] - gstat[2 * gl] * sc[e];
+    }
+    T* yb = y + base;
+    int p = pl;
+    const T* xp = xb + (size_t)p * C; T* yp = yb + (size_t)p * C;
+    for (; p + 3 * tp < HW; p += 4 * tp, xp += 4 * st, yp += 4 * st) {
+        vec8<T> xv[4];
+#pragma unroll
+        for (int u = 0; u < 4; u++) xv[u] = *reinterpret_cast<const vec8<T>*>(xp + u * st);
+#pragma unroll
+        for (int u = 0; u < 4; u++) {
+            vec8<T> o;
+#pragma unroll
+            for (int e = 0; e < 8; e++) {
+                float z = fmaf((float)xv[u][e], sc[e], sh[e]);
+                if (silu) z = silu_f(z);
+                o[e] = (T)z;
+            }
+            *reinterpret_cast<vec8<T>*>(yp + u * st) = o;
+        }
+    }
+    for (; p < HW; p += tp, xp += st, yp += st) {
+        const vec8<T> xv = *reinterpret_cast<const vec8<T>*>(xp);
+        vec8<T> o;
+#pragma unroll
+        for (int e = 0; e < 8; e++) {
+            float z = fmaf((float)xv[e], sc[e], sh[e]);
+            if (silu) z = silu_f(z);
+            o[e] = (T)z;
+        }
+        *reinterpret_cast<vec8<T>*>(yp) = o;
+    }
+}
+
 // forward apply: y = silu?((x - mean) * rstd * gamma + beta)
 // backward apply: dx = rstd * (dyh - mean(dyh) - xhat * mean(dyh * xhat)) [+ residual]
 // Same thread layout as the reduction: a thread owns ONE 8-channel chunk (its affine parameters and group statistics live
@@ -435,6 +544,23 @@ int dwg_groupnorm_forward_dt(int32_t dtype, int32_t B, int32_t HW, int32_t C, in
     int rppb, rchunks;
     gn_reduce_geometry(HW, C, &rppb, &rchunks);
     hipStream_t stream = (hipStream_t)stream_;
+    {
+        // small images: one launch for the whole layer (k_gn_small) when a bundle of gb whole groups is a whole number of 16-byte chunks and
+        // a workgroup's two walks over it stay short (<= 24 trips per thread)
+        static const bool no_small = getenv("DWG_GN_NO_SMALL") != nullptr;
+        const int cg = C / G;
+        int gb = 0;
+        for (int c = 1; c <= 8 && !gb; c *= 2) if ((c * cg) % 8 == 0 && G % c == 0) gb = c;
+        if (!no_small && gb && HW <= 1024 && (long long)HW * (gb * cg / 8) <= 6144 && gb * cg / 8 <= 64) {
+            const int nb = gb * cg, tp = 256 / (nb / 8);
+            const size_t sl = (size_t)(2 * tp * nb + 2 * nb) * sizeof(float);
+            DWG_DT_SWITCH(dtype,
+                DWG_LAUNCH("gn_small", (k_gn_small<T>), dim3(G / gb, B), dim3(256), sl, stream, HW, C, G, gb, (const T*)x, gamma, beta, fuse_silu,
+                           eps, (T*)y, stats))
+            DWG_RETURN_IF_LAUNCH_FAILED();
+            return DWG_OK;
+        }
+    }
     static const int fold_max = getenv("DWG_GN_FOLD") ? atoi(getenv("DWG_GN_FOLD")) : GN_FOLD_MAX_CHUNKS;
     const bool fold = rchunks <= fold_max && 2 * G * 4 <= 256;     // finalize folded into the apply pass
     DWG_DT_SWITCH(dtype,

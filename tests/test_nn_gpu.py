@@ -21,7 +21,10 @@ def _err(a, r):
 
 @pytest.mark.parametrize("B,H,C,silu,eps", [(2, 64, 320, True, 1e-5), (2, 16, 1280, False, 1e-6), (1, 96, 128, True, 1e-6),
                                             (2, 8, 2560, True, 1e-5), (1, 33, 64, False, 1e-5), (2, 32, 960, True, 1e-5),
-                                            (1, 128, 256, True, 1e-6)])   # 128^2 x 8 ch per group: the three-kernel path
+                                            (1, 128, 256, True, 1e-6),    # 128^2 x 8 ch per group: the three-kernel path
+                                            # the one-launch small-image kernel (k_gn_small): group bundles of 1 / 2 / 4 groups, 5-15 chunks wide
+                                            (2, 32, 640, True, 1e-5), (2, 32, 1280, True, 1e-5), (2, 16, 1920, True, 1e-5), (2, 8, 960, False, 1e-5),
+                                            (1, 32, 320, True, 1e-5), (2, 16, 2560, True, 1e-5), (3, 8, 1280, True, 1e-6)])
 def test_groupnorm_forward_backward(B, H, C, silu, eps):
     from dreamwaltz_g_amd import nn_ops
     g = torch.Generator().manual_seed(C + H)
