@@ -172,7 +172,16 @@ __global__ __launch_bounds__(256) void k_gn_small(int HW, int C, int G, int gb, 
     if (active) {
         int p = pl;
         const T* xp = xb + (size_t)p * C;
-        for (; p + 3 * tp < HW; p += 4 * tp, xp += 4 * st) {       // four independent loads in flight
+        for (; p + 7 * tp < HW; p += 8 * tp, xp += 8 * st) {       // eight independent loads in flight: the walk is L2 latency, nothing else
+            vec8<T> xv[8];
+#pragma unroll
+            for (int u = 0; u < 8; u++) xv[u] = *reinterpret_cast<const vec8<T>*>(xp + u * st);
+#pragma unroll
+            for (int u = 0; u < 8; u++)
+#pragma unroll
+                for (int e = 0; e < 8; e++) { const float a = (float)xv[u][e]; s[e] += a; q[e] = fmaf(a, a, q[e]); }
+        }
+        for (; p + 3 * tp < HW; p += 4 * tp, xp += 4 * st) {
             const vec8<T> x0 = *reinterpret_cast<const vec8<T>*>(xp), x1 = *reinterpret_cast<const vec8<T>*>(xp + st),
                           x2 = *reinterpret_cast<const vec8<T>*>(xp + 2 * st), x3 = *reinterpret_cast<const vec8<T>*>(xp + 3 * st);
 #pragma unroll
@@ -228,6 +237,22 @@ __global__ __launch_bounds__(256) void k_gn_small(int HW, int C, int G, int gb, 
     T* yb = y + base;
     int p = pl;
     const T* xp = xb + (size_t)p * C; T* yp = yb + (size_t)p * C;
+    for (; p + 7 * tp < HW; p += 8 * tp, xp += 8 * st, yp += 8 * st) {
+        vec8<T> xv[8];
+#pragma unroll
+        for (int u = 0; u < 8; u++) xv[u] = *reinterpret_cast<const vec8<T>*>(xp + u * st);
+#pragma unroll
+        for (int u = 0; u < 8; u++) {
+            vec8<T> o;
+#pragma unroll
+            for (int e = 0; e < 8; e++) {
+                float z = fmaf((float)xv[u][e], sc[e], sh[e]);
+                if (silu) z = silu_f(z);
+                o[e] = (T)z;
+            }
+            *reinterpret_cast<vec8<T>*>(yp + u * st) = o;
+        }
+    }
     for (; p + 3 * tp < HW; p += 4 * tp, xp += 4 * st, yp += 4 * st) {
         vec8<T> xv[4];
 #pragma unroll
@@ -551,7 +576,8 @@ int dwg_groupnorm_forward_dt(int32_t dtype, int32_t B, int32_t HW, int32_t C, in
         const int cg = C / G;
         int gb = 0;
         for (int c = 1; c <= 8 && !gb; c *= 2) if ((c * cg) % 8 == 0 && G % c == 0) gb = c;
-        if (!no_small && gb && HW <= 1024 && (long long)HW * (gb * cg / 8) <= 6144 && gb * cg / 8 <= 64) {
+        static const int small_max = getenv("DWG_GN_SMALL_MAX") ? atoi(getenv("DWG_GN_SMALL_MAX")) : 6144;     // chunks per workgroup walk
+        if (!no_small && gb && HW <= 1024 && (long long)HW * (gb * cg / 8) <= small_max && gb * cg / 8 <= 64) {
             const int nb = gb * cg, tp = 256 / (nb / 8);
             const size_t sl = (size_t)(2 * tp * nb + 2 * nb) * sizeof(float);
             DWG_DT_SWITCH(dtype,
