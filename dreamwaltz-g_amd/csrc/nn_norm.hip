@@ -577,11 +577,12 @@ int dwg_groupnorm_forward_dt(int32_t dtype, int32_t B, int32_t HW, int32_t C, in
         int gb = 0;
         for (int c = 1; c <= 8 && !gb; c *= 2) if ((c * cg) % 8 == 0 && G % c == 0) gb = c;
         static const int small_max = getenv("DWG_GN_SMALL_MAX") ? atoi(getenv("DWG_GN_SMALL_MAX")) : 6144;     // chunks per workgroup walk
-        // ... and only while the whole tensor stays L2-resident: a bundle is an 80-240-byte slice of every pixel row, so the walks touch partial
-        // cache lines that neighbouring bundles touch again -- free out of L2, 3x the traffic out of HBM (a batched multi-view step has 8x the
-        // batch: c4 on one GPU fell from 92 to 71 views/s with this path on its 42 MB tensors)
+        // ... and only for the small batches it was built for (B <= 4, tensor <= 8 MB: L2-resident).  A bundle is an 80-240-byte slice of every
+        // pixel row, so the walks touch partial cache lines that neighbouring bundles touch again -- free out of L2, several times the traffic
+        // beyond it -- and with 8x the batch the three-launch path has all the parallelism it needs: the batched 8-view step (batch 16) fell
+        // from 92 to 68 views/s with this kernel on (A/B, DWG_GN_NO_SMALL), so it keeps the three-launch path
         const long long tensor_bytes = (long long)B * HW * C * (dtype == DWG_DTYPE_F32 ? 4 : 2);
-        if (!no_small && gb && HW <= 1024 && (long long)HW * (gb * cg / 8) <= small_max && gb * cg / 8 <= 64 && tensor_bytes <= (12ll << 20)) {
+        if (!no_small && gb && B <= 4 && HW <= 1024 && (long long)HW * (gb * cg / 8) <= small_max && gb * cg / 8 <= 64 && tensor_bytes <= (8ll << 20)) {
             const int nb = gb * cg, tp = 256 / (nb / 8);
             const size_t sl = (size_t)(2 * tp * nb + 2 * nb) * sizeof(float);
             DWG_DT_SWITCH(dtype,
