@@ -100,6 +100,13 @@ def _patch_scene_module(mod):
 # --------------------------------------------------------------------------------------------------------------------------------------
 # B4: guidance
 # --------------------------------------------------------------------------------------------------------------------------------------
+def plan_dtype_for(ref, dtype=None):
+    """Storage type of the HIP plans for a constructed reference guidance object: the explicit argument, else DWG_BIND_DTYPE, else fp16 when the
+    reference loaded its pipeline in torch.float16 (`--guide.dtype fp16`: core/guidance/basic.py:24-27,233), else bf16."""
+    import torch
+    return dtype or os.environ.get("DWG_BIND_DTYPE") or ("f16" if getattr(ref, "torch_dtype", None) is torch.float16 else "bf16")
+
+
 def bind_guidance(ref, dtype=None, keep_modules=None):
     """Binds `_predict` and `encode_images` of a constructed reference ControlNetScoreDistillation to HIP plans fed from the state_dict()s
     of its loaded diffusers modules (pipe.unet, controlnet, pipe.vae).  Returns `ref` (the same object)."""
@@ -108,7 +115,7 @@ def bind_guidance(ref, dtype=None, keep_modules=None):
     _pkg()
     import torch
     from dreamwaltz_g_amd import guidance as gd, sd15
-    dtype = dtype or os.environ.get("DWG_BIND_DTYPE") or ("f16" if getattr(ref, "torch_dtype", None) is torch.float16 else "bf16")
+    dtype = plan_dtype_for(ref, dtype)
     unet, cnet, vae = ref.pipe.unet, ref.controlnet, ref.pipe.vae
     if type(cnet).__name__ == "MultiControlNetModel":
         raise NotImplementedError("MultiControlNetModel (several condition types at once)")

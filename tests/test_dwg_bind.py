@@ -53,6 +53,23 @@ def test_unet_config_from_a_diffusers_style_config():
     assert sd15.vae_config_from(None).scaling_factor == 0.18215
 
 
+def test_plan_dtype_follows_the_reference_pipeline_dtype(monkeypatch):
+    """`--guide.dtype fp16` (the reference loads UNet / ControlNet / VAE in torch.float16: core/guidance/basic.py:233) -> fp16 plans; its
+    fp32 default -> the bf16 plans; DWG_BIND_DTYPE and the explicit argument override."""
+    import types
+    sys.path.insert(0, os.path.join(ROOT, "dropin"))
+    try:
+        import dwg_bind
+    finally:
+        sys.path.pop(0)
+    monkeypatch.delenv("DWG_BIND_DTYPE", raising=False)
+    half, full = types.SimpleNamespace(torch_dtype=torch.float16), types.SimpleNamespace(torch_dtype=torch.float32)
+    assert dwg_bind.plan_dtype_for(half) == "f16" and dwg_bind.plan_dtype_for(full) == "bf16" and dwg_bind.plan_dtype_for(object()) == "bf16"
+    assert dwg_bind.plan_dtype_for(half, "f32") == "f32"
+    monkeypatch.setenv("DWG_BIND_DTYPE", "f32")
+    assert dwg_bind.plan_dtype_for(half) == "f32" and dwg_bind.plan_dtype_for(full, "bf16") == "bf16"
+
+
 # ---------------------------------------------------------------------------------------------------------------------------------------
 @pytest.mark.gpu
 def test_bound_avatar_renders_like_the_avatar_it_adopted():
