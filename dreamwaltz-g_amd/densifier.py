@@ -11,7 +11,8 @@ for parameters that live in the ONE flat optimizer buffer of this path.
 
 What differs from the reference is only WHERE the tensors live: the reference replaces nn.Parameters inside a torch.optim.Adam and
 re-keys its state dict (:120-180); here `optim.resize_flat_params` lays the flat parameter / gradient / moment buffers out afresh, the
-Parameters keep their identity, the Adam moments are carried over row by row (zeros for new rows), and -- as in the reference, whose new
+resized Parameters become NEW nn.Parameter objects re-registered under the same names (a Parameter whose `.data` changed shape keeps a stale
+AccumulateGrad node; `_rebind` hands the new objects to the owning modules), the Adam moments are carried over row by row (zeros for new rows), and -- as in the reference, whose new
 Parameters have `grad is None` at the following `optimizer.step()` -- the resized groups sit out that one step.  Runs on the device the
 parameters are on with torch indexing ops (every `densification_interval` steps: not part of the per-step hot path); the three per-step
 statistics updates are element-wise torch ops on [N] tensors.  `use_densifier` is off in every shipped recipe (configs/__init__.py:159)."""
