@@ -19,8 +19,17 @@
 
 // The 16-bit operand type of this translation unit.  gemm.hip itself is the bf16 (+ exact-f32) unit; gemm_f16.hip re-includes it with
 // DWG_GEMM_F16_TU defined: the same kernels on _Float16 operands (v_mfma_f32_32x32x16_f16) for the fp16-storage plans -- the reference's
-// autocast storage type (configs/__init__.py:462).  Every kernel lives in an anonymous namespace, so the two units do not clash.
-#ifdef DWG_GEMM_F16_TU
+// autocast storage type (configs/__init__.py:462).  Every kernel lives in an anonymous namespace, so the units do not clash.
+// gemm_x.hip re-includes it a third time with DWG_GEMM_X_TU: the split-precision unit (DWG_DTYPE_F32X, dwg_xfmt.h).  There HT is the PHYSICAL
+// fp16 half of the hi / lo planes: the loaders see "a 2-byte tensor with 2 K columns" (the entry point doubles K, Cin and every operand stride),
+// the k-loops form each product from three MFMAs into two accumulator sets, and the epilogue splits what it stores.
+#if defined(DWG_GEMM_X_TU)
+#include "dwg_xfmt.h"
+typedef _Float16 HT;
+#define DWG_DTYPE_HALF DWG_DTYPE_F32X
+#define DWG_MFMA16(a, b, c) __builtin_amdgcn_mfma_f32_32x32x16_f16(a, b, c, 0, 0, 0)
+#define DWG_HALF_NAME "f32x"
+#elif defined(DWG_GEMM_F16_TU)
 typedef _Float16 HT;
 #define DWG_DTYPE_HALF DWG_DTYPE_F16
 #define DWG_MFMA16(a, b, c) __builtin_amdgcn_mfma_f32_32x32x16_f16(a, b, c, 0, 0, 0)
@@ -61,6 +70,30 @@ struct GemmP {
 
 __device__ __forceinline__ float bf2f(HT x) { return (float)x; }
 __device__ __forceinline__ HT f2bf(float x) { return (HT)x; }
+
+// Element access to a C / residual tensor of this unit's 16-bit storage type (index in LOGICAL elements).  The split-precision unit stores
+// hi / lo halves per 8-channel group (dwg_xfmt.h); the bf16 / fp16 units one 2-byte element.
+struct bf16x4_t { HT v[4]; };
+#ifdef DWG_GEMM_X_TU
+__device__ __forceinline__ float ld_half1(const void* base, long long i) { return dwg_x_get1(base, i); }
+__device__ __forceinline__ void st_half1(void* base, long long i, float v) { dwg_x_put1(base, i, v); }
+__device__ __forceinline__ void ld_half4(const void* base, long long i, float (&v)[4]) { dwg_x_get4(base, i, v); }
+__device__ __forceinline__ void st_half4(void* base, long long i, const float (&v)[4]) { dwg_x_put4(base, i, v); }
+#else
+__device__ __forceinline__ float ld_half1(const void* base, long long i) { return bf2f(reinterpret_cast<const HT*>(base)[i]); }
+__device__ __forceinline__ void st_half1(void* base, long long i, float v) { reinterpret_cast<HT*>(base)[i] = f2bf(v); }
+__device__ __forceinline__ void ld_half4(const void* base, long long i, float (&v)[4]) {
+    const bf16x4_t r = *reinterpret_cast<const bf16x4_t*>(reinterpret_cast<const HT*>(base) + i);
+#pragma unroll
+    for (int e = 0; e < 4; e++) v[e] = bf2f(r.v[e]);
+}
+__device__ __forceinline__ void st_half4(void* base, long long i, const float (&v)[4]) {
+    bf16x4_t o;
+#pragma unroll
+    for (int e = 0; e < 4; e++) o.v[e] = f2bf(v[e]);
+    *reinterpret_cast<bf16x4_t*>(reinterpret_cast<HT*>(base) + i) = o;
+}
+#endif
 
 // LIGHT: only identity / SiLU are compiled in (the LDS-patch convolution's epilogue: the erf of GELU would cost it registers it
 // does not have; the dispatcher sends other activations down the generic kernels)
@@ -253,9 +286,9 @@ __device__ __forceinline__ void epilogue_store(const GemmP& p, float v, int row,
     v = apply_act<LIGHT>(v, p.act);
     if (p.residual) {
         const long long ri = roff + (long long)row * p.ldr + col;
-        v += p.res_bf16 ? bf2f(reinterpret_cast<const HT*>(p.residual)[ri]) : reinterpret_cast<const float*>(p.residual)[ri];
+        v += p.res_bf16 ? ld_half1(p.residual, ri) : reinterpret_cast<const float*>(p.residual)[ri];
     }
-    if (p.out_bf16) reinterpret_cast<HT*>(p.C)[ci] = f2bf(v);
+    if (p.out_bf16) st_half1(p.C, ci, v);
     else if (p.accumulate) reinterpret_cast<float*>(p.C)[ci] += v;
     else reinterpret_cast<float*>(p.C)[ci] = v;
 }
@@ -267,8 +300,6 @@ __device__ __forceinline__ void epilogue_store(const GemmP& p, float v, int row,
 // split-K slab) instead of one 2-byte element per instruction: 4x fewer epilogue instructions and memory requests, which is
 // what the small-K layers (5-20 k-steps per tile) spend most of their time on.
 // ---------------------------------------------------------------------------------------------------------------------
-struct bf16x4_t { HT v[4]; };
-
 __device__ __forceinline__ bool epilogue_vec_ok(const GemmP& p, long long coff, long long roff) {
     bool ok = (p.N & 3) == 0 && (p.ldc & 3) == 0 && (coff & 3) == 0 && ((uintptr_t)p.C & 15) == 0;
     if (p.residual) ok = ok && (p.ldr & 3) == 0 && (roff & 3) == 0 && ((uintptr_t)p.residual & 15) == 0;
@@ -301,9 +332,10 @@ __device__ __forceinline__ void epilogue_store4(const GemmP& p, float (&v)[4], i
     if (p.residual) {
         const long long ri = roff + (long long)row * p.ldr + col;
         if (p.res_bf16) {
-            bf16x4_t r = *reinterpret_cast<const bf16x4_t*>(reinterpret_cast<const HT*>(p.residual) + ri);
+            float r[4];
+            ld_half4(p.residual, ri, r);
 #pragma unroll
-            for (int e = 0; e < 4; e++) v[e] += bf2f(r.v[e]);
+            for (int e = 0; e < 4; e++) v[e] += r[e];
         } else {
             float4 r = *reinterpret_cast<const float4*>(reinterpret_cast<const float*>(p.residual) + ri);
             v[0] += r.x; v[1] += r.y; v[2] += r.z; v[3] += r.w;
@@ -311,10 +343,7 @@ __device__ __forceinline__ void epilogue_store4(const GemmP& p, float (&v)[4], i
     }
     const long long ci = coff + (long long)row * p.ldc + col;
     if (p.out_bf16) {
-        bf16x4_t o;
-#pragma unroll
-        for (int e = 0; e < 4; e++) o.v[e] = f2bf(v[e]);
-        *reinterpret_cast<bf16x4_t*>(reinterpret_cast<HT*>(p.C) + ci) = o;
+        st_half4(p.C, ci, v);
     } else {
         float4* dst = reinterpret_cast<float4*>(reinterpret_cast<float*>(p.C) + ci);
         float4 o = make_float4(v[0], v[1], v[2], v[3]);
@@ -401,13 +430,10 @@ __device__ __forceinline__ void tile_epilogue_lds(const GemmP& p, f32x16 (&acc)[
                     const long long ci = coff + (long long)row * p.ldc + (n0 + b * 64) / 2 + w;
                     if (p.out_bf16) {
                         if (vec_store) {
-                            bf16x4_t o;
-#pragma unroll
-                            for (int e = 0; e < 4; e++) o.v[e] = f2bf(v[e]);
-                            *reinterpret_cast<bf16x4_t*>(reinterpret_cast<HT*>(p.C) + ci) = o;
+                            st_half4(p.C, ci, v);
                         } else {
 #pragma unroll
-                            for (int e = 0; e < 4; e++) reinterpret_cast<HT*>(p.C)[ci + e] = f2bf(v[e]);
+                            for (int e = 0; e < 4; e++) st_half1(p.C, ci + e, v[e]);
                         }
                     } else {
 #pragma unroll
@@ -455,9 +481,10 @@ __device__ __forceinline__ void tile_epilogue_lds(const GemmP& p, f32x16 (&acc)[
                     if (p.residual) {
                         const long long ri = roff + (long long)row * p.ldr + col;
                         if (p.res_bf16) {
-                            const bf16x4_t r = *reinterpret_cast<const bf16x4_t*>(reinterpret_cast<const HT*>(p.residual) + ri);
+                            float r[4];
+                            ld_half4(p.residual, ri, r);
 #pragma unroll
-                            for (int e = 0; e < 4; e++) v[e] += bf2f(r.v[e]);
+                            for (int e = 0; e < 4; e++) v[e] += r[e];
                         } else {
                             const float4 r = *reinterpret_cast<const float4*>(reinterpret_cast<const float*>(p.residual) + ri);
                             v[0] += r.x; v[1] += r.y; v[2] += r.z; v[3] += r.w;
@@ -465,10 +492,7 @@ __device__ __forceinline__ void tile_epilogue_lds(const GemmP& p, f32x16 (&acc)[
                     }
                     const long long ci = coff + (long long)row * p.ldc + col;
                     if (p.out_bf16) {
-                        bf16x4_t o;
-#pragma unroll
-                        for (int e = 0; e < 4; e++) o.v[e] = f2bf(v[e]);
-                        *reinterpret_cast<bf16x4_t*>(reinterpret_cast<HT*>(p.C) + ci) = o;
+                        st_half4(p.C, ci, v);
                     } else {
                         *reinterpret_cast<float4*>(reinterpret_cast<float*>(p.C) + ci) = make_float4(v[0], v[1], v[2], v[3]);
                     }
@@ -810,6 +834,15 @@ __global__ __launch_bounds__(256, 2) void k_gemm_glds(GemmP p) {     // 2 waves 
         for (int j = 0; j < TN; j++)
 #pragma unroll
             for (int r = 0; r < 16; r++) acc[i][j][r] = 0.f;
+#ifdef DWG_GEMM_X_TU
+    f32x16 acx[TM][TN];                 // the two cross products al bh + ah bl (lo planes carry a factor 2^11: dwg_xfmt.h)
+#pragma unroll
+    for (int i = 0; i < TM; i++)
+#pragma unroll
+        for (int j = 0; j < TN; j++)
+#pragma unroll
+            for (int r = 0; r < 16; r++) acx[i][j][r] = 0.f;
+#endif
     typename ALoaderOf<BM, AKIND>::type la;
     GldsLoader<BN, false> lb;
     la.init(A, p.sam, p.M, m0, kbeg, kend, p.conv);
@@ -832,6 +865,37 @@ __global__ __launch_bounds__(256, 2) void k_gemm_glds(GemmP p) {     // 2 waves 
         if (p.dbg == 1) { cur = cur + 1 == S ? 0 : cur + 1; nxt = nxt + 1 == S ? 0 : nxt + 1; continue; }
         const unsigned char* ta = smem_raw + cur * STAGE + (wm * TM * 32 + frow) * 128;
         const unsigned char* tb = smem_raw + cur * STAGE + ABYTES + (wn * 64 + frow) * 128;
+#ifdef DWG_GEMM_X_TU
+        // a 128-byte row holds 32 logical k: chunks [h0 l0 h1 l1 h2 l2 h3 l3], eight k each.  MFMA slab ks (16 k): lanes 0-31 take group 2 ks,
+        // lanes 32-63 group 2 ks + 1 -- hi chunk 4 ks + 2 fh, lo chunk right behind it.
+#pragma unroll
+        for (int ks = 0; ks < 2; ks++) {
+            const int offh = (((ks * 4 + fh * 2) ^ fx) << 4), offl = (((ks * 4 + fh * 2 + 1) ^ fx) << 4);
+            bf16x8 ah[TM], al[TM], bh[TN], bl[TN];
+#pragma unroll
+            for (int i = 0; i < TM; i++) {
+                ah[i] = *reinterpret_cast<const bf16x8*>(ta + i * 32 * 128 + offh);
+                al[i] = *reinterpret_cast<const bf16x8*>(ta + i * 32 * 128 + offl);
+            }
+#pragma unroll
+            for (int j = 0; j < TN; j++) {
+                bh[j] = *reinterpret_cast<const bf16x8*>(tb + j * 32 * 128 + offh);
+                bl[j] = *reinterpret_cast<const bf16x8*>(tb + j * 32 * 128 + offl);
+            }
+#pragma unroll
+            for (int i = 0; i < TM; i++)
+#pragma unroll
+                for (int j = 0; j < TN; j++) acc[i][j] = DWG_MFMA16(bh[j], ah[i], acc[i][j]);   // transposed: see tile_epilogue_t
+#pragma unroll
+            for (int i = 0; i < TM; i++)
+#pragma unroll
+                for (int j = 0; j < TN; j++) acx[i][j] = DWG_MFMA16(bl[j], ah[i], acx[i][j]);
+#pragma unroll
+            for (int i = 0; i < TM; i++)
+#pragma unroll
+                for (int j = 0; j < TN; j++) acx[i][j] = DWG_MFMA16(bh[j], al[i], acx[i][j]);
+        }
+#else
 #pragma unroll
         for (int ks = 0; ks < 4; ks++) {
             const int off = (((ks * 2 + fh) ^ fx) << 4);
@@ -845,9 +909,18 @@ __global__ __launch_bounds__(256, 2) void k_gemm_glds(GemmP p) {     // 2 waves 
 #pragma unroll
                 for (int j = 0; j < TN; j++) acc[i][j] = DWG_MFMA16(bf[j], af[i], acc[i][j]);   // transposed: see tile_epilogue_t
         }
+#endif
         cur = cur + 1 == S ? 0 : cur + 1; nxt = nxt + 1 == S ? 0 : nxt + 1;
     }
     wait_vmcnt<0>();                        // drain the zero-line tail loads before LDS is handed back
+#ifdef DWG_GEMM_X_TU
+#pragma unroll
+    for (int i = 0; i < TM; i++)
+#pragma unroll
+        for (int j = 0; j < TN; j++)
+#pragma unroll
+            for (int r = 0; r < 16; r++) acc[i][j][r] = fmaf(acx[i][j][r], DWG_X_LO_INV, acc[i][j][r]);
+#endif
     constexpr int NPASS = EpiLds<BN>::passes((size_t)S * STAGE);
     static_assert((size_t)S * STAGE >= EpiLds<BN>::bytes(NPASS), "epilogue staging fits in the operand stages");
     tile_epilogue_lds<BN, NPASS, TM, TN, false>(p, acc, reinterpret_cast<float*>(smem_raw), n0, wm, wn, lane, tid, ks_id, z1 * p.bC1 + z2 * p.bC2,
@@ -858,6 +931,9 @@ __global__ __launch_bounds__(256, 2) void k_gemm_glds(GemmP p) {     // 2 waves 
 // dgrad) convolution not counted.
 static double gemm_flops(const GemmP& p, int batch) {
     double f = 2.0 * p.M * p.N * p.K * batch;
+#ifdef DWG_GEMM_X_TU
+    f *= 0.5;           // p.K counts physical halves (hi + lo plane); the three MFMAs per product are ONE algorithmic multiply-add
+#endif
     if (p.conv.enabled && p.conv.dil > 1) f /= (double)(p.conv.dil * p.conv.dil);
     return f;
 }
@@ -979,6 +1055,15 @@ __global__ __launch_bounds__(256, 2) void k_conv3x3_patch(GemmP p) {   // 2 wave
         for (int j = 0; j < TN; j++)
 #pragma unroll
             for (int r = 0; r < 16; r++) acc[i][j][r] = 0.f;
+#ifdef DWG_GEMM_X_TU
+    f32x16 acx[TM][TN];
+#pragma unroll
+    for (int i = 0; i < TM; i++)
+#pragma unroll
+        for (int j = 0; j < TN; j++)
+#pragma unroll
+            for (int r = 0; r < 16; r++) acx[i][j][r] = 0.f;
+#endif
     // this lane's output pixels (rows of the A operand): r = (wm*TM + i)*32 + (lane & 31) -> (oy, ox) = (r >> 4, r & 15)
     int pbase[TM];
 #pragma unroll
@@ -1001,6 +1086,12 @@ __global__ __launch_bounds__(256, 2) void k_conv3x3_patch(GemmP p) {   // 2 wave
     // 9 taps unrolled: the tap's patch offset is an immediate and there is no step -> (slab, tap) division in the loop
     for (int cc = cc0; cc < ncc; cc++) {
         const unsigned char* pa = sP + (cc & 1) * PBYTES;
+#ifdef DWG_GEMM_X_TU
+        // two accumulator sets leave no room for the 9 x TM x 4 loop-invariant fragment addresses the compiler otherwise hoists out of this loop
+        // (304 bytes of scratch per lane in the 128-wide instantiation): launder the pixel bases so they are recomputed next to their reads
+#pragma unroll
+        for (int i = 0; i < TM; i++) asm volatile("" : "+v"(pbase[i]));
+#endif
 #pragma unroll
         for (int tap = 0; tap < 9; tap++) {
             const int par = (cc + tap) & 1;                     // step parity: 9 steps per slab
@@ -1010,6 +1101,36 @@ __global__ __launch_bounds__(256, 2) void k_conv3x3_patch(GemmP p) {   // 2 wave
             if (tap == 0 && cc + 1 < ncc) issue_patch(cc + 1, sP + ((cc + 1) & 1) * PBYTES);   // a full slab ahead
             const unsigned char* tb = sB + par * BBYTES + (wn * 64 + frow) * 128;
             const int toff = (tap / 3) * WP + (tap % 3);
+#ifdef DWG_GEMM_X_TU
+#pragma unroll
+            for (int ks = 0; ks < 2; ks++) {
+                const int cl = ks * 4 + fh * 2;              // hi chunk; the lo chunk is cl + 1 (see k_gemm_glds)
+                bf16x8 ah[TM], al[TM], bh[TN], bl[TN];
+#pragma unroll
+                for (int i = 0; i < TM; i++) {
+                    const int pi = pbase[i] + toff, sw = (pi >> 1) & 7;
+                    ah[i] = *reinterpret_cast<const bf16x8*>(pa + pi * 128 + ((cl ^ sw) << 4));
+                    al[i] = *reinterpret_cast<const bf16x8*>(pa + pi * 128 + (((cl + 1) ^ sw) << 4));
+                }
+#pragma unroll
+                for (int j = 0; j < TN; j++) {
+                    bh[j] = *reinterpret_cast<const bf16x8*>(tb + j * 32 * 128 + ((cl ^ fx) << 4));
+                    bl[j] = *reinterpret_cast<const bf16x8*>(tb + j * 32 * 128 + (((cl + 1) ^ fx) << 4));
+                }
+#pragma unroll
+                for (int i = 0; i < TM; i++)
+#pragma unroll
+                    for (int j = 0; j < TN; j++) acc[i][j] = DWG_MFMA16(bh[j], ah[i], acc[i][j]);   // transposed
+#pragma unroll
+                for (int i = 0; i < TM; i++)
+#pragma unroll
+                    for (int j = 0; j < TN; j++) acx[i][j] = DWG_MFMA16(bl[j], ah[i], acx[i][j]);
+#pragma unroll
+                for (int i = 0; i < TM; i++)
+#pragma unroll
+                    for (int j = 0; j < TN; j++) acx[i][j] = DWG_MFMA16(bh[j], al[i], acx[i][j]);
+            }
+#else
 #pragma unroll
             for (int ks = 0; ks < 4; ks++) {
                 const int cl = ks * 2 + fh;
@@ -1026,8 +1147,17 @@ __global__ __launch_bounds__(256, 2) void k_conv3x3_patch(GemmP p) {   // 2 wave
 #pragma unroll
                     for (int j = 0; j < TN; j++) acc[i][j] = DWG_MFMA16(bf[j], af[i], acc[i][j]);   // transposed
             }
+#endif
         }
     }
+#ifdef DWG_GEMM_X_TU
+#pragma unroll
+    for (int i = 0; i < TM; i++)
+#pragma unroll
+        for (int j = 0; j < TN; j++)
+#pragma unroll
+            for (int r = 0; r < 16; r++) acc[i][j][r] = fmaf(acx[i][j][r], DWG_X_LO_INV, acc[i][j][r]);
+#endif
     // epilogue: tile-local row rr <-> output pixel (y0 + rr / 16, x0 + rr % 16) of image img
     constexpr int NPASS = EpiLds<BN>::passes((size_t)2 * PBYTES + 2 * BBYTES);
     static_assert((size_t)2 * PBYTES + 2 * BBYTES >= EpiLds<BN>::bytes(NPASS), "epilogue staging fits in the patch / weight buffers");
@@ -1137,22 +1267,56 @@ static int pick_mode(const void* base, long long srow, long long sk, int nrows, 
 
 }  // namespace
 
+#ifdef DWG_GEMM_X_TU
+// The split-precision unit takes the LOGICAL descriptor (strides and K in fp32-sized elements, dwg_gemm.h) and hands the kernels the PHYSICAL
+// one: a 2-byte tensor with 2 K columns.  C / residual indexing stays logical (st_half4 / ld_half4 know the layout).
+static bool x_physical(const dwg_gemm_desc* d, dwg_gemm_desc* o) {
+    if (!d) return false;
+    *o = *d;
+    if (d->dtype != DWG_DTYPE_F32X) return false;
+    if (d->K % 8 || d->a_k_stride != 1 || d->b_k_stride != 1) return false;                    // both operands K-contiguous, whole 8-groups
+    if ((d->a_row_stride | d->b_row_stride | d->a_batch1_stride | d->a_batch2_stride | d->b_batch1_stride | d->b_batch2_stride) % 8) return false;
+    if (d->out_dtype == DWG_DTYPE_F32X && ((d->ldc | d->c_batch1_stride | d->c_batch2_stride) % 8 || ((uintptr_t)d->C % 16))) return false;
+    if (d->residual && d->residual_dtype == DWG_DTYPE_F32X &&
+        (((d->ldr ? d->ldr : d->ldc) | d->r_batch1_stride | d->r_batch2_stride) % 8 || ((uintptr_t)d->residual % 16))) return false;
+    if (d->act == DWG_ACT_GEGLU_PAIR && d->out_dtype == DWG_DTYPE_F32X && d->N % 16) return false;
+    if (d->conv_enabled && (d->conv_cin % 8 || (d->A2 && d->conv_cin1 % 8))) return false;
+    o->K = 2 * d->K;
+    o->a_row_stride = 2 * d->a_row_stride; o->b_row_stride = 2 * d->b_row_stride;
+    o->a_batch1_stride = 2 * d->a_batch1_stride; o->a_batch2_stride = 2 * d->a_batch2_stride;
+    o->b_batch1_stride = 2 * d->b_batch1_stride; o->b_batch2_stride = 2 * d->b_batch2_stride;
+    o->conv_cin = 2 * d->conv_cin; o->conv_cin1 = 2 * d->conv_cin1;
+    return true;
+}
+#endif
+
 extern "C" {
 
-#ifdef DWG_GEMM_F16_TU
+#if defined(DWG_GEMM_X_TU)
+#define DWG_GEMM_FN dwg_gemm_x
+#define DWG_GEMM_WS_FN dwg_gemm_workspace_bytes_x
+#elif defined(DWG_GEMM_F16_TU)
 #define DWG_GEMM_FN dwg_gemm_f16
 #define DWG_GEMM_WS_FN dwg_gemm_workspace_bytes_f16
 #else
 #define DWG_GEMM_FN dwg_gemm
 #define DWG_GEMM_WS_FN dwg_gemm_workspace_bytes
-// the fp16-operand unit (gemm_f16.hip): same descriptor, dtype == DWG_DTYPE_F16
+// the fp16-operand unit (gemm_f16.hip) and the split-precision unit (gemm_x.hip): same descriptor, dtype == DWG_DTYPE_F16 / DWG_DTYPE_F32X
 size_t dwg_gemm_workspace_bytes_f16(const dwg_gemm_desc* d);
 int dwg_gemm_f16(const dwg_gemm_desc* d, dwg_stream_t stream);
+size_t dwg_gemm_workspace_bytes_x(const dwg_gemm_desc* d);
+int dwg_gemm_x(const dwg_gemm_desc* d, dwg_stream_t stream);
 #endif
 
 size_t DWG_GEMM_WS_FN(const dwg_gemm_desc* d) {
-#ifndef DWG_GEMM_F16_TU
+#if !defined(DWG_GEMM_F16_TU) && !defined(DWG_GEMM_X_TU)
     if (d && d->dtype == DWG_DTYPE_F16) return dwg_gemm_workspace_bytes_f16(d);
+    if (d && d->dtype == DWG_DTYPE_F32X) return dwg_gemm_workspace_bytes_x(d);
+#endif
+#ifdef DWG_GEMM_X_TU
+    dwg_gemm_desc xd;
+    if (!x_physical(d, &xd)) return 0;
+    d = &xd;
 #endif
     if (!d || d->batch1 * d->batch2 != 1 || d->M <= 0 || d->N <= 0) return 0;
     if ((long long)d->M * d->N >= (1LL << 33)) return 0;       // k_splitk_epilogue indexes the float4 pieces of C with 32 bits
@@ -1162,8 +1326,14 @@ size_t DWG_GEMM_WS_FN(const dwg_gemm_desc* d) {
 }
 
 int DWG_GEMM_FN(const dwg_gemm_desc* d, dwg_stream_t stream_) {
-#ifndef DWG_GEMM_F16_TU
+#if !defined(DWG_GEMM_F16_TU) && !defined(DWG_GEMM_X_TU)
     if (d && d->dtype == DWG_DTYPE_F16) return dwg_gemm_f16(d, stream_);
+    if (d && d->dtype == DWG_DTYPE_F32X) return dwg_gemm_x(d, stream_);
+#endif
+#ifdef DWG_GEMM_X_TU
+    dwg_gemm_desc xd;
+    if (!x_physical(d, &xd)) return DWG_E_ARG;
+    d = &xd;
 #endif
     if (!d || !d->A || !d->B || !d->C) return DWG_E_ARG;
     if (d->M < 0 || d->N < 0 || d->K < 0 || d->batch1 < 1 || d->batch2 < 1) return DWG_E_ARG;
@@ -1261,10 +1431,15 @@ int DWG_GEMM_FN(const dwg_gemm_desc* d, dwg_stream_t stream_) {
                 else if (akind == 1) launch_glds<128, 1>(p, batch, stream, name);
                 else launch_glds<128, 0>(p, batch, stream, name);
             }
-        } else if (narrow) dispatch_a<T, 64>(p, amode, bmode, batch, stream, name);
+        }
+#ifdef DWG_GEMM_X_TU
+        else return DWG_E_ARG;     // split-precision operands exist only for the direct-to-LDS kernels (K-contiguous, 16-byte aligned rows)
+#else
+        else if (narrow) dispatch_a<T, 64>(p, amode, bmode, batch, stream, name);
         else dispatch_a<T, 128>(p, amode, bmode, batch, stream, name);
+#endif
     } else {
-#ifdef DWG_GEMM_F16_TU
+#if defined(DWG_GEMM_F16_TU) || defined(DWG_GEMM_X_TU)
         return DWG_E_ARG;          // the exact-f32 kernels live in the bf16 unit
 #else
         // exact-f32 path (v_mfma_f32_32x32x2_f32): the avatar's MLPs, and every layer of the fp32 denoiser / VAE plans -- the precision the

@@ -5,7 +5,7 @@ import torch
 
 from . import _lib
 
-F32, BF16, F16 = 0, 1, 2
+F32, BF16, F16, F32X = 0, 1, 2, 3        # DWG_DTYPE_* (include/dwg_types.h); F32X tensors are int32-typed (xfmt.py)
 ACT = {None: 0, "none": 0, "relu": 1, "leaky_relu": 2, "silu": 3, "gelu": 4, "sigmoid": 5, "geglu_pair": 6}
 
 
@@ -42,7 +42,9 @@ def _dt(t):
         return BF16
     if t.dtype == torch.float16:
         return F16
-    raise TypeError("dwg gemm supports float32, bfloat16 and float16 tensors, got %s" % t.dtype)
+    if t.dtype == torch.int32:
+        return F32X
+    raise TypeError("dwg gemm supports float32, bfloat16, float16 and f32x (int32-typed, xfmt.py) tensors, got %s" % t.dtype)
 
 
 def _stream(t):

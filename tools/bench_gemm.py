@@ -4,7 +4,14 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 import torch
 import dwg_import  # noqa
-from dreamwaltz_g_amd import gemm, _lib
+from dreamwaltz_g_amd import gemm, _lib, xfmt
+
+DT = (sys.argv[1] if len(sys.argv) > 1 else "bf16")       # bf16 | f16 | f32 | f32x
+ODT = {"bf16": torch.bfloat16, "f16": torch.float16, "f32": torch.float32, "f32x": torch.int32}[DT]
+
+
+def cv(t):
+    return xfmt.pack(t) if DT == "f32x" else t.to(ODT)
 
 
 def timeit(fn, n=20):
@@ -35,9 +42,9 @@ def finish(d):
 
 
 def conv_case(name, B, H, Cin, Cout, k=3, stride=1):
-    x = torch.randn(B, H, H, Cin, device="cuda").bfloat16(); w = torch.randn(Cout, k, k, Cin, device="cuda").bfloat16() * 0.02
+    x = cv(torch.randn(B, H, H, Cin, device="cuda")); w = cv(torch.randn(Cout, k, k, Cin, device="cuda") * 0.02)
     Ho = H // stride
-    y = torch.empty(B, Ho, Ho, Cout, device="cuda", dtype=torch.bfloat16)
+    y = torch.empty(B, Ho, Ho, Cout, device="cuda", dtype=ODT)
     M, N, K = B * Ho * Ho, Cout, k * k * Cin
     d = gemm.gemm_raw(x, w, y, M, N, K, (0, 1), (K, 1), Cout, conv=(Cin, H, H, Ho, Ho, k, k, stride, k // 2, k // 2, 1), run=False)
     finish(d)
@@ -46,8 +53,8 @@ def conv_case(name, B, H, Cin, Cout, k=3, stride=1):
 
 
 def lin_case(name, M, N, K):
-    x = torch.randn(M, K, device="cuda").bfloat16(); w = torch.randn(N, K, device="cuda").bfloat16() * 0.02
-    y = torch.empty(M, N, device="cuda", dtype=torch.bfloat16)
+    x = cv(torch.randn(M, K, device="cuda")); w = cv(torch.randn(N, K, device="cuda") * 0.02)
+    y = torch.empty(M, N, device="cuda", dtype=ODT)
     d = gemm.gemm_raw(x, w, y, M, N, K, (K, 1), (K, 1), N, run=False)
     finish(d)
     ms = timeit(lambda: gemm.run_desc(d, st))
@@ -79,5 +86,6 @@ lin_case("ff_in 16^2", 512, 10240, 1280)
 lin_case("ff_out 16^2", 512, 1280, 5120)
 lin_case("kv text", 154, 640, 768)
 lin_case("big 4096^3", 4096, 4096, 4096)
+print("dtype", DT)
 for r in rows:
     print("%-30s M=%7d N=%5d K=%6d  %8.3f ms  %8.1f TF/s" % r)
