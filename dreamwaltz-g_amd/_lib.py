@@ -62,6 +62,9 @@ SIGNATURES = {
     "dwg_gemm": (ctypes.c_int, [_vp, _vp]),
     "dwg_gemm_workspace_bytes": (_sz, [_vp]),
     "dwg_transpose_2byte": (ctypes.c_int, [_i32, _i32, _i32, _vp, _i64, _i64, _vp, _i64, _i64, _vp]),
+    "dwg_transpose_dt": (ctypes.c_int, [_i32, _i32, _i32, _i32, _vp, _i64, _i64, _vp, _i64, _i64, _vp]),
+    "dwg_xfmt_pack": (ctypes.c_int, [_i64, _vp, _vp, _vp]),
+    "dwg_xfmt_unpack": (ctypes.c_int, [_i64, _vp, _vp, _vp]),
     # include/dwg_elementwise.h
     "dwg_act_backward_colsum": (ctypes.c_int, [_i32, _i32, _i32, _vp, _vp, _vp, _vp, _vp]),
     "dwg_mlp_chain_forward": (ctypes.c_int, [_i32, _i32, _vp, _i32, _i32, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i32, _vp]),

@@ -245,10 +245,15 @@ int dwg_attention_forward_f16(int32_t B, int32_t H, int32_t Nq, int32_t Nk, int3
                               const void* K, int64_t ldk, int64_t bk, const void* V, int64_t ldv, int64_t bv, void* O, int64_t ldo,
                               int64_t bo, float scale, dwg_stream_t stream_);         // attention_f16.hip
 
+int dwg_attention_forward_x(int32_t B, int32_t H, int32_t Nq, int32_t Nk, int32_t d, const void* Q, int64_t ldq, int64_t bq,
+                            const void* K, int64_t ldk, int64_t bk, const void* V, int64_t ldv, int64_t bv, void* O, int64_t ldo,
+                            int64_t bo, float scale, dwg_stream_t stream_);           // attention_x.hip (split-precision operands)
+
 int dwg_attention_forward_dt(int32_t dtype, int32_t B, int32_t H, int32_t Nq, int32_t Nk, int32_t d, const void* Q, int64_t ldq, int64_t bq,
                              const void* K, int64_t ldk, int64_t bk, const void* V, int64_t ldv, int64_t bv, void* O, int64_t ldo,
                              int64_t bo, float scale, dwg_stream_t stream) {
     if (dtype == DWG_DTYPE_F16) return dwg_attention_forward_f16(B, H, Nq, Nk, d, Q, ldq, bq, K, ldk, bk, V, ldv, bv, O, ldo, bo, scale, stream);
+    if (dtype == DWG_DTYPE_F32X) return dwg_attention_forward_x(B, H, Nq, Nk, d, Q, ldq, bq, K, ldk, bk, V, ldv, bv, O, ldo, bo, scale, stream);
     if (dtype != DWG_DTYPE_BF16) return DWG_E_ARG;          // fp32 plans run attention as QK^T -> softmax -> PV on dwg_gemm
     return dwg_attention_forward(B, H, Nq, Nk, d, Q, ldq, bq, K, ldk, bk, V, ldv, bv, O, ldo, bo, scale, stream);
 }

@@ -1,0 +1,289 @@
+// attention_x.hip -- fused (flash-style) multi-head attention forward on SPLIT-PRECISION ("f32x", dwg_xfmt.h) operands: fp32-grade
+// scores, probabilities and outputs at the 16-bit MFMA rate.  Same wave64 design as attention.hip (one lane = one query column of
+// S^T = K Q^T, online softmax in registers, O^T += V^T P^T with P taken straight from the accumulator registers), with every product
+// formed from three v_mfma_f32_32x32x16_f16:   a b ~= ah bh + 2^-11 (al bh + ah bl)
+//   * Q, K, V arrive as hi / lo fp16 planes (32 bytes per 8 channels): the staging pass writes the two planes of a K / V^T tile to
+//     separate LDS images, the fragment reads are the bf16 kernel's;
+//   * S^T is accumulated in two register sets (main, cross) and joined before the softmax;
+//   * P (in (0, 1]) is split in registers: ph = fp16(p), pl = fp16((p - ph) 2^11) -- four VALU instructions per score next to the six
+//     of the softmax;
+//   * O^T likewise in two accumulator sets, joined in the epilogue, which splits the result into the output's planes.
+// Used by the "f32x" denoiser plans for every attention site of the SD-1.5 UNet / ControlNet (boundary B4, controlnet.py:98-114); the
+// reference runs these sites in fp32 (configs/__init__.py:236,241) through diffusers' scaled_dot_product_attention.
+#include "dwg_common.h"
+#include <cstdlib>
+#include "dwg_prof_internal.h"
+#include "../../include/dwg_nn.h"
+#include "dwg_xfmt.h"
+
+namespace {
+
+typedef _Float16 HT;
+typedef __attribute__((ext_vector_type(8))) HT h8;
+typedef __attribute__((ext_vector_type(4))) HT h4;
+typedef __attribute__((ext_vector_type(16))) float f32x16;
+#define MFMA16(a, b, c) __builtin_amdgcn_mfma_f32_32x32x16_f16(a, b, c, 0, 0, 0)
+
+struct AttnXP {
+    const dwg_xs* Q; const dwg_xs* K; const dwg_xs* V; dwg_xs* O;
+    int Nq, Nk, H, d;
+    long long ldq, ldk, ldv, ldo;          // row strides (logical elements)
+    long long bq, bk, bv, bo;              // per-image strides; head h starts at column h*d
+    float scale_log2;                      // softmax scale * log2(e)
+};
+
+// DK = head dim padded to a multiple of 16, DV = padded to a multiple of 32.  LD > 0: the head dim is exactly LD < DV and row LD of the hi
+// plane of V^T holds ONES (lo plane: zeros), so the PV MFMAs accumulate the softmax denominator (of the split P the MFMAs use) in
+// accumulator row LD of both sets -- see attention.hip.
+template <int DK, int DV, int LD, int MINB>
+__global__ __launch_bounds__(256, MINB) void k_flash_fwd_x(AttnXP p) {
+    constexpr int KT = 32;
+    constexpr int LDK = DK + 8;
+    constexpr int LDV = KT + 8;
+    constexpr int NKS = DK / 16, NVB = DV / 32;
+    constexpr int TILE_HALVES = 2 * KT * LDK + 2 * DV * LDV;               // K hi | K lo | V^T hi | V^T lo
+    constexpr int ROWB = DV * 4 + 16;                                      // bytes of one staged output row (f32x) + pad
+    constexpr int OUT_BYTES = 4 * 32 * ROWB;
+    constexpr bool STAGE = OUT_BYTES <= 56 * 1024;                         // d = 160 (8x8 / 16x16 latents, a few workgroups): rows go out from registers
+    constexpr int SMEM = (STAGE && OUT_BYTES > TILE_HALVES * 2) ? OUT_BYTES : TILE_HALVES * 2;
+    __shared__ __attribute__((aligned(16))) unsigned char smem[SMEM];
+    HT* sKh = reinterpret_cast<HT*>(smem);
+    HT* sKl = sKh + KT * LDK;
+    HT* sVh = sKl + KT * LDK;
+    HT* sVl = sVh + DV * LDV;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, half = lane >> 5, ql = lane & 31;
+    const int img = blockIdx.y / p.H, head = blockIdx.y % p.H;
+    const int q0 = blockIdx.x * 128 + wave * 32;
+    const dwg_xs* Q = p.Q + img * p.bq + (long long)head * p.d;
+    const dwg_xs* K = p.K + img * p.bk + (long long)head * p.d;
+    const dwg_xs* V = p.V + img * p.bv + (long long)head * p.d;
+    dwg_xs* O = p.O + img * p.bo + (long long)head * p.d;
+
+    // this lane's query row as MFMA B-operand fragments, both planes: element e of step s = Q[q][16 s + 8 half + e]
+    h8 qh[NKS], qlo[NKS];
+    {
+        const int q = q0 + ql;
+#pragma unroll
+        for (int s = 0; s < NKS; s++) {
+            const int c = 16 * s + 8 * half;
+            dwg_x8 v;
+#pragma unroll
+            for (int e = 0; e < 8; e++) { v.hi[e] = (HT)0.f; v.lo[e] = (HT)0.f; }
+            if (q < p.Nq && c < p.d) v = dwg_x8::load(Q + (long long)q * p.ldq + c);      // d % 8 == 0
+            qh[s] = v.hi; qlo[s] = v.lo;
+        }
+    }
+    f32x16 acc[NVB], acx[NVB];
+#pragma unroll
+    for (int j = 0; j < NVB; j++)
+#pragma unroll
+        for (int r = 0; r < 16; r++) { acc[j][r] = 0.f; acx[j][r] = 0.f; }
+    float m_run = -3.0e38f, acc_l = 0.f;
+
+    const int ntiles = (p.Nk + KT - 1) / KT;
+    constexpr int NKC = (KT * (DK / 8) + 255) / 256, NVC = (KT * (DV / 8) + 255) / 256;
+    dwg_x8 kreg[NKC], vreg[NVC];
+    int kkey[NKC], vkey[NVC];
+    bool vone[NVC];
+    const dwg_xs* kptr[NKC]; const dwg_xs* vptr[NVC];
+    int klds[NKC], vlds[NVC];              // LDS offsets in halves (hi plane; the lo plane sits at a constant distance), -1: none
+#pragma unroll
+    for (int i = 0; i < NKC; i++) {
+        const int c = tid + i * 256;
+        const int key = c / (DK / 8), dc = (c % (DK / 8)) * 8;
+        const bool on = c < KT * (DK / 8) && dc < p.d;
+        kkey[i] = on ? key : (1 << 30);
+        kptr[i] = K + (long long)key * p.ldk + dc;
+        klds[i] = c < KT * (DK / 8) ? key * LDK + dc : -1;
+    }
+#pragma unroll
+    for (int i = 0; i < NVC; i++) {
+        const int c = tid + i * 256;
+        const int key = c % KT, dc = (c / KT) * 8;
+        const bool on = c < KT * (DV / 8) && dc < p.d;
+        vkey[i] = on ? key : (1 << 30);
+        vone[i] = LD > 0 && c < KT * (DV / 8) && dc == LD;
+        vptr[i] = V + (long long)key * p.ldv + dc;
+        vlds[i] = c < KT * (DV / 8) ? dc * LDV + key : -1;
+    }
+    auto fetch = [&](int k0) {
+        dwg_x8 z, one0;
+#pragma unroll
+        for (int e = 0; e < 8; e++) { z.hi[e] = (HT)0.f; z.lo[e] = (HT)0.f; one0.hi[e] = (HT)(e == 0 ? 1.f : 0.f); one0.lo[e] = (HT)0.f; }
+#pragma unroll
+        for (int i = 0; i < NKC; i++)
+            kreg[i] = (long long)k0 + kkey[i] < p.Nk ? dwg_x8::load(kptr[i] + (long long)k0 * p.ldk) : z;
+#pragma unroll
+        for (int i = 0; i < NVC; i++)
+            vreg[i] = (long long)k0 + vkey[i] < p.Nk ? dwg_x8::load(vptr[i] + (long long)k0 * p.ldv) : (vone[i] ? one0 : z);
+    };
+    // K / V staging is software-pipelined through registers (tile t + 1 in flight while tile t is multiplied) -- except at d = 160, whose two
+    // accumulator sets leave no registers for it: there the tile is fetched right before it is staged (8x8 / 16x16 latents: a few tiles)
+    constexpr bool PF = DV <= 96;
+    if (PF && ntiles > 0) fetch(0);
+    for (int t = 0; t < ntiles; t++) {
+        const int k0 = t * KT;
+        if constexpr (!PF) fetch(k0);
+        __syncthreads();
+#pragma unroll
+        for (int i = 0; i < NKC; i++)
+            if (klds[i] >= 0) {
+                *reinterpret_cast<h8*>(sKh + klds[i]) = kreg[i].hi;
+                *reinterpret_cast<h8*>(sKl + klds[i]) = kreg[i].lo;
+            }
+#pragma unroll
+        for (int i = 0; i < NVC; i++)
+            if (vlds[i] >= 0) {
+#pragma unroll
+                for (int e = 0; e < 8; e++) { sVh[vlds[i] + e * LDV] = vreg[i].hi[e]; sVl[vlds[i] + e * LDV] = vreg[i].lo[e]; }
+            }
+        __syncthreads();
+        if (PF && t + 1 < ntiles) fetch(k0 + KT);
+        // S^T tile: rows = keys, cols = queries; main and cross sets
+        f32x16 s, sx;
+#pragma unroll
+        for (int r = 0; r < 16; r++) { s[r] = 0.f; sx[r] = 0.f; }
+#pragma unroll
+        for (int ks = 0; ks < NKS; ks++) {
+            const h8 kh = *reinterpret_cast<const h8*>(&sKh[ql * LDK + 16 * ks + 8 * half]);
+            const h8 kl = *reinterpret_cast<const h8*>(&sKl[ql * LDK + 16 * ks + 8 * half]);
+            s = MFMA16(kh, qh[ks], s);
+            sx = MFMA16(kl, qh[ks], sx);
+            sx = MFMA16(kh, qlo[ks], sx);
+        }
+#pragma unroll
+        for (int r = 0; r < 16; r++) s[r] = fmaf(sx[r], DWG_X_LO_INV, s[r]);
+        if (k0 + KT > p.Nk) {
+#pragma unroll
+            for (int r = 0; r < 16; r++) {
+                int key = k0 + (r & 3) + 8 * (r >> 2) + 4 * half;
+                if (key >= p.Nk) s[r] = -3.0e38f;
+            }
+        }
+        float mx = s[0];
+#pragma unroll
+        for (int r = 1; r < 16; r++) mx = fmaxf(mx, s[r]);
+        mx = fmaxf(mx, __shfl_xor(mx, 32));
+        const float m_new = fmaxf(m_run, mx * p.scale_log2);
+        float rs = 0.f;
+#pragma unroll
+        for (int r = 0; r < 16; r++) {
+            s[r] = __builtin_amdgcn_exp2f(fmaf(s[r], p.scale_log2, -m_new));
+            if constexpr (LD == 0) rs += s[r];
+        }
+        if constexpr (LD == 0) rs += __shfl_xor(rs, 32);
+        if (__any(m_new != m_run)) {
+            const float alpha = __builtin_amdgcn_exp2f(m_run - m_new);
+#pragma unroll
+            for (int j = 0; j < NVB; j++)
+#pragma unroll
+                for (int r = 0; r < 16; r++) { acc[j][r] *= alpha; acx[j][r] *= alpha; }
+            if constexpr (LD == 0) acc_l *= alpha;
+        }
+        if constexpr (LD == 0) acc_l += rs;
+        m_run = m_new;
+        // P^T as B operand, split into its planes: step st uses registers 8 st .. 8 st + 7 of this lane
+        h8 ph[2], pl[2];
+#pragma unroll
+        for (int st = 0; st < 2; st++)
+#pragma unroll
+            for (int e = 0; e < 8; e++) {
+                const float pv = s[8 * st + e];
+                const HT a = (HT)pv;
+                ph[st][e] = a; pl[st][e] = (HT)((pv - (float)a) * DWG_X_LO_SCALE);
+            }
+#pragma unroll
+        for (int j = 0; j < NVB; j++) {
+#pragma unroll
+            for (int st = 0; st < 2; st++) {
+                const int off = (32 * j + ql) * LDV + 16 * st + 4 * half;
+                const h4 a0 = *reinterpret_cast<const h4*>(sVh + off), a1 = *reinterpret_cast<const h4*>(sVh + off + 8);
+                const h4 b0 = *reinterpret_cast<const h4*>(sVl + off), b1 = *reinterpret_cast<const h4*>(sVl + off + 8);
+                h8 vh, vl;
+                vh[0] = a0[0]; vh[1] = a0[1]; vh[2] = a0[2]; vh[3] = a0[3]; vh[4] = a1[0]; vh[5] = a1[1]; vh[6] = a1[2]; vh[7] = a1[3];
+                vl[0] = b0[0]; vl[1] = b0[1]; vl[2] = b0[2]; vl[3] = b0[3]; vl[4] = b1[0]; vl[5] = b1[1]; vl[6] = b1[2]; vl[7] = b1[3];
+                acc[j] = MFMA16(vh, ph[st], acc[j]);
+                acx[j] = MFMA16(vl, ph[st], acx[j]);
+                acx[j] = MFMA16(vh, pl[st], acx[j]);
+            }
+        }
+    }
+    // epilogue: join the sets, O[q][dv] = acc / l; lane owns query column ql, register r of block j <-> dv = 32 j + (r&3) + 8 (r>>2) + 4 half,
+    // i.e. four consecutive channels (4 half .. 4 half + 3) of 8-group 4 j + (r >> 2): split and staged in LDS as f32x rows, then 16-byte stores.
+#pragma unroll
+    for (int j = 0; j < NVB; j++)
+#pragma unroll
+        for (int r = 0; r < 16; r++) acc[j][r] = fmaf(acx[j][r], DWG_X_LO_INV, acc[j][r]);
+    float l_run;
+    if constexpr (LD > 0) {
+        constexpr int W = LD % 32, R = (W & 3) + 4 * (W >> 3), HL = (W >> 2) & 1;
+        l_run = __shfl(acc[LD / 32][R], ql + 32 * HL);
+    } else {
+        l_run = acc_l;
+    }
+    const float inv = l_run > 0.f ? 1.f / l_run : 0.f;
+    if constexpr (!STAGE) {
+        const int q = q0 + ql;
+        if (q < p.Nq) {
+#pragma unroll
+            for (int j = 0; j < NVB; j++)
+#pragma unroll
+                for (int r4 = 0; r4 < 4; r4++) {
+                    const int dv = 32 * j + 8 * r4 + 4 * half;
+                    if (dv < p.d) {
+                        const float v[4] = {acc[j][4 * r4] * inv, acc[j][4 * r4 + 1] * inv, acc[j][4 * r4 + 2] * inv, acc[j][4 * r4 + 3] * inv};
+                        dwg_x_put4(O + (long long)q * p.ldo, dv, v);
+                    }
+                }
+        }
+        return;
+    }
+    __syncthreads();                                   // the K / V tiles are dead: their LDS becomes the output stage
+    unsigned char* myO = smem + wave * 32 * ROWB;
+#pragma unroll
+    for (int j = 0; j < NVB; j++)
+#pragma unroll
+        for (int r4 = 0; r4 < 4; r4++) {
+            h4 oh, ol;
+#pragma unroll
+            for (int e = 0; e < 4; e++) { HT a, b; dwg_x_split(acc[j][4 * r4 + e] * inv, a, b); oh[e] = a; ol[e] = b; }
+            unsigned char* g = myO + ql * ROWB + (4 * j + r4) * 32 + half * 8;
+            *reinterpret_cast<h4*>(g) = oh; *reinterpret_cast<h4*>(g + 16) = ol;
+        }
+    __syncthreads();
+    const int pieces = p.d / 4;                        // 16-byte pieces per row (two per 8-group)
+    for (int c = lane; c < 32 * pieces; c += 64) {
+        const int q = c / pieces, pc = c % pieces;
+        if (q0 + q < p.Nq)
+            *reinterpret_cast<uint4*>(reinterpret_cast<unsigned char*>(O + (long long)(q0 + q) * p.ldo) + pc * 16) =
+                *reinterpret_cast<const uint4*>(myO + q * ROWB + pc * 16);
+    }
+}
+
+}  // namespace
+
+extern "C" {
+
+int dwg_attention_forward_x(int32_t B, int32_t H, int32_t Nq, int32_t Nk, int32_t d, const void* Q, int64_t ldq, int64_t bq, const void* K,
+                            int64_t ldk, int64_t bk, const void* V, int64_t ldv, int64_t bv, void* O, int64_t ldo, int64_t bo, float scale,
+                            dwg_stream_t stream_) {
+    if (B <= 0 || H <= 0 || Nq <= 0 || Nk <= 0 || d <= 0 || d % 8 || d > 160 || !Q || !K || !V || !O) return DWG_E_ARG;
+    if ((ldq | ldk | ldv | ldo | bq | bk | bv | bo) % 8) return DWG_E_ARG;   // whole 8-channel groups
+    if (((uintptr_t)Q | (uintptr_t)K | (uintptr_t)V | (uintptr_t)O) % 16) return DWG_E_ARG;
+    AttnXP p{(const dwg_xs*)Q, (const dwg_xs*)K, (const dwg_xs*)V, (dwg_xs*)O, Nq, Nk, H, d, ldq, ldk, ldv, ldo, bq, bk, bv, bo,
+             scale * 1.4426950408889634f};
+    dim3 grid(dwg_cdiv(Nq, 128), B * H), block(256);
+    hipStream_t stream = (hipStream_t)stream_;
+    const double flops = 4.0 * B * H * (double)Nq * Nk * d;     // QK^T and PV on the logical head size, one multiply-add per product
+    if (d <= 32) DWG_LAUNCH_W("flash_attn_d32", "k_flash_fwd_x<32, 32, 0, 2>", flops, (k_flash_fwd_x<32, 32, 0, 2>), grid, block, 0, stream, p);
+    else if (d == 40) DWG_LAUNCH_W("flash_attn_d48", "k_flash_fwd_x<48, 64, 40, 2>", flops, (k_flash_fwd_x<48, 64, 40, 2>), grid, block, 0, stream, p);
+    else if (d <= 48) DWG_LAUNCH_W("flash_attn_d48", "k_flash_fwd_x<48, 64, 0, 2>", flops, (k_flash_fwd_x<48, 64, 0, 2>), grid, block, 0, stream, p);
+    else if (d <= 64) DWG_LAUNCH_W("flash_attn_d64", "k_flash_fwd_x<64, 64, 0, 2>", flops, (k_flash_fwd_x<64, 64, 0, 2>), grid, block, 0, stream, p);
+    else if (d == 80) DWG_LAUNCH_W("flash_attn_d96", "k_flash_fwd_x<96, 96, 80, 1>", flops, (k_flash_fwd_x<96, 96, 80, 1>), grid, block, 0, stream, p);
+    else if (d <= 96) DWG_LAUNCH_W("flash_attn_d96", "k_flash_fwd_x<96, 96, 0, 1>", flops, (k_flash_fwd_x<96, 96, 0, 1>), grid, block, 0, stream, p);
+    else DWG_LAUNCH_W("flash_attn_d160", "k_flash_fwd_x<160, 160, 0, 1>", flops, (k_flash_fwd_x<160, 160, 0, 1>), grid, block, 0, stream, p);
+    DWG_RETURN_IF_LAUNCH_FAILED();
+    return DWG_OK;
+}
+
+}  // extern "C"

@@ -3,6 +3,7 @@
 #include "dwg_common.h"
 #include "dwg_prof_internal.h"
 #include "../../include/dwg_elementwise.h"
+#include "dwg_xfmt.h"
 
 namespace {
 
@@ -340,6 +341,62 @@ __global__ __launch_bounds__(256) void k_cast_f32_t(long long n, const float* __
     for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long long)gridDim.x * 256) dst[i] = (T)src[i];
 }
 
+// ---- the split-precision f32x format (dwg_xfmt.h): fp32 <-> hi / lo fp16 planes, 8 channels (32 bytes) per thread and trip ----
+__global__ __launch_bounds__(256) void k_x_pack(long long n8, const float* __restrict__ src, dwg_xs* __restrict__ dst) {
+    for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < n8; i += (long long)gridDim.x * 256) {
+        const float4 a = reinterpret_cast<const float4*>(src)[2 * i], b = reinterpret_cast<const float4*>(src)[2 * i + 1];
+        const float v[8] = {a.x, a.y, a.z, a.w, b.x, b.y, b.z, b.w};
+        dwg_x8 o;
+#pragma unroll
+        for (int e = 0; e < 8; e++) o.set(e, v[e]);
+        o.store(dst + 8 * i);
+    }
+}
+__global__ __launch_bounds__(256) void k_x_unpack(long long n8, const dwg_xs* __restrict__ src, float* __restrict__ dst) {
+    for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < n8; i += (long long)gridDim.x * 256) {
+        const dwg_x8 x = dwg_x8::load(src + 8 * i);
+        reinterpret_cast<float4*>(dst)[2 * i] = make_float4(x.get(0), x.get(1), x.get(2), x.get(3));
+        reinterpret_cast<float4*>(dst)[2 * i + 1] = make_float4(x.get(4), x.get(5), x.get(6), x.get(7));
+    }
+}
+__global__ __launch_bounds__(256) void k_add_x(long long n8, const dwg_xs* __restrict__ a, const dwg_xs* __restrict__ b, dwg_xs* __restrict__ out) {
+    for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < n8; i += (long long)gridDim.x * 256) {
+        const dwg_x8 x = dwg_x8::load(a + 8 * i), y = dwg_x8::load(b + 8 * i);
+        dwg_x8 o;
+#pragma unroll
+        for (int e = 0; e < 8; e++) o.set(e, x.get(e) + y.get(e));
+        o.store(out + 8 * i);
+    }
+}
+// out[b][c][r] = in[b][r][c] for f32x tensors (the 8-channel groups run along c on the way in, along r on the way out): 64 x 64 logical
+// tiles decoded into LDS as floats, re-split for the other axis.  R % 8 == 0, C % 8 == 0.
+__global__ __launch_bounds__(256) void k_transpose_x(int R, int C, const dwg_xs* __restrict__ in, long long ld_in, long long bs_in,
+                                                     dwg_xs* __restrict__ out, long long ld_out, long long bs_out) {
+    __shared__ float tile[64][65];
+    const int tid = threadIdx.x;
+    const int r0 = blockIdx.y * 64, c0 = blockIdx.x * 64;
+    in += (long long)blockIdx.z * bs_in; out += (long long)blockIdx.z * bs_out;
+#pragma unroll
+    for (int i = 0; i < 2; i++) {
+        const int idx = tid + i * 256, r = idx >> 3, ch = (idx & 7) * 8;
+        if (r0 + r < R && c0 + ch < C) {
+            const dwg_x8 v = dwg_x8::load(in + (long long)(r0 + r) * ld_in + c0 + ch);
+#pragma unroll
+            for (int e = 0; e < 8; e++) tile[r][ch + e] = v.get(e);
+        }
+    }
+    __syncthreads();
+#pragma unroll
+    for (int i = 0; i < 2; i++) {
+        const int idx = tid + i * 256, c = idx >> 3, rh = (idx & 7) * 8;
+        if (c0 + c >= C || r0 + rh >= R) continue;
+        dwg_x8 o;
+#pragma unroll
+        for (int k = 0; k < 8; k++) o.set(k, tile[rh + k][c]);
+        o.store(out + (long long)(c0 + c) * ld_out + r0 + rh);
+    }
+}
+
 static int grid_for(long long n) { long long b = (n + 255) / 256; if (b < 1) b = 1; if (b > 4096) b = 4096; return (int)b; }
 
 // out[b, 2i+py, 2j+px, :] = sub[py*2+px][b, i, j, :]  (16-byte pieces; C % 8 == 0)
@@ -473,6 +530,9 @@ int dwg_add_dt(int32_t dtype, int64_t n, const void* a, const void* b, void* out
     else if (dtype == DWG_DTYPE_F32)
         DWG_LAUNCH("add_f32", k_add_t<float>, dim3(grid_for(n / 8)), dim3(256), 0, (hipStream_t)stream, (long long)(n / 8), (const float*)a,
                    (const float*)b, (float*)out);
+    else if (dtype == DWG_DTYPE_F32X)
+        DWG_LAUNCH("add_f32x", k_add_x, dim3(grid_for(n / 8)), dim3(256), 0, (hipStream_t)stream, (long long)(n / 8), (const dwg_xs*)a,
+                   (const dwg_xs*)b, (dwg_xs*)out);
     else return DWG_E_ARG;
     DWG_RETURN_IF_LAUNCH_FAILED();
     return DWG_OK;
@@ -486,6 +546,7 @@ int dwg_cast_f32_to_dt(int32_t dtype, int64_t n, const float* src, void* dst, dw
         DWG_LAUNCH("cast_f32_f16", k_cast_f32_t<_Float16>, dim3(grid_for(n)), dim3(256), 0, (hipStream_t)stream, (long long)n, src, (_Float16*)dst);
     else if (dtype == DWG_DTYPE_F32)
         DWG_LAUNCH("cast_f32_f32", k_cast_f32_t<float>, dim3(grid_for(n)), dim3(256), 0, (hipStream_t)stream, (long long)n, src, (float*)dst);
+    else if (dtype == DWG_DTYPE_F32X) return dwg_xfmt_pack(n, src, dst, stream);
     else return DWG_E_ARG;
     DWG_RETURN_IF_LAUNCH_FAILED();
     return DWG_OK;
@@ -536,6 +597,36 @@ int dwg_interleave2x2(int32_t B, int32_t Ho, int32_t Wo, int32_t C, const void* 
     long long blocks = (n + 255) / 256; if (blocks > 8192) blocks = 8192;
     DWG_LAUNCH("interleave2x2", k_interleave2x2, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, B, Ho, Wo, C / 8, (const uint4*)s00,
                (const uint4*)s01, (const uint4*)s10, (const uint4*)s11, (uint4*)out);
+    DWG_RETURN_IF_LAUNCH_FAILED();
+    return DWG_OK;
+}
+
+int dwg_xfmt_pack(int64_t n, const float* src, void* dst, dwg_stream_t stream) {
+    if (n < 0 || n % 8 || !src || !dst || ((uintptr_t)src | (uintptr_t)dst) % 16) return DWG_E_ARG;
+    if (n == 0) return DWG_OK;
+    DWG_LAUNCH("xfmt_pack", k_x_pack, dim3(grid_for(n / 8)), dim3(256), 0, (hipStream_t)stream, (long long)(n / 8), src, (dwg_xs*)dst);
+    DWG_RETURN_IF_LAUNCH_FAILED();
+    return DWG_OK;
+}
+
+int dwg_xfmt_unpack(int64_t n, const void* src, float* dst, dwg_stream_t stream) {
+    if (n < 0 || n % 8 || !src || !dst || ((uintptr_t)src | (uintptr_t)dst) % 16) return DWG_E_ARG;
+    if (n == 0) return DWG_OK;
+    DWG_LAUNCH("xfmt_unpack", k_x_unpack, dim3(grid_for(n / 8)), dim3(256), 0, (hipStream_t)stream, (long long)(n / 8), (const dwg_xs*)src, dst);
+    DWG_RETURN_IF_LAUNCH_FAILED();
+    return DWG_OK;
+}
+
+int dwg_transpose_dt(int32_t dtype, int32_t batch, int32_t R, int32_t C, const void* in, int64_t ld_in, int64_t batch_stride_in, void* out,
+                     int64_t ld_out, int64_t batch_stride_out, dwg_stream_t stream) {
+    if (dtype == DWG_DTYPE_BF16 || dtype == DWG_DTYPE_F16)
+        return dwg_transpose_2byte(batch, R, C, in, ld_in, batch_stride_in, out, ld_out, batch_stride_out, stream);
+    if (dtype != DWG_DTYPE_F32X) return DWG_E_ARG;
+    if (batch < 0 || R < 0 || C < 0 || R % 8 || C % 8 || ld_in % 8 || ld_out % 8 || batch_stride_in % 8 || batch_stride_out % 8) return DWG_E_ARG;
+    if (batch == 0 || R == 0 || C == 0) return DWG_OK;
+    if (!in || !out || ((uintptr_t)in | (uintptr_t)out) % 16) return DWG_E_ARG;
+    DWG_LAUNCH("transpose_x", k_transpose_x, dim3((C + 63) / 64, (R + 63) / 64, batch), dim3(256), 0, (hipStream_t)stream, R, C,
+               (const dwg_xs*)in, (long long)ld_in, (long long)batch_stride_in, (dwg_xs*)out, (long long)ld_out, (long long)batch_stride_out);
     DWG_RETURN_IF_LAUNCH_FAILED();
     return DWG_OK;
 }

@@ -7,11 +7,34 @@
 #include <cstdlib>
 #include "dwg_prof_internal.h"
 #include "../../include/dwg_nn.h"
+#include "dwg_xfmt.h"
 
 namespace {
 
-// element type T of the activations: T (default plans), _Float16 (the reference's --optim.fp16 storage), float (its GS-stage fp32)
+// element type T of the activations: __bf16 (default plans), _Float16 (the reference's --optim.fp16 storage), float (its GS-stage fp32), dwg_xs
+// (the split-precision f32x plans: fp32-grade values as hi + lo fp16 halves, 32 bytes per 8 channels -- dwg_xfmt.h)
 template <typename T> using vec8 = T __attribute__((ext_vector_type(8)));
+
+// eight consecutive channels of one activation row in registers; every kernel below walks its tensor in these units
+template <typename T> struct V8 {
+    vec8<T> v;
+    __device__ __forceinline__ static V8 load(const T* p) { V8 r; r.v = *reinterpret_cast<const vec8<T>*>(p); return r; }
+    __device__ __forceinline__ void store(T* p) const { *reinterpret_cast<vec8<T>*>(p) = v; }
+    __device__ __forceinline__ float get(int e) const { return (float)v[e]; }
+    __device__ __forceinline__ void set(int e, float z) { v[e] = (T)z; }
+};
+template <> struct V8<dwg_xs> {
+    dwg_x8 v;
+    __device__ __forceinline__ static V8 load(const dwg_xs* p) { V8 r; r.v = dwg_x8::load(p); return r; }
+    __device__ __forceinline__ void store(dwg_xs* p) const { v.store(p); }
+    __device__ __forceinline__ float get(int e) const { return v.get(e); }
+    __device__ __forceinline__ void set(int e, float z) { v.set(e, z); }
+};
+// single elements of a row (the row softmax kernels): index in logical elements from a row start
+template <typename T> __device__ __forceinline__ float ld1(const T* row, long long j) { return (float)row[j]; }
+template <typename T> __device__ __forceinline__ void st1(T* row, long long j, float v) { row[j] = (T)v; }
+template <> __device__ __forceinline__ float ld1<dwg_xs>(const dwg_xs* row, long long j) { return dwg_x_get1(row, j); }
+template <> __device__ __forceinline__ void st1<dwg_xs>(dwg_xs* row, long long j, float v) { dwg_x_put1(row, j, v); }
 
 __device__ __forceinline__ float silu_f(float z) { return z / (1.f + __expf(-z)); }
 __device__ __forceinline__ float silu_grad(float z) { float s = 1.f / (1.f + __expf(-z)); return s * (1.f + z * (1.f - s)); }
@@ -63,11 +86,11 @@ __global__ __launch_bounds__(256) void k_gn_reduce(int HW, int C, int G, int pix
                 for (; deep && p + 3 * rows < p1; p += 4 * rows) {
                     const T* xp = x + ((size_t)b * HW + p) * C + (size_t)cc * 8;
                     const size_t st = (size_t)rows * C;
-                    const vec8<T> x0 = *reinterpret_cast<const vec8<T>*>(xp), x1 = *reinterpret_cast<const vec8<T>*>(xp + st),
-                                  x2 = *reinterpret_cast<const vec8<T>*>(xp + 2 * st), x3 = *reinterpret_cast<const vec8<T>*>(xp + 3 * st);
+                    const V8<T> x0 = V8<T>::load(xp), x1 = V8<T>::load(xp + st),
+                                  x2 = V8<T>::load(xp + 2 * st), x3 = V8<T>::load(xp + 3 * st);
 #pragma unroll
                     for (int e = 0; e < 8; e++) {
-                        const float a = (float)x0[e], bq = (float)x1[e], c = (float)x2[e], d = (float)x3[e];
+                        const float a = x0.get(e), bq = x1.get(e), c = x2.get(e), d = x3.get(e);
                         s1[e] += (a + bq) + (c + d); s2[e] += (a * a + bq * bq) + (c * c + d * d);
                     }
                 }
@@ -76,14 +99,14 @@ __global__ __launch_bounds__(256) void k_gn_reduce(int HW, int C, int G, int pix
                 // arithmetic itself costs 70 more registers and halves the occupancy)
                 size_t off = ((size_t)b * HW + p) * C + (size_t)cc * 8;
                 const size_t st = (size_t)rows * C;
-                vec8<T> xc = *reinterpret_cast<const vec8<T>*>(x + off), dc = *reinterpret_cast<const vec8<T>*>(dy + off);
+                V8<T> xc = V8<T>::load(x + off), dc = V8<T>::load(dy + off);
                 for (; p < p1; p += rows) {
-                    vec8<T> xn = xc, dn = dc;
-                    if (p + rows < p1) { xn = *reinterpret_cast<const vec8<T>*>(x + off + st); dn = *reinterpret_cast<const vec8<T>*>(dy + off + st); }
+                    V8<T> xn = xc, dn = dc;
+                    if (p + rows < p1) { xn = V8<T>::load(x + off + st); dn = V8<T>::load(dy + off + st); }
 #pragma unroll
                     for (int e = 0; e < 8; e++) {
-                        float xh = ((float)xc[e] - mu[e]) * rs[e];
-                        float g = (float)dc[e];
+                        float xh = (xc.get(e) - mu[e]) * rs[e];
+                        float g = dc.get(e);
                         if (silu) g *= silu_grad(xh * ga[e] + be[e]);
                         g *= ga[e];
                         s1[e] += g; s2[e] += g * xh;
@@ -93,16 +116,16 @@ __global__ __launch_bounds__(256) void k_gn_reduce(int HW, int C, int G, int pix
             }
             for (; p < p1; p += rows) {
                 size_t off = ((size_t)b * HW + p) * C + (size_t)cc * 8;
-                vec8<T> xv = *reinterpret_cast<const vec8<T>*>(x + off);
+                V8<T> xv = V8<T>::load(x + off);
                 if (!BWD) {
 #pragma unroll
-                    for (int e = 0; e < 8; e++) { float v = (float)xv[e]; s1[e] += v; s2[e] += v * v; }
+                    for (int e = 0; e < 8; e++) { float v = xv.get(e); s1[e] += v; s2[e] += v * v; }
                 } else {
-                    vec8<T> dv = *reinterpret_cast<const vec8<T>*>(dy + off);
+                    V8<T> dv = V8<T>::load(dy + off);
 #pragma unroll
                     for (int e = 0; e < 8; e++) {
-                        float xh = ((float)xv[e] - mu[e]) * rs[e];
-                        float g = (float)dv[e];
+                        float xh = (xv.get(e) - mu[e]) * rs[e];
+                        float g = dv.get(e);
                         if (silu) g *= silu_grad(xh * ga[e] + be[e]);
                         g *= ga[e];
                         s1[e] += g; s2[e] += g * xh;
@@ -173,28 +196,28 @@ __global__ __launch_bounds__(256) void k_gn_small(int HW, int C, int G, int gb, 
         int p = pl;
         const T* xp = xb + (size_t)p * C;
         for (; p + 7 * tp < HW; p += 8 * tp, xp += 8 * st) {       // eight independent loads in flight: the walk is L2 latency, nothing else
-            vec8<T> xv[8];
+            V8<T> xv[8];
 #pragma unroll
-            for (int u = 0; u < 8; u++) xv[u] = *reinterpret_cast<const vec8<T>*>(xp + u * st);
+            for (int u = 0; u < 8; u++) xv[u] = V8<T>::load(xp + u * st);
 #pragma unroll
             for (int u = 0; u < 8; u++)
 #pragma unroll
-                for (int e = 0; e < 8; e++) { const float a = (float)xv[u][e]; s[e] += a; q[e] = fmaf(a, a, q[e]); }
+                for (int e = 0; e < 8; e++) { const float a = xv[u].get(e); s[e] += a; q[e] = fmaf(a, a, q[e]); }
         }
         for (; p + 3 * tp < HW; p += 4 * tp, xp += 4 * st) {
-            const vec8<T> x0 = *reinterpret_cast<const vec8<T>*>(xp), x1 = *reinterpret_cast<const vec8<T>*>(xp + st),
-                          x2 = *reinterpret_cast<const vec8<T>*>(xp + 2 * st), x3 = *reinterpret_cast<const vec8<T>*>(xp + 3 * st);
+            const V8<T> x0 = V8<T>::load(xp), x1 = V8<T>::load(xp + st),
+                          x2 = V8<T>::load(xp + 2 * st), x3 = V8<T>::load(xp + 3 * st);
 #pragma unroll
             for (int e = 0; e < 8; e++) {
-                const float a0 = (float)x0[e], a1 = (float)x1[e], a2 = (float)x2[e], a3 = (float)x3[e];
+                const float a0 = x0.get(e), a1 = x1.get(e), a2 = x2.get(e), a3 = x3.get(e);
                 s[e] += (a0 + a1) + (a2 + a3);
                 q[e] += (a0 * a0 + a1 * a1) + (a2 * a2 + a3 * a3);
             }
         }
         for (; p < HW; p += tp, xp += st) {
-            const vec8<T> xv = *reinterpret_cast<const vec8<T>*>(xp);
+            const V8<T> xv = V8<T>::load(xp);
 #pragma unroll
-            for (int e = 0; e < 8; e++) { const float a = (float)xv[e]; s[e] += a; q[e] = fmaf(a, a, q[e]); }
+            for (int e = 0; e < 8; e++) { const float a = xv.get(e); s[e] += a; q[e] = fmaf(a, a, q[e]); }
         }
     }
     float* cs = lds; float* cq = lds + tp * nb; float* col = lds + 2 * tp * nb;
@@ -238,47 +261,47 @@ __global__ __launch_bounds__(256) void k_gn_small(int HW, int C, int G, int gb, 
     int p = pl;
     const T* xp = xb + (size_t)p * C; T* yp = yb + (size_t)p * C;
     for (; p + 7 * tp < HW; p += 8 * tp, xp += 8 * st, yp += 8 * st) {
-        vec8<T> xv[8];
+        V8<T> xv[8];
 #pragma unroll
-        for (int u = 0; u < 8; u++) xv[u] = *reinterpret_cast<const vec8<T>*>(xp + u * st);
+        for (int u = 0; u < 8; u++) xv[u] = V8<T>::load(xp + u * st);
 #pragma unroll
         for (int u = 0; u < 8; u++) {
-            vec8<T> o;
+            V8<T> o;
 #pragma unroll
             for (int e = 0; e < 8; e++) {
-                float z = fmaf((float)xv[u][e], sc[e], sh[e]);
+                float z = fmaf(xv[u].get(e), sc[e], sh[e]);
                 if (silu) z = silu_f(z);
-                o[e] = (T)z;
+                o.set(e, z);
             }
-            *reinterpret_cast<vec8<T>*>(yp + u * st) = o;
+            o.store(yp + u * st);
         }
     }
     for (; p + 3 * tp < HW; p += 4 * tp, xp += 4 * st, yp += 4 * st) {
-        vec8<T> xv[4];
+        V8<T> xv[4];
 #pragma unroll
-        for (int u = 0; u < 4; u++) xv[u] = *reinterpret_cast<const vec8<T>*>(xp + u * st);
+        for (int u = 0; u < 4; u++) xv[u] = V8<T>::load(xp + u * st);
 #pragma unroll
         for (int u = 0; u < 4; u++) {
-            vec8<T> o;
+            V8<T> o;
 #pragma unroll
             for (int e = 0; e < 8; e++) {
-                float z = fmaf((float)xv[u][e], sc[e], sh[e]);
+                float z = fmaf(xv[u].get(e), sc[e], sh[e]);
                 if (silu) z = silu_f(z);
-                o[e] = (T)z;
+                o.set(e, z);
             }
-            *reinterpret_cast<vec8<T>*>(yp + u * st) = o;
+            o.store(yp + u * st);
         }
     }
     for (; p < HW; p += tp, xp += st, yp += st) {
-        const vec8<T> xv = *reinterpret_cast<const vec8<T>*>(xp);
-        vec8<T> o;
+        const V8<T> xv = V8<T>::load(xp);
+        V8<T> o;
 #pragma unroll
         for (int e = 0; e < 8; e++) {
-            float z = fmaf((float)xv[e], sc[e], sh[e]);
+            float z = fmaf(xv.get(e), sc[e], sh[e]);
             if (silu) z = silu_f(z);
-            o[e] = (T)z;
+            o.set(e, z);
         }
-        *reinterpret_cast<vec8<T>*>(yp) = o;
+        o.store(yp);
     }
 }
 
@@ -346,78 +369,78 @@ __global__ __launch_bounds__(256) void k_gn_apply(int HW, int C, int G, int pix_
         if (!BWD) {
             // long pixel ranges: four independent loads in flight per thread (see k_gn_reduce)
             for (; deep && p + 3 * rows < p1; p += 4 * rows) {
-                vec8<T> xv[4];
+                V8<T> xv[4];
 #pragma unroll
-                for (int u = 0; u < 4; u++) xv[u] = *reinterpret_cast<const vec8<T>*>(xp + u * step);
+                for (int u = 0; u < 4; u++) xv[u] = V8<T>::load(xp + u * step);
 #pragma unroll
                 for (int u = 0; u < 4; u++) {
-                    vec8<T> o;
+                    V8<T> o;
 #pragma unroll
                     for (int e = 0; e < 8; e++) {
-                        float z = ((float)xv[u][e] - mu[e]) * rs[e] * ga[e] + be[e];
-                        o[e] = (T)(silu ? silu_f(z) : z);
+                        float z = (xv[u].get(e) - mu[e]) * rs[e] * ga[e] + be[e];
+                        o.set(e, silu ? silu_f(z) : z);
                     }
-                    *reinterpret_cast<vec8<T>*>(op + u * step) = o;
+                    o.store(op + u * step);
                 }
                 xp += 4 * step; op += 4 * step;
             }
         } else {
             for (; deep && p + rows < p1; p += 2 * rows) {
-                vec8<T> xv[2], dv[2], rv[2];
+                V8<T> xv[2], dv[2], rv[2];
 #pragma unroll
                 for (int u = 0; u < 2; u++) {
-                    xv[u] = *reinterpret_cast<const vec8<T>*>(xp + u * step); dv[u] = *reinterpret_cast<const vec8<T>*>(dp + u * step);
-                    if (rp) rv[u] = *reinterpret_cast<const vec8<T>*>(rp + u * step);
+                    xv[u] = V8<T>::load(xp + u * step); dv[u] = V8<T>::load(dp + u * step);
+                    if (rp) rv[u] = V8<T>::load(rp + u * step);
                 }
 #pragma unroll
                 for (int u = 0; u < 2; u++) {
-                    vec8<T> o;
+                    V8<T> o;
 #pragma unroll
                     for (int e = 0; e < 8; e++) {
-                        float xh = ((float)xv[u][e] - mu[e]) * rs[e];
-                        float gq = (float)dv[u][e];
+                        float xh = (xv[u].get(e) - mu[e]) * rs[e];
+                        float gq = dv[u].get(e);
                         if (silu) gq *= silu_grad(xh * ga[e] + be[e]);
                         gq *= ga[e];
-                        o[e] = (T)(rs[e] * (gq - m1[e] - xh * m2[e]));
+                        o.set(e, rs[e] * (gq - m1[e] - xh * m2[e]));
                     }
                     if (rp) {
 #pragma unroll
-                        for (int e = 0; e < 8; e++) o[e] = (T)((float)o[e] + (float)rv[u][e]);
+                        for (int e = 0; e < 8; e++) o.set(e, o.get(e) + rv[u].get(e));
                     }
-                    *reinterpret_cast<vec8<T>*>(op + u * step) = o;
+                    o.store(op + u * step);
                 }
                 xp += 2 * step; op += 2 * step; dp += 2 * step;
                 if (rp) rp += 2 * step;
             }
         }
         for (; p < p1; p += rows) {
-            vec8<T> xv = *reinterpret_cast<const vec8<T>*>(xp);
-            vec8<T> o;
+            V8<T> xv = V8<T>::load(xp);
+            V8<T> o;
             if (!BWD) {
 #pragma unroll
                 for (int e = 0; e < 8; e++) {
-                    float z = ((float)xv[e] - mu[e]) * rs[e] * ga[e] + be[e];
-                    o[e] = (T)(silu ? silu_f(z) : z);
+                    float z = (xv.get(e) - mu[e]) * rs[e] * ga[e] + be[e];
+                    o.set(e, silu ? silu_f(z) : z);
                 }
             } else {
-                vec8<T> dv = *reinterpret_cast<const vec8<T>*>(dp);
+                V8<T> dv = V8<T>::load(dp);
 #pragma unroll
                 for (int e = 0; e < 8; e++) {
-                    float xh = ((float)xv[e] - mu[e]) * rs[e];
-                    float gq = (float)dv[e];
+                    float xh = (xv.get(e) - mu[e]) * rs[e];
+                    float gq = dv.get(e);
                     if (silu) gq *= silu_grad(xh * ga[e] + be[e]);
                     gq *= ga[e];
-                    o[e] = (T)(rs[e] * (gq - m1[e] - xh * m2[e]));
+                    o.set(e, rs[e] * (gq - m1[e] - xh * m2[e]));
                 }
                 if (rp) {                       // skip-connection gradient added here instead of a separate add pass
-                    vec8<T> rv = *reinterpret_cast<const vec8<T>*>(rp);
+                    V8<T> rv = V8<T>::load(rp);
 #pragma unroll
-                    for (int e = 0; e < 8; e++) o[e] = (T)((float)o[e] + (float)rv[e]);
+                    for (int e = 0; e < 8; e++) o.set(e, o.get(e) + rv.get(e));
                     rp += step;
                 }
                 dp += step;
             }
-            *reinterpret_cast<vec8<T>*>(op) = o;
+            o.store(op);
             xp += step; op += step;
         }
     }
@@ -438,9 +461,9 @@ __global__ __launch_bounds__(256) void k_layernorm(int M, int C, const T* __rest
     for (int it = 0; it < 4; it++) {
         int cc = lane + it * 64;
         if (cc < C8) {
-            vec8<T> xv = *reinterpret_cast<const vec8<T>*>(x + (size_t)row * C + (size_t)cc * 8);
+            V8<T> xv = V8<T>::load(x + (size_t)row * C + (size_t)cc * 8);
 #pragma unroll
-            for (int e = 0; e < 8; e++) { v[it][e] = (float)xv[e]; s += v[it][e]; }
+            for (int e = 0; e < 8; e++) { v[it][e] = xv.get(e); s += v[it][e]; }
         }
     }
     s = dwg_wave_sum_all(s);
@@ -460,10 +483,10 @@ __global__ __launch_bounds__(256) void k_layernorm(int M, int C, const T* __rest
     for (int it = 0; it < 4; it++) {
         int cc = lane + it * 64;
         if (cc < C8) {
-            vec8<T> o;
+            V8<T> o;
 #pragma unroll
-            for (int e = 0; e < 8; e++) { int ch = cc * 8 + e; o[e] = (T)((v[it][e] - mean) * rstd * gamma[ch] + beta[ch]); }
-            *reinterpret_cast<vec8<T>*>(y + (size_t)row * C + (size_t)cc * 8) = o;
+            for (int e = 0; e < 8; e++) { int ch = cc * 8 + e; o.set(e, (v[it][e] - mean) * rstd * gamma[ch] + beta[ch]); }
+            o.store(y + (size_t)row * C + (size_t)cc * 8);
         }
     }
 }
@@ -475,15 +498,15 @@ __global__ __launch_bounds__(256) void k_geglu(long long M, int F, const T* __re
     const long long n = M * F8;
     for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long long)gridDim.x * 256) {
         long long m = i / F8; int fc = (int)(i % F8);
-        vec8<T> a = *reinterpret_cast<const vec8<T>*>(x + m * 2 * F + (size_t)fc * 8);
-        vec8<T> g = *reinterpret_cast<const vec8<T>*>(x + m * 2 * F + F + (size_t)fc * 8);
-        vec8<T> o;
+        V8<T> a = V8<T>::load(x + m * 2 * F + (size_t)fc * 8);
+        V8<T> g = V8<T>::load(x + m * 2 * F + F + (size_t)fc * 8);
+        V8<T> o;
 #pragma unroll
         for (int e = 0; e < 8; e++) {
-            float gv = (float)g[e];
-            o[e] = (T)((float)a[e] * 0.5f * gv * (1.f + dwg_erf_fast(gv * 0.70710678118654752f)));
+            float gv = g.get(e);
+            o.set(e, a.get(e) * 0.5f * gv * (1.f + dwg_erf_fast(gv * 0.70710678118654752f)));
         }
-        *reinterpret_cast<vec8<T>*>(out + m * F + (size_t)fc * 8) = o;
+        o.store(out + m * F + (size_t)fc * 8);
     }
 }
 
@@ -502,7 +525,7 @@ __global__ __launch_bounds__(256) void k_softmax_rows(int rows, int n, float sca
     sum = dwg_wave_sum_all(sum);
     const float inv = 1.f / sum;
     T* p = P + (size_t)row * ldp;
-    for (int j = lane; j < n; j += 64) p[j] = (T)(__expf(s[j] * scale - mx) * inv);
+    for (int j = lane; j < n; j += 64) st1<T>(p, j, __expf(s[j] * scale - mx) * inv);
 }
 
 // dS = scale * P * (dP - sum_j dP_j P_j)   (P bf16, dP fp32) -> bf16
@@ -514,10 +537,10 @@ __global__ __launch_bounds__(256) void k_softmax_rows_bwd(int rows, int n, float
     if (row >= rows) return;
     const T* p = P + (size_t)row * ldp; const float* dp = dP + (size_t)row * lddp;
     float dot = 0.f;
-    for (int j = lane; j < n; j += 64) dot += (float)p[j] * dp[j];
+    for (int j = lane; j < n; j += 64) dot += ld1<T>(p, j) * dp[j];
     dot = dwg_wave_sum_all(dot);
     T* ds = dS + (size_t)row * ldds;
-    for (int j = lane; j < n; j += 64) ds[j] = (T)(scale * (float)p[j] * (dp[j] - dot));
+    for (int j = lane; j < n; j += 64) st1<T>(ds, j, scale * ld1<T>(p, j) * (dp[j] - dot));
 }
 
 // DWG_GN_SHALLOW=1: the round-2 loops (one load in flight per thread) -- A/B switch for the long-range paths
@@ -553,6 +576,7 @@ static void gn_reduce_geometry(int HW, int C, int* pix_per_block, int* chunks) {
         case DWG_DTYPE_BF16: { typedef __bf16 T; __VA_ARGS__; } break;                   \
         case DWG_DTYPE_F16: { typedef _Float16 T; __VA_ARGS__; } break;                  \
         case DWG_DTYPE_F32: { typedef float T; __VA_ARGS__; } break;                     \
+        case DWG_DTYPE_F32X: { typedef dwg_xs T; __VA_ARGS__; } break;                   \
         default: return DWG_E_ARG;                                                       \
     }
 
@@ -581,7 +605,7 @@ int dwg_groupnorm_forward_dt(int32_t dtype, int32_t B, int32_t HW, int32_t C, in
         // pixel row, so the walks touch partial cache lines that neighbouring bundles touch again -- free out of L2, several times the traffic
         // beyond it -- and with 8x the batch the three-launch path has all the parallelism it needs: the batched 8-view step (batch 16) fell
         // from 92 to 68 views/s with this kernel on (A/B, DWG_GN_NO_SMALL), so it keeps the three-launch path
-        const long long tensor_bytes = (long long)B * HW * C * (dtype == DWG_DTYPE_F32 ? 4 : 2);
+        const long long tensor_bytes = (long long)B * HW * C * (dtype == DWG_DTYPE_F32 || dtype == DWG_DTYPE_F32X ? 4 : 2);
         if (!no_small && gb && B <= 4 && HW <= 1024 && (long long)HW * (gb * cg / 8) <= small_max && gb * cg / 8 <= 64 && tensor_bytes <= (8ll << 20)) {
             const int nb = gb * cg, tp = 256 / (nb / 8);
             const size_t sl = (size_t)(2 * tp * nb + 2 * nb) * sizeof(float);

@@ -18,7 +18,7 @@ from typing import Dict, List, Optional, Tuple
 
 import torch
 
-from . import _lib, gemm
+from . import _lib, gemm, xfmt
 
 BF16 = torch.bfloat16
 
@@ -29,15 +29,20 @@ BF16 = torch.bfloat16
 #           QK^T -> row softmax -> PV.  It is the full-precision reference the bf16 plans are measured against ON THE GPU.
 #   "f16"   the reference's `--guide.dtype fp16` (core/guidance/basic.py:24-27,233) / autocast storage type (configs/__init__.py:462): the same kernels as "bf16" compiled for _Float16 operands
 #           (csrc/gemm_f16.hip, attention_f16.hip: v_mfma_f32_32x32x16_f16 -- same MFMA rate), 10 mantissa bits instead of 7, range 65504.
-TORCH_DTYPE = {"bf16": torch.bfloat16, "f32": torch.float32, "f16": torch.float16}
-DT_CODE = {"f32": 0, "bf16": 1, "f16": 2}          # DWG_DTYPE_* (include/dwg_types.h)
+#   "f32x"  SPLIT PRECISION -- the reference's fp32 results at the 16-bit MFMA rate: every activation and weight is held as hi + 2^-11 lo fp16
+#           halves (32 bytes per 8 channels, csrc/dwg_xfmt.h; torch.int32-typed tensors here, xfmt.py), every product is three
+#           v_mfma_f32_32x32x16_f16 with fp32 accumulation (csrc/gemm_x.hip, attention_x.hip), norm / softmax / element-wise layers decode and
+#           re-split in registers.  22 significand bits end to end: eps and SDS gradients agree with the fp32 oracle like the exact "f32"
+#           plans do (tests/test_sd15_f32x_gpu.py), at 2.5-4x their speed.
+TORCH_DTYPE = {"bf16": torch.bfloat16, "f32": torch.float32, "f16": torch.float16, "f32x": xfmt.DTYPE}
+DT_CODE = {"f32": 0, "bf16": 1, "f16": 2, "f32x": 3}          # DWG_DTYPE_* (include/dwg_types.h)
 
 
 def dtype_name(dtype) -> str:
     names = {"bf16": "bf16", "bfloat16": "bf16", torch.bfloat16: "bf16", "f32": "f32", "fp32": "f32", "float32": "f32", torch.float32: "f32",
-             "f16": "f16", "fp16": "f16", "float16": "f16", "half": "f16", torch.float16: "f16"}
+             "f16": "f16", "fp16": "f16", "float16": "f16", "half": "f16", torch.float16: "f16", "f32x": "f32x", "fp32x": "f32x"}
     if dtype not in names:
-        raise ValueError("plan dtype must be one of bf16 / f32 / f16, got %r" % (dtype,))
+        raise ValueError("plan dtype must be one of bf16 / f32 / f16 / f32x, got %r" % (dtype,))
     return names[dtype]
 
 
@@ -273,7 +278,8 @@ class Plan:
         self.device = device
         self.dtype_name = dtype_name(dtype)
         self.dtype, self.dt = TORCH_DTYPE[self.dtype_name], DT_CODE[self.dtype_name]
-        self.esize = 4 if self.dtype_name == "f32" else 2
+        self.esize = 4 if self.dtype_name in ("f32", "f32x") else 2
+        self.is_x = self.dtype_name == "f32x"
         self.ops = []
         self.keep = []          # descriptors / tensors kept alive
         self.tags = []
@@ -331,6 +337,36 @@ class Plan:
         self.keep.append(t)
         self.tags.append((len(self.ops), tuple(shape)))
         return t
+
+    # -- host <-> plan buffers: fp32 values in, the plan's storage type out (and back) ------------------------------------------
+    def store(self, dst, src, stage=None):
+        """dst (a whole, contiguous activation buffer of this plan) <- fp32 values.  `src` has dst's logical shape, or fewer channels: the rest
+        of `stage` (a zero-initialised fp32 tensor of dst's shape, kept by the caller) pads it -- an f32x buffer is written in whole
+        8-channel groups by ONE pack launch (dwg_xfmt_pack) on the current stream."""
+        if not self.is_x:
+            (dst if src.shape == dst.shape else dst[..., :src.shape[-1]]).copy_(src)
+            return
+        if stage is not None:
+            stage[..., :src.shape[-1]].copy_(src)
+            src = stage
+        elif src.dtype != torch.float32 or not src.is_contiguous():
+            src = src.float().contiguous()
+        assert src.shape == dst.shape and dst.is_contiguous(), (src.shape, dst.shape)
+        _lib.check(self._lib.dwg_xfmt_pack(src.numel(), ctypes.c_void_p(src.data_ptr()), ctypes.c_void_p(dst.data_ptr()),
+                                           ctypes.c_void_p(torch.cuda.current_stream(self.device).cuda_stream)), "dwg_xfmt_pack")
+
+    def load(self, t):
+        """fp32 copy of a whole, contiguous activation buffer of this plan."""
+        if not (self.is_x and t.dtype == xfmt.DTYPE):
+            return t.float()
+        out = torch.empty(t.shape, device=t.device, dtype=torch.float32)
+        _lib.check(self._lib.dwg_xfmt_unpack(t.numel(), ctypes.c_void_p(t.data_ptr()), ctypes.c_void_p(out.data_ptr()),
+                                             ctypes.c_void_p(torch.cuda.current_stream(self.device).cuda_stream)), "dwg_xfmt_unpack")
+        return out
+
+    def stage_like(self, buf):
+        """Zeroed fp32 staging tensor for `store` into an f32x buffer from fewer channels (None for the other plan types)."""
+        return torch.zeros(buf.shape, device=self.device, dtype=torch.float32) if self.is_x else None
 
     def add_gemm(self, desc, allow_split=True):
         if allow_split and desc.batch1 * desc.batch2 == 1 and desc.splitk <= 1 and not desc.accumulate:
@@ -412,6 +448,13 @@ class Weights:
         self.sd = sd
         self.cache = {}
         self.wdtype = TORCH_DTYPE[dtype_name(dtype)]         # storage type of the conv / linear weights (biases, norm affine: fp32)
+        self.is_x = dtype_name(dtype) == "f32x"
+
+    def _to_dev(self, w):
+        """fp32 kernel-layout weight (contraction axis innermost) -> the plan's storage type on the device."""
+        if self.is_x:
+            return xfmt.pack(w.to(self.device)).contiguous()
+        return w.to(self.device, self.wdtype).contiguous()
 
     def conv(self, name, flip_for_dgrad=False):
         key = (name, flip_for_dgrad)
@@ -422,7 +465,7 @@ class Weights:
             cout, cin = w.shape[0], w.shape[1]
             wp = torch.zeros(_pad8(cout) if flip_for_dgrad else cout, w.shape[2], w.shape[3], _pad8(cin))
             wp[:cout, :, :, :cin] = w.permute(0, 2, 3, 1)
-            self.cache[key] = wp.to(self.device, self.wdtype).contiguous()
+            self.cache[key] = self._to_dev(wp)
         return self.cache[key]
 
     def conv_dgrad_s2(self, name, py, px):
@@ -440,21 +483,22 @@ class Weights:
             for ty, ky in enumerate(kys):
                 for tx, kx in enumerate(kxs):
                     wp[:cx, ty, tx, :cy] = w[:, :, ky, kx].t()
-            self.cache[key] = wp.to(self.device, self.wdtype).contiguous()
+            self.cache[key] = self._to_dev(wp)
         return self.cache[key]
 
     def lin(self, *names):
         key = ("lin",) + names
         if key not in self.cache:
-            self.cache[key] = torch.cat([self.sd[n + ".weight"].float().reshape(self.sd[n + ".weight"].shape[0], -1)
-                                         for n in names], 0).to(self.device, self.wdtype).contiguous()
+            self.cache[key] = self._to_dev(torch.cat([self.sd[n + ".weight"].float().reshape(self.sd[n + ".weight"].shape[0], -1)
+                                                      for n in names], 0))
         return self.cache[key]
 
     def lin_t(self, name):
         """The transposed copy [in, out] of a linear weight: the backward product dy @ W as a K-contiguous GEMM (B(n, k) = W^T[n][k])."""
         key = ("lin_t", name)
         if key not in self.cache:
-            self.cache[key] = self.lin(name).t().contiguous()
+            w = self.sd[name + ".weight"].float()
+            self.cache[key] = self._to_dev(w.reshape(w.shape[0], -1).t().contiguous())
         return self.cache[key]
 
     def lin_geglu(self, name):
@@ -466,7 +510,7 @@ class Weights:
             F = w.shape[0] // 2
             idx = torch.arange(F).view(-1, 32)
             perm = torch.cat([idx, idx + F], dim=1).reshape(-1)          # [q*64 + 0..31] = hidden, [q*64 + 32..63] = gate
-            self.cache[key] = (w[perm].to(self.device, self.wdtype).contiguous(), b[perm].to(self.device).contiguous())
+            self.cache[key] = (self._to_dev(w[perm]), b[perm].to(self.device).contiguous())
         return self.cache[key]
 
     def f32(self, name):
@@ -656,16 +700,16 @@ class Builder:
         return out
 
     def transpose(self, x):
-        """[B, R, C] -> [B, C, R] (2-byte element plans): operands of the VAE attention made K-contiguous for the direct-to-LDS GEMM kernels."""
+        """[B, R, C] -> [B, C, R] (2-byte element and f32x plans): operands of the VAE attention made K-contiguous for the direct-to-LDS GEMM kernels."""
         B, R, C = x.shape
         y = self.p.buf(B, C, R)
         pp = lambda t: ctypes.c_void_p(t.data_ptr())  # noqa: E731
-        self.p.add_call(self.L.dwg_transpose_2byte, B, R, C, pp(x), x.stride(1), x.stride(0), pp(y), R, C * R)
+        self.p.add_call(self.L.dwg_transpose_dt, self.p.dt, B, R, C, pp(x), x.stride(1), x.stride(0), pp(y), R, C * R)
         return y
 
     def cast_bf16(self, x):
         """fp32 accumulator buffer -> the plan's activation type (a no-op for the fp32 plans)."""
-        if self.p.dtype == torch.float32:
+        if self.p.dtype_name == "f32":
             return x
         y = self.p.buf(*x.shape)
         pp = lambda t: ctypes.c_void_p(t.data_ptr())  # noqa: E731
@@ -812,6 +856,7 @@ class DenoiserPlan:
         self.text = p.buf(B, text_len, cfg.cross_dim)
         self.cond_scale = 2 ** (len(cfg.cond_channels) - 1)      # one stride-2 convolution per embedding level: 8 for SD-1.5
         self.cond = p.buf(self.views, hw * self.cond_scale, hw * self.cond_scale, _pad8(cfg.cond_in_channels), zero=True)
+        self._lat_stage, self._cond_stage = p.stage_like(self.latents), p.stage_like(self.cond)
         # ---- UNet encoder (does not depend on the ControlNet)
         up_names = []
         rev_attn = list(reversed(cfg.attn_blocks))
@@ -856,17 +901,17 @@ class DenoiserPlan:
     def set_inputs(self, latents_nchw, t, text, cond_nchw=None):
         """latents [B,4,h,w] fp32, t scalar / [V] (one per view, repeated over the CFG entries) / [B], text [B,77,768],
         cond [V,3,8h,8w] in [0,1] (optional)."""
-        c = latents_nchw.shape[1]
-        self.latents[..., :c].copy_(latents_nchw.permute(0, 2, 3, 1))
+        p = self.plan
+        p.store(self.latents, latents_nchw.permute(0, 2, 3, 1), self._lat_stage)
         t = t.reshape(-1)
         if t.numel() not in (1, self.B):
             assert self.B % t.numel() == 0, (self.B, t.numel())
             t = t.repeat(self.B // t.numel())                 # [t_0..t_{V-1} | t_0..t_{V-1}]: the batch order of the CFG halves
         te = timestep_embedding(t.expand(self.B), self.cfg.block_out_channels[0])
-        self.temb_u.tin.copy_(te); self.temb_c.tin.copy_(te)
-        self.text.copy_(text)
+        p.store(self.temb_u.tin, te); p.store(self.temb_c.tin, te)
+        p.store(self.text, text)
         if cond_nchw is not None:
-            self.cond[..., :cond_nchw.shape[1]].copy_(cond_nchw.permute(0, 2, 3, 1))
+            p.store(self.cond, cond_nchw.permute(0, 2, 3, 1), self._cond_stage)
 
     def run(self):
         self.plan.run()
@@ -885,6 +930,7 @@ class VAEEncoderPlan:
         self.weights = w            # kernel-layout weight tensors must outlive the plans that point at them
         f, r = Builder(self.fwd, w, cfg.groups, "vaef"), Builder(self.bwd, w, cfg.groups, "vaeb")
         self.x = self.fwd.buf(self.B, image_hw, image_hw, 8, zero=True)
+        self._x_stage = self.fwd.stage_like(self.x)
         boc = cfg.block_out_channels
         tape = []      # closures that extend the backward plan, replayed in reverse order
 
@@ -965,7 +1011,7 @@ class VAEEncoderPlan:
         # 2-byte plans: every product below runs with BOTH operands K-contiguous (the direct-to-LDS MFMA kernels: 3-4x the rate of the
         # register-staged strided loader) -- v, do, k, q, P and dS are transposed once each (dwg_transpose_2byte: 4 / 32 MB, ~3 / ~15 us)
         # and the backward uses transposed copies of the four projection weights.  The fp32 plans keep the strided products.
-        kc = f.p.esize == 2
+        kc = f.p.esize == 2 or f.p.is_x          # f32x operands exist ONLY K-contiguous (8-channel groups along the contraction)
         if kc:
             vT = f.transpose(v)
             f.p.add_gemm(gemm.gemm_raw(P, vT, o, N, C, N, (N, 1), (N, 1), C, batch=(B, 1), a_batch=(N * N, 0), b_batch=(N * C, 0),
@@ -1026,12 +1072,12 @@ class VAEEncoderPlan:
 
     def encode(self, image_nchw):
         """image [B,3,H,W] fp32 in [0,1] -> moments [B,8,h,w] fp32 (NCHW view)."""
-        self.x[..., :3].copy_((image_nchw * 2.0 - 1.0).permute(0, 2, 3, 1))
+        self.fwd.store(self.x, (image_nchw * 2.0 - 1.0).permute(0, 2, 3, 1), self._x_stage)
         self.fwd.run()
         return self.moments.permute(0, 3, 1, 2)
 
     def backward(self, dmoments_nchw):
         """d loss / d moments [B,8,h,w] -> d loss / d image [B,3,H,W] fp32."""
-        self.dmoments.copy_(dmoments_nchw.permute(0, 2, 3, 1))
+        self.bwd.store(self.dmoments, dmoments_nchw.permute(0, 2, 3, 1))
         self.bwd.run()
-        return self.dx[..., :3].permute(0, 3, 1, 2).float() * 2.0
+        return self.bwd.load(self.dx)[..., :3].permute(0, 3, 1, 2) * 2.0

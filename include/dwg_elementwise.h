@@ -53,7 +53,7 @@ int dwg_interleave2x2(int32_t B, int32_t Ho, int32_t Wo, int32_t C, const void* 
                       void* out, dwg_stream_t stream);
 /* fp32 -> bf16 copy. */
 int dwg_cast_f32_to_bf16(int64_t n, const float* src, void* dst, dwg_stream_t stream);
-/* The typed passes for the other plan element types (dtype = DWG_DTYPE_BF16 | DWG_DTYPE_F16 | DWG_DTYPE_F32, dwg_types.h).  The two byte
+/* The typed passes for the other plan element types (dtype = DWG_DTYPE_BF16 | DWG_DTYPE_F16 | DWG_DTYPE_F32 | DWG_DTYPE_F32X, dwg_types.h).  The two byte
  * movers above (concat, interleave) serve them as they are: pass channel counts in units of 2-byte elements (2 C for fp32). */
 int dwg_add_dt(int32_t dtype, int64_t n, const void* a, const void* b, void* out, dwg_stream_t stream);
 int dwg_cast_f32_to_dt(int32_t dtype, int64_t n, const float* src, void* dst, dwg_stream_t stream);
@@ -63,6 +63,15 @@ int dwg_cast_f32_to_dt(int32_t dtype, int64_t n, const float* src, void* dst, dw
  * and backward is a K-contiguous GEMM (the direct-to-LDS MFMA kernels) instead of a strided one. */
 int dwg_transpose_2byte(int32_t batch, int32_t R, int32_t C, const void* in, int64_t ld_in, int64_t batch_stride_in, void* out, int64_t ld_out,
                         int64_t batch_stride_out, dwg_stream_t stream);
+
+/* The split-precision f32x format (DWG_DTYPE_F32X, dwg_types.h; layout: dreamwaltz-g_amd/csrc/dwg_xfmt.h): fp32 <-> hi / lo fp16 planes of a
+ * contiguous tensor whose rows are multiples of 8 elements (n % 8 == 0, 16-byte aligned).  Input / output converters of the f32x denoiser / VAE
+ * plans (the reference hands fp32 latents, text embeddings and images across boundary B4: core/guidance/controlnet.py:83-114, vae.py:34-40). */
+int dwg_xfmt_pack(int64_t n, const float* src, void* dst, dwg_stream_t stream);
+int dwg_xfmt_unpack(int64_t n, const void* src, float* dst, dwg_stream_t stream);
+/* dwg_transpose_2byte for any 2-byte plan type, and for f32x tensors (groups of 8 along c on the way in, along r on the way out). */
+int dwg_transpose_dt(int32_t dtype, int32_t batch, int32_t R, int32_t C, const void* in, int64_t ld_in, int64_t batch_stride_in, void* out,
+                     int64_t ld_out, int64_t batch_stride_out, dwg_stream_t stream);
 
 #ifdef __cplusplus
 }

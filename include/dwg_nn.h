@@ -62,7 +62,8 @@ int dwg_groupnorm_backward_dt(int32_t dtype, int32_t B, int32_t HW, int32_t C, i
 int dwg_layernorm_forward_dt(int32_t dtype, int32_t M, int32_t C, const void* x, const float* gamma, const float* beta, float eps,
                              void* y, dwg_stream_t stream);
 int dwg_geglu_forward_dt(int32_t dtype, int64_t M, int32_t F, const void* x, void* out, dwg_stream_t stream);
-/* fused attention: DWG_DTYPE_BF16 or DWG_DTYPE_F16 (the fp32 plans run attention as QK^T -> row softmax -> PV on dwg_gemm) */
+/* fused attention: DWG_DTYPE_BF16, DWG_DTYPE_F16 or DWG_DTYPE_F32X (split-precision operands, csrc/attention_x.hip: three 16-bit MFMAs per
+ * product, fp32-grade scores / probabilities / outputs); the exact-fp32 plans run attention as QK^T -> row softmax -> PV on dwg_gemm */
 int dwg_attention_forward_dt(int32_t dtype, int32_t B, int32_t H, int32_t Nq, int32_t Nk, int32_t d, const void* Q, int64_t ldq,
                              int64_t bq, const void* K, int64_t ldk, int64_t bk, const void* V, int64_t ldv, int64_t bv, void* O,
                              int64_t ldo, int64_t bo, float scale, dwg_stream_t stream);

@@ -140,24 +140,15 @@ def test_full_width_denoiser_fp32_vs_oracle_and_the_bf16_trade():
     """(1) fp32 plan == fp32 CPU oracle at t = 500 (whole ControlNet + UNet, 1.22 G parameters, CFG batch 2);
     (2) bf16 plan vs fp32 plan ON THE GPU at t in {20, 500, 980} x 3 seeds of latents / text / condition / noise."""
     from dreamwaltz_g_amd import sd15
-    from oracle import sd15 as osd
-    torch.set_num_threads(min(64, max(1, os.cpu_count() or 1)))
-    ucfg = sd15.UNetConfig()
-    usd = sd15.random_state_dict(sd15.unet_param_shapes(ucfg), seed=0)
-    csd = sd15.random_state_dict(sd15.controlnet_param_shapes(ucfg), seed=1)
+    from tests import sd15_cases as cases
+    ucfg, usd, csd = cases.denoiser_weights()
     dev = torch.device("cuda")
     p32 = sd15.DenoiserPlan(ucfg, usd, csd, dev, batch=2, latent_hw=64, dtype="f32")
     p16 = sd15.DenoiserPlan(ucfg, usd, csd, dev, batch=2, latent_hw=64, dtype="bf16")
-
-    def draw(seed):
-        g = torch.Generator().manual_seed(seed)
-        return (torch.randn(1, 4, 64, 64, generator=g).repeat(2, 1, 1, 1), torch.randn(2, 77, 768, generator=g),
-                torch.rand(1, 3, 512, 512, generator=g), torch.randn(1, 4, 64, 64, generator=g))
-
+    draw = cases.denoiser_draw
     lat, text, cond, noise = draw(5)
     t = torch.tensor([500])
-    with torch.no_grad():
-        ref = osd.predict_noise(ucfg, usd, csd, lat, t, text, cond.repeat(2, 1, 1, 1))
+    ref = cases.denoiser_oracle(5, 500)
     p32.set_inputs(lat.cuda(), t.cuda(), text.cuda(), cond.cuda())
     got32 = p32.run().float().cpu().clone()
     g32, _ = _sds(got32, noise); gref, dref = _sds(ref, noise)
@@ -194,16 +185,8 @@ def test_full_width_denoiser_fp32_vs_oracle_and_the_bf16_trade():
 @pytest.mark.slow
 def test_full_width_vae_encoder_fp32_vs_oracle_and_the_bf16_trade():
     from dreamwaltz_g_amd import sd15
-    from oracle import sd15 as osd
-    torch.set_num_threads(min(64, max(1, os.cpu_count() or 1)))
-    vcfg = sd15.VAEConfig()
-    sd = sd15.random_state_dict(sd15.vae_encoder_param_shapes(vcfg), seed=2)
-    g = torch.Generator().manual_seed(6)
-    img = torch.rand(1, 3, 512, 512, generator=g)
-    imgr = img.clone().requires_grad_(True)
-    ref = osd.vae_encode_moments(vcfg, sd, imgr)
-    gm = torch.randn(ref.shape, generator=g)
-    (gref,) = torch.autograd.grad(ref, imgr, gm)
+    from tests import sd15_cases as cases
+    vcfg, sd, img, gm, ref, gref = cases.vae_case()
     dev = torch.device("cuda")
     p32 = sd15.VAEEncoderPlan(vcfg, sd, dev, image_hw=512, dtype="f32")
     got = p32.encode(img.cuda()).float().cpu().clone()
