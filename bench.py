@@ -40,7 +40,8 @@ from dreamwaltz_g_amd import _lib  # noqa: E402
 from dreamwaltz_g_amd import sds_step  # noqa: E402
 
 HBM_PEAK_GBS = 8000.0                                  # MI355X_MICROARCH.md: 8 TB/s HBM3E
-MFMA_PEAK_TFLOPS = {"bf16": 2500.0, "f16": 2500.0, "f32": 157.3}      # dense MFMA peaks per operand type (same guide)
+MFMA_PEAK_TFLOPS = {"bf16": 2500.0, "f16": 2500.0, "f32": 157.3, "f32x": 2500.0}      # dense MFMA peaks per operand type (same guide); f32x runs on the
+                                                                                       # f16 MFMA pipe, its ALGORITHMIC flops (one multiply-add per product, not the three MFMAs) are priced against that peak
 TRAFFIC_JSON = os.path.join(ROOT, "profiles", "r03_pmc_traffic.json")
 HEADLINE_METRIC = "SDS steps/sec @512^2, 100k Gaussians, SD1.5+ControlNet; raster Mpix/s vs HBM roofline"
 
@@ -52,7 +53,7 @@ def parse():
     ap.add_argument("--warmup", type=int, default=None, help="default: 3 (c3), 1 (c4), 20 (c1 / c2 / c5)")
     ap.add_argument("--config", choices=["c1", "c2", "c3", "c4", "c5"], default="c3")
     ap.add_argument("--views", type=int, default=None, help="views per step over ALL GPUs (default: one per GPU for c3, 8 for c4)")
-    ap.add_argument("--dtype", choices=["bf16", "f32", "f16"], default="bf16", help="storage type of the denoiser / VAE plans")
+    ap.add_argument("--dtype", choices=["bf16", "f32", "f16", "f32x"], default="bf16", help="storage type of the denoiser / VAE plans")
     ap.add_argument("--gaussians", type=int, default=None)
     ap.add_argument("--res", type=int, default=None)
     ap.add_argument("--headline-only", action="store_true", help="skip the attached configs / by_dtype / cpu_baseline legs")

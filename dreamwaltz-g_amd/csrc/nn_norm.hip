@@ -143,12 +143,22 @@ __global__ __launch_bounds__(256) void k_gn_reduce(int HW, int C, int G, int pix
             }
         }
         __syncthreads();
-        // one thread per channel of this pass: sum over rows, then add into its group
+        // one thread per channel of this pass: sum over rows (kept in row 0 of its own column) ...
         for (int c = tid; c < Cb; c += 256) {
             float a = 0.f, q = 0.f;
             for (int r = 0; r < rows; r++) { a += lds[(r * Cb + c) * 2]; q += lds[(r * Cb + c) * 2 + 1]; }
-            int g = (cb * 8 + c) / cg;
-            atomicAdd(&gacc[2 * g], a); atomicAdd(&gacc[2 * g + 1], q);
+            lds[c * 2] = a; lds[c * 2 + 1] = q;
+        }
+        __syncthreads();
+        // ... then one thread per (group, statistic) adds the group's channels of this pass IN CHANNEL ORDER: no LDS float atomics, whose
+        // arrival order -- and with it the last bit of the statistics -- varied between launches (invisible after a bf16 rounding, visible
+        // in the fp32-grade f32x plans, whose hipGraph replay must equal the eager run bit for bit)
+        if (tid < 2 * G) {
+            const int g = tid >> 1, st = tid & 1;
+            const int c_lo = max(g * cg, cb * 8) - cb * 8, c_hi = min((g + 1) * cg, cb * 8 + Cb) - cb * 8;
+            float a = 0.f;
+            for (int c = c_lo; c < c_hi; c++) a += lds[c * 2 + st];
+            if (c_hi > c_lo) gacc[tid] += a;
         }
         __syncthreads();
     }

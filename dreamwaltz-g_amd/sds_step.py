@@ -204,7 +204,9 @@ class SDSStep:
             "sub-path only (NOT the headline workload): animate + raster %dx%d fwd+bwd + Adam, no diffusion" % (self.res, self.res))
         gdt = self.guidance.dtype_name if self.guidance is not None else "f32"
         prec = {"bf16": "denoiser+VAE bf16 storage / fp32 accumulate (MFMA bf16)", "f32": "denoiser+VAE fp32 storage and arithmetic (exact-f32 MFMA)",
-                "f16": "denoiser+VAE fp16 storage / fp32 accumulate (MFMA f16)"}[gdt]
+                "f16": "denoiser+VAE fp16 storage / fp32 accumulate (MFMA f16)",
+                "f32x": "denoiser+VAE fp32-grade split precision: every value hi + 2^-11 lo fp16 halves (22 significand bits, 4 bytes), every product "
+                        "three f16 MFMAs with fp32 accumulate (eps 3e-6 / SDS gradient 1e-5 vs the fp32 CPU oracle: the reference's fp32 results)"}[gdt]
         return {"dtype": gdt,
                 "config": {"workload": wl, "gaussians": self.G, "resolution": self.res, "views_per_step": self.views,
                            "views_per_step_per_gpu": len(self.my_views),
