@@ -19,8 +19,10 @@ sit inside Trainer methods: /root/reference/core/trainer.py:446-453,529-530), so
                                              built from the loaded modules' state_dict()s.  Everything else (get_text_embeds, __call__,
                                              calc_gradients, tp_scheduler, pipe, decode_latents, isinstance checks) is the reference's own.
 
-Environment: DWG_BIND_DTYPE = bf16 | f32 | f16         storage type of the denoiser / VAE plans.  Unset: f16 when the reference loaded its
-                                                     pipeline in torch.float16 (`--guide.dtype fp16`, core/guidance/basic.py:24-27,233), else bf16
+Environment: DWG_BIND_DTYPE = f32x | f32 | f16 | bf16  storage type of the denoiser / VAE plans.  Unset: the precision the reference loaded its
+                                                     pipeline in -- torch.float32 (its default, core/guidance/basic.py:233) -> f32x (fp32-grade
+                                                     split precision on the 16-bit MFMA pipe), torch.float16 (`--guide.dtype fp16`,
+                                                     basic.py:24-27) -> f16.  bf16 narrows the user's precision: only on request
              DWG_BIND_KEEP_MODULES = 1               keep the diffusers UNet / ControlNet on the GPU (default: moved to the CPU once their
                                                      weights live in the plans -- the text encoder and the VAE decoder stay where they were)
 """
@@ -101,10 +103,13 @@ def _patch_scene_module(mod):
 # B4: guidance
 # --------------------------------------------------------------------------------------------------------------------------------------
 def plan_dtype_for(ref, dtype=None):
-    """Storage type of the HIP plans for a constructed reference guidance object: the explicit argument, else DWG_BIND_DTYPE, else fp16 when the
-    reference loaded its pipeline in torch.float16 (`--guide.dtype fp16`: core/guidance/basic.py:24-27,233), else bf16."""
+    """Storage type of the HIP plans for a constructed reference guidance object: the explicit argument, else DWG_BIND_DTYPE, else the
+    precision the reference itself loaded its pipeline in (core/guidance/basic.py:233 `torch_dtype=self.torch_dtype`): torch.float32 (the
+    default of every shipped recipe) -> "f32x", whose results are the fp32 ones (eps 3e-6 vs the fp32 oracle); torch.float16
+    (`--guide.dtype fp16`, basic.py:24-27) -> "f16".  The binding never narrows the user's arithmetic on its own: bf16 plans (eps 1.5 % off)
+    only through the argument / DWG_BIND_DTYPE=bf16."""
     import torch
-    return dtype or os.environ.get("DWG_BIND_DTYPE") or ("f16" if getattr(ref, "torch_dtype", None) is torch.float16 else "bf16")
+    return dtype or os.environ.get("DWG_BIND_DTYPE") or ("f16" if getattr(ref, "torch_dtype", None) is torch.float16 else "f32x")
 
 
 def bind_guidance(ref, dtype=None, keep_modules=None):

@@ -55,7 +55,8 @@ def test_unet_config_from_a_diffusers_style_config():
 
 def test_plan_dtype_follows_the_reference_pipeline_dtype(monkeypatch):
     """`--guide.dtype fp16` (the reference loads UNet / ControlNet / VAE in torch.float16: core/guidance/basic.py:233) -> fp16 plans; its
-    fp32 default -> the bf16 plans; DWG_BIND_DTYPE and the explicit argument override."""
+    fp32 default -> the fp32-grade f32x plans (never a narrower type on the binding's own initiative); DWG_BIND_DTYPE and the explicit
+    argument override."""
     import types
     sys.path.insert(0, os.path.join(ROOT, "dropin"))
     try:
@@ -64,7 +65,7 @@ def test_plan_dtype_follows_the_reference_pipeline_dtype(monkeypatch):
         sys.path.pop(0)
     monkeypatch.delenv("DWG_BIND_DTYPE", raising=False)
     half, full = types.SimpleNamespace(torch_dtype=torch.float16), types.SimpleNamespace(torch_dtype=torch.float32)
-    assert dwg_bind.plan_dtype_for(half) == "f16" and dwg_bind.plan_dtype_for(full) == "bf16" and dwg_bind.plan_dtype_for(object()) == "bf16"
+    assert dwg_bind.plan_dtype_for(half) == "f16" and dwg_bind.plan_dtype_for(full) == "f32x" and dwg_bind.plan_dtype_for(object()) == "f32x"
     assert dwg_bind.plan_dtype_for(half, "f32") == "f32"
     monkeypatch.setenv("DWG_BIND_DTYPE", "f32")
     assert dwg_bind.plan_dtype_for(half) == "f32" and dwg_bind.plan_dtype_for(full, "bf16") == "bf16"
@@ -162,7 +163,8 @@ def test_bound_guidance_seams_run_the_hip_plans():
     assert dwg_bind.bind_guidance(ref) is ref and dwg_bind.bind_guidance(ref) is ref
     assert unet.where == "cpu" and cnet.where == "cpu" and vae.where == "cuda"
     direct = gd.ControlNetScoreDistillation(dev, unet_cfg=ucfg_bound, vae_cfg=sd15.vae_config_from(vae.config), unet_sd=usd, controlnet_sd=csd,
-                                            vae_sd=vsd, image_hw=64, cfg=configs.GuideConfig())
+                                            vae_sd=vsd, image_hw=64, cfg=configs.GuideConfig(), dtype=dwg_bind.plan_dtype_for(ref))
+    assert direct.dtype_name == "f32x"          # a reference pipeline without torch_dtype = its fp32 default -> the fp32-grade plans
     g = torch.Generator().manual_seed(3)
     lat = torch.randn(1, 4, 32, 32, generator=g).repeat(2, 1, 1, 1).to(dev)
     text = torch.randn(2, 77, 48, generator=g).to(dev)

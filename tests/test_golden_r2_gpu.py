@@ -1,6 +1,7 @@
 """-m gpu: the PRODUCT (HIP kernels behind the reference-shaped API) against golden outputs of the reference's own code
 (tests/golden/capture_golden_r2.py): DreamWaltzG.animate incl. the learned-betas variant and every parameter gradient,
 Scene.forward, inverse_lbs_transform, the RigidTransform kernel paths, and the guidance call on reduced-width networks."""
+import json
 import os
 
 import numpy as np
@@ -133,9 +134,18 @@ def test_scene_forward_matches_the_reference_scene_forward():
         assert float(torch.quantile(err.reshape(-1), 0.999)) < 3e-4, (k, float(err.max()))
 
 
-def test_guidance_call_matches_the_reference_call_on_reduced_width_networks():
-    """ControlNetScoreDistillation.__call__ (bf16 HIP plans) vs the reference's BasicScoreDistillation.__call__ / calc_gradients run on
-    the fp32 oracle networks (golden sd.sds.*): result keys, latents, sources / targets, loss == 1, gradients, d loss / d image."""
+# (latents, gradients, image gradient) rel-L2 bars per plan precision against the golden captured from the REFERENCE's own
+# BasicScoreDistillation.__call__ on the fp32 oracle networks.  f32x / f32 = the reference's precision: 1e-3 everywhere; f16 / bf16: the stated
+# tolerance of those plans on these reduced-width networks under CFG 50, ~1.5x the measured values (profiles/r04_parity_sds_step.json).
+# measured: f32x 4.7e-7 / 2.4e-6 / 2.6e-6, f32 5.1e-7 / 2.4e-6 / 2.6e-6, f16 6.2e-4 / 3.0e-3 / 3.4e-3, bf16 5.0e-3 / 2.4e-2 / 2.8e-2
+_CALL_BARS = {"f32x": (1e-4, 1e-4, 1e-4), "f32": (1e-4, 1e-4, 1e-4), "f16": (2e-3, 6e-3, 6e-3), "bf16": (1e-2, 5e-2, 5e-2)}
+
+
+@pytest.mark.parametrize("dtype", ["f32x", "f32", "f16", "bf16"])
+def test_guidance_call_matches_the_reference_call_on_reduced_width_networks(dtype):
+    """ControlNetScoreDistillation.__call__ (HIP plans of each precision) vs the reference's BasicScoreDistillation.__call__ / calc_gradients
+    run on the fp32 oracle networks (golden sd.sds.*; /root/reference/core/guidance/basic.py:778-917): result keys, latents, sources /
+    targets, loss == 1, gradients, d loss / d image."""
     from dreamwaltz_g_amd import guidance, sd15
     c = [int(x) for x in G["sd.sds.cfg"]]
     ucfg = sd15.UNetConfig(block_out_channels=(c[0], c[1]), layers_per_block=c[2], heads=c[3], cross_dim=c[4], groups=c[5],
@@ -147,15 +157,22 @@ def test_guidance_call_matches_the_reference_call_on_reduced_width_networks():
     dev = torch.device("cuda")
     hw = int(G["sd.sds.call.image"].shape[-1])
     text_len = int(G["sd.sds.text.text"].shape[1])
-    gd = guidance.ControlNetScoreDistillation(dev, ucfg, vcfg, usd, csd, vsd, image_hw=hw, text_len=text_len)
+    gd = guidance.ControlNetScoreDistillation(dev, ucfg, vcfg, usd, csd, vsd, image_hw=hw, text_len=text_len, dtype=dtype)
     text = {k: T("sd.sds.text." + k).cuda() for k in ("null", "text", "neg")}
     img = T("sd.sds.call.image").cuda().requires_grad_(True)
     res = gd(img, text, train_step=10, max_iteration=100, cond_inputs=T("sd.sds.cond").cuda(), timestep=T("sd.sds.timestep").cuda(),
              noise=T("sd.sds.call.noise").cuda(), posterior_noise=T("sd.sds.call.vae_noise").cuda())
     assert sorted(res.keys()) == [str(k) for k in G["sd.sds.call.keys"]]
     assert float(res["diffusion_loss"]) == float(G["sd.sds.call.diffusion_loss"][0]) == 1.0
-    assert _rel(res["latents"], T("sd.sds.call.latents")) < 3e-2
-    assert _rel(res["gradients"], T("sd.sds.call.gradients")) < 2e-1
+    b_lat, b_grad, b_img = _CALL_BARS[dtype]
     assert torch.allclose(res["targets"], res["sources"] - res["gradients"])
     (res["diffusion_loss"] * 1.0).backward()
-    assert _rel(img.grad, T("sd.sds.call.image_grad")) < 3e-1
+    rep = dict(latents=_rel(res["latents"], T("sd.sds.call.latents")), gradients=_rel(res["gradients"], T("sd.sds.call.gradients")),
+               image_grad=_rel(img.grad, T("sd.sds.call.image_grad")))
+    print("[parity] guidance_call_golden_" + dtype, rep)
+    path = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "gpurun_out", "parity_sds_step.json")
+    os.makedirs(os.path.dirname(path), exist_ok=True)
+    d = json.load(open(path)) if os.path.exists(path) else {}
+    d["guidance_call_golden_" + dtype] = rep
+    json.dump(d, open(path, "w"), indent=1)
+    assert rep["latents"] < b_lat and rep["gradients"] < b_grad and rep["image_grad"] < b_img, (dtype, rep)

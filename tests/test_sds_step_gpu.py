@@ -104,10 +104,20 @@ def test_step_without_guidance_matches_oracle_chain_and_first_adam_update(async_
     assert step.trainer.redone_frames == 0
 
 
-def test_step_with_reduced_width_guidance_matches_oracle_chain():
+# Bars of the end-to-end "image -> guidance -> raster backward -> parameters" chain per plan precision: (every parameter gradient rel-L2,
+# cosine).  f32x / f32 are the reference's own precision for the guidance stage (configs/__init__.py:236,241): what is left is the avatar
+# side's own agreement with the oracle chain (float atomics, <= 2e-3 without diffusion).  f16 / bf16: the stated tolerance of those plans for
+# PARAMETER gradients at this reduced width under CFG 50 -- about 1.5x the values measured on an MI355X (profiles/r04_parity_sds_step.json,
+# DESIGN.md section 2).
+# measured: f32x / f32 2.6e-4 .. 1.4e-3 (identical to 2 digits: the avatar side's float atomics, not the guidance); f16 1.5 .. 4.2 %; bf16 15 .. 28 %
+_STEP_BARS = {"f32x": (2e-3, 0.99999), "f32": (2e-3, 0.99999), "f16": (6e-2, 0.998), "bf16": (0.42, 0.95)}
+
+
+@pytest.mark.parametrize("dtype", ["f32x", "f32", "f16", "bf16"])
+def test_step_with_reduced_width_guidance_matches_oracle_chain(dtype):
     """The same chain with the SDS gradient in the middle (reduced-width UNet / ControlNet / VAE, 128x128, forced timestep and
-    noises): d loss / d _positions and the table gradient against oracle.animate -> raster oracle -> oracle.sd15.sds_step.
-    The bf16 denoiser under CFG 50 bounds the agreement (see test_guidance_gpu.py)."""
+    noises): EVERY parameter gradient (free Gaussians' positions / scales / quaternions, grid table, mesh-bound barycentrics / scales)
+    against oracle.animate -> raster oracle -> oracle.sd15.sds_step (all fp32 / fp64 on the CPU), per plan precision."""
     from dreamwaltz_g_amd import guidance, sd15, sds_step, synth
     res = 128
     dev = torch.device("cuda")
@@ -116,7 +126,7 @@ def test_step_with_reduced_width_guidance_matches_oracle_chain():
     usd = sd15.random_state_dict(sd15.unet_param_shapes(ucfg), seed=1)
     csd = sd15.random_state_dict(sd15.controlnet_param_shapes(ucfg), seed=2)
     vsd = sd15.random_state_dict(sd15.vae_encoder_param_shapes(vcfg), seed=3)
-    gd = guidance.ControlNetScoreDistillation(dev, ucfg, vcfg, usd, csd, vsd, image_hw=res)
+    gd = guidance.ControlNetScoreDistillation(dev, ucfg, vcfg, usd, csd, vsd, image_hw=res, dtype=dtype)
     a, params, nets, body, _, cnl, mesh = _avatar_pair(with_mesh=True)
     step = sds_step.SDSStep(res=res, guidance=True, avatar=a, guidance_obj=gd, async_pair_count=False, gpu_condition=False)
     obs = synth.random_smpl_inputs(seed=0)
@@ -136,12 +146,15 @@ def test_step_with_reduced_width_guidance_matches_oracle_chain():
     loss, render_outputs, sd_outputs, _ = step.run(timestep=t.to(dev), noise=noise.to(dev), posterior_noise=vnoise.to(dev))
     assert float(loss) == 1.0 and sd_outputs["gradients"].shape == (1, 4, res // 8, res // 8)
     assert sorted(sd_outputs.keys()) == ['diffusion_loss', 'gradients', 'latents', 'sources', 'targets', 'timestep']
+    got = {"_positions": a._positions.grad, "_scales": a._scales.grad, "_quaternions": a._quaternions.grad, "table": a.nerf_encoder.embeddings.grad,
+           "bary": a.mesh_binding_gaussians["hands"]._bary_coords.grad, "mesh_scales": a.mesh_binding_gaussians["hands"]._scales.grad}
     rep = {}
-    for k, got in (("_positions", a._positions.grad), ("_scales", a._scales.grad), ("table", a.nerf_encoder.embeddings.grad)):
-        rep[k + "_rel"], rep[k + "_cos"] = _rel(got, gref[k]), _cos(got, gref[k])
-    _note("step_reduced_width_guidance", **rep)
-    assert rep["_positions_cos"] > 0.9 and rep["_positions_rel"] < 0.5, rep
-    assert rep["table_cos"] > 0.9, rep
+    for k, gv in got.items():
+        rep[k + "_rel"], rep[k + "_cos"] = _rel(gv, gref[k]), _cos(gv, gref[k])
+    _note("step_reduced_width_guidance_" + dtype, **rep)
+    bar, cmin = _STEP_BARS[dtype]
+    for k in got:
+        assert rep[k + "_rel"] < bar and rep[k + "_cos"] > cmin, (dtype, k, rep)
 
 
 def test_step_draws_its_condition_image_on_the_gpu():
