@@ -503,6 +503,7 @@ class DreamWaltzG(nn.Module):
     # -- checkpoints ------------------------------------------------------------------------------------------------
     def invalidate_caches(self):
         """Everything derived from parameters / buffers that a checkpoint load or an in-place edit may have changed."""
+        self.cache_generation = getattr(self, "cache_generation", 0) + 1       # the trainer refills the caches on ONE stream (trainer._check_caches)
         self._canonical_cache = None
         self._canonical_vertices = {}
         self.nerf_encoder._host_offsets_py = None

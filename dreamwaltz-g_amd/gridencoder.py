@@ -126,7 +126,23 @@ def xcd_counters_for(device):
     return _xcd_counters[key]
 
 
-INPLACE_TABLE_GRAD = True      # see _grid_encode.backward; a multi-stream multi-view step turns it off (concurrent read-add-writes of one buffer)
+_INPLACE_OK = [True]
+
+
+class table_grad_inplace:
+    """`with table_grad_inplace(False):` -- forwards issued inside the block opt OUT of the in-place table gradient (see
+    _grid_encode.backward): a multi-stream multi-view step, whose concurrent backwards must not read-add-write one gradient slice.  The
+    decision is taken at FORWARD time and travels on the autograd ctx; nothing global is consulted by the backward, and leaving the block
+    (normally or by an exception) restores the previous setting."""
+
+    def __init__(self, ok: bool):
+        self.ok = bool(ok)
+
+    def __enter__(self):
+        self.prev, _INPLACE_OK[0] = _INPLACE_OK[0], self.ok
+
+    def __exit__(self, *exc):
+        _INPLACE_OK[0] = self.prev
 
 _SLAB_WS = {}     # (device, stream) -> byte workspace of the slab-binned backward (grown on demand; backwards on one stream are ordered,
                   # a workspace replaced by a bigger one is only released by the caching allocator in that stream's order)
@@ -204,6 +220,7 @@ class _grid_encode(Function):
         ctx.dims = [B, D, C, L, S, H, gridtype, interpolation]
         ctx.align_corners = align_corners
         ctx.host_offsets = host_offsets
+        ctx.inplace_ok = _INPLACE_OK[0]
         return outputs
 
     @staticmethod
@@ -221,12 +238,14 @@ class _grid_encode(Function):
             mode = "device"
         scratch = xcd_scratch_for(embeddings) if mode == "copies" else None
         slab_ws = slab_workspace_for(inputs.device, B, L, int(embeddings.shape[0])) if mode == "slabs" else None
-        # The table is a leaf Parameter whose .grad is its slice of the flat gradient buffer (optim.FlatBuffers): the slab pass ADDS straight
-        # into it and autograd is handed None -- instead of a zeroed 50 MB temporary that autograd then adds to .grad (a 50 MB fill and a
-        # 150 MB add per backward).  DWG_GRID_GRAD_INPLACE=0 restores the temporary.
-        in_place = (mode == "slabs" and embeddings.is_leaf and embeddings.grad is not None and embeddings.grad.is_contiguous()
+        # The table is a leaf Parameter whose .grad is its slice of the flat gradient buffer (optim.FlatBuffers marks such parameters:
+        # `_dwg_flat`): the slab pass ADDS straight into it and autograd is handed None -- instead of a zeroed 50 MB temporary that autograd
+        # then adds to .grad (a 50 MB fill and a 150 MB add per backward).  Opt-in PER PARAMETER: any other caller (torch.autograd.grad on
+        # the table, tensor hooks, another optimizer) gets the gradient returned the ordinary way.  DWG_GRID_GRAD_INPLACE=0: always.
+        flat = getattr(embeddings, "_dwg_flat", None)
+        in_place = (mode == "slabs" and flat is not None and embeddings.is_leaf and embeddings.grad is not None and embeddings.grad.is_contiguous()
                     and embeddings.grad.dtype == torch.float32 and embeddings.grad.shape == embeddings.shape
-                    and INPLACE_TABLE_GRAD and os.environ.get("DWG_GRID_GRAD_INPLACE", "1") != "0")
+                    and ctx.inplace_ok and os.environ.get("DWG_GRID_GRAD_INPLACE", "1") != "0")
         grad_embeddings = embeddings.grad if in_place else torch.zeros_like(embeddings)
         counters = xcd_counters_for(inputs.device) if (mode == "owner" and grad_embeddings.data_ptr() % 128 == 0) else None
         try:
@@ -237,6 +256,8 @@ class _grid_encode(Function):
             if scratch is not None:
                 scratch.zero_()        # a failed launch must not leave partial sums for the next call
             raise
+        if in_place:
+            flat.touch(embeddings)      # autograd never sees this gradient: record the parameter's participation for the optimizer
         return grad_inputs, (None if in_place else grad_embeddings), None, None, None, None, None, None, None, None
 
 

@@ -46,7 +46,14 @@ class AdamSpec:
 
 class FlatBuffers:
     """ONE flat fp32 buffer each for parameters, gradients and the two Adam moments (16-byte aligned slices).  The nn.Parameters
-    are re-homed into the flat buffers (`.data` and `.grad` become views)."""
+    are re-homed into the flat buffers (`.data` and `.grad` become views).
+
+    Participation: with `.grad` always defined (a view of the flat gradient buffer) an optimizer cannot tell a parameter that took no part
+    in this step's backward from one whose gradient is zero -- torch.optim.Adam can (`grad is None` after `zero_grad()`: the parameter, its
+    moments and its step count stay as they are; gaussian_optimizer.py:93, trainer.py:861-890).  Every parameter therefore carries a
+    post-accumulate hook that records that autograd wrote its slice this step (`touch` for kernels that add into the slice themselves: the
+    grid table's in-place gradient), and FlatOptimizer.step() leaves un-touched groups alone.  Callers that fill the flat gradient by hand
+    (no backward ran: nothing was recorded) get the plain "step everything" behaviour."""
 
     def __init__(self, params: List[torch.nn.Parameter], device):
         total, self.slices = 0, []
@@ -57,11 +64,30 @@ class FlatBuffers:
         self.grad = torch.zeros(total, device=device)
         self.m = torch.zeros(total, device=device)
         self.v = torch.zeros(total, device=device)
+        self.tracking = False           # some backward has recorded participation since the last zero_grad
+        self._hooks = []
         for p, (off, n) in zip(params, self.slices):
             self.flat[off:off + n].copy_(p.data.reshape(-1))
             p.data = self.flat[off:off + n].view_as(p.data)
             p.grad = self.grad[off:off + n].view_as(p.data)
+            p._dwg_flat = self          # "my .grad is a slice of a flat gradient buffer": what lets a kernel add into it in place
+            p._dwg_touched = False
+            if p.requires_grad:
+                self._hooks.append(p.register_post_accumulate_grad_hook(self.touch))
         self.total = total
+
+    def touch(self, p):
+        p._dwg_touched = True
+        self.tracking = True
+
+    def release(self, params):
+        """Detach from the parameters (the buffers are being replaced: resize_flat_params)."""
+        for h in self._hooks:
+            h.remove()
+        self._hooks = []
+        for p in params:
+            if getattr(p, "_dwg_flat", None) is self:
+                p._dwg_flat = None
 
 
 class FlatOptimizer:
@@ -105,6 +131,10 @@ class FlatOptimizer:
 
     def zero_grad(self, set_to_none: bool = False):
         self.buf.grad[self.start:self.end].zero_()
+        self.buf.tracking = False
+        for pg in self.param_groups:
+            for p in pg.get('params', ()):
+                p._dwg_touched = False
 
     def step(self):
         """One Adam step of every param group.  Bias correction uses the group's OWN step count (torch.optim.Adam keeps one per parameter):
@@ -117,6 +147,10 @@ class FlatOptimizer:
                 # it (and its moments) alone for this step (gaussian_densifier.py:141-161 + trainer.py:876-890)
                 continue
             if pg["end"] <= pg["start"]:
+                continue
+            if self.buf.tracking and pg.get('params') and not any(getattr(p, "_dwg_touched", False) for p in pg['params']):
+                # no parameter of this group took part in this step's backward: torch.optim.Adam sees `grad is None` and leaves the
+                # parameter, both moments and the step count untouched (no drift on stale momentum, no ageing of the bias correction)
                 continue
             pg["t"] = pg.get("t", 0) + 1
             self._launch(pg)
@@ -213,6 +247,7 @@ def resize_flat_params(opts: FlatOptimizerDict, new_values: Dict[torch.nn.Parame
         for pg in o.param_groups:
             if 'params' in pg:
                 pg['params'] = [renamed.get(p, p) for p in pg['params']]
+    old.release(list(keep.keys()))
     for p in opts.params:
         p.data = keep[p][0]
         p.grad = None

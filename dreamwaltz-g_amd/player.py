@@ -47,12 +47,8 @@ class GraphedAnimation:
         own = PairCapacity()
         own.cap = max(shared.cap, int(most * grow), shared.min_pairs, int(min_cap))
         own.frozen = True
-        self._state, self._state_key = own, (self.scene.renderer, (str(self._dev_key()), H, W))
+        self._state, self._state_key = own, (self.scene.renderer, (H, W))
         self._capture_frozen()
-
-    def _dev_key(self):
-        d = torch.device(self.device)
-        return torch.device("cuda", torch.cuda.current_device()) if d.index is None else d
 
     def _forget_pose_caches(self):
         # the skeleton pass remembers its last result per input tensors and versions (avatar.GeneralLinearBlendSkinning.forward): the
@@ -65,9 +61,7 @@ class GraphedAnimation:
         """Capture one frame at the pair capacity the state holds now."""
         state = self._state
         state.overflow, state.pending, state.frozen = False, False, True
-        renderer, key = self._state_key
-        shared = renderer._pair_states.get(key)
-        renderer._pair_states[key] = state                                     # only while the two frames below are issued
+        renderer, (H, W) = self._state_key
         for entry in self.scene.renderer._visit_orders.values():               # the renderer's periodic refresh of the binning order must not
             entry[1] = 0                                                       # fall into the two frames below (it would be replayed per frame)
         # The captured kernels read the binning order through its DEVICE POINTER.  Eager frames through the same renderer replace the
@@ -77,6 +71,11 @@ class GraphedAnimation:
         side = torch.cuda.Stream(device=self.device)
         side.wait_stream(torch.cuda.current_stream(self.device))
         with torch.cuda.stream(side):
+            # the key the renderer computes for frames issued on THIS stream (it carries the stream once a multi-view step has switched the
+            # renderer to per-stream states): asked of the renderer, not rebuilt here
+            key = renderer.pair_state_key(self.device, H, W)
+            shared = renderer._pair_states.get(key)
+            renderer._pair_states[key] = state                                 # only while the two frames below are issued
             self._frame()                                                      # once eagerly at the frozen capacity (allocator warm-up)
             side.synchronize()
             self._forget_pose_caches()

@@ -50,7 +50,8 @@ class PairCapacity:
         self.frozen = False              # True: fixed capacity, no events, no host waits (a frame captured into a graph, see player.py)
         self.seq = 0                     # frames rendered through this state; `pending_seq` = the frame whose count is in flight
         self.pending_seq = 0
-        self.overflow_seq = -1           # the (latest) frame that was truncated: its backward returns zeros (see _RasterizeGaussians.backward)
+        self.overflow_seqs = set()       # EVERY recent frame that was truncated (several may be in flight through one state before their
+                                         # backwards run): each one's backward returns zeros (see _RasterizeGaussians.backward)
         self.last_num_pairs = 0          # pairs after exact culling (what the buffers hold)
         self.last_num_pairs_ref = 0      # sum of 16x16 reference tiles touched (the K of SURVEY 8d's byte formula)
 
@@ -66,7 +67,9 @@ class PairCapacity:
         self.last_num_pairs, self.last_num_pairs_ref = K, Kref
         if ovf:
             self.overflow = True
-            self.overflow_seq = self.pending_seq
+            self.overflow_seqs.add(self.pending_seq)
+            if len(self.overflow_seqs) > 64:                 # bounded: frames this old have had their backward or never will
+                self.overflow_seqs = {q for q in self.overflow_seqs if q > self.pending_seq - 64}
         if ovf or K * 2 > self.cap:
             self.cap = max(self.cap, int(K * self.headroom))
 
@@ -189,7 +192,7 @@ class _RasterizeGaussians(torch.autograd.Function):
         G = int(means3D.shape[0])
         if ctx.pair_state is not None:
             ctx.pair_state.resolve()     # this frame's forward finished long ago: free, and latches a capacity overflow
-            if ctx.pair_state.overflow_seq == ctx.frame_seq:
+            if ctx.frame_seq in ctx.pair_state.overflow_seqs:
                 # THIS frame was truncated by the pair capacity: its owner renders it again (SDSTrainer.train_step).  Its gradient is
                 # ZERO, not the truncated frame's partial one -- a multi-view step accumulates several frames into one gradient buffer
                 # before the optimizer runs, and the re-rendered frame must be the only contribution of its view.

@@ -73,16 +73,23 @@ class GaussianRenderer:
         self._visit_orders = {}
 
     # -- capacity bookkeeping of the async mode ------------------------------------------------------------------------
-    def pair_state(self, device, H, W) -> Optional[PairCapacity]:
-        if not self.async_pair_count:
-            return None
+    def pair_state_key(self, device, H, W):
+        """The key of the PairCapacity a frame rendered NOW (this device, size and current stream) uses: one helper for `pair_state` and for
+        whoever installs a state of its own (player.GraphedAnimation's frozen capacity) -- the two cannot disagree about the key's shape."""
         device = torch.device(device)
         if device.type == "cuda" and device.index is None:          # "cuda" and "cuda:<current>" are one device, one state
             device = torch.device("cuda", torch.cuda.current_device())
-        # one state per stream as well: a multi-view step renders its views concurrently on side streams, and a state's pinned count /
+        # one state per stream as well once a multi-view step has rendered its views concurrently on side streams: a state's pinned count /
         # overflow words belong to ONE in-flight frame
+        if not stream_keyed(self):
+            return (str(device), int(H), int(W))
         stream = torch.cuda.current_stream(device).cuda_stream if device.type == "cuda" else 0
-        key = (str(device), int(H), int(W)) if not stream_keyed(self) else (str(device), int(H), int(W), stream)
+        return (str(device), int(H), int(W), stream)
+
+    def pair_state(self, device, H, W) -> Optional[PairCapacity]:
+        if not self.async_pair_count:
+            return None
+        key = self.pair_state_key(device, H, W)
         if key not in self._pair_states:
             self._pair_states[key] = PairCapacity()
         return self._pair_states[key]

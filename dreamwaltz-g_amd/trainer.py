@@ -36,6 +36,13 @@ class SDSTrainer:
         self.past_checkpoints = []
         self.set_views(world)                       # one view per rank unless the caller says otherwise: mean of the summed gradients,
                                                     # folded into the Adam kernel
+        # SURVEY 8e replica-consistency guard (nothing in the reference to mirror: it is single-GPU).  Replicas start from rank 0's
+        # parameters, and every `replica_check_every` steps a 64-bit checksum of the flat parameter buffer is compared across the ranks
+        # (one all-reduce of two int64 words): a drift -- a non-deterministic reduction order, a rank that missed an update -- raises on
+        # every rank instead of training on silently diverged replicas.  DWG_REPLICA_CHECK_EVERY=0 turns the check off.
+        self.replica_check_every = int(os.environ.get("DWG_REPLICA_CHECK_EVERY", "100"))
+        if self.world > 1:
+            self.sync_replicas()
 
     # -- checkpoints (trainer.py:188-259): {'train_step', 'checkpoints', 'model': Scene.state_dict()[, 'optimizers', 'scaler']} ------
     def save_checkpoint(self, ckpt_dir, full: bool = False, max_keep_ckpts: int = 2):
@@ -116,7 +123,19 @@ class SDSTrainer:
             if renderer is not None:
                 renderer.per_stream_pair_states = True
         from . import gridencoder as _ge
-        _ge.INPLACE_TABLE_GRAD = not multi          # concurrent backwards must not read-add-write the table's gradient slice in place
+        seeded = [v.get('rng_seed') is not None for v in views]
+        if any(seeded) and not all(seeded):
+            raise ValueError("train_forward_views: `rng_seed` must be given for every view of a batched step or for none "
+                             "(%d of %d views carry one)" % (sum(seeded), len(views)))
+        with _ge.table_grad_inplace(not multi):     # concurrent backwards must not read-add-write the table's gradient slice in place
+            self._render_views(views, multi, main, images, texts, names, conds, draws, outs, forced)
+        if multi:
+            for side in self._view_streams[:len(views)]:
+                main.wait_stream(side)
+        self._views_warm = True
+        return self._guide_views(images, texts, names, conds, draws, outs, forced)
+
+    def _render_views(self, views, multi, main, images, texts, names, conds, draws, outs, forced):
         for i, data in enumerate(views):
             if multi:
                 side = self._view_streams[i]
@@ -140,10 +159,8 @@ class SDSTrainer:
                     self._view_rng = torch.Generator(device=images[-1].device)
                 self._view_rng.manual_seed(int(seed))
                 draws.append(self.diffusion.draw_view_randoms(self._view_rng, self.train_step_index, self.max_step))
-        if multi:
-            for side in self._view_streams[:len(views)]:
-                main.wait_stream(side)
-        self._views_warm = True
+
+    def _guide_views(self, images, texts, names, conds, draws, outs, forced):
         sd_inputs = torch.cat(images, dim=0).contiguous()
         embeds = dict(self.text_embeds_dict)
         if texts[0] is not None:
@@ -223,6 +240,8 @@ class SDSTrainer:
         Every view's gradient is accumulated into the one flat buffer, then ONE all-reduce (RCCL over xGMI) when world > 1, then the
         fused Adam with 1 / V folded in (the mean over ALL views of the step, `set_views`)."""
         views = list(data) if isinstance(data, (list, tuple)) else [data]
+        self._check_densifier(len(views))
+        self._check_caches()
         self.train_step_index += 1
         self._begin_step(self.get_spatial_scale(views[0]))
         out = None
@@ -232,8 +251,6 @@ class SDSTrainer:
             while True:
                 loss, outs, sd_outputs, names = self.train_forward_views(views, **forced)
                 loss.backward()
-                from . import gridencoder as _ge
-                _ge.INPLACE_TABLE_GRAD = True
                 if renderer is None or not renderer.consume_overflow():
                     break
                 self.redone_frames += 1         # a truncated frame contributed zeros, the others did not: start the step's gradient over
@@ -243,20 +260,58 @@ class SDSTrainer:
             for view in views:
                 out = self._view(view, **forced)
         if self.densifiers is not None:
-            # trainer.py:879-886: between backward and the optimizer steps; single-view steps only (the reference's only kind) -- the
-            # accumulated statistics are per rendered frame, and replicas of a multi-GPU job would have to densify identically
-            if len(views) != 1 or self.world != 1:
-                raise NotImplementedError("densification inside a multi-view / multi-GPU step")
+            # trainer.py:879-886: between backward and the optimizer steps (single-view, single-rank steps only: checked before the forward)
             self.model.densify(densifiers=self.densifiers, render_outputs=out[1], spatial_scale=self.get_spatial_scale(views[0]),
                                train_step=self.train_step_index)
         if self.world > 1:
             self.dist.all_reduce(self.optimizers.all_grads())       # one flat fp32 buffer
         for optimizer in self.optimizers.values():
             optimizer.step()
+        if self.world > 1 and self.replica_check_every > 0 and self.train_step_index % self.replica_check_every == 0:
+            self.check_replicas()
         return out
+
+    def _check_densifier(self, n_views):
+        """The densifier is the reference's single-view, single-GPU feature (trainer.py:879-886): its statistics are per rendered frame, and
+        replicas of a multi-GPU job would have to densify identically.  Refused BEFORE a step's forward / backward run."""
+        if self.densifiers is not None and (n_views != 1 or self.world != 1 or self.total_views != 1):
+            raise NotImplementedError("densification inside a multi-view / multi-GPU step (views this rank: %d, ranks: %d, views per step: %d)"
+                                      % (n_views, self.world, self.total_views))
+
+    def _check_caches(self):
+        """The constant canonical-pose caches of the avatar are (re)filled by the first render after `invalidate_caches()` (checkpoint load,
+        densification): that render must run on ONE stream -- the per-view side streams of a batched step have no dependency on each other."""
+        gen = getattr(getattr(self.model, "avatar", None), "cache_generation", None)
+        if gen != getattr(self, "_cache_generation", None):
+            self._cache_generation = gen
+            self._views_warm = False
+
+    # -- replica consistency (world > 1) ------------------------------------------------------------------------------------------------
+    def sync_replicas(self, src: int = 0):
+        """Every rank takes rank `src`'s flat parameter buffer and Adam moments (construction, and after a checkpoint load on one rank)."""
+        buf = getattr(self.optimizers, "buffers", None)
+        if self.world <= 1 or buf is None or self.dist is None:
+            return
+        for t in (buf.flat, buf.m, buf.v):
+            self.dist.broadcast(t, src=src)
+
+    def replica_checksum(self) -> torch.Tensor:
+        """64-bit checksum of the flat parameter buffer: the sum of its fp32 words read as int32, in int64 (exact, order-independent)."""
+        return self.optimizers.buffers.flat.view(torch.int32).sum(dtype=torch.int64)
+
+    def check_replicas(self):
+        """all-reduce(MAX) of (c, -c): max and min of the ranks' checksums in one collective; raises RuntimeError on EVERY rank on drift."""
+        c = self.replica_checksum().reshape(1)
+        both = torch.cat([c, -c])
+        self.dist.all_reduce(both, op=self.dist.ReduceOp.MAX)
+        hi, lo = int(both[0]), -int(both[1])
+        if hi != lo:
+            raise RuntimeError("replica drift at step %d: parameter checksums differ across the %d ranks (max %d, min %d; this rank %d) -- "
+                               "the replicas of a multi-GPU SDS job must apply bit-identical updates" % (self.train_step_index, self.world, hi, lo, int(c)))
 
     def set_views(self, total_views: int):
         """Views per step over ALL ranks (default: one per rank): the optimizers see the MEAN gradient over them."""
         self.total_views = int(total_views)
+        self._check_densifier(1)
         if hasattr(self.optimizers, "set_grad_scale"):
             self.optimizers.set_grad_scale(1.0 / self.total_views)

@@ -168,3 +168,60 @@ def test_train_step_multiview_two_ranks_equal_one_process_accumulating_the_same_
     finally:
         optim.FlatOptimizer._launch = saved
     assert opts1["avatar"].grad_scale == 1.0 and not torch.equal(before, opts1.buffers.flat)
+
+
+# ---------------------------------------------------------------------------------------------------------------------------------------
+# SURVEY 8e replica-consistency guard: rank 0's parameters are broadcast at construction; a checksum of the flat parameter buffer is
+# compared across the ranks every `replica_check_every` steps and a drift raises on EVERY rank.
+# ---------------------------------------------------------------------------------------------------------------------------------------
+def _guard_worker(rank, world, port, q):
+    import sys
+    sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    import dwg_import  # noqa: F401
+    os.environ["MASTER_ADDR"] = "127.0.0.1"; os.environ["MASTER_PORT"] = str(port)
+    os.environ["DWG_REPLICA_CHECK_EVERY"] = "2"
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    V = 2
+    from dreamwaltz_g_amd import configs, optim, sds_step, trainer
+    optim.FlatOptimizer._launch = _cpu_adam_launch
+    cfg = configs.TrainConfig(); cfg.device = "cpu"; cfg.prompt.text_augmentation = False
+    scene = _ToyScene()
+    with torch.no_grad():
+        scene.a.add_(0.25 * rank)                       # replicas that were initialised DIFFERENTLY ...
+    opts = optim.build_flat_optimizers({"avatar": optim.AdamSpec([dict(params=[scene.a], lr=1e-2)], eps=1e-15),
+                                        "nerf": optim.AdamSpec([dict(params=[scene.b], lr=1e-3)], betas=(0.9, 0.99), eps=1e-15)}, torch.device("cpu"))
+    w = torch.randn(1, 4, 4, 3, generator=torch.Generator().manual_seed(9))
+    tr = trainer.SDSTrainer(cfg, scene, sds_step._ImageLoss(w), opts, {}, use_controlnet=False, dist=dist, world=world, max_step=100)
+    tr.set_views(V)
+    start = opts.buffers.flat.clone()                   # ... are rank 0's after construction
+    log = []
+    for step in range(4):                               # checks at steps 2 and 4: clean
+        tr.train_step(_toy_views(range(rank, V, world), step))
+    log.append("clean")
+    if rank == 1:
+        with torch.no_grad():
+            scene.b[0] += 1e-6                          # one rank drifts by one fp32 word
+    try:
+        for step in range(4, 6):                        # the check at step 6 must raise on BOTH ranks
+            tr.train_step(_toy_views(range(rank, V, world), step))
+        log.append("not detected")
+    except RuntimeError as e:
+        log.append("raised" if "replica drift" in str(e) else "other: %s" % e)
+    q.put((rank, start.numpy().copy(), log))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_replica_guard_broadcasts_rank0_and_raises_on_drift_on_every_rank():
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_guard_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = sorted([q.get(timeout=300) for _ in range(2)], key=lambda t: t[0])
+    for p in procs:
+        p.join(timeout=120)
+        assert p.exitcode == 0
+    assert (res[0][1] == res[1][1]).all()               # the differently initialised rank took rank 0's parameters
+    assert res[0][2] == ["clean", "raised"] and res[1][2] == ["clean", "raised"], (res[0][2], res[1][2])

@@ -236,3 +236,53 @@ def test_frozen_pair_capacity_never_waits():
     assert st.cap == cap and st.pending
     st.frozen, st.pending = False, False
     assert st.consume_overflow() is False
+
+
+def test_flat_optimizer_leaves_groups_without_a_gradient_alone_like_torch_adam():
+    """torch.optim.Adam skips a parameter whose `grad is None` (it took no part in this step's backward): parameter, moments and step count
+    stay (/root/reference/core/gaussian/gaussian_optimizer.py:93 builds exactly that optimizer; trainer.py:861-890 zero_grad()s to None).
+    The flat-buffer optimizers reproduce it from the participation the backward recorded -- one group's gradient withheld on alternating
+    steps, against torch.optim.Adam step for step.  (The fused HIP Adam launch is restated in torch: no GPU here.)"""
+    import torch
+    from dreamwaltz_g_amd import optim
+    from tests.test_distributed_cpu import _cpu_adam_launch
+    saved = optim.FlatOptimizer._launch
+    optim.FlatOptimizer._launch = _cpu_adam_launch
+    try:
+        g = torch.Generator().manual_seed(0)
+        a = torch.nn.Parameter(torch.randn(6, 3, generator=g)); b = torch.nn.Parameter(torch.randn(5, generator=g))
+        c = torch.nn.Parameter(torch.randn(4, generator=g))
+        ra, rb, rc = (torch.nn.Parameter(t.detach().clone()) for t in (a, b, c))
+        ref = torch.optim.Adam([dict(params=[ra], lr=1e-2), dict(params=[rb], lr=3e-3), dict(params=[rc], lr=1e-3)], eps=1e-15)
+        opts = optim.build_flat_optimizers({"avatar": optim.AdamSpec([dict(params=[a], lr=1e-2), dict(params=[b], lr=3e-3)], eps=1e-15),
+                                            "lbs": optim.AdamSpec([dict(params=[c], lr=1e-3)], eps=1e-15)}, torch.device("cpu"))
+
+        def loss_of(pa, pb, pc, it):
+            x = torch.linspace(0.1, 1.0, 3) * (it + 1)
+            out = (pa @ x).pow(2).sum()
+            if it % 2 == 0:
+                out = out + (pb * pb).sum() * 0.5 + pc.sum() * 0.0      # c takes part with an exactly ZERO gradient: it IS stepped
+            return out                                                  # odd steps: b and c take no part at all
+        for it in range(6):
+            for o in opts.values():
+                o.zero_grad()
+            ref.zero_grad(set_to_none=True)
+            loss_of(a, b, c, it).backward()
+            loss_of(ra, rb, rc, it).backward()
+            assert (rb.grad is None) == (it % 2 == 1)
+            for o in opts.values():
+                o.step()
+            ref.step()
+            for p, r in ((a, ra), (b, rb), (c, rc)):
+                assert torch.allclose(p.data, r.data, rtol=1e-6, atol=1e-7), (it, float((p.data - r.data).abs().max()))
+        assert opts["avatar"].param_groups[0]["t"] == 6 and opts["avatar"].param_groups[1]["t"] == 3 and opts["lbs"].param_groups[0]["t"] == 3
+        # gradients written by hand (no backward ran, nothing recorded): every group steps, as before
+        for o in opts.values():
+            o.zero_grad()
+        before = b.data.clone()
+        b.grad.fill_(1.0)
+        for o in opts.values():
+            o.step()
+        assert not torch.equal(before, b.data) and opts["avatar"].param_groups[1]["t"] == 4
+    finally:
+        optim.FlatOptimizer._launch = saved
