@@ -162,65 +162,79 @@ def _cpu_pass(w, backward):
     return t1 - t0, t2 - t1
 
 
-_THREADS = {}
+CPU_BASELINE_THREADS = 32     # the SAME thread count on every box (torch intra-op pool and the OpenMP tile rasterizer alike)
 
 
-def _pick_threads(host):
-    """torch thread count for the oracle: the faster of {all host cores, 32} on a micro-probe of what the oracle's
-    `animate` is made of -- a few dozen element-wise / reduction / small-matmul ops on [1e4, 55]-sized tensors, forward and backward.
-    (Measured on the 256-core GPU hosts, round 3: the WHOLE 10k-Gaussian oracle pass takes 0.16 s on 32 threads and 33.7 s on 256, 3.7 s
-    vs 110 s with the backward -- every small op pays the wake-up of 256 OpenMP threads; probing with the full pass cost the default
-    bench run four minutes, hence the micro-probe.)  Cached for the process."""
-    if host in _THREADS:
-        return _THREADS[host]
-    g = torch.Generator().manual_seed(0)
-    w = torch.rand(10000, 55, generator=g); A = torch.randn(55, 16, generator=g); p = torch.randn(10000, 3, generator=g)
+class _pinned:
+    """Pins EVERY thread of this process to `n` cores of its allowed set for the duration of the block and restores the masks afterwards:
+    the oracle's small-tensor torch ops migrate between the 256 cores of a GPU host otherwise, and the same leg measured 0.24 .. 0.91
+    steps/s on different boxes (round 3).  Threads created inside the block inherit the mask."""
 
-    def probe():
-        t0 = time.perf_counter()
-        for _ in range(3):
-            x = p.clone().requires_grad_(True)
-            wn = w / w.sum(-1, keepdim=True)
-            T = (wn @ A).view(-1, 4, 4)
-            y = (T[:, :3, :3] @ x[:, :, None])[..., 0] + T[:, :3, 3]
-            q = torch.nn.functional.normalize(torch.cat([y, y.norm(dim=-1, keepdim=True)], -1), dim=-1)
-            (torch.sigmoid(q).sum() + torch.exp(-y * y).sum()).backward()
-        return time.perf_counter() - t0
-    out = {}
-    for th in sorted({host, min(host, 32)}):
-        torch.set_num_threads(th)
-        probe()
-        out[th] = probe()
-    _THREADS[host] = (min(out, key=out.get), out)
-    return _THREADS[host]
+    def __init__(self, n):
+        self.n = n
+
+    def _tids(self):
+        try:
+            return [int(t) for t in os.listdir("/proc/self/task")]
+        except OSError:
+            return [0]
+
+    def __enter__(self):
+        self.saved = {}
+        try:
+            allowed = sorted(os.sched_getaffinity(0))
+        except (AttributeError, OSError):
+            self.cpus = None
+            return self
+        self.cpus = set(allowed[:self.n])
+        for t in self._tids():
+            try:
+                self.saved[t] = os.sched_getaffinity(t)
+                os.sched_setaffinity(t, self.cpus)
+            except OSError:
+                pass
+        return self
+
+    def __exit__(self, *exc):
+        for t, m in self.saved.items():
+            try:
+                os.sched_setaffinity(t, m)
+            except OSError:
+                pass
 
 
 def cpu_baseline(G, res, backward=True, canonical=False, budget_s=10.0, unit="steps/s"):
     """The oracle (CPU restatement of the reference's PyTorch LBS / encoder / MLP path + the C tile rasterizer, OpenMP over tiles) timed on
-    the host cores on the SAME kind of workload the GPU step renders.  Thread count: BASELINE.md section 4 prescribes
-    torch.set_num_threads(os.cpu_count()); on the 256-core GPU hosts the oracle's small-tensor torch ops run far slower with every core
-    than with 32 threads, so both settings are timed on a micro-probe (`_pick_threads`) and the passes use the faster one (both probe
-    times are reported; the C rasterizer always uses every core through OpenMP).  The reference has no CPU diffusion path, so the diffusion half of a step has no CPU
-    counterpart and is NOT in this number."""
+    the host cores on the SAME kind of workload the GPU step renders.  Hygiene (round 4): a FIXED 32 threads on every box (BASELINE.md
+    section 4 prescribes all cores; on the 256-core GPU hosts the oracle's small-tensor ops are 30x slower that way -- every op pays the
+    wake-up of 256 OpenMP threads), every thread of the process pinned to 32 cores while the passes run, one untimed warm-up pass, then
+    at least 5 timed passes: min AND median reported, `value` = from the median.  The reference has no CPU diffusion path, so the diffusion
+    half of a step has no CPU counterpart and is NOT in this number."""
     import numpy as np
     host = os.cpu_count() or 1
-    os.environ["OMP_NUM_THREADS"] = str(host)            # the OpenMP raster oracle reads it when its library is first loaded
-    best, probe_s = _pick_threads(host)
-    torch.set_num_threads(best)
-    w = _cpu_workload(G, res, canonical)
-    ta, tr, spent = [], [], 0.0
-    while len(ta) < 5 and (spent < budget_s or len(ta) < 2):            # median of the passes that fit ~budget_s of CPU work, at most 5
-        a, r = _cpu_pass(w, backward)
-        ta.append(a); tr.append(r); spent += a + r
+    nthr = min(CPU_BASELINE_THREADS, host)
+    os.environ["OMP_NUM_THREADS"] = str(nthr)            # the OpenMP raster oracle reads it when its library is first loaded
+    prev_threads = torch.get_num_threads()
+    with _pinned(nthr) as pin:
+        torch.set_num_threads(nthr)
+        w = _cpu_workload(G, res, canonical)
+        _cpu_pass(w, backward)                           # warm-up: library load, OpenMP pools, allocator
+        ta, tr, spent = [], [], 0.0
+        while len(ta) < 5 or (spent < budget_s and len(ta) < 9):
+            a, r = _cpu_pass(w, backward)
+            ta.append(a); tr.append(r); spent += a + r
+    torch.set_num_threads(prev_threads)
+    tot = np.array(ta) + np.array(tr)
+    t_med, t_min = float(np.median(tot)), float(tot.min())
     t_an, t_ra = float(np.median(ta)), float(np.median(tr))
     what = "fwd+bwd" if backward else "forward"
-    return {"value": 1.0 / (t_an + t_ra), "unit": "%s (animate + rasterizer %s, no diffusion)" % (unit, what), "cores": best, "kind": "port",
-            "host_cores": host,
-            "threads_probe_s": {str(k): round(v, 3) for k, v in probe_s.items()},
-            "sample": "median of %d passes (%.0f s of CPU work): oracle animate %s %.3f s on %d torch threads (%d free Gaussians with 4 non-zero "
-                      "skinning weights + %d mesh-bound) + C tile rasterizer %s %.3f s (OpenMP over tiles, %d threads; %d Gaussians @%dx%d); thread "
-                      "count = the faster of {all %d cores, 32} on a micro-probe of the oracle's op mix"
-                      % (len(ta), spent, what, t_an, best, w["N"], w["M"], what, t_ra, host, G, res, res, host)}
+    return {"value": 1.0 / t_med, "value_best": 1.0 / t_min, "unit": "%s (animate + rasterizer %s, no diffusion)" % (unit, what), "cores": nthr,
+            "kind": "port", "host_cores": host, "pinned": pin.cpus is not None, "passes": len(ta),
+            "s_per_pass": {"min": round(t_min, 4), "median": round(t_med, 4), "max": round(float(tot.max()), 4)},
+            "sample": "%d timed passes after 1 warm-up (%.0f s of CPU work), value = 1 / median: oracle animate %s %.3f s (%d free Gaussians with 4 "
+                      "non-zero skinning weights + %d mesh-bound) + C tile rasterizer %s %.3f s (OpenMP over tiles; %d Gaussians @%dx%d); %d threads "
+                      "for both, every thread of the process pinned to %d cores of the %d-core host"
+                      % (len(ta), spent, what, t_an, w["N"], w["M"], what, t_ra, G, res, res, nthr, nthr, host)}
 
 
 # ------------------------------------------------------------------------------------------------------------------------------------

@@ -33,6 +33,7 @@ class SDSTrainer:
         self.redone_frames = 0
         self._view_rng = None
         self._view_streams, self._views_warm = [], False
+        self._cache_generation = getattr(getattr(model, "avatar", None), "cache_generation", None)
         self.past_checkpoints = []
         self.set_views(world)                       # one view per rank unless the caller says otherwise: mean of the summed gradients,
                                                     # folded into the Adam kernel
@@ -122,6 +123,14 @@ class SDSTrainer:
             renderer = getattr(self.model, "renderer", None)
             if renderer is not None:
                 renderer.per_stream_pair_states = True
+            # The views' backward chains run on their forwards' side streams and all end in the SAME parameters' AccumulateGrad nodes (created
+            # by whichever view touched the parameter first): autograd orders each accumulation behind its producer with an event wait -- the
+            # synchronisation this design wants, one per (parameter, view), not an accident -- and warns about the stream mismatch once per
+            # process.  The single-view step creates and consumes its nodes on one stream and never triggers it.
+            warn_off = getattr(torch.autograd.graph, "set_warn_on_accumulate_grad_stream_mismatch", None)
+            if warn_off is not None and not getattr(self, "_accum_warn_off", False):
+                warn_off(False)
+                self._accum_warn_off = True
         from . import gridencoder as _ge
         seeded = [v.get('rng_seed') is not None for v in views]
         if any(seeded) and not all(seeded):
