@@ -165,76 +165,59 @@ def _cpu_pass(w, backward):
 CPU_BASELINE_THREADS = 32     # the SAME thread count on every box (torch intra-op pool and the OpenMP tile rasterizer alike)
 
 
-class _pinned:
-    """Pins EVERY thread of this process to `n` cores of its allowed set for the duration of the block and restores the masks afterwards:
-    the oracle's small-tensor torch ops migrate between the 256 cores of a GPU host otherwise, and the same leg measured 0.24 .. 0.91
-    steps/s on different boxes (round 3).  Threads created inside the block inherit the mask."""
-
-    def __init__(self, n):
-        self.n = n
-
-    def _tids(self):
-        try:
-            return [int(t) for t in os.listdir("/proc/self/task")]
-        except OSError:
-            return [0]
-
-    def __enter__(self):
-        self.saved = {}
-        try:
-            allowed = sorted(os.sched_getaffinity(0))
-        except (AttributeError, OSError):
-            self.cpus = None
-            return self
-        self.cpus = set(allowed[:self.n])
-        for t in self._tids():
-            try:
-                self.saved[t] = os.sched_getaffinity(t)
-                os.sched_setaffinity(t, self.cpus)
-            except OSError:
-                pass
-        return self
-
-    def __exit__(self, *exc):
-        for t, m in self.saved.items():
-            try:
-                os.sched_setaffinity(t, m)
-            except OSError:
-                pass
+def _cpu_worker(spec):
+    """Body of the `--_cpu-worker` child process (see cpu_baseline): affinity and thread counts are set BEFORE torch / the OpenMP oracle create
+    their pools, so every pool has `nthr` threads on `nthr` cores and nothing left over from the GPU legs spins beside them."""
+    import numpy as np
+    nthr = spec["threads"]
+    try:
+        allowed = sorted(os.sched_getaffinity(0))
+        os.sched_setaffinity(0, set(allowed[:nthr]))
+        pinned = True
+    except (AttributeError, OSError):
+        pinned = False
+    torch.set_num_threads(nthr)
+    w = _cpu_workload(spec["G"], spec["res"], spec["canonical"])
+    _cpu_pass(w, spec["backward"])                       # warm-up: library load, OpenMP pools, allocator
+    ta, tr, spent = [], [], 0.0
+    while len(ta) < 5 or (spent < spec["budget_s"] and len(ta) < 9):
+        a, r = _cpu_pass(w, spec["backward"])
+        ta.append(a); tr.append(r); spent += a + r
+    print("CPU_WORKER_RESULT " + json.dumps({"ta": ta, "tr": tr, "spent": spent, "pinned": pinned, "N": w["N"], "M": w["M"]}), flush=True)
 
 
 def cpu_baseline(G, res, backward=True, canonical=False, budget_s=10.0, unit="steps/s"):
     """The oracle (CPU restatement of the reference's PyTorch LBS / encoder / MLP path + the C tile rasterizer, OpenMP over tiles) timed on
-    the host cores on the SAME kind of workload the GPU step renders.  Hygiene (round 4): a FIXED 32 threads on every box (BASELINE.md
-    section 4 prescribes all cores; on the 256-core GPU hosts the oracle's small-tensor ops are 30x slower that way -- every op pays the
-    wake-up of 256 OpenMP threads), every thread of the process pinned to 32 cores while the passes run, one untimed warm-up pass, then
-    at least 5 timed passes: min AND median reported, `value` = from the median.  The reference has no CPU diffusion path, so the diffusion
-    half of a step has no CPU counterpart and is NOT in this number."""
+    the host cores on the SAME kind of workload the GPU step renders.  Hygiene (round 4; the same leg measured 0.24 .. 0.91 steps/s on
+    different boxes in round 3): the passes run in a FRESH child process pinned to 32 cores with a FIXED 32 threads for the torch pool and
+    the OpenMP rasterizer alike -- set before either library creates a pool, so no spinning left-over threads share the cores (BASELINE.md
+    section 4 prescribes all cores; on the 256-core GPU hosts the oracle's small-tensor ops are 30x slower that way: every op pays the
+    wake-up of 256 OpenMP threads) -- one untimed warm-up pass, then at least 5 timed passes: min AND median reported, `value` = from the
+    median.  The reference has no CPU diffusion path, so the diffusion half of a step has no CPU counterpart and is NOT in this number."""
     import numpy as np
     host = os.cpu_count() or 1
     nthr = min(CPU_BASELINE_THREADS, host)
-    os.environ["OMP_NUM_THREADS"] = str(nthr)            # the OpenMP raster oracle reads it when its library is first loaded
-    prev_threads = torch.get_num_threads()
-    with _pinned(nthr) as pin:
-        torch.set_num_threads(nthr)
-        w = _cpu_workload(G, res, canonical)
-        _cpu_pass(w, backward)                           # warm-up: library load, OpenMP pools, allocator
-        ta, tr, spent = [], [], 0.0
-        while len(ta) < 5 or (spent < budget_s and len(ta) < 9):
-            a, r = _cpu_pass(w, backward)
-            ta.append(a); tr.append(r); spent += a + r
-    torch.set_num_threads(prev_threads)
+    spec = {"G": int(G), "res": int(res), "backward": bool(backward), "canonical": bool(canonical), "budget_s": float(budget_s), "threads": nthr}
+    env = dict(os.environ)
+    env.update(OMP_NUM_THREADS=str(nthr), MKL_NUM_THREADS=str(nthr), OMP_PROC_BIND="false", HIP_VISIBLE_DEVICES="", CUDA_VISIBLE_DEVICES="")
+    r = subprocess.run([sys.executable, os.path.abspath(__file__), "--_cpu-worker", json.dumps(spec)], env=env, capture_output=True, text=True,
+                       timeout=600)
+    line = [ln for ln in r.stdout.splitlines() if ln.startswith("CPU_WORKER_RESULT ")]
+    if r.returncode != 0 or not line:
+        return {"value": None, "unit": unit, "cores": nthr, "kind": "port", "error": (r.stderr or r.stdout)[-600:]}
+    o = json.loads(line[-1][len("CPU_WORKER_RESULT "):])
+    ta, tr = o["ta"], o["tr"]
     tot = np.array(ta) + np.array(tr)
     t_med, t_min = float(np.median(tot)), float(tot.min())
     t_an, t_ra = float(np.median(ta)), float(np.median(tr))
     what = "fwd+bwd" if backward else "forward"
     return {"value": 1.0 / t_med, "value_best": 1.0 / t_min, "unit": "%s (animate + rasterizer %s, no diffusion)" % (unit, what), "cores": nthr,
-            "kind": "port", "host_cores": host, "pinned": pin.cpus is not None, "passes": len(ta),
+            "kind": "port", "host_cores": host, "pinned": o["pinned"], "passes": len(ta),
             "s_per_pass": {"min": round(t_min, 4), "median": round(t_med, 4), "max": round(float(tot.max()), 4)},
-            "sample": "%d timed passes after 1 warm-up (%.0f s of CPU work), value = 1 / median: oracle animate %s %.3f s (%d free Gaussians with 4 "
-                      "non-zero skinning weights + %d mesh-bound) + C tile rasterizer %s %.3f s (OpenMP over tiles; %d Gaussians @%dx%d); %d threads "
-                      "for both, every thread of the process pinned to %d cores of the %d-core host"
-                      % (len(ta), spent, what, t_an, w["N"], w["M"], what, t_ra, G, res, res, nthr, nthr, host)}
+            "sample": "%d timed passes after 1 warm-up (%.0f s of CPU work) in a fresh process, value = 1 / median: oracle animate %s %.3f s (%d free "
+                      "Gaussians with 4 non-zero skinning weights + %d mesh-bound) + C tile rasterizer %s %.3f s (OpenMP over tiles; %d Gaussians "
+                      "@%dx%d); %d threads for both, the process pinned to %d cores of the %d-core host"
+                      % (len(ta), o["spent"], what, t_an, o["N"], o["M"], what, t_ra, G, res, res, nthr, nthr, host)}
 
 
 # ------------------------------------------------------------------------------------------------------------------------------------
@@ -552,7 +535,7 @@ def run_c1(ctx, steps=None, warmup=None):
             "kernel_ms_per_step": {k: round(v[1] / ps, 4) for k, v in sorted(prof.items(), key=lambda kv: -kv[1][1])[:12]}}
 
 
-def _brief(line, keys=("value", "unit", "ms_per_step", "steps", "warmup", "dtype", "views_per_s", "views_per_step", "config", "roofline",
+def _brief(line, keys=("value", "unit", "ms_per_step", "steps", "warmup", "repeats", "dtype", "views_per_s", "views_per_step", "config", "roofline",
                        "raster_mpix_per_s", "cpu_baseline", "metric", "redone_frames")):
     return {k: line[k] for k in keys if k in line}
 
@@ -638,4 +621,7 @@ def main():
 
 
 if __name__ == "__main__":
-    main()
+    if len(sys.argv) >= 3 and sys.argv[1] == "--_cpu-worker":
+        _cpu_worker(json.loads(sys.argv[2]))
+    else:
+        main()
