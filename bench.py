@@ -258,7 +258,7 @@ def raster_report(prof, G, Kref, K, P, steps, pmc=False):
     if tj is not None:       # HBM bytes per frame from the PMC passes (taken on the default c3 workload only)
         tk = tj["kernels"]
         fwd = ("k_preprocess", "k_scan_tiles", "k_scatter", "k_tile_sort", "k_tile_sort_regs", "k_render_fwd", "k_camera_setup")
-        bwd = ("k_render_bwd", "k_preprocess_bwd")
+        bwd = ("k_render_bwd", "k_gather_partials", "k_preprocess_bwd")
         for key, names in (("raster_forward", fwd), ("raster_backward", bwd)):
             if key in out:
                 t = sum(v["hbm_bytes_per_launch"] * v.get("launches_per_step", 1) for k, v in tk.items() if k.split("<")[0] in names)

@@ -28,6 +28,7 @@
 //   backward k_render_bwd      1 wave / (block, segment), one global atomic per (splat, block, component)
 //            k_preprocess_bwd  1 thread / Gaussian: conic -> cov2D -> cov3D -> (scale, quaternion), mean chain
 #include "dwg_common.h"
+#include <atomic>
 #include "dwg_prof_internal.h"
 #include "../../include/dwg_raster.h"
 
@@ -38,6 +39,9 @@ namespace {
 #define SEG 128          // splats per backward segment / forward checkpoint interval
 #define NCLASS 4         // sort size classes
 #define NBUCKET 20       // render-order buckets (log2 of the list length)
+#define GTILE 1024       // Gaussian indices per workgroup of the pair-row scan (k_scan_tiles)
+#define IDBIN 64         // ... whose base is the sum of per-IDBIN-indices pair counts (fine bins: ~IDBIN integer atomics per address in k_preprocess;
+                         // with one bin per GTILE indices the 1000 same-address atomics of a bin tripled that kernel's time)
 
 struct Params {
     int G, H, W, tiles_x, tiles_y;      // tiles_* count 8x8 BLOCKS
@@ -55,7 +59,7 @@ struct Params {
 enum { H_K = 0, H_OVERFLOW = 1, H_KREF = 2, H_NSEG = 3, H_CLASS0 = 4 /* .. +NCLASS */ };
 
 struct GeomLayout {
-    size_t header, rec0, rec1, rec2, rect, tile_count, tile_cursor, tile_start, seg_start, tile_neff, order, cls, total;
+    size_t header, rec0, rec1, rec2, rect, npairs, goff, tile_count, tile_cursor, idsum, tile_start, seg_start, tile_neff, order, cls, total;
 };
 
 static GeomLayout geom_layout(int G, int H, int W) {
@@ -68,8 +72,11 @@ static GeomLayout geom_layout(int G, int H, int W) {
     L.rec1 = o; o = dwg_align_up(o + g * sizeof(float4), 256);
     L.rec2 = o; o = dwg_align_up(o + g * sizeof(float4), 256);
     L.rect = o; o = dwg_align_up(o + g * sizeof(uint2), 256);
-    L.tile_count = o; o = dwg_align_up(o + T * 4, 256);      // tile_count and tile_cursor are cleared together
+    L.npairs = o; o = dwg_align_up(o + g * 4, 256);              // (Gaussian, block) pairs of every Gaussian after exact culling ...
+    L.goff = o; o = dwg_align_up(o + (g + 1) * 4, 256);          // ... and their exclusive prefix in INDEX order: pair row q = goff[g] + e
+    L.tile_count = o; o = dwg_align_up(o + T * 4, 256);      // tile_count, tile_cursor and idsum are cleared together
     L.tile_cursor = o; o = dwg_align_up(o + T * 4, 256);
+    L.idsum = o; o = dwg_align_up(o + (g / IDBIN + 2) * 4, 256);   // pair count of every run of IDBIN Gaussian indices (integer atomics: exact)
     L.tile_start = o; o = dwg_align_up(o + (T + 1) * 4, 256);
     L.seg_start = o; o = dwg_align_up(o + (T + 1) * 4, 256);
     L.tile_neff = o; o = dwg_align_up(o + T * 4, 256);
@@ -82,14 +89,15 @@ static GeomLayout geom_layout(int G, int H, int W) {
 static int64_t seg_capacity(int64_t cap, int H, int W) {
     return cap / SEG + (int64_t)dwg_cdiv(W, BT) * dwg_cdiv(H, BT) + 1;
 }
-struct PairLayout { size_t keys, sorted, seg_tile, ckpt, total; };
+struct PairLayout { size_t keys, sorted, seg_tile, ckpt, part, total; };
 static PairLayout pair_layout(int64_t cap, int H, int W) {
     PairLayout L; size_t c = (size_t)(cap > 0 ? cap : 1);
     size_t ns = (size_t)seg_capacity((int64_t)c, H, W);
     L.keys = 0; L.sorted = dwg_align_up(c * 8, 256);
     L.seg_tile = dwg_align_up(L.sorted + c * 4, 256);
     L.ckpt = dwg_align_up(L.seg_tile + ns * 4, 256);
-    L.total = dwg_align_up(L.ckpt + ns * 6 * 64 * sizeof(float), 256);
+    L.part = dwg_align_up(L.ckpt + ns * 6 * 64 * sizeof(float), 256);      // backward: one row of GSTRIDE floats per pair, in pair-row order
+    L.total = dwg_align_up(L.part + c * 12 * sizeof(float), 256);
     return L;
 }
 struct ImageLayout { size_t final_T, n_contrib, craw, total; };
@@ -305,8 +313,8 @@ __global__ __launch_bounds__(256) void k_preprocess(Params p, const float* __res
                                                     const float* __restrict__ rots, const float* __restrict__ cov3Dp,
                                                     int* __restrict__ radii, float4* __restrict__ rec0,
                                                     float4* __restrict__ rec1, float4* __restrict__ rec2,
-                                                    uint2* __restrict__ rect, uint32_t* __restrict__ tile_count,
-                                                    int32_t* __restrict__ header, int use_lds_hist) {
+                                                    uint2* __restrict__ rect, uint32_t* __restrict__ npairs, uint32_t* __restrict__ idsum,
+                                                    uint32_t* __restrict__ tile_count, int32_t* __restrict__ header, int use_lds_hist) {
     __shared__ float cam[32];
     extern __shared__ uint32_t hist[];      // [T] block-private histogram (hot blocks: one global atomic per workgroup, not per splat)
     const int T = p.tiles_x * p.tiles_y;
@@ -363,12 +371,14 @@ __global__ __launch_bounds__(256) void k_preprocess(Params p, const float* __res
             }
         }
     }
+    uint32_t ng = 0;     // this Gaussian's (Gaussian, block) pairs: its rows of the pair-ordered backward partials (k_scan_tiles scans them)
     {   // exact-culled per-block histogram: small splats by their own lane, big ones by the whole wave
         const bool big = span_is_big(sp);
         if (!big) {
             for (int by = sp.by0; by < sp.by1; by++) {
                 int xa, xb;
                 block_row(sp, by, &xa, &xb);
+                ng += (uint32_t)max(0, xb - xa);
                 for (int bx = xa; bx < xb; bx++) {
                     if (use_lds_hist) atomicAdd(&hist[by * p.tiles_x + bx], 1u);
                     else atomicAdd(&tile_count[by * p.tiles_x + bx], 1u);
@@ -381,17 +391,23 @@ __global__ __launch_bounds__(256) void k_preprocess(Params p, const float* __res
             const int src = __ffsll((long long)m) - 1;
             m &= m - 1;
             const BlockSpan w = span_from_lane(sp, src);
+            int rows_blocks = 0;
             for (int by = w.by0 + (lane >> 2); by < w.by1; by += 16) {
                 int xa, xb;
                 block_row(w, by, &xa, &xb);
+                if ((lane & 3) == 0) rows_blocks += max(0, xb - xa);
                 for (int bx = xa + (lane & 3); bx < xb; bx += 4) {
                     if (use_lds_hist) atomicAdd(&hist[by * p.tiles_x + bx], 1u);
                     else atomicAdd(&tile_count[by * p.tiles_x + bx], 1u);
                 }
             }
+            const int tot = (int)dwg_wave_sum_all((float)rows_blocks);      // < 2^24 blocks: exact in fp32
+            if (lane == src) ng = (uint32_t)tot;
         }
     }
     if (live_thread) {
+        npairs[i] = ng;
+        if (ng) atomicAdd(&idsum[i / IDBIN], ng);       // integer: order-independent
         radii[i] = radius;
         rect[i] = rc;
         rec0[i] = r0; rec1[i] = r1; rec2[i] = r2;
@@ -409,8 +425,39 @@ __device__ __forceinline__ int sort_class_of(uint32_t n) { return n <= 1024u ? 0
 // one workgroup of 1024 threads: exclusive scans of the pair and segment counts, size-class lists, render order
 __global__ __launch_bounds__(1024) void k_scan_tiles(int T, const uint32_t* __restrict__ tile_count, uint32_t* __restrict__ tile_start,
                                                      uint32_t* __restrict__ seg_start, uint32_t* __restrict__ cls,
-                                                     uint32_t* __restrict__ order, int32_t* __restrict__ header) {
+                                                     uint32_t* __restrict__ order, int32_t* __restrict__ header, int G,
+                                                     const uint32_t* __restrict__ npairs, const uint32_t* __restrict__ idsum,
+                                                     uint32_t* __restrict__ goff) {
     __shared__ uint32_t part[1024], parts[1024];
+    if (blockIdx.x > 0) {
+        // Workgroups 1 .. ceil(G / GTILE): pair rows.  goff = exclusive prefix of the per-Gaussian pair counts in INDEX order: row
+        // q = goff[g] + e (e: the pair's place in g's block enumeration) is unique per pair, contiguous per Gaussian -- the backward's per-pair
+        // partials are written by row (k_render_bwd finds e from the splat's geometry) and summed per Gaussian as one streamed range
+        // (k_gather_partials): no float atomics.  Only the backward reads goff; the forward pays these workgroups nothing (they run beside
+        // workgroup 0).  A workgroup scans its GTILE counts on top of the sum of the earlier index runs (idsum, accumulated by k_preprocess
+        // with integer atomics): no second launch, no inter-workgroup wait.
+        const int b = blockIdx.x - 1, tid = threadIdx.x, g = b * GTILE + tid;
+        uint32_t pre = 0;
+        for (int t = tid; t < b * (GTILE / IDBIN); t += 1024) pre += idsum[t];
+        part[tid] = pre;
+        const uint32_t v = g < G ? npairs[g] : 0u;
+        parts[tid] = v;
+        __syncthreads();
+        for (int off = 512; off >= 1; off >>= 1) {             // base: plain tree sum
+            if (tid < off) part[tid] += part[tid + off];
+            __syncthreads();
+        }
+        const uint32_t base = part[0];
+        for (int off = 1; off < 1024; off <<= 1) {              // inclusive scan of the run's counts
+            const uint32_t u = tid >= off ? parts[tid - off] : 0u;
+            __syncthreads();
+            parts[tid] += u;
+            __syncthreads();
+        }
+        if (g < G) goff[g] = base + parts[tid] - v;
+        if (g == G - 1) goff[G] = base + parts[tid];
+        return;
+    }
     __shared__ uint32_t cls_cnt[NCLASS], bkt_cnt[NBUCKET], bkt_base[NBUCKET];
     const int tid = threadIdx.x;
     if (tid < NCLASS) cls_cnt[tid] = 0u;
@@ -786,21 +833,39 @@ __global__ __launch_bounds__(64) void k_render_fwd(Params p, const uint32_t* __r
 //   w_i = alpha_i T_i,   sum over LATER splats of c_j w_j = (final sum) - (prefix sum including i)
 //   dL/dalpha_i = sum_ch (c_i T_i - later_ch / (1 - alpha_i)) g_ch - T_final / (1 - alpha_i) (bg . g_rgb)
 // T_i follows the forward's own recurrence from the checkpoint, bit for bit.
-// GD: a depth-map gradient is given (component 9 of the per-splat partials is non-zero only then -- the SDS path has none, and skips its
-// six-step wave reduction, LDS add and atomic)
+//
+// Round 4: no cross-lane reduction per splat and no float atomics.  The walk (a lane = a pixel, serial through T) only leaves two numbers
+// per (splat, pixel) in LDS -- Q = dL/dalpha * G and W = alpha T; every gradient component of a pair is a sum over the block's pixels of
+// Q or W times a polynomial in (dx, dy) / the pixel's incoming gradient.  After SUB splats the wave TURNS: four lanes per splat, each
+// summing a quarter of the pixels in registers (9 running sums, 16 trips), two quad-DPP steps to join the quarters -- ~18 instructions per
+// splat where nine 6-step wave reductions took 54 -- and the pair's row of partials goes out with plain 16-byte stores to row q of the
+// pair-ordered buffer: row q = goff[g] + e, e = the block's place in Gaussian g's own block enumeration (the scanline walk of k_preprocess,
+// recomputed here from the splat's record by the four lanes of its quad: ~100 instructions per TURN for typical splats).  The forward is
+// untouched by all this.  k_gather_partials sums a Gaussian's rows, a contiguous range, in a fixed order: the rasterizer's backward is now
+// bit-reproducible, and the ~9 M float atomics per frame (each forwarded to the memory side on this chip) are gone.  A row carries the
+// frame's TAG in its last word: pairs no segment reaches (behind the block's deepest contributor) simply keep an old tag and are skipped by
+// the gather -- no zero-fill, no memset.
+// GD: a depth-map gradient is given (component 9 is non-zero only then; the SDS path has none).
+// second word of a row's 64-bit frame tag (a 32-bit tag alone would match left-over bits once per ~4000 frames at a million rows)
+__device__ __forceinline__ uint32_t dwg_tag2(uint32_t tag) { return (tag * 0x85ebca6bu) ^ 0xc2b2ae35u; }
+#define SUB 16           // splats per turn of the two-phase reduction
+#define SUBLD 65         // row stride of the Q / W tables: lane (splat s, quarter h) reads [s][16 h + i] -> bank (s + 16 h + i) mod 64, conflict-free
 template <bool GD>
 __global__ __launch_bounds__(64) void k_render_bwd(Params p, const int32_t* __restrict__ header, int64_t cap_segs,
                                                    const uint32_t* __restrict__ seg_tile, const uint32_t* __restrict__ seg_start,
                                                    const uint32_t* __restrict__ tile_start, const uint32_t* __restrict__ tile_neff,
-                                                   const uint32_t* __restrict__ sorted, const float4* __restrict__ rec0,
+                                                   const uint32_t* __restrict__ sorted, const uint2* __restrict__ rect,
+                                                   const uint32_t* __restrict__ goff, uint32_t tag, const float4* __restrict__ rec0,
                                                    const float4* __restrict__ rec1, const float4* __restrict__ rec2,
                                                    int64_t cap, const float* __restrict__ ckpt, const float* __restrict__ final_T,
                                                    const int* __restrict__ n_contrib, const float* __restrict__ craw,
                                                    const float* __restrict__ g_color, const float* __restrict__ g_depth,
-                                                   const float* __restrict__ g_alpha, float* __restrict__ gacc /* [G][GSTRIDE] */) {
+                                                   const float* __restrict__ g_alpha, float* __restrict__ part /* [cap][GSTRIDE] */) {
     __shared__ float4 s0[64], s1[64], s2[64];
-    __shared__ float sacc[NGRAD * 64];
-    constexpr int NG = GD ? NGRAD : NGRAD - 1;        // components actually reduced
+    __shared__ uint2 srect[64];
+    __shared__ uint32_t sgo[64];
+    __shared__ float qt[SUB * SUBLD], wt[SUB * SUBLD];
+    __shared__ float gpx[4][64];
     const int64_t seg = blockIdx.x;
     if (seg >= (int64_t)header[H_NSEG] || seg >= cap_segs || header[H_OVERFLOW]) return;    // a truncated frame is redone by the caller
     const int tile = (int)seg_tile[seg];
@@ -809,10 +874,12 @@ __global__ __launch_bounds__(64) void k_render_bwd(Params p, const int32_t* __re
     int64_t rs = tile_start[tile], re = tile_start[tile + 1];
     if (rs > cap) rs = cap; if (re > cap) re = cap;
     const int lo = sidx * SEG;
-    const int hi = min(min((int)(re - rs), (int)tile_neff[tile]), lo + SEG);
+    const int seg_hi = min((int)(re - rs), lo + SEG);              // the rows this wave owns: [lo, seg_hi)
+    const int hi = min(seg_hi, (int)tile_neff[tile]);              // ... of which [lo, hi) can carry a gradient
+    if (lo >= seg_hi) return;
+    const int lane = threadIdx.x;
     if (lo >= hi) return;
     const int tx = tile % p.tiles_x, ty = tile / p.tiles_x;
-    const int lane = threadIdx.x;
     const int px = tx * BT + (lane & 7), py = ty * BT + (lane >> 3);
     const bool inside = px < p.W && py < p.H;
     const float fx = (float)px, fy = (float)py;
@@ -827,69 +894,172 @@ __global__ __launch_bounds__(64) void k_render_bwd(Params p, const int32_t* __re
         if (GD) gpd = g_depth[pix];
         if (g_alpha) gpa = g_alpha[pix];
     }
+    gpx[0][lane] = gp0; gpx[1][lane] = gp1; gpx[2][lane] = gp2; gpx[3][lane] = gpd;
     const float bgdot = p.bg[0] * gp0 + p.bg[1] * gp1 + p.bg[2] * gp2;
     const float* ck = ckpt + (size_t)seg * 6 * 64 + lane;
     float T = 1.f, P0 = 0.f, P1 = 0.f, P2 = 0.f, Pd = 0.f, Pa = 0.f;
     if (sidx > 0) { T = ck[0]; P0 = ck[64]; P1 = ck[128]; P2 = ck[192]; Pd = ck[256]; Pa = ck[320]; }
     const float ddelx = 0.5f * p.W, ddely = 0.5f * p.H;
-#pragma unroll
-    for (int c = 0; c < NG; c++) sacc[c * 64 + lane] = 0.f;
+    // second phase: lane = 4 s + h sums pixels 16 h .. 16 h + 15 (block rows 2 h, 2 h + 1) of splat s
+    const int ps = lane >> 2, ph = lane & 3;
+    const float pfy0 = (float)(ty * BT + 2 * ph), pfx0 = (float)(tx * BT);
     for (int base = lo; base < hi; base += 64) {
         const int cnt = min(64, hi - base);
-        uint32_t gid = 0;
-        __syncthreads();
-        if (lane < cnt) { gid = sorted[rs + base + lane]; s0[lane] = rec0[gid]; s1[lane] = rec1[gid]; s2[lane] = rec2[gid]; }
-        __syncthreads();
-        float4 an = s0[0], bn = s1[0], cn = s2[0];
-        for (int j = 0; j < cnt; j++) {
-            const float4 a = an, b = bn, col = cn;
-            const int jn = min(j + 1, cnt - 1);
-            an = s0[jn]; bn = s1[jn]; cn = s2[jn];          // the next splat's records are in flight while this one is evaluated
-            const float dx = a.x - fx, dy = a.y - fy;
-            const float power = splat_power(b.x, b.y, b.z, dx, dy);
-            const float Gv = expf(power);
-            const float alpha = fminf(0.99f, a.w * Gv);
-            const bool valid = (base + j < last) && (power <= 0.f) && (alpha >= (1.f / 255.f));
-            if (!__any(valid)) continue;  // wave-uniform skip
-            float v[NGRAD];
-#pragma unroll
-            for (int c = 0; c < NGRAD; c++) v[c] = 0.f;
-            if (valid) {
-                const float om = 1.f - alpha;
-                const float inv1a = 1.f / om;
-                const float w = __fmul_rn(alpha, T);
-                P0 = __fmaf_rn(col.x, w, P0); P1 = __fmaf_rn(col.y, w, P1); P2 = __fmaf_rn(col.z, w, P2);
-                Pd = __fmaf_rn(a.z, w, Pd); Pa += w;
-                const float dL_dalpha = (col.x * T - (t0 - P0) * inv1a) * gp0 + (col.y * T - (t1 - P1) * inv1a) * gp1 +
-                                        (col.z * T - (t2 - P2) * inv1a) * gp2 + (a.z * T - (td - Pd) * inv1a) * gpd +
-                                        (T - (ta - Pa) * inv1a) * gpa - T_final * inv1a * bgdot;
-                const float dL_dG = a.w * dL_dalpha;
-                const float gdx = b.x * dx + b.y * dy, gdy = b.z * dy + b.y * dx;
-                v[0] = -dL_dG * Gv * gdx * ddelx;
-                v[1] = -dL_dG * Gv * gdy * ddely;
-                const float h = -0.5f * Gv * dL_dG;
-                v[2] = h * dx * dx; v[3] = h * dx * dy; v[4] = h * dy * dy;
-                v[5] = Gv * dL_dalpha;
-                v[6] = w * gp0; v[7] = w * gp1; v[8] = w * gp2; v[9] = w * gpd;
-                T = __fmul_rn(T, om);
-            }
-#pragma unroll
-            for (int c = 0; c < NG; c++) v[c] = dwg_wave_sum_to_lane63(v[c]);
-            if (lane == 63) {
-#pragma unroll
-                for (int c = 0; c < NG; c++) sacc[c * 64 + j] += v[c];
-            }
-        }
         __syncthreads();
         if (lane < cnt) {
-            float* dst = gacc + (size_t)gid * GSTRIDE;
-#pragma unroll
-            for (int c = 0; c < NG; c++) {
-                const float x = sacc[c * 64 + lane];
-                if (x != 0.f) { atomicAdd(dst + c, x); sacc[c * 64 + lane] = 0.f; }
+            const uint32_t gid = sorted[rs + base + lane];
+            s0[lane] = rec0[gid]; s1[lane] = rec1[gid]; s2[lane] = rec2[gid]; srect[lane] = rect[gid]; sgo[lane] = goff[gid];
+        }
+        __syncthreads();
+        for (int jb = 0; jb < cnt; jb += SUB) {
+            const int jn = min(SUB, cnt - jb);
+            unsigned anym = 0u;                                 // wave-uniform: splats of this turn with a contributing pixel
+            float4 an = s0[jb], bn = s1[jb], cn = s2[jb];
+            for (int j = 0; j < jn; j++) {
+                const float4 a = an, b = bn, col = cn;
+                const int jx = jb + min(j + 1, jn - 1);
+                an = s0[jx]; bn = s1[jx]; cn = s2[jx];          // the next splat's records are in flight while this one is evaluated
+                const float dx = a.x - fx, dy = a.y - fy;
+                const float power = splat_power(b.x, b.y, b.z, dx, dy);
+                const float Gv = expf(power);
+                const float alpha = fminf(0.99f, a.w * Gv);
+                const bool valid = (base + jb + j < last) && (power <= 0.f) && (alpha >= (1.f / 255.f));
+                float Qv = 0.f, Wv = 0.f;
+                if (valid) {
+                    const float om = 1.f - alpha;
+                    const float inv1a = 1.f / om;
+                    const float w = __fmul_rn(alpha, T);
+                    P0 = __fmaf_rn(col.x, w, P0); P1 = __fmaf_rn(col.y, w, P1); P2 = __fmaf_rn(col.z, w, P2);
+                    Pd = __fmaf_rn(a.z, w, Pd); Pa += w;
+                    const float dL_dalpha = (col.x * T - (t0 - P0) * inv1a) * gp0 + (col.y * T - (t1 - P1) * inv1a) * gp1 +
+                                            (col.z * T - (t2 - P2) * inv1a) * gp2 + (a.z * T - (td - Pd) * inv1a) * gpd +
+                                            (T - (ta - Pa) * inv1a) * gpa - T_final * inv1a * bgdot;
+                    Qv = dL_dalpha * Gv; Wv = w;
+                    T = __fmul_rn(T, om);
+                }
+                if (__any(valid)) anym |= 1u << j;
+                qt[j * SUBLD + lane] = Qv; wt[j * SUBLD + lane] = Wv;
             }
+            __syncthreads();
+            // the turn: per (splat, pixel quarter) sums, joined across the quad
+            {
+                const bool mine = ps < jn;
+                const bool work = mine && ((anym >> ps) & 1u);
+                float S = 0.f, Sx = 0.f, Sy = 0.f, Sxx = 0.f, Sxy = 0.f, Syy = 0.f, C0 = 0.f, C1 = 0.f, C2 = 0.f, Cd = 0.f;
+                const float4 a = s0[jb + (mine ? ps : 0)];
+                if (work) {
+                    const float* qrow = qt + ps * SUBLD + 16 * ph; const float* wrow = wt + ps * SUBLD + 16 * ph;
+#pragma unroll
+                    for (int i = 0; i < 16; i++) {
+                        const float Q = qrow[i], Wq = wrow[i];
+                        const float dx = a.x - (pfx0 + (float)(i & 7)), dy = a.y - (pfy0 + (float)(i >> 3));
+                        const float Qx = Q * dx, Qy = Q * dy;
+                        S += Q; Sx += Qx; Sy += Qy;
+                        Sxx = fmaf(Qx, dx, Sxx); Sxy = fmaf(Qx, dy, Sxy); Syy = fmaf(Qy, dy, Syy);
+                        const int pp = 16 * ph + i;
+                        C0 = fmaf(Wq, gpx[0][pp], C0); C1 = fmaf(Wq, gpx[1][pp], C1); C2 = fmaf(Wq, gpx[2][pp], C2);
+                        if (GD) Cd = fmaf(Wq, gpx[3][pp], Cd);
+                    }
+                }
+#define DWG_QUAD_SUM(v) do { v = dwg_dpp_add<0xB1, 0xF>(v); v = dwg_dpp_add<0x4E, 0xF>(v); } while (0)
+                DWG_QUAD_SUM(S); DWG_QUAD_SUM(Sx); DWG_QUAD_SUM(Sy); DWG_QUAD_SUM(Sxx); DWG_QUAD_SUM(Sxy); DWG_QUAD_SUM(Syy);
+                DWG_QUAD_SUM(C0); DWG_QUAD_SUM(C1); DWG_QUAD_SUM(C2);
+                if (GD) DWG_QUAD_SUM(Cd);
+#undef DWG_QUAD_SUM
+                if (mine) {
+                    const float4 b = s1[jb + ps];
+                    // the pair's row: goff[g] + (blocks of g's enumeration before this one).  The quad shares the splat's block rows above
+                    // this block; the enumeration is k_preprocess's (same block_span / block_row), so rows are a bijection onto g's range.
+                    const uint2 rc = srect[jb + ps];
+                    const BlockSpan sp = block_span(a.x, a.y, b.x, b.y, b.z, a.w, (int)(rc.x & 0xffff), (int)(rc.x >> 16), (int)(rc.y & 0xffff),
+                                                    (int)(rc.y >> 16), p.tiles_x, p.tiles_y);
+                    int before = 0;
+                    for (int by = sp.by0 + ph; by < ty; by += 4) { int xa, xb; block_row(sp, by, &xa, &xb); before += max(0, xb - xa); }
+                    before += __shfl_xor(before, 1); before += __shfl_xor(before, 2);
+                    int xa, xb;
+                    block_row(sp, ty, &xa, &xb);
+                    const int64_t q = (int64_t)sgo[jb + ps] + before + (tx - xa);
+                    if (ph < 3 && q < cap) {
+                        const float ao = a.w;                           // opacity: dL/dG = opacity * dL/dalpha
+                        float4 o;
+                        if (ph == 0) o = make_float4(-ao * ddelx * (b.x * Sx + b.y * Sy), -ao * ddely * (b.z * Sy + b.y * Sx), -0.5f * ao * Sxx, -0.5f * ao * Sxy);
+                        else if (ph == 1) o = make_float4(-0.5f * ao * Syy, S, C0, C1);
+                        else o = make_float4(C2, Cd, __uint_as_float(dwg_tag2(tag)), __uint_as_float(tag));
+                        reinterpret_cast<float4*>(part + (size_t)q * GSTRIDE)[ph] = o;
+                    }
+                }
+            }
+            __syncthreads();
         }
     }
+}
+
+// gacc[g][:] = sum of Gaussian g's pair rows [goff[g], goff[g+1]) -- a contiguous range -- in row order: deterministic, no atomics.
+// Four lanes per Gaussian: lane h of the quad adds 16-byte piece h of every row, so a quad reads one contiguous 48-byte row per trip (16
+// rows per wave-instruction, neighbouring Gaussians' rows being neighbours in memory) and ends up holding piece h of the sum -- no
+// cross-lane reduction, no LDS, no barrier.  (Tried first: a thread per Gaussian reading its own rows -- 64 scattered lines per instruction,
+// 53 us at 50 k Gaussians; streaming a workgroup's whole run through LDS -- the chunk loop's length is set by the big splats in the run,
+// 150-960 us.)  Big splats (> GBIG rows) are summed by their whole wave, lane-strided over the rows, and joined by a fixed tree.
+#define GBIG 192
+__global__ __launch_bounds__(256) void k_gather_partials(int G, const uint32_t* __restrict__ goff, const float* __restrict__ part, int64_t cap,
+                                                         const int32_t* __restrict__ header, uint32_t tag, float* __restrict__ gacc) {
+    const int i = blockIdx.x * 64 + (threadIdx.x >> 2), h = threadIdx.x & 3, lane = threadIdx.x & 63;
+    const bool ok = !header[H_OVERFLOW];                       // a truncated frame is redone by the caller: zeros
+    const int64_t capc = cap > 0 ? cap : 0;
+    int64_t q0 = 0, q1 = 0;
+    if (i < G && ok) { q0 = min((int64_t)goff[i], capc); q1 = min((int64_t)goff[i + 1], capc); }
+    const int64_t n = q1 - q0;
+    const bool big = n > GBIG;
+    const float4* rows = reinterpret_cast<const float4*>(part);
+    // a row counts only if THIS frame's backward wrote it: piece 2 carries the 64-bit frame tag in its last two words (k_render_bwd)
+    float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+    {
+        // lane 2 of the quad holds piece 2 of every row, whose last two words are the tag: it judges the rows and tells the quad (one DPP
+        // broadcast per four rows); every lane of the wave takes part in the broadcasts, lanes without work add nothing
+        const bool work = !big && h < 3;
+        const float4* src = rows + q0 * 3 + min(h, 2);
+        const uint32_t tag2 = dwg_tag2(tag);
+        const int64_t nn = work ? n : 0;
+        int64_t nmax = nn;                                     // quad-uniform trip count (n is per Gaussian = per quad already)
+        int64_t r = 0;
+        for (; r + 3 < nmax; r += 4) {                         // four rows in flight; added in row order
+            const float4 a = src[3 * r], b = src[3 * r + 3], c = src[3 * r + 6], d = src[3 * r + 9];
+            int ok4 = 0;
+            if (h == 2) ok4 = (int)(__float_as_uint(a.z) == tag2 && __float_as_uint(a.w) == tag) | ((int)(__float_as_uint(b.z) == tag2 && __float_as_uint(b.w) == tag) << 1) |
+                              ((int)(__float_as_uint(c.z) == tag2 && __float_as_uint(c.w) == tag) << 2) | ((int)(__float_as_uint(d.z) == tag2 && __float_as_uint(d.w) == tag) << 3);
+            ok4 = __builtin_amdgcn_update_dpp(0, ok4, 0xAA, 0xF, 0xF, false);      // quad_perm [2,2,2,2]
+            if (ok4 & 1) { acc.x += a.x; acc.y += a.y; acc.z += a.z; acc.w += a.w; }
+            if (ok4 & 2) { acc.x += b.x; acc.y += b.y; acc.z += b.z; acc.w += b.w; }
+            if (ok4 & 4) { acc.x += c.x; acc.y += c.y; acc.z += c.z; acc.w += c.w; }
+            if (ok4 & 8) { acc.x += d.x; acc.y += d.y; acc.z += d.z; acc.w += d.w; }
+        }
+        for (; r < nmax; r++) {
+            const float4 a = src[3 * r];
+            int ok1 = (h == 2) ? (int)(__float_as_uint(a.z) == tag2 && __float_as_uint(a.w) == tag) : 0;
+            ok1 = __builtin_amdgcn_update_dpp(0, ok1, 0xAA, 0xF, 0xF, false);
+            if (ok1) { acc.x += a.x; acc.y += a.y; acc.z += a.z; acc.w += a.w; }
+        }
+    }
+    unsigned long long m = __ballot(big && h == 0);
+    while (m) {
+        const int src = __ffsll((long long)m) - 1;
+        m &= m - 1;
+        const int64_t wq0 = (int64_t)((uint32_t)__shfl((int)(uint32_t)q0, src)), wn = (int64_t)((uint32_t)__shfl((int)(uint32_t)n, src));
+        const float4* row = rows + wq0 * 3;
+        float t[12] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+        for (int64_t r = lane; r < wn; r += 64) {
+            const float4 a = row[3 * r], b = row[3 * r + 1], c = row[3 * r + 2];
+            if (__float_as_uint(c.w) == tag && __float_as_uint(c.z) == dwg_tag2(tag)) {
+                t[0] += a.x; t[1] += a.y; t[2] += a.z; t[3] += a.w; t[4] += b.x; t[5] += b.y; t[6] += b.z; t[7] += b.w; t[8] += c.x; t[9] += c.y;
+            }
+        }
+#pragma unroll
+        for (int c = 0; c < 10; c++) t[c] = dwg_wave_sum_all(t[c]);
+        // the splat's quad: lane src + hh takes piece hh
+        if ((lane & ~3) == src && h < 3) acc = make_float4(t[4 * h], t[4 * h + 1], t[4 * h + 2], t[4 * h + 3]);
+    }
+    if (h == 2) { acc.z = 0.f; acc.w = 0.f; }                   // the tag's slots
+    if (i < G && h < 3) reinterpret_cast<float4*>(gacc + (size_t)i * GSTRIDE)[h] = acc;
 }
 
 __global__ __launch_bounds__(256) void k_preprocess_bwd(Params p, const float* __restrict__ means3D,
@@ -1150,12 +1320,14 @@ int dwg_raster_forward_bin(const dwg_raster_settings* cfg, int32_t G, const floa
         const int use_lds_hist = lds_hist_ok(T);
         DWG_LAUNCH("raster_preprocess", k_preprocess, dim3(dwg_cdiv(G, 256)), dim3(256), use_lds_hist ? (size_t)T * 4 : 0, stream, p,
                    means3D, shs, colors_precomp, opacities, scales, rotations, cov3D_precomp, radii, (float4*)(ws + L.rec0),
-                   (float4*)(ws + L.rec1), (float4*)(ws + L.rec2), (uint2*)(ws + L.rect), (uint32_t*)(ws + L.tile_count),
-                   (int32_t*)(ws + L.header), use_lds_hist);
+                   (float4*)(ws + L.rec1), (float4*)(ws + L.rec2), (uint2*)(ws + L.rect), (uint32_t*)(ws + L.npairs),
+                   (uint32_t*)(ws + L.idsum), (uint32_t*)(ws + L.tile_count), (int32_t*)(ws + L.header), use_lds_hist);
     }
-    DWG_LAUNCH("raster_scan_tiles", k_scan_tiles, dim3(1), dim3(1024), 0, stream, T, (const uint32_t*)(ws + L.tile_count),
+    // workgroup 0: block lists (starts, segments, size classes, render order); workgroups 1..: the pair rows of GTILE Gaussians each
+    DWG_LAUNCH("raster_scan_tiles", k_scan_tiles, dim3(1 + dwg_cdiv(G, GTILE)), dim3(1024), 0, stream, T, (const uint32_t*)(ws + L.tile_count),
                (uint32_t*)(ws + L.tile_start), (uint32_t*)(ws + L.seg_start), (uint32_t*)(ws + L.cls), (uint32_t*)(ws + L.order),
-               (int32_t*)(ws + L.header));
+               (int32_t*)(ws + L.header), G, (const uint32_t*)(ws + L.npairs), (const uint32_t*)(ws + L.idsum),
+               (uint32_t*)(ws + L.goff));
     DWG_RETURN_IF_LAUNCH_FAILED();
     return DWG_OK;
 }
@@ -1254,14 +1426,21 @@ int dwg_raster_backward(const dwg_raster_settings* cfg, int32_t G, const float* 
     ImageLayout IL = image_layout(p.H, p.W);
     const int64_t cap_segs = seg_capacity(pair_capacity > 0 ? pair_capacity : 1, p.H, p.W);
     const char* ws = (const char*)ws_geom; const char* wp = (const char*)ws_pairs; const char* wi = (const char*)ws_image;
-    if (hipMemsetAsync(ws_grad, 0, (size_t)G * GSTRIDE * sizeof(float), stream) != hipSuccess) return DWG_E_LAUNCH;
+    // per-pair partials in pair-row order (no atomics), then each Gaussian's contiguous rows summed into ws_grad [G][GSTRIDE]
+    // a fresh tag per backward: rows of the pair-ordered partials count only if this frame wrote them (no clearing of the buffer)
+    static std::atomic<uint32_t> frame_tag{0x5eed0001u};
+    const uint32_t tag = frame_tag.fetch_add(0x9e3779b1u) | 1u;
 #define DWG_BWD_ARGS p, (const int32_t*)(ws + L.header), cap_segs, (const uint32_t*)(wp + PL.seg_tile), (const uint32_t*)(ws + L.seg_start),   \
-        (const uint32_t*)(ws + L.tile_start), (const uint32_t*)(ws + L.tile_neff), (const uint32_t*)(wp + PL.sorted), (const float4*)(ws + L.rec0), \
-        (const float4*)(ws + L.rec1), (const float4*)(ws + L.rec2), pair_capacity, (const float*)(wp + PL.ckpt), (const float*)(wi + IL.final_T),  \
-        (const int*)(wi + IL.n_contrib), (const float*)(wi + IL.craw), dL_dout_color, dL_dout_depth, dL_dout_alpha, (float*)ws_grad
+        (const uint32_t*)(ws + L.tile_start), (const uint32_t*)(ws + L.tile_neff), (const uint32_t*)(wp + PL.sorted),                               \
+        (const uint2*)(ws + L.rect), (const uint32_t*)(ws + L.goff), tag, (const float4*)(ws + L.rec0), (const float4*)(ws + L.rec1),           \
+        (const float4*)(ws + L.rec2), pair_capacity, (const float*)(wp + PL.ckpt), (const float*)(wi + IL.final_T),                              \
+        (const int*)(wi + IL.n_contrib), (const float*)(wi + IL.craw), dL_dout_color, dL_dout_depth, dL_dout_alpha,                              \
+        (float*)(const_cast<char*>(wp) + PL.part)
     if (dL_dout_depth) DWG_LAUNCH("raster_render_bwd", k_render_bwd<true>, dim3((unsigned)cap_segs), dim3(64), 0, stream, DWG_BWD_ARGS);
     else DWG_LAUNCH("raster_render_bwd", k_render_bwd<false>, dim3((unsigned)cap_segs), dim3(64), 0, stream, DWG_BWD_ARGS);
 #undef DWG_BWD_ARGS
+    DWG_LAUNCH("raster_gather_bwd", k_gather_partials, dim3(dwg_cdiv(G, 64)), dim3(256), 0, stream, G, (const uint32_t*)(ws + L.goff),
+               (const float*)(wp + PL.part), pair_capacity, (const int32_t*)(ws + L.header), tag, (float*)ws_grad);
     DWG_LAUNCH("raster_preprocess_bwd", k_preprocess_bwd, dim3(dwg_cdiv(G, 256)), dim3(256), 0, stream, p, means3D, shs, colors_precomp,
                scales, rotations, cov3D_precomp, (const uint2*)(ws + L.rect), (const float4*)(ws + L.rec2),
                (const float*)ws_grad, dL_dmeans3D, dL_dmeans2D, dL_dshs, dL_dcolors, dL_dopacities, dL_dscales,
