@@ -45,7 +45,7 @@ from dreamwaltz_g_amd import sds_step  # noqa: E402
 HBM_PEAK_GBS = 8000.0                                  # MI355X_MICROARCH.md: 8 TB/s HBM3E
 MFMA_PEAK_TFLOPS = {"bf16": 2500.0, "f16": 2500.0, "f32": 157.3, "f32x": 2500.0}      # dense MFMA peaks per operand type (same guide); f32x runs on the
                                                                                        # f16 MFMA pipe, its ALGORITHMIC flops (one multiply-add per product, not the three MFMAs) are priced against that peak
-TRAFFIC_JSON = os.path.join(ROOT, "profiles", "r03_pmc_traffic.json")
+TRAFFIC_JSON = os.path.join(ROOT, "profiles", "r04_pmc_traffic.json")      # PMC passes over the f32x (headline) step: tools/profile_round.sh
 HEADLINE_DTYPE = "f32x"       # the reference runs the guidance stage in fp32 (configs/__init__.py:236,241): the headline is a same-precision number
 HEADLINE_METRIC = "SDS steps/sec @512^2, 100k Gaussians, SD1.5+ControlNet; raster Mpix/s vs HBM roofline"
 
@@ -262,8 +262,14 @@ def raster_report(prof, G, Kref, K, P, steps, pmc=False):
         for key, names in (("raster_forward", fwd), ("raster_backward", bwd)):
             if key in out:
                 t = sum(v["hbm_bytes_per_launch"] * v.get("launches_per_step", 1) for k, v in tk.items() if k.split("<")[0] in names)
+                tu = sum(v.get("hbm_bytes_per_launch_uncorrected", v["hbm_bytes_per_launch"]) * v.get("launches_per_step", 1) for k, v in tk.items()
+                         if k.split("<")[0] in names)
                 out[key]["traffic"] = t
                 out[key]["traffic_over_algorithmic"] = t / out[key]["bytes"]
+                # the x2 FETCH_SIZE correction is calibrated for 16 B/lane streams, not for these kernels' 16-byte gathers: the truth lies
+                # between the uncorrected and the corrected sum
+                out[key]["traffic_uncorrected"] = tu
+                out[key]["traffic_over_algorithmic_uncorrected"] = tu / out[key]["bytes"]
                 out[key]["traffic_stale"] = bool(stale)
     return out
 
@@ -290,11 +296,11 @@ def roofline(prof, prof_sym, prof_steps, G, Kref, K, P, dtype="bf16"):
             out["mfma_all"] = {"tflops": tw / (tms * 1e-3) / 1e12, "frac": tw / (tms * 1e-3) / 1e12 / peak, "flops_per_step": tw / prof_steps,
                                "ms_per_step": tms / prof_steps, "includes": "GEMM / conv / attention launches"}
         tj, stale = _traffic()
-        if tj is not None and out.get("kernel") and dtype == "bf16":
+        if tj is not None and out.get("kernel") and dtype == tj.get("plan_dtype", "bf16"):
             tk = tj["kernels"].get(out["kernel"].replace(" ", ""))
             if tk:
                 out["traffic"] = tk["hbm_bytes_per_launch"]
-                out["traffic_source"] = "profiles/r03_pmc_traffic.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes, gfx950 corrections)"
+                out["traffic_source"] = "profiles/%s (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes, gfx950 corrections)" % os.path.basename(TRAFFIC_JSON)
                 out["traffic_stale"] = bool(stale)       # True: the profile was taken on other kernel sources than the ones running now
     out.update(raster_report(prof, G, Kref, K, P, prof_steps, pmc=(G == 100000 and P == 512 * 512)))
     return out

@@ -49,9 +49,10 @@ def main():
             continue
         fb, wb = f * 1024 / max(nf, 1), w * 1024 / max(nw, 1)
         out[k] = {"launches": n, "fetch_bytes_per_launch_raw": fb, "fetch_bytes_per_launch_corrected": 2 * fb,
-                  "write_bytes_per_launch": wb, "hbm_bytes_per_launch": 2 * fb + wb}
-    json.dump({"sources_sha": sources_sha(), "commit": sys.argv[4] if len(sys.argv) > 4 else None, "source": "rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate passes) over python bench.py --steps 2 --warmup 1 --eager",
-               "corrections": "KiB->bytes x1024; gfx950 FETCH_SIZE doubled for wide coalesced reads (MI355X_MICROARCH.md HBM section); WRITE_SIZE as reported",
+                  "write_bytes_per_launch": wb, "hbm_bytes_per_launch": 2 * fb + wb, "hbm_bytes_per_launch_uncorrected": fb + wb}
+    json.dump({"sources_sha": sources_sha(), "commit": sys.argv[4] if len(sys.argv) > 4 else None, "plan_dtype": sys.argv[5] if len(sys.argv) > 5 else "f32x", "source": "rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate passes) over python bench.py --steps 2 --warmup 1 --eager",
+               "corrections": "KiB->bytes x1024; gfx950 FETCH_SIZE doubled for wide coalesced reads (MI355X_MICROARCH.md HBM section: calibrated for 16 B/lane streams = the GEMM / conv / norm "
+                              "kernels; for the gather-heavy rasterizer kernels the factor is uncalibrated: hbm_bytes_per_launch_uncorrected .. hbm_bytes_per_launch bracket the truth); WRITE_SIZE as reported",
                "kernels": out}, open(sys.argv[3], "w"), indent=1)
     for k, v in sorted(out.items(), key=lambda kv: -kv[1]["hbm_bytes_per_launch"] * kv[1]["launches"])[:14]:
         print("%-34s %5d launches  fetch(corr) %9.2f MB  write %9.2f MB" % (k, v["launches"], v["fetch_bytes_per_launch_corrected"] / 1e6, v["write_bytes_per_launch"] / 1e6))

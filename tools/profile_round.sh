@@ -3,7 +3,7 @@
 # (the box has no .git: pass `git rev-parse --short HEAD` as the second argument; the PMC profile is also stamped with a hash of the kernel sources)
 # (kernel-trace / stats in their own runs, PMC counters in their own runs -- gpurun refuses the combination)
 set -u
-R=${1:-r03}
+R=${1:-r04}
 COMMIT=${2:-unknown}
 # DWG_PROFILE_PARTS: which passes to run (default all): eager graph pmc bench
 PARTS=${DWG_PROFILE_PARTS:-"eager graph pmc sq bench"}
@@ -24,7 +24,7 @@ has sq && tail -18 $OUT/pmc_sq_summary.log
 find $OUT -name "*kernel_stats.csv" | head
 has eager && cp $(find $OUT/eager -name "*kernel_stats.csv" | head -1) profiles/${R}_sds_step_eager_kernel_stats.csv
 has graph && cp $(find $OUT/graph -name "*kernel_stats.csv" | head -1) profiles/${R}_sds_step_graph_kernel_stats.csv
-has pmc && python tools/pmc_traffic.py $(find $OUT/pmc_fetch -name "*counter_collection.csv" | head -1) $(find $OUT/pmc_write -name "*counter_collection.csv" | head -1) profiles/${R}_pmc_traffic.json $COMMIT > $OUT/pmc_traffic.log 2>&1
+has pmc && python tools/pmc_traffic.py $(find $OUT/pmc_fetch -name "*counter_collection.csv" | head -1) $(find $OUT/pmc_write -name "*counter_collection.csv" | head -1) profiles/${R}_pmc_traffic.json $COMMIT ${DWG_PROFILE_DTYPE:-f32x} > $OUT/pmc_traffic.log 2>&1
 has pmc && tail -2 $OUT/pmc_traffic.log
 has eager && grep '^{"metric"' $OUT/eager.log | tail -1 > profiles/${R}_sds_step_eager_bench_line.json
 # bench lines (the default command, then the two other BASELINE configs)
