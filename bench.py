@@ -170,10 +170,23 @@ def _cpu_worker(spec):
     their pools, so every pool has `nthr` threads on `nthr` cores and nothing left over from the GPU legs spins beside them."""
     import numpy as np
     nthr = spec["threads"]
+    pinned = False
+    # Affinity: NOT pinned by default.  Measured on the pool's 2 x 64-core EPYC 9575F hosts (tools/cpu_probe.sh, same box, 100 k / 512^2,
+    # s per pass min / median / max): unpinned 2.8 / 3.0 / 4.7, pinned to the first 32 CPUs 3.8 / 7.0 / 15.1, to every 8th CPU 8.0 / 12.5 /
+    # 19.7 -- the hosts are shared, and a pinned process cannot move away from cores somebody else is using.  DWG_CPU_PIN=first|spread pins.
+    mode = os.environ.get("DWG_CPU_PIN", "none")
     try:
         allowed = sorted(os.sched_getaffinity(0))
-        os.sched_setaffinity(0, set(allowed[:nthr]))
-        pinned = True
+        if mode == "first":
+            pick = allowed[:nthr]
+        elif mode == "spread":                           # every (n / nthr)-th allowed CPU: one thread per physical core, all NUMA nodes
+            st = max(1, len(allowed) // nthr)
+            pick = allowed[::st][:nthr]
+        else:
+            pick = None
+        if pick:
+            os.sched_setaffinity(0, set(pick))
+            pinned = mode
     except (AttributeError, OSError):
         pinned = False
     torch.set_num_threads(nthr)
@@ -189,8 +202,9 @@ def _cpu_worker(spec):
 def cpu_baseline(G, res, backward=True, canonical=False, budget_s=10.0, unit="steps/s"):
     """The oracle (CPU restatement of the reference's PyTorch LBS / encoder / MLP path + the C tile rasterizer, OpenMP over tiles) timed on
     the host cores on the SAME kind of workload the GPU step renders.  Hygiene (round 4; the same leg measured 0.24 .. 0.91 steps/s on
-    different boxes in round 3): the passes run in a FRESH child process pinned to 32 cores with a FIXED 32 threads for the torch pool and
-    the OpenMP rasterizer alike -- set before either library creates a pool, so no spinning left-over threads share the cores (BASELINE.md
+    different boxes in round 3): the passes run in a FRESH child process with a FIXED 32 threads for the torch pool and the OpenMP rasterizer
+    alike -- set before either library creates a pool, so no spinning left-over threads of the GPU legs compete (affinity pinning was
+    measured and made the SHARED hosts of this pool slower and noisier: see _cpu_worker) (BASELINE.md
     section 4 prescribes all cores; on the 256-core GPU hosts the oracle's small-tensor ops are 30x slower that way: every op pays the
     wake-up of 256 OpenMP threads) -- one untimed warm-up pass, then at least 5 timed passes: min AND median reported, `value` = from the
     median.  The reference has no CPU diffusion path, so the diffusion half of a step has no CPU counterpart and is NOT in this number."""
@@ -216,8 +230,8 @@ def cpu_baseline(G, res, backward=True, canonical=False, budget_s=10.0, unit="st
             "s_per_pass": {"min": round(t_min, 4), "median": round(t_med, 4), "max": round(float(tot.max()), 4)},
             "sample": "%d timed passes after 1 warm-up (%.0f s of CPU work) in a fresh process, value = 1 / median: oracle animate %s %.3f s (%d free "
                       "Gaussians with 4 non-zero skinning weights + %d mesh-bound) + C tile rasterizer %s %.3f s (OpenMP over tiles; %d Gaussians "
-                      "@%dx%d); %d threads for both, the process pinned to %d cores of the %d-core host"
-                      % (len(ta), o["spent"], what, t_an, o["N"], o["M"], what, t_ra, G, res, res, nthr, nthr, host)}
+                      "@%dx%d); %d threads for both on the %d-CPU host (affinity: %s)"
+                      % (len(ta), o["spent"], what, t_an, o["N"], o["M"], what, t_ra, G, res, res, nthr, host, o["pinned"] or "not pinned")}
 
 
 # ------------------------------------------------------------------------------------------------------------------------------------
