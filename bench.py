@@ -65,6 +65,8 @@ def parse():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-guidance", action="store_true", help="raster+LBS sub-path only (not the headline workload)")
     ap.add_argument("--frame-graph", action="store_true", help="config c5: replay each frame as one captured hipGraph (player.GraphedAnimation)")
+    ap.add_argument("--step-graph", action="store_true", help="config c2: the whole step (zero_grad, animate, raster fwd + bwd, Adam) as ONE captured "
+                                                              "HIP graph replayed per pose (step_graph.GraphedTrainStep)")
     ap.add_argument("--eager", action="store_true", help="launch every kernel eagerly (no hipGraph replay of the denoiser/VAE plans)")
     ap.add_argument("--no-gpu-condition", action="store_true", help="fixed condition image instead of the per-step GPU OpenPose image of the posed body")
     ap.add_argument("--sync-pairs", action="store_true", help="exact pair-buffer sizing through a 16-byte read-back per frame")
@@ -396,7 +398,7 @@ def _timed(ctx, fn, steps, warmup):
     return dt
 
 
-def run_sds(ctx, config, dtype=HEADLINE_DTYPE, views=None, steps=None, warmup=None, profile=True, batch_views=None, repeats=None):
+def run_sds(ctx, config, dtype=HEADLINE_DTYPE, views=None, steps=None, warmup=None, profile=True, batch_views=None, repeats=None, step_graph=None):
     """c2 / c3 / c4: SDSStep-based workloads.  Returns the JSON line as a dict (rank 0) or None."""
     args = ctx.args
     steps, warmup = defaults(config, steps, warmup)
@@ -425,7 +427,15 @@ def run_sds(ctx, config, dtype=HEADLINE_DTYPE, views=None, steps=None, warmup=No
         _lib.prof_enable(True)
     if repeats is None:
         repeats = args.repeats or (3 if config == "c4" else 1)
-    dts = [_timed(ctx, step.run, steps, warmup if r == 0 else 0) for r in range(max(1, repeats))]       # each: barrier + sync on both sides, max over ranks
+    run = step.run
+    whole_graph = (bool(getattr(args, "step_graph", False)) if step_graph is None else bool(step_graph)) and config == "c2" and not guidance \
+        and not args.eager and ctx.world == 1
+    if whole_graph:
+        runner = step.graphed()
+        run = runner.step
+    dts = [_timed(ctx, run, steps, warmup if r == 0 else 0) for r in range(max(1, repeats))]       # each: barrier + sync on both sides, max over ranks
+    if whole_graph and runner.graph.check():
+        raise SystemExit("bench.py: a captured step was truncated by the frozen pair capacity")
     dt = sorted(dts)[len(dts) // 2]
     prof_steps, prof, prof_sym = steps, {}, {}
     if profile and not args.eager:
@@ -471,7 +481,8 @@ def run_sds(ctx, config, dtype=HEADLINE_DTYPE, views=None, steps=None, warmup=No
         out["raster_mpix_per_s"] = rf["mpix_per_s"] if rf else None      # the rasterizer's own forward rate (pixels / forward-chain time)
         out["kernel_ms_per_step"] = {k: round(v[1] / prof_steps, 4) for k, v in sorted(prof.items(), key=lambda kv: -kv[1][1])[:40]}
     out["redone_frames"] = step.trainer.redone_frames
-    out["launch_mode"] = "eager" if args.eager else "hipGraph replay of denoiser/VAE plans; kernel timers from an eager replay after the timed region"
+    out["launch_mode"] = ("eager" if args.eager else "the WHOLE step (zero_grad, animate, raster fwd + bwd, Adam) replayed as one captured HIP graph per pose"
+                          if whole_graph else "hipGraph replay of denoiser/VAE plans; kernel timers from an eager replay after the timed region")
     return out
 
 
@@ -538,7 +549,14 @@ def run_c1(ctx, steps=None, warmup=None):
     def frame():
         with torch.inference_mode():
             return scene.forward(data, smpl_observed_inputs=None, use_densifier=False, bg_mode=None)
-    dt = _timed(ctx, frame, steps, warmup)
+    player = None
+    if not args.eager:          # the frame as ONE captured graph (player.GraphedAnimation, canonical pose: no per-frame input)
+        from dreamwaltz_g_amd import player as pl
+        player = pl.GraphedAnimation(scene, data, None)
+    dt = _timed(ctx, player.replay if player is not None else frame, steps, warmup)
+    if player is not None:
+        assert player.check(), "a replayed frame was truncated by the frozen pair capacity"
+        player.close()
     _lib.prof_enable(True)
     ps = min(steps, 5)
     for _ in range(ps):
@@ -551,11 +569,12 @@ def run_c1(ctx, steps=None, warmup=None):
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
             "config": {"workload": "c1: canonical-pose forward (%d free + %d mesh-bound Gaussians through the encoder / MLPs) + raster forward %dx%d, "
                                    "inference_mode" % (N, M, res, res), "gaussians": G, "resolution": res},
-            "roofline": raster_report(prof, G, Kref, K, res * res, ps), "launch_mode": "eager",
+            "roofline": raster_report(prof, G, Kref, K, res * res, ps),
+            "launch_mode": "eager" if args.eager else "one hipGraph per frame (player.GraphedAnimation); kernel timers from eager frames after the timed region",
             "kernel_ms_per_step": {k: round(v[1] / ps, 4) for k, v in sorted(prof.items(), key=lambda kv: -kv[1][1])[:12]}}
 
 
-def _brief(line, keys=("value", "unit", "ms_per_step", "steps", "warmup", "repeats", "dtype", "views_per_s", "views_per_step", "config", "roofline",
+def _brief(line, keys=("value", "unit", "ms_per_step", "steps", "warmup", "repeats", "launch_mode", "dtype", "views_per_s", "views_per_step", "config", "roofline",
                        "raster_mpix_per_s", "cpu_baseline", "metric", "redone_frames")):
     return {k: line[k] for k in keys if k in line}
 
@@ -586,8 +605,10 @@ def main():
             # the three host-fed configurations (2-ms steps: their rate is the host's enqueue rate) run FIRST, in the state a process of
             # their own would have -- after the denoiser / VAE plans exist, the interpreter's heap holds ~1e5 more objects and the same
             # loops measured 25 % slower (c2: 364 vs 516 steps/s)
-            c2 = run_sds(ctx, "c2", steps=200, warmup=20)
+            c2 = run_sds(ctx, "c2", steps=200, warmup=20, step_graph=True)        # the whole step replayed as one captured graph per pose
             pre_cfgs["c2"] = _brief(c2)
+            c2e = run_sds(ctx, "c2", steps=200, warmup=20, step_graph=False, profile=False)
+            pre_cfgs["c2_eager_launches"] = _brief(c2e, ("value", "unit", "ms_per_step", "steps", "warmup", "launch_mode"))
             c5 = run_c5(ctx, 200, 20)
             c1 = run_c1(ctx, 200, 20)
             if cpu_ok:

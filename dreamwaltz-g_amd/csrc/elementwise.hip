@@ -76,15 +76,18 @@ __global__ __launch_bounds__(256) void k_act_bwd_colsum(int M, int N, int act, c
 
 // Adam (torch.optim.Adam semantics, amsgrad=False, weight_decay=0, maximize=False):
 //   m = b1 m + (1-b1) g ; v = b2 v + (1-b2) g^2 ; p -= lr/(1-b1^t) * m / (sqrt(v)/sqrt(1-b2^t) + eps)
+// `hyper` != nullptr: the per-step scalars come from DEVICE memory -- hyper[0] = lr / (1 - b1^t), hyper[1] = sqrt(1 - b2^t), hyper[2] =
+// grad_scale -- so that the launch can sit inside a captured graph whose replays see the learning-rate schedule and the step count move.
 __global__ __launch_bounds__(256) void k_adam(size_t n, float* __restrict__ p, const float* __restrict__ g,
                                               float* __restrict__ m, float* __restrict__ v, float lr, float b1, float b2,
-                                              float eps, float bc1, float bc2_sqrt, float grad_scale) {
+                                              float eps, float bc1, float bc2_sqrt, float grad_scale, const float* __restrict__ hyper) {
     size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
     const size_t stride = (size_t)gridDim.x * 256;
     const size_t n4 = n / 4;
     float4* p4 = reinterpret_cast<float4*>(p); const float4* g4 = reinterpret_cast<const float4*>(g);
     float4* m4 = reinterpret_cast<float4*>(m); float4* v4 = reinterpret_cast<float4*>(v);
-    const float step = lr / bc1;
+    float step = lr / bc1;
+    if (hyper) { step = hyper[0]; bc2_sqrt = hyper[1]; grad_scale = hyper[2]; }
     for (size_t k = i; k < n4; k += stride) {
         float4 pp = p4[k], gg = g4[k], mm = m4[k], vv = v4[k];
 #define UPD(c) { float gr = gg.c * grad_scale; mm.c = b1 * mm.c + (1.f - b1) * gr; vv.c = b2 * vv.c + (1.f - b2) * gr * gr; \
@@ -583,7 +586,22 @@ int dwg_adam_step(int64_t n, float* param, const float* grad, float* exp_avg, fl
     if (blocks < 1) blocks = 1;
     if (blocks > 2048) blocks = 2048;
     DWG_LAUNCH("adam_step", k_adam, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, (size_t)n, param, grad, exp_avg,
-               exp_avg_sq, lr, beta1, beta2, eps, bc1, bc2_sqrt, grad_scale);
+               exp_avg_sq, lr, beta1, beta2, eps, bc1, bc2_sqrt, grad_scale, (const float*)nullptr);
+    DWG_RETURN_IF_LAUNCH_FAILED();
+    return DWG_OK;
+}
+
+int dwg_adam_step_dev(int64_t n, float* param, const float* grad, float* exp_avg, float* exp_avg_sq, const float* hyper, float beta1,
+                      float beta2, float eps, dwg_stream_t stream) {
+    if (n < 0 || !hyper) return DWG_E_ARG;
+    if (n == 0) return DWG_OK;
+    if (!param || !grad || !exp_avg || !exp_avg_sq) return DWG_E_ARG;
+    if (((uintptr_t)param | (uintptr_t)grad | (uintptr_t)exp_avg | (uintptr_t)exp_avg_sq) % 16) return DWG_E_ARG;
+    size_t blocks = ((size_t)n / 4 + 255) / 256;
+    if (blocks < 1) blocks = 1;
+    if (blocks > 2048) blocks = 2048;
+    DWG_LAUNCH("adam_step", k_adam, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, (size_t)n, param, grad, exp_avg,
+               exp_avg_sq, 0.f, beta1, beta2, eps, 1.f, 1.f, 1.f, hyper);
     DWG_RETURN_IF_LAUNCH_FAILED();
     return DWG_OK;
 }

@@ -155,6 +155,35 @@ class FlatOptimizer:
             pg["t"] = pg.get("t", 0) + 1
             self._launch(pg)
 
+    # -- the same step in two halves, for a captured graph of the whole avatar-side step (step_graph.GraphedTrainStep) ----------------
+    def prepare_step(self, hyper_host: torch.Tensor, base: int):
+        """HOST half of step(): step counts and this step's scalars of every group -> rows base, base + 1, ... of the (pinned) hyper table
+        {lr / (1 - b1^t), sqrt(1 - b2^t), grad_scale, 0}.  Returns the number of rows used.  (Participation is not consulted: a captured
+        step replays the same launches every time.)"""
+        self.t += 1
+        self.current_iteration += 1
+        for k, pg in enumerate(self.param_groups):
+            pg["t"] = pg.get("t", 0) + 1
+            b1, b2 = pg["betas"]
+            hyper_host[base + k, 0] = float(pg["lr"]) / (1.0 - b1 ** pg["t"])
+            hyper_host[base + k, 1] = math.sqrt(1.0 - b2 ** pg["t"])
+            hyper_host[base + k, 2] = float(self.grad_scale)
+        return len(self.param_groups)
+
+    def launch_step(self, hyper_dev: torch.Tensor, base: int):
+        """DEVICE half: one fused Adam launch per group reading its scalars from row base + k of the device hyper table (capturable)."""
+        b = self.buf
+        st = ctypes.c_void_p(torch.cuda.current_stream(b.flat.device).cuda_stream)
+        for k, pg in enumerate(self.param_groups):
+            n, o = pg["end"] - pg["start"], pg["start"] * 4
+            if n <= 0:
+                continue
+            _lib.check(_lib.lib().dwg_adam_step_dev(n, ctypes.c_void_p(b.flat.data_ptr() + o), ctypes.c_void_p(b.grad.data_ptr() + o),
+                                                    ctypes.c_void_p(b.m.data_ptr() + o), ctypes.c_void_p(b.v.data_ptr() + o),
+                                                    ctypes.c_void_p(hyper_dev.data_ptr() + (base + k) * 16), float(pg["betas"][0]),
+                                                    float(pg["betas"][1]), float(pg["eps"]), st), "dwg_adam_step_dev")
+        return len(self.param_groups)
+
     def _launch(self, pg):
         """The fused Adam launch of one group over its slice of the flat buffers (csrc/elementwise.hip k_adam)."""
         b = self.buf

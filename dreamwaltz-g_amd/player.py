@@ -15,18 +15,20 @@ import torch
 
 
 class GraphedAnimation:
-    def __init__(self, scene, data: dict, example_pose: Dict[str, torch.Tensor], warmup_poses: Optional[Iterable[dict]] = None,
+    def __init__(self, scene, data: dict, example_pose: Optional[Dict[str, torch.Tensor]], warmup_poses: Optional[Iterable[dict]] = None,
                  bg_mode: Optional[str] = None):
+        """`example_pose` None: the canonical-pose frame (Scene.forward without observed pose: BASELINE config c1) -- no per-frame input at
+        all, a replay is one graph launch."""
         self.scene, self.data, self.bg_mode = scene, data, bg_mode
-        self.device = next(iter(example_pose.values())).device
+        self.device = next(iter(example_pose.values())).device if example_pose is not None else torch.device(data['extrinsic'].device)
         if self.device.type != "cuda":
             raise RuntimeError("dreamwaltz_g_amd.player runs on the GPU only (HIP kernels)")
         if not scene.renderer.async_pair_count:
             raise ValueError("GraphedAnimation needs a renderer with async_pair_count=True (no host read-back inside the frame)")
-        self.pose = {k: v.clone() for k, v in example_pose.items()}          # static inputs of the graph
+        self.pose = {k: v.clone() for k, v in example_pose.items()} if example_pose is not None else None      # static inputs of the graph
         self.graph, self.outputs = None, None
         self._state = None
-        self._capture(list(warmup_poses) if warmup_poses is not None else [example_pose])
+        self._capture(list(warmup_poses) if warmup_poses is not None else [example_pose] * (1 if example_pose is not None else 3))
 
     def _frame(self):
         with torch.inference_mode():
@@ -90,11 +92,13 @@ class GraphedAnimation:
             renderer._pair_states.pop(key, None)
         torch.cuda.current_stream(self.device).wait_stream(side)
 
-    def set_pose(self, pose: Dict[str, torch.Tensor]):
+    def set_pose(self, pose: Optional[Dict[str, torch.Tensor]]):
+        if pose is None or self.pose is None:
+            return
         for k, v in pose.items():
             self.pose[k].copy_(v, non_blocking=True)
 
-    def replay(self, pose: Dict[str, torch.Tensor]) -> dict:
+    def replay(self, pose: Optional[Dict[str, torch.Tensor]] = None) -> dict:
         """One frame: the outputs dict of Scene.forward (static tensors, overwritten by the next replay)."""
         self.set_pose(pose)
         self.graph.replay()

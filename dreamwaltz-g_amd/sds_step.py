@@ -188,6 +188,30 @@ class SDSStep:
         self.step_idx += 1
         return out
 
+    def graphed(self, warmup=4):
+        """The whole step as ONE captured HIP graph (step_graph.GraphedTrainStep): single-view steps without guidance (config c2).  Returns
+        an object whose `.step()` takes the place of `run()`: same pose sequence, same updates."""
+        from . import step_graph
+        if self.guidance is not None or len(self.my_views) != 1:
+            raise NotImplementedError("only the single-view step without guidance is captured as a whole")
+        d = self.view_data[self.my_views[0]]
+        v = self.my_views[0]
+        poses = [{k: t.to(self.device) for k, t in synth.random_smpl_inputs(seed=1000 * v + self.step_idx + i, device="cpu").items()}
+                 for i in range(warmup + 1)]
+        data = {k: t for k, t in d.items() if k != "smpl_inputs"}
+        g = step_graph.GraphedTrainStep(self.trainer, data, poses[0], warmup_poses=poses[:warmup], capture_pose=poses[warmup])
+        self.step_idx += warmup + 1          # the warm-up steps and the capture's eager step were real optimizer steps
+        step = self
+
+        class _Runner:
+            graph = g
+
+            def step(self_inner):
+                out = g.step(synth.random_smpl_inputs(seed=1000 * v + step.step_idx, device="cpu"))
+                step.step_idx += 1
+                return out
+        return _Runner()
+
     @property
     def num_pairs(self):
         """(pairs after exact culling, reference tile-pair count K of SURVEY 8d) of the last rendered frame."""

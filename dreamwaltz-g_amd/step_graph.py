@@ -1,0 +1,172 @@
+"""The avatar side of a training step as ONE captured HIP graph (BASELINE config c2: LBS / encoder / MLP deform + rasterizer forward and
+backward + the optimizer, no guidance): zero_grad -> Scene.forward (animate -> render) -> loss -> backward (rasterizer, LBS, grid encoder,
+MLPs, mesh binding) -> fused Adam of every named optimizer, i.e. the loop body of /root/reference/core/trainer.py:859-890 without the
+diffusion call, replayed per pose.
+
+Why: the c2 step is ~0.9 ms of kernels and its ~250 launches + autograd bookkeeping cost the host 2-2.5 ms -- the eager loop is host-bound
+(DESIGN.md, round-3 verdict).  A replay costs one copy of the pose into static buffers, one 16-byte-per-group copy of the optimizer scalars
+and one graph launch.
+
+What is static in the graph: the camera, the Gaussian count, the rasterizer's pair capacity (frozen at `grow` x the largest count of the
+warm-up steps, as player.GraphedAnimation does; a step that needs more pairs is TRUNCATED by the kernels and flags it -- `check()` reports
+it, `recapture()` grows the capacity), the binning order of the rasterizer (results do not depend on it).  What moves per replay without
+being captured: the pose (static device buffers, refreshed by an asynchronous copy before the launch) and the optimizers' per-step scalars
+(learning-rate schedule, bias corrections: `FlatOptimizer.prepare_step` writes them to a pinned table, one copy puts them where
+`dwg_adam_step_dev` reads them).  The densifier and multi-view / multi-rank steps are not captured (they change shapes / need the host).
+"""
+from typing import Dict
+
+import torch
+
+from .rasterizer import PairCapacity
+
+
+class GraphedTrainStep:
+    def __init__(self, trainer, data: dict, example_pose: Dict[str, torch.Tensor], warmup_poses=None, grow: float = 1.5, capture_pose=None):
+        """`trainer`: an SDSTrainer whose `diffusion` makes no host round trips and draws no random numbers (the no-guidance image loss of
+        c2); `data`: the loader's dict of the (fixed) camera WITHOUT 'smpl_inputs'; `example_pose`: device tensors, cloned into the graph's
+        static pose buffers.  Building it takes REAL optimizer steps: one per warm-up pose, and one more -- on `capture_pose` (default: the
+        last warm-up pose again) -- at the frozen pair capacity right before the capture."""
+        self.trainer, self.grow = trainer, float(grow)
+        self.device = next(iter(example_pose.values())).device
+        if self.device.type != "cuda":
+            raise RuntimeError("dreamwaltz_g_amd.step_graph runs on the GPU only (HIP kernels)")
+        renderer = trainer.model.renderer
+        if not renderer.async_pair_count:
+            raise ValueError("GraphedTrainStep needs a renderer with async_pair_count=True (no host read-back inside the step)")
+        if trainer.densifiers is not None or trainer.world != 1 or trainer.total_views != 1:
+            raise NotImplementedError("a captured step is single-view, single-rank and without the densifier")
+        self.pose = {k: v.clone() for k, v in example_pose.items()}
+        self.data = dict(data); self.data["smpl_inputs"] = self.pose
+        self._pinned = [{k: torch.empty_like(v, device="cpu").pin_memory() for k, v in example_pose.items()} for _ in range(4)]
+        self._slot = 0
+        opts = trainer.optimizers
+        self._rows = sum(len(o.param_groups) for o in opts.values())
+        # per-step host inputs go through NSLOT rotating pinned slots; a slot is rewritten only after the replay that read it has finished
+        # (nothing else throttles the host here: the eager loop is paced by the rasterizer's pair-count event, a replay is not)
+        self._hyper_slots = [torch.zeros(self._rows, 4).pin_memory() for _ in range(4)]
+        self._slot_events = [None] * 4
+        self.hyper_host = self._hyper_slots[0]
+        self.hyper_dev = torch.zeros(self._rows, 4, device=self.device)
+        self.graph, self.loss, self.outputs = None, None, None
+        self._side = torch.cuda.Stream(device=self.device)
+        H, W = int(data["image_height"]), int(data["image_width"])
+        self._hw = (H, W)
+        self._spatial_scale = trainer.get_spatial_scale(self.data)           # the camera is static: one host read, not one per step
+        # eager warm-up steps ON THE CAPTURE STREAM (autograd's AccumulateGrad nodes, lazy kernel attributes, the allocator, pair counts)
+        self._side.wait_stream(torch.cuda.current_stream(self.device))
+        most = 0
+        with torch.cuda.stream(self._side):
+            shared = renderer.pair_state(self.device, H, W)
+            for pose in (list(warmup_poses) if warmup_poses is not None else [example_pose] * 3):
+                self._set_pose_now(pose)
+                self._eager_step()
+                shared.resolve()
+                most = max(most, shared.last_num_pairs)
+            self._side.synchronize()
+        own = PairCapacity()
+        own.cap = max(shared.cap, int(most * self.grow), shared.min_pairs)
+        own.frozen = True
+        self._state = own
+        if capture_pose is not None:
+            with torch.cuda.stream(self._side):
+                self._set_pose_now(capture_pose)
+        self._capture()
+
+    # -- pieces ------------------------------------------------------------------------------------------------------------
+    def _set_pose_now(self, pose):
+        for k, v in pose.items():
+            self.pose[k].copy_(v, non_blocking=True)
+
+    def _host_prepare(self):
+        """What the eager trainer does on the host around a step (trainer.py:861-870, 888-890): step index, learning-rate schedule, the
+        optimizers' step counts and scalars -> the pinned table."""
+        tr = self.trainer
+        tr.train_step_index += 1
+        scale = self._spatial_scale
+        base = 0
+        for o in tr.optimizers.values():
+            if hasattr(o, "update_learning_rate"):
+                o.update_learning_rate(iteration=tr.train_step_index, spatial_scale=scale)
+            base += o.prepare_step(self.hyper_host, base)
+
+    def _device_body(self):
+        """The captured region."""
+        tr = self.trainer
+        for o in tr.optimizers.values():
+            o.zero_grad()
+        loss, render_outputs, _, _ = tr.train_forward(self.data)
+        loss.backward()
+        base = 0
+        for o in tr.optimizers.values():
+            base += o.launch_step(self.hyper_dev, base)
+        return loss, render_outputs
+
+    def _eager_step(self):
+        torch.cuda.current_stream(self.device).synchronize()    # set-up path: the pinned table is free to rewrite
+        self._host_prepare()
+        self.hyper_dev.copy_(self.hyper_host, non_blocking=True)
+        return self._device_body()
+
+    def _capture(self):
+        tr, renderer = self.trainer, self.trainer.model.renderer
+        H, W = self._hw
+        state = self._state
+        state.overflow, state.pending, state.frozen = False, False, True
+        for entry in renderer._visit_orders.values():      # the periodic refresh of the binning order must not fall into the captured step
+            entry[1] = 0
+        self._side.wait_stream(torch.cuda.current_stream(self.device))
+        with torch.cuda.stream(self._side):
+            key = renderer.pair_state_key(self.device, H, W)
+            shared = renderer._pair_states.get(key)
+            renderer._pair_states[key] = state
+            self._eager_step()                                  # once eagerly at the frozen capacity (allocator warm-up)
+            self._side.synchronize()
+            self._forget_pose_caches()
+            self.graph = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(self.graph, stream=self._side):
+                self.loss, self.outputs = self._device_body()
+            self._forget_pose_caches()
+            self._keep = [entry[0] for entry in renderer._visit_orders.values()]
+            if shared is not None:
+                renderer._pair_states[key] = shared
+            else:
+                renderer._pair_states.pop(key, None)
+        torch.cuda.current_stream(self.device).wait_stream(self._side)
+
+    def _forget_pose_caches(self):
+        for m in self.trainer.model.modules():
+            if getattr(m, "_last_forward", None) is not None:
+                m._last_forward = None
+
+    # -- per step ------------------------------------------------------------------------------------------------------------
+    def step(self, pose_cpu: Dict[str, torch.Tensor]):
+        """One optimizer step for `pose_cpu` (host tensors): returns (loss, render outputs) -- static tensors, overwritten by the next step."""
+        i = self._slot; self._slot = (self._slot + 1) % len(self._pinned)
+        if self._slot_events[i] is not None:
+            self._slot_events[i].synchronize()                  # the replay that read this slot four steps ago is done
+        self.hyper_host = self._hyper_slots[i]
+        self._host_prepare()
+        slot = self._pinned[i]
+        for k, v in pose_cpu.items():
+            slot[k].copy_(v)
+            self.pose[k].copy_(slot[k], non_blocking=True)
+        self.hyper_dev.copy_(self.hyper_host, non_blocking=True)
+        self.graph.replay()
+        ev = torch.cuda.Event(); ev.record(torch.cuda.current_stream(self.device))
+        self._slot_events[i] = ev
+        return self.loss, self.outputs
+
+    def check(self) -> bool:
+        """True if a step since the last call was truncated by the frozen pair capacity (one stream synchronisation)."""
+        torch.cuda.current_stream(self.device).synchronize()
+        st = self._state
+        ovf = bool(st.host is not None and int(st.host[1]) != 0)
+        if st.host is not None:
+            st.last_num_pairs, st.last_num_pairs_ref = int(st.host[0]), int(st.host[2])
+        return ovf
+
+    def recapture(self, grow: float = 2.0):
+        self._state.cap = int(self._state.cap * grow)
+        self.graph = None
+        self._capture()

@@ -41,6 +41,12 @@ int dwg_mlp_chain_forward(int32_t M, int32_t Kin, const float* x, int32_t ldx, i
  * grad is multiplied by grad_scale first (1/world_size after a sum all-reduce).  Buffers must be 16-byte aligned. */
 int dwg_adam_step(int64_t n, float* param, const float* grad, float* exp_avg, float* exp_avg_sq, float lr, float beta1,
                   float beta2, float eps, int32_t step, float grad_scale, dwg_stream_t stream);
+/* The same update with the per-step scalars read from DEVICE memory: hyper[0] = lr / (1 - beta1^t), hyper[1] = sqrt(1 - beta2^t),
+ * hyper[2] = grad_scale (three floats the host refreshes before each replay) -- the form a launch needs inside a captured graph of the
+ * whole avatar-side step (step_graph.GraphedTrainStep), where kernel arguments are frozen at capture time but the learning-rate schedule
+ * (gaussian_optimizer.py:130-141) and the bias correction move every step. */
+int dwg_adam_step_dev(int64_t n, float* param, const float* grad, float* exp_avg, float* exp_avg_sq, const float* hyper, float beta1,
+                      float beta2, float eps, dwg_stream_t stream);
 
 /* NHWC channel concat (torch.cat([h, skip], 1) of the UNet up blocks): out[r] = [a[r] | b[r]], bf16, Ca % 8 == Cb % 8 == 0. */
 int dwg_concat_channels(int64_t rows, int32_t Ca, int32_t Cb, const void* a, const void* b, void* out, dwg_stream_t stream);

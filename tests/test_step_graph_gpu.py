@@ -1,0 +1,57 @@
+"""-m gpu: the avatar side of a training step captured as ONE HIP graph (step_graph.GraphedTrainStep; BASELINE config c2's loop body,
+/root/reference/core/trainer.py:859-890 without the diffusion call) against the eager trainer on the same pose sequence."""
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+
+def _rel(a, b):
+    return float((a.double() - b.double()).norm() / b.double().norm().clamp_min(1e-30))
+
+
+def test_graphed_step_matches_the_eager_step_sequence():
+    """Identical avatars, the same ten poses: two stepped eagerly by SDSTrainer.train_step, one by replays of the captured step (its
+    warm-up steps included).  Adam with eps = 1e-15 turns the float-atomic noise of the grid-encoder table gradient into sign flips of
+    near-zero entries, so two EAGER runs already differ; the graphed run must differ from an eager one no more than they differ from each
+    other (x3), on the parameters and on the rendered image.  The learning-rate schedule and the per-group step counts moved inside the
+    graph (device-side Adam scalars); the frozen pair capacity was not exceeded."""
+    import dwg_import  # noqa: F401
+    from dreamwaltz_g_amd import sds_step
+    dev = torch.device("cuda:0")
+    torch.cuda.set_stream(torch.cuda.Stream(device=dev))
+    n_steps, warm = 6, 3
+
+    def make():
+        return sds_step.SDSStep(n_gaussians=8000, res=128, device=dev, guidance=False, async_pair_count=True, iters=1000)
+    eagers = []
+    for _ in range(2):
+        e = make()
+        for _ in range(n_steps + warm + 1):       # the graphed twin takes warm + 1 real steps while it is being built
+            out = e.run()
+        eagers.append((e, out[1]["image"].detach().clone()))
+    torch.cuda.synchronize()
+    twin = make()
+    runner = twin.graphed(warmup=warm)
+    for _ in range(n_steps):
+        loss, outs = runner.step()
+    assert not runner.graph.check()
+    (e0, img0), (e1, img1) = eagers
+    assert twin.step_idx == e0.step_idx and twin.trainer.train_step_index == e0.trainer.train_step_index
+    b0, b1, bt = e0.optimizers.buffers, e1.optimizers.buffers, twin.optimizers.buffers
+    d_ee, d_ge = _rel(b1.flat, b0.flat), _rel(bt.flat, b0.flat)
+    i_ee, i_ge = _rel(img1, img0), _rel(outs["image"], img0)
+    print("[parity] step_graph: params eager/eager %.3e graph/eager %.3e; image %.3e / %.3e" % (d_ee, d_ge, i_ee, i_ge))
+    assert d_ge <= 3.0 * d_ee + 1e-6, (d_ge, d_ee)
+    assert i_ge <= 3.0 * i_ee + 1e-5, (i_ge, i_ee)
+    # what does not depend on the atomics' order: the positions (lr 1.6e-4) and every optimizer's schedule state
+    pe, pt = e0.avatar._positions.detach(), twin.avatar._positions.detach()
+    assert _rel(pt, pe) < 1e-3
+    for name in e0.optimizers:
+        for ge, gt in zip(e0.optimizers[name].param_groups, twin.optimizers[name].param_groups):
+            assert ge["t"] == gt["t"] and abs(ge["lr"] - gt["lr"]) <= 1e-12 * max(1.0, abs(ge["lr"])), (name, ge["lr"], gt["lr"])
+    assert torch.isfinite(loss).all() and outs["image"].shape[1:3] == (128, 128)
+    # the graph keeps working after eager steps through the same trainer (shared parameters, own frozen pair state)
+    twin.run()
+    runner.step()
+    assert not runner.graph.check()
