@@ -65,8 +65,9 @@ def parse():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-guidance", action="store_true", help="raster+LBS sub-path only (not the headline workload)")
     ap.add_argument("--frame-graph", action="store_true", help="config c5: replay each frame as one captured hipGraph (player.GraphedAnimation)")
-    ap.add_argument("--step-graph", action="store_true", help="config c2: the whole step (zero_grad, animate, raster fwd + bwd, Adam) as ONE captured "
-                                                              "HIP graph replayed per pose (step_graph.GraphedTrainStep)")
+    ap.add_argument("--step-graph", action="store_true", help="config c2 / single-GPU c3: the whole step (zero_grad, condition image, animate, raster, "
+                                                              "VAE, ControlNet + UNet, backward, Adam) as ONE captured HIP graph replayed per pose "
+                                                              "(step_graph.GraphedTrainStep)")
     ap.add_argument("--eager", action="store_true", help="launch every kernel eagerly (no hipGraph replay of the denoiser/VAE plans)")
     ap.add_argument("--no-gpu-condition", action="store_true", help="fixed condition image instead of the per-step GPU OpenPose image of the posed body")
     ap.add_argument("--sync-pairs", action="store_true", help="exact pair-buffer sizing through a 16-byte read-back per frame")
@@ -428,8 +429,8 @@ def run_sds(ctx, config, dtype=HEADLINE_DTYPE, views=None, steps=None, warmup=No
     if repeats is None:
         repeats = args.repeats or (3 if config == "c4" else 1)
     run = step.run
-    whole_graph = (bool(getattr(args, "step_graph", False)) if step_graph is None else bool(step_graph)) and config == "c2" and not guidance \
-        and not args.eager and ctx.world == 1
+    whole_graph = (bool(getattr(args, "step_graph", False)) if step_graph is None else bool(step_graph)) and not args.eager and ctx.world == 1 \
+        and ((config == "c2" and not guidance) or (config == "c3" and guidance and views == 1))
     if whole_graph:
         runner = step.graphed()
         run = runner.step

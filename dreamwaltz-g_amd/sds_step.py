@@ -192,14 +192,20 @@ class SDSStep:
         """The whole step as ONE captured HIP graph (step_graph.GraphedTrainStep): single-view steps without guidance (config c2).  Returns
         an object whose `.step()` takes the place of `run()`: same pose sequence, same updates."""
         from . import step_graph
-        if self.guidance is not None or len(self.my_views) != 1:
-            raise NotImplementedError("only the single-view step without guidance is captured as a whole")
+        if len(self.my_views) != 1 or self.world != 1:
+            raise NotImplementedError("only the single-view, single-rank step is captured as a whole")
         d = self.view_data[self.my_views[0]]
         v = self.my_views[0]
         poses = [{k: t.to(self.device) for k, t in synth.random_smpl_inputs(seed=1000 * v + self.step_idx + i, device="cpu").items()}
                  for i in range(warmup + 1)]
         data = {k: t for k, t in d.items() if k != "smpl_inputs"}
-        g = step_graph.GraphedTrainStep(self.trainer, data, poses[0], warmup_poses=poses[:warmup], capture_pose=poses[warmup])
+        cond_fn = (lambda pose: self.condition_image(pose, d)) if getattr(self, "condition", None) is not None else None
+        # the view's device-RNG stream of step k (0-based) is seeded as run() seeds it: the trainer's index is k + 1 when the draws are made
+        seed_fn = (lambda idx: (1234 + v) * 1000003 + (idx - 1)) if self.guidance is not None else None
+        if self.guidance is not None and cond_fn is None:
+            data["cond_images"] = d["cond_images"]
+        g = step_graph.GraphedTrainStep(self.trainer, data, poses[0], warmup_poses=poses[:warmup], capture_pose=poses[warmup],
+                                        condition_fn=cond_fn, seed_fn=seed_fn)
         self.step_idx += warmup + 1          # the warm-up steps and the capture's eager step were real optimizer steps
         step = self
 

@@ -1,7 +1,9 @@
-"""The avatar side of a training step as ONE captured HIP graph (BASELINE config c2: LBS / encoder / MLP deform + rasterizer forward and
-backward + the optimizer, no guidance): zero_grad -> Scene.forward (animate -> render) -> loss -> backward (rasterizer, LBS, grid encoder,
-MLPs, mesh binding) -> fused Adam of every named optimizer, i.e. the loop body of /root/reference/core/trainer.py:859-890 without the
-diffusion call, replayed per pose.
+"""A whole training step as ONE captured HIP graph, replayed per pose: zero_grad -> [condition image of the posed body] -> Scene.forward
+(animate -> render) -> diffusion(...) -> backward (VAE, rasterizer, LBS, grid encoder, MLPs, mesh binding) -> fused Adam of every named
+optimizer, i.e. the loop body of /root/reference/core/trainer.py:859-890.  Without guidance (BASELINE config c2) it is the avatar side alone;
+with it (config c3) the VAE / ControlNet + UNet plans are captured INLINE (their own hipGraphs are switched off: one graph, no nesting) and
+the call's three random draws (VAE posterior, timestep, noise: checklist Q12) are made eagerly into static tensors right before each replay,
+from the same per-step seed the eager step uses -- the numbers are the eager step's.
 
 Why: the c2 step is ~0.9 ms of kernels and its ~250 launches + autograd bookkeeping cost the host 2-2.5 ms -- the eager loop is host-bound
 (DESIGN.md, round-3 verdict).  A replay costs one copy of the pose into static buffers, one 16-byte-per-group copy of the optimizer scalars
@@ -22,10 +24,12 @@ from .rasterizer import PairCapacity
 
 
 class GraphedTrainStep:
-    def __init__(self, trainer, data: dict, example_pose: Dict[str, torch.Tensor], warmup_poses=None, grow: float = 1.5, capture_pose=None):
+    def __init__(self, trainer, data: dict, example_pose: Dict[str, torch.Tensor], warmup_poses=None, grow: float = 1.5, capture_pose=None,
+                 condition_fn=None, seed_fn=None):
         """`trainer`: an SDSTrainer whose `diffusion` makes no host round trips and draws no random numbers (the no-guidance image loss of
         c2); `data`: the loader's dict of the (fixed) camera WITHOUT 'smpl_inputs'; `example_pose`: device tensors, cloned into the graph's
-        static pose buffers.  Building it takes REAL optimizer steps: one per warm-up pose, and one more -- on `capture_pose` (default: the
+        static pose buffers.  `condition_fn(pose) -> [1,3,H,W]`: the loader's condition image of the posed body, drawn inside the graph;
+        `seed_fn(step index) -> int`: the seed of the step's device-RNG stream (guidance only).  Building it takes REAL optimizer steps: one per warm-up pose, and one more -- on `capture_pose` (default: the
         last warm-up pose again) -- at the frozen pair capacity right before the capture."""
         self.trainer, self.grow = trainer, float(grow)
         self.device = next(iter(example_pose.values())).device
@@ -38,6 +42,15 @@ class GraphedTrainStep:
             raise NotImplementedError("a captured step is single-view, single-rank and without the densifier")
         self.pose = {k: v.clone() for k, v in example_pose.items()}
         self.data = dict(data); self.data["smpl_inputs"] = self.pose
+        self.condition_fn, self.seed_fn = condition_fn, seed_fn
+        self.guided = hasattr(trainer.diffusion, "draw_view_randoms")
+        self._rng, self._rand = None, None
+        if self.guided:
+            trainer.diffusion.set_use_graphs(False)            # the plans' kernels go into THIS graph, not into graphs of their own
+            self._rng = torch.Generator(device=self.device)
+            pn, t, n = trainer.diffusion.draw_view_randoms(self._rng, 1, trainer.max_step)
+            self._rand = (pn.clone(), t.clone(), n.clone())     # static: refreshed eagerly before every replay
+            self._view_index = None
         self._pinned = [{k: torch.empty_like(v, device="cpu").pin_memory() for k, v in example_pose.items()} for _ in range(4)]
         self._slot = 0
         opts = trainer.optimizers
@@ -90,12 +103,27 @@ class GraphedTrainStep:
                 o.update_learning_rate(iteration=tr.train_step_index, spatial_scale=scale)
             base += o.prepare_step(self.hyper_host, base)
 
+    def _draw(self):
+        """The step's random draws in the reference's order, from the step's own seed, into the static tensors (eager, before the replay)."""
+        if not self.guided:
+            return
+        tr = self.trainer
+        if self.seed_fn is not None:
+            self._rng.manual_seed(int(self.seed_fn(tr.train_step_index)))
+        pn, t, n = tr.diffusion.draw_view_randoms(self._rng, tr.train_step_index, tr.max_step)
+        self._rand[0].copy_(pn); self._rand[1].copy_(t); self._rand[2].copy_(n)
+
     def _device_body(self):
         """The captured region."""
         tr = self.trainer
         for o in tr.optimizers.values():
             o.zero_grad()
-        loss, render_outputs, _, _ = tr.train_forward(self.data)
+        forced = {}
+        if self.guided:
+            forced = dict(posterior_noise=self._rand[0], timestep=self._rand[1], noise=self._rand[2])
+            if self.condition_fn is not None:
+                self.data["cond_images"] = self.condition_fn(self.pose)
+        loss, render_outputs, _, _ = tr.train_forward(self.data, **forced)
         loss.backward()
         base = 0
         for o in tr.optimizers.values():
@@ -105,6 +133,7 @@ class GraphedTrainStep:
     def _eager_step(self):
         torch.cuda.current_stream(self.device).synchronize()    # set-up path: the pinned table is free to rewrite
         self._host_prepare()
+        self._draw()
         self.hyper_dev.copy_(self.hyper_host, non_blocking=True)
         return self._device_body()
 
@@ -147,6 +176,7 @@ class GraphedTrainStep:
             self._slot_events[i].synchronize()                  # the replay that read this slot four steps ago is done
         self.hyper_host = self._hyper_slots[i]
         self._host_prepare()
+        self._draw()
         slot = self._pinned[i]
         for k, v in pose_cpu.items():
             slot[k].copy_(v)

@@ -55,3 +55,52 @@ def test_graphed_step_matches_the_eager_step_sequence():
     twin.run()
     runner.step()
     assert not runner.graph.check()
+
+
+def test_graphed_guided_step_matches_the_eager_step_sequence():
+    """The FULL step (condition image of the posed body -> animate -> raster -> VAE -> ControlNet + UNet -> backward -> Adam; BASELINE
+    config c3's loop body) as one captured graph, reduced-width f32x plans: the same poses and the same per-step random draws (VAE
+    posterior / timestep / noise from the step's seed, drawn eagerly into the graph's static tensors) as the eager trainer.  Same
+    self-calibrating bar as above (two eager runs differ by the grid-encoder's float atomics under Adam)."""
+    import dwg_import  # noqa: F401
+    from dreamwaltz_g_amd import guidance, sd15, sds_step
+    dev = torch.device("cuda:0")
+    torch.cuda.set_stream(torch.cuda.Stream(device=dev))
+    res, n_steps, warm = 128, 4, 2
+    ucfg = sd15.UNetConfig(block_out_channels=(64, 128, 128, 128), cross_dim=64, cond_channels=(16, 32, 32, 64))
+    vcfg = sd15.VAEConfig(block_out_channels=(32, 64, 64, 64))
+    usd = sd15.random_state_dict(sd15.unet_param_shapes(ucfg), seed=1)
+    csd = sd15.random_state_dict(sd15.controlnet_param_shapes(ucfg), seed=2)
+    vsd = sd15.random_state_dict(sd15.vae_encoder_param_shapes(vcfg), seed=3)
+    gd = guidance.ControlNetScoreDistillation(dev, ucfg, vcfg, usd, csd, vsd, image_hw=res, dtype="f32x")
+
+    def make():
+        return sds_step.SDSStep(n_gaussians=6000, res=res, device=dev, guidance=True, guidance_obj=gd, async_pair_count=True, iters=1000)
+    eagers = []
+    for _ in range(2):
+        e = make()
+        ts = []
+        for _ in range(n_steps + warm + 1):
+            out = e.run()
+            ts.append(int(out[2]["timestep"][0]))
+        eagers.append((e, out[1]["image"].detach().clone(), ts))
+    torch.cuda.synchronize()
+    assert eagers[0][2] == eagers[1][2] and len(set(eagers[0][2])) > 1      # seeded per step: the same timesteps, and not all equal
+    twin = make()
+    runner = twin.graphed(warmup=warm)
+    assert runner.graph.guided and runner.graph.condition_fn is not None
+    ts = []
+    for _ in range(n_steps):
+        loss, outs = runner.step()
+        ts.append(int(runner.graph._rand[1][0]))
+    assert not runner.graph.check()
+    assert ts == eagers[0][2][warm + 1:], (ts, eagers[0][2])               # the replayed steps drew the eager steps' timesteps
+    (e0, img0, _), (e1, img1, _) = eagers
+    assert twin.step_idx == e0.step_idx and twin.trainer.train_step_index == e0.trainer.train_step_index
+    b0, b1, bt = e0.optimizers.buffers, e1.optimizers.buffers, twin.optimizers.buffers
+    d_ee, d_ge = _rel(b1.flat, b0.flat), _rel(bt.flat, b0.flat)
+    i_ee, i_ge = _rel(img1, img0), _rel(outs["image"], img0)
+    print("[parity] guided step_graph: params eager/eager %.3e graph/eager %.3e; image %.3e / %.3e" % (d_ee, d_ge, i_ee, i_ge))
+    assert d_ge <= 3.0 * d_ee + 1e-6, (d_ge, d_ee)
+    assert i_ge <= 3.0 * i_ee + 1e-5, (i_ge, i_ee)
+    gd.set_use_graphs(True)
