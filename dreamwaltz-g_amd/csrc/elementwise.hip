@@ -283,8 +283,10 @@ __global__ __launch_bounds__(64 * MLPC_WAVES) void k_mlp_chain(MlpChainP p, int 
 #pragma unroll
                     for (int e = 0; e < 4; e++) v[e] = mlpc_act(acc[4 * q + e] + sB[n0 + e], p.act[l]);
                     if (!last) {
+                        if (n0 < N) {       // (the padding columns of a width that is not a multiple of 32 would land on valid positions)
 #pragma unroll
-                        for (int e = 0; e < 4; e++) sX[m * MLPC_LD + mlpc_pos(n0 + e, N)] = v[e];      // next layer's input (K = N), in place
+                            for (int e = 0; e < 4; e++) sX[m * MLPC_LD + mlpc_pos(n0 + e, N)] = v[e];  // next layer's input (K = N), in place
+                        }
                         if (p.hidden[l] && grow < p.M && n0 < N)
                             *reinterpret_cast<float4*>(p.hidden[l] + (size_t)grow * N + n0) = make_float4(v[0], v[1], v[2], v[3]);
                     } else if (grow < p.M) {
@@ -295,6 +297,208 @@ __global__ __launch_bounds__(64 * MLPC_WAVES) void k_mlp_chain(MlpChainP p, int 
             }
             __builtin_amdgcn_wave_barrier();
         }
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------------------------
+// Backward of the whole per-Gaussian MLP in ONE launch (+ one reduce): the mirror of k_mlp_chain.  Layer by layer the backward was four
+// launches per layer (activation backward + bias gradient, weight-gradient partials, their reduce, the input-gradient GEMM: 32 launches and
+// ~0.33 ms for the two networks of a 50 k-Gaussian step, each [M, 64] gradient written to HBM and read back twice).  Here a workgroup
+// walks 64-row chunks: the chunk's gradient lives in LDS across all layers (dz_l -> dx -> dz_{l-1} in place), every layer's weights are
+// staged in LDS once per workgroup, the saved activations are read ONCE (the output of layer l-1 is both the input of layer l's weight
+// gradient and the argument of layer l-1's activation derivative) one layer ahead of their use, and the weight gradients of ALL layers
+// stay in registers across the chunks (one 32 x 32 quadrant per wave and layer, exact-f32 MFMA) -- written out once per workgroup and
+// summed by k_mlp_chain_bwd_final in a fixed order (deterministic, no atomics).
+// LDS images: sG [64][68] = dz of the current layer with the columns of every group of eight permuted (mlpb_pos) so that BOTH uses are
+// conflict-free: the weight-gradient MFMA reads a ROW (lanes = columns), the input-gradient MFMA reads four contraction steps of one
+// parity as ONE 16-byte piece per lane (lanes = rows, stride 68 words); sX [64][68] = the layer's input rows, natural order.
+// ---------------------------------------------------------------------------------------------------------------------
+#define MLPB_LD 68
+#define MLPB_PART (4096 + 256)      // floats per (workgroup, layer): the 64 x 64 weight-gradient tile + 4 row-quarter bias partials of 64
+struct MlpChainBwdP {
+    const float* x; int M, Kin, ldx, nlayers;
+    const float* W[MLPC_MAXL]; const float* hidden[MLPC_MAXL];      // hidden[l]: the saved OUTPUT of layer l (l < nlayers - 1)
+    int ldw[MLPC_MAXL], N[MLPC_MAXL], K[MLPC_MAXL], act[MLPC_MAXL];
+    const float* out; int ldo;          // saved output of the last layer: read only when its activation is not the identity
+    const float* dy; int lddy;
+    float* dx; int lddx;                // may be null
+    float* partial;                     // [gridDim.x][nlayers][MLPB_PART]
+};
+__device__ __forceinline__ int mlpb_pos(int n) { return (n & ~7) | ((n & 1) << 2) | ((n >> 1) & 3); }
+
+// 64 rows x 64 columns of a row-major [M, width] tensor -> 16 registers per thread (element idx = tid + 256 i: row idx >> 6, column idx & 63;
+// a wave reads one 256-byte row segment per load), zeros outside the tensor
+__device__ __forceinline__ void mlpb_fetch(float (&v)[16], const float* __restrict__ src, int ld, int width, int r0, int M, int tid) {
+#pragma unroll
+    for (int i = 0; i < 16; i++) {
+        const int idx = tid + 256 * i, r = r0 + (idx >> 6), c = idx & 63;
+        v[i] = (r < M && c < width) ? src[(size_t)r * ld + c] : 0.f;
+    }
+}
+
+__global__ __launch_bounds__(256) void k_mlp_chain_bwd(MlpChainBwdP p) {
+    typedef __attribute__((ext_vector_type(16))) float f32x16_t;
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    float* sWall = smem;                                    // [nlayers][64][MLPB_LD]: W_l[n][k], zero padded
+    float* sG = smem + p.nlayers * 64 * MLPB_LD;
+    float* sX = sG + 64 * MLPB_LD;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int qr = wave >> 1, qc = wave & 1, half = lane >> 5, l31 = lane & 31;
+    for (int l = 0; l < p.nlayers; l++) {
+        const int N = p.N[l], K = p.K[l];
+        for (int i = tid; i < 64 * 64; i += 256) {
+            const int n = i >> 6, k = i & 63;
+            sWall[(l * 64 + n) * MLPB_LD + k] = (n < N && k < K) ? p.W[l][(size_t)n * p.ldw[l] + k] : 0.f;
+        }
+    }
+    f32x16_t accw[MLPC_MAXL];
+    float accb[MLPC_MAXL];
+#pragma unroll
+    for (int l = 0; l < MLPC_MAXL; l++) {
+        accb[l] = 0.f;
+#pragma unroll
+        for (int r = 0; r < 16; r++) accw[l][r] = 0.f;
+    }
+    const int L = p.nlayers - 1;
+    const int nchunks = (p.M + 63) >> 6;
+    for (int chunk = blockIdx.x; chunk < nchunks; chunk += gridDim.x) {
+        const int r0 = chunk * 64;
+        float pf[16];
+        __syncthreads();                                    // the weights are staged / the previous chunk's images are no longer read
+        mlpb_fetch(pf, p.dy, p.lddy, p.N[L], r0, p.M, tid);
+        if (p.act[L] != 0) {
+            float yo[16];
+            mlpb_fetch(yo, p.out, p.ldo, p.N[L], r0, p.M, tid);
+#pragma unroll
+            for (int i = 0; i < 16; i++) pf[i] *= act_grad_from_output(yo[i], p.act[L]);
+        }
+#pragma unroll
+        for (int i = 0; i < 16; i++) { const int idx = tid + 256 * i; sG[(idx >> 6) * MLPB_LD + mlpb_pos(idx & 63)] = pf[i]; }
+        mlpb_fetch(pf, L > 0 ? p.hidden[L - 1] : p.x, L > 0 ? p.N[L - 1] : p.ldx, p.K[L], r0, p.M, tid);
+#pragma unroll
+        for (int i = 0; i < 16; i++) { const int idx = tid + 256 * i; sX[(idx >> 6) * MLPB_LD + (idx & 63)] = pf[i]; }
+        __syncthreads();
+#pragma unroll
+        for (int l = MLPC_MAXL - 1; l >= 0; l--) {
+            if (l > L) continue;
+            const int N = p.N[l], K = p.K[l];
+            // the input rows of layer l - 1, in flight while this layer's products run
+            if (l > 0) mlpb_fetch(pf, l > 1 ? p.hidden[l - 2] : p.x, l > 1 ? p.N[l - 2] : p.ldx, p.K[l - 1], r0, p.M, tid);
+            {   // bias gradient: column tid & 63 over the row quarter tid >> 6
+                const float* g = sG + (wave * 16) * MLPB_LD + mlpb_pos(lane);
+                float s = 0.f;
+#pragma unroll
+                for (int r = 0; r < 16; r++) s += g[r * MLPB_LD];
+                accb[l] += s;
+            }
+            if (qr * 32 < N && qc * 32 < K) {               // dW[n][k] += sum_m dz[m][n] x[m][k], quadrant (qr, qc)
+                const float* pa = sG + half * MLPB_LD + mlpb_pos(qr * 32 + l31);
+                const float* pb = sX + half * MLPB_LD + qc * 32 + l31;
+#pragma unroll 8
+                for (int st = 0; st < 32; st++)
+                    accw[l] = __builtin_amdgcn_mfma_f32_32x32x2f32(pa[st * 2 * MLPB_LD], pb[st * 2 * MLPB_LD], accw[l], 0, 0, 0);
+            }
+            f32x16_t accd;
+#pragma unroll
+            for (int r = 0; r < 16; r++) accd[r] = 0.f;
+            if (qc * 32 < K && (l > 0 || p.dx)) {           // dx[m][k] = sum_n dz[m][n] W[n][k], rows qr, columns qc
+                const float4* pA = reinterpret_cast<const float4*>(sG + (qr * 32 + l31) * MLPB_LD + 4 * half);
+                const float* pB = sWall + (l * 64 + half) * MLPB_LD + qc * 32 + l31;
+                const int nq = (N + 7) >> 3;
+#pragma unroll 2
+                for (int q = 0; q < nq; q++) {
+                    const float4 a = pA[2 * q];
+                    const float* b = pB + 8 * q * MLPB_LD;
+                    accd = __builtin_amdgcn_mfma_f32_32x32x2f32(a.x, b[0], accd, 0, 0, 0);
+                    accd = __builtin_amdgcn_mfma_f32_32x32x2f32(a.y, b[2 * MLPB_LD], accd, 0, 0, 0);
+                    accd = __builtin_amdgcn_mfma_f32_32x32x2f32(a.z, b[4 * MLPB_LD], accd, 0, 0, 0);
+                    accd = __builtin_amdgcn_mfma_f32_32x32x2f32(a.w, b[6 * MLPB_LD], accd, 0, 0, 0);
+                }
+            }
+            if (l > 0) {                                    // dz_{l-1} = dx * act'_{l-1}(output of layer l - 1 = this layer's input)
+                const int act = p.act[l - 1];
+#pragma unroll
+                for (int r = 0; r < 16; r++) {
+                    const int i = qr * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
+                    accd[r] *= act_grad_from_output(sX[i * MLPB_LD + qc * 32 + l31], act);
+                }
+            }
+            __syncthreads();                                // every read of this layer's dz / input image is done
+            if (l > 0) {
+#pragma unroll
+                for (int r = 0; r < 16; r++) {
+                    const int i = qr * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
+                    sG[i * MLPB_LD + mlpb_pos(qc * 32 + l31)] = accd[r];
+                }
+#pragma unroll
+                for (int i = 0; i < 16; i++) { const int idx = tid + 256 * i; sX[(idx >> 6) * MLPB_LD + (idx & 63)] = pf[i]; }
+                __syncthreads();
+            } else if (p.dx) {
+                const int k = qc * 32 + l31;
+#pragma unroll
+                for (int r = 0; r < 16; r++) {
+                    const int m = r0 + qr * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
+                    if (m < p.M && k < K) p.dx[(size_t)m * p.lddx + k] = accd[r];
+                }
+            }
+        }
+    }
+    float* dst = p.partial + (size_t)blockIdx.x * p.nlayers * MLPB_PART;
+#pragma unroll
+    for (int l = 0; l < MLPC_MAXL; l++) {
+        if (l > L) continue;
+        float* d = dst + (size_t)l * MLPB_PART;
+#pragma unroll
+        for (int r = 0; r < 16; r++) {
+            const int n = qr * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
+            d[n * 64 + qc * 32 + l31] = accw[l][r];
+        }
+        d[4096 + wave * 64 + lane] = accb[l];
+    }
+}
+
+struct MlpChainBwdOut {
+    float* dw[MLPC_MAXL]; float* db[MLPC_MAXL]; int lddw[MLPC_MAXL], N[MLPC_MAXL], K[MLPC_MAXL];
+    const float* extra; int n_extra;
+};
+// grid (257, nlayers): blocks 0..255 sum 16 weight-gradient entries each over the workgroups' partial tiles (16 strands, fixed order);
+// block 256 the bias gradients -- and, for the first layer, the columns of the vector folded into its bias (dW[:, K + e] = db * extra[e])
+__global__ __launch_bounds__(256) void k_mlp_chain_bwd_final(int blocks, int nlayers, const float* __restrict__ partial, MlpChainBwdOut o) {
+    __shared__ float part[16][65];
+    const int l = blockIdx.y;
+    const float* src = partial + (size_t)l * MLPB_PART;
+    const size_t stride = (size_t)nlayers * MLPB_PART;
+    const int N = o.N[l], K = o.K[l];
+    if (blockIdx.x < 256) {
+        const int oo = threadIdx.x & 15, strand = threadIdx.x >> 4;
+        const int e = blockIdx.x * 16 + oo;
+        float s = 0.f;
+        for (int b = strand; b < blocks; b += 16) s += src[(size_t)b * stride + e];
+        part[strand][oo] = s;
+        __syncthreads();
+        if (strand == 0) {
+            const int n = e >> 6, k = e & 63;
+            float t = 0.f;
+#pragma unroll
+            for (int q = 0; q < 16; q++) t += part[q][oo];
+            if (n < N && k < K) o.dw[l][(size_t)n * o.lddw[l] + k] = t;
+        }
+        return;
+    }
+    // bias: 4 strands x 64 columns; a strand walks the workgroups, each holding four row-quarter partials
+    const int col = threadIdx.x & 63, strand = threadIdx.x >> 6;
+    float s = 0.f;
+    for (int b = strand; b < blocks; b += 4) {
+        const float* q = src + (size_t)b * stride + 4096 + col;
+        s += (q[0] + q[64]) + (q[128] + q[192]);
+    }
+    part[strand][col] = s;
+    __syncthreads();
+    if (strand == 0 && col < N) {
+        const float t = (part[0][col] + part[1][col]) + (part[2][col] + part[3][col]);
+        if (o.db[l]) o.db[l][col] = t;
+        if (l == 0 && o.extra)
+            for (int e = 0; e < o.n_extra; e++) o.dw[0][(size_t)col * o.lddw[0] + K + e] = t * o.extra[e];
     }
 }
 
@@ -475,9 +679,9 @@ int dwg_mlp_wgrad(int32_t M, int32_t N, int32_t K, const float* dz, int32_t lddz
 int dwg_mlp_chain_forward(int32_t M, int32_t Kin, const float* x, int32_t ldx, int32_t nlayers, const float* const* weights,
                           const int32_t* ldw, const float* const* biases, const int32_t* widths, const int32_t* acts,
                           float* const* hidden, float* out, int32_t ldo, dwg_stream_t stream) {
-    if (M < 0 || nlayers < 1 || nlayers > MLPC_MAXL || Kin < 8 || Kin > 64 || (Kin & 7) || !x || !weights || !ldw || !widths || !acts || !out)
-        return DWG_E_ARG;
-    if (M == 0) return DWG_OK;
+    if (M < 0 || nlayers < 1 || nlayers > MLPC_MAXL || Kin < 8 || Kin > 64 || (Kin & 7) || !weights || !ldw || !widths || !acts) return DWG_E_ARG;
+    if (M == 0) return DWG_OK;          // an empty batch has no rows to read or write (x / out may be the null pointer of an empty tensor)
+    if (!x || !out) return DWG_E_ARG;
     MlpChainP p;
     p.x = x; p.M = M; p.Kin = Kin; p.ldx = ldx; p.nlayers = nlayers; p.out = out; p.ldo = ldo;
     int k = Kin;
@@ -501,6 +705,56 @@ int dwg_mlp_chain_forward(int32_t M, int32_t Kin, const float* x, int32_t ldx, i
     }
     const int wgs = dwg_cdiv(dwg_cdiv(M, 32), MLPC_WAVES);
     DWG_LAUNCH("mlp_chain_fwd", k_mlp_chain, dim3(wgs < 256 ? wgs : 256), dim3(64 * MLPC_WAVES), lds, (hipStream_t)stream, p, wfloats);    // persistent
+    DWG_RETURN_IF_LAUNCH_FAILED();
+    return DWG_OK;
+}
+
+static int mlp_chain_bwd_blocks(int32_t M) {
+    const int chunks = dwg_cdiv(M > 0 ? M : 1, 64);
+    return chunks < 256 ? chunks : 256;
+}
+
+size_t dwg_mlp_chain_backward_workspace_floats(int32_t M, int32_t nlayers) {
+    return (size_t)mlp_chain_bwd_blocks(M) * (size_t)(nlayers > 0 ? nlayers : 1) * MLPB_PART;
+}
+
+int dwg_mlp_chain_backward(int32_t M, int32_t Kin, const float* x, int32_t ldx, int32_t nlayers, const float* const* weights,
+                           const int32_t* ldw, const int32_t* widths, const int32_t* acts, const float* const* hidden, const float* out,
+                           int32_t ldo, const float* dy, int32_t lddy, float* dx, int32_t lddx, float* const* dw, const int32_t* lddw,
+                           float* const* db, const float* extra, int32_t n_extra, float* workspace, dwg_stream_t stream) {
+    if (M < 0 || nlayers < 1 || nlayers > MLPC_MAXL || Kin < 8 || Kin > 64 || (Kin & 7) || !x || !weights || !ldw || !widths || !acts || !dy ||
+        !dw || !lddw || !workspace || n_extra < 0 || (n_extra > 0 && !extra))
+        return DWG_E_ARG;
+    if (nlayers > 1 && !hidden) return DWG_E_ARG;
+    MlpChainBwdP p;
+    MlpChainBwdOut o;
+    p.x = x; p.M = M; p.Kin = Kin; p.ldx = ldx; p.nlayers = nlayers; p.out = out; p.ldo = ldo; p.dy = dy; p.lddy = lddy; p.dx = dx; p.lddx = lddx;
+    p.partial = workspace;
+    o.extra = n_extra > 0 ? extra : nullptr; o.n_extra = n_extra;
+    int k = Kin;
+    for (int l = 0; l < MLPC_MAXL; l++) {
+        const bool on = l < nlayers;
+        if (on && (widths[l] < 1 || widths[l] > 64 || !weights[l] || ldw[l] < k || !dw[l] || lddw[l] < k + (l == 0 ? n_extra : 0))) return DWG_E_ARG;
+        if (on && l + 1 < nlayers && ((widths[l] & 7) || !hidden[l])) return DWG_E_ARG;
+        if (on && acts[l] != 0 && acts[l] != 1 && acts[l] != 2 && acts[l] != 5) return DWG_E_ARG;
+        p.W[l] = on ? weights[l] : nullptr; p.hidden[l] = (on && l + 1 < nlayers) ? hidden[l] : nullptr;
+        p.ldw[l] = on ? ldw[l] : 0; p.N[l] = on ? widths[l] : 0; p.K[l] = on ? k : 0; p.act[l] = on ? acts[l] : 0;
+        o.dw[l] = on ? dw[l] : nullptr; o.db[l] = (on && db) ? db[l] : nullptr; o.lddw[l] = on ? lddw[l] : 0; o.N[l] = p.N[l]; o.K[l] = p.K[l];
+        if (on) k = widths[l];
+    }
+    if (acts[nlayers - 1] != 0 && !out) return DWG_E_ARG;
+    if (dx && lddx < Kin) return DWG_E_ARG;
+    if (M == 0) return DWG_OK;      // the caller zero-fills the gradients of an empty batch
+    const size_t lds = (size_t)(nlayers + 2) * 64 * MLPB_LD * sizeof(float);           // <= 139 KiB: one workgroup per CU
+    static bool attr_set = false;
+    if (!attr_set) {
+        hipFuncSetAttribute(reinterpret_cast<const void*>(&k_mlp_chain_bwd), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        attr_set = true;
+    }
+    const int blocks = mlp_chain_bwd_blocks(M);
+    DWG_LAUNCH("mlp_chain_bwd", k_mlp_chain_bwd, dim3(blocks), dim3(256), lds, (hipStream_t)stream, p);
+    DWG_LAUNCH("mlp_chain_bwd_final", k_mlp_chain_bwd_final, dim3(257, nlayers), dim3(256), 0, (hipStream_t)stream, blocks, nlayers,
+               (const float*)workspace, o);
     DWG_RETURN_IF_LAUNCH_FAILED();
     return DWG_OK;
 }

@@ -314,12 +314,12 @@ __device__ __forceinline__ uint32_t gs_wg_chunks(uint32_t nchunks) { return (nch
 template <bool SCATTER>
 __global__ __launch_bounds__(256) void k_gs_bin(GridP p, uint32_t nchunks, uint32_t nslab, uint32_t first_entry, const float* __restrict__ grad,
                                                 const float* __restrict__ x, const int* __restrict__ offsets, uint32_t first_table_level,
-                                                uint32_t* __restrict__ counts /*[GS_NWG][nslab]: counts, then prefixes*/,
+                                                uint32_t* __restrict__ counts /*[nslab][GS_NWG]: counts, then prefixes*/,
                                                 const uint32_t* __restrict__ slab_start, uint4* __restrict__ records,
                                                 const float* __restrict__ dy_dx, float* __restrict__ grad_x) {
     extern __shared__ uint32_t cur[];       // [nslab]
     const uint32_t wg = blockIdx.x;
-    for (uint32_t s_ = threadIdx.x; s_ < nslab; s_ += 256) cur[s_] = SCATTER ? slab_start[s_] + counts[(size_t)wg * nslab + s_] : 0u;
+    for (uint32_t s_ = threadIdx.x; s_ < nslab; s_ += 256) cur[s_] = SCATTER ? slab_start[s_] + counts[(size_t)s_ * GS_NWG + wg] : 0u;
     __syncthreads();
     const uint32_t cpw = gs_wg_chunks(nchunks);
     const uint32_t c0 = wg * cpw, c1 = min(nchunks, c0 + cpw);
@@ -372,12 +372,33 @@ __global__ __launch_bounds__(256) void k_gs_bin(GridP p, uint32_t nchunks, uint3
     }
     if (!SCATTER) {
         __syncthreads();
-        for (uint32_t s_ = threadIdx.x; s_ < nslab; s_ += 256) counts[(size_t)wg * nslab + s_] = cur[s_];
+        for (uint32_t s_ = threadIdx.x; s_ < nslab; s_ += 256) counts[(size_t)s_ * GS_NWG + wg] = cur[s_];
     }
 }
 
-// pass 2 (one workgroup): per slab the exclusive prefix over the workgroups' counts (in place), the slab's start, and the work units
-__global__ __launch_bounds__(1024) void k_gs_scan(uint32_t nslab, uint32_t* __restrict__ counts, uint32_t* __restrict__ slab_start /*[nslab+1]*/,
+// pass 2a (one WAVE per slab): the exclusive prefix over the GS_NWG workgroups' counts of a slab (in place; the slab's 256 counts are one
+// contiguous KiB: four per lane, one wave scan) and the slab's total.  Round 4: this and pass 2b were ONE workgroup walking all
+// GS_NWG x nslab counts with 16 loads in flight per thread -- 50 us of dependent latency at 1500 slabs.
+__global__ __launch_bounds__(256) void k_gs_scan_slab(uint32_t nslab, uint32_t* __restrict__ counts, uint32_t* __restrict__ slab_total) {
+    static_assert(GS_NWG == 256u, "four counts per lane of one wave");
+    const uint32_t s_ = blockIdx.x * 4u + (threadIdx.x >> 6), lane = threadIdx.x & 63u;
+    if (s_ >= nslab) return;
+    uint4* row = reinterpret_cast<uint4*>(counts + (size_t)s_ * GS_NWG) + lane;
+    const uint4 c = *row;
+    const uint32_t mine = c.x + c.y + c.z + c.w;
+    uint32_t inc = mine;
+#pragma unroll
+    for (int off = 1; off < 64; off <<= 1) {
+        const uint32_t v = __shfl_up(inc, off);
+        if ((int)lane >= off) inc += v;
+    }
+    const uint32_t ex = inc - mine;
+    *row = make_uint4(ex, ex + c.x, ex + c.x + c.y, ex + c.x + c.y + c.z);
+    if (lane == 63u) slab_total[s_] = inc;
+}
+
+// pass 2b (one workgroup): the slabs' starts and the work units from the slab totals
+__global__ __launch_bounds__(1024) void k_gs_scan(uint32_t nslab, const uint32_t* __restrict__ slab_total, uint32_t* __restrict__ slab_start /*[nslab+1]*/,
                                                   GsUnit* __restrict__ units, uint32_t* __restrict__ n_units) {
     __shared__ uint32_t tot[1024], ucnt[1024];
     __shared__ uint32_t carry_t, carry_u;
@@ -386,16 +407,7 @@ __global__ __launch_bounds__(1024) void k_gs_scan(uint32_t nslab, uint32_t* __re
     __syncthreads();
     for (uint32_t base = 0; base < nslab; base += 1024u) {
         const uint32_t s_ = base + tid;
-        uint32_t run = 0;
-        if (s_ < nslab) {
-            for (uint32_t w0 = 0; w0 < GS_NWG; w0 += 16u) {     // 16 independent loads in flight, then their prefixes
-                uint32_t c[16];
-#pragma unroll
-                for (int i = 0; i < 16; i++) c[i] = counts[(size_t)(w0 + i) * nslab + s_];
-#pragma unroll
-                for (int i = 0; i < 16; i++) { counts[(size_t)(w0 + i) * nslab + s_] = run; run += c[i]; }
-            }
-        }
+        const uint32_t run = s_ < nslab ? slab_total[s_] : 0u;
         const uint32_t nu = s_ < nslab ? (run > GS_MAXREC ? (run + GS_MAXREC - 1u) / GS_MAXREC : 1u) : 0u;
         tot[tid] = run; ucnt[tid] = nu;
         __syncthreads();
@@ -597,7 +609,7 @@ size_t dwg_grid_backward_slabs_workspace_bytes(uint32_t B, uint32_t L, uint32_t 
     const size_t nslab = (total_entries + GS_SLAB - 1u) / GS_SLAB;
     const size_t recs = (size_t)B * L * 8;
     const size_t max_units = nslab + recs / GS_MAXREC + 2;
-    return dwg_align_up(recs * sizeof(uint4), 256) + dwg_align_up((size_t)GS_NWG * nslab * 4, 256) + dwg_align_up((nslab + 1) * 4, 256) +
+    return dwg_align_up(recs * sizeof(uint4), 256) + dwg_align_up((size_t)GS_NWG * nslab * 4, 256) + 2 * dwg_align_up((nslab + 1) * 4, 256) +
            dwg_align_up(max_units * sizeof(GsUnit), 256) + 256;
 }
 
@@ -654,6 +666,7 @@ static int grid_backward_slabs(const float* grad, const float* inputs, const flo
     uint4* records = reinterpret_cast<uint4*>(w); w += dwg_align_up(recs * sizeof(uint4), 256);
     uint32_t* counts = reinterpret_cast<uint32_t*>(w); w += dwg_align_up((size_t)GS_NWG * ((total_entries + GS_SLAB - 1u) / GS_SLAB) * 4, 256);
     uint32_t* slab_start = reinterpret_cast<uint32_t*>(w); w += dwg_align_up(((size_t)(total_entries + GS_SLAB - 1u) / GS_SLAB + 1) * 4, 256);
+    uint32_t* slab_total = reinterpret_cast<uint32_t*>(w); w += dwg_align_up(((size_t)(total_entries + GS_SLAB - 1u) / GS_SLAB + 1) * 4, 256);
     GsUnit* units = reinterpret_cast<GsUnit*>(w); w += dwg_align_up(((size_t)(total_entries + GS_SLAB - 1u) / GS_SLAB + recs / GS_MAXREC + 2) * sizeof(GsUnit), 256);
     uint32_t* n_units = reinterpret_cast<uint32_t*>(w);
     static bool attr2 = false;
@@ -663,7 +676,8 @@ static int grid_backward_slabs(const float* grad, const float* inputs, const flo
     }
     DWG_LAUNCH("grid_bwd_count", (k_gs_bin<false>), dim3(GS_NWG), dim3(256), (size_t)nslab * 4, st, p, nchunks, nslab, first_entry, grad, inputs,
                offsets, first_table_level, counts, (const uint32_t*)slab_start, records, dy_dx, grad_inputs);
-    DWG_LAUNCH("grid_bwd_scan", k_gs_scan, dim3(1), dim3(1024), 0, st, nslab, counts, slab_start, units, n_units);
+    DWG_LAUNCH("grid_bwd_scan", k_gs_scan_slab, dim3((nslab + 3u) / 4u), dim3(256), 0, st, nslab, counts, slab_total);
+    DWG_LAUNCH("grid_bwd_scan", k_gs_scan, dim3(1), dim3(1024), 0, st, nslab, (const uint32_t*)slab_total, slab_start, units, n_units);
     DWG_LAUNCH("grid_bwd_scatter", (k_gs_bin<true>), dim3(GS_NWG), dim3(256), (size_t)nslab * 4, st, p, nchunks, nslab, first_entry, grad, inputs,
                offsets, first_table_level, counts, (const uint32_t*)slab_start, records, dy_dx, grad_inputs);
     DWG_LAUNCH("grid_bwd", k_gs_accumulate, dim3((unsigned)max_units), dim3(256), (size_t)GS_SLAB * 8, st, first_entry, total_entries,

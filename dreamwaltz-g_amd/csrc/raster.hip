@@ -56,7 +56,13 @@ struct Params {
 };
 
 // header words of the geometry workspace
-enum { H_K = 0, H_OVERFLOW = 1, H_KREF = 2, H_NSEG = 3, H_CLASS0 = 4 /* .. +NCLASS */ };
+enum { H_K = 0, H_OVERFLOW = 1, H_KREF = 2, H_NSEG = 3, H_CLASS0 = 4 /* .. +NCLASS */, H_TAG = 4 + NCLASS };
+
+// Frame tags of the backward's pair-ordered partial rows (k_render_bwd / k_gather_partials) are drawn ON THE DEVICE, by the forward's scan
+// kernel, from this counter: a tag chosen by the host at launch time is a kernel argument, and kernel arguments are frozen into a captured
+// graph -- every replay of a captured step would then carry the SAME tag and rows left over from the previous replay would pass for this
+// frame's (step_graph.py / player.py replay the launches, not the host code around them).
+__device__ uint32_t g_frame_tag = 0x5eed0001u;
 
 struct GeomLayout {
     size_t header, rec0, rec1, rec2, rect, npairs, goff, tile_count, tile_cursor, idsum, tile_start, seg_start, tile_neff, order, cls, total;
@@ -485,6 +491,7 @@ __global__ __launch_bounds__(1024) void k_scan_tiles(int T, const uint32_t* __re
     if (tid == 1023) {
         tile_start[T] = part[1023]; seg_start[T] = parts[1023];
         header[H_K] = (int32_t)part[1023]; header[H_OVERFLOW] = 0; header[H_NSEG] = (int32_t)parts[1023];
+        header[H_TAG] = (int32_t)(atomicAdd(&g_frame_tag, 0x9e3779b1u) | 1u);      // this frame's tag (odd: never the zero of a fresh buffer)
     }
     __syncthreads();
     if (tid == 0) {
@@ -868,6 +875,7 @@ __global__ __launch_bounds__(64) void k_render_bwd(Params p, const int32_t* __re
     __shared__ float gpx[4][64];
     const int64_t seg = blockIdx.x;
     if (seg >= (int64_t)header[H_NSEG] || seg >= cap_segs || header[H_OVERFLOW]) return;    // a truncated frame is redone by the caller
+    tag = (uint32_t)header[H_TAG];                             // the frame's tag (the argument is unused: see g_frame_tag)
     const int tile = (int)seg_tile[seg];
     if ((unsigned)tile >= (unsigned)(p.tiles_x * p.tiles_y)) return;
     const int sidx = (int)(seg - (int64_t)seg_start[tile]);
@@ -1005,6 +1013,7 @@ __global__ __launch_bounds__(256) void k_gather_partials(int G, const uint32_t* 
                                                          const int32_t* __restrict__ header, uint32_t tag, float* __restrict__ gacc) {
     const int i = blockIdx.x * 64 + (threadIdx.x >> 2), h = threadIdx.x & 3, lane = threadIdx.x & 63;
     const bool ok = !header[H_OVERFLOW];                       // a truncated frame is redone by the caller: zeros
+    tag = (uint32_t)header[H_TAG];
     const int64_t capc = cap > 0 ? cap : 0;
     int64_t q0 = 0, q1 = 0;
     if (i < G && ok) { q0 = min((int64_t)goff[i], capc); q1 = min((int64_t)goff[i + 1], capc); }
@@ -1428,8 +1437,8 @@ int dwg_raster_backward(const dwg_raster_settings* cfg, int32_t G, const float* 
     const char* ws = (const char*)ws_geom; const char* wp = (const char*)ws_pairs; const char* wi = (const char*)ws_image;
     // per-pair partials in pair-row order (no atomics), then each Gaussian's contiguous rows summed into ws_grad [G][GSTRIDE]
     // a fresh tag per backward: rows of the pair-ordered partials count only if this frame wrote them (no clearing of the buffer)
-    static std::atomic<uint32_t> frame_tag{0x5eed0001u};
-    const uint32_t tag = frame_tag.fetch_add(0x9e3779b1u) | 1u;
+    // (the tag itself is header[H_TAG], drawn on the device by the forward's scan kernel: see g_frame_tag)
+    const uint32_t tag = 0u;
 #define DWG_BWD_ARGS p, (const int32_t*)(ws + L.header), cap_segs, (const uint32_t*)(wp + PL.seg_tile), (const uint32_t*)(ws + L.seg_start),   \
         (const uint32_t*)(ws + L.tile_start), (const uint32_t*)(ws + L.tile_neff), (const uint32_t*)(wp + PL.sorted),                               \
         (const uint2*)(ws + L.rect), (const uint32_t*)(ws + L.goff), tag, (const float4*)(ws + L.rec0), (const float4*)(ws + L.rec1),           \

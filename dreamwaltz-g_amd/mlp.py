@@ -8,11 +8,16 @@ Class / parameter names mirror the reference so its state_dicts load unchanged:
 """
 import ctypes
 import math
+import os
 
 import torch
 import torch.nn as nn
 
 from . import _lib, gemm
+
+
+# DWG_MLP_BWD_PER_LAYER=1: the layer-by-layer backward of a chain (four launches per layer) instead of the fused kernel -- experiments only
+PER_LAYER_BACKWARD = os.environ.get("DWG_MLP_BWD_PER_LAYER", "0") == "1"
 
 
 def _st(t):
@@ -129,6 +134,34 @@ class _MlpChain(torch.autograd.Function):
         ws, hidden = list(saved[2:2 + nl]), list(saved[2 + nl:2 + nl + nl - 1])
         extra = saved[-1] if ctx.has_extra else None
         grads = [None] * (2 * nl)
+        if not PER_LAYER_BACKWARD:
+            # the whole chain in one launch + one reduce (csrc/elementwise.hip k_mlp_chain_bwd, include/dwg_elementwise.h dwg_mlp_chain_backward)
+            L = _lib.lib()
+            M, Kx = x.shape
+            dev = x.device
+            dy = dy.contiguous().float()
+            need_dx = ctx.needs_input_grad[0]
+            dx = torch.empty_like(x) if need_dx else None
+            if M == 0:
+                for l, w in enumerate(ws):
+                    grads[2 * l] = torch.zeros_like(w)
+                    grads[2 * l + 1] = torch.zeros(w.shape[0], device=dev) if ctx.has_b[l] else None
+                return (dx, None, None) + tuple(grads)
+            dws = [torch.empty_like(w) for w in ws]
+            dbs = torch.empty(nl, 64, device=dev)
+            e = extra.reshape(-1).contiguous().float() if extra is not None else None
+            wsp = torch.empty(L.dwg_mlp_chain_backward_workspace_floats(M, nl), device=dev, dtype=torch.float32)
+            vp, i32 = ctypes.c_void_p * nl, ctypes.c_int32 * nl
+            _lib.check(L.dwg_mlp_chain_backward(
+                M, Kx, _lib.ptr(x), Kx, nl, vp(*[w.data_ptr() for w in ws]), i32(*[int(w.stride(0)) for w in ws]),
+                i32(*[int(w.shape[0]) for w in ws]), i32(*[gemm.ACT[a] for a in ctx.acts]), vp(*[h.data_ptr() for h in hidden] + [None]),
+                _lib.ptr(out), int(out.shape[1]), _lib.ptr(dy), int(dy.shape[1]), _lib.ptr(dx) if need_dx else None, Kx,
+                vp(*[d.data_ptr() for d in dws]), i32(*[int(d.stride(0)) for d in dws]), vp(*[dbs[l].data_ptr() for l in range(nl)]),
+                _lib.ptr(e) if e is not None else None, int(e.numel()) if e is not None else 0, _lib.ptr(wsp), _st(x)), "dwg_mlp_chain_backward")
+            for l, w in enumerate(ws):
+                grads[2 * l] = dws[l]
+                grads[2 * l + 1] = dbs[l, :w.shape[0]] if ctx.has_b[l] else None
+            return (dx, None, None) + tuple(grads)
         g = dy
         # one zero fill for every layer's bias-gradient accumulator and weight-gradient tile (16 fills per step before)
         sizes = [(int(w.shape[0]), int(w.numel())) for w in ws]

@@ -48,6 +48,7 @@ class PairCapacity:
         self.pending = False
         self.overflow = False
         self.frozen = False              # True: fixed capacity, no events, no host waits (a frame captured into a graph, see player.py)
+        self.truncated, self.truncated_host = None, None      # frozen states: device count of truncated frames + its pinned mirror
         self.seq = 0                     # frames rendered through this state; `pending_seq` = the frame whose count is in flight
         self.pending_seq = 0
         self.overflow_seqs = set()       # EVERY recent frame that was truncated (several may be in flight through one state before their
@@ -169,6 +170,14 @@ class _RasterizeGaussians(torch.autograd.Function):
             if pair_state.host is None:
                 pair_state.host = torch.zeros(4, dtype=torch.int32).pin_memory()
             pair_state.host.copy_(ws_geom[:16].view(torch.int32), non_blocking=True)
+            if pair_state.frozen:
+                # frames of a captured graph: nobody waits per frame, so truncations are COUNTED on the device and the count is what the
+                # owner's check() reads (the per-frame words above only describe the last frame)
+                if pair_state.truncated is None:
+                    pair_state.truncated = torch.zeros(1, dtype=torch.int32, device=device)
+                    pair_state.truncated_host = torch.zeros(1, dtype=torch.int32).pin_memory()
+                pair_state.truncated.add_(ws_geom[:16].view(torch.int32)[1:2])
+                pair_state.truncated_host.copy_(pair_state.truncated, non_blocking=True)
             pair_state.seq += 1
             if not pair_state.frozen:
                 ev = torch.cuda.Event(); ev.record(torch.cuda.current_stream(device))

@@ -24,7 +24,7 @@ from .rasterizer import PairCapacity
 
 
 class GraphedTrainStep:
-    def __init__(self, trainer, data: dict, example_pose: Dict[str, torch.Tensor], warmup_poses=None, grow: float = 1.5, capture_pose=None,
+    def __init__(self, trainer, data: dict, example_pose: Dict[str, torch.Tensor], warmup_poses=None, grow: float = 4.0, capture_pose=None,
                  condition_fn=None, seed_fn=None):
         """`trainer`: an SDSTrainer whose `diffusion` makes no host round trips and draws no random numbers (the no-guidance image loss of
         c2); `data`: the loader's dict of the (fixed) camera WITHOUT 'smpl_inputs'; `example_pose`: device tensors, cloned into the graph's
@@ -191,9 +191,12 @@ class GraphedTrainStep:
         """True if a step since the last call was truncated by the frozen pair capacity (one stream synchronisation)."""
         torch.cuda.current_stream(self.device).synchronize()
         st = self._state
-        ovf = bool(st.host is not None and int(st.host[1]) != 0)
+        ovf = bool(st.truncated_host is not None and int(st.truncated_host[0]) != 0)      # counted on the device over every replay
         if st.host is not None:
             st.last_num_pairs, st.last_num_pairs_ref = int(st.host[0]), int(st.host[2])
+        if ovf:
+            st.truncated.zero_()
+            st.truncated_host.zero_()
         return ovf
 
     def recapture(self, grow: float = 2.0):

@@ -37,6 +37,19 @@ int dwg_mlp_chain_forward(int32_t M, int32_t Kin, const float* x, int32_t ldx, i
                           const int32_t* ldw, const float* const* biases, const int32_t* widths, const int32_t* acts,
                           float* const* hidden, float* out, int32_t ldo, dwg_stream_t stream);
 
+/* The backward of dwg_mlp_chain_forward in one launch + one reduce (nerf_model.py:28-33 / deform_model.py:111-143 under autograd): given
+ * dy [M, widths[last]] (row stride lddy), the input x, the kept hidden activations (hidden[l] [M, widths[l]] contiguous, l < nlayers - 1)
+ * and, when the last activation is not the identity, the output `out`: dx [M, Kin] (row stride lddx; NULL = not wanted), per layer
+ * dw[l] [widths[l], >= K_l] with row stride lddw[l] (columns 0..K_l-1 written) and db[l] [widths[l]] (db or entries may be NULL).
+ * `extra` [n_extra] (device; NULL / 0 = none): the vector the caller folded into the first layer's bias through the trailing columns of
+ * W_0 -- their gradient dw[0][:, Kin + e] = db_0 * extra[e] is written too.  Deterministic (fixed summation order, no atomics).
+ * workspace: dwg_mlp_chain_backward_workspace_floats(M, nlayers) floats.  Array arguments are HOST arrays of length nlayers (<= 6). */
+size_t dwg_mlp_chain_backward_workspace_floats(int32_t M, int32_t nlayers);
+int dwg_mlp_chain_backward(int32_t M, int32_t Kin, const float* x, int32_t ldx, int32_t nlayers, const float* const* weights,
+                           const int32_t* ldw, const int32_t* widths, const int32_t* acts, const float* const* hidden, const float* out,
+                           int32_t ldo, const float* dy, int32_t lddy, float* dx, int32_t lddx, float* const* dw, const int32_t* lddw,
+                           float* const* db, const float* extra, int32_t n_extra, float* workspace, dwg_stream_t stream);
+
 /* torch.optim.Adam update (amsgrad=False, weight_decay=0) on n contiguous floats, step >= 1 is the 1-based step count;
  * grad is multiplied by grad_scale first (1/world_size after a sum all-reduce).  Buffers must be 16-byte aligned. */
 int dwg_adam_step(int64_t n, float* param, const float* grad, float* exp_avg, float* exp_avg_sq, float lr, float beta1,

@@ -187,3 +187,59 @@ def test_backward_is_bit_reproducible(G, H, W, kw):
     for k in runs[0]:
         assert float(runs[0][k].abs().sum()) > 0, k
         assert torch.equal(runs[0][k], runs[1][k]) and torch.equal(runs[0][k], runs[2][k]), k
+
+
+def test_captured_backward_replays_do_not_see_the_previous_frames_rows():
+    """Round 4 regression: the backward's pair-ordered partial rows are validated by a per-frame TAG.  The tag used to be a kernel argument
+    chosen by the host at launch -- frozen into a captured graph, so that every replay carried the same tag and rows left over from the
+    previous replay (pairs this frame's walk never reaches) passed for this frame's.  It is drawn on the device now (raster.hip
+    g_frame_tag).  One forward + backward is captured with a frozen pair capacity and replayed on three different scenes; each replay's
+    gradients must equal the eager backward of the same scene BIT FOR BIT (the backward is deterministic)."""
+    from dreamwaltz_g_amd.rasterizer import GaussianRasterizationSettings, GaussianRasterizer, PairCapacity
+    G, H, W = 6000, 128, 128
+    dev = torch.device("cuda")
+    scenes = [rc.make_scene(G, H, W, seed=s, **kw) for s, kw in ((11, dict(scale_mul=4.0)), (12, dict(cluster=0.05, opacity_range=(0.3, 0.9))),
+                                                                 (13, dict(scale_mul=2.0, opacity_range=(0.5, 1.0))))]
+    wc = torch.from_numpy(np.random.RandomState(1).randn(3, H, W).astype(np.float32)).to(dev)
+    names = ("means3D", "opacities", "colors", "scales", "rotations")
+    eager = []
+    for sc in scenes:
+        out = rc.hip_render(sc, requires_grad=True)
+        (out["color"] * wc).sum().backward()
+        eager.append({k: out["leaves"][k].grad.detach().clone() for k in names})
+    side = torch.cuda.Stream(device=dev)
+    side.wait_stream(torch.cuda.current_stream(dev))
+    with torch.cuda.stream(side):
+        t0 = {k: (v.to(dev) if torch.is_tensor(v) else v) for k, v in scenes[0].items()}
+        rs = GaussianRasterizationSettings(image_height=H, image_width=W, tanfovx=t0["tanfovx"], tanfovy=t0["tanfovy"], bg=t0["bg"], scale_modifier=1.0,
+                                           viewmatrix=t0["viewmatrix"], projmatrix=t0["projmatrix"], sh_degree=0, campos=t0["campos"],
+                                           prefiltered=False, debug=False)
+        state = PairCapacity()
+        state.cap, state.frozen = 4 << 20, True
+        rast = GaussianRasterizer(rs, pair_state=state)
+        leaves = {k: t0[k].clone().requires_grad_(True) for k in names}
+        m2d = torch.zeros_like(leaves["means3D"], requires_grad=True)
+        grads = {k: torch.zeros_like(v) for k, v in leaves.items()}
+
+        def body():
+            color, radii, depth, alpha = rast(means3D=leaves["means3D"], means2D=m2d, opacities=leaves["opacities"], shs=None,
+                                              colors_precomp=leaves["colors"], scales=leaves["scales"], rotations=leaves["rotations"], cov3D_precomp=None)
+            gs = torch.autograd.grad((color * wc).sum(), [leaves[k] for k in names])
+            for k, g_ in zip(names, gs):
+                grads[k].copy_(g_)
+        for _ in range(2):
+            body()
+        side.synchronize()
+        graph = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(graph, stream=side):
+            body()
+        for rnd in range(2):
+            for i in (0, 1, 2, 1, 0):
+                with torch.no_grad():
+                    for k in names:
+                        leaves[k].copy_(scenes[i][k].to(dev))
+                graph.replay()
+                side.synchronize()
+                assert int(state.truncated_host[0]) == 0
+                for k in names:
+                    assert torch.equal(grads[k], eager[i][k]), (rnd, i, k, float((grads[k] - eager[i][k]).abs().max()))

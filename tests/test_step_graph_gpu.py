@@ -6,6 +6,14 @@ import torch
 pytestmark = pytest.mark.gpu
 
 
+# Two EAGER runs of the same steps differ by 1.7e-5 ... 1.2e-4 (relative L2 of the flat parameter buffer after 7-10 Adam steps; five boxes,
+# round 4): a handful of near-zero table gradients change sign with the order of the grid encoder's float adds and Adam (eps 1e-15) moves
+# those entries by 2 lr -- discrete events, so the pairwise distance is heavy-tailed.  A graphed run must stay within 3x the distance of
+# THIS run's eager pair or within the top of that range; the bugs this test has caught (a stale pose: 2.3 %, a rewritten pinned
+# scalar table: 1.3 %) sit two orders of magnitude above it.
+NOISE_FLOOR = 3.0e-4
+
+
 def _rel(a, b):
     return float((a.double() - b.double()).norm() / b.double().norm().clamp_min(1e-30))
 
@@ -42,7 +50,7 @@ def test_graphed_step_matches_the_eager_step_sequence():
     d_ee, d_ge = _rel(b1.flat, b0.flat), _rel(bt.flat, b0.flat)
     i_ee, i_ge = _rel(img1, img0), _rel(outs["image"], img0)
     print("[parity] step_graph: params eager/eager %.3e graph/eager %.3e; image %.3e / %.3e" % (d_ee, d_ge, i_ee, i_ge))
-    assert d_ge <= 3.0 * d_ee + 1e-6, (d_ge, d_ee)
+    assert d_ge <= max(3.0 * d_ee, NOISE_FLOOR), (d_ge, d_ee)
     assert i_ge <= 3.0 * i_ee + 1e-5, (i_ge, i_ee)
     # what does not depend on the atomics' order: the positions (lr 1.6e-4) and every optimizer's schedule state
     pe, pt = e0.avatar._positions.detach(), twin.avatar._positions.detach()
@@ -101,6 +109,6 @@ def test_graphed_guided_step_matches_the_eager_step_sequence():
     d_ee, d_ge = _rel(b1.flat, b0.flat), _rel(bt.flat, b0.flat)
     i_ee, i_ge = _rel(img1, img0), _rel(outs["image"], img0)
     print("[parity] guided step_graph: params eager/eager %.3e graph/eager %.3e; image %.3e / %.3e" % (d_ee, d_ge, i_ee, i_ge))
-    assert d_ge <= 3.0 * d_ee + 1e-6, (d_ge, d_ee)
+    assert d_ge <= max(3.0 * d_ee, NOISE_FLOOR), (d_ge, d_ee)
     assert i_ge <= 3.0 * i_ee + 1e-5, (i_ge, i_ee)
     gd.set_use_graphs(True)
