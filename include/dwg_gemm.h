@@ -25,7 +25,7 @@
 extern "C" {
 #endif
 
-/* DWG_DTYPE_F32 / DWG_DTYPE_BF16: dwg_types.h */
+/* DWG_DTYPE_F32 / _BF16 / _F16 / _F32X: dwg_types.h */
 
 #define DWG_ACT_NONE 0
 #define DWG_ACT_RELU 1
@@ -45,7 +45,10 @@ typedef struct dwg_gemm_desc {
     int32_t batch1, batch2;
     int64_t a_batch1_stride, a_batch2_stride, b_batch1_stride, b_batch2_stride, c_batch1_stride, c_batch2_stride,
         r_batch1_stride, r_batch2_stride;
-    int32_t dtype;            /* DWG_DTYPE_F32 | DWG_DTYPE_BF16 | DWG_DTYPE_F16 of A and B (F16: the fp16-operand unit, csrc/gemm_f16.hip) */
+    int32_t dtype;            /* DWG_DTYPE_F32 | DWG_DTYPE_BF16 | DWG_DTYPE_F16 | DWG_DTYPE_F32X of A and B (F16: the fp16-operand unit,
+                                 csrc/gemm_f16.hip; F32X: split-precision fp32 operands -- csrc/dwg_xfmt.h, csrc/gemm_x.hip: M, N, K, strides and
+                                 conv_cin count LOGICAL elements, every 8 of them 32 bytes; operands must be K-contiguous (k stride 1) with
+                                 K, row strides and Cin multiples of 8, else DWG_E_ARG) */
     int32_t out_dtype;        /* DWG_DTYPE_F32 or the operand type */
     int32_t residual_dtype;
     int32_t act;              /* DWG_ACT_* */

@@ -84,7 +84,10 @@ int dwg_raster_forward_render(const dwg_raster_settings* cfg, int32_t num_gaussi
                               dwg_stream_t stream);
 
 /* Backward of the whole rasterizer. dL_dout_depth / dL_dout_alpha may be NULL (treated as zero).
- * Gradient buffers are OVERWRITTEN (not accumulated). Any of dL_dshs / dL_dcolors / dL_dscales /
+ * No float atomics: every (Gaussian, block) pair's partial gradients go to the pair's own 48-byte row of a pair-ordered buffer inside
+ * ws_pairs (a Gaussian's rows are contiguous), and ws_grad receives each Gaussian's rows summed in row order -- the same bits on every
+ * run.  The rows' frame tag is drawn on the device by the forward of the same frame, so the three launches may be replayed from a
+ * captured graph.  Gradient buffers are OVERWRITTEN (not accumulated). Any of dL_dshs / dL_dcolors / dL_dscales /
  * dL_drotations / dL_dcov3D may be NULL when the corresponding input was not supplied.
  * ws_geom / ws_pairs / ws_image must be the ones the forward of the same frame filled. */
 int dwg_raster_backward(const dwg_raster_settings* cfg, int32_t num_gaussians,
