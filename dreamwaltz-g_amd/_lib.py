@@ -70,7 +70,7 @@ SIGNATURES = {
     "dwg_mlp_chain_forward": (ctypes.c_int, [_i32, _i32, _vp, _i32, _i32, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i32, _vp]),
     "dwg_mlp_chain_backward_workspace_floats": (ctypes.c_size_t, [_i32, _i32]),
     "dwg_mlp_chain_backward": (ctypes.c_int, [_i32, _i32, _vp, _i32, _i32, _vp, _vp, _vp, _vp, _vp, _vp, _i32, _vp, _i32, _vp, _i32, _vp, _vp, _vp,
-                                              _vp, _i32, _vp, _vp]),
+                                              _vp, _vp, _i32, _vp, _vp]),
     "dwg_adam_step": (ctypes.c_int, [_i64, _vp, _vp, _vp, _vp, _f32, _f32, _f32, _f32, _i32, _f32, _vp]),
     "dwg_adam_step_dev": (ctypes.c_int, [_i64, _vp, _vp, _vp, _vp, _vp, _f32, _f32, _f32, _vp]),
     # include/dwg_nn.h

@@ -459,6 +459,7 @@ __global__ __launch_bounds__(256) void k_mlp_chain_bwd(MlpChainBwdP p) {
 
 struct MlpChainBwdOut {
     float* dw[MLPC_MAXL]; float* db[MLPC_MAXL]; int lddw[MLPC_MAXL], N[MLPC_MAXL], K[MLPC_MAXL];
+    int acc[MLPC_MAXL];                 // bit 0: dw[l] += (the caller's gradient slice already holds other contributions), bit 1: db[l] +=
     const float* extra; int n_extra;
 };
 // grid (257, nlayers): blocks 0..255 sum 16 weight-gradient entries each over the workgroups' partial tiles (16 strands, fixed order);
@@ -481,7 +482,7 @@ __global__ __launch_bounds__(256) void k_mlp_chain_bwd_final(int blocks, int nla
             float t = 0.f;
 #pragma unroll
             for (int q = 0; q < 16; q++) t += part[q][oo];
-            if (n < N && k < K) o.dw[l][(size_t)n * o.lddw[l] + k] = t;
+            if (n < N && k < K) { float* d = o.dw[l] + (size_t)n * o.lddw[l] + k; *d = (o.acc[l] & 1) ? *d + t : t; }
         }
         return;
     }
@@ -496,9 +497,12 @@ __global__ __launch_bounds__(256) void k_mlp_chain_bwd_final(int blocks, int nla
     __syncthreads();
     if (strand == 0 && col < N) {
         const float t = (part[0][col] + part[1][col]) + (part[2][col] + part[3][col]);
-        if (o.db[l]) o.db[l][col] = t;
+        if (o.db[l]) o.db[l][col] = (o.acc[l] & 2) ? o.db[l][col] + t : t;
         if (l == 0 && o.extra)
-            for (int e = 0; e < o.n_extra; e++) o.dw[0][(size_t)col * o.lddw[0] + K + e] = t * o.extra[e];
+            for (int e = 0; e < o.n_extra; e++) {
+                float* d = o.dw[0] + (size_t)col * o.lddw[0] + K + e;
+                *d = (o.acc[0] & 1) ? *d + t * o.extra[e] : t * o.extra[e];
+            }
     }
 }
 
@@ -721,7 +725,8 @@ size_t dwg_mlp_chain_backward_workspace_floats(int32_t M, int32_t nlayers) {
 int dwg_mlp_chain_backward(int32_t M, int32_t Kin, const float* x, int32_t ldx, int32_t nlayers, const float* const* weights,
                            const int32_t* ldw, const int32_t* widths, const int32_t* acts, const float* const* hidden, const float* out,
                            int32_t ldo, const float* dy, int32_t lddy, float* dx, int32_t lddx, float* const* dw, const int32_t* lddw,
-                           float* const* db, const float* extra, int32_t n_extra, float* workspace, dwg_stream_t stream) {
+                           float* const* db, const int32_t* accumulate, const float* extra, int32_t n_extra, float* workspace,
+                           dwg_stream_t stream) {
     if (M < 0 || nlayers < 1 || nlayers > MLPC_MAXL || Kin < 8 || Kin > 64 || (Kin & 7) || !x || !weights || !ldw || !widths || !acts || !dy ||
         !dw || !lddw || !workspace || n_extra < 0 || (n_extra > 0 && !extra))
         return DWG_E_ARG;
@@ -740,6 +745,7 @@ int dwg_mlp_chain_backward(int32_t M, int32_t Kin, const float* x, int32_t ldx, 
         p.W[l] = on ? weights[l] : nullptr; p.hidden[l] = (on && l + 1 < nlayers) ? hidden[l] : nullptr;
         p.ldw[l] = on ? ldw[l] : 0; p.N[l] = on ? widths[l] : 0; p.K[l] = on ? k : 0; p.act[l] = on ? acts[l] : 0;
         o.dw[l] = on ? dw[l] : nullptr; o.db[l] = (on && db) ? db[l] : nullptr; o.lddw[l] = on ? lddw[l] : 0; o.N[l] = p.N[l]; o.K[l] = p.K[l];
+        o.acc[l] = (on && accumulate) ? accumulate[l] : 0;
         if (on) k = widths[l];
     }
     if (acts[nlayers - 1] != 0 && !out) return DWG_E_ARG;

@@ -24,6 +24,23 @@ def _st(t):
     return ctypes.c_void_p(torch.cuda.current_stream(t.device).cuda_stream)
 
 
+def _inplace_allowed():
+    from . import gridencoder
+    return bool(gridencoder._INPLACE_OK[0]) and os.environ.get("DWG_MLP_GRAD_INPLACE", "1") != "0"
+
+
+def _flat_slice(p, used):
+    """The FlatBuffers object whose gradient buffer `p.grad` is a slice of, if the backward may add into it directly: `p` is a leaf
+    Parameter marked by optim.FlatBuffers, its .grad is a contiguous fp32 tensor of its own shape, and (weights) the tensor the kernels
+    read IS the parameter (no dtype / layout copy in between)."""
+    flat = getattr(p, "_dwg_flat", None) if p is not None else None
+    if flat is None or not p.is_leaf or p.grad is None or not p.grad.is_contiguous() or p.grad.dtype != torch.float32 or p.grad.shape != p.shape:
+        return None
+    if used is not None and (used.data_ptr() != p.data_ptr() or used.shape != p.shape):
+        return None
+    return flat
+
+
 def _splitk(M):
     return max(1, min(256, (M + 1023) // 1024))
 
@@ -122,6 +139,11 @@ class _MlpChain(torch.autograd.Function):
         ctx.acts, ctx.nl = acts, nl
         ctx.has_b = [b is not None for b in bs]
         ctx.has_extra = extra is not None
+        # the parameters themselves (not copies) and whether this forward may add into their flat-gradient slices in its backward: several
+        # backwards running concurrently on their own streams (the views of a batched step) must not read-add-write one slice -- the switch the
+        # grid encoder's in-place table gradient obeys (gridencoder.table_grad_inplace)
+        ctx.params = [(wb[2 * l], wb[2 * l + 1]) for l in range(nl)]
+        ctx.inplace_ok = _inplace_allowed()
         if keep:
             ctx.save_for_backward(x, out, *(ws + hidden + ([extra] if extra is not None else [])))
         return out
@@ -147,8 +169,16 @@ class _MlpChain(torch.autograd.Function):
                     grads[2 * l] = torch.zeros_like(w)
                     grads[2 * l + 1] = torch.zeros(w.shape[0], device=dev) if ctx.has_b[l] else None
                 return (dx, None, None) + tuple(grads)
-            dws = [torch.empty_like(w) for w in ws]
+            # A weight / bias that is a leaf Parameter whose .grad is its slice of a flat gradient buffer (optim.FlatBuffers marks those:
+            # `_dwg_flat`) gets its gradient ADDED into that slice by the reduce kernel and autograd is handed None -- no temporary, no
+            # AccumulateGrad `add_` launch per parameter (sixteen per step for the two networks).  Anything else (the concatenated heads of
+            # the deformation network, torch.autograd.grad callers, parameters of another optimizer) gets its gradient returned as usual.
+            wflat = [_flat_slice(ctx.params[l][0], ws[l]) if ctx.inplace_ok else None for l in range(nl)]
+            bflat = [_flat_slice(ctx.params[l][1], None) if (ctx.inplace_ok and ctx.has_b[l]) else None for l in range(nl)]
+            dws = [ctx.params[l][0].grad if wflat[l] is not None else torch.empty_like(ws[l]) for l in range(nl)]
             dbs = torch.empty(nl, 64, device=dev)
+            dbp = [ctx.params[l][1].grad.data_ptr() if bflat[l] is not None else dbs[l].data_ptr() for l in range(nl)]
+            acc = [(1 if wflat[l] is not None else 0) | (2 if bflat[l] is not None else 0) for l in range(nl)]
             e = extra.reshape(-1).contiguous().float() if extra is not None else None
             wsp = torch.empty(L.dwg_mlp_chain_backward_workspace_floats(M, nl), device=dev, dtype=torch.float32)
             vp, i32 = ctypes.c_void_p * nl, ctypes.c_int32 * nl
@@ -156,11 +186,17 @@ class _MlpChain(torch.autograd.Function):
                 M, Kx, _lib.ptr(x), Kx, nl, vp(*[w.data_ptr() for w in ws]), i32(*[int(w.stride(0)) for w in ws]),
                 i32(*[int(w.shape[0]) for w in ws]), i32(*[gemm.ACT[a] for a in ctx.acts]), vp(*[h.data_ptr() for h in hidden] + [None]),
                 _lib.ptr(out), int(out.shape[1]), _lib.ptr(dy), int(dy.shape[1]), _lib.ptr(dx) if need_dx else None, Kx,
-                vp(*[d.data_ptr() for d in dws]), i32(*[int(d.stride(0)) for d in dws]), vp(*[dbs[l].data_ptr() for l in range(nl)]),
+                vp(*[d.data_ptr() for d in dws]), i32(*[int(d.stride(0)) for d in dws]), vp(*dbp), i32(*acc),
                 _lib.ptr(e) if e is not None else None, int(e.numel()) if e is not None else 0, _lib.ptr(wsp), _st(x)), "dwg_mlp_chain_backward")
             for l, w in enumerate(ws):
-                grads[2 * l] = dws[l]
-                grads[2 * l + 1] = dbs[l, :w.shape[0]] if ctx.has_b[l] else None
+                if wflat[l] is not None:
+                    wflat[l].touch(ctx.params[l][0])        # autograd never sees this gradient: record the participation for the optimizer
+                else:
+                    grads[2 * l] = dws[l]
+                if bflat[l] is not None:
+                    bflat[l].touch(ctx.params[l][1])
+                elif ctx.has_b[l]:
+                    grads[2 * l + 1] = dbs[l, :w.shape[0]]
             return (dx, None, None) + tuple(grads)
         g = dy
         # one zero fill for every layer's bias-gradient accumulator and weight-gradient tile (16 fills per step before)

@@ -40,7 +40,22 @@ class GraphedTrainStep:
             raise ValueError("GraphedTrainStep needs a renderer with async_pair_count=True (no host read-back inside the step)")
         if trainer.densifiers is not None or trainer.world != 1 or trainer.total_views != 1:
             raise NotImplementedError("a captured step is single-view, single-rank and without the densifier")
-        self.pose = {k: v.clone() for k, v in example_pose.items()}
+        # ONE device block holds everything the host refreshes per replay -- the optimizers' scalar table, then the pose tensors (16-byte
+        # aligned views) -- so that a step costs one asynchronous copy from a pinned twin of the block, not one per tensor (nine before)
+        opts = trainer.optimizers
+        self._rows = sum(len(o.param_groups) for o in opts.values())
+        if any(v.dtype != torch.float32 for v in example_pose.values()):
+            raise TypeError("GraphedTrainStep: pose tensors must be float32")
+        offs, o = {}, self._rows * 4
+        for k, v in example_pose.items():
+            offs[k] = o
+            o += (v.numel() + 3) // 4 * 4
+        self._block_floats = o
+        self._block_dev = torch.zeros(o, device=self.device)
+        self.hyper_dev = self._block_dev[:self._rows * 4].view(self._rows, 4)
+        self.pose = {k: self._block_dev[offs[k]:offs[k] + v.numel()].view(v.shape) for k, v in example_pose.items()}
+        for k, v in example_pose.items():
+            self.pose[k].copy_(v)
         self.data = dict(data); self.data["smpl_inputs"] = self.pose
         self.condition_fn, self.seed_fn = condition_fn, seed_fn
         self.guided = hasattr(trainer.diffusion, "draw_view_randoms")
@@ -51,16 +66,14 @@ class GraphedTrainStep:
             pn, t, n = trainer.diffusion.draw_view_randoms(self._rng, 1, trainer.max_step)
             self._rand = (pn.clone(), t.clone(), n.clone())     # static: refreshed eagerly before every replay
             self._view_index = None
-        self._pinned = [{k: torch.empty_like(v, device="cpu").pin_memory() for k, v in example_pose.items()} for _ in range(4)]
+        # per-step host inputs go through NSLOT rotating pinned twins of the block; a slot is rewritten only after the replay that read it has
+        # finished (nothing else throttles the host here: the eager loop is paced by the rasterizer's pair-count event, a replay is not)
+        self._slots = [torch.zeros(self._block_floats).pin_memory() for _ in range(4)]
+        self._pinned = [{k: b[offs[k]:offs[k] + v.numel()].view(v.shape) for k, v in example_pose.items()} for b in self._slots]
+        self._hyper_slots = [b[:self._rows * 4].view(self._rows, 4) for b in self._slots]
         self._slot = 0
-        opts = trainer.optimizers
-        self._rows = sum(len(o.param_groups) for o in opts.values())
-        # per-step host inputs go through NSLOT rotating pinned slots; a slot is rewritten only after the replay that read it has finished
-        # (nothing else throttles the host here: the eager loop is paced by the rasterizer's pair-count event, a replay is not)
-        self._hyper_slots = [torch.zeros(self._rows, 4).pin_memory() for _ in range(4)]
         self._slot_events = [None] * 4
         self.hyper_host = self._hyper_slots[0]
-        self.hyper_dev = torch.zeros(self._rows, 4, device=self.device)
         self.graph, self.loss, self.outputs = None, None, None
         self._side = torch.cuda.Stream(device=self.device)
         H, W = int(data["image_height"]), int(data["image_width"])
@@ -178,10 +191,12 @@ class GraphedTrainStep:
         self._host_prepare()
         self._draw()
         slot = self._pinned[i]
+        if pose_cpu.keys() != slot.keys():
+            raise KeyError("GraphedTrainStep.step: the pose must carry exactly the tensors of the example pose (%s), got %s"
+                           % (sorted(slot.keys()), sorted(pose_cpu.keys())))
         for k, v in pose_cpu.items():
             slot[k].copy_(v)
-            self.pose[k].copy_(slot[k], non_blocking=True)
-        self.hyper_dev.copy_(self.hyper_host, non_blocking=True)
+        self._block_dev.copy_(self._slots[i], non_blocking=True)        # the scalar table and the pose: one copy
         self.graph.replay()
         ev = torch.cuda.Event(); ev.record(torch.cuda.current_stream(self.device))
         self._slot_events[i] = ev

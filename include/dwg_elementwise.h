@@ -42,13 +42,16 @@ int dwg_mlp_chain_forward(int32_t M, int32_t Kin, const float* x, int32_t ldx, i
  * and, when the last activation is not the identity, the output `out`: dx [M, Kin] (row stride lddx; NULL = not wanted), per layer
  * dw[l] [widths[l], >= K_l] with row stride lddw[l] (columns 0..K_l-1 written) and db[l] [widths[l]] (db or entries may be NULL).
  * `extra` [n_extra] (device; NULL / 0 = none): the vector the caller folded into the first layer's bias through the trailing columns of
- * W_0 -- their gradient dw[0][:, Kin + e] = db_0 * extra[e] is written too.  Deterministic (fixed summation order, no atomics).
+ * W_0 -- their gradient dw[0][:, Kin + e] = db_0 * extra[e] is written too.  accumulate (HOST array, may be NULL = all 0): per layer bit 0
+ * "dw[l] += " and bit 1 "db[l] += " instead of "=" (the caller's gradient slice already holds other contributions: the parameters' slices
+ * of a flat gradient buffer).  Deterministic (fixed summation order, no atomics).
  * workspace: dwg_mlp_chain_backward_workspace_floats(M, nlayers) floats.  Array arguments are HOST arrays of length nlayers (<= 6). */
 size_t dwg_mlp_chain_backward_workspace_floats(int32_t M, int32_t nlayers);
 int dwg_mlp_chain_backward(int32_t M, int32_t Kin, const float* x, int32_t ldx, int32_t nlayers, const float* const* weights,
                            const int32_t* ldw, const int32_t* widths, const int32_t* acts, const float* const* hidden, const float* out,
                            int32_t ldo, const float* dy, int32_t lddy, float* dx, int32_t lddx, float* const* dw, const int32_t* lddw,
-                           float* const* db, const float* extra, int32_t n_extra, float* workspace, dwg_stream_t stream);
+                           float* const* db, const int32_t* accumulate, const float* extra, int32_t n_extra, float* workspace,
+                           dwg_stream_t stream);
 
 /* torch.optim.Adam update (amsgrad=False, weight_decay=0) on n contiguous floats, step >= 1 is the 1-based step count;
  * grad is multiplied by grad_scale first (1/world_size after a sum all-reduce).  Buffers must be 16-byte aligned. */

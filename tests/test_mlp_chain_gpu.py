@@ -134,3 +134,45 @@ def test_chain_backward_without_an_input_gradient_and_on_an_empty_batch():
     e = torch.zeros(0, 32, device=dev, requires_grad=True)
     mlp.mlp_chain(e, layers, ["relu", None]).sum().backward()
     assert e.grad.shape == (0, 32) and float(layers[0][0].grad.abs().sum()) == 0.0
+
+
+def test_gradients_of_flat_buffer_parameters_are_added_in_place():
+    """Parameters whose .grad is a slice of a flat gradient buffer (optim.FlatBuffers) get their MLP gradients ADDED into the slice by the
+    reduce kernel (no AccumulateGrad launch): two backwards accumulate, participation is recorded for the optimizer, a parameter that is not
+    part of the flat buffer (here: the last layer's weight, passed as a concatenation like the deformation network's heads) still gets its
+    gradient through autograd, and `gridencoder.table_grad_inplace(False)` switches the in-place path off."""
+    import dwg_import  # noqa: F401
+    from dreamwaltz_g_amd import gridencoder, mlp, optim
+    dev = torch.device("cuda")
+    g = torch.Generator().manual_seed(5)
+    net = mlp.MLP(32, 4, 64, 3).to(dev)
+    head_a = torch.nn.Parameter((torch.randn(2, 64, generator=g) / 8).to(dev)); head_b = torch.nn.Parameter((torch.randn(2, 64, generator=g) / 8).to(dev))
+    params = [p for p in net.parameters()]
+    flat = optim.FlatBuffers(params + [head_a, head_b], dev)
+    x = torch.randn(5000, 32, generator=g).to(dev)
+    gy = torch.randn(5000, 4, generator=g).to(dev)
+
+    def run():
+        layers = [(m.weight, m.bias) for m in net.net[:2]] + [(torch.cat([head_a, head_b], 0), net.net[2].bias)]
+        return mlp.mlp_chain(x, layers, ["relu", "relu", None])
+    xr, pr, yr = _reference(x, [(m.weight, m.bias) for m in net.net[:2]] + [(torch.cat([head_a, head_b], 0), net.net[2].bias)], ["relu", "relu", None], None)
+    yr.backward(gy.double().cpu())
+    for rounds in (1, 2):
+        flat.grad.zero_()
+        for p in params + [head_a, head_b]:
+            p._dwg_touched = False
+        for _ in range(rounds):
+            run().backward(gy)
+        assert all(p._dwg_touched for p in (net.net[0].weight, net.net[0].bias, net.net[1].weight, net.net[1].bias, net.net[2].bias, head_a, head_b))
+        assert not net.net[2].weight._dwg_touched                       # not on this path at all
+        for l in range(2):
+            assert net.net[l].weight.grad.data_ptr() == flat.grad[flat.slices[2 * l][0]:].data_ptr()     # still the flat slice
+            assert _rel(net.net[l].weight.grad, rounds * pr[l][0].grad) < 2e-5 and _rel(net.net[l].bias.grad, rounds * pr[l][1].grad) < 2e-5
+        assert _rel(torch.cat([head_a.grad, head_b.grad], 0), rounds * pr[2][0].grad) < 2e-5 and _rel(net.net[2].bias.grad, rounds * pr[2][1].grad) < 2e-5
+    inplace = flat.grad.clone()
+    flat.grad.zero_()
+    with gridencoder.table_grad_inplace(False):
+        out = run()
+    for _ in range(1):
+        out.backward(gy, retain_graph=True); out.backward(gy)
+    assert _rel(flat.grad, inplace) < 1e-6
