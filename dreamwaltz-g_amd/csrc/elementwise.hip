@@ -462,48 +462,49 @@ struct MlpChainBwdOut {
     int acc[MLPC_MAXL];                 // bit 0: dw[l] += (the caller's gradient slice already holds other contributions), bit 1: db[l] +=
     const float* extra; int n_extra;
 };
-// grid (257, nlayers): blocks 0..255 sum 16 weight-gradient entries each over the workgroups' partial tiles (16 strands, fixed order);
-// block 256 the bias gradients -- and, for the first layer, the columns of the vector folded into its bias (dW[:, K + e] = db * extra[e])
+// grid (260, nlayers): blocks 0..255 sum 16 weight-gradient entries each over the workgroups' partial tiles, blocks 256..259 sixteen bias
+// gradients each (a workgroup's four row-quarter partials first) -- 16 strands per output, a strand's loads issued eight at a time (a
+// rolled loop was a chain of dependent-latency loads: 30 us per launch for 20 MB), fixed combination order -- and, for the first layer, the
+// columns of the vector folded into its bias (dW[:, K + e] = db * extra[e])
 __global__ __launch_bounds__(256) void k_mlp_chain_bwd_final(int blocks, int nlayers, const float* __restrict__ partial, MlpChainBwdOut o) {
-    __shared__ float part[16][65];
+    __shared__ float part[16][17];
     const int l = blockIdx.y;
     const float* src = partial + (size_t)l * MLPB_PART;
     const size_t stride = (size_t)nlayers * MLPB_PART;
     const int N = o.N[l], K = o.K[l];
-    if (blockIdx.x < 256) {
-        const int oo = threadIdx.x & 15, strand = threadIdx.x >> 4;
-        const int e = blockIdx.x * 16 + oo;
-        float s = 0.f;
-        for (int b = strand; b < blocks; b += 16) s += src[(size_t)b * stride + e];
-        part[strand][oo] = s;
-        __syncthreads();
-        if (strand == 0) {
-            const int n = e >> 6, k = e & 63;
-            float t = 0.f;
+    const int oo = threadIdx.x & 15, strand = threadIdx.x >> 4;
+    const bool bias = blockIdx.x >= 256;
+    const int e = bias ? (blockIdx.x - 256) * 16 + oo : blockIdx.x * 16 + oo;          // bias: column; else entry n * 64 + k
+    const float* q = src + (bias ? 4096 + e : e);
+    float acc[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+    for (int b0 = strand; b0 < blocks; b0 += 128) {
 #pragma unroll
-            for (int q = 0; q < 16; q++) t += part[q][oo];
-            if (n < N && k < K) { float* d = o.dw[l] + (size_t)n * o.lddw[l] + k; *d = (o.acc[l] & 1) ? *d + t : t; }
+        for (int u = 0; u < 8; u++) {
+            const int b = b0 + 16 * u;
+            if (b < blocks) {
+                const float* r = q + (size_t)b * stride;
+                acc[u] += bias ? (r[0] + r[64]) + (r[128] + r[192]) : r[0];
+            }
         }
+    }
+    part[strand][oo] = ((acc[0] + acc[1]) + (acc[2] + acc[3])) + ((acc[4] + acc[5]) + (acc[6] + acc[7]));
+    __syncthreads();
+    if (strand != 0) return;
+    float t = 0.f;
+#pragma unroll
+    for (int s_ = 0; s_ < 16; s_++) t += part[s_][oo];
+    if (!bias) {
+        const int n = e >> 6, k = e & 63;
+        if (n < N && k < K) { float* d = o.dw[l] + (size_t)n * o.lddw[l] + k; *d = (o.acc[l] & 1) ? *d + t : t; }
         return;
     }
-    // bias: 4 strands x 64 columns; a strand walks the workgroups, each holding four row-quarter partials
-    const int col = threadIdx.x & 63, strand = threadIdx.x >> 6;
-    float s = 0.f;
-    for (int b = strand; b < blocks; b += 4) {
-        const float* q = src + (size_t)b * stride + 4096 + col;
-        s += (q[0] + q[64]) + (q[128] + q[192]);
-    }
-    part[strand][col] = s;
-    __syncthreads();
-    if (strand == 0 && col < N) {
-        const float t = (part[0][col] + part[1][col]) + (part[2][col] + part[3][col]);
-        if (o.db[l]) o.db[l][col] = (o.acc[l] & 2) ? o.db[l][col] + t : t;
-        if (l == 0 && o.extra)
-            for (int e = 0; e < o.n_extra; e++) {
-                float* d = o.dw[0] + (size_t)col * o.lddw[0] + K + e;
-                *d = (o.acc[0] & 1) ? *d + t * o.extra[e] : t * o.extra[e];
-            }
-    }
+    if (e >= N) return;
+    if (o.db[l]) o.db[l][e] = (o.acc[l] & 2) ? o.db[l][e] + t : t;
+    if (l == 0 && o.extra)
+        for (int x_ = 0; x_ < o.n_extra; x_++) {
+            float* d = o.dw[0] + (size_t)e * o.lddw[0] + K + x_;
+            *d = (o.acc[0] & 1) ? *d + t * o.extra[x_] : t * o.extra[x_];
+        }
 }
 
 typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8_t;
@@ -759,7 +760,7 @@ int dwg_mlp_chain_backward(int32_t M, int32_t Kin, const float* x, int32_t ldx, 
     }
     const int blocks = mlp_chain_bwd_blocks(M);
     DWG_LAUNCH("mlp_chain_bwd", k_mlp_chain_bwd, dim3(blocks), dim3(256), lds, (hipStream_t)stream, p);
-    DWG_LAUNCH("mlp_chain_bwd_final", k_mlp_chain_bwd_final, dim3(257, nlayers), dim3(256), 0, (hipStream_t)stream, blocks, nlayers,
+    DWG_LAUNCH("mlp_chain_bwd_final", k_mlp_chain_bwd_final, dim3(260, nlayers), dim3(256), 0, (hipStream_t)stream, blocks, nlayers,
                (const float*)workspace, o);
     DWG_RETURN_IF_LAUNCH_FAILED();
     return DWG_OK;

@@ -305,7 +305,8 @@ static int check(uint32_t B, uint32_t D, uint32_t C, uint32_t L) {
 // ---------------------------------------------------------------------------------------------------------------------
 #define GS_SLAB 4096u          // table entries (float2) per slab: 32 KiB of LDS (four accumulate workgroups per CU)
 #define GS_NWG 256u            // workgroups of the count / scatter passes (each owns a contiguous range of (point, level) chunks)
-#define GS_MAXREC 32768u       // records one accumulate workgroup takes
+#define GS_MAXREC 8192u        // records one accumulate workgroup takes (round 4: 32768 -- the kernel's time was its longest unit: 128 trips of a
+                               // one-load-in-flight loop; the extra units of a dense slab add their non-zero entries with global atomics)
 struct GsUnit { uint32_t slab, begin, end, multi; };
 
 __device__ __forceinline__ uint32_t gs_wg_chunks(uint32_t nchunks) { return (nchunks + GS_NWG - 1u) / GS_NWG; }
@@ -442,10 +443,17 @@ __global__ __launch_bounds__(256) void k_gs_accumulate(uint32_t first_entry, uin
     const GsUnit u = units[blockIdx.x];
     for (uint32_t e = threadIdx.x; e < GS_SLAB * 2u; e += 256) tab[e] = 0.f;
     __syncthreads();
-    for (uint32_t r = u.begin + threadIdx.x; r < u.end; r += 256) {
-        const uint4 rec = records[r];
-        atomicAdd(&tab[2u * rec.x], __uint_as_float(rec.y));
-        atomicAdd(&tab[2u * rec.x + 1u], __uint_as_float(rec.z));
+    for (uint32_t r0 = u.begin + threadIdx.x; r0 < u.end; r0 += 1024) {        // four records in flight per thread
+        uint4 rec[4];
+#pragma unroll
+        for (int i = 0; i < 4; i++) { const uint32_t r = r0 + 256u * i; rec[i] = r < u.end ? records[r] : make_uint4(0u, 0u, 0u, 0u); }
+#pragma unroll
+        for (int i = 0; i < 4; i++) {
+            if (r0 + 256u * i < u.end) {
+                atomicAdd(&tab[2u * rec[i].x], __uint_as_float(rec[i].y));
+                atomicAdd(&tab[2u * rec[i].x + 1u], __uint_as_float(rec[i].z));
+            }
+        }
     }
     __syncthreads();
     const uint32_t e0 = first_entry + u.slab * GS_SLAB;                     // first table entry of this slab
