@@ -67,7 +67,7 @@ SIGNATURES = {
     "dwg_xfmt_unpack": (ctypes.c_int, [_i64, _vp, _vp, _vp]),
     # include/dwg_elementwise.h
     "dwg_act_backward_colsum": (ctypes.c_int, [_i32, _i32, _i32, _vp, _vp, _vp, _vp, _vp]),
-    "dwg_mlp_chain_forward": (ctypes.c_int, [_i32, _i32, _vp, _i32, _i32, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i32, _vp]),
+    "dwg_mlp_chain_forward": (ctypes.c_int, [_i32, _i32, _vp, _i32, _i32, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i32, _vp, _i32, _vp]),
     "dwg_mlp_chain_backward_workspace_floats": (ctypes.c_size_t, [_i32, _i32]),
     "dwg_mlp_chain_backward": (ctypes.c_int, [_i32, _i32, _vp, _i32, _i32, _vp, _vp, _vp, _vp, _vp, _vp, _i32, _vp, _i32, _vp, _i32, _vp, _vp, _vp,
                                               _vp, _vp, _i32, _vp, _vp]),

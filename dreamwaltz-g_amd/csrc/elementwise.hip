@@ -186,6 +186,8 @@ __global__ __launch_bounds__(256) void k_mlp_wgrad_final(int blocks, int N, int 
 #define MLPC_LD 68          // row stride in floats: multiple of 4 (16-byte fragment reads)
 struct MlpChainP {
     const float* x; int M, Kin, ldx, nlayers;
+    const float* extra; int n_extra;        // vector folded into the first layer's bias through W_0's trailing columns (may be null / 0)
+    int waves;                              // waves per workgroup of this launch (<= MLPC_WAVES)
     const float* W[MLPC_MAXL]; const float* b[MLPC_MAXL]; float* hidden[MLPC_MAXL];
     int ldw[MLPC_MAXL], N[MLPC_MAXL], K[MLPC_MAXL], act[MLPC_MAXL];
     float* out; int ldo;
@@ -209,28 +211,76 @@ __global__ __launch_bounds__(64 * MLPC_WAVES) void k_mlp_chain(MlpChainP p, int 
     float* sBall = smem + wfloats;                          // [nlayers][64]
     float* sXall = sBall + MLPC_MAXL * 64;                  // [MLPC_WAVES][32][MLPC_LD]
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int nthr = 64 * p.waves;
     {
         int off = 0;
         for (int l = 0; l < p.nlayers; l++) {
             const int N = p.N[l], K = p.K[l], Np = (N + 31) & ~31;
-            for (int i = tid; i < Np * K; i += 64 * MLPC_WAVES) {
-                const int n = i / K, k = i - n * K;
-                sWall[off + n * MLPC_LD + mlpc_pos(k, K)] = n < N ? p.W[l][(size_t)n * p.ldw[l] + k] : 0.f;
+            // eight loads in flight per thread (one load per trip made the staging a chain of dependent latencies: ~40 us of a 10 k-row launch)
+            for (int i0 = tid; i0 < Np * K; i0 += 8 * nthr) {
+                float v[8];
+#pragma unroll
+                for (int u = 0; u < 8; u++) {
+                    const int i = i0 + u * nthr, n = i / K, k = i - n * K;
+                    v[u] = (i < Np * K && n < N) ? p.W[l][(size_t)n * p.ldw[l] + k] : 0.f;
+                }
+#pragma unroll
+                for (int u = 0; u < 8; u++) {
+                    const int i = i0 + u * nthr, n = i / K, k = i - n * K;
+                    if (i < Np * K) sWall[off + n * MLPC_LD + mlpc_pos(k, K)] = v[u];
+                }
             }
             if (tid < 64) sBall[l * 64 + tid] = (tid < N && p.b[l]) ? p.b[l][tid] : 0.f;
             off += Np * MLPC_LD;
+        }
+        if (p.extra) {
+            // b_0[n] += sum_e W_0[n][Kin + e] extra[e] (deform_model.py:113-115 concatenates the expanded body pose to every row: the same
+            // product for all rows, i.e. a bias) -- a launch of its own before (a [1, 63] x [63, 64] GEMM: 13 us on the frame's critical path).
+            // Wave w sums the terms e = w, w + waves, ...; the partial sums are added in wave order.
+            float* sP = sXall;                                  // [waves][64] scratch (the activation rows are not in use yet)
+            const int n = lane, N0 = p.N[0];
+            float a = 0.f;
+            if (n < N0) {
+                const float* wrow = p.W[0] + (size_t)n * p.ldw[0] + p.Kin;
+                for (int e0 = wave; e0 < p.n_extra; e0 += 4 * p.waves) {          // four independent loads in flight
+                    float w4[4], x4[4];
+#pragma unroll
+                    for (int u = 0; u < 4; u++) {
+                        const int e = e0 + u * p.waves;
+                        w4[u] = e < p.n_extra ? wrow[e] : 0.f; x4[u] = e < p.n_extra ? p.extra[e] : 0.f;
+                    }
+#pragma unroll
+                    for (int u = 0; u < 4; u++) a = fmaf(w4[u], x4[u], a);
+                }
+            }
+            sP[wave * 64 + n] = a;
+            __syncthreads();
+            if (tid < 64) {
+                float t = sBall[tid];
+                for (int w = 0; w < p.waves; w++) t += sP[w * 64 + tid];
+                sBall[tid] = tid < N0 ? t : 0.f;
+            }
         }
     }
     __syncthreads();
     float* sX = sXall + wave * 32 * MLPC_LD;
     const int m = lane & 31, half = lane >> 5;
     const int ngroups = (p.M + 31) >> 5;
-    for (int g = blockIdx.x * MLPC_WAVES + wave; g < ngroups; g += gridDim.x * MLPC_WAVES) {
+    for (int g = blockIdx.x * p.waves + wave; g < ngroups; g += gridDim.x * p.waves) {
         const int r0 = g * 32;
         __builtin_amdgcn_wave_barrier();
-        for (int i = lane; i < 32 * p.Kin; i += 64) {       // this wave's rows -> LDS, coalesced
-            const int r = i / p.Kin, k = i - r * p.Kin;
-            sX[r * MLPC_LD + mlpc_pos(k, p.Kin)] = (r0 + r < p.M) ? p.x[(size_t)(r0 + r) * p.ldx + k] : 0.f;
+        for (int i0 = lane; i0 < 32 * p.Kin; i0 += 8 * 64) {        // this wave's rows -> LDS, coalesced, eight loads in flight per lane
+            float v[8];
+#pragma unroll
+            for (int u = 0; u < 8; u++) {
+                const int i = i0 + 64 * u, r = i / p.Kin, k = i - r * p.Kin;
+                v[u] = (i < 32 * p.Kin && r0 + r < p.M) ? p.x[(size_t)(r0 + r) * p.ldx + k] : 0.f;
+            }
+#pragma unroll
+            for (int u = 0; u < 8; u++) {
+                const int i = i0 + 64 * u, r = i / p.Kin, k = i - r * p.Kin;
+                if (i < 32 * p.Kin) sX[r * MLPC_LD + mlpc_pos(k, p.Kin)] = v[u];
+            }
         }
         __builtin_amdgcn_wave_barrier();
         const int grow = r0 + m;
@@ -346,9 +396,16 @@ __global__ __launch_bounds__(256) void k_mlp_chain_bwd(MlpChainBwdP p) {
     const int qr = wave >> 1, qc = wave & 1, half = lane >> 5, l31 = lane & 31;
     for (int l = 0; l < p.nlayers; l++) {
         const int N = p.N[l], K = p.K[l];
-        for (int i = tid; i < 64 * 64; i += 256) {
-            const int n = i >> 6, k = i & 63;
-            sWall[(l * 64 + n) * MLPB_LD + k] = (n < N && k < K) ? p.W[l][(size_t)n * p.ldw[l] + k] : 0.f;
+        float v[16];                                        // sixteen loads in flight per thread
+#pragma unroll
+        for (int u = 0; u < 16; u++) {
+            const int i = tid + 256 * u, n = i >> 6, k = i & 63;
+            v[u] = (n < N && k < K) ? p.W[l][(size_t)n * p.ldw[l] + k] : 0.f;
+        }
+#pragma unroll
+        for (int u = 0; u < 16; u++) {
+            const int i = tid + 256 * u;
+            sWall[(l * 64 + (i >> 6)) * MLPB_LD + (i & 63)] = v[u];
         }
     }
     f32x16_t accw[MLPC_MAXL];
@@ -683,16 +740,19 @@ int dwg_mlp_wgrad(int32_t M, int32_t N, int32_t K, const float* dz, int32_t lddz
 
 int dwg_mlp_chain_forward(int32_t M, int32_t Kin, const float* x, int32_t ldx, int32_t nlayers, const float* const* weights,
                           const int32_t* ldw, const float* const* biases, const int32_t* widths, const int32_t* acts,
-                          float* const* hidden, float* out, int32_t ldo, dwg_stream_t stream) {
-    if (M < 0 || nlayers < 1 || nlayers > MLPC_MAXL || Kin < 8 || Kin > 64 || (Kin & 7) || !weights || !ldw || !widths || !acts) return DWG_E_ARG;
+                          float* const* hidden, float* out, int32_t ldo, const float* extra, int32_t n_extra, dwg_stream_t stream) {
+    if (M < 0 || nlayers < 1 || nlayers > MLPC_MAXL || Kin < 8 || Kin > 64 || (Kin & 7) || !weights || !ldw || !widths || !acts || n_extra < 0 ||
+        (n_extra > 0 && !extra))
+        return DWG_E_ARG;
     if (M == 0) return DWG_OK;          // an empty batch has no rows to read or write (x / out may be the null pointer of an empty tensor)
     if (!x || !out) return DWG_E_ARG;
     MlpChainP p;
     p.x = x; p.M = M; p.Kin = Kin; p.ldx = ldx; p.nlayers = nlayers; p.out = out; p.ldo = ldo;
+    p.extra = n_extra > 0 ? extra : nullptr; p.n_extra = n_extra;
     int k = Kin;
     for (int l = 0; l < MLPC_MAXL; l++) {
         const bool on = l < nlayers;
-        if (on && (widths[l] < 1 || widths[l] > 64 || !weights[l] || ldw[l] < k)) return DWG_E_ARG;
+        if (on && (widths[l] < 1 || widths[l] > 64 || !weights[l] || ldw[l] < k + (l == 0 ? n_extra : 0))) return DWG_E_ARG;
         if (on && l + 1 < nlayers && (widths[l] & 7)) return DWG_E_ARG;       // hidden widths (the next layer's K): multiples of 8
         if (on && acts[l] != 0 && acts[l] != 1 && acts[l] != 2 && acts[l] != 5) return DWG_E_ARG;
         p.W[l] = on ? weights[l] : nullptr; p.b[l] = (on && biases) ? biases[l] : nullptr;
@@ -708,8 +768,13 @@ int dwg_mlp_chain_forward(int32_t M, int32_t Kin, const float* x, int32_t ldx, i
         hipFuncSetAttribute(reinterpret_cast<const void*>(&k_mlp_chain), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
         attr_set = true;
     }
-    const int wgs = dwg_cdiv(dwg_cdiv(M, 32), MLPC_WAVES);
-    DWG_LAUNCH("mlp_chain_fwd", k_mlp_chain, dim3(wgs < 256 ? wgs : 256), dim3(64 * MLPC_WAVES), lds, (hipStream_t)stream, p, wfloats);    // persistent
+    // waves per workgroup: eight share one LDS copy of the weights when there are row groups for every SIMD of the chip (two waves per SIMD
+    // hide each other's latencies); a small batch (the 10 k-Gaussian frames: 313 groups) runs four per workgroup -- twice the CUs, one wave per
+    // SIMD, so that a group's serial chain of layers has the MFMA pipe to itself (c1: the deformation network's launch 54 us before)
+    const int groups = dwg_cdiv(M, 32);
+    p.waves = groups <= 1024 ? 4 : MLPC_WAVES;
+    const int wgs = dwg_cdiv(groups, p.waves);
+    DWG_LAUNCH("mlp_chain_fwd", k_mlp_chain, dim3(wgs < 256 ? wgs : 256), dim3(64 * p.waves), lds, (hipStream_t)stream, p, wfloats);    // persistent
     DWG_RETURN_IF_LAUNCH_FAILED();
     return DWG_OK;
 }

@@ -1377,6 +1377,8 @@ int dwg_raster_forward_render(const dwg_raster_settings* cfg, int32_t G, void* w
         // (a block of class c holds more than {0, 1024, 4096, 16384} pairs, so at most capacity / that many such blocks exist)
         const int nD = (int)min((int64_t)T, pair_capacity / 16384 + 1), nC = (int)min((int64_t)T, pair_capacity / 4096 + 1),
                   nB = (int)min((int64_t)T, pair_capacity / 1024 + 1);
+        // (the four classes sort disjoint blocks; running the three long ones as a parallel branch of a captured graph was measured SLOWER --
+        // c1 0.280 -> 0.336 ms per frame, c2 1.21 -> 1.29 ms per step: a cross-stream edge costs a replay more than three near-empty nodes)
         DWG_LAUNCH("raster_tile_sort_g", (k_tile_sort<3, 1024, true>), dim3(nD), dim3(1024), 0, stream, T, cls, header, tile_start,
                    keys, sorted, pair_capacity);
         static const bool lds_sort = getenv("DWG_RASTER_LDS_SORT") != nullptr;      // experiment switch: the round-1 LDS network

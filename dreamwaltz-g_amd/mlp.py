@@ -106,8 +106,8 @@ def _linear_backward(x, w, y, extra, act, dy, need_dx, zeros=None):
 
 
 class _MlpChain(torch.autograd.Function):
-    """The whole MLP in one forward launch (csrc/elementwise.hip k_mlp_chain, include/dwg_elementwise.h dwg_mlp_chain_forward);
-    backward layer by layer with the kernels of _Linear.  args: x, extra (vector folded into the first bias, or None), acts (tuple of
+    """The whole MLP in one forward launch (csrc/elementwise.hip k_mlp_chain, include/dwg_elementwise.h dwg_mlp_chain_forward) and one
+    backward launch + reduce (k_mlp_chain_bwd, dwg_mlp_chain_backward; DWG_MLP_BWD_PER_LAYER=1: layer by layer with the kernels of _Linear).  args: x, extra (vector folded into the first bias, or None), acts (tuple of
     names, one per layer), then w_0, b_0, w_1, b_1, ..."""
 
     @staticmethod
@@ -119,14 +119,9 @@ class _MlpChain(torch.autograd.Function):
         x = x.contiguous().float()
         M, Kx = x.shape
         dev = x.device
-        bias0 = bs[0].float() if bs[0] is not None else torch.zeros(ws[0].shape[0], device=dev)
-        if extra is not None:      # c = extra @ w_0[:, Kx:]^T + b_0   (1 x Ke) x (Ke x N)
-            e = extra.reshape(1, -1).contiguous().float()
-            c = torch.empty(1, ws[0].shape[0], device=dev)
-            gemm.gemm_raw(e, ws[0][:, Kx:], c, 1, ws[0].shape[0], e.shape[1], (e.shape[1], 1), (ws[0].stride(0), 1), ws[0].shape[0],
-                          bias=bias0.contiguous(), name="mlp_pose_bias")
-            bias0 = c.reshape(-1)
-        biases = [bias0.contiguous()] + [None if b is None else b.contiguous().float() for b in bs[1:]]
+        # `extra` (the body pose every row is extended by) meets the trailing columns of w_0 inside the launch: a bias
+        e = extra.reshape(-1).contiguous().float() if extra is not None else None
+        biases = [None if b is None else b.contiguous().float() for b in bs]
         widths = [int(w.shape[0]) for w in ws]
         keep = any(ctx.needs_input_grad)
         hidden = [torch.empty(M, widths[l], device=dev) if keep else None for l in range(nl - 1)]
@@ -135,7 +130,9 @@ class _MlpChain(torch.autograd.Function):
         pv = lambda t: None if t is None else t.data_ptr()       # noqa: E731
         _lib.check(L.dwg_mlp_chain_forward(M, Kx, _lib.ptr(x), Kx, nl, vp(*[w.data_ptr() for w in ws]), i32(*[int(w.stride(0)) for w in ws]),
                                            vp(*[pv(b) for b in biases]), i32(*widths), i32(*[gemm.ACT[a] for a in acts]),
-                                           vp(*[pv(h) for h in hidden] + [None]), _lib.ptr(out), widths[-1], _st(x)), "dwg_mlp_chain_forward")
+                                           vp(*[pv(h) for h in hidden] + [None]), _lib.ptr(out), widths[-1],
+                                           _lib.ptr(e) if e is not None else None, int(e.numel()) if e is not None else 0, _st(x)),
+                   "dwg_mlp_chain_forward")
         ctx.acts, ctx.nl = acts, nl
         ctx.has_b = [b is not None for b in bs]
         ctx.has_extra = extra is not None

@@ -29,13 +29,15 @@ int dwg_mlp_wgrad(int32_t M, int32_t N, int32_t K, const float* dz, int32_t lddz
 
 /* A whole per-Gaussian MLP in one launch (nerf_model.py:28-33 / deform_model.py:111-143 forward): h_0 = x [M, Kin] (row stride ldx),
  * h_{l+1} = act_l(h_l W_l^T + b_l) for l < nlayers, W_l [widths[l], K_l] with row stride ldw[l] (only the first K_l columns are read:
- * the pose columns of the deformation network's first layer are folded into its bias by the caller), widths <= 64, Kin and the
+ * `extra` [n_extra] (device; NULL / 0 = none) is a vector every row of the first layer's input is extended by -- the body pose that
+ * deform_model.py:113-115 expands and concatenates: its product with W_0[:, Kin : Kin + n_extra] is the same for all rows and is added to
+ * b_0 inside the launch), widths <= 64, Kin and the
  * hidden widths multiples of 8, acts in {NONE, RELU, LEAKY_RELU, SIGMOID}.  out [M, widths[last]] with row stride ldo.  hidden (may be
  * NULL) holds per hidden layer a [M, widths[l]] buffer that receives h_{l+1} (kept for the backward), or NULL entries.
  * weights / ldw / biases / widths / acts / hidden are HOST arrays of length nlayers (<= 6). */
 int dwg_mlp_chain_forward(int32_t M, int32_t Kin, const float* x, int32_t ldx, int32_t nlayers, const float* const* weights,
                           const int32_t* ldw, const float* const* biases, const int32_t* widths, const int32_t* acts,
-                          float* const* hidden, float* out, int32_t ldo, dwg_stream_t stream);
+                          float* const* hidden, float* out, int32_t ldo, const float* extra, int32_t n_extra, dwg_stream_t stream);
 
 /* The backward of dwg_mlp_chain_forward in one launch + one reduce (nerf_model.py:28-33 / deform_model.py:111-143 under autograd): given
  * dy [M, widths[last]] (row stride lddy), the input x, the kept hidden activations (hidden[l] [M, widths[l]] contiguous, l < nlayers - 1)
