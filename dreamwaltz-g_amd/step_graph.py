@@ -26,11 +26,13 @@ from .rasterizer import PairCapacity
 class GraphedTrainStep:
     def __init__(self, trainer, data: dict, example_pose: Dict[str, torch.Tensor], warmup_poses=None, grow: float = 4.0, capture_pose=None,
                  condition_fn=None, seed_fn=None):
-        """`trainer`: an SDSTrainer whose `diffusion` makes no host round trips and draws no random numbers (the no-guidance image loss of
-        c2); `data`: the loader's dict of the (fixed) camera WITHOUT 'smpl_inputs'; `example_pose`: device tensors, cloned into the graph's
-        static pose buffers.  `condition_fn(pose) -> [1,3,H,W]`: the loader's condition image of the posed body, drawn inside the graph;
-        `seed_fn(step index) -> int`: the seed of the step's device-RNG stream (guidance only).  Building it takes REAL optimizer steps: one per warm-up pose, and one more -- on `capture_pose` (default: the
-        last warm-up pose again) -- at the frozen pair capacity right before the capture."""
+        """`trainer`: an SDSTrainer whose `diffusion` makes no host round trips inside a call -- the no-guidance image loss of c2, or a
+        ControlNetScoreDistillation (recognised by `draw_view_randoms`: its random draws are made here, outside the graph); `data`: the
+        loader's dict of the (fixed) camera WITHOUT 'smpl_inputs'; `example_pose`: device tensors (float32), copied into the graph's static
+        pose buffers.  `condition_fn(pose) -> [1,3,H,W]`: the loader's condition image of the posed body, drawn inside the graph;
+        `seed_fn(step index) -> int`: the seed of the step's device-RNG stream (guidance only; None: the generator just runs on).  Building
+        it takes REAL optimizer steps: one per warm-up pose, and one more -- on `capture_pose` (default: the last warm-up pose again) -- at
+        the frozen pair capacity right before the capture."""
         self.trainer, self.grow = trainer, float(grow)
         self.device = next(iter(example_pose.values())).device
         if self.device.type != "cuda":
@@ -65,7 +67,6 @@ class GraphedTrainStep:
             self._rng = torch.Generator(device=self.device)
             pn, t, n = trainer.diffusion.draw_view_randoms(self._rng, 1, trainer.max_step)
             self._rand = (pn.clone(), t.clone(), n.clone())     # static: refreshed eagerly before every replay
-            self._view_index = None
         # per-step host inputs go through NSLOT rotating pinned twins of the block; a slot is rewritten only after the replay that read it has
         # finished (nothing else throttles the host here: the eager loop is paced by the rasterizer's pair-count event, a replay is not)
         self._slots = [torch.zeros(self._block_floats).pin_memory() for _ in range(4)]
