@@ -9,9 +9,9 @@ pytestmark = pytest.mark.gpu
 # Two EAGER runs of the same steps differ by 1.7e-5 ... 1.2e-4 (relative L2 of the flat parameter buffer after 7-10 Adam steps; five boxes,
 # round 4): a handful of near-zero table gradients change sign with the order of the grid encoder's float adds and Adam (eps 1e-15) moves
 # those entries by 2 lr -- discrete events, so the pairwise distance is heavy-tailed.  A graphed run must stay within 3x the distance of
-# THIS run's eager pair or within the top of that range; the bugs this test has caught (a stale pose: 2.3 %, a rewritten pinned
-# scalar table: 1.3 %) sit two orders of magnitude above it.
-NOISE_FLOOR = 3.0e-4
+# THIS run's eager pair or under a floor several times the top of that range (graphed / eager distances seen: 0.3e-4 ... 1.5e-4); the
+# bugs this test has caught (a stale pose: 2.3 %, a rewritten pinned scalar table: 1.3 %) sit an order of magnitude above the floor.
+NOISE_FLOOR = 1.0e-3
 
 
 def _rel(a, b):
