@@ -99,6 +99,11 @@ SIGNATURES = {
     "dwg_add_bf16": (ctypes.c_int, [_i64, _vp, _vp, _vp, _vp]),
     "dwg_interleave2x2": (ctypes.c_int, [_i32, _i32, _i32, _i32, _vp, _vp, _vp, _vp, _vp, _vp]),
     "dwg_cast_f32_to_bf16": (ctypes.c_int, [_i64, _vp, _vp, _vp]),
+    # include/dwg_sds.h
+    "dwg_sds_posterior_sample": (ctypes.c_int, [_i32, ctypes.c_int64, _vp, _vp, ctypes.c_float, _vp, _vp]),
+    "dwg_sds_posterior_sample_backward": (ctypes.c_int, [_i32, ctypes.c_int64, _vp, _vp, ctypes.c_float, _vp, _vp, _vp]),
+    "dwg_sds_add_noise": (ctypes.c_int, [_i32, ctypes.c_int64, _vp, _vp, _vp, _i32, _vp, _vp, _vp]),
+    "dwg_sds_gradient": (ctypes.c_int, [_i32, ctypes.c_int64, _vp, _vp, _vp, _i32, _vp, ctypes.c_float, _i32, _i32, _vp, _vp, _vp]),
     # include/dwg_gaussian.h
     "dwg_gaussian_assemble_forward": (ctypes.c_int, [_i32, _i32, _vp, _vp, _f32, _vp, _vp, _f32, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
     "dwg_gaussian_assemble_backward": (ctypes.c_int, [_i32, _i32, _f32, _vp, _f32, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp,

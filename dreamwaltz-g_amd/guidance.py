@@ -14,6 +14,8 @@ Attributes other code reads (basic.py:334-335,453): scheduler.scale_model_input,
 pipe.unet.config.sample_size.  Device RNG draw order per call is the reference's (checklist Q12): VAE posterior noise -> timestep ->
 latent noise.  Test-only keyword extensions: noise=, posterior_noise= (fixed draws for parity tests).
 """
+import ctypes
+import os
 import types
 from typing import Dict, List, Optional, Union
 
@@ -21,7 +23,7 @@ import numpy as np
 import torch
 import torch.nn.functional as F
 
-from . import sd15
+from . import _lib, sd15
 from .configs import GuideConfig
 from .pgc import build_grad_hook_func, build_pgc_hook_func
 
@@ -36,6 +38,44 @@ class SpecifyGradient(torch.autograd.Function):
     def backward(ctx, grad_scale):
         (gt_grad,) = ctx.saved_tensors
         return gt_grad * grad_scale, None
+
+
+def _st(t):
+    return ctypes.c_void_p(torch.cuda.current_stream(t.device).cuda_stream)
+
+
+def _fused_ok(*ts):
+    """The one-launch forms of the latent algebra (csrc/sds.hip, include/dwg_sds.h) take fp32 CUDA tensors; DWG_SDS_TORCH=1 keeps the
+    element-wise torch statements (experiments / A-B)."""
+    return not _SDS_TORCH and all(t is not None and t.is_cuda and t.dtype == torch.float32 for t in ts)
+
+
+_SDS_TORCH = os.environ.get("DWG_SDS_TORCH", "0") == "1"
+_WEIGHT_CODE = {None: 0, 'sjc': 0, 'dreamfusion': 1, 'latent-nerf': 2, 'ism': 3}
+
+
+class _PosteriorSample(torch.autograd.Function):
+    """vae.py:34-40 after the encoder: DiagonalGaussianDistribution(moments).sample() * scaling_factor with the given noise, one launch each
+    way (include/dwg_sds.h dwg_sds_posterior_sample / _backward) instead of seven element-wise statements and their autograd twins."""
+
+    @staticmethod
+    def forward(ctx, moments, noise, scale):
+        m, e = moments.contiguous(), noise.contiguous()
+        V, n = m.shape[0], m[0].numel() // 2
+        out = torch.empty_like(e)
+        _lib.check(_lib.lib().dwg_sds_posterior_sample(V, n, _lib.ptr(m), _lib.ptr(e), float(scale), _lib.ptr(out), _st(m)), "dwg_sds_posterior_sample")
+        ctx.save_for_backward(m, e)
+        ctx.scale = float(scale)
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        m, e = ctx.saved_tensors
+        g = g.contiguous().float()
+        gm = torch.empty_like(m)
+        _lib.check(_lib.lib().dwg_sds_posterior_sample_backward(m.shape[0], m[0].numel() // 2, _lib.ptr(m), _lib.ptr(e), ctx.scale, _lib.ptr(g),
+                                                                _lib.ptr(gm), _st(m)), "dwg_sds_posterior_sample_backward")
+        return gm, None, None
 
 
 class _VAEEncode(torch.autograd.Function):
@@ -155,6 +195,15 @@ class ControlNetScoreDistillation:
 
     def add_noise(self, latents, noise, timestep):
         """DDPMScheduler.add_noise [3P-memory]: sqrt(acp_t) x + sqrt(1 - acp_t) eps."""
+        if (_fused_ok(latents, noise) and not (latents.requires_grad and torch.is_grad_enabled()) and torch.is_tensor(timestep) and timestep.is_cuda
+                and timestep.dtype == torch.long and timestep.numel() == latents.shape[0] and latents[0].numel() % 4 == 0
+                and latents.shape == noise.shape):
+            x, e = latents.contiguous(), noise.contiguous()
+            out = torch.empty_like(x)
+            _lib.check(_lib.lib().dwg_sds_add_noise(x.shape[0], x[0].numel(), _lib.ptr(x), _lib.ptr(e), _lib.ptr(self.alphas_cumprod),
+                                                    int(self.alphas_cumprod.numel()), _lib.ptr(timestep.contiguous()), _lib.ptr(out), _st(x)),
+                       "dwg_sds_add_noise")
+            return out
         a = self.alphas_cumprod[timestep].reshape(-1, 1, 1, 1)
         return a.sqrt() * latents + (1 - a).sqrt() * noise
 
@@ -175,9 +224,11 @@ class ControlNetScoreDistillation:
     def encode_images(self, images: torch.Tensor, posterior_noise: Optional[torch.Tensor] = None, generator=None) -> torch.Tensor:
         moments = _VAEEncode.apply(images, self.vae)
         mean, logvar = moments.chunk(2, dim=1)
-        std = torch.exp(0.5 * torch.clamp(logvar, -30.0, 20.0))
         if posterior_noise is None:
             posterior_noise = torch.randn(mean.shape, device=mean.device, dtype=mean.dtype, generator=generator)      # RNG draw #1
+        if _fused_ok(moments, posterior_noise) and moments[0].numel() % 8 == 0:
+            return _PosteriorSample.apply(moments, posterior_noise, self.scaling_factor)
+        std = torch.exp(0.5 * torch.clamp(logvar, -30.0, 20.0))
         return (mean + std * posterior_noise) * self.scaling_factor
 
     def prepare_latents(self, inputs: torch.Tensor, posterior_noise=None, generator=None):
@@ -260,6 +311,18 @@ class ControlNetScoreDistillation:
             raise NotImplementedError("guidance_scale <= 1 (no classifier-free guidance): the plans are built for the CFG batch of 2")
         latents_model_input = self.scheduler.scale_model_input(latents_model_input, self.timestep)
         noise_pred = self._predict(latents_model_input, text_embeddings, **kwargs)
+        plain = not (guidance_rescale > 0.0 or self.cfg.grad_latent_clip or self.cfg.grad_latent_norm) and self.weight_type in _WEIGHT_CODE
+        if (plain and _fused_ok(noise_pred, noise) and noise_pred.shape[0] == 2 * noise.shape[0] and noise_pred.shape[1:] == noise.shape[1:]
+                and noise[0].numel() % 4 == 0 and torch.is_tensor(self.timestep) and self.timestep.is_cuda and self.timestep.dtype == torch.long
+                and self.timestep.numel() == noise.shape[0]):
+            # basic.py:602-646 in one launch: classifier-free combination, minus the noise, timestep weight, nan_to_num
+            noise_pred, noise = noise_pred.contiguous(), noise.contiguous()       # (the plan hands its output over as a channels-last view)
+            gradients, combined = torch.empty_like(noise), torch.empty_like(noise)
+            _lib.check(_lib.lib().dwg_sds_gradient(noise.shape[0], noise[0].numel(), _lib.ptr(noise_pred), _lib.ptr(noise), _lib.ptr(self.alphas_cumprod),
+                                                   int(self.alphas_cumprod.numel()), _lib.ptr(self.timestep.contiguous()), float(self.guidance_scale),
+                                                   _WEIGHT_CODE[self.weight_type], int(bool(self.cfg.grad_latent_nan_to_num)), _lib.ptr(gradients),
+                                                   _lib.ptr(combined), _st(noise)), "dwg_sds_gradient")
+            return gradients, combined, text_embeddings
         noise_pred_uncond, noise_pred_text = noise_pred.chunk(2)
         noise_pred = noise_pred_uncond + self.guidance_scale * (noise_pred_text - noise_pred_uncond)
         if guidance_rescale > 0.0:

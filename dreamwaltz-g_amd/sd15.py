@@ -845,6 +845,7 @@ class DenoiserPlan:
 
     def __init__(self, cfg: UNetConfig, unet_sd, cn_sd, device, batch=2, latent_hw=64, text_len=77, dtype="bf16", views=1, weights=None):
         self.cfg, self.device, self.B, self.hw, self.views = cfg, device, batch, latent_hw, int(views)
+        self._temb_table = None
         assert batch % self.views == 0, (batch, views)
         self.plan = Plan(device, dtype)
         p = self.plan
@@ -907,7 +908,13 @@ class DenoiserPlan:
         if t.numel() not in (1, self.B):
             assert self.B % t.numel() == 0, (self.B, t.numel())
             t = t.repeat(self.B // t.numel())                 # [t_0..t_{V-1} | t_0..t_{V-1}]: the batch order of the CFG halves
-        te = timestep_embedding(t.expand(self.B), self.cfg.block_out_channels[0])
+        if t.dtype == torch.long and t.is_cuda:
+            # integer timesteps: rows of a table computed once with the same statements (eight element-wise launches per call otherwise)
+            if self._temb_table is None:
+                self._temb_table = timestep_embedding(torch.arange(1000, device=t.device), self.cfg.block_out_channels[0])
+            te = self._temb_table.index_select(0, t.expand(self.B))
+        else:
+            te = timestep_embedding(t.expand(self.B), self.cfg.block_out_channels[0])
         p.store(self.temb_u.tin, te); p.store(self.temb_c.tin, te)
         p.store(self.text, text)
         if cond_nchw is not None:
