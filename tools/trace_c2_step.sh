@@ -1,11 +1,11 @@
 #!/bin/bash
 # where the captured c2 step (1.5 ms) goes: per-kernel trace of graph replays + the torch-op inventory of the step
-mkdir -p gpurun_out/r4l
+mkdir -p gpurun_out/c2_trace
 cd /root/repo
-timeout 300 python tools/count_torch_ops.py > gpurun_out/r4l/torch_ops.log 2>&1
+timeout 300 python tools/count_torch_ops.py > gpurun_out/c2_trace/torch_ops.log 2>&1
 export TMPDIR=/tmp
-timeout 600 rocprofv3 --kernel-trace --output-format csv -d gpurun_out/r4l/trace -- python bench.py --config c2 --step-graph --headline-only --steps 50 --warmup 10 > gpurun_out/r4l/c2.log 2>&1
-f=$(ls gpurun_out/r4l/trace/*/*kernel_trace.csv | head -1)
+timeout 600 rocprofv3 --kernel-trace --output-format csv -d gpurun_out/c2_trace/trace -- python bench.py --config c2 --step-graph --headline-only --steps 50 --warmup 10 > gpurun_out/c2_trace/c2.log 2>&1
+f=$(ls gpurun_out/c2_trace/trace/*/*kernel_trace.csv | head -1)
 python - "$f" <<'PY'
 import csv, sys, collections
 rows = list(csv.DictReader(open(sys.argv[1])))
