@@ -6,7 +6,7 @@ set -u
 R=${1:-r04}
 COMMIT=${2:-unknown}
 # DWG_PROFILE_PARTS: which passes to run (default all): eager graph pmc bench
-PARTS=${DWG_PROFILE_PARTS:-"eager graph pmc sq bench"}
+PARTS=${DWG_PROFILE_PARTS:-"eager graph pmc sq bench small"}
 has() { case " $PARTS " in *" $1 "*) return 0;; *) return 1;; esac; }
 REPO=$(cd "$(dirname "$0")/.." && pwd)
 OUT=$REPO/gpurun_out/prof_$R
@@ -27,6 +27,15 @@ has graph && cp $(find $OUT/graph -name "*kernel_stats.csv" | head -1) profiles/
 has pmc && python tools/pmc_traffic.py $(find $OUT/pmc_fetch -name "*counter_collection.csv" | head -1) $(find $OUT/pmc_write -name "*counter_collection.csv" | head -1) profiles/${R}_pmc_traffic.json $COMMIT ${DWG_PROFILE_DTYPE:-f32x} > $OUT/pmc_traffic.log 2>&1
 has pmc && tail -2 $OUT/pmc_traffic.log
 has eager && grep '^{"metric"' $OUT/eager.log | tail -1 > profiles/${R}_sds_step_eager_bench_line.json
+# the two captured small configurations: per-kernel statistics of the replayed c2 step and c1 frame
+if has small; then
+cd /tmp
+timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/c2 -o c2 -- python $REPO/bench.py --config c2 --step-graph --headline-only --no-cpu-baseline --steps 200 --warmup 20 > $OUT/c2.log 2>&1
+timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/c1 -o c1 -- python $REPO/bench.py --config c1 --headline-only --no-cpu-baseline --steps 200 --warmup 20 > $OUT/c1.log 2>&1
+cd $REPO
+cp $(find $OUT/c2 -name "*kernel_stats.csv" | head -1) profiles/${R}_c2_step_graph_kernel_stats.csv
+cp $(find $OUT/c1 -name "*kernel_stats.csv" | head -1) profiles/${R}_c1_frame_graph_kernel_stats.csv
+fi
 # bench lines (the default command, then the two other BASELINE configs)
 if has bench; then
 # the default command carries c1 / c2 / c4 (8 views on one GPU) / c5 and the fp32 line as attachments
