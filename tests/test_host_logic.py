@@ -286,3 +286,33 @@ def test_flat_optimizer_leaves_groups_without_a_gradient_alone_like_torch_adam()
         assert not torch.equal(before, b.data) and opts["avatar"].param_groups[1]["t"] == 4
     finally:
         optim.FlatOptimizer._launch = saved
+
+
+def test_mlp_gradients_go_in_place_only_into_genuine_flat_gradient_slices():
+    """mlp._flat_slice decides whether the fused MLP backward may ADD a parameter's gradient straight into `p.grad` (no AccumulateGrad
+    launch): only for a leaf Parameter marked by optim.FlatBuffers whose .grad is the contiguous fp32 slice of its own shape and whose
+    values the kernels read in place; everything else goes through autograd as usual."""
+    from dreamwaltz_g_amd import gridencoder, mlp
+    w, b = torch.nn.Parameter(torch.randn(8, 16)), torch.nn.Parameter(torch.randn(8))
+    other = torch.nn.Parameter(torch.randn(8, 16))
+    flat = optim.FlatBuffers([w, b], torch.device("cpu"))
+    assert mlp._flat_slice(w, w) is flat and mlp._flat_slice(b, None) is flat
+    assert mlp._flat_slice(other, other) is None                                   # not part of a flat buffer
+    assert mlp._flat_slice(None, None) is None                                     # a layer without a bias
+    assert mlp._flat_slice(w, w.detach().clone()) is None                          # the kernels read a COPY (dtype / layout conversion)
+    cat = torch.cat([w, other], 0)
+    assert mlp._flat_slice(cat, cat) is None                                       # a concatenation of parameters is not a leaf
+    g = w.grad
+    w.grad = None
+    assert mlp._flat_slice(w, w) is None                                           # zero_grad(set_to_none=True)-style callers
+    w.grad = g.t().contiguous().t()                                                # same shape, not contiguous: not the flat slice
+    assert mlp._flat_slice(w, w) is None
+    w.grad = g
+    assert mlp._flat_slice(w, w) is flat
+    flat.release([w, b])
+    assert mlp._flat_slice(w, w) is None                                           # buffers replaced (densifier resize): no stale target
+    # concurrent backwards (the views of a batched step on their own streams) opt out through the grid encoder's switch
+    assert mlp._inplace_allowed()
+    with gridencoder.table_grad_inplace(False):
+        assert not mlp._inplace_allowed()
+    assert mlp._inplace_allowed()
