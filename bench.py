@@ -274,7 +274,7 @@ def raster_report(prof, G, Kref, K, P, steps, pmc=False):
     tj, stale = _traffic() if pmc else (None, None)
     if tj is not None:       # HBM bytes per frame from the PMC passes (taken on the default c3 workload only)
         tk = tj["kernels"]
-        fwd = ("k_preprocess", "k_scan_tiles", "k_scatter", "k_tile_sort", "k_tile_sort_regs", "k_render_fwd", "k_camera_setup")
+        fwd = ("k_preprocess", "k_scan_super", "k_scatter_super", "k_sort_super", "k_scan_tiles", "k_render_fwd", "k_camera_setup")
         bwd = ("k_render_bwd", "k_gather_partials", "k_preprocess_bwd")
         for key, names in (("raster_forward", fwd), ("raster_backward", bwd)):
             if key in out:

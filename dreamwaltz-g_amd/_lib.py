@@ -25,6 +25,11 @@ class RasterSettingsC(ctypes.Structure):
     ]
 
 
+class RasterFramesC(ctypes.Structure):
+    """struct dwg_raster_frames (include/dwg_raster.h)."""
+    _fields_ = [("num_frames", ctypes.c_int32), ("gaussian_stride", ctypes.c_int64), ("camera_stride", ctypes.c_int64)]
+
+
 # name -> (restype, argtypes); every symbol include/*.h declares must be listed here (tests check it)
 _vp, _i32, _i64, _f32, _sz = ctypes.c_void_p, ctypes.c_int32, ctypes.c_int64, ctypes.c_float, ctypes.c_size_t
 _u32 = ctypes.c_uint32
@@ -36,6 +41,9 @@ SIGNATURES = {
     "dwg_raster_forward_bin": (ctypes.c_int, [ctypes.POINTER(RasterSettingsC), _i32] + [_vp] * 9 + [_vp]),
     "dwg_raster_forward_render": (ctypes.c_int, [ctypes.POINTER(RasterSettingsC), _i32, _vp, _vp, _i64, _vp, _vp, _vp,
                                                  _vp, _vp]),
+    "dwg_raster_forward_bin_frames": (ctypes.c_int, [ctypes.POINTER(RasterSettingsC), ctypes.POINTER(RasterFramesC), _i32] + [_vp] * 9 + [_vp]),
+    "dwg_raster_forward_render_frames": (ctypes.c_int, [ctypes.POINTER(RasterSettingsC), ctypes.POINTER(RasterFramesC), _i32, _vp, _vp, _i64, _vp,
+                                                        _vp, _vp, _vp, _vp]),
     "dwg_raster_backward": (ctypes.c_int, [ctypes.POINTER(RasterSettingsC), _i32] + [_vp] * 7 + [_vp, _vp, _i64, _vp, _vp]
                             + [_vp] * 3 + [_vp] * 8 + [_vp]),
     # include/dwg_lbs.h

@@ -8,24 +8,30 @@
 // pixel's 16x16 screen tile.  The WORK decomposition is not the reference's:
 //
 //   * one wave64 owns one 8x8 pixel block (a quarter of a reference tile): per-block lists are ~2x shorter than per-tile
-//     lists, the forward needs no barrier, and the backward reduces per-splat partials with DPP adds inside ONE wave;
+//     lists, the forward needs no barrier, and the backward reduces per-splat partials inside ONE wave;
 //   * exact pair culling: a (Gaussian, block) pair is only emitted if some pixel of the block can reach alpha >= 1/255
 //     (minimum of the conic's quadratic form over the block rectangle against 2 ln(255 opacity), with a safety margin far
 //     above fp32 rounding) -- pairs the per-pixel test would reject for all 64 pixels never exist, results are unchanged;
-//   * per-block depth sort: ascending-only bitonic network on 64-bit (depth bits, id) keys in LDS, dispatched by size class
-//     (one wave per block up to 1024 pairs, one 256-thread workgroup up to 4096, one 1024-thread workgroup up to 16384);
+//   * round 5 -- SORT COARSE, SPLIT FINE: Gaussians are binned and depth-sorted per 32x32-pixel SUPERTILE (4x4 blocks; ~4x
+//     fewer keys than (Gaussian, block) pairs, one register-blocked bitonic network per supertile), and the sorted list is
+//     split STABLY into its sixteen block lists by the sorting workgroup itself (a block's list is a subsequence of its
+//     supertile's).  This replaced a per-block 64-bit sort of every pair (102 of the 290 us forward chain at 100 k
+//     Gaussians / 512^2) and the per-pair LDS histogram / scatter atomics of the two binning kernels (39 + 63 us);
 //   * the forward checkpoints the per-pixel compositing state every SEG splats; the backward then runs one wave per
 //     (block, segment) FRONT-TO-BACK from its checkpoint -- perfectly balanced, no serial chain over a long list -- using
 //     "sum over later splats" = (final sum) - (prefix sum);
-//   * blocks are rendered longest-list-first (bucketed by log2 of the list length).
+//   * blocks are rendered longest-list-first (bucketed by log2 of the list length);
+//   * every forward kernel runs on a (work, frames) grid: F frames (poses and / or cameras) per launch chain.
 //
-//   stage A  k_preprocess      1 thread / Gaussian: project, EWA covariance, 3-sigma radius, tile rect, 48-byte splat record
-//                              (3 x float4, 16-B aligned gathers), exact-culled per-block histogram (LDS-privatised)
-//            k_scan_tiles      one workgroup: exclusive scans (pairs, segments), size-class lists, render order
-//   stage B  k_scatter         1 thread / Gaussian: (depth|id) 64-bit key into its blocks' ranges
-//            k_tile_sort       bitonic network per block, by size class
+//   stage A  k_preprocess      1 thread / Gaussian, index order (coalesced): project, EWA covariance, 3-sigma radius, tile rect,
+//                              48-byte splat record, exact pair count (scanline), supertile histogram (LDS-privatised)
+//            k_scan_super      supertile starts + size classes; per-Gaussian pair-row offsets (goff); the frame's pair count
+//   stage B  k_scatter_super   1 thread / Gaussian: (depth|id) 64-bit key into its supertiles' ranges
+//            k_sort_super      1 workgroup / supertile: sort, 16-bit block masks, stable split into the sixteen block lists
+//            k_scan_tiles      segment starts, render order, frame tag
 //            k_render_fwd      1 wave / block, records staged through LDS, next batch prefetched into registers
-//   backward k_render_bwd      1 wave / (block, segment), one global atomic per (splat, block, component)
+//   backward k_render_bwd      1 wave / (block, segment): pair-ordered partial rows, no atomics
+//            k_gather_partials per-Gaussian sum of its rows
 //            k_preprocess_bwd  1 thread / Gaussian: conic -> cov2D -> cov3D -> (scale, quaternion), mean chain
 #include "dwg_common.h"
 #include <atomic>
@@ -36,6 +42,7 @@ namespace {
 
 #define RT 16            // the reference's tile edge: decides WHICH Gaussians a pixel sees
 #define BT 8             // pixel-block edge of this implementation (one wave64)
+#define ST 4             // blocks per supertile edge: Gaussians are binned and depth-sorted per 32x32-pixel supertile
 #define SEG 128          // splats per backward segment / forward checkpoint interval
 #define NCLASS 4         // sort size classes
 #define NBUCKET 20       // render-order buckets (log2 of the list length)
@@ -53,10 +60,17 @@ struct Params {
     const float* proj;
     const float* campos;
     const int32_t* visit_order;         // permutation in which the binning stages walk the Gaussians (NULL: index order)
+    int stiles_x, stiles_y;             // supertiles (ST x ST blocks)
+    // frames (blockIdx.y of the forward kernels): distance between consecutive frames'
+    int64_t in_stride;                  // ... per-Gaussian input rows, in Gaussians (0: every frame reads the same rows)
+    int64_t cam_stride;                 // ... viewmatrix / projmatrix / campos, in floats (0: one camera)
+    size_t geom_stride, pairs_stride, image_stride;      // ... workspaces, in bytes
+    int dbg;                            // DWG_RASTER_DEBUG bits (timing experiments; results are garbage): 1 no sort network, 2 no block masks, 4 no split
 };
 
 // header words of the geometry workspace
-enum { H_K = 0, H_OVERFLOW = 1, H_KREF = 2, H_NSEG = 3, H_CLASS0 = 4 /* .. +NCLASS */, H_TAG = 4 + NCLASS };
+enum { H_K = 0, H_OVERFLOW = 1, H_KREF = 2, H_NSEG = 3, H_CLASS0 = 4 /* .. +NCLASS */, H_TAG = 4 + NCLASS,
+       H_KS = 5 + NCLASS /* (Gaussian, supertile) pairs */, H_POOL = 6 + NCLASS /* running end of the block lists handed out so far */ };
 
 // Frame tags of the backward's pair-ordered partial rows (k_render_bwd / k_gather_partials) are drawn ON THE DEVICE, by the forward's scan
 // kernel, from this counter: a tag chosen by the host at launch time is a kernel argument, and kernel arguments are frozen into a captured
@@ -65,12 +79,14 @@ enum { H_K = 0, H_OVERFLOW = 1, H_KREF = 2, H_NSEG = 3, H_CLASS0 = 4 /* .. +NCLA
 __device__ uint32_t g_frame_tag = 0x5eed0001u;
 
 struct GeomLayout {
-    size_t header, rec0, rec1, rec2, rect, npairs, goff, tile_count, tile_cursor, idsum, tile_start, seg_start, tile_neff, order, cls, total;
+    size_t header, rec0, rec1, rec2, rect, npairs, goff, tile_count, super_count, super_cursor, idsum, zero_end, tile_start, super_start, seg_start,
+        tile_neff, order, cls, total;
 };
 
 static GeomLayout geom_layout(int G, int H, int W) {
     GeomLayout L;
     size_t T = (size_t)dwg_cdiv(W, BT) * dwg_cdiv(H, BT);
+    size_t S = (size_t)dwg_cdiv(dwg_cdiv(W, BT), ST) * dwg_cdiv(dwg_cdiv(H, BT), ST);
     size_t g = (size_t)(G > 0 ? G : 1);
     size_t o = 0;
     L.header = o; o += 256;
@@ -80,14 +96,17 @@ static GeomLayout geom_layout(int G, int H, int W) {
     L.rect = o; o = dwg_align_up(o + g * sizeof(uint2), 256);
     L.npairs = o; o = dwg_align_up(o + g * 4, 256);              // (Gaussian, block) pairs of every Gaussian after exact culling ...
     L.goff = o; o = dwg_align_up(o + (g + 1) * 4, 256);          // ... and their exclusive prefix in INDEX order: pair row q = goff[g] + e
-    L.tile_count = o; o = dwg_align_up(o + T * 4, 256);      // tile_count, tile_cursor and idsum are cleared together
-    L.tile_cursor = o; o = dwg_align_up(o + T * 4, 256);
+    L.tile_count = o; o = dwg_align_up(o + T * 4, 256);          // tile_count .. idsum are cleared together (one memset per frame)
+    L.super_count = o; o = dwg_align_up(o + S * 4, 256);
+    L.super_cursor = o; o = dwg_align_up(o + S * 4, 256);
     L.idsum = o; o = dwg_align_up(o + (g / IDBIN + 2) * 4, 256);   // pair count of every run of IDBIN Gaussian indices (integer atomics: exact)
-    L.tile_start = o; o = dwg_align_up(o + (T + 1) * 4, 256);
+    L.zero_end = o;
+    L.tile_start = o; o = dwg_align_up(o + T * 4, 256);          // a block's list is sorted[tile_start, tile_start + tile_count)
+    L.super_start = o; o = dwg_align_up(o + (S + 1) * 4, 256);
     L.seg_start = o; o = dwg_align_up(o + (T + 1) * 4, 256);
     L.tile_neff = o; o = dwg_align_up(o + T * 4, 256);
     L.order = o; o = dwg_align_up(o + T * 4, 256);
-    L.cls = o; o = dwg_align_up(o + (size_t)NCLASS * T * 4, 256);
+    L.cls = o; o = dwg_align_up(o + (size_t)NCLASS * S * 4, 256);
     L.total = o;
     return L;
 }
@@ -141,7 +160,7 @@ __device__ __forceinline__ void quat_to_R(float4 q, float R[9]) {
     R[3] = 2.f * (x * y + r * z);       R[4] = 1.f - 2.f * (x * x + z * z); R[5] = 2.f * (y * z - r * x);
     R[6] = 2.f * (x * z - r * y);       R[7] = 2.f * (y * z + r * x);       R[8] = 1.f - 2.f * (x * x + y * y);
 }
-__device__ __forceinline__ void cov3d_of(const float* scales, const float* rots, const float* cov3Dp, int i,
+__device__ __forceinline__ void cov3d_of(const float* scales, const float* rots, const float* cov3Dp, size_t i,
                                          float mod, float c6[6]) {
     if (cov3Dp) {
 #pragma unroll
@@ -266,6 +285,9 @@ struct BlockSpan {
 };
 __device__ __forceinline__ BlockSpan block_span(float gx, float gy, float ca, float cb, float cc, float opacity, int tx0, int ty0, int tx1,
                                                 int ty1, int tiles_x, int tiles_y) {
+    // four kernels (pair count, supertile keys, block masks, the backward's row index) evaluate this enumeration and must agree to the bit:
+    // no contraction, so that the result never depends on what a call site's surrounding code lets the backend fuse
+#pragma clang fp contract(off)
     BlockSpan s;
     s.gx = gx; s.gy = gy; s.ca = ca; s.cb = cb; s.cc = cc;
     s.bx0 = 2 * tx0; s.bx1 = min(2 * tx1, tiles_x); s.by0 = 2 * ty0; s.by1 = min(2 * ty1, tiles_y);
@@ -284,6 +306,7 @@ __device__ __forceinline__ BlockSpan block_span(float gx, float gy, float ca, fl
 }
 // columns [xa, xb) of block row `by` the splat reaches
 __device__ __forceinline__ void block_row(const BlockSpan& s, int by, int* xa, int* xb) {
+#pragma clang fp contract(off)
     if (s.all) { *xa = s.bx0; *xb = s.bx1; return; }
     const float y0 = (float)(by * BT) - s.gy, y1 = y0 + (float)(BT - 1);
     const float ya = fmaxf(y0, -s.hy), yb = fminf(y1, s.hy);
@@ -296,19 +319,36 @@ __device__ __forceinline__ void block_row(const BlockSpan& s, int by, int* xa, i
     *xa = max(a, s.bx0); *xb = min(b, s.bx1);
 }
 
-// A splat whose block rectangle is large is enumerated by the WHOLE wave (16 block rows x 4 column phases at a time) instead of by the
-// one lane that owns it: the pair counts are heavy-tailed (c5: radius median 20 px, 1 % above 82 px), and with one lane per Gaussian the
-// sum of per-wave maxima was 2.5x the mean work of the two binning stages (tools/diag_binning_balance.py).
-#define BIG_SPLAT_BLOCKS 32
-__device__ __forceinline__ BlockSpan span_from_lane(const BlockSpan& s, int src) {
-    BlockSpan o;
-    o.by0 = __shfl(s.by0, src); o.by1 = __shfl(s.by1, src); o.bx0 = __shfl(s.bx0, src); o.bx1 = __shfl(s.bx1, src);
-    o.gx = __shfl(s.gx, src); o.gy = __shfl(s.gy, src); o.ca = __shfl(s.ca, src); o.cb = __shfl(s.cb, src); o.cc = __shfl(s.cc, src);
-    o.thr = __shfl(s.thr, src); o.det = __shfl(s.det, src); o.hy = __shfl(s.hy, src); o.yr = __shfl(s.yr, src);
-    o.all = __shfl((int)s.all, src) != 0;
-    return o;
+// ------------------------------------------------------------------------------------------------
+// frames: every forward kernel is launched on a (work, F) grid; blockIdx.y = frame, whose inputs / camera / workspaces / outputs lie at a
+// fixed stride behind frame 0's (Params::*_stride).  F = 1 for the autograd path; the playback path renders several posed frames per launch.
+// ------------------------------------------------------------------------------------------------
+template <typename T>
+__device__ __forceinline__ T* frame_ptr(T* p, size_t stride_bytes) {
+    return p ? (T*)((const char*)p + stride_bytes * blockIdx.y) : p;
 }
-__device__ __forceinline__ bool span_is_big(const BlockSpan& s) { return (s.by1 - s.by0) * (s.bx1 - s.bx0) > BIG_SPLAT_BLOCKS; }
+#define DWG_GEOM(ptr) ptr = frame_ptr(ptr, p.geom_stride)
+#define DWG_PAIRS(ptr) ptr = frame_ptr(ptr, p.pairs_stride)
+#define DWG_IMAGE(ptr) ptr = frame_ptr(ptr, p.image_stride)
+
+// The supertiles a splat reaches, by block-row scanline: the blocks of one supertile row (ST block rows) span columns [cmin, cmax), so the
+// supertiles are the contiguous run cmin / ST .. (cmax - 1) / ST of that row.  Returns the splat's exact (Gaussian, block) pair count.
+// k_preprocess (counts) and k_scatter_super (keys) run this very function on the same inputs: their enumerations agree by construction.
+template <typename Fn>
+__device__ __forceinline__ uint32_t for_each_supertile(const BlockSpan& sp, Fn&& fn) {
+    uint32_t ng = 0;
+    int cmin = 0x7fffffff, cmax = -1;
+    for (int by = sp.by0; by < sp.by1; by++) {
+        int xa, xb;
+        block_row(sp, by, &xa, &xb);
+        if (xb > xa) { ng += (uint32_t)(xb - xa); cmin = min(cmin, xa); cmax = max(cmax, xb); }
+        if ((by & (ST - 1)) == ST - 1 || by == sp.by1 - 1) {
+            if (cmax > cmin) { const int sy = by / ST; for (int sx = cmin / ST; sx <= (cmax - 1) / ST; sx++) fn(sy, sx); }
+            cmin = 0x7fffffff; cmax = -1;
+        }
+    }
+    return ng;
+}
 
 // ------------------------------------------------------------------------------------------------
 // stage A
@@ -320,20 +360,27 @@ __global__ __launch_bounds__(256) void k_preprocess(Params p, const float* __res
                                                     int* __restrict__ radii, float4* __restrict__ rec0,
                                                     float4* __restrict__ rec1, float4* __restrict__ rec2,
                                                     uint2* __restrict__ rect, uint32_t* __restrict__ npairs, uint32_t* __restrict__ idsum,
-                                                    uint32_t* __restrict__ tile_count, int32_t* __restrict__ header, int use_lds_hist) {
-    __shared__ float cam[32];
-    extern __shared__ uint32_t hist[];      // [T] block-private histogram (hot blocks: one global atomic per workgroup, not per splat)
-    const int T = p.tiles_x * p.tiles_y;
-    if (threadIdx.x < 16) cam[threadIdx.x] = p.view[threadIdx.x];
-    else if (threadIdx.x < 32) cam[threadIdx.x] = p.proj[threadIdx.x - 16];
-    if (use_lds_hist) for (int t = threadIdx.x; t < T; t += 256) hist[t] = 0u;
+                                                    uint32_t* __restrict__ super_count, int32_t* __restrict__ header, int use_lds_hist) {
+    __shared__ float cam[35];
+    extern __shared__ uint32_t hist[];      // [S] workgroup-private supertile histogram (one global atomic per workgroup and supertile)
+    const int S = p.stiles_x * p.stiles_y;
+    DWG_GEOM(rec0); DWG_GEOM(rec1); DWG_GEOM(rec2); DWG_GEOM(rect); DWG_GEOM(npairs); DWG_GEOM(idsum); DWG_GEOM(super_count); DWG_GEOM(header);
+    const size_t go = (size_t)blockIdx.y * (size_t)p.in_stride;            // this frame's first input row
+    const size_t co = (size_t)blockIdx.y * (size_t)p.cam_stride;
+    radii += (size_t)blockIdx.y * p.G;
+    if (threadIdx.x < 16) cam[threadIdx.x] = p.view[co + threadIdx.x];
+    else if (threadIdx.x < 32) cam[threadIdx.x] = p.proj[co + threadIdx.x - 16];
+    else if (threadIdx.x < 35 && p.campos) cam[threadIdx.x] = p.campos[co + threadIdx.x - 32];
+    if (use_lds_hist) for (int t = threadIdx.x; t < S; t += 256) hist[t] = 0u;
     __syncthreads();
     int i = blockIdx.x * 256 + threadIdx.x;
     const bool live_thread = i < p.G;
     if (!live_thread) i = 0;
     else if (p.visit_order) i = p.visit_order[i];
+    const size_t gi = go + (size_t)i;
     const float* view = cam; const float* proj = cam + 16;
-    float3 pos = make_float3(means3D[3 * i], means3D[3 * i + 1], means3D[3 * i + 2]);
+    float3 pos = make_float3(0.f, 0.f, 0.f);
+    if (p.G > 0) pos = make_float3(means3D[3 * gi], means3D[3 * gi + 1], means3D[3 * gi + 2]);
     int radius = 0;
     uint2 rc = make_uint2(0u, 0u);
     float4 r0 = make_float4(0.f, 0.f, 0.f, 0.f), r1 = r0, r2 = r0;
@@ -347,7 +394,7 @@ __global__ __launch_bounds__(256) void k_preprocess(Params p, const float* __res
         float pw = 1.f / (ph.w + 1e-7f);
         float ndcx = ph.x * pw, ndcy = ph.y * pw;
         float c6[6];
-        cov3d_of(scales, rots, cov3Dp, i, p.scale_mod, c6);
+        cov3d_of(scales, rots, cov3Dp, gi, p.scale_mod, c6);
         Ewa e = ewa_project(p, view, pv, c6);
         float det = e.a * e.c - e.b * e.b;
         if (det != 0.f) {
@@ -367,9 +414,9 @@ __global__ __launch_bounds__(256) void k_preprocess(Params p, const float* __res
                 rc = make_uint2((unsigned)tx0 | ((unsigned)ty0 << 16), (unsigned)tx1 | ((unsigned)ty1 << 16));
                 kref = (float)((tx1 - tx0) * (ty1 - ty0));
                 float3 col; unsigned cb = 0;
-                if (colors) col = make_float3(colors[3 * i], colors[3 * i + 1], colors[3 * i + 2]);
-                else col = sh_color(p.sh_degree, p.sh_coeffs, shs + (size_t)i * p.sh_coeffs * 3, pos, p.campos, &cb);
-                const float op = opac[i];
+                if (colors) col = make_float3(colors[3 * gi], colors[3 * gi + 1], colors[3 * gi + 2]);
+                else col = sh_color(p.sh_degree, p.sh_coeffs, shs + gi * p.sh_coeffs * 3, pos, cam + 32, &cb);
+                const float op = opac[gi];
                 r0 = make_float4(px, py, pv.z, op);
                 r1 = make_float4(e.c * di, -e.b * di, e.a * di, 0.f);
                 r2 = make_float4(col.x, col.y, col.z, __uint_as_float(cb));
@@ -377,40 +424,11 @@ __global__ __launch_bounds__(256) void k_preprocess(Params p, const float* __res
             }
         }
     }
-    uint32_t ng = 0;     // this Gaussian's (Gaussian, block) pairs: its rows of the pair-ordered backward partials (k_scan_tiles scans them)
-    {   // exact-culled per-block histogram: small splats by their own lane, big ones by the whole wave
-        const bool big = span_is_big(sp);
-        if (!big) {
-            for (int by = sp.by0; by < sp.by1; by++) {
-                int xa, xb;
-                block_row(sp, by, &xa, &xb);
-                ng += (uint32_t)max(0, xb - xa);
-                for (int bx = xa; bx < xb; bx++) {
-                    if (use_lds_hist) atomicAdd(&hist[by * p.tiles_x + bx], 1u);
-                    else atomicAdd(&tile_count[by * p.tiles_x + bx], 1u);
-                }
-            }
-        }
-        unsigned long long m = __ballot(big);
-        const int lane = threadIdx.x & 63;
-        while (m) {
-            const int src = __ffsll((long long)m) - 1;
-            m &= m - 1;
-            const BlockSpan w = span_from_lane(sp, src);
-            int rows_blocks = 0;
-            for (int by = w.by0 + (lane >> 2); by < w.by1; by += 16) {
-                int xa, xb;
-                block_row(w, by, &xa, &xb);
-                if ((lane & 3) == 0) rows_blocks += max(0, xb - xa);
-                for (int bx = xa + (lane & 3); bx < xb; bx += 4) {
-                    if (use_lds_hist) atomicAdd(&hist[by * p.tiles_x + bx], 1u);
-                    else atomicAdd(&tile_count[by * p.tiles_x + bx], 1u);
-                }
-            }
-            const int tot = (int)dwg_wave_sum_all((float)rows_blocks);      // < 2^24 blocks: exact in fp32
-            if (lane == src) ng = (uint32_t)tot;
-        }
-    }
+    // exact (Gaussian, block) pair count of this splat (its rows of the pair-ordered backward partials) + the supertile histogram
+    const uint32_t ng = for_each_supertile(sp, [&](int sy, int sx) {
+        const int s = sy * p.stiles_x + sx;
+        if (use_lds_hist) atomicAdd(&hist[s], 1u); else atomicAdd(&super_count[s], 1u);
+    });
     if (live_thread) {
         npairs[i] = ng;
         if (ng) atomicAdd(&idsum[i / IDBIN], ng);       // integer: order-independent
@@ -422,27 +440,28 @@ __global__ __launch_bounds__(256) void k_preprocess(Params p, const float* __res
     if ((threadIdx.x & 63) == 63 && kref > 0.f) atomicAdd(&header[H_KREF], (int32_t)kref);
     if (use_lds_hist) {
         __syncthreads();
-        for (int t = threadIdx.x; t < T; t += 256) { uint32_t c = hist[t]; if (c) atomicAdd(&tile_count[t], c); }
+        for (int t = threadIdx.x; t < S; t += 256) { uint32_t c = hist[t]; if (c) atomicAdd(&super_count[t], c); }
     }
 }
 
+// sort size classes of a supertile list: one wave / 1024 threads with 34 KiB / 1024 threads with 136 KiB of LDS / in global memory
 __device__ __forceinline__ int sort_class_of(uint32_t n) { return n <= 1024u ? 0 : (n <= 4096u ? 1 : (n <= 16384u ? 2 : 3)); }
 
-// one workgroup of 1024 threads: exclusive scans of the pair and segment counts, size-class lists, render order
-__global__ __launch_bounds__(1024) void k_scan_tiles(int T, const uint32_t* __restrict__ tile_count, uint32_t* __restrict__ tile_start,
-                                                     uint32_t* __restrict__ seg_start, uint32_t* __restrict__ cls,
-                                                     uint32_t* __restrict__ order, int32_t* __restrict__ header, int G,
+// Workgroup 0: exclusive scan of the supertile counts + the four size-class lists.  Workgroups 1 .. ceil(G / GTILE): pair rows -- goff =
+// exclusive prefix of the per-Gaussian pair counts in INDEX order: row q = goff[g] + e (e: the pair's place in g's block enumeration) is
+// unique per pair, contiguous per Gaussian -- the backward's per-pair partials are written by row (k_render_bwd finds e from the splat's
+// geometry) and summed per Gaussian as one streamed range (k_gather_partials): no float atomics.  A workgroup scans its GTILE counts on top
+// of the sum of the earlier index runs (idsum, accumulated by k_preprocess with integer atomics): no second launch, no inter-workgroup wait.
+// The last of them leaves the frame's pair count K in the header (what the caller sizes the pair workspace by).
+__global__ __launch_bounds__(1024) void k_scan_super(Params p, const uint32_t* __restrict__ super_count, uint32_t* __restrict__ super_start,
+                                                     uint32_t* __restrict__ cls, int32_t* __restrict__ header,
                                                      const uint32_t* __restrict__ npairs, const uint32_t* __restrict__ idsum,
                                                      uint32_t* __restrict__ goff) {
     __shared__ uint32_t part[1024], parts[1024];
+    DWG_GEOM(super_count); DWG_GEOM(super_start); DWG_GEOM(cls); DWG_GEOM(header); DWG_GEOM(npairs); DWG_GEOM(idsum); DWG_GEOM(goff);
+    const int G = p.G, tid = threadIdx.x;
     if (blockIdx.x > 0) {
-        // Workgroups 1 .. ceil(G / GTILE): pair rows.  goff = exclusive prefix of the per-Gaussian pair counts in INDEX order: row
-        // q = goff[g] + e (e: the pair's place in g's block enumeration) is unique per pair, contiguous per Gaussian -- the backward's per-pair
-        // partials are written by row (k_render_bwd finds e from the splat's geometry) and summed per Gaussian as one streamed range
-        // (k_gather_partials): no float atomics.  Only the backward reads goff; the forward pays these workgroups nothing (they run beside
-        // workgroup 0).  A workgroup scans its GTILE counts on top of the sum of the earlier index runs (idsum, accumulated by k_preprocess
-        // with integer atomics): no second launch, no inter-workgroup wait.
-        const int b = blockIdx.x - 1, tid = threadIdx.x, g = b * GTILE + tid;
+        const int b = blockIdx.x - 1, g = b * GTILE + tid;
         uint32_t pre = 0;
         for (int t = tid; t < b * (GTILE / IDBIN); t += 1024) pre += idsum[t];
         part[tid] = pre;
@@ -461,64 +480,50 @@ __global__ __launch_bounds__(1024) void k_scan_tiles(int T, const uint32_t* __re
             __syncthreads();
         }
         if (g < G) goff[g] = base + parts[tid] - v;
-        if (g == G - 1) goff[G] = base + parts[tid];
+        if (g == G - 1) { goff[G] = base + parts[tid]; header[H_K] = (int32_t)(base + parts[tid]); }
         return;
     }
-    __shared__ uint32_t cls_cnt[NCLASS], bkt_cnt[NBUCKET], bkt_base[NBUCKET];
-    const int tid = threadIdx.x;
+    __shared__ uint32_t cls_cnt[NCLASS];
+    const int S = p.stiles_x * p.stiles_y;
     if (tid < NCLASS) cls_cnt[tid] = 0u;
-    if (tid < NBUCKET) bkt_cnt[tid] = 0u;
-    const int chunk = (T + 1023) / 1024;
-    const int lo = tid * chunk, hi = min(T, lo + chunk);
-    uint32_t s = 0, ss = 0;
-    for (int t = lo; t < hi; t++) { uint32_t n = tile_count[t]; s += n; ss += (n + SEG - 1) / SEG; }
-    part[tid] = s; parts[tid] = ss;
+    const int chunk = (S + 1023) / 1024;
+    const int lo = min(S, tid * chunk), hi = min(S, lo + chunk);
+    uint32_t s = 0;
+    for (int t = lo; t < hi; t++) s += super_count[t];
+    part[tid] = s;
     __syncthreads();
     for (int off = 1; off < 1024; off <<= 1) {
-        uint32_t v = tid >= off ? part[tid - off] : 0u, vs = tid >= off ? parts[tid - off] : 0u;
+        const uint32_t v = tid >= off ? part[tid - off] : 0u;
         __syncthreads();
-        part[tid] += v; parts[tid] += vs;
+        part[tid] += v;
         __syncthreads();
     }
-    uint32_t run = part[tid] - s, runs = parts[tid] - ss;
+    uint32_t run = part[tid] - s;
     for (int t = lo; t < hi; t++) {
-        const uint32_t n = tile_count[t];
-        tile_start[t] = run; seg_start[t] = runs;
-        run += n; runs += (n + SEG - 1) / SEG;
-        if (n) { const int c = sort_class_of(n); cls[(size_t)c * T + atomicAdd(&cls_cnt[c], 1u)] = (uint32_t)t; }
-        atomicAdd(&bkt_cnt[n ? min(NBUCKET - 1, 32 - __clz((int)n)) : 0], 1u);
+        const uint32_t n = super_count[t];
+        super_start[t] = run;
+        run += n;
+        if (n) { const int c = sort_class_of(n); cls[(size_t)c * S + atomicAdd(&cls_cnt[c], 1u)] = (uint32_t)t; }
     }
-    if (tid == 1023) {
-        tile_start[T] = part[1023]; seg_start[T] = parts[1023];
-        header[H_K] = (int32_t)part[1023]; header[H_OVERFLOW] = 0; header[H_NSEG] = (int32_t)parts[1023];
-        header[H_TAG] = (int32_t)(atomicAdd(&g_frame_tag, 0x9e3779b1u) | 1u);      // this frame's tag (odd: never the zero of a fresh buffer)
-    }
+    if (tid == 1023) { super_start[S] = part[1023]; header[H_KS] = (int32_t)part[1023]; }
     __syncthreads();
-    if (tid == 0) {
-        uint32_t b = 0;
-        for (int k = NBUCKET - 1; k >= 0; k--) { bkt_base[k] = b; b += bkt_cnt[k]; bkt_cnt[k] = 0u; }     // longest lists first
-        for (int c = 0; c < NCLASS; c++) header[H_CLASS0 + c] = (int32_t)cls_cnt[c];
-    }
-    __syncthreads();
-    for (int t = lo; t < hi; t++) {
-        const uint32_t n = tile_count[t];
-        const int k = n ? min(NBUCKET - 1, 32 - __clz((int)n)) : 0;
-        order[bkt_base[k] + atomicAdd(&bkt_cnt[k], 1u)] = (uint32_t)t;
-    }
+    if (tid < NCLASS) header[H_CLASS0 + tid] = (int32_t)cls_cnt[tid];
 }
 
 // ------------------------------------------------------------------------------------------------
 // stage B
 // ------------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void k_scatter(Params p, const float4* __restrict__ rec0, const float4* __restrict__ rec1,
-                                                 const uint2* __restrict__ rect, const uint32_t* __restrict__ tile_start,
-                                                 uint32_t* __restrict__ tile_cursor, uint64_t* __restrict__ keys,
-                                                 int64_t cap, int32_t* __restrict__ header, int use_lds) {
-    // Two sweeps over this workgroup's splats: (1) count per block in LDS, reserve ONE contiguous range per (workgroup, block) with
-    // a single returning global atomic; (2) hand out slots inside the reserved ranges with LDS atomics (the counter then holds
-    // the absolute running slot).
-    extern __shared__ uint32_t cnt[];       // [T]
-    const int T = p.tiles_x * p.tiles_y, G = p.G;
+// One (depth bits << 32 | id) key per (Gaussian, supertile) into the supertile's range.  Two sweeps over this workgroup's splats: (1) count
+// per supertile in LDS, reserve ONE contiguous range per (workgroup, supertile) with a single returning global atomic; (2) hand out slots
+// inside the reserved ranges with LDS atomics (the counter then holds the absolute running slot).  The order inside a range is whatever the
+// atomics made it: the list is sorted next.
+__global__ __launch_bounds__(256) void k_scatter_super(Params p, const float4* __restrict__ rec0, const float4* __restrict__ rec1,
+                                                       const uint2* __restrict__ rect, const uint32_t* __restrict__ super_start,
+                                                       uint32_t* __restrict__ super_cursor, uint64_t* __restrict__ keys,
+                                                       int64_t cap, int32_t* __restrict__ header, int use_lds) {
+    extern __shared__ uint32_t cnt[];       // [S]
+    DWG_GEOM(rec0); DWG_GEOM(rec1); DWG_GEOM(rect); DWG_GEOM(super_start); DWG_GEOM(super_cursor); DWG_GEOM(header); DWG_PAIRS(keys);
+    const int S = p.stiles_x * p.stiles_y, G = p.G;
     int i = blockIdx.x * 256 + threadIdx.x;
     uint64_t key = 0;
     BlockSpan sp;
@@ -532,59 +537,31 @@ __global__ __launch_bounds__(256) void k_scatter(Params p, const float4* __restr
         key = ((uint64_t)__float_as_uint(a.z) << 32) | (uint32_t)i;
         if (tx1 > tx0 && ty1 > ty0) sp = block_span(a.x, a.y, b.x, b.y, b.z, a.w, tx0, ty0, tx1, ty1, p.tiles_x, p.tiles_y);
     }
-    // the SAME enumeration as k_preprocess (small splats by their lane, big ones by the whole wave: see span_is_big), three times
-    const bool big = span_is_big(sp);
-    const unsigned long long bigmask = __ballot(big);
-    const int lane = threadIdx.x & 63;
-#define DWG_FOR_EACH_BLOCK(KEYVAR, BODY)                                                        \
-    do {                                                                                        \
-        if (!big) {                                                                             \
-            const uint64_t KEYVAR = key; (void)KEYVAR;                                          \
-            for (int by = sp.by0; by < sp.by1; by++) {                                          \
-                int xa, xb;                                                                     \
-                block_row(sp, by, &xa, &xb);                                                    \
-                for (int bx = xa; bx < xb; bx++) { const int t = by * p.tiles_x + bx; BODY; }   \
-            }                                                                                   \
-        }                                                                                       \
-        unsigned long long m__ = bigmask;                                                       \
-        while (m__) {                                                                           \
-            const int src = __ffsll((long long)m__) - 1;                                        \
-            m__ &= m__ - 1;                                                                     \
-            const BlockSpan w = span_from_lane(sp, src);                                        \
-            const uint64_t KEYVAR = ((uint64_t)(uint32_t)__shfl((int)(uint32_t)(key >> 32), src) << 32) |   \
-                                    (uint32_t)__shfl((int)(uint32_t)key, src);                  \
-            (void)KEYVAR;                                                                       \
-            for (int by = w.by0 + (lane >> 2); by < w.by1; by += 16) {                          \
-                int xa, xb;                                                                     \
-                block_row(w, by, &xa, &xb);                                                     \
-                for (int bx = xa + (lane & 3); bx < xb; bx += 4) { const int t = by * p.tiles_x + bx; BODY; }   \
-            }                                                                                   \
-        }                                                                                       \
-    } while (0)
     if (!use_lds) {
-        DWG_FOR_EACH_BLOCK(k, {
-            int64_t slot = (int64_t)tile_start[t] + atomicAdd(&tile_cursor[t], 1u);
-            if (slot < cap) keys[slot] = k; else header[H_OVERFLOW] = 1;
+        for_each_supertile(sp, [&](int sy, int sx) {
+            const int s = sy * p.stiles_x + sx;
+            const int64_t slot = (int64_t)super_start[s] + atomicAdd(&super_cursor[s], 1u);
+            if (slot < cap) keys[slot] = key; else header[H_OVERFLOW] = 1;
         });
         return;
     }
-    for (int t = threadIdx.x; t < T; t += 256) cnt[t] = 0u;
+    for (int t = threadIdx.x; t < S; t += 256) cnt[t] = 0u;
     __syncthreads();
-    DWG_FOR_EACH_BLOCK(k, { atomicAdd(&cnt[t], 1u); });
+    for_each_supertile(sp, [&](int sy, int sx) { atomicAdd(&cnt[sy * p.stiles_x + sx], 1u); });
     __syncthreads();
-    for (int t = threadIdx.x; t < T; t += 256) {
+    for (int t = threadIdx.x; t < S; t += 256) {
         const uint32_t c = cnt[t];
-        if (c) cnt[t] = tile_start[t] + atomicAdd(&tile_cursor[t], c);
+        if (c) cnt[t] = super_start[t] + atomicAdd(&super_cursor[t], c);
     }
     __syncthreads();
-    DWG_FOR_EACH_BLOCK(k, {
-        const int64_t slot = (int64_t)atomicAdd(&cnt[t], 1u);
-        if (slot < cap) keys[slot] = k; else header[H_OVERFLOW] = 1;
+    for_each_supertile(sp, [&](int sy, int sx) {
+        const int64_t slot = (int64_t)atomicAdd(&cnt[sy * p.stiles_x + sx], 1u);
+        if (slot < cap) keys[slot] = key; else header[H_OVERFLOW] = 1;
     });
-#undef DWG_FOR_EACH_BLOCK
 }
 
-// Ascending-only bitonic network (mirror step + half-cleaners) so that virtual +inf padding above n is legal.
+// Ascending-only bitonic network (mirror step + half-cleaners) so that virtual +inf padding above n is legal: the in-memory network of
+// the lists too long for LDS.
 template <typename Mem>
 __device__ __forceinline__ void bitonic_network(Mem& m, int n, int npad) {
     const int tid = threadIdx.x, nthr = blockDim.x;
@@ -606,57 +583,32 @@ __device__ __forceinline__ void bitonic_network(Mem& m, int n, int npad) {
         }
     }
 }
-struct LdsMem { uint64_t* p; __device__ uint64_t get(int i) const { return p[i]; } __device__ void set(int i, uint64_t v) { p[i] = v; } };
 struct GlbMem { volatile uint64_t* p; __device__ uint64_t get(int i) const { return p[i]; } __device__ void set(int i, uint64_t v) { p[i] = v; } };
 
-// One workgroup per block of size class CLS (list compacted by k_scan_tiles); workgroups beyond the class count exit.
-template <int CLS, int THREADS, bool GLOBAL>
-__global__ __launch_bounds__(THREADS) void k_tile_sort(int T, const uint32_t* __restrict__ cls, const int32_t* __restrict__ header,
-                                                       const uint32_t* __restrict__ tile_start, uint64_t* __restrict__ keys,
-                                                       uint32_t* __restrict__ sorted, int64_t cap) {
-    extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
-    if ((int)blockIdx.x >= header[H_CLASS0 + CLS]) return;
-    const int tile = (int)cls[(size_t)CLS * T + blockIdx.x];
-    int64_t s = tile_start[tile], e = tile_start[tile + 1];
-    if (s > cap) s = cap; if (e > cap) e = cap;
-    const int n = (int)(e - s);
-    if (n <= 0) return;
-    int npad = 2; while (npad < n) npad <<= 1;
-    if (!GLOBAL) {
-        uint64_t* sk = reinterpret_cast<uint64_t*>(smem_raw);
-        for (int i = threadIdx.x; i < n; i += THREADS) sk[i] = keys[s + i];
-        __syncthreads();
-        LdsMem m{sk};
-        if (n > 1) bitonic_network(m, n, npad);
-        for (int i = threadIdx.x; i < n; i += THREADS) sorted[s + i] = (uint32_t)sk[i];
-    } else {
-        GlbMem m{keys + s};
-        __syncthreads();
-        bitonic_network(m, n, npad);
-        for (int i = threadIdx.x; i < n; i += THREADS) sorted[s + i] = (uint32_t)m.get(i);
-    }
-}
-
-// Register-blocked bitonic sort for the two common size classes.  The LDS network above moves every key through LDS on every one
-// of its log^2 passes (55 for 1024 keys: 0.9 MB of LDS traffic per block, and the blocks of a CU share ONE 128 B/clk LDS pipe -- the
-// sorts were LDS-bandwidth-bound: 0.19 of the 0.44 ms forward chain at c3, 0.51 of 1.1 ms at c5).  Here a thread owns EPT
-// CONSECUTIVE keys in registers (key i lives in thread i / EPT, register i % EPT), so every compare-exchange with stride < EPT is
-// register-only (34 of the 55 passes at EPT = 16), strides up to 32 * EPT go lane to lane inside the wave, and only the last few
-// strides of a 4096-key block cross waves through LDS.  Padding above n is real +inf keys, so the plain network applies.
+// Register-blocked bitonic sort.  A thread owns EPT CONSECUTIVE keys in registers (key i lives in thread i / EPT, register i % EPT), so
+// every compare-exchange with stride < EPT is register-only, strides up to 32 * EPT go lane to lane inside the wave, and only the last
+// strides of a multi-wave list cross waves through LDS (a pure LDS network moves every key through the CU's one LDS pipe on every one of
+// its log^2 passes and is bound by it).  Padding above n is real +inf keys, so the plain network applies.
 __device__ __forceinline__ uint64_t shfl_xor_u64(uint64_t v, int m) {
     const uint32_t lo = (uint32_t)__shfl_xor((int)(uint32_t)v, m), hi = (uint32_t)__shfl_xor((int)(uint32_t)(v >> 32), m);
     return ((uint64_t)hi << 32) | lo;
 }
-// LDS slot of key i: one 8-byte pad per 16 keys, so that a thread's 16 consecutive keys and the lanes' strided accesses spread over banks
+// LDS slot of key i: one 8-byte pad per 16 keys, so that a thread's consecutive keys and the lanes' strided accesses spread over banks
 __device__ __forceinline__ int sort_slot(int i) { return i + (i >> 4); }
+struct LdsSlotMem {
+    uint64_t* p;
+    __device__ uint64_t get(int i) const { return p[sort_slot(i)]; }
+    __device__ void set(int i, uint64_t v) { p[sort_slot(i)] = v; }
+};
 
+// sorts keys_in[0, n) ascending; on return (behind a barrier) key e is at lds[sort_slot(e)]
 template <int THREADS, int EPT>
-__device__ __forceinline__ void block_sort_regs(const uint64_t* __restrict__ keys_in, uint32_t* __restrict__ sorted_out, int n,
-                                                uint64_t* __restrict__ lds) {
+__device__ __forceinline__ void sort_in_lds(const uint64_t* __restrict__ keys_in, int n, uint64_t* __restrict__ lds, int skip) {
     constexpr int N = THREADS * EPT;
     const int tid = threadIdx.x;
     for (int e = tid; e < N; e += THREADS) lds[sort_slot(e)] = e < n ? keys_in[e] : ~0ull;      // coalesced in, +inf above n
     __syncthreads();
+    if (skip) return;
     uint64_t v[EPT];
 #pragma unroll
     for (int r = 0; r < EPT; r++) v[r] = lds[sort_slot(tid * EPT + r)];
@@ -676,7 +628,7 @@ __device__ __forceinline__ void block_sort_regs(const uint64_t* __restrict__ key
                         const bool take = keep_min ? (o < v[r]) : (o > v[r]);
                         v[r] = take ? o : v[r];
                     }
-                } else {                                       // across waves: through LDS (a few passes of the 4096-key class only)
+                } else {                                       // across waves: through LDS
                     __syncthreads();
 #pragma unroll
                     for (int r = 0; r < EPT; r++) lds[sort_slot(tid * EPT + r)] = v[r];
@@ -707,39 +659,207 @@ __device__ __forceinline__ void block_sort_regs(const uint64_t* __restrict__ key
 #pragma unroll
     for (int r = 0; r < EPT; r++) lds[sort_slot(tid * EPT + r)] = v[r];
     __syncthreads();
-    for (int e = tid; e < n; e += THREADS) sorted_out[e] = (uint32_t)lds[sort_slot(e)];            // coalesced out
 }
 
-// classes 0 (<= 1024 keys, one wave; 64 / 256 / 1024-key networks by list length), 1 (<= 4096 keys, four waves) and 2 (<= 16384, sixteen)
+// The depth-sorted list of a supertile, split STABLY into the lists of its ST x ST blocks (what replaced the per-block sorts: a block's list
+// is a subsequence of its supertile's, so ONE sort per 32x32 pixels orders sixteen lists).
+//   E1  every candidate's 16-bit block mask -- bit 4 r + c set iff block (ST sx + c, ST sy + r) lies in the splat's scanline enumeration
+//       (block_span / block_row, the functions k_preprocess counted the pairs with) -- parked in the sorted key's upper word (the depth has
+//       done its work);
+//   E2  per wave (a contiguous run of 64-candidate chunks) and per bit: how many candidates carry the bit; a scan over the waves;
+//   E3  the supertile takes a contiguous piece of the frame's pair pool with ONE atomic (where a list lands depends on arrival order, what
+//       it holds does not) and cuts it into sixteen lists: tile_start / tile_count of its blocks;
+//   E4  every wave walks its chunks again: a candidate with bit b goes to slot run_b + (candidates of the chunk below it with bit b).
+template <int THREADS, typename Mem>
+__device__ __forceinline__ void split_to_blocks(const Params& p, Mem m, int n, int s, const float4* __restrict__ rec0,
+                                                const float4* __restrict__ rec1, const uint2* __restrict__ rect,
+                                                uint32_t* __restrict__ tile_count, uint32_t* __restrict__ tile_start,
+                                                uint32_t* __restrict__ sorted, int64_t cap, int32_t* __restrict__ header,
+                                                uint32_t* __restrict__ wt /* [THREADS / 64][16] */, uint32_t* __restrict__ bs /* [16] */) {
+    constexpr int NW = THREADS / 64;
+    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+    const int sx = s % p.stiles_x, sy = s / p.stiles_x;
+    // four candidates per trip: their twelve record gathers are in flight together (one candidate per trip made this phase a chain of
+    // dependent L2 round trips: 40 of the 73 us of the single-wave class at 100 k Gaussians)
+    for (int e0 = tid; e0 < n; e0 += 4 * THREADS) {
+        uint32_t id[4]; uint2 rc[4]; float4 ra[4], rb[4];
+#pragma unroll
+        for (int u = 0; u < 4; u++) {
+            const int e = e0 + u * THREADS;
+            id[u] = e < n ? (uint32_t)m.get(e) : 0u;
+            rc[u] = rect[id[u]]; ra[u] = rec0[id[u]]; rb[u] = rec1[id[u]];
+        }
+#pragma unroll
+        for (int u = 0; u < 4; u++) {
+            const int e = e0 + u * THREADS;
+            if (e >= n) break;
+            uint32_t mask = 0;
+            if (!(p.dbg & 2)) {
+                const float4 a = ra[u], b = rb[u];
+                const BlockSpan sp = block_span(a.x, a.y, b.x, b.y, b.z, a.w, (int)(rc[u].x & 0xffff), (int)(rc[u].x >> 16), (int)(rc[u].y & 0xffff),
+                                                (int)(rc[u].y >> 16), p.tiles_x, p.tiles_y);
+#pragma unroll
+                for (int r = 0; r < ST; r++) {
+                    const int by = sy * ST + r;
+                    if (by >= sp.by0 && by < sp.by1) {
+                        int xa, xb;
+                        block_row(sp, by, &xa, &xb);
+                        const int lo = max(xa, sx * ST), hi = min(xb, sx * ST + ST);
+                        if (hi > lo) mask |= ((1u << (hi - lo)) - 1u) << (r * ST + lo - sx * ST);
+                    }
+                }
+            } else mask = 1u;
+            m.set(e, ((uint64_t)mask << 32) | id[u]);
+        }
+    }
+    __syncthreads();
+    if (p.dbg & 4) return;
+    const int C = (n + 63) >> 6, per = (C + NW - 1) / NW, c0 = min(C, w * per), c1 = min(C, c0 + per);
+    uint32_t mine = 0;
+    for (int c = c0; c < c1; c++) {
+        const int e = c * 64 + lane;
+        const uint32_t mask = e < n ? (uint32_t)(m.get(e) >> 32) : 0u;
+#pragma unroll
+        for (int b = 0; b < ST * ST; b++) {
+            const unsigned long long bal = __ballot((mask >> b) & 1u);
+            if (lane == b) mine += (uint32_t)__popcll(bal);
+        }
+    }
+    if (lane < ST * ST) wt[w * (ST * ST) + lane] = mine;
+    __syncthreads();
+    if (tid < ST * ST) {
+        uint32_t run = 0;
+        for (int k = 0; k < NW; k++) { const uint32_t t = wt[k * (ST * ST) + tid]; wt[k * (ST * ST) + tid] = run; run += t; }
+        bs[tid] = run;
+    }
+    __syncthreads();
+    if (tid == 0) {
+        uint32_t tot = 0;
+        for (int b = 0; b < ST * ST; b++) tot += bs[b];
+        const uint32_t base = tot ? atomicAdd(reinterpret_cast<uint32_t*>(&header[H_POOL]), tot) : 0u;
+        if ((int64_t)base + (int64_t)tot > cap) header[H_OVERFLOW] = 1;          // truncated: the caller renders the frame again
+        uint32_t run = base;
+        for (int b = 0; b < ST * ST; b++) {
+            const uint32_t c = bs[b];
+            bs[b] = run;
+            const int by = sy * ST + b / ST, bx = sx * ST + b % ST;
+            if (bx < p.tiles_x && by < p.tiles_y) {
+                const int64_t room = cap - (int64_t)run;
+                tile_start[by * p.tiles_x + bx] = run;
+                tile_count[by * p.tiles_x + bx] = room <= 0 ? 0u : (uint32_t)min((int64_t)c, room);
+            }
+            run += c;
+        }
+    }
+    __syncthreads();
+    uint32_t runb = lane < ST * ST ? bs[lane] + wt[w * (ST * ST) + lane] : 0u;
+    const unsigned long long below = (1ull << lane) - 1ull;
+    for (int c = c0; c < c1; c++) {
+        const int e = c * 64 + lane;
+        const uint64_t kv = e < n ? m.get(e) : 0ull;
+        const uint32_t mask = (uint32_t)(kv >> 32), id = (uint32_t)kv;
+#pragma unroll
+        for (int b = 0; b < ST * ST; b++) {
+            const bool bit = (mask >> b) & 1u;
+            const unsigned long long bal = __ballot(bit);
+            const uint32_t r0 = (uint32_t)__builtin_amdgcn_readlane((int)runb, b);
+            if (bit) {
+                const int64_t pos = (int64_t)r0 + __popcll(bal & below);
+                if (pos < cap) sorted[pos] = id;
+            }
+            if (lane == b) runb += (uint32_t)__popcll(bal);
+        }
+    }
+}
+
+// One workgroup per supertile of size class CLS (lists compacted by k_scan_super); workgroups beyond the class count exit.
+//   CLS 0: <= 1024 keys (THREADS = 256: 256 .. 1024-key networks by list length) | 1: <= 4096 (1024 threads) | 2: <= 16384 (1024 threads,
+//   136 KiB of LDS) | 3: longer -- the in-memory network.
 template <int CLS, int THREADS>
-__global__ __launch_bounds__(THREADS) void k_tile_sort_regs(int T, const uint32_t* __restrict__ cls, const int32_t* __restrict__ header,
-                                                            const uint32_t* __restrict__ tile_start, const uint64_t* __restrict__ keys,
-                                                            uint32_t* __restrict__ sorted, int64_t cap) {
+__global__ __launch_bounds__(THREADS) void k_sort_super(Params p, const uint32_t* __restrict__ cls, int32_t* __restrict__ header,
+                                                        const uint32_t* __restrict__ super_start, uint64_t* __restrict__ keys,
+                                                        const float4* __restrict__ rec0, const float4* __restrict__ rec1,
+                                                        const uint2* __restrict__ rect, uint32_t* __restrict__ tile_count,
+                                                        uint32_t* __restrict__ tile_start, uint32_t* __restrict__ sorted, int64_t cap) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+    __shared__ uint32_t wt[(THREADS / 64) * ST * ST], bs[ST * ST];
+    DWG_GEOM(cls); DWG_GEOM(header); DWG_GEOM(super_start); DWG_GEOM(rec0); DWG_GEOM(rec1); DWG_GEOM(rect); DWG_GEOM(tile_count);
+    DWG_GEOM(tile_start); DWG_PAIRS(keys); DWG_PAIRS(sorted);
     if ((int)blockIdx.x >= header[H_CLASS0 + CLS]) return;
-    const int tile = (int)cls[(size_t)CLS * T + blockIdx.x];
-    int64_t s = tile_start[tile], e = tile_start[tile + 1];
-    if (s > cap) s = cap; if (e > cap) e = cap;
-    const int n = (int)(e - s);
+    const int S = p.stiles_x * p.stiles_y;
+    const int s = (int)cls[(size_t)CLS * S + blockIdx.x];
+    int64_t a = super_start[s], e = super_start[s + 1];
+    if (a > cap) a = cap; if (e > cap) e = cap;
+    const int n = (int)(e - a);
     if (n <= 0) return;
+    if (CLS == 3) {
+        int npad = 2; while (npad < n) npad <<= 1;
+        GlbMem m{keys + a};
+        bitonic_network(m, n, npad);
+        split_to_blocks<THREADS>(p, m, n, s, rec0, rec1, rect, tile_count, tile_start, sorted, cap, header, wt, bs);
+        return;
+    }
     uint64_t* lds = reinterpret_cast<uint64_t*>(smem_raw);
-    if (n == 1) { if (threadIdx.x == 0) sorted[s] = (uint32_t)keys[s]; return; }
-    if (CLS == 0) {
-        if (n <= 64) block_sort_regs<64, 1>(keys + s, sorted + s, n, lds);
-        else if (n <= 256) block_sort_regs<64, 4>(keys + s, sorted + s, n, lds);
-        else block_sort_regs<64, 16>(keys + s, sorted + s, n, lds);
-    } else if (CLS == 1) {
-        if (n <= 2048) block_sort_regs<256, 8>(keys + s, sorted + s, n, lds);
-        else block_sort_regs<256, 16>(keys + s, sorted + s, n, lds);
-    } else {
-        if (n <= 8192) block_sort_regs<1024, 8>(keys + s, sorted + s, n, lds);
-        else block_sort_regs<1024, 16>(keys + s, sorted + s, n, lds);
+    const uint64_t* kin = keys + a;
+    // the network of N = THREADS x EPT >= n keys (EPT consecutive keys per thread)
+    if (n <= THREADS) sort_in_lds<THREADS, 1>(kin, n, lds, p.dbg & 1);
+    else if (n <= 2 * THREADS) sort_in_lds<THREADS, 2>(kin, n, lds, p.dbg & 1);
+    else if (n <= 4 * THREADS) sort_in_lds<THREADS, 4>(kin, n, lds, p.dbg & 1);
+    else if (n <= 8 * THREADS) sort_in_lds<THREADS, 8>(kin, n, lds, p.dbg & 1);
+    else sort_in_lds<THREADS, 16>(kin, n, lds, p.dbg & 1);
+    LdsSlotMem m{lds};
+    split_to_blocks<THREADS>(p, m, n, s, rec0, rec1, rect, tile_count, tile_start, sorted, cap, header, wt, bs);
+}
+
+// one workgroup of 1024 threads per frame: exclusive scan of the blocks' segment counts, the render order (longest list first), the frame's tag
+__global__ __launch_bounds__(1024) void k_scan_tiles(Params p, const uint32_t* __restrict__ tile_count, uint32_t* __restrict__ seg_start,
+                                                     uint32_t* __restrict__ order, int32_t* __restrict__ header) {
+    __shared__ uint32_t parts[1024];
+    __shared__ uint32_t bkt_cnt[NBUCKET], bkt_base[NBUCKET];
+    DWG_GEOM(tile_count); DWG_GEOM(seg_start); DWG_GEOM(order); DWG_GEOM(header);
+    const int T = p.tiles_x * p.tiles_y, tid = threadIdx.x;
+    if (tid < NBUCKET) bkt_cnt[tid] = 0u;
+    const int chunk = (T + 1023) / 1024;
+    const int lo = min(T, tid * chunk), hi = min(T, lo + chunk);
+    uint32_t ss = 0;
+    for (int t = lo; t < hi; t++) ss += (tile_count[t] + SEG - 1) / SEG;
+    parts[tid] = ss;
+    __syncthreads();
+    for (int off = 1; off < 1024; off <<= 1) {
+        const uint32_t vs = tid >= off ? parts[tid - off] : 0u;
+        __syncthreads();
+        parts[tid] += vs;
+        __syncthreads();
+    }
+    uint32_t runs = parts[tid] - ss;
+    for (int t = lo; t < hi; t++) {
+        const uint32_t n = tile_count[t];
+        seg_start[t] = runs;
+        runs += (n + SEG - 1) / SEG;
+        atomicAdd(&bkt_cnt[n ? min(NBUCKET - 1, 32 - __clz((int)n)) : 0], 1u);
+    }
+    if (tid == 1023) {
+        seg_start[T] = parts[1023];
+        header[H_NSEG] = (int32_t)parts[1023];
+        header[H_TAG] = (int32_t)(atomicAdd(&g_frame_tag, 0x9e3779b1u) | 1u);      // this frame's tag (odd: never the zero of a fresh buffer)
+    }
+    __syncthreads();
+    if (tid == 0) {
+        uint32_t b = 0;
+        for (int k = NBUCKET - 1; k >= 0; k--) { bkt_base[k] = b; b += bkt_cnt[k]; bkt_cnt[k] = 0u; }     // longest lists first
+    }
+    __syncthreads();
+    for (int t = lo; t < hi; t++) {
+        const uint32_t n = tile_count[t];
+        const int k = n ? min(NBUCKET - 1, 32 - __clz((int)n)) : 0;
+        order[bkt_base[k] + atomicAdd(&bkt_cnt[k], 1u)] = (uint32_t)t;
     }
 }
 
 // One wave64 per 8x8 pixel block, longest list first.  Splat records of the current batch of 64 live in LDS (broadcast reads);
 // the next batch's records are gathered into registers while the current one is composited.
 __global__ __launch_bounds__(64) void k_render_fwd(Params p, const uint32_t* __restrict__ order, const uint32_t* __restrict__ tile_start,
+                                                   const uint32_t* __restrict__ tile_count,
                                                    const uint32_t* __restrict__ seg_start, const uint32_t* __restrict__ sorted,
                                                    const float4* __restrict__ rec0, const float4* __restrict__ rec1,
                                                    const float4* __restrict__ rec2, int64_t cap, int64_t cap_segs,
@@ -749,14 +869,19 @@ __global__ __launch_bounds__(64) void k_render_fwd(Params p, const uint32_t* __r
                                                    float* __restrict__ out_color, float* __restrict__ out_depth,
                                                    float* __restrict__ out_alpha) {
     __shared__ float4 s0[64], s1[64], s2[64];
+    DWG_GEOM(order); DWG_GEOM(tile_start); DWG_GEOM(tile_count); DWG_GEOM(seg_start); DWG_GEOM(rec0); DWG_GEOM(rec1); DWG_GEOM(rec2); DWG_GEOM(tile_neff);
+    DWG_PAIRS(sorted); DWG_PAIRS(seg_tile); DWG_PAIRS(ckpt); DWG_IMAGE(final_T); DWG_IMAGE(n_contrib); DWG_IMAGE(craw);
+    {
+        const size_t fo = (size_t)blockIdx.y * (size_t)p.H * p.W;
+        out_color += 3 * fo; out_depth += fo; out_alpha += fo;
+    }
     const int tile = (int)order[blockIdx.x];
     const int tx = tile % p.tiles_x, ty = tile / p.tiles_x;
     const int lane = threadIdx.x;
     const int px = tx * BT + (lane & 7), py = ty * BT + (lane >> 3);
     const bool inside = px < p.W && py < p.H;
-    int64_t rs = tile_start[tile], re = tile_start[tile + 1];
-    if (rs > cap) rs = cap; if (re > cap) re = cap;
-    const int n = (int)(re - rs);
+    const int64_t rs = tile_start[tile];                    // the block's list: sorted[rs, rs + n) (n already clamped to the capacity)
+    const int n = (int)tile_count[tile];
     const int64_t sbase = seg_start[tile];
     for (int s = lane; s < (n + SEG - 1) / SEG; s += 64) if (sbase + s < cap_segs) seg_tile[sbase + s] = (uint32_t)tile;
     const float fx = (float)px, fy = (float)py;
@@ -860,7 +985,8 @@ __device__ __forceinline__ uint32_t dwg_tag2(uint32_t tag) { return (tag * 0x85e
 template <bool GD>
 __global__ __launch_bounds__(64) void k_render_bwd(Params p, const int32_t* __restrict__ header, int64_t cap_segs,
                                                    const uint32_t* __restrict__ seg_tile, const uint32_t* __restrict__ seg_start,
-                                                   const uint32_t* __restrict__ tile_start, const uint32_t* __restrict__ tile_neff,
+                                                   const uint32_t* __restrict__ tile_start, const uint32_t* __restrict__ tile_count,
+                                                   const uint32_t* __restrict__ tile_neff,
                                                    const uint32_t* __restrict__ sorted, const uint2* __restrict__ rect,
                                                    const uint32_t* __restrict__ goff, uint32_t tag, const float4* __restrict__ rec0,
                                                    const float4* __restrict__ rec1, const float4* __restrict__ rec2,
@@ -879,10 +1005,9 @@ __global__ __launch_bounds__(64) void k_render_bwd(Params p, const int32_t* __re
     const int tile = (int)seg_tile[seg];
     if ((unsigned)tile >= (unsigned)(p.tiles_x * p.tiles_y)) return;
     const int sidx = (int)(seg - (int64_t)seg_start[tile]);
-    int64_t rs = tile_start[tile], re = tile_start[tile + 1];
-    if (rs > cap) rs = cap; if (re > cap) re = cap;
+    const int64_t rs = tile_start[tile];
     const int lo = sidx * SEG;
-    const int seg_hi = min((int)(re - rs), lo + SEG);              // the rows this wave owns: [lo, seg_hi)
+    const int seg_hi = min((int)tile_count[tile], lo + SEG);       // the rows this wave owns: [lo, seg_hi)
     const int hi = min(seg_hi, (int)tile_neff[tile]);              // ... of which [lo, hi) can carry a gradient
     if (lo >= seg_hi) return;
     const int lane = threadIdx.x;
@@ -1007,10 +1132,11 @@ __global__ __launch_bounds__(64) void k_render_bwd(Params p, const int32_t* __re
 // rows per wave-instruction, neighbouring Gaussians' rows being neighbours in memory) and ends up holding piece h of the sum -- no
 // cross-lane reduction, no LDS, no barrier.  (Tried first: a thread per Gaussian reading its own rows -- 64 scattered lines per instruction,
 // 53 us at 50 k Gaussians; streaming a workgroup's whole run through LDS -- the chunk loop's length is set by the big splats in the run,
-// 150-960 us.)  Big splats (> GBIG rows) are summed by their whole wave, lane-strided over the rows, and joined by a fixed tree.
-#define GBIG 192
+// 150-960 us.)  Big splats (> GBIG rows; 64 by default: the quad path costs a wave its LONGEST quad, a dependent trip per four rows, and the pair
+// counts are heavy-tailed -- at 192 the launch was its tail, waves parked 0.82 of the time) are summed by their whole wave, lane-strided over
+// the rows, and joined by a fixed tree.
 __global__ __launch_bounds__(256) void k_gather_partials(int G, const uint32_t* __restrict__ goff, const float* __restrict__ part, int64_t cap,
-                                                         const int32_t* __restrict__ header, uint32_t tag, float* __restrict__ gacc) {
+                                                         const int32_t* __restrict__ header, uint32_t tag, float* __restrict__ gacc, int GBIG) {
     const int i = blockIdx.x * 64 + (threadIdx.x >> 2), h = threadIdx.x & 3, lane = threadIdx.x & 63;
     const bool ok = !header[H_OVERFLOW];                       // a truncated frame is redone by the caller: zeros
     tag = (uint32_t)header[H_TAG];
@@ -1253,12 +1379,14 @@ __global__ void k_camera_setup(const float* __restrict__ extrinsic, const float*
     }
 }
 
-static int make_params(const dwg_raster_settings* cfg, int G, Params* p) {
+static int make_params(const dwg_raster_settings* cfg, const dwg_raster_frames* fr, int G, Params* p) {
     if (!cfg || G < 0 || cfg->image_height <= 0 || cfg->image_width <= 0) return DWG_E_ARG;
     if (!cfg->bg || !cfg->viewmatrix || !cfg->projmatrix) return DWG_E_ARG;
+    if (fr && (fr->num_frames < 1 || fr->gaussian_stride < 0 || fr->camera_stride < 0)) return DWG_E_ARG;
     p->G = G; p->H = cfg->image_height; p->W = cfg->image_width;
     p->tiles_x = dwg_cdiv(p->W, BT); p->tiles_y = dwg_cdiv(p->H, BT);
     p->rtiles_x = dwg_cdiv(p->W, RT); p->rtiles_y = dwg_cdiv(p->H, RT);
+    p->stiles_x = dwg_cdiv(p->tiles_x, ST); p->stiles_y = dwg_cdiv(p->tiles_y, ST);
     if (p->rtiles_x > 0x7fff || p->rtiles_y > 0x7fff) return DWG_E_ARG;
     p->tanfovx = cfg->tanfovx; p->tanfovy = cfg->tanfovy;
     p->focal_x = p->W / (2.f * cfg->tanfovx); p->focal_y = p->H / (2.f * cfg->tanfovy);
@@ -1266,22 +1394,20 @@ static int make_params(const dwg_raster_settings* cfg, int G, Params* p) {
     p->sh_degree = cfg->sh_degree; p->sh_coeffs = cfg->sh_coeffs;
     p->bg = cfg->bg; p->view = cfg->viewmatrix; p->proj = cfg->projmatrix; p->campos = cfg->campos;
     p->visit_order = cfg->visit_order;
+    p->in_stride = fr ? fr->gaussian_stride : 0; p->cam_stride = fr ? fr->camera_stride : 0;
+    p->geom_stride = p->pairs_stride = p->image_stride = 0;      // set by the callers that know the capacity
+    static const int dbg = getenv("DWG_RASTER_DEBUG") ? atoi(getenv("DWG_RASTER_DEBUG")) : 0;
+    p->dbg = dbg;
     return DWG_OK;
 }
 
 }  // namespace
 
-// Block-private LDS histograms (one global atomic per workgroup and block instead of one per pair) up to 16384 blocks (1024^2);
-// DWG_RASTER_LDS_MAXT lowers the limit (experiment switch).
-static int lds_hist_ok(int T) {
-    static const int lds_max_t = getenv("DWG_RASTER_LDS_MAXT") ? atoi(getenv("DWG_RASTER_LDS_MAXT")) : 16384;
-    static bool attr_set = false;
-    if (!attr_set) {      // 64 KiB of histogram + the static camera words is over the 64 KiB default limit
-        hipFuncSetAttribute(reinterpret_cast<const void*>(&k_preprocess), hipFuncAttributeMaxDynamicSharedMemorySize, 16384 * 4);
-        hipFuncSetAttribute(reinterpret_cast<const void*>(&k_scatter), hipFuncAttributeMaxDynamicSharedMemorySize, 16384 * 4);
-        attr_set = true;
-    }
-    return T <= lds_max_t && T <= 16384;
+// Workgroup-private LDS supertile histograms (one global atomic per workgroup and supertile instead of one per (Gaussian, supertile)
+// pair) up to 16384 supertiles (4096^2 pixels); DWG_RASTER_LDS_MAXS lowers the limit (experiment switch).
+static int lds_hist_ok(int S) {
+    static const int lds_max_s = getenv("DWG_RASTER_LDS_MAXS") ? atoi(getenv("DWG_RASTER_LDS_MAXS")) : 16384;
+    return S <= lds_max_s && S <= 16384;
 }
 
 extern "C" {
@@ -1304,12 +1430,12 @@ int dwg_raster_camera_setup(const float* extrinsic, const float* projection, con
     return DWG_OK;
 }
 
-int dwg_raster_forward_bin(const dwg_raster_settings* cfg, int32_t G, const float* means3D, const float* shs,
-                           const float* colors_precomp, const float* opacities, const float* scales,
-                           const float* rotations, const float* cov3D_precomp, int32_t* radii, void* ws_geom,
-                           dwg_stream_t stream_) {
+int dwg_raster_forward_bin_frames(const dwg_raster_settings* cfg, const dwg_raster_frames* frames, int32_t G, const float* means3D,
+                                  const float* shs, const float* colors_precomp, const float* opacities, const float* scales,
+                                  const float* rotations, const float* cov3D_precomp, int32_t* radii, void* ws_geom,
+                                  dwg_stream_t stream_) {
     Params p;
-    int rc = make_params(cfg, G, &p);
+    int rc = make_params(cfg, frames, G, &p);
     if (rc) return rc;
     if (!ws_geom) return DWG_E_ARG;
     if (G > 0) {  // with G == 0 every per-Gaussian pointer may be NULL
@@ -1319,24 +1445,106 @@ int dwg_raster_forward_bin(const dwg_raster_settings* cfg, int32_t G, const floa
         if (shs && (!cfg->campos || cfg->sh_degree < 0 || cfg->sh_degree > 3 ||
                     cfg->sh_coeffs < (cfg->sh_degree + 1) * (cfg->sh_degree + 1))) return DWG_E_ARG;
     }
+    const int F = frames ? frames->num_frames : 1;
     hipStream_t stream = (hipStream_t)stream_;
     GeomLayout L = geom_layout(G, p.H, p.W);
+    p.geom_stride = L.total;
     char* ws = (char*)ws_geom;
-    int T = p.tiles_x * p.tiles_y;
-    if (hipMemsetAsync(ws + L.header, 0, 256, stream) != hipSuccess) return DWG_E_LAUNCH;
-    if (hipMemsetAsync(ws + L.tile_count, 0, L.tile_start - L.tile_count, stream) != hipSuccess) return DWG_E_LAUNCH;
+    const int S = p.stiles_x * p.stiles_y;
+    for (int f = 0; f < F; f++) {
+        char* wf = ws + (size_t)f * L.total;
+        if (hipMemsetAsync(wf + L.header, 0, 256, stream) != hipSuccess) return DWG_E_LAUNCH;
+        if (hipMemsetAsync(wf + L.tile_count, 0, L.zero_end - L.tile_count, stream) != hipSuccess) return DWG_E_LAUNCH;
+    }
+    static bool attr_set = false;
+    if (!attr_set) {      // 64 KiB of histogram + the static camera words is over the 64 KiB default limit
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_preprocess), hipFuncAttributeMaxDynamicSharedMemorySize, 16384 * 4);
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_scatter_super), hipFuncAttributeMaxDynamicSharedMemorySize, 16384 * 4);
+        attr_set = true;
+    }
     if (G > 0) {
-        const int use_lds_hist = lds_hist_ok(T);
-        DWG_LAUNCH("raster_preprocess", k_preprocess, dim3(dwg_cdiv(G, 256)), dim3(256), use_lds_hist ? (size_t)T * 4 : 0, stream, p,
+        const int use_lds_hist = lds_hist_ok(S);
+        DWG_LAUNCH("raster_preprocess", k_preprocess, dim3(dwg_cdiv(G, 256), F), dim3(256), use_lds_hist ? (size_t)S * 4 : 0, stream, p,
                    means3D, shs, colors_precomp, opacities, scales, rotations, cov3D_precomp, radii, (float4*)(ws + L.rec0),
                    (float4*)(ws + L.rec1), (float4*)(ws + L.rec2), (uint2*)(ws + L.rect), (uint32_t*)(ws + L.npairs),
-                   (uint32_t*)(ws + L.idsum), (uint32_t*)(ws + L.tile_count), (int32_t*)(ws + L.header), use_lds_hist);
+                   (uint32_t*)(ws + L.idsum), (uint32_t*)(ws + L.super_count), (int32_t*)(ws + L.header), use_lds_hist);
     }
-    // workgroup 0: block lists (starts, segments, size classes, render order); workgroups 1..: the pair rows of GTILE Gaussians each
-    DWG_LAUNCH("raster_scan_tiles", k_scan_tiles, dim3(1 + dwg_cdiv(G, GTILE)), dim3(1024), 0, stream, T, (const uint32_t*)(ws + L.tile_count),
-               (uint32_t*)(ws + L.tile_start), (uint32_t*)(ws + L.seg_start), (uint32_t*)(ws + L.cls), (uint32_t*)(ws + L.order),
-               (int32_t*)(ws + L.header), G, (const uint32_t*)(ws + L.npairs), (const uint32_t*)(ws + L.idsum),
-               (uint32_t*)(ws + L.goff));
+    // workgroup 0: supertile lists (starts, size classes); workgroups 1..: the pair rows of GTILE Gaussians each + the frame's pair count
+    DWG_LAUNCH("raster_scan_super", k_scan_super, dim3(1 + dwg_cdiv(G, GTILE), F), dim3(1024), 0, stream, p,
+               (const uint32_t*)(ws + L.super_count), (uint32_t*)(ws + L.super_start), (uint32_t*)(ws + L.cls), (int32_t*)(ws + L.header),
+               (const uint32_t*)(ws + L.npairs), (const uint32_t*)(ws + L.idsum), (uint32_t*)(ws + L.goff));
+    DWG_RETURN_IF_LAUNCH_FAILED();
+    return DWG_OK;
+}
+
+int dwg_raster_forward_bin(const dwg_raster_settings* cfg, int32_t G, const float* means3D, const float* shs,
+                           const float* colors_precomp, const float* opacities, const float* scales,
+                           const float* rotations, const float* cov3D_precomp, int32_t* radii, void* ws_geom,
+                           dwg_stream_t stream_) {
+    return dwg_raster_forward_bin_frames(cfg, nullptr, G, means3D, shs, colors_precomp, opacities, scales, rotations, cov3D_precomp, radii,
+                                         ws_geom, stream_);
+}
+
+int dwg_raster_forward_render_frames(const dwg_raster_settings* cfg, const dwg_raster_frames* frames, int32_t G, void* ws_geom,
+                                     void* ws_pairs, int64_t pair_capacity, void* ws_image, float* out_color, float* out_depth,
+                                     float* out_alpha, dwg_stream_t stream_) {
+    Params p;
+    int rc = make_params(cfg, frames, G, &p);
+    if (rc) return rc;
+    if (!ws_geom || !ws_pairs || !ws_image || !out_color || !out_depth || !out_alpha || pair_capacity < 0) return DWG_E_ARG;
+    if (pair_capacity > 0xfffffff0ll) return DWG_E_ARG;       // list offsets are 32-bit
+    const int F = frames ? frames->num_frames : 1;
+    hipStream_t stream = (hipStream_t)stream_;
+    GeomLayout L = geom_layout(G, p.H, p.W);
+    PairLayout PL = pair_layout(pair_capacity, p.H, p.W);
+    ImageLayout IL = image_layout(p.H, p.W);
+    p.geom_stride = L.total; p.pairs_stride = PL.total; p.image_stride = IL.total;
+    const int64_t cap_segs = seg_capacity(pair_capacity > 0 ? pair_capacity : 1, p.H, p.W);
+    char* ws = (char*)ws_geom; char* wp = (char*)ws_pairs; char* wi = (char*)ws_image;
+    const int T = p.tiles_x * p.tiles_y, S = p.stiles_x * p.stiles_y;
+    uint64_t* keys = (uint64_t*)(wp + PL.keys);
+    uint32_t* sorted = (uint32_t*)(wp + PL.sorted);
+    uint32_t* tile_start = (uint32_t*)(ws + L.tile_start);
+    uint32_t* tile_count = (uint32_t*)(ws + L.tile_count);
+    const uint32_t* super_start = (const uint32_t*)(ws + L.super_start);
+    const uint32_t* cls = (const uint32_t*)(ws + L.cls);
+    int32_t* header = (int32_t*)(ws + L.header);
+    if (G > 0) {
+        const int use_lds = lds_hist_ok(S);
+        DWG_LAUNCH("raster_scatter", k_scatter_super, dim3(dwg_cdiv(G, 256), F), dim3(256), use_lds ? (size_t)S * 4 : 0, stream, p,
+                   (const float4*)(ws + L.rec0), (const float4*)(ws + L.rec1), (const uint2*)(ws + L.rect), super_start,
+                   (uint32_t*)(ws + L.super_cursor), keys, pair_capacity, header, use_lds);
+        // size classes (lists compacted by k_scan_super; surplus workgroups exit on their first instruction).  A supertile of class c holds
+        // more than {0, 1024, 4096, 16384} keys and the keys of a frame number at most its (Gaussian, block) pairs <= capacity, so at most
+        // capacity / that many such supertiles exist.  The long classes go first: they are the critical path.
+        static bool attr_set = false;
+        if (!attr_set) {
+            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_sort_super<2, 1024>), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                (16384 + 1024) * 8);
+            attr_set = true;
+        }
+        const int nD = (int)min((int64_t)S, pair_capacity / 16384 + 1), nC = (int)min((int64_t)S, pair_capacity / 4096 + 1),
+                  nB = (int)min((int64_t)S, pair_capacity / 1024 + 1);
+#define DWG_SORT_ARGS p, cls, header, super_start, keys, (const float4*)(ws + L.rec0), (const float4*)(ws + L.rec1), (const uint2*)(ws + L.rect), \
+                      tile_count, tile_start, sorted, pair_capacity
+        static const int t0 = getenv("DWG_RASTER_SORT_T0") ? atoi(getenv("DWG_RASTER_SORT_T0")) : 256;      // experiment switches: threads of the
+        static const int t1 = getenv("DWG_RASTER_SORT_T1") ? atoi(getenv("DWG_RASTER_SORT_T1")) : 1024;     // two common size classes
+        DWG_LAUNCH("raster_sort_super_g", (k_sort_super<3, 1024>), dim3(nD, F), dim3(1024), 0, stream, DWG_SORT_ARGS);
+        DWG_LAUNCH("raster_sort_super_xl", (k_sort_super<2, 1024>), dim3(nC, F), dim3(1024), (16384 + 1024) * 8, stream, DWG_SORT_ARGS);
+        if (t1 == 256) DWG_LAUNCH("raster_sort_super_l", (k_sort_super<1, 256>), dim3(nB, F), dim3(256), (4096 + 256) * 8, stream, DWG_SORT_ARGS);
+        else DWG_LAUNCH("raster_sort_super_l", (k_sort_super<1, 1024>), dim3(nB, F), dim3(1024), (4096 + 256) * 8, stream, DWG_SORT_ARGS);
+        if (t0 == 64) DWG_LAUNCH("raster_sort_super", (k_sort_super<0, 64>), dim3(S, F), dim3(64), (1024 + 64) * 8, stream, DWG_SORT_ARGS);
+        else DWG_LAUNCH("raster_sort_super", (k_sort_super<0, 256>), dim3(S, F), dim3(256), (1024 + 64) * 8, stream, DWG_SORT_ARGS);
+#undef DWG_SORT_ARGS
+    }
+    DWG_LAUNCH("raster_scan_tiles", k_scan_tiles, dim3(1, F), dim3(1024), 0, stream, p, (const uint32_t*)tile_count,
+               (uint32_t*)(ws + L.seg_start), (uint32_t*)(ws + L.order), header);
+    DWG_LAUNCH("raster_render_fwd", k_render_fwd, dim3(T, F), dim3(64), 0, stream, p, (const uint32_t*)(ws + L.order),
+               (const uint32_t*)tile_start, (const uint32_t*)tile_count,
+               (const uint32_t*)(ws + L.seg_start), (const uint32_t*)sorted, (const float4*)(ws + L.rec0), (const float4*)(ws + L.rec1),
+               (const float4*)(ws + L.rec2), pair_capacity, cap_segs, (uint32_t*)(wp + PL.seg_tile), (float*)(wp + PL.ckpt),
+               (uint32_t*)(ws + L.tile_neff), (float*)(wi + IL.final_T), (int*)(wi + IL.n_contrib), (float*)(wi + IL.craw), out_color,
+               out_depth, out_alpha);
     DWG_RETURN_IF_LAUNCH_FAILED();
     return DWG_OK;
 }
@@ -1344,76 +1552,7 @@ int dwg_raster_forward_bin(const dwg_raster_settings* cfg, int32_t G, const floa
 int dwg_raster_forward_render(const dwg_raster_settings* cfg, int32_t G, void* ws_geom, void* ws_pairs,
                               int64_t pair_capacity, void* ws_image, float* out_color, float* out_depth,
                               float* out_alpha, dwg_stream_t stream_) {
-    Params p;
-    int rc = make_params(cfg, G, &p);
-    if (rc) return rc;
-    if (!ws_geom || !ws_pairs || !ws_image || !out_color || !out_depth || !out_alpha || pair_capacity < 0) return DWG_E_ARG;
-    hipStream_t stream = (hipStream_t)stream_;
-    GeomLayout L = geom_layout(G, p.H, p.W);
-    PairLayout PL = pair_layout(pair_capacity, p.H, p.W);
-    ImageLayout IL = image_layout(p.H, p.W);
-    const int64_t cap_segs = seg_capacity(pair_capacity > 0 ? pair_capacity : 1, p.H, p.W);
-    char* ws = (char*)ws_geom; char* wp = (char*)ws_pairs; char* wi = (char*)ws_image;
-    int T = p.tiles_x * p.tiles_y;
-    uint64_t* keys = (uint64_t*)(wp + PL.keys);
-    uint32_t* sorted = (uint32_t*)(wp + PL.sorted);
-    const uint32_t* tile_start = (const uint32_t*)(ws + L.tile_start);
-    const uint32_t* cls = (const uint32_t*)(ws + L.cls);
-    const int32_t* header = (const int32_t*)(ws + L.header);
-    if (G > 0) {
-        const int use_lds = lds_hist_ok(T);
-        DWG_LAUNCH("raster_scatter", k_scatter, dim3(dwg_cdiv(G, 256)), dim3(256), use_lds ? (size_t)T * 4 : 0, stream, p,
-                   (const float4*)(ws + L.rec0), (const float4*)(ws + L.rec1), (const uint2*)(ws + L.rect), tile_start,
-                   (uint32_t*)(ws + L.tile_cursor), keys, pair_capacity, (int32_t*)(ws + L.header), use_lds);
-        // size classes (lists compacted by k_scan_tiles; surplus workgroups exit on their first instruction):
-        //   <= 1024 pairs: one wave, 8 KiB LDS | <= 4096: 256 threads, 32 KiB | <= 16384: 1024 threads, 128 KiB | larger: in global memory
-        static bool attr_set = false;
-        if (!attr_set) {
-            hipFuncSetAttribute(reinterpret_cast<const void*>(&k_tile_sort<2, 1024, false>), hipFuncAttributeMaxDynamicSharedMemorySize,
-                                16384 * 8);
-            attr_set = true;
-        }
-        // the long classes first: they are the critical path, the short ones fill in behind them
-        // (a block of class c holds more than {0, 1024, 4096, 16384} pairs, so at most capacity / that many such blocks exist)
-        const int nD = (int)min((int64_t)T, pair_capacity / 16384 + 1), nC = (int)min((int64_t)T, pair_capacity / 4096 + 1),
-                  nB = (int)min((int64_t)T, pair_capacity / 1024 + 1);
-        // (the four classes sort disjoint blocks; running the three long ones as a parallel branch of a captured graph was measured SLOWER --
-        // c1 0.280 -> 0.336 ms per frame, c2 1.21 -> 1.29 ms per step: a cross-stream edge costs a replay more than three near-empty nodes)
-        DWG_LAUNCH("raster_tile_sort_g", (k_tile_sort<3, 1024, true>), dim3(nD), dim3(1024), 0, stream, T, cls, header, tile_start,
-                   keys, sorted, pair_capacity);
-        static const bool lds_sort = getenv("DWG_RASTER_LDS_SORT") != nullptr;      // experiment switch: the round-1 LDS network
-        if (!lds_sort) {
-            static bool attr2 = false;
-            if (!attr2) {
-                hipFuncSetAttribute(reinterpret_cast<const void*>(&k_tile_sort_regs<2, 1024>), hipFuncAttributeMaxDynamicSharedMemorySize,
-                                    (16384 + 1024) * 8);
-                attr2 = true;
-            }
-            DWG_LAUNCH("raster_tile_sort_xl", (k_tile_sort_regs<2, 1024>), dim3(nC), dim3(1024), (16384 + 1024) * 8, stream, T, cls, header,
-                       tile_start, (const uint64_t*)keys, sorted, pair_capacity);
-        } else {
-            DWG_LAUNCH("raster_tile_sort_xl", (k_tile_sort<2, 1024, false>), dim3(nC), dim3(1024), 16384 * 8, stream, T, cls, header, tile_start,
-                       keys, sorted, pair_capacity);
-        }
-        if (lds_sort) {
-            DWG_LAUNCH("raster_tile_sort_l", (k_tile_sort<1, 256, false>), dim3(nB), dim3(256), 4096 * 8, stream, T, cls, header, tile_start,
-                       keys, sorted, pair_capacity);
-            DWG_LAUNCH("raster_tile_sort", (k_tile_sort<0, 64, false>), dim3(T), dim3(64), 1024 * 8, stream, T, cls, header, tile_start,
-                       keys, sorted, pair_capacity);
-        } else {
-            DWG_LAUNCH("raster_tile_sort_l", (k_tile_sort_regs<1, 256>), dim3(nB), dim3(256), (4096 + 256) * 8, stream, T, cls, header,
-                       tile_start, (const uint64_t*)keys, sorted, pair_capacity);
-            DWG_LAUNCH("raster_tile_sort", (k_tile_sort_regs<0, 64>), dim3(T), dim3(64), (1024 + 64) * 8, stream, T, cls, header, tile_start,
-                       (const uint64_t*)keys, sorted, pair_capacity);
-        }
-    }
-    DWG_LAUNCH("raster_render_fwd", k_render_fwd, dim3(T), dim3(64), 0, stream, p, (const uint32_t*)(ws + L.order), tile_start,
-               (const uint32_t*)(ws + L.seg_start), (const uint32_t*)sorted, (const float4*)(ws + L.rec0), (const float4*)(ws + L.rec1),
-               (const float4*)(ws + L.rec2), pair_capacity, cap_segs, (uint32_t*)(wp + PL.seg_tile), (float*)(wp + PL.ckpt),
-               (uint32_t*)(ws + L.tile_neff), (float*)(wi + IL.final_T), (int*)(wi + IL.n_contrib), (float*)(wi + IL.craw), out_color,
-               out_depth, out_alpha);
-    DWG_RETURN_IF_LAUNCH_FAILED();
-    return DWG_OK;
+    return dwg_raster_forward_render_frames(cfg, nullptr, G, ws_geom, ws_pairs, pair_capacity, ws_image, out_color, out_depth, out_alpha, stream_);
 }
 
 int dwg_raster_backward(const dwg_raster_settings* cfg, int32_t G, const float* means3D, const float* shs,
@@ -1423,7 +1562,7 @@ int dwg_raster_backward(const dwg_raster_settings* cfg, int32_t G, const float* 
                         const float* dL_dout_depth, const float* dL_dout_alpha, float* dL_dmeans3D, float* dL_dmeans2D, float* dL_dshs, float* dL_dcolors, float* dL_dopacities,
                         float* dL_dscales, float* dL_drotations, float* dL_dcov3D, dwg_stream_t stream_) {
     Params p;
-    int rc = make_params(cfg, G, &p);
+    int rc = make_params(cfg, nullptr, G, &p);
     if (rc) return rc;
     if (!ws_geom || !ws_pairs || !ws_image || !ws_grad || !dL_dout_color || !dL_dmeans3D || pair_capacity < 0)
         return DWG_E_ARG;
@@ -1441,8 +1580,9 @@ int dwg_raster_backward(const dwg_raster_settings* cfg, int32_t G, const float* 
     // a fresh tag per backward: rows of the pair-ordered partials count only if this frame wrote them (no clearing of the buffer)
     // (the tag itself is header[H_TAG], drawn on the device by the forward's scan kernel: see g_frame_tag)
     const uint32_t tag = 0u;
+    static const int gbig = getenv("DWG_RASTER_GBIG") ? atoi(getenv("DWG_RASTER_GBIG")) : 64;      // experiment switch (see k_gather_partials)
 #define DWG_BWD_ARGS p, (const int32_t*)(ws + L.header), cap_segs, (const uint32_t*)(wp + PL.seg_tile), (const uint32_t*)(ws + L.seg_start),   \
-        (const uint32_t*)(ws + L.tile_start), (const uint32_t*)(ws + L.tile_neff), (const uint32_t*)(wp + PL.sorted),                               \
+        (const uint32_t*)(ws + L.tile_start), (const uint32_t*)(ws + L.tile_count), (const uint32_t*)(ws + L.tile_neff), (const uint32_t*)(wp + PL.sorted), \
         (const uint2*)(ws + L.rect), (const uint32_t*)(ws + L.goff), tag, (const float4*)(ws + L.rec0), (const float4*)(ws + L.rec1),           \
         (const float4*)(ws + L.rec2), pair_capacity, (const float*)(wp + PL.ckpt), (const float*)(wi + IL.final_T),                              \
         (const int*)(wi + IL.n_contrib), (const float*)(wi + IL.craw), dL_dout_color, dL_dout_depth, dL_dout_alpha,                              \
@@ -1451,7 +1591,7 @@ int dwg_raster_backward(const dwg_raster_settings* cfg, int32_t G, const float* 
     else DWG_LAUNCH("raster_render_bwd", k_render_bwd<false>, dim3((unsigned)cap_segs), dim3(64), 0, stream, DWG_BWD_ARGS);
 #undef DWG_BWD_ARGS
     DWG_LAUNCH("raster_gather_bwd", k_gather_partials, dim3(dwg_cdiv(G, 64)), dim3(256), 0, stream, G, (const uint32_t*)(ws + L.goff),
-               (const float*)(wp + PL.part), pair_capacity, (const int32_t*)(ws + L.header), tag, (float*)ws_grad);
+               (const float*)(wp + PL.part), pair_capacity, (const int32_t*)(ws + L.header), tag, (float*)ws_grad, gbig);
     DWG_LAUNCH("raster_preprocess_bwd", k_preprocess_bwd, dim3(dwg_cdiv(G, 256)), dim3(256), 0, stream, p, means3D, shs, colors_precomp,
                scales, rotations, cov3D_precomp, (const uint2*)(ws + L.rect), (const float4*)(ws + L.rec2),
                (const float*)ws_grad, dL_dmeans3D, dL_dmeans2D, dL_dshs, dL_dcolors, dL_dopacities, dL_dscales,

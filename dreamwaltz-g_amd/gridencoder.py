@@ -240,11 +240,12 @@ class _grid_encode(Function):
         slab_ws = slab_workspace_for(inputs.device, B, L, int(embeddings.shape[0])) if mode == "slabs" else None
         # The table is a leaf Parameter whose .grad is its slice of the flat gradient buffer (optim.FlatBuffers marks such parameters:
         # `_dwg_flat`): the slab pass ADDS straight into it and autograd is handed None -- instead of a zeroed 50 MB temporary that autograd
-        # then adds to .grad (a 50 MB fill and a 150 MB add per backward).  Opt-in PER PARAMETER: any other caller (torch.autograd.grad on
-        # the table, tensor hooks, another optimizer) gets the gradient returned the ordinary way.  DWG_GRID_GRAD_INPLACE=0: always.
+        # then adds to .grad (a 50 MB fill and a 150 MB add per backward).  Opt-in PER PARAMETER: a frozen table, a table whose .grad was
+        # rebound, a table of another optimizer or one autograd did not ask a gradient for gets the gradient returned the ordinary way
+        # (FlatBuffers.owns_grad).  `torch.autograd.grad(out, [table])` on a flat-buffer table cannot be told from `.backward()` here: such
+        # a caller wraps the forward in `table_grad_inplace(False)`.  DWG_GRID_GRAD_INPLACE=0: never in place.
         flat = getattr(embeddings, "_dwg_flat", None)
-        in_place = (mode == "slabs" and flat is not None and embeddings.is_leaf and embeddings.grad is not None and embeddings.grad.is_contiguous()
-                    and embeddings.grad.dtype == torch.float32 and embeddings.grad.shape == embeddings.shape
+        in_place = (mode == "slabs" and flat is not None and ctx.needs_input_grad[1] and flat.owns_grad(embeddings)
                     and ctx.inplace_ok and os.environ.get("DWG_GRID_GRAD_INPLACE", "1") != "0")
         grad_embeddings = embeddings.grad if in_place else torch.zeros_like(embeddings)
         counters = xcd_counters_for(inputs.device) if (mode == "owner" and grad_embeddings.data_ptr() % 128 == 0) else None

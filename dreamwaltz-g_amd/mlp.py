@@ -29,12 +29,13 @@ def _inplace_allowed():
     return bool(gridencoder._INPLACE_OK[0]) and os.environ.get("DWG_MLP_GRAD_INPLACE", "1") != "0"
 
 
-def _flat_slice(p, used):
-    """The FlatBuffers object whose gradient buffer `p.grad` is a slice of, if the backward may add into it directly: `p` is a leaf
-    Parameter marked by optim.FlatBuffers, its .grad is a contiguous fp32 tensor of its own shape, and (weights) the tensor the kernels
-    read IS the parameter (no dtype / layout copy in between)."""
+def _flat_slice(p, used, needed=True):
+    """The FlatBuffers object whose gradient buffer `p.grad` is a slice of, if the backward may add into it directly: autograd asked for
+    this input's gradient (`needed` = the matching ctx.needs_input_grad entry), `p` is a TRAINABLE leaf Parameter optim.FlatBuffers
+    re-homed whose .grad still is that slice (FlatBuffers.owns_grad: address, shape and dtype -- a frozen parameter, or a .grad the user
+    rebound, gets the ordinary returned gradient), and (weights) the tensor the kernels read IS the parameter (no dtype / layout copy)."""
     flat = getattr(p, "_dwg_flat", None) if p is not None else None
-    if flat is None or not p.is_leaf or p.grad is None or not p.grad.is_contiguous() or p.grad.dtype != torch.float32 or p.grad.shape != p.shape:
+    if flat is None or not needed or not flat.owns_grad(p):
         return None
     if used is not None and (used.data_ptr() != p.data_ptr() or used.shape != p.shape):
         return None
@@ -169,9 +170,13 @@ class _MlpChain(torch.autograd.Function):
             # A weight / bias that is a leaf Parameter whose .grad is its slice of a flat gradient buffer (optim.FlatBuffers marks those:
             # `_dwg_flat`) gets its gradient ADDED into that slice by the reduce kernel and autograd is handed None -- no temporary, no
             # AccumulateGrad `add_` launch per parameter (sixteen per step for the two networks).  Anything else (the concatenated heads of
-            # the deformation network, torch.autograd.grad callers, parameters of another optimizer) gets its gradient returned as usual.
-            wflat = [_flat_slice(ctx.params[l][0], ws[l]) if ctx.inplace_ok else None for l in range(nl)]
-            bflat = [_flat_slice(ctx.params[l][1], None) if (ctx.inplace_ok and ctx.has_b[l]) else None for l in range(nl)]
+            # the deformation network, frozen parameters, inputs autograd did not ask a gradient for, parameters of another optimizer or
+            # with a rebound .grad) gets its gradient returned as usual.  NOT detectable here: `torch.autograd.grad(out, [weight])` on a
+            # flat-buffer parameter -- that caller would receive None while the slice is added to; it must wrap the FORWARD in
+            # `gridencoder.table_grad_inplace(False)` (what the concurrent multi-view backwards do, trainer.py).
+            nig = ctx.needs_input_grad
+            wflat = [_flat_slice(ctx.params[l][0], ws[l], nig[3 + 2 * l]) if ctx.inplace_ok else None for l in range(nl)]
+            bflat = [_flat_slice(ctx.params[l][1], None, nig[4 + 2 * l]) if (ctx.inplace_ok and ctx.has_b[l]) else None for l in range(nl)]
             dws = [ctx.params[l][0].grad if wflat[l] is not None else torch.empty_like(ws[l]) for l in range(nl)]
             dbs = torch.empty(nl, 64, device=dev)
             dbp = [ctx.params[l][1].grad.data_ptr() if bflat[l] is not None else dbs[l].data_ptr() for l in range(nl)]

@@ -71,6 +71,7 @@ class FlatBuffers:
             p.data = self.flat[off:off + n].view_as(p.data)
             p.grad = self.grad[off:off + n].view_as(p.data)
             p._dwg_flat = self          # "my .grad is a slice of a flat gradient buffer": what lets a kernel add into it in place
+            p._dwg_off = off            # ... namely the one that starts at element `off` (checked by `owns_grad` before any in-place add)
             p._dwg_touched = False
             if p.requires_grad:
                 self._hooks.append(p.register_post_accumulate_grad_hook(self.touch))
@@ -79,6 +80,15 @@ class FlatBuffers:
     def touch(self, p):
         p._dwg_touched = True
         self.tracking = True
+
+    def owns_grad(self, p) -> bool:
+        """True iff a kernel may ADD p's gradient into `p.grad` and report participation through `touch` instead of returning it to autograd:
+        p is a trainable leaf this object re-homed and `p.grad` still IS its slice of the flat gradient buffer (same address, shape, dtype) --
+        not a tensor a user rebound since, which the fused Adam would never read.  Frozen parameters (requires_grad False) are refused:
+        autograd would have dropped their gradient and the optimizer must not see one."""
+        g = p.grad
+        return (getattr(p, "_dwg_flat", None) is self and p.is_leaf and p.requires_grad and g is not None and g.dtype == torch.float32
+                and g.is_contiguous() and g.shape == p.shape and g.data_ptr() == self.grad.data_ptr() + 4 * int(getattr(p, "_dwg_off", -1)))
 
     def release(self, params):
         """Detach from the parameters (the buffers are being replaced: resize_flat_params)."""

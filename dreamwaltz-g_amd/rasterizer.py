@@ -233,6 +233,71 @@ class _RasterizeGaussians(torch.autograd.Function):
         return d_means3D, d_means2D, d_sh, d_colors, d_opac, d_scales, d_rots, d_cov, None, None, None, None
 
 
+def rasterize_frames(means3D, opacities, colors_precomp=None, shs=None, scales=None, rotations=None, cov3D_precomp=None, *,
+                     cameras, image_height, image_width, tanfovx, tanfovy, bg, sh_degree=0, scale_modifier=1.0, pair_capacity=None):
+    """Forward of F frames in ONE launch chain (include/dwg_raster.h `dwg_raster_frames`; no autograd: the playback path).
+
+    Per-Gaussian inputs are either [F, G, ...] (one posed set of Gaussians per frame) or [G, ...] (shared by all frames);
+    `cameras` is [F, 35] or [35] float32 = [viewmatrix 16 | projmatrix 16 | campos 3] rows as `dwg_raster_camera_setup` writes them.
+    Frame f's outputs are bit-identical to a single-frame call with its inputs (the reference's call at
+    /root/reference/core/gaussian/gaussian_renderer.py:186-195, once per frame).
+    -> color [F,3,H,W], radii [F,G] int32, depth [F,1,H,W], alpha [F,1,H,W], info dict(num_pairs [F], overflow [F], capacity)."""
+    if not means3D.is_cuda:
+        raise RuntimeError("dreamwaltz_g_amd rasterizer runs on the GPU only (HIP kernels); got a CPU tensor")
+    L = _lib.lib()
+    device = means3D.device
+    per_frame = means3D.dim() == 3
+    cameras = _f32c(cameras)
+    F = int(means3D.shape[0]) if per_frame else (int(cameras.shape[0]) if cameras.dim() == 2 else 1)
+    if cameras.dim() == 2 and int(cameras.shape[0]) not in (1, F):
+        raise ValueError("rasterize_frames: %d cameras for %d frames" % (cameras.shape[0], F))
+    G = int(means3D.shape[-2])
+    H, W = int(image_height), int(image_width)
+
+    def arr(t, tail):
+        if t is None:
+            return None
+        t = _f32c(t)
+        want = ((F, G) if per_frame else (G,)) + tail
+        if tuple(t.shape) != want and not (tail == () and tuple(t.shape) == want + (1,)):
+            raise ValueError("rasterize_frames: expected shape %s, got %s" % (want, tuple(t.shape)))
+        return t
+    means3D = arr(means3D, (3,)); opac = arr(opacities, ())
+    colors_precomp = arr(colors_precomp, (3,)); scales = arr(scales, (3,)); rotations = arr(rotations, (4,)); cov3D = arr(cov3D_precomp, (6,))
+    M = 0
+    if shs is not None:
+        shs = _f32c(shs); M = int(shs.shape[-2])
+    if (shs is None) == (colors_precomp is None):
+        raise Exception("Please provide excatly one of either SHs or precomputed colors!")
+    keep = []
+    rs = GaussianRasterizationSettings(H, W, float(tanfovx), float(tanfovy), bg, float(scale_modifier), cameras.reshape(-1)[0:16],
+                                       cameras.reshape(-1)[16:32], int(sh_degree), cameras.reshape(-1)[32:35], False, False)
+    cfg = _settings_struct(rs, device, M, keep)
+    fr = _lib.RasterFramesC(F, G if per_frame else 0, 35 if (cameras.dim() == 2 and cameras.shape[0] == F and F > 1) else 0)
+    gb, pb, ib = ctypes.c_size_t(), ctypes.c_size_t(), ctypes.c_size_t()
+    _lib.check(L.dwg_raster_workspace_sizes(G, H, W, 0, ctypes.byref(gb), ctypes.byref(pb), ctypes.byref(ib)), "dwg_raster_workspace_sizes")
+    ws_geom = torch.empty(F * gb.value, dtype=torch.uint8, device=device)
+    ws_image = torch.empty(F * ib.value, dtype=torch.uint8, device=device)
+    radii = torch.zeros(F, G, dtype=torch.int32, device=device)
+    st, p = _stream(device), _lib.ptr
+    _lib.check(L.dwg_raster_forward_bin_frames(ctypes.byref(cfg), ctypes.byref(fr), G, p(means3D), p(shs), p(colors_precomp), p(opac),
+                                               p(scales), p(rotations), p(cov3D), p(radii), p(ws_geom), st), "dwg_raster_forward_bin_frames")
+    hdrs = ws_geom.view(F, gb.value)[:, :16].contiguous().view(torch.int32)
+    if pair_capacity is None:              # one read-back of the F pair counts sizes the shared capacity exactly
+        cap = max(int(hdrs[:, 0].max().item()), 1)
+    else:
+        cap = int(pair_capacity)
+    _lib.check(L.dwg_raster_workspace_sizes(G, H, W, cap, ctypes.byref(gb), ctypes.byref(pb), ctypes.byref(ib)), "dwg_raster_workspace_sizes")
+    ws_pairs = torch.empty(F * pb.value, dtype=torch.uint8, device=device)
+    color = torch.empty(F, 3, H, W, dtype=torch.float32, device=device)
+    depth = torch.empty(F, 1, H, W, dtype=torch.float32, device=device)
+    alpha = torch.empty(F, 1, H, W, dtype=torch.float32, device=device)
+    _lib.check(L.dwg_raster_forward_render_frames(ctypes.byref(cfg), ctypes.byref(fr), G, p(ws_geom), p(ws_pairs), cap, p(ws_image),
+                                                  p(color), p(depth), p(alpha), st), "dwg_raster_forward_render_frames")
+    hdrs = ws_geom.view(F, -1)[:, :16].contiguous().view(torch.int32)         # device tensor: [F, 4] = K, overflow, K_ref, segments
+    return color, radii, depth, alpha, dict(headers=hdrs, capacity=cap)
+
+
 def morton_order(positions: torch.Tensor, bits: int = 10) -> torch.Tensor:
     """int32 permutation that walks `positions` [G,3] along a Z-order curve of their bounding box (3 x `bits` bits).  Gaussians that
     are neighbours in the walk are neighbours in space, hence on screen: a workgroup of the binning stages then touches a few

@@ -66,9 +66,10 @@ class GaussianRenderer:
         self._bg_dev = {}
         self.last_rasterizer = None
         # Binning order (rasterizer.morton_order): refreshed from the current positions every `reorder_every` frames per Gaussian
-        # count (0: never -- index order); the images do not depend on it.  DWG_RASTER_REORDER overrides the default of 64.
+        # count (0, the default since round 5: never -- index order, coalesced reads; the supertile histograms merge their atomics either way);
+        # the images do not depend on it.  DWG_RASTER_REORDER=<frames> switches the refresh on.
         if reorder_every is None:
-            reorder_every = int(os.environ.get("DWG_RASTER_REORDER", "64"))
+            reorder_every = int(os.environ.get("DWG_RASTER_REORDER", "0"))
         self.reorder_every = int(reorder_every)
         self._visit_orders = {}
 

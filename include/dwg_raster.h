@@ -44,10 +44,24 @@ typedef struct dwg_raster_settings {
     const float* projmatrix; /* [16] device */
     const float* campos;     /* [3]  device (only read for SH colours) */
     const int32_t* visit_order; /* [G] device or NULL: a PERMUTATION of 0..G-1, the order in which the binning stages walk the
-                                 * Gaussians.  Results do not depend on it (every per-block list is sorted by (depth, index)); a
-                                 * spatially coherent order makes the Gaussians of one workgroup share blocks, which is what the
-                                 * block-private binning histograms need to merge their global atomics.  NULL = index order. */
+                                 * Gaussians.  Results do not depend on it (every per-block list is sorted by (depth, index)).
+                                 * Since round 5 the binning granule is the 32x32-pixel supertile, whose workgroup-private
+                                 * histograms merge their global atomics in index order as well: NULL (index order, coalesced
+                                 * reads of the five input arrays) is the default; a spatially coherent order is still honoured. */
 } dwg_raster_settings;
+
+/* Several frames per launch chain (round 5): frame f reads per-Gaussian input row g at [f * gaussian_stride + g] of every input array
+ * (0: all frames share one set of Gaussians, e.g. several cameras on one pose) and its camera at viewmatrix / projmatrix / campos +
+ * f * camera_stride floats (0: one camera; 35 for the [viewmatrix 16 | projmatrix 16 | campos 3] blocks dwg_raster_camera_setup writes).
+ * Workspaces and outputs are frame-major: frame f owns bytes [f * size, (f + 1) * size) of each workspace (sizes from
+ * dwg_raster_workspace_sizes for ONE frame), radii [F, G], color [F, 3, H, W], depth / alpha [F, 1, H, W].  Every frame of a call has
+ * the same Gaussian count, image size, field of view and pair capacity.  The semantics of one frame are those of the single-frame
+ * call (/root/reference/core/gaussian/gaussian_renderer.py:186-195 once per frame), bit for bit. */
+typedef struct dwg_raster_frames {
+    int32_t num_frames;
+    int64_t gaussian_stride;
+    int64_t camera_stride;
+} dwg_raster_frames;
 
 /* Byte sizes of the three caller-owned workspaces.
  *  geom : per-Gaussian splat records + per-tile counters (kept from forward to backward)
@@ -61,7 +75,8 @@ int dwg_raster_workspace_sizes(int32_t num_gaussians, int32_t image_height, int3
  *   [0] K     pairs (Gaussian, 8x8 block) after exact culling = what the pair workspace must hold
  *   [1] overflow flag (stage B found pair_capacity < K: the frame is truncated and must be redone)
  *   [2] K_ref  sum over Gaussians of the 16x16 reference tiles their 3-sigma square touches (the K of SURVEY 8d's byte formula)
- *   [3] number of backward segments. */
+ *   [3] number of backward segments
+ *   [9] (Gaussian, 32x32 supertile) pairs = keys sorted this frame. */
 const int32_t* dwg_raster_num_pairs_ptr(const void* ws_geom);
 
 /* viewmatrix = extrinsic^T, projmatrix = viewmatrix @ projection^T, campos = c2w[:3,3] exactly as
@@ -70,18 +85,29 @@ const int32_t* dwg_raster_num_pairs_ptr(const void* ws_geom);
 int dwg_raster_camera_setup(const float* extrinsic, const float* projection, const float* c2w, float* out35,
                             dwg_stream_t stream);
 
-/* Stage A: project, build splat records, count (exact-culled) pairs per 8x8 pixel block, scan. */
+/* Stage A: project, build splat records, count the exact-culled (Gaussian, 8x8 block) pairs per Gaussian and the Gaussians per 32x32
+ * supertile, scan. */
 int dwg_raster_forward_bin(const dwg_raster_settings* cfg, int32_t num_gaussians,
                            const float* means3D, const float* shs, const float* colors_precomp,
                            const float* opacities, const float* scales, const float* rotations,
                            const float* cov3D_precomp, int32_t* radii, void* ws_geom,
                            dwg_stream_t stream);
 
-/* Stage B: scatter pairs into tile lists, depth-sort every tile in LDS, composite front-to-back. */
+/* Stage B: one (depth, id) key per (Gaussian, supertile), one sort per 32x32-pixel supertile, stable split into the supertile's sixteen
+ * 8x8-block lists, front-to-back compositing per block. */
 int dwg_raster_forward_render(const dwg_raster_settings* cfg, int32_t num_gaussians, void* ws_geom,
                               void* ws_pairs, int64_t pair_capacity, void* ws_image,
                               float* out_color, float* out_depth, float* out_alpha,
                               dwg_stream_t stream);
+
+/* The two forward stages for `frames->num_frames` frames per launch (see dwg_raster_frames; frames == NULL: one frame). */
+int dwg_raster_forward_bin_frames(const dwg_raster_settings* cfg, const dwg_raster_frames* frames, int32_t num_gaussians,
+                                  const float* means3D, const float* shs, const float* colors_precomp,
+                                  const float* opacities, const float* scales, const float* rotations,
+                                  const float* cov3D_precomp, int32_t* radii, void* ws_geom, dwg_stream_t stream);
+int dwg_raster_forward_render_frames(const dwg_raster_settings* cfg, const dwg_raster_frames* frames, int32_t num_gaussians,
+                                     void* ws_geom, void* ws_pairs, int64_t pair_capacity, void* ws_image,
+                                     float* out_color, float* out_depth, float* out_alpha, dwg_stream_t stream);
 
 /* Backward of the whole rasterizer. dL_dout_depth / dL_dout_alpha may be NULL (treated as zero).
  * No float atomics: every (Gaussian, block) pair's partial gradients go to the pair's own 48-byte row of a pair-ordered buffer inside

@@ -31,8 +31,10 @@ def _check_images(st, name):
     (1, 64, 64, {}),
     (333, 250, 130, {}),                                     # ragged image (not multiples of 16), non-square
     (3000, 128, 128, dict(scale_mul=6.0)),                   # large splats, many tiles per Gaussian
-    (6000, 64, 64, dict(cluster=0.05, opacity_range=(0.01, 0.05))),   # > 2048 pairs in a tile (64 KiB LDS class)
-    (12000, 64, 64, dict(cluster=0.02, opacity_range=(0.004, 0.02))),  # > 8192 pairs in a tile (global-sort class)
+    (6000, 64, 64, dict(cluster=0.05, opacity_range=(0.01, 0.05))),   # > 4096 keys in a supertile (sixteen-wave classes)
+    (12000, 64, 64, dict(cluster=0.02, opacity_range=(0.004, 0.02))),  # > 8192 keys in a supertile (136-KiB LDS class)
+    (20000, 64, 64, dict(cluster=0.02, opacity_range=(0.004, 0.02))),  # > 16384 keys in a supertile (in-memory sort class)
+    (2500, 40, 200, dict(scale_mul=3.0)),                    # ragged supertiles: 5 x 25 blocks, partial supertiles on both edges
     (2000, 128, 128, dict(same_depth=True)),                 # depth ties -> id order
 ])
 def test_forward_parity(G, H, W, kw):
@@ -243,3 +245,29 @@ def test_captured_backward_replays_do_not_see_the_previous_frames_rows():
                 assert int(state.truncated_host[0]) == 0
                 for k in names:
                     assert torch.equal(grads[k], eager[i][k]), (rnd, i, k, float((grads[k] - eager[i][k]).abs().max()))
+
+
+@pytest.mark.parametrize("shared_gaussians", [False, True])
+def test_frames_per_launch_equal_single_frames_bit_for_bit(shared_gaussians):
+    """Round 5: F frames per launch chain (include/dwg_raster.h dwg_raster_frames; the semantics of one frame are those of the reference's
+    call at gaussian_renderer.py:186-195).  Frame f of a batched call == the single-frame call on frame f's inputs, every output bit --
+    per-frame Gaussians with per-frame cameras (animation playback), and one set of Gaussians seen by several cameras (views of a step)."""
+    from dreamwaltz_g_amd.rasterizer import rasterize_frames
+    G, H, W, F = 9000, 136, 200, 3
+    scenes = [rc.make_scene(G, H, W, seed=21 + (0 if shared_gaussians else f), azimuth=30.0 + 40.0 * f, scale_mul=1.0 + 0.5 * f) for f in range(F)]
+    if shared_gaussians:
+        for sc in scenes[1:]:
+            for k in ("means3D", "opacities", "colors", "scales", "rotations"):
+                sc[k] = scenes[0][k]
+    cams = torch.stack([torch.cat([sc["viewmatrix"].reshape(-1), sc["projmatrix"].reshape(-1), sc["campos"].reshape(-1)]) for sc in scenes]).cuda()
+    stack = (lambda k: scenes[0][k].cuda()) if shared_gaussians else (lambda k: torch.stack([sc[k] for sc in scenes]).cuda())
+    color, radii, depth, alpha, info = rasterize_frames(stack("means3D"), stack("opacities"), colors_precomp=stack("colors"), scales=stack("scales"),
+                                                        rotations=stack("rotations"), cameras=cams, image_height=H, image_width=W,
+                                                        tanfovx=scenes[0]["tanfovx"], tanfovy=scenes[0]["tanfovy"], bg=scenes[0]["bg"].cuda())
+    hdr = info["headers"].cpu()
+    assert int(hdr[:, 1].max()) == 0 and int(hdr[:, 0].min()) > 0
+    for f, sc in enumerate(scenes):
+        one = rc.hip_render(sc)
+        assert torch.equal(one["color"], color[f]) and torch.equal(one["depth"], depth[f]) and torch.equal(one["alpha"], alpha[f]), f
+        assert torch.equal(one["radii"], radii[f]), f
+    _check_images(rc.image_err_stats(dict(color=color[1], depth=depth[1], alpha=alpha[1], radii=radii[1]), rc.oracle_forward(scenes[1])), "frame 1")
