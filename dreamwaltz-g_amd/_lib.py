@@ -6,7 +6,7 @@ import ctypes
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "csrc", "libdwg_hip.so")
+LIB_PATH = os.environ.get("DWG_LIB") or os.path.join(_HERE, "csrc", "libdwg_hip.so")      # DWG_LIB: an alternative build of the library (A/B experiments)
 _lib = None
 
 c_f32p = ctypes.c_void_p

@@ -13,9 +13,9 @@
 //     (minimum of the conic's quadratic form over the block rectangle against 2 ln(255 opacity), with a safety margin far
 //     above fp32 rounding) -- pairs the per-pixel test would reject for all 64 pixels never exist, results are unchanged;
 //   * round 5 -- SORT COARSE, SPLIT FINE: Gaussians are binned and depth-sorted per 32x32-pixel SUPERTILE (4x4 blocks; ~4x
-//     fewer keys than (Gaussian, block) pairs, one register-blocked bitonic network per supertile), and the sorted list is
-//     split STABLY into its sixteen block lists by the sorting workgroup itself (a block's list is a subsequence of its
-//     supertile's).  This replaced a per-block 64-bit sort of every pair (102 of the 290 us forward chain at 100 k
+//     fewer keys than (Gaussian, block) pairs; every 1024-key chunk of every list sorted by its own workgroup, the chunks of
+//     a list merged by rank -- one binary search per sibling chunk and key, no merge tree, no workgroup owning a long list),
+//     and the sorted list is split STABLY into its sixteen block lists (a block's list is a subsequence of its supertile's).  This replaced a per-block 64-bit sort of every pair (102 of the 290 us forward chain at 100 k
 //     Gaussians / 512^2) and the per-pair LDS histogram / scatter atomics of the two binning kernels (39 + 63 us);
 //   * the forward checkpoints the per-pixel compositing state every SEG splats; the backward then runs one wave per
 //     (block, segment) FRONT-TO-BACK from its checkpoint -- perfectly balanced, no serial chain over a long list -- using
@@ -27,8 +27,9 @@
 //                              48-byte splat record, exact pair count (scanline), supertile histogram (LDS-privatised)
 //            k_scan_super      supertile starts + size classes; per-Gaussian pair-row offsets (goff); the frame's pair count
 //   stage B  k_scatter_super   1 thread / Gaussian: (depth|id) 64-bit key into its supertiles' ranges
-//            k_sort_super      1 workgroup / supertile: sort, 16-bit block masks, stable split into the sixteen block lists
-//            k_scan_tiles      segment starts, render order, frame tag
+//            k_chunk_sort      1 workgroup / 1024 keys of a supertile's list: register-blocked bitonic network
+//            k_rank_merge      1 thread / key: place in the supertile's sorted list by binary searches in the sibling chunks; block mask
+//            k_split           1 workgroup / supertile: stable split into the sixteen block lists; list / segment / render-order pools
 //            k_render_fwd      1 wave / block, records staged through LDS, next batch prefetched into registers
 //   backward k_render_bwd      1 wave / (block, segment): pair-ordered partial rows, no atomics
 //            k_gather_partials per-Gaussian sum of its rows
@@ -42,9 +43,11 @@ namespace {
 
 #define RT 16            // the reference's tile edge: decides WHICH Gaussians a pixel sees
 #define BT 8             // pixel-block edge of this implementation (one wave64)
-#define ST 4             // blocks per supertile edge: Gaussians are binned and depth-sorted per 32x32-pixel supertile
+#ifndef ST
+#define ST 4
+#endif                   // blocks per supertile edge: Gaussians are binned and depth-sorted per 32x32-pixel supertile
 #define SEG 128          // splats per backward segment / forward checkpoint interval
-#define NCLASS 4         // sort size classes
+#define CHUNK 1024       // keys per sorting workgroup: a supertile's list is sorted in chunks, then rank-merged
 #define NBUCKET 20       // render-order buckets (log2 of the list length)
 #define GTILE 1024       // Gaussian indices per workgroup of the pair-row scan (k_scan_tiles)
 #define IDBIN 64         // ... whose base is the sum of per-IDBIN-indices pair counts (fine bins: ~IDBIN integer atomics per address in k_preprocess;
@@ -69,8 +72,9 @@ struct Params {
 };
 
 // header words of the geometry workspace
-enum { H_K = 0, H_OVERFLOW = 1, H_KREF = 2, H_NSEG = 3, H_CLASS0 = 4 /* .. +NCLASS */, H_TAG = 4 + NCLASS,
-       H_KS = 5 + NCLASS /* (Gaussian, supertile) pairs */, H_POOL = 6 + NCLASS /* running end of the block lists handed out so far */ };
+enum { H_K = 0, H_OVERFLOW = 1, H_KREF = 2, H_NSEG = 3 /* backward segments handed out so far */, H_NCHUNK = 4 /* sorting chunks of the frame */,
+       H_TAG = 8, H_KS = 9 /* (Gaussian, supertile) pairs */, H_POOL = 10 /* running end of the block lists handed out so far */,
+       H_BKT0 = 16 /* .. + NBUCKET: blocks per render-order bucket */ };
 
 // Frame tags of the backward's pair-ordered partial rows (k_render_bwd / k_gather_partials) are drawn ON THE DEVICE, by the forward's scan
 // kernel, from this counter: a tag chosen by the host at launch time is a kernel argument, and kernel arguments are frozen into a captured
@@ -80,7 +84,7 @@ __device__ uint32_t g_frame_tag = 0x5eed0001u;
 
 struct GeomLayout {
     size_t header, rec0, rec1, rec2, rect, npairs, goff, tile_count, super_count, super_cursor, idsum, zero_end, tile_start, super_start, seg_start,
-        tile_neff, order, cls, total;
+        tile_neff, order, chunk_start, kref_part, total;
 };
 
 static GeomLayout geom_layout(int G, int H, int W) {
@@ -89,24 +93,25 @@ static GeomLayout geom_layout(int G, int H, int W) {
     size_t S = (size_t)dwg_cdiv(dwg_cdiv(W, BT), ST) * dwg_cdiv(dwg_cdiv(H, BT), ST);
     size_t g = (size_t)(G > 0 ? G : 1);
     size_t o = 0;
-    L.header = o; o += 256;
+    L.header = o; o += 256;                                      // header .. idsum are cleared together (one memset per frame)
+    L.tile_count = o; o = dwg_align_up(o + T * 4, 256);
+    L.super_count = o; o = dwg_align_up(o + S * 4, 256);
+    L.super_cursor = o; o = dwg_align_up(o + S * 4, 256);
+    L.idsum = o; o = dwg_align_up(o + (g / IDBIN + 8) * 4, 256);   // pair count of every run of IDBIN Gaussian indices (one slot per wave of k_preprocess)
+    L.zero_end = o;
     L.rec0 = o; o = dwg_align_up(o + g * sizeof(float4), 256);
     L.rec1 = o; o = dwg_align_up(o + g * sizeof(float4), 256);
     L.rec2 = o; o = dwg_align_up(o + g * sizeof(float4), 256);
     L.rect = o; o = dwg_align_up(o + g * sizeof(uint2), 256);
     L.npairs = o; o = dwg_align_up(o + g * 4, 256);              // (Gaussian, block) pairs of every Gaussian after exact culling ...
     L.goff = o; o = dwg_align_up(o + (g + 1) * 4, 256);          // ... and their exclusive prefix in INDEX order: pair row q = goff[g] + e
-    L.tile_count = o; o = dwg_align_up(o + T * 4, 256);          // tile_count .. idsum are cleared together (one memset per frame)
-    L.super_count = o; o = dwg_align_up(o + S * 4, 256);
-    L.super_cursor = o; o = dwg_align_up(o + S * 4, 256);
-    L.idsum = o; o = dwg_align_up(o + (g / IDBIN + 2) * 4, 256);   // pair count of every run of IDBIN Gaussian indices (integer atomics: exact)
-    L.zero_end = o;
     L.tile_start = o; o = dwg_align_up(o + T * 4, 256);          // a block's list is sorted[tile_start, tile_start + tile_count)
     L.super_start = o; o = dwg_align_up(o + (S + 1) * 4, 256);
     L.seg_start = o; o = dwg_align_up(o + (T + 1) * 4, 256);
     L.tile_neff = o; o = dwg_align_up(o + T * 4, 256);
-    L.order = o; o = dwg_align_up(o + T * 4, 256);
-    L.cls = o; o = dwg_align_up(o + (size_t)NCLASS * S * 4, 256);
+    L.order = o; o = dwg_align_up(o + (size_t)NBUCKET * T * 4, 256);   // render order: bucket k (log2 of the list length) owns order[k T ..]
+    L.chunk_start = o; o = dwg_align_up(o + (S + 1) * 4, 256);
+    L.kref_part = o; o = dwg_align_up(o + (g / 256 + 2) * 4, 256);
     L.total = o;
     return L;
 }
@@ -114,11 +119,12 @@ static GeomLayout geom_layout(int G, int H, int W) {
 static int64_t seg_capacity(int64_t cap, int H, int W) {
     return cap / SEG + (int64_t)dwg_cdiv(W, BT) * dwg_cdiv(H, BT) + 1;
 }
-struct PairLayout { size_t keys, sorted, seg_tile, ckpt, part, total; };
+struct PairLayout { size_t keys, cand, sorted, seg_tile, ckpt, part, total; };
 static PairLayout pair_layout(int64_t cap, int H, int W) {
     PairLayout L; size_t c = (size_t)(cap > 0 ? cap : 1);
     size_t ns = (size_t)seg_capacity((int64_t)c, H, W);
-    L.keys = 0; L.sorted = dwg_align_up(c * 8, 256);
+    L.keys = 0; L.cand = dwg_align_up(c * 8, 256);          // (depth | id) keys per supertile; (block mask | id) candidates in sorted order
+    L.sorted = dwg_align_up(L.cand + c * 8, 256);
     L.seg_tile = dwg_align_up(L.sorted + c * 4, 256);
     L.ckpt = dwg_align_up(L.seg_tile + ns * 4, 256);
     L.part = dwg_align_up(L.ckpt + ns * 6 * 64 * sizeof(float), 256);      // backward: one row of GSTRIDE floats per pair, in pair-row order
@@ -280,9 +286,14 @@ __device__ float3 sh_color(int deg, int M, const float* sh, float3 pos, const fl
 struct BlockSpan {
     int by0, by1;        // block rows [by0, by1)
     int bx0, bx1;        // block columns of the reference tile rect [bx0, bx1)
-    float gx, gy, ca, cb, cc, thr, det, hy, yr;
+    float gx, gy, ca, cb, cc, thr, det, hy, yr, ica;
     bool all;            // no culling (conic not positive definite / opacity not a positive number): every block of the rect
 };
+// hardware reciprocal / square root / log2 (1 ulp; ~2e-7 relative): the enumeration only has to be CONSERVATIVE -- its margins are four orders
+// of magnitude above these errors -- and identical wherever it is evaluated, and the IEEE-rounded division / sqrtf / logf sequences were most
+// of the instructions of a block row (k_preprocess: issue-stall 0.62 on them)
+__device__ __forceinline__ float fast_rcp(float x) { return __builtin_amdgcn_rcpf(x); }
+__device__ __forceinline__ float fast_sqrt(float x) { return __builtin_amdgcn_sqrtf(x); }
 __device__ __forceinline__ BlockSpan block_span(float gx, float gy, float ca, float cb, float cc, float opacity, int tx0, int ty0, int tx1,
                                                 int ty1, int tiles_x, int tiles_y) {
     // four kernels (pair count, supertile keys, block masks, the backward's row index) evaluate this enumeration and must agree to the bit:
@@ -291,16 +302,18 @@ __device__ __forceinline__ BlockSpan block_span(float gx, float gy, float ca, fl
     BlockSpan s;
     s.gx = gx; s.gy = gy; s.ca = ca; s.cb = cb; s.cc = cc;
     s.bx0 = 2 * tx0; s.bx1 = min(2 * tx1, tiles_x); s.by0 = 2 * ty0; s.by1 = min(2 * ty1, tiles_y);
-    s.thr = 2.f * logf(255.f * opacity) * (1.f + 1e-4f) + 1e-3f;
+    s.thr = (2.f * 0.6931471805599453f) * __builtin_amdgcn_logf(255.f * opacity) * (1.f + 1e-4f) + 1e-3f;      // 2 ln(255 opacity), with margin
     s.det = ca * cc - cb * cb;
     s.all = !(ca > 0.f) || !(cc > 0.f) || !(s.det > 0.f) || !(s.thr == s.thr);
-    s.hy = 0.f; s.yr = 0.f;
+    s.hy = 0.f; s.yr = 0.f; s.ica = 0.f;
     if (!s.all) {
         if (!(s.thr > 0.f)) { s.by1 = s.by0; return s; }                  // never reaches alpha 1/255
-        s.hy = sqrtf(s.thr * ca / s.det) + 1e-3f;                           // half height of the ellipse
-        s.yr = -cb / cc * sqrtf(s.thr * cc / s.det);                        // y of its rightmost point (leftmost: -yr)
-        s.by0 = max(s.by0, (int)ceilf((gy - s.hy - (float)(BT - 1)) / BT));
-        s.by1 = min(s.by1, (int)floorf((gy + s.hy) / BT) + 1);
+        const float idet = fast_rcp(s.det);
+        s.ica = fast_rcp(ca);
+        s.hy = fast_sqrt(s.thr * ca * idet) * (1.f + 1e-5f) + 1e-3f;       // half height of the ellipse
+        s.yr = -cb * fast_rcp(cc) * fast_sqrt(s.thr * cc * idet);          // y of its rightmost point (leftmost: -yr)
+        s.by0 = max(s.by0, (int)ceilf((gy - s.hy - (float)(BT - 1)) * (1.f / BT)));
+        s.by1 = min(s.by1, (int)floorf((gy + s.hy) * (1.f / BT)) + 1);
     }
     return s;
 }
@@ -313,9 +326,11 @@ __device__ __forceinline__ void block_row(const BlockSpan& s, int by, int* xa, i
     if (ya > yb) { *xa = 0; *xb = 0; return; }
     const float yR = fminf(yb, fmaxf(ya, s.yr)), yL = fminf(yb, fmaxf(ya, -s.yr));
     const float dR = fmaxf(0.f, s.ca * s.thr - s.det * yR * yR), dL = fmaxf(0.f, s.ca * s.thr - s.det * yL * yL);
-    const float xr = (-s.cb * yR + sqrtf(dR)) / s.ca + 1e-3f, xl = (-s.cb * yL - sqrtf(dL)) / s.ca - 1e-3f;
+    const float mr = 1.f + 1e-5f;                                         // the hardware rcp / sqrt are 1 ulp: widen by 1e-5 relative, far inside the margin below
+    const float xr = (-s.cb * yR + fast_sqrt(dR) * mr) * s.ica, xl = (-s.cb * yL - fast_sqrt(dL) * mr) * s.ica;
+    const float wr = fabsf(xr) * 1e-5f + 1e-3f, wl = fabsf(xl) * 1e-5f + 1e-3f;
     // block bx holds pixel centres [BT bx, BT bx + BT - 1]: it meets [xl, xr] iff BT bx <= xr + gx and BT bx + BT - 1 >= xl + gx
-    int a = (int)ceilf((xl + s.gx - (float)(BT - 1)) / BT), b = (int)floorf((xr + s.gx) / BT) + 1;
+    int a = (int)ceilf((xl - wl + s.gx - (float)(BT - 1)) * (1.f / BT)), b = (int)floorf((xr + wr + s.gx) * (1.f / BT)) + 1;
     *xa = max(a, s.bx0); *xb = min(b, s.bx1);
 }
 
@@ -360,11 +375,11 @@ __global__ __launch_bounds__(256) void k_preprocess(Params p, const float* __res
                                                     int* __restrict__ radii, float4* __restrict__ rec0,
                                                     float4* __restrict__ rec1, float4* __restrict__ rec2,
                                                     uint2* __restrict__ rect, uint32_t* __restrict__ npairs, uint32_t* __restrict__ idsum,
-                                                    uint32_t* __restrict__ super_count, int32_t* __restrict__ header, int use_lds_hist) {
-    __shared__ float cam[35];
+                                                    uint32_t* __restrict__ super_count, uint32_t* __restrict__ kref_part, int use_lds_hist) {
+    __shared__ float cam[35], krs[4];
     extern __shared__ uint32_t hist[];      // [S] workgroup-private supertile histogram (one global atomic per workgroup and supertile)
     const int S = p.stiles_x * p.stiles_y;
-    DWG_GEOM(rec0); DWG_GEOM(rec1); DWG_GEOM(rec2); DWG_GEOM(rect); DWG_GEOM(npairs); DWG_GEOM(idsum); DWG_GEOM(super_count); DWG_GEOM(header);
+    DWG_GEOM(rec0); DWG_GEOM(rec1); DWG_GEOM(rec2); DWG_GEOM(rect); DWG_GEOM(npairs); DWG_GEOM(idsum); DWG_GEOM(super_count); DWG_GEOM(kref_part);
     const size_t go = (size_t)blockIdx.y * (size_t)p.in_stride;            // this frame's first input row
     const size_t co = (size_t)blockIdx.y * (size_t)p.cam_stride;
     radii += (size_t)blockIdx.y * p.G;
@@ -387,7 +402,7 @@ __global__ __launch_bounds__(256) void k_preprocess(Params p, const float* __res
     float kref = 0.f;
     BlockSpan sp;
     sp.by0 = sp.by1 = sp.bx0 = sp.bx1 = 0; sp.all = false;
-    sp.gx = sp.gy = sp.ca = sp.cb = sp.cc = sp.thr = sp.det = sp.hy = sp.yr = 0.f;
+    sp.gx = sp.gy = sp.ca = sp.cb = sp.cc = sp.thr = sp.det = sp.hy = sp.yr = sp.ica = 0.f;
     float3 pv = xform43(view, pos);
     if (live_thread && pv.z > 0.2f) {
         float4 ph = xform44(proj, pos);
@@ -425,40 +440,49 @@ __global__ __launch_bounds__(256) void k_preprocess(Params p, const float* __res
         }
     }
     // exact (Gaussian, block) pair count of this splat (its rows of the pair-ordered backward partials) + the supertile histogram
+    if (p.dbg & 8) sp.by1 = sp.by0;
     const uint32_t ng = for_each_supertile(sp, [&](int sy, int sx) {
         const int s = sy * p.stiles_x + sx;
         if (use_lds_hist) atomicAdd(&hist[s], 1u); else atomicAdd(&super_count[s], 1u);
     });
+    // pair count of this run of IDBIN = 64 indices.  In index order the run IS this wave: one plain store of the wave's sum (64 lanes adding
+    // to ONE address with atomics were serialised by the L2's atomic unit -- 30 of this kernel's 37 us at 100 k Gaussians); under a visit
+    // order the lanes' indices are scattered and every lane adds its own (integer: order-independent).
+    if (!p.visit_order) {
+        const float wsum = dwg_wave_sum_to_lane63((float)ng);           // < 2^24 pairs per 64 splats: exact in fp32
+        if ((threadIdx.x & 63) == 63) idsum[(blockIdx.x * 256 + threadIdx.x) / IDBIN] = (uint32_t)wsum;
+    } else if (live_thread && ng) atomicAdd(&idsum[i / IDBIN], ng);
     if (live_thread) {
         npairs[i] = ng;
-        if (ng) atomicAdd(&idsum[i / IDBIN], ng);       // integer: order-independent
         radii[i] = radius;
         rect[i] = rc;
         rec0[i] = r0; rec1[i] = r1; rec2[i] = r2;
     }
+    // the workgroup's share of K_ref goes to ITS slot (k_scan_super sums the slots): one atomic per wave on the header word serialised
+    // 4.7 k same-address atomics at 300 k Gaussians -- half of this kernel's time
     kref = dwg_wave_sum_to_lane63(kref);
-    if ((threadIdx.x & 63) == 63 && kref > 0.f) atomicAdd(&header[H_KREF], (int32_t)kref);
-    if (use_lds_hist) {
-        __syncthreads();
+    if ((threadIdx.x & 63) == 63) krs[threadIdx.x >> 6] = kref;
+    __syncthreads();
+    if (threadIdx.x == 0) kref_part[blockIdx.x] = (uint32_t)(krs[0] + krs[1] + krs[2] + krs[3]);
+    if (use_lds_hist && !(p.dbg & 32))
         for (int t = threadIdx.x; t < S; t += 256) { uint32_t c = hist[t]; if (c) atomicAdd(&super_count[t], c); }
-    }
 }
 
 // sort size classes of a supertile list: one wave / 1024 threads with 34 KiB / 1024 threads with 136 KiB of LDS / in global memory
-__device__ __forceinline__ int sort_class_of(uint32_t n) { return n <= 1024u ? 0 : (n <= 4096u ? 1 : (n <= 16384u ? 2 : 3)); }
-
-// Workgroup 0: exclusive scan of the supertile counts + the four size-class lists.  Workgroups 1 .. ceil(G / GTILE): pair rows -- goff =
-// exclusive prefix of the per-Gaussian pair counts in INDEX order: row q = goff[g] + e (e: the pair's place in g's block enumeration) is
-// unique per pair, contiguous per Gaussian -- the backward's per-pair partials are written by row (k_render_bwd finds e from the splat's
-// geometry) and summed per Gaussian as one streamed range (k_gather_partials): no float atomics.  A workgroup scans its GTILE counts on top
-// of the sum of the earlier index runs (idsum, accumulated by k_preprocess with integer atomics): no second launch, no inter-workgroup wait.
-// The last of them leaves the frame's pair count K in the header (what the caller sizes the pair workspace by).
+// Workgroup 0: exclusive scans of the supertile counts (super_start) and of their CHUNK counts (chunk_start: a supertile's key list is
+// sorted in chunks of CHUNK keys, one workgroup each).  Workgroups 1 .. ceil(G / GTILE): pair rows -- goff = exclusive prefix of the
+// per-Gaussian pair counts in INDEX order: row q = goff[g] + e (e: the pair's place in g's block enumeration) is unique per pair, contiguous
+// per Gaussian -- the backward's per-pair partials are written by row (k_render_bwd finds e from the splat's geometry) and summed per
+// Gaussian as one streamed range (k_gather_partials): no float atomics.  A workgroup scans its GTILE counts on top of the sum of the earlier
+// index runs (idsum, accumulated by k_preprocess with integer atomics): no second launch, no inter-workgroup wait.  The last of them leaves
+// the frame's pair count K in the header (what the caller sizes the pair workspace by).
 __global__ __launch_bounds__(1024) void k_scan_super(Params p, const uint32_t* __restrict__ super_count, uint32_t* __restrict__ super_start,
-                                                     uint32_t* __restrict__ cls, int32_t* __restrict__ header,
+                                                     uint32_t* __restrict__ chunk_start, int32_t* __restrict__ header,
                                                      const uint32_t* __restrict__ npairs, const uint32_t* __restrict__ idsum,
-                                                     uint32_t* __restrict__ goff) {
+                                                     uint32_t* __restrict__ goff, const uint32_t* __restrict__ kref_part) {
     __shared__ uint32_t part[1024], parts[1024];
-    DWG_GEOM(super_count); DWG_GEOM(super_start); DWG_GEOM(cls); DWG_GEOM(header); DWG_GEOM(npairs); DWG_GEOM(idsum); DWG_GEOM(goff);
+    DWG_GEOM(super_count); DWG_GEOM(super_start); DWG_GEOM(chunk_start); DWG_GEOM(header); DWG_GEOM(npairs); DWG_GEOM(idsum); DWG_GEOM(goff);
+    DWG_GEOM(kref_part);
     const int G = p.G, tid = threadIdx.x;
     if (blockIdx.x > 0) {
         const int b = blockIdx.x - 1, g = b * GTILE + tid;
@@ -483,31 +507,41 @@ __global__ __launch_bounds__(1024) void k_scan_super(Params p, const uint32_t* _
         if (g == G - 1) { goff[G] = base + parts[tid]; header[H_K] = (int32_t)(base + parts[tid]); }
         return;
     }
-    __shared__ uint32_t cls_cnt[NCLASS];
     const int S = p.stiles_x * p.stiles_y;
-    if (tid < NCLASS) cls_cnt[tid] = 0u;
     const int chunk = (S + 1023) / 1024;
     const int lo = min(S, tid * chunk), hi = min(S, lo + chunk);
-    uint32_t s = 0;
-    for (int t = lo; t < hi; t++) s += super_count[t];
-    part[tid] = s;
+    uint32_t s = 0, sc = 0;
+    for (int t = lo; t < hi; t++) { const uint32_t n = super_count[t]; s += n; sc += (n + CHUNK - 1) / CHUNK; }
+    part[tid] = s; parts[tid] = sc;
     __syncthreads();
     for (int off = 1; off < 1024; off <<= 1) {
-        const uint32_t v = tid >= off ? part[tid - off] : 0u;
+        const uint32_t v = tid >= off ? part[tid - off] : 0u, vc = tid >= off ? parts[tid - off] : 0u;
         __syncthreads();
-        part[tid] += v;
+        part[tid] += v; parts[tid] += vc;
         __syncthreads();
     }
-    uint32_t run = part[tid] - s;
+    uint32_t run = part[tid] - s, runc = parts[tid] - sc;
     for (int t = lo; t < hi; t++) {
         const uint32_t n = super_count[t];
-        super_start[t] = run;
-        run += n;
-        if (n) { const int c = sort_class_of(n); cls[(size_t)c * S + atomicAdd(&cls_cnt[c], 1u)] = (uint32_t)t; }
+        super_start[t] = run; chunk_start[t] = runc;
+        run += n; runc += (n + CHUNK - 1) / CHUNK;
     }
-    if (tid == 1023) { super_start[S] = part[1023]; header[H_KS] = (int32_t)part[1023]; }
+    if (tid == 1023) {
+        super_start[S] = part[1023]; chunk_start[S] = parts[1023];
+        header[H_KS] = (int32_t)part[1023]; header[H_NCHUNK] = (int32_t)parts[1023];
+        header[H_TAG] = (int32_t)(atomicAdd(&g_frame_tag, 0x9e3779b1u) | 1u);      // this frame's tag (odd: never the zero of a fresh buffer)
+    }
+    // K_ref = the sum of k_preprocess's per-workgroup shares
     __syncthreads();
-    if (tid < NCLASS) header[H_CLASS0 + tid] = (int32_t)cls_cnt[tid];
+    uint32_t kr = 0;
+    for (int t = tid; t < (G + 255) / 256; t += 1024) kr += kref_part[t];
+    part[tid] = kr;
+    __syncthreads();
+    for (int off = 512; off >= 1; off >>= 1) {
+        if (tid < off) part[tid] += part[tid + off];
+        __syncthreads();
+    }
+    if (tid == 0) header[H_KREF] = (int32_t)part[0];
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -528,7 +562,7 @@ __global__ __launch_bounds__(256) void k_scatter_super(Params p, const float4* _
     uint64_t key = 0;
     BlockSpan sp;
     sp.by0 = sp.by1 = sp.bx0 = sp.bx1 = 0; sp.all = false;
-    sp.gx = sp.gy = sp.ca = sp.cb = sp.cc = sp.thr = sp.det = sp.hy = sp.yr = 0.f;
+    sp.gx = sp.gy = sp.ca = sp.cb = sp.cc = sp.thr = sp.det = sp.hy = sp.yr = sp.ica = 0.f;
     if (i < G) {
         if (p.visit_order) i = p.visit_order[i];
         const uint2 rc = rect[i];
@@ -560,30 +594,7 @@ __global__ __launch_bounds__(256) void k_scatter_super(Params p, const float4* _
     });
 }
 
-// Ascending-only bitonic network (mirror step + half-cleaners) so that virtual +inf padding above n is legal: the in-memory network of
-// the lists too long for LDS.
-template <typename Mem>
-__device__ __forceinline__ void bitonic_network(Mem& m, int n, int npad) {
-    const int tid = threadIdx.x, nthr = blockDim.x;
-    for (int size = 2; size <= npad; size <<= 1) {
-        int half = size >> 1;
-        for (int t = tid; t < (npad >> 1); t += nthr) {
-            int blk = t / half, r = t - blk * half;
-            int i = blk * size + r, j = blk * size + (size - 1 - r);
-            if (j < n) { uint64_t a = m.get(i), b = m.get(j); if (b < a) { m.set(i, b); m.set(j, a); } }
-        }
-        __syncthreads();
-        for (int stride = half >> 1; stride >= 1; stride >>= 1) {
-            for (int t = tid; t < (npad >> 1); t += nthr) {
-                int blk = t / stride, r = t - blk * stride;
-                int i = blk * 2 * stride + r, j = i + stride;
-                if (j < n) { uint64_t a = m.get(i), b = m.get(j); if (b < a) { m.set(i, b); m.set(j, a); } }
-            }
-            __syncthreads();
-        }
-    }
-}
-struct GlbMem { volatile uint64_t* p; __device__ uint64_t get(int i) const { return p[i]; } __device__ void set(int i, uint64_t v) { p[i] = v; } };
+struct GlbMem { const uint64_t* p; __device__ uint64_t get(int i) const { return p[i]; } };
 
 // Register-blocked bitonic sort.  A thread owns EPT CONSECUTIVE keys in registers (key i lives in thread i / EPT, register i % EPT), so
 // every compare-exchange with stride < EPT is register-only, strides up to 32 * EPT go lane to lane inside the wave, and only the last
@@ -661,59 +672,57 @@ __device__ __forceinline__ void sort_in_lds(const uint64_t* __restrict__ keys_in
     __syncthreads();
 }
 
-// The depth-sorted list of a supertile, split STABLY into the lists of its ST x ST blocks (what replaced the per-block sorts: a block's list
-// is a subsequence of its supertile's, so ONE sort per 32x32 pixels orders sixteen lists).
-//   E1  every candidate's 16-bit block mask -- bit 4 r + c set iff block (ST sx + c, ST sy + r) lies in the splat's scanline enumeration
-//       (block_span / block_row, the functions k_preprocess counted the pairs with) -- parked in the sorted key's upper word (the depth has
-//       done its work);
+// Lanes 0 .. 15 of the workgroup each publish one block of the supertile: its list (start, length), its first checkpoint segment, and its
+// place in the render order -- bucket k = log2 of the list length, one array per bucket, a counter per bucket in the header; k_render_fwd
+// walks the buckets longest first.  (This replaced a one-workgroup scan kernel over all blocks between the split and the render.)
+__device__ __forceinline__ void register_blocks(const Params& p, int sx, int sy, const uint32_t* __restrict__ bs, const uint32_t* __restrict__ bc,
+                                                uint32_t* __restrict__ tile_count, uint32_t* __restrict__ tile_start,
+                                                uint32_t* __restrict__ seg_start, uint32_t* __restrict__ order, int32_t* __restrict__ header) {
+    if (threadIdx.x >= 64) return;                         // the first wave; its lanes 0 .. 15 own a block each
+    const int b = threadIdx.x;
+    const int by = sy * ST + b / ST, bx = sx * ST + b % ST;
+    const bool mine = b < ST * ST && bx < p.tiles_x && by < p.tiles_y;
+    const int t = by * p.tiles_x + bx;
+    int k = -1;
+    if (mine) {
+        uint32_t seg = bc[ST * ST];
+        for (int q = 0; q < b; q++) seg += (bc[q] + SEG - 1) / SEG;
+        const uint32_t n = bc[b];
+        tile_start[t] = bs[b]; tile_count[t] = n; seg_start[t] = seg;
+        k = n ? min(NBUCKET - 1, 32 - __clz((int)n)) : 0;
+    }
+    // one atomic per bucket PRESENT among the supertile's blocks (a returning atomic per block put ~8 k of them on one header word at
+    // 1024^2: 130 of this kernel's 173 us)
+    const unsigned long long below = (1ull << b) - 1ull;
+    unsigned long long todo = __ballot(k >= 0);
+    while (todo) {
+        const int src = __ffsll((long long)todo) - 1;
+        const int kk = __shfl(k, src);
+        const unsigned long long same = __ballot(k == kk);
+        uint32_t base = 0;
+        if (b == src) base = atomicAdd(reinterpret_cast<uint32_t*>(&header[H_BKT0 + kk]), (uint32_t)__popcll(same));
+        base = (uint32_t)__shfl((int)base, src);
+        if (k == kk) order[(size_t)kk * (p.tiles_x * p.tiles_y) + base + (uint32_t)__popcll(same & below)] = (uint32_t)t;
+        todo &= ~same;
+    }
+    (void)t;
+}
+
+// The depth-sorted candidates of a supertile -- (block mask << 32 | id), written by k_rank_merge -- split STABLY into the lists of its
+// ST x ST blocks (a block's list is a subsequence of its supertile's: ONE sort per 32x32 pixels orders sixteen lists).
 //   E2  per wave (a contiguous run of 64-candidate chunks) and per bit: how many candidates carry the bit; a scan over the waves;
 //   E3  the supertile takes a contiguous piece of the frame's pair pool with ONE atomic (where a list lands depends on arrival order, what
 //       it holds does not) and cuts it into sixteen lists: tile_start / tile_count of its blocks;
 //   E4  every wave walks its chunks again: a candidate with bit b goes to slot run_b + (candidates of the chunk below it with bit b).
 template <int THREADS, typename Mem>
-__device__ __forceinline__ void split_to_blocks(const Params& p, Mem m, int n, int s, const float4* __restrict__ rec0,
-                                                const float4* __restrict__ rec1, const uint2* __restrict__ rect,
-                                                uint32_t* __restrict__ tile_count, uint32_t* __restrict__ tile_start,
+__device__ __forceinline__ void split_to_blocks(const Params& p, Mem m, int n, int s, uint32_t* __restrict__ tile_count,
+                                                uint32_t* __restrict__ tile_start, uint32_t* __restrict__ seg_start, uint32_t* __restrict__ order,
                                                 uint32_t* __restrict__ sorted, int64_t cap, int32_t* __restrict__ header,
-                                                uint32_t* __restrict__ wt /* [THREADS / 64][16] */, uint32_t* __restrict__ bs /* [16] */) {
+                                                uint32_t* __restrict__ wt /* [THREADS / 64][16] */, uint32_t* __restrict__ bs /* [16] list starts */,
+                                                uint32_t* __restrict__ bc /* [17] list lengths + the first segment */) {
     constexpr int NW = THREADS / 64;
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
     const int sx = s % p.stiles_x, sy = s / p.stiles_x;
-    // four candidates per trip: their twelve record gathers are in flight together (one candidate per trip made this phase a chain of
-    // dependent L2 round trips: 40 of the 73 us of the single-wave class at 100 k Gaussians)
-    for (int e0 = tid; e0 < n; e0 += 4 * THREADS) {
-        uint32_t id[4]; uint2 rc[4]; float4 ra[4], rb[4];
-#pragma unroll
-        for (int u = 0; u < 4; u++) {
-            const int e = e0 + u * THREADS;
-            id[u] = e < n ? (uint32_t)m.get(e) : 0u;
-            rc[u] = rect[id[u]]; ra[u] = rec0[id[u]]; rb[u] = rec1[id[u]];
-        }
-#pragma unroll
-        for (int u = 0; u < 4; u++) {
-            const int e = e0 + u * THREADS;
-            if (e >= n) break;
-            uint32_t mask = 0;
-            if (!(p.dbg & 2)) {
-                const float4 a = ra[u], b = rb[u];
-                const BlockSpan sp = block_span(a.x, a.y, b.x, b.y, b.z, a.w, (int)(rc[u].x & 0xffff), (int)(rc[u].x >> 16), (int)(rc[u].y & 0xffff),
-                                                (int)(rc[u].y >> 16), p.tiles_x, p.tiles_y);
-#pragma unroll
-                for (int r = 0; r < ST; r++) {
-                    const int by = sy * ST + r;
-                    if (by >= sp.by0 && by < sp.by1) {
-                        int xa, xb;
-                        block_row(sp, by, &xa, &xb);
-                        const int lo = max(xa, sx * ST), hi = min(xb, sx * ST + ST);
-                        if (hi > lo) mask |= ((1u << (hi - lo)) - 1u) << (r * ST + lo - sx * ST);
-                    }
-                }
-            } else mask = 1u;
-            m.set(e, ((uint64_t)mask << 32) | id[u]);
-        }
-    }
-    __syncthreads();
-    if (p.dbg & 4) return;
     const int C = (n + 63) >> 6, per = (C + NW - 1) / NW, c0 = min(C, w * per), c1 = min(C, c0 + per);
     uint32_t mine = 0;
     for (int c = c0; c < c1; c++) {
@@ -738,20 +747,20 @@ __device__ __forceinline__ void split_to_blocks(const Params& p, Mem m, int n, i
         for (int b = 0; b < ST * ST; b++) tot += bs[b];
         const uint32_t base = tot ? atomicAdd(reinterpret_cast<uint32_t*>(&header[H_POOL]), tot) : 0u;
         if ((int64_t)base + (int64_t)tot > cap) header[H_OVERFLOW] = 1;          // truncated: the caller renders the frame again
-        uint32_t run = base;
+        uint32_t run = base, nseg = 0;
         for (int b = 0; b < ST * ST; b++) {
             const uint32_t c = bs[b];
-            bs[b] = run;
-            const int by = sy * ST + b / ST, bx = sx * ST + b % ST;
-            if (bx < p.tiles_x && by < p.tiles_y) {
-                const int64_t room = cap - (int64_t)run;
-                tile_start[by * p.tiles_x + bx] = run;
-                tile_count[by * p.tiles_x + bx] = room <= 0 ? 0u : (uint32_t)min((int64_t)c, room);
-            }
+            const int64_t room = cap - (int64_t)run;
+            const uint32_t cc = room <= 0 ? 0u : (uint32_t)min((int64_t)c, room);      // what of the list fits the pair workspace
+            bs[b] = run; bc[b] = cc;
+            nseg += (cc + SEG - 1) / SEG;
             run += c;
         }
+        // the supertile's checkpoint segments: one piece of the frame's segment numbering (k_render_bwd runs one wave per segment)
+        bc[ST * ST] = nseg ? atomicAdd(reinterpret_cast<uint32_t*>(&header[H_NSEG]), nseg) : 0u;
     }
     __syncthreads();
+    register_blocks(p, sx, sy, bs, bc, tile_count, tile_start, seg_start, order, header);
     uint32_t runb = lane < ST * ST ? bs[lane] + wt[w * (ST * ST) + lane] : 0u;
     const unsigned long long below = (1ull << lane) - 1ull;
     for (int c = c0; c < c1; c++) {
@@ -772,93 +781,171 @@ __device__ __forceinline__ void split_to_blocks(const Params& p, Mem m, int n, i
     }
 }
 
-// One workgroup per supertile of size class CLS (lists compacted by k_scan_super); workgroups beyond the class count exit.
-//   CLS 0: <= 1024 keys (THREADS = 256: 256 .. 1024-key networks by list length) | 1: <= 4096 (1024 threads) | 2: <= 16384 (1024 threads,
-//   136 KiB of LDS) | 3: longer -- the in-memory network.
-template <int CLS, int THREADS>
-__global__ __launch_bounds__(THREADS) void k_sort_super(Params p, const uint32_t* __restrict__ cls, int32_t* __restrict__ header,
-                                                        const uint32_t* __restrict__ super_start, uint64_t* __restrict__ keys,
-                                                        const float4* __restrict__ rec0, const float4* __restrict__ rec1,
-                                                        const uint2* __restrict__ rect, uint32_t* __restrict__ tile_count,
-                                                        uint32_t* __restrict__ tile_start, uint32_t* __restrict__ sorted, int64_t cap) {
+// Which supertile chunk c of the frame belongs to, its place in the supertile's key list and its length (wave-uniform: every lane searches
+// chunk_start alike).  false: no such chunk.
+struct ChunkRef { int s; int j; int64_t sa; int nsup; int a; int n; };      // supertile, chunk index, list start, list length, chunk offset / length
+__device__ __forceinline__ bool find_chunk(const Params& p, int c, const uint32_t* __restrict__ chunk_start, const uint32_t* __restrict__ super_start,
+                                           const int32_t* __restrict__ header, int64_t cap, ChunkRef* r) {
+    if (c >= header[H_NCHUNK]) return false;
+    int lo = 0, hi = p.stiles_x * p.stiles_y;              // largest s with chunk_start[s] <= c (chunk_start[S] = total > c)
+    while (hi - lo > 1) { const int mid = (lo + hi) >> 1; if ((int)chunk_start[mid] <= c) lo = mid; else hi = mid; }
+    int64_t sa = super_start[lo], se = super_start[lo + 1];
+    if (sa > cap) sa = cap; if (se > cap) se = cap;
+    r->s = lo; r->j = c - (int)chunk_start[lo]; r->sa = sa; r->nsup = (int)(se - sa);
+    r->a = r->j * CHUNK; r->n = min(CHUNK, r->nsup - r->a);
+    return r->n > 0;
+}
+
+// One workgroup per CHUNK keys of a supertile's list: sorted in place.  Every chunk of every supertile of the frame at once -- the dense
+// supertiles (thousands of keys, a few dozen of them under a body) no longer pin ONE workgroup each to a long barrier-bound network while
+// the rest of the chip idles (SQ counters of that version: waves parked 0.48 of the time).
+__global__ __launch_bounds__(256) void k_chunk_sort(Params p, const uint32_t* __restrict__ chunk_start, const uint32_t* __restrict__ super_start,
+                                                    const int32_t* __restrict__ header, uint64_t* __restrict__ keys, int64_t cap) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
-    __shared__ uint32_t wt[(THREADS / 64) * ST * ST], bs[ST * ST];
-    DWG_GEOM(cls); DWG_GEOM(header); DWG_GEOM(super_start); DWG_GEOM(rec0); DWG_GEOM(rec1); DWG_GEOM(rect); DWG_GEOM(tile_count);
-    DWG_GEOM(tile_start); DWG_PAIRS(keys); DWG_PAIRS(sorted);
-    if ((int)blockIdx.x >= header[H_CLASS0 + CLS]) return;
-    const int S = p.stiles_x * p.stiles_y;
-    const int s = (int)cls[(size_t)CLS * S + blockIdx.x];
+    DWG_GEOM(chunk_start); DWG_GEOM(super_start); DWG_GEOM(header); DWG_PAIRS(keys);
+    ChunkRef r;
+    if (!find_chunk(p, (int)blockIdx.x, chunk_start, super_start, header, cap, &r)) return;
+    uint64_t* lds = reinterpret_cast<uint64_t*>(smem_raw);
+    uint64_t* kc = keys + r.sa + r.a;
+    if (r.n <= 256) sort_in_lds<256, 1>(kc, r.n, lds, p.dbg & 1);
+    else if (r.n <= 512) sort_in_lds<256, 2>(kc, r.n, lds, p.dbg & 1);
+    else sort_in_lds<256, 4>(kc, r.n, lds, p.dbg & 1);
+    for (int e = threadIdx.x; e < r.n; e += 256) kc[e] = lds[sort_slot(e)];
+}
+
+// first index of sorted run[0, len) whose key is not below `key` = the number of its keys below `key` (keys are unique: (depth, id))
+__device__ __forceinline__ int lower_bound_u64(const uint64_t* __restrict__ run, int len, uint64_t key) {
+    int lo = 0;
+    while (len > 0) {
+        const int half = len >> 1;
+        const bool lt = run[lo + half] < key;
+        lo = lt ? lo + half + 1 : lo;
+        len = lt ? len - half - 1 : half;
+    }
+    return lo;
+}
+
+// One workgroup per chunk again, one thread per key: the key's place in its supertile's sorted list is its place in its own chunk plus the
+// number of keys below it in every sibling chunk (a binary search each: the siblings are sorted) -- a multiway merge without a merge tree,
+// every key independent.  The thread also works out the candidate's 16-bit BLOCK MASK -- bit 4 r + c set iff block (ST sx + c, ST sy + r)
+// lies in the splat's scanline enumeration (block_span / block_row, the functions k_preprocess counted the pairs with) -- and leaves
+// (mask << 32 | id) at the key's sorted place: what k_split cuts into block lists.
+__global__ __launch_bounds__(256) void k_rank_merge(Params p, const uint32_t* __restrict__ chunk_start, const uint32_t* __restrict__ super_start,
+                                                    const int32_t* __restrict__ header, const uint64_t* __restrict__ keys,
+                                                    const float4* __restrict__ rec0, const float4* __restrict__ rec1,
+                                                    const uint2* __restrict__ rect, uint64_t* __restrict__ cand, int64_t cap) {
+    DWG_GEOM(chunk_start); DWG_GEOM(super_start); DWG_GEOM(header); DWG_GEOM(rec0); DWG_GEOM(rec1); DWG_GEOM(rect); DWG_PAIRS(keys); DWG_PAIRS(cand);
+    ChunkRef r;
+    if (!find_chunk(p, (int)blockIdx.x, chunk_start, super_start, header, cap, &r)) return;
+    const uint64_t* ks = keys + r.sa;
+    const int nch = (r.nsup + CHUNK - 1) / CHUNK;
+    const int sx = r.s % p.stiles_x, sy = r.s / p.stiles_x;
+    constexpr int KPT = CHUNK / 256;
+    uint64_t key[KPT]; uint2 rc[KPT]; float4 ra[KPT], rb[KPT]; int pos[KPT];
+#pragma unroll
+    for (int u = 0; u < KPT; u++) {                            // the record gathers of the mask are in flight under the searches
+        const int e = threadIdx.x + u * 256;
+        key[u] = e < r.n ? ks[r.a + e] : 0ull;
+        const uint32_t id = (uint32_t)key[u];
+        rc[u] = rect[id]; ra[u] = rec0[id]; rb[u] = rec1[id];
+        pos[u] = e;                                            // place in the own chunk ...
+    }
+    // ... plus the keys below it in every sibling chunk, four siblings per round.  A search is two-level: six steps over the sibling's 64
+    // PIVOTS (every 16th key, staged in LDS by the workgroup once per round), then at most five steps inside the one 16-key window they
+    // leave -- 128 bytes, one or two lines -- instead of eleven dependent probes spread over the sibling's 8 KiB (the flat searches were
+    // bound by the request rate of those probes: 156 us at 300 k Gaussians / 1024^2, unchanged by keeping sixteen of them in flight).
+    __shared__ uint64_t piv[4][64];
+    for (int j0 = 0; j0 < nch; j0 += 4) {
+        __syncthreads();                                       // the previous round's pivots have been read
+        {
+            const int q = threadIdx.x >> 6, i = threadIdx.x & 63, jj = j0 + q;
+            const int l = (jj < nch && jj != r.j) ? min(CHUNK, r.nsup - jj * CHUNK) : 0;
+            piv[q][i] = 16 * i + 15 < l ? ks[(size_t)jj * CHUNK + 16 * i + 15] : ~0ull;      // +inf behind the last whole window
+        }
+        __syncthreads();
+#pragma unroll
+        for (int q = 0; q < 4; q++) {
+            const int jj = j0 + q;
+            const int l = (jj < nch && jj != r.j) ? min(CHUNK, r.nsup - jj * CHUNK) : 0;
+            if (l == 0) continue;                              // wave-uniform
+            const uint64_t* run = ks + (size_t)jj * CHUNK;
+            int w0[KPT], lo[KPT], len[KPT];
+#pragma unroll
+            for (int u = 0; u < KPT; u++) {                    // pivots below the key: all of their windows lie below it too
+                int c = 0;
+#pragma unroll
+                for (int step = 32; step >= 1; step >>= 1) c += (piv[q][c + step - 1] < key[u]) ? step : 0;
+                c += (c == 63 && piv[q][63] < key[u]) ? 1 : 0;
+                w0[u] = 16 * c; lo[u] = 0; len[u] = max(0, min(16, l - 16 * c));
+            }
+#pragma unroll
+            for (int step = 0; step < 5; step++) {
+#pragma unroll
+                for (int u = 0; u < KPT; u++) {
+                    const int half = len[u] >> 1;
+                    const bool live = len[u] > 0;
+                    const uint64_t v = live ? run[w0[u] + lo[u] + half] : 0ull;
+                    const bool lt = live && v < key[u];
+                    lo[u] = lt ? lo[u] + half + 1 : lo[u];
+                    len[u] = lt ? len[u] - half - 1 : half;
+                }
+            }
+#pragma unroll
+            for (int u = 0; u < KPT; u++) pos[u] += w0[u] + lo[u];
+        }
+    }
+#pragma unroll
+    for (int u = 0; u < KPT; u++) {
+        const int e = threadIdx.x + u * 256;
+        if (e >= r.n) break;
+        uint32_t mask = 0;
+        if (!(p.dbg & 2)) {
+            const float4 a = ra[u], b = rb[u];
+            const BlockSpan sp = block_span(a.x, a.y, b.x, b.y, b.z, a.w, (int)(rc[u].x & 0xffff), (int)(rc[u].x >> 16), (int)(rc[u].y & 0xffff),
+                                            (int)(rc[u].y >> 16), p.tiles_x, p.tiles_y);
+#pragma unroll
+            for (int rr = 0; rr < ST; rr++) {
+                const int by = sy * ST + rr;
+                if (by >= sp.by0 && by < sp.by1) {
+                    int xa, xb;
+                    block_row(sp, by, &xa, &xb);
+                    const int lo = max(xa, sx * ST), hi = min(xb, sx * ST + ST);
+                    if (hi > lo) mask |= ((1u << (hi - lo)) - 1u) << (rr * ST + lo - sx * ST);
+                }
+            }
+        } else mask = 1u;
+        cand[r.sa + pos[u]] = ((uint64_t)mask << 32) | (uint32_t)key[u];
+    }
+}
+
+// One workgroup per supertile: its sorted candidates -> its sixteen block lists (split_to_blocks); a supertile nothing reaches only
+// publishes its (empty) blocks.
+template <int THREADS>
+__global__ __launch_bounds__(THREADS) void k_split(Params p, int32_t* __restrict__ header, const uint32_t* __restrict__ super_start,
+                                                   const uint64_t* __restrict__ cand, uint32_t* __restrict__ tile_count,
+                                                   uint32_t* __restrict__ tile_start, uint32_t* __restrict__ seg_start,
+                                                   uint32_t* __restrict__ order, uint32_t* __restrict__ sorted, int64_t cap) {
+    __shared__ uint32_t wt[(THREADS / 64) * ST * ST], bs[ST * ST], bc[ST * ST + 1];
+    DWG_GEOM(header); DWG_GEOM(super_start); DWG_GEOM(tile_count); DWG_GEOM(tile_start); DWG_GEOM(seg_start); DWG_GEOM(order);
+    DWG_PAIRS(cand); DWG_PAIRS(sorted);
+    const int s = (int)blockIdx.x;
     int64_t a = super_start[s], e = super_start[s + 1];
     if (a > cap) a = cap; if (e > cap) e = cap;
     const int n = (int)(e - a);
-    if (n <= 0) return;
-    if (CLS == 3) {
-        int npad = 2; while (npad < n) npad <<= 1;
-        GlbMem m{keys + a};
-        bitonic_network(m, n, npad);
-        split_to_blocks<THREADS>(p, m, n, s, rec0, rec1, rect, tile_count, tile_start, sorted, cap, header, wt, bs);
+    if (n <= 0) {
+        if (threadIdx.x <= ST * ST) { if (threadIdx.x < ST * ST) bs[threadIdx.x] = 0u; bc[threadIdx.x] = 0u; }
+        __syncthreads();
+        register_blocks(p, s % p.stiles_x, s / p.stiles_x, bs, bc, tile_count, tile_start, seg_start, order, header);
         return;
     }
-    uint64_t* lds = reinterpret_cast<uint64_t*>(smem_raw);
-    const uint64_t* kin = keys + a;
-    // the network of N = THREADS x EPT >= n keys (EPT consecutive keys per thread)
-    if (n <= THREADS) sort_in_lds<THREADS, 1>(kin, n, lds, p.dbg & 1);
-    else if (n <= 2 * THREADS) sort_in_lds<THREADS, 2>(kin, n, lds, p.dbg & 1);
-    else if (n <= 4 * THREADS) sort_in_lds<THREADS, 4>(kin, n, lds, p.dbg & 1);
-    else if (n <= 8 * THREADS) sort_in_lds<THREADS, 8>(kin, n, lds, p.dbg & 1);
-    else sort_in_lds<THREADS, 16>(kin, n, lds, p.dbg & 1);
-    LdsSlotMem m{lds};
-    split_to_blocks<THREADS>(p, m, n, s, rec0, rec1, rect, tile_count, tile_start, sorted, cap, header, wt, bs);
-}
-
-// one workgroup of 1024 threads per frame: exclusive scan of the blocks' segment counts, the render order (longest list first), the frame's tag
-__global__ __launch_bounds__(1024) void k_scan_tiles(Params p, const uint32_t* __restrict__ tile_count, uint32_t* __restrict__ seg_start,
-                                                     uint32_t* __restrict__ order, int32_t* __restrict__ header) {
-    __shared__ uint32_t parts[1024];
-    __shared__ uint32_t bkt_cnt[NBUCKET], bkt_base[NBUCKET];
-    DWG_GEOM(tile_count); DWG_GEOM(seg_start); DWG_GEOM(order); DWG_GEOM(header);
-    const int T = p.tiles_x * p.tiles_y, tid = threadIdx.x;
-    if (tid < NBUCKET) bkt_cnt[tid] = 0u;
-    const int chunk = (T + 1023) / 1024;
-    const int lo = min(T, tid * chunk), hi = min(T, lo + chunk);
-    uint32_t ss = 0;
-    for (int t = lo; t < hi; t++) ss += (tile_count[t] + SEG - 1) / SEG;
-    parts[tid] = ss;
-    __syncthreads();
-    for (int off = 1; off < 1024; off <<= 1) {
-        const uint32_t vs = tid >= off ? parts[tid - off] : 0u;
-        __syncthreads();
-        parts[tid] += vs;
-        __syncthreads();
-    }
-    uint32_t runs = parts[tid] - ss;
-    for (int t = lo; t < hi; t++) {
-        const uint32_t n = tile_count[t];
-        seg_start[t] = runs;
-        runs += (n + SEG - 1) / SEG;
-        atomicAdd(&bkt_cnt[n ? min(NBUCKET - 1, 32 - __clz((int)n)) : 0], 1u);
-    }
-    if (tid == 1023) {
-        seg_start[T] = parts[1023];
-        header[H_NSEG] = (int32_t)parts[1023];
-        header[H_TAG] = (int32_t)(atomicAdd(&g_frame_tag, 0x9e3779b1u) | 1u);      // this frame's tag (odd: never the zero of a fresh buffer)
-    }
-    __syncthreads();
-    if (tid == 0) {
-        uint32_t b = 0;
-        for (int k = NBUCKET - 1; k >= 0; k--) { bkt_base[k] = b; b += bkt_cnt[k]; bkt_cnt[k] = 0u; }     // longest lists first
-    }
-    __syncthreads();
-    for (int t = lo; t < hi; t++) {
-        const uint32_t n = tile_count[t];
-        const int k = n ? min(NBUCKET - 1, 32 - __clz((int)n)) : 0;
-        order[bkt_base[k] + atomicAdd(&bkt_cnt[k], 1u)] = (uint32_t)t;
-    }
+    GlbMem m{cand + a};
+    split_to_blocks<THREADS>(p, m, n, s, tile_count, tile_start, seg_start, order, sorted, cap, header, wt, bs, bc);
 }
 
 // One wave64 per 8x8 pixel block, longest list first.  Splat records of the current batch of 64 live in LDS (broadcast reads);
 // the next batch's records are gathered into registers while the current one is composited.
-__global__ __launch_bounds__(64) void k_render_fwd(Params p, const uint32_t* __restrict__ order, const uint32_t* __restrict__ tile_start,
+__global__ __launch_bounds__(64) void k_render_fwd(Params p, const int32_t* __restrict__ header, const uint32_t* __restrict__ order,
+                                                   const uint32_t* __restrict__ tile_start,
                                                    const uint32_t* __restrict__ tile_count,
                                                    const uint32_t* __restrict__ seg_start, const uint32_t* __restrict__ sorted,
                                                    const float4* __restrict__ rec0, const float4* __restrict__ rec1,
@@ -869,13 +956,20 @@ __global__ __launch_bounds__(64) void k_render_fwd(Params p, const uint32_t* __r
                                                    float* __restrict__ out_color, float* __restrict__ out_depth,
                                                    float* __restrict__ out_alpha) {
     __shared__ float4 s0[64], s1[64], s2[64];
-    DWG_GEOM(order); DWG_GEOM(tile_start); DWG_GEOM(tile_count); DWG_GEOM(seg_start); DWG_GEOM(rec0); DWG_GEOM(rec1); DWG_GEOM(rec2); DWG_GEOM(tile_neff);
+    DWG_GEOM(header); DWG_GEOM(order); DWG_GEOM(tile_start); DWG_GEOM(tile_count); DWG_GEOM(seg_start); DWG_GEOM(rec0); DWG_GEOM(rec1); DWG_GEOM(rec2);
+    DWG_GEOM(tile_neff);
     DWG_PAIRS(sorted); DWG_PAIRS(seg_tile); DWG_PAIRS(ckpt); DWG_IMAGE(final_T); DWG_IMAGE(n_contrib); DWG_IMAGE(craw);
     {
         const size_t fo = (size_t)blockIdx.y * (size_t)p.H * p.W;
         out_color += 3 * fo; out_depth += fo; out_alpha += fo;
     }
-    const int tile = (int)order[blockIdx.x];
+    // longest lists first: bucket NBUCKET - 1 down to 0, each with its own array (filled by k_split in arrival order)
+    int tile;
+    {
+        int r = (int)blockIdx.x, k = NBUCKET - 1;
+        for (; k > 0; k--) { const int c = header[H_BKT0 + k]; if (r < c) break; r -= c; }
+        tile = (int)order[(size_t)k * (p.tiles_x * p.tiles_y) + r];
+    }
     const int tx = tile % p.tiles_x, ty = tile / p.tiles_x;
     const int lane = threadIdx.x;
     const int px = tx * BT + (lane & 7), py = ty * BT + (lane >> 3);
@@ -1453,8 +1547,7 @@ int dwg_raster_forward_bin_frames(const dwg_raster_settings* cfg, const dwg_rast
     const int S = p.stiles_x * p.stiles_y;
     for (int f = 0; f < F; f++) {
         char* wf = ws + (size_t)f * L.total;
-        if (hipMemsetAsync(wf + L.header, 0, 256, stream) != hipSuccess) return DWG_E_LAUNCH;
-        if (hipMemsetAsync(wf + L.tile_count, 0, L.zero_end - L.tile_count, stream) != hipSuccess) return DWG_E_LAUNCH;
+        if (hipMemsetAsync(wf + L.header, 0, L.zero_end - L.header, stream) != hipSuccess) return DWG_E_LAUNCH;
     }
     static bool attr_set = false;
     if (!attr_set) {      // 64 KiB of histogram + the static camera words is over the 64 KiB default limit
@@ -1467,12 +1560,12 @@ int dwg_raster_forward_bin_frames(const dwg_raster_settings* cfg, const dwg_rast
         DWG_LAUNCH("raster_preprocess", k_preprocess, dim3(dwg_cdiv(G, 256), F), dim3(256), use_lds_hist ? (size_t)S * 4 : 0, stream, p,
                    means3D, shs, colors_precomp, opacities, scales, rotations, cov3D_precomp, radii, (float4*)(ws + L.rec0),
                    (float4*)(ws + L.rec1), (float4*)(ws + L.rec2), (uint2*)(ws + L.rect), (uint32_t*)(ws + L.npairs),
-                   (uint32_t*)(ws + L.idsum), (uint32_t*)(ws + L.super_count), (int32_t*)(ws + L.header), use_lds_hist);
+                   (uint32_t*)(ws + L.idsum), (uint32_t*)(ws + L.super_count), (uint32_t*)(ws + L.kref_part), use_lds_hist);
     }
     // workgroup 0: supertile lists (starts, size classes); workgroups 1..: the pair rows of GTILE Gaussians each + the frame's pair count
     DWG_LAUNCH("raster_scan_super", k_scan_super, dim3(1 + dwg_cdiv(G, GTILE), F), dim3(1024), 0, stream, p,
-               (const uint32_t*)(ws + L.super_count), (uint32_t*)(ws + L.super_start), (uint32_t*)(ws + L.cls), (int32_t*)(ws + L.header),
-               (const uint32_t*)(ws + L.npairs), (const uint32_t*)(ws + L.idsum), (uint32_t*)(ws + L.goff));
+               (const uint32_t*)(ws + L.super_count), (uint32_t*)(ws + L.super_start), (uint32_t*)(ws + L.chunk_start), (int32_t*)(ws + L.header),
+               (const uint32_t*)(ws + L.npairs), (const uint32_t*)(ws + L.idsum), (uint32_t*)(ws + L.goff), (const uint32_t*)(ws + L.kref_part));
     DWG_RETURN_IF_LAUNCH_FAILED();
     return DWG_OK;
 }
@@ -1507,39 +1600,29 @@ int dwg_raster_forward_render_frames(const dwg_raster_settings* cfg, const dwg_r
     uint32_t* tile_start = (uint32_t*)(ws + L.tile_start);
     uint32_t* tile_count = (uint32_t*)(ws + L.tile_count);
     const uint32_t* super_start = (const uint32_t*)(ws + L.super_start);
-    const uint32_t* cls = (const uint32_t*)(ws + L.cls);
+    const uint32_t* chunk_start = (const uint32_t*)(ws + L.chunk_start);
+    uint64_t* cand = (uint64_t*)(wp + PL.cand);
     int32_t* header = (int32_t*)(ws + L.header);
     if (G > 0) {
         const int use_lds = lds_hist_ok(S);
         DWG_LAUNCH("raster_scatter", k_scatter_super, dim3(dwg_cdiv(G, 256), F), dim3(256), use_lds ? (size_t)S * 4 : 0, stream, p,
                    (const float4*)(ws + L.rec0), (const float4*)(ws + L.rec1), (const uint2*)(ws + L.rect), super_start,
                    (uint32_t*)(ws + L.super_cursor), keys, pair_capacity, header, use_lds);
-        // size classes (lists compacted by k_scan_super; surplus workgroups exit on their first instruction).  A supertile of class c holds
-        // more than {0, 1024, 4096, 16384} keys and the keys of a frame number at most its (Gaussian, block) pairs <= capacity, so at most
-        // capacity / that many such supertiles exist.  The long classes go first: they are the critical path.
-        static bool attr_set = false;
-        if (!attr_set) {
-            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_sort_super<2, 1024>), hipFuncAttributeMaxDynamicSharedMemorySize,
-                                (16384 + 1024) * 8);
-            attr_set = true;
-        }
-        const int nD = (int)min((int64_t)S, pair_capacity / 16384 + 1), nC = (int)min((int64_t)S, pair_capacity / 4096 + 1),
-                  nB = (int)min((int64_t)S, pair_capacity / 1024 + 1);
-#define DWG_SORT_ARGS p, cls, header, super_start, keys, (const float4*)(ws + L.rec0), (const float4*)(ws + L.rec1), (const uint2*)(ws + L.rect), \
-                      tile_count, tile_start, sorted, pair_capacity
-        static const int t0 = getenv("DWG_RASTER_SORT_T0") ? atoi(getenv("DWG_RASTER_SORT_T0")) : 256;      // experiment switches: threads of the
-        static const int t1 = getenv("DWG_RASTER_SORT_T1") ? atoi(getenv("DWG_RASTER_SORT_T1")) : 1024;     // two common size classes
-        DWG_LAUNCH("raster_sort_super_g", (k_sort_super<3, 1024>), dim3(nD, F), dim3(1024), 0, stream, DWG_SORT_ARGS);
-        DWG_LAUNCH("raster_sort_super_xl", (k_sort_super<2, 1024>), dim3(nC, F), dim3(1024), (16384 + 1024) * 8, stream, DWG_SORT_ARGS);
-        if (t1 == 256) DWG_LAUNCH("raster_sort_super_l", (k_sort_super<1, 256>), dim3(nB, F), dim3(256), (4096 + 256) * 8, stream, DWG_SORT_ARGS);
-        else DWG_LAUNCH("raster_sort_super_l", (k_sort_super<1, 1024>), dim3(nB, F), dim3(1024), (4096 + 256) * 8, stream, DWG_SORT_ARGS);
-        if (t0 == 64) DWG_LAUNCH("raster_sort_super", (k_sort_super<0, 64>), dim3(S, F), dim3(64), (1024 + 64) * 8, stream, DWG_SORT_ARGS);
-        else DWG_LAUNCH("raster_sort_super", (k_sort_super<0, 256>), dim3(S, F), dim3(256), (1024 + 64) * 8, stream, DWG_SORT_ARGS);
-#undef DWG_SORT_ARGS
+        // A frame's keys number at most its (Gaussian, block) pairs <= capacity, in at most capacity / CHUNK + S chunks (every supertile's
+        // last chunk may be short); surplus workgroups exit on their first instruction.
+        const int64_t max_chunks = pair_capacity / CHUNK + S;
+        if (max_chunks > 0x7fffffffll) return DWG_E_ARG;
+        DWG_LAUNCH("raster_chunk_sort", k_chunk_sort, dim3((unsigned)max_chunks, F), dim3(256), (CHUNK + CHUNK / 16) * 8, stream, p, chunk_start,
+                   super_start, (const int32_t*)header, keys, pair_capacity);
+        DWG_LAUNCH("raster_rank_merge", k_rank_merge, dim3((unsigned)max_chunks, F), dim3(256), 0, stream, p, chunk_start, super_start,
+                   (const int32_t*)header, (const uint64_t*)keys, (const float4*)(ws + L.rec0), (const float4*)(ws + L.rec1),
+                   (const uint2*)(ws + L.rect), cand, pair_capacity);
     }
-    DWG_LAUNCH("raster_scan_tiles", k_scan_tiles, dim3(1, F), dim3(1024), 0, stream, p, (const uint32_t*)tile_count,
-               (uint32_t*)(ws + L.seg_start), (uint32_t*)(ws + L.order), header);
-    DWG_LAUNCH("raster_render_fwd", k_render_fwd, dim3(T, F), dim3(64), 0, stream, p, (const uint32_t*)(ws + L.order),
+    // sixteen waves per supertile: a dense list (up to 16 k candidates under a body) is two passes of 16 chunks per wave, not of 64; every
+    // supertile publishes its blocks (list, segments, render-order bucket) -- also when there are no Gaussians at all
+    DWG_LAUNCH("raster_split", k_split<1024>, dim3(S, F), dim3(1024), 0, stream, p, header, super_start, (const uint64_t*)cand, tile_count,
+               tile_start, (uint32_t*)(ws + L.seg_start), (uint32_t*)(ws + L.order), sorted, pair_capacity);
+    DWG_LAUNCH("raster_render_fwd", k_render_fwd, dim3(T, F), dim3(64), 0, stream, p, (const int32_t*)header, (const uint32_t*)(ws + L.order),
                (const uint32_t*)tile_start, (const uint32_t*)tile_count,
                (const uint32_t*)(ws + L.seg_start), (const uint32_t*)sorted, (const float4*)(ws + L.rec0), (const float4*)(ws + L.rec1),
                (const float4*)(ws + L.rec2), pair_capacity, cap_segs, (uint32_t*)(wp + PL.seg_tile), (float*)(wp + PL.ckpt),
