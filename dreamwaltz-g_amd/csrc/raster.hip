@@ -97,7 +97,7 @@ static GeomLayout geom_layout(int G, int H, int W) {
     L.tile_count = o; o = dwg_align_up(o + T * 4, 256);
     L.super_count = o; o = dwg_align_up(o + S * 4, 256);
     L.super_cursor = o; o = dwg_align_up(o + S * 4, 256);
-    L.idsum = o; o = dwg_align_up(o + (g / IDBIN + 8) * 4, 256);   // pair count of every run of IDBIN Gaussian indices (one slot per wave of k_preprocess)
+    L.idsum = o; o = dwg_align_up(o + (g / IDBIN + 24) * 4, 256);   // pair count of every run of IDBIN Gaussian indices (one slot per wave of k_preprocess)
     L.zero_end = o;
     L.rec0 = o; o = dwg_align_up(o + g * sizeof(float4), 256);
     L.rec1 = o; o = dwg_align_up(o + g * sizeof(float4), 256);
@@ -368,7 +368,8 @@ __device__ __forceinline__ uint32_t for_each_supertile(const BlockSpan& sp, Fn&&
 // ------------------------------------------------------------------------------------------------
 // stage A
 // ------------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void k_preprocess(Params p, const float* __restrict__ means3D,
+template <int PB>
+__global__ __launch_bounds__(PB) void k_preprocess(Params p, const float* __restrict__ means3D,
                                                     const float* __restrict__ shs, const float* __restrict__ colors,
                                                     const float* __restrict__ opac, const float* __restrict__ scales,
                                                     const float* __restrict__ rots, const float* __restrict__ cov3Dp,
@@ -376,7 +377,7 @@ __global__ __launch_bounds__(256) void k_preprocess(Params p, const float* __res
                                                     float4* __restrict__ rec1, float4* __restrict__ rec2,
                                                     uint2* __restrict__ rect, uint32_t* __restrict__ npairs, uint32_t* __restrict__ idsum,
                                                     uint32_t* __restrict__ super_count, uint32_t* __restrict__ kref_part, int use_lds_hist) {
-    __shared__ float cam[35], krs[4];
+    __shared__ float cam[35], krs[PB / 64];
     extern __shared__ uint32_t hist[];      // [S] workgroup-private supertile histogram (one global atomic per workgroup and supertile)
     const int S = p.stiles_x * p.stiles_y;
     DWG_GEOM(rec0); DWG_GEOM(rec1); DWG_GEOM(rec2); DWG_GEOM(rect); DWG_GEOM(npairs); DWG_GEOM(idsum); DWG_GEOM(super_count); DWG_GEOM(kref_part);
@@ -386,9 +387,9 @@ __global__ __launch_bounds__(256) void k_preprocess(Params p, const float* __res
     if (threadIdx.x < 16) cam[threadIdx.x] = p.view[co + threadIdx.x];
     else if (threadIdx.x < 32) cam[threadIdx.x] = p.proj[co + threadIdx.x - 16];
     else if (threadIdx.x < 35 && p.campos) cam[threadIdx.x] = p.campos[co + threadIdx.x - 32];
-    if (use_lds_hist) for (int t = threadIdx.x; t < S; t += 256) hist[t] = 0u;
+    if (use_lds_hist) for (int t = threadIdx.x; t < S; t += PB) hist[t] = 0u;
     __syncthreads();
-    int i = blockIdx.x * 256 + threadIdx.x;
+    int i = blockIdx.x * PB + threadIdx.x;
     const bool live_thread = i < p.G;
     if (!live_thread) i = 0;
     else if (p.visit_order) i = p.visit_order[i];
@@ -450,7 +451,7 @@ __global__ __launch_bounds__(256) void k_preprocess(Params p, const float* __res
     // order the lanes' indices are scattered and every lane adds its own (integer: order-independent).
     if (!p.visit_order) {
         const float wsum = dwg_wave_sum_to_lane63((float)ng);           // < 2^24 pairs per 64 splats: exact in fp32
-        if ((threadIdx.x & 63) == 63) idsum[(blockIdx.x * 256 + threadIdx.x) / IDBIN] = (uint32_t)wsum;
+        if ((threadIdx.x & 63) == 63) idsum[(blockIdx.x * PB + threadIdx.x) / IDBIN] = (uint32_t)wsum;
     } else if (live_thread && ng) atomicAdd(&idsum[i / IDBIN], ng);
     if (live_thread) {
         npairs[i] = ng;
@@ -463,9 +464,13 @@ __global__ __launch_bounds__(256) void k_preprocess(Params p, const float* __res
     kref = dwg_wave_sum_to_lane63(kref);
     if ((threadIdx.x & 63) == 63) krs[threadIdx.x >> 6] = kref;
     __syncthreads();
-    if (threadIdx.x == 0) kref_part[blockIdx.x] = (uint32_t)(krs[0] + krs[1] + krs[2] + krs[3]);
+    if (threadIdx.x == 0) {
+        float k = 0.f;
+        for (int w = 0; w < PB / 64; w++) k += krs[w];
+        kref_part[blockIdx.x] = (uint32_t)k;
+    }
     if (use_lds_hist && !(p.dbg & 32))
-        for (int t = threadIdx.x; t < S; t += 256) { uint32_t c = hist[t]; if (c) atomicAdd(&super_count[t], c); }
+        for (int t = threadIdx.x; t < S; t += PB) { uint32_t c = hist[t]; if (c) atomicAdd(&super_count[t], c); }
 }
 
 // sort size classes of a supertile list: one wave / 1024 threads with 34 KiB / 1024 threads with 136 KiB of LDS / in global memory
@@ -479,7 +484,7 @@ __global__ __launch_bounds__(256) void k_preprocess(Params p, const float* __res
 __global__ __launch_bounds__(1024) void k_scan_super(Params p, const uint32_t* __restrict__ super_count, uint32_t* __restrict__ super_start,
                                                      uint32_t* __restrict__ chunk_start, int32_t* __restrict__ header,
                                                      const uint32_t* __restrict__ npairs, const uint32_t* __restrict__ idsum,
-                                                     uint32_t* __restrict__ goff, const uint32_t* __restrict__ kref_part) {
+                                                     uint32_t* __restrict__ goff, const uint32_t* __restrict__ kref_part, int pb) {
     __shared__ uint32_t part[1024], parts[1024];
     DWG_GEOM(super_count); DWG_GEOM(super_start); DWG_GEOM(chunk_start); DWG_GEOM(header); DWG_GEOM(npairs); DWG_GEOM(idsum); DWG_GEOM(goff);
     DWG_GEOM(kref_part);
@@ -534,7 +539,7 @@ __global__ __launch_bounds__(1024) void k_scan_super(Params p, const uint32_t* _
     // K_ref = the sum of k_preprocess's per-workgroup shares
     __syncthreads();
     uint32_t kr = 0;
-    for (int t = tid; t < (G + 255) / 256; t += 1024) kr += kref_part[t];
+    for (int t = tid; t < (G + pb - 1) / pb; t += 1024) kr += kref_part[t];
     part[tid] = kr;
     __syncthreads();
     for (int off = 512; off >= 1; off >>= 1) {
@@ -551,14 +556,15 @@ __global__ __launch_bounds__(1024) void k_scan_super(Params p, const uint32_t* _
 // per supertile in LDS, reserve ONE contiguous range per (workgroup, supertile) with a single returning global atomic; (2) hand out slots
 // inside the reserved ranges with LDS atomics (the counter then holds the absolute running slot).  The order inside a range is whatever the
 // atomics made it: the list is sorted next.
-__global__ __launch_bounds__(256) void k_scatter_super(Params p, const float4* __restrict__ rec0, const float4* __restrict__ rec1,
+template <int PB>
+__global__ __launch_bounds__(PB) void k_scatter_super(Params p, const float4* __restrict__ rec0, const float4* __restrict__ rec1,
                                                        const uint2* __restrict__ rect, const uint32_t* __restrict__ super_start,
                                                        uint32_t* __restrict__ super_cursor, uint64_t* __restrict__ keys,
                                                        int64_t cap, int32_t* __restrict__ header, int use_lds) {
     extern __shared__ uint32_t cnt[];       // [S]
     DWG_GEOM(rec0); DWG_GEOM(rec1); DWG_GEOM(rect); DWG_GEOM(super_start); DWG_GEOM(super_cursor); DWG_GEOM(header); DWG_PAIRS(keys);
     const int S = p.stiles_x * p.stiles_y, G = p.G;
-    int i = blockIdx.x * 256 + threadIdx.x;
+    int i = blockIdx.x * PB + threadIdx.x;
     uint64_t key = 0;
     BlockSpan sp;
     sp.by0 = sp.by1 = sp.bx0 = sp.bx1 = 0; sp.all = false;
@@ -579,11 +585,11 @@ __global__ __launch_bounds__(256) void k_scatter_super(Params p, const float4* _
         });
         return;
     }
-    for (int t = threadIdx.x; t < S; t += 256) cnt[t] = 0u;
+    for (int t = threadIdx.x; t < S; t += PB) cnt[t] = 0u;
     __syncthreads();
     for_each_supertile(sp, [&](int sy, int sx) { atomicAdd(&cnt[sy * p.stiles_x + sx], 1u); });
     __syncthreads();
-    for (int t = threadIdx.x; t < S; t += 256) {
+    for (int t = threadIdx.x; t < S; t += PB) {
         const uint32_t c = cnt[t];
         if (c) cnt[t] = super_start[t] + atomicAdd(&super_cursor[t], c);
     }
@@ -1251,22 +1257,20 @@ __global__ __launch_bounds__(256) void k_gather_partials(int G, const uint32_t* 
         const int64_t nn = work ? n : 0;
         int64_t nmax = nn;                                     // quad-uniform trip count (n is per Gaussian = per quad already)
         int64_t r = 0;
-        for (; r + 3 < nmax; r += 4) {                         // four rows in flight; added in row order
-            const float4 a = src[3 * r], b = src[3 * r + 3], c = src[3 * r + 6], d = src[3 * r + 9];
-            int ok4 = 0;
-            if (h == 2) ok4 = (int)(__float_as_uint(a.z) == tag2 && __float_as_uint(a.w) == tag) | ((int)(__float_as_uint(b.z) == tag2 && __float_as_uint(b.w) == tag) << 1) |
-                              ((int)(__float_as_uint(c.z) == tag2 && __float_as_uint(c.w) == tag) << 2) | ((int)(__float_as_uint(d.z) == tag2 && __float_as_uint(d.w) == tag) << 3);
-            ok4 = __builtin_amdgcn_update_dpp(0, ok4, 0xAA, 0xF, 0xF, false);      // quad_perm [2,2,2,2]
-            if (ok4 & 1) { acc.x += a.x; acc.y += a.y; acc.z += a.z; acc.w += a.w; }
-            if (ok4 & 2) { acc.x += b.x; acc.y += b.y; acc.z += b.z; acc.w += b.w; }
-            if (ok4 & 4) { acc.x += c.x; acc.y += c.y; acc.z += c.z; acc.w += c.w; }
-            if (ok4 & 8) { acc.x += d.x; acc.y += d.y; acc.z += d.z; acc.w += d.w; }
-        }
-        for (; r < nmax; r++) {
-            const float4 a = src[3 * r];
-            int ok1 = (h == 2) ? (int)(__float_as_uint(a.z) == tag2 && __float_as_uint(a.w) == tag) : 0;
-            ok1 = __builtin_amdgcn_update_dpp(0, ok1, 0xAA, 0xF, 0xF, false);
-            if (ok1) { acc.x += a.x; acc.y += a.y; acc.z += a.z; acc.w += a.w; }
+        // sixteen rows in flight per trip, added in row order (a typical splat has ~10 rows: one round trip)
+        for (; r < nmax; r += 16) {
+            float4 v[16];
+#pragma unroll
+            for (int u = 0; u < 16; u++) v[u] = r + u < nmax ? src[3 * (r + u)] : make_float4(0.f, 0.f, 0.f, 0.f);
+            int okm = 0;
+            if (h == 2) {
+#pragma unroll
+                for (int u = 0; u < 16; u++) okm |= (int)(__float_as_uint(v[u].z) == tag2 && __float_as_uint(v[u].w) == tag) << u;
+            }
+            okm = __builtin_amdgcn_update_dpp(0, okm, 0xAA, 0xF, 0xF, false);      // quad_perm [2,2,2,2]
+#pragma unroll
+            for (int u = 0; u < 16; u++)
+                if ((okm >> u) & 1) { acc.x += v[u].x; acc.y += v[u].y; acc.z += v[u].z; acc.w += v[u].w; }
         }
     }
     unsigned long long m = __ballot(big && h == 0);
@@ -1499,6 +1503,14 @@ static int make_params(const dwg_raster_settings* cfg, const dwg_raster_frames* 
 
 // Workgroup-private LDS supertile histograms (one global atomic per workgroup and supertile instead of one per (Gaussian, supertile)
 // pair) up to 16384 supertiles (4096^2 pixels); DWG_RASTER_LDS_MAXS lowers the limit (experiment switch).
+// Threads per workgroup of the two per-Gaussian binning kernels: 1024 from 128 k Gaussians (a quarter of the (workgroup, supertile) global
+// atomics of 256-thread workgroups: scatter 52 -> 26 us on 300 k shuffled Gaussians), 256 below (small frames need the workgroup count).
+static int binning_block(int G) {
+    static const int forced = getenv("DWG_RASTER_PB") ? atoi(getenv("DWG_RASTER_PB")) : 0;
+    if (forced == 256 || forced == 1024) return forced;
+    return G >= (1 << 17) ? 1024 : 256;
+}
+
 static int lds_hist_ok(int S) {
     static const int lds_max_s = getenv("DWG_RASTER_LDS_MAXS") ? atoi(getenv("DWG_RASTER_LDS_MAXS")) : 16384;
     return S <= lds_max_s && S <= 16384;
@@ -1551,21 +1563,25 @@ int dwg_raster_forward_bin_frames(const dwg_raster_settings* cfg, const dwg_rast
     }
     static bool attr_set = false;
     if (!attr_set) {      // 64 KiB of histogram + the static camera words is over the 64 KiB default limit
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_preprocess), hipFuncAttributeMaxDynamicSharedMemorySize, 16384 * 4);
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_scatter_super), hipFuncAttributeMaxDynamicSharedMemorySize, 16384 * 4);
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_preprocess<256>), hipFuncAttributeMaxDynamicSharedMemorySize, 16384 * 4);
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_preprocess<1024>), hipFuncAttributeMaxDynamicSharedMemorySize, 16384 * 4);
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_scatter_super<256>), hipFuncAttributeMaxDynamicSharedMemorySize, 16384 * 4);
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_scatter_super<1024>), hipFuncAttributeMaxDynamicSharedMemorySize, 16384 * 4);
         attr_set = true;
     }
     if (G > 0) {
         const int use_lds_hist = lds_hist_ok(S);
-        DWG_LAUNCH("raster_preprocess", k_preprocess, dim3(dwg_cdiv(G, 256), F), dim3(256), use_lds_hist ? (size_t)S * 4 : 0, stream, p,
-                   means3D, shs, colors_precomp, opacities, scales, rotations, cov3D_precomp, radii, (float4*)(ws + L.rec0),
-                   (float4*)(ws + L.rec1), (float4*)(ws + L.rec2), (uint2*)(ws + L.rect), (uint32_t*)(ws + L.npairs),
-                   (uint32_t*)(ws + L.idsum), (uint32_t*)(ws + L.super_count), (uint32_t*)(ws + L.kref_part), use_lds_hist);
+#define DWG_PRE_ARGS p, means3D, shs, colors_precomp, opacities, scales, rotations, cov3D_precomp, radii, (float4*)(ws + L.rec0),                  \
+                     (float4*)(ws + L.rec1), (float4*)(ws + L.rec2), (uint2*)(ws + L.rect), (uint32_t*)(ws + L.npairs),                        \
+                     (uint32_t*)(ws + L.idsum), (uint32_t*)(ws + L.super_count), (uint32_t*)(ws + L.kref_part), use_lds_hist
+        if (binning_block(G) == 1024) DWG_LAUNCH("raster_preprocess", k_preprocess<1024>, dim3(dwg_cdiv(G, 1024), F), dim3(1024), use_lds_hist ? (size_t)S * 4 : 0, stream, DWG_PRE_ARGS);
+        else DWG_LAUNCH("raster_preprocess", k_preprocess<256>, dim3(dwg_cdiv(G, 256), F), dim3(256), use_lds_hist ? (size_t)S * 4 : 0, stream, DWG_PRE_ARGS);
+#undef DWG_PRE_ARGS
     }
     // workgroup 0: supertile lists (starts, size classes); workgroups 1..: the pair rows of GTILE Gaussians each + the frame's pair count
     DWG_LAUNCH("raster_scan_super", k_scan_super, dim3(1 + dwg_cdiv(G, GTILE), F), dim3(1024), 0, stream, p,
                (const uint32_t*)(ws + L.super_count), (uint32_t*)(ws + L.super_start), (uint32_t*)(ws + L.chunk_start), (int32_t*)(ws + L.header),
-               (const uint32_t*)(ws + L.npairs), (const uint32_t*)(ws + L.idsum), (uint32_t*)(ws + L.goff), (const uint32_t*)(ws + L.kref_part));
+               (const uint32_t*)(ws + L.npairs), (const uint32_t*)(ws + L.idsum), (uint32_t*)(ws + L.goff), (const uint32_t*)(ws + L.kref_part), binning_block(G));
     DWG_RETURN_IF_LAUNCH_FAILED();
     return DWG_OK;
 }
@@ -1605,9 +1621,11 @@ int dwg_raster_forward_render_frames(const dwg_raster_settings* cfg, const dwg_r
     int32_t* header = (int32_t*)(ws + L.header);
     if (G > 0) {
         const int use_lds = lds_hist_ok(S);
-        DWG_LAUNCH("raster_scatter", k_scatter_super, dim3(dwg_cdiv(G, 256), F), dim3(256), use_lds ? (size_t)S * 4 : 0, stream, p,
-                   (const float4*)(ws + L.rec0), (const float4*)(ws + L.rec1), (const uint2*)(ws + L.rect), super_start,
-                   (uint32_t*)(ws + L.super_cursor), keys, pair_capacity, header, use_lds);
+#define DWG_SCAT_ARGS p, (const float4*)(ws + L.rec0), (const float4*)(ws + L.rec1), (const uint2*)(ws + L.rect), super_start,                      \
+                      (uint32_t*)(ws + L.super_cursor), keys, pair_capacity, header, use_lds
+        if (binning_block(G) == 1024) DWG_LAUNCH("raster_scatter", k_scatter_super<1024>, dim3(dwg_cdiv(G, 1024), F), dim3(1024), use_lds ? (size_t)S * 4 : 0, stream, DWG_SCAT_ARGS);
+        else DWG_LAUNCH("raster_scatter", k_scatter_super<256>, dim3(dwg_cdiv(G, 256), F), dim3(256), use_lds ? (size_t)S * 4 : 0, stream, DWG_SCAT_ARGS);
+#undef DWG_SCAT_ARGS
         // A frame's keys number at most its (Gaussian, block) pairs <= capacity, in at most capacity / CHUNK + S chunks (every supertile's
         // last chunk may be short); surplus workgroups exit on their first instruction.
         const int64_t max_chunks = pair_capacity / CHUNK + S;
