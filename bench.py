@@ -45,7 +45,8 @@ from dreamwaltz_g_amd import sds_step  # noqa: E402
 HBM_PEAK_GBS = 8000.0                                  # MI355X_MICROARCH.md: 8 TB/s HBM3E
 MFMA_PEAK_TFLOPS = {"bf16": 2500.0, "f16": 2500.0, "f32": 157.3, "f32x": 2500.0}      # dense MFMA peaks per operand type (same guide); f32x runs on the
                                                                                        # f16 MFMA pipe, its ALGORITHMIC flops (one multiply-add per product, not the three MFMAs) are priced against that peak
-TRAFFIC_JSON = os.path.join(ROOT, "profiles", "r04_pmc_traffic.json")      # PMC passes over the f32x (headline) step: tools/profile_round.sh
+N1_LINE_JSON = os.path.join(ROOT, "profiles", "r05_bench_line.json")           # the round's single-GPU line: N = 1 references of an N > 1 line
+TRAFFIC_JSON = os.path.join(ROOT, "profiles", "r05_pmc_traffic.json")      # PMC passes over the f32x (headline) step: tools/profile_round.sh
 HEADLINE_DTYPE = "f32x"       # the reference runs the guidance stage in fp32 (configs/__init__.py:236,241): the headline is a same-precision number
 HEADLINE_METRIC = "SDS steps/sec @512^2, 100k Gaussians, SD1.5+ControlNet; raster Mpix/s vs HBM roofline"
 
@@ -473,9 +474,24 @@ def run_sds(ctx, config, dtype=HEADLINE_DTYPE, views=None, steps=None, warmup=No
     else:
         metric = "config %s sub-path (NOT the headline): animate + raster fwd+bwd + Adam steps/s, %dk Gaussians @%d^2, no guidance" % (config, G // 1000, res)
         value, unit, scaling = views * steps / dt, "steps/s", "weak"
-    out = {"metric": metric, "value": value, "unit": unit, "n_gpus": ctx.world, "steps": steps, "warmup": warmup if not args.eager else 0,
-           "ms_per_step": dt / steps * 1e3, "higher_is_better": True, "scaling": scaling, "vs_baseline": None, "dtype": info["dtype"],
-           "data": "synthetic", "config": info["config"]}
+    out = {"metric": metric, "value": value, "unit": unit, "n_gpus": ctx.world}
+    if ctx.world > 1:
+        # what a reader of an N > 1 line needs inside its first 2 KB: that N ranks really ran, over which backend, what the exchange step
+        # costs, and how the rate compares with the two N = 1 forms of the same work (profiles/: measured on ONE GPU by the default run)
+        out["dist"] = {"world_size": ctx.dist.get_world_size(), "backend": ctx.dist.get_backend(), "views_per_step": views,
+                       "views_per_s": views * steps / dt, "allreduce_ms_per_step": step.trainer.allreduce_ms,
+                       "allreduce": "one asynchronous all-reduce per named optimizer's slice of the flat fp32 gradient buffer (%.1f MB in all), "
+                                    "smallest first, each optimizer stepping behind its slice; the time is issue .. last optimizer launched"
+                                    % (step.optimizers.buffers.grad.numel() * 4 / 1e6)}
+        ref = n1_reference(config, guidance)
+        if ref:
+            out["dist"].update(ref)
+            for k in ("n1_batched_views_per_s", "n1_sequential_views_per_s", "n1_views_per_s"):
+                if ref.get(k):
+                    out["dist"]["scaling_vs_" + k[:-len("_views_per_s")]] = (views * steps / dt) / ref[k]
+    out.update({"steps": steps, "warmup": warmup if not args.eager else 0,
+                "ms_per_step": dt / steps * 1e3, "higher_is_better": True, "scaling": scaling, "vs_baseline": None, "dtype": info["dtype"],
+                "data": "synthetic", "config": info["config"]})
     out["views_per_s"] = views * steps / dt
     if len(dts) > 1:
         out["repeats"] = {"n": len(dts), "value_is": "median", "ms_per_step_min": min(dts) / steps * 1e3, "ms_per_step_median": dt / steps * 1e3,
@@ -494,6 +510,24 @@ def run_sds(ctx, config, dtype=HEADLINE_DTYPE, views=None, steps=None, warmup=No
     out["launch_mode"] = ("eager" if args.eager else "the WHOLE step (zero_grad, animate, raster fwd + bwd, Adam) replayed as one captured HIP graph per pose"
                           if whole_graph else "hipGraph replay of denoiser/VAE plans; kernel timers from an eager replay after the timed region")
     return out
+
+
+def n1_reference(config, guidance):
+    """The N = 1 rates an N > 1 line is compared with, read from the round's committed single-GPU line (profiles/, labelled with its file):
+    for c4 both ways one GPU can do the step's 8 views -- ONE batched guidance call, or one call per view -- and for c3 the single-view rate.
+    The driver computes scaling efficiency itself from its own per-N runs; these ratios only make a lone N = 8 line readable."""
+    if not guidance or not os.path.exists(N1_LINE_JSON):
+        return None
+    try:
+        d = json.load(open(N1_LINE_JSON))
+        src = "profiles/" + os.path.basename(N1_LINE_JSON)
+        if config == "c4":
+            c = d.get("configs", {})
+            return {"n1_batched_views_per_s": c["c4_n1"]["views_per_s"], "n1_sequential_views_per_s": c["c4_n1_sequential_views"]["views_per_s"],
+                    "n1_source": src}
+        return {"n1_views_per_s": d["value"], "n1_source": src}
+    except Exception:       # an older line without these legs: no reference, no ratios
+        return None
 
 
 def _scene(ctx, G):

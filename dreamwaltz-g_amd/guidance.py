@@ -106,14 +106,15 @@ def C(value, current_step=None, max_iteration=None) -> float:
 class ControlNetScoreDistillation:
     def __init__(self, device, unet_cfg: Optional[sd15.UNetConfig] = None, vae_cfg: Optional[sd15.VAEConfig] = None,
                  unet_sd=None, controlnet_sd=None, vae_sd=None, image_hw=512, guidance_scale=None, min_timestep=None,
-                 max_timestep=None, seed=0, cfg: Optional[GuideConfig] = None, text_len=77, dtype="bf16", views=1, share_weights_with=None):
+                 max_timestep=None, seed=0, cfg: Optional[GuideConfig] = None, text_len=77, dtype="f32x", views=1, share_weights_with=None):
         """`views` > 1: ONE call distils that many rendered views at once (inputs [V,3,H,W]; the plans are built for a VAE batch of V and a
         denoiser batch of 2 V -- nothing in the reference to mirror, its call is batch 1: checklist Q11).  `share_weights_with`: another
         guidance object of the same dtype whose kernel-layout weights this one's plans point at (no second copy in HBM)."""
         self.device = torch.device(device)
         self.views = int(views)
-        self.dtype_name = sd15.dtype_name(dtype)          # storage type of the denoiser / VAE plans: "bf16" (default) | "f32" (the reference's
-                                                          # GS-stage precision, configs/__init__.py:236,241) | "f16" (its --guide.dtype fp16)
+        self.dtype_name = sd15.dtype_name(dtype)          # precision of the denoiser / VAE plans: "f32x" (default: the reference's fp32 GS-stage
+                                                          # results, configs/__init__.py:236,241, on the 16-bit MFMA pipe) | "f32" (exact-f32
+                                                          # MFMA) | "f16" (its --guide.dtype fp16) | "bf16" (reduced precision, opt-in only)
         self.cfg = cfg if cfg is not None else GuideConfig()
         self.unet_cfg = unet_cfg or sd15.UNetConfig()
         self.vae_cfg = vae_cfg or sd15.VAEConfig()
@@ -155,6 +156,7 @@ class ControlNetScoreDistillation:
         self.scheduler = types.SimpleNamespace(scale_model_input=lambda sample, timestep=None: sample)   # DDPM / PNDM: identity
         self.alphas_cumprod = sd15_alphas_cumprod(self.device)
         self.num_train_timesteps = 1000
+        self.denoiser.temb_rows = self.num_train_timesteps + 1      # the integer-timestep embedding table covers the scheduler's range
         self.time_sampling = self.cfg.time_sampling
         self.min_step_cfg = self.cfg.min_timestep if min_timestep is None else min_timestep
         self.max_step_cfg = self.cfg.max_timestep if max_timestep is None else max_timestep

@@ -146,19 +146,24 @@ class FlatOptimizer:
             for p in pg.get('params', ()):
                 p._dwg_touched = False
 
-    def step(self):
+    def step(self, participation=None):
         """One Adam step of every param group.  Bias correction uses the group's OWN step count (torch.optim.Adam keeps one per parameter):
-        a group that sat a step out -- its parameter was just replaced by the densifier, `grad is None` in the reference -- does not age."""
+        a group that sat a step out -- its parameter was just replaced by the densifier, `grad is None` in the reference -- does not age.
+        `participation`: one bool per group, decided by the caller (the multi-rank step agrees on it across the ranks, trainer._reduce_and_step)
+        instead of this process's own record of which parameters its backward touched."""
         self.t += 1
         self.current_iteration += 1
-        for pg in self.param_groups:
+        for gi, pg in enumerate(self.param_groups):
             if pg.pop("skip_once", False):
                 # the densifier just replaced this group's parameter: torch.optim.Adam finds `grad is None` on the new Parameter and leaves
                 # it (and its moments) alone for this step (gaussian_densifier.py:141-161 + trainer.py:876-890)
                 continue
             if pg["end"] <= pg["start"]:
                 continue
-            if self.buf.tracking and pg.get('params') and not any(getattr(p, "_dwg_touched", False) for p in pg['params']):
+            if participation is not None:
+                if not participation[gi]:
+                    continue
+            elif self.buf.tracking and pg.get('params') and not any(getattr(p, "_dwg_touched", False) for p in pg['params']):
                 # no parameter of this group took part in this step's backward: torch.optim.Adam sees `grad is None` and leaves the
                 # parameter, both moments and the step count untouched (no drift on stale momentum, no ageing of the bias correction)
                 continue
@@ -290,7 +295,11 @@ def resize_flat_params(opts: FlatOptimizerDict, new_values: Dict[torch.nn.Parame
     for p in opts.params:
         p.data = keep[p][0]
         p.grad = None
+    touched = {p: bool(getattr(p, "_dwg_touched", False)) for p in opts.params}      # this step's participation survives the re-homing
     buf = FlatBuffers(opts.params, old.flat.device)
+    buf.tracking = old.tracking
+    for p in opts.params:
+        p._dwg_touched = touched[p]
     for p, (off, n) in zip(opts.params, buf.slices):
         buf.m[off:off + n].copy_(keep[p][1].reshape(-1)); buf.v[off:off + n].copy_(keep[p][2].reshape(-1))
         if keep[p][3] is not None:

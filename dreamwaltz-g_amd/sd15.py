@@ -846,6 +846,7 @@ class DenoiserPlan:
     def __init__(self, cfg: UNetConfig, unet_sd, cn_sd, device, batch=2, latent_hw=64, text_len=77, dtype="bf16", views=1, weights=None):
         self.cfg, self.device, self.B, self.hw, self.views = cfg, device, batch, latent_hw, int(views)
         self._temb_table = None
+        self.temb_rows = 1001                 # timesteps the embedding table covers: 0 .. the scheduler's num_train_timesteps (guidance sets it)
         assert batch % self.views == 0, (batch, views)
         self.plan = Plan(device, dtype)
         p = self.plan
@@ -910,8 +911,10 @@ class DenoiserPlan:
             t = t.repeat(self.B // t.numel())                 # [t_0..t_{V-1} | t_0..t_{V-1}]: the batch order of the CFG halves
         if t.dtype == torch.long and t.is_cuda:
             # integer timesteps: rows of a table computed once with the same statements (eight element-wise launches per call otherwise)
-            if self._temb_table is None:
-                self._temb_table = timestep_embedding(torch.arange(1000, device=t.device), self.cfg.block_out_channels[0])
+            # (rows 0 .. temb_rows - 1 = every timestep of the owner's scheduler, which also indexes its alphas_cumprod with t: a timestep
+            # outside the scheduler's range is an error there as here)
+            if self._temb_table is None or self._temb_table.shape[0] != self.temb_rows:
+                self._temb_table = timestep_embedding(torch.arange(self.temb_rows, device=t.device), self.cfg.block_out_channels[0])
             te = self._temb_table.index_select(0, t.expand(self.B))
         else:
             te = timestep_embedding(t.expand(self.B), self.cfg.block_out_channels[0])

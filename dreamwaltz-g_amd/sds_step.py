@@ -54,7 +54,7 @@ def build_synthetic_avatar(n_gaussians, device, seed=0, learn_hand_betas=False):
 
 class SDSStep:
     def __init__(self, n_gaussians=100000, res=512, device="cuda", rank=0, world=1, guidance=True, dist=None, seed=0, cfg=None,
-                 avatar=None, guidance_obj=None, async_pair_count=True, iters=10000, gpu_condition=True, views=None, dtype="bf16",
+                 avatar=None, guidance_obj=None, async_pair_count=True, iters=10000, gpu_condition=True, views=None, dtype="f32x",
                  batch_views=False):
         self.device, self.rank, self.world, self.dist, self.res = torch.device(device), rank, world, dist, res
         self.views = int(views) if views is not None else world           # views per step over ALL ranks

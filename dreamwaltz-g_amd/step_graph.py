@@ -216,6 +216,21 @@ class GraphedTrainStep:
         return ovf
 
     def recapture(self, grow: float = 2.0):
+        """After check() reported a truncated step: capture again at `grow` x the pair capacity WITHOUT taking a step.  Capturing needs one
+        eager pass at the new capacity (allocator warm-up) and that pass is a whole optimizer step on whatever pose the static buffer holds:
+        parameters, Adam moments, every group's step count / learning rate and the trainer's step index are put back afterwards, so the
+        step sequence -- poses, seeds, bias corrections -- stays the eager run's (the truncated step itself is the caller's to repeat)."""
+        tr = self.trainer
+        buf = tr.optimizers.buffers
+        snap = (buf.flat.clone(), buf.m.clone(), buf.v.clone(), tr.train_step_index,
+                [(o.t, o.current_iteration, [(pg.get("t", 0), pg["lr"]) for pg in o.param_groups]) for o in tr.optimizers.values()])
         self._state.cap = int(self._state.cap * grow)
         self.graph = None
         self._capture()
+        torch.cuda.current_stream(self.device).synchronize()
+        buf.flat.copy_(snap[0]); buf.m.copy_(snap[1]); buf.v.copy_(snap[2])
+        tr.train_step_index = snap[3]
+        for o, (t, it, groups) in zip(tr.optimizers.values(), snap[4]):
+            o.t, o.current_iteration = t, it
+            for pg, (gt, lr) in zip(o.param_groups, groups):
+                pg["t"], pg["lr"] = gt, lr

@@ -42,6 +42,7 @@ class SDSTrainer:
         # (one all-reduce of two int64 words): a drift -- a non-deterministic reduction order, a rank that missed an update -- raises on
         # every rank instead of training on silently diverged replicas.  DWG_REPLICA_CHECK_EVERY=0 turns the check off.
         self.replica_check_every = int(os.environ.get("DWG_REPLICA_CHECK_EVERY", "100"))
+        self._allreduce_events, self.allreduce_ms_total, self.allreduce_steps = [], 0.0, 0      # exchange-step timing (world > 1)
         if self.world > 1:
             self.sync_replicas()
 
@@ -273,12 +274,59 @@ class SDSTrainer:
             self.model.densify(densifiers=self.densifiers, render_outputs=out[1], spatial_scale=self.get_spatial_scale(views[0]),
                                train_step=self.train_step_index)
         if self.world > 1:
-            self.dist.all_reduce(self.optimizers.all_grads())       # one flat fp32 buffer
-        for optimizer in self.optimizers.values():
-            optimizer.step()
+            self._reduce_and_step()
+        else:
+            for optimizer in self.optimizers.values():
+                optimizer.step()
         if self.world > 1 and self.replica_check_every > 0 and self.train_step_index % self.replica_check_every == 0:
             self.check_replicas()
         return out
+
+    def _reduce_and_step(self):
+        """The exchange step of a multi-rank SDS step (nothing in the reference to mirror: SURVEY 2.2 finds no torch.distributed).
+        The flat gradient buffer is reduced SLICE BY SLICE, one asynchronous all-reduce per named optimizer, smallest slice first -- the grid
+        table's 50 MB go last -- and every optimizer steps as soon as ITS slice has arrived, so the fused Adam launches of the small groups
+        run under the table's reduce instead of behind it.  The sums are the ones a single all-reduce of the whole buffer gives (slices are
+        disjoint ranges of one allocation).  Participation -- which groups took part in this step's backward, optim.FlatBuffers -- is agreed
+        on ACROSS the ranks first (MAX of a per-group flag): a group some rank touched steps everywhere, a group no rank touched keeps its
+        moments and step count everywhere; a rank deciding alone would let the replicas diverge.  The reduce's duration (events on the
+        current stream around issue .. last wait) is kept in `allreduce_ms`."""
+        opts, buf = self.optimizers, self.optimizers.buffers
+        order = sorted(opts.values(), key=lambda o: o.end - o.start)
+        cuda = buf.grad.is_cuda
+        if cuda:
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+        groups = [pg for o in order for pg in o.param_groups]
+        flags = torch.tensor([1 if (not buf.tracking or not pg.get('params') or any(getattr(q, "_dwg_touched", False) for q in pg['params'])) else 0
+                              for pg in groups], dtype=torch.int32, device=buf.grad.device)
+        fwork = self.dist.all_reduce(flags, op=self.dist.ReduceOp.MAX, async_op=True)
+        works = [self.dist.all_reduce(buf.grad[o.start:o.end], async_op=True) for o in order]
+        fwork.wait()
+        took_part = [bool(f) for f in flags.tolist()]
+        k = 0
+        for o, work in zip(order, works):
+            work.wait()
+            n = len(o.param_groups)
+            o.step(participation=took_part[k:k + n])
+            k += n
+        if cuda:
+            e1.record()
+            self._allreduce_events.append((e0, e1))
+            if len(self._allreduce_events) > 64:
+                self._drain_allreduce_events()
+
+    def _drain_allreduce_events(self):
+        for e0, e1 in self._allreduce_events:
+            e1.synchronize()
+            self.allreduce_ms_total += e0.elapsed_time(e1); self.allreduce_steps += 1
+        self._allreduce_events = []
+
+    @property
+    def allreduce_ms(self):
+        """Mean duration of the exchange step (issue of the first slice's reduce .. last optimizer launched), ms per step; None: no step yet."""
+        self._drain_allreduce_events()
+        return self.allreduce_ms_total / self.allreduce_steps if self.allreduce_steps else None
 
     def _check_densifier(self, n_views):
         """The densifier is the reference's single-view, single-GPU feature (trainer.py:879-886): its statistics are per rendered frame, and
@@ -297,12 +345,31 @@ class SDSTrainer:
 
     # -- replica consistency (world > 1) ------------------------------------------------------------------------------------------------
     def sync_replicas(self, src: int = 0):
-        """Every rank takes rank `src`'s flat parameter buffer and Adam moments (construction, and after a checkpoint load on one rank)."""
+        """Every rank takes rank `src`'s state: the flat parameter buffer and Adam moments, the optimizers' scalars (step counts per group,
+        iteration, learning rates: what the bias corrections and the schedule are computed from), the trainer's step index and the model's
+        buffers that live outside the flat buffer -- at construction, and after a checkpoint load on one rank."""
         buf = getattr(self.optimizers, "buffers", None)
         if self.world <= 1 or buf is None or self.dist is None:
             return
         for t in (buf.flat, buf.m, buf.v):
             self.dist.broadcast(t, src=src)
+        scal = [float(self.train_step_index)]
+        for o in self.optimizers.values():
+            scal += [float(o.t), float(o.current_iteration)]
+            for pg in o.param_groups:
+                scal += [float(pg.get("t", 0)), float(pg["lr"])]
+        st = torch.tensor(scal, dtype=torch.float64, device=buf.flat.device)
+        self.dist.broadcast(st, src=src)
+        vals = st.tolist()
+        self.train_step_index = int(vals[0]); k = 1
+        for o in self.optimizers.values():
+            o.t, o.current_iteration = int(vals[k]), int(vals[k + 1]); k += 2
+            for pg in o.param_groups:
+                pg["t"], pg["lr"] = int(vals[k]), vals[k + 1]; k += 2
+        if isinstance(self.model, torch.nn.Module):
+            for b in self.model.buffers():
+                if b.device == buf.flat.device and b.is_contiguous() and b.numel() > 0 and b.dtype != torch.bool:
+                    self.dist.broadcast(b, src=src)
 
     def replica_checksum(self) -> torch.Tensor:
         """64-bit checksum of the flat parameter buffer: the sum of its fp32 words read as int32, in int64 (exact, order-independent)."""

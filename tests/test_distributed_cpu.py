@@ -39,7 +39,7 @@ def _worker(rank, world, port, q):
     gathered = [torch.zeros_like(local) for _ in range(world)]
     dist.all_gather(gathered, local)
     assert torch.allclose(opt.grad, sum(gathered))
-    q.put((rank, opt.grad.clone(), a.grad.clone()))
+    q.put((rank, opt.grad.numpy().copy(), a.grad.numpy().copy()))      # by value: a tensor travels as a file descriptor its sender must outlive
     dist.barrier()
     dist.destroy_process_group()
 
@@ -52,6 +52,7 @@ def test_flat_gradient_allreduce_gloo_world2():
     for p in procs:
         p.start()
     res = sorted([q.get(timeout=300) for _ in range(2)], key=lambda t: t[0])
+    res = [(r, torch.from_numpy(g), torch.from_numpy(ag)) for r, g, ag in res]
     for p in procs:
         p.join(timeout=120)
         assert p.exitcode == 0
@@ -225,3 +226,77 @@ def test_replica_guard_broadcasts_rank0_and_raises_on_drift_on_every_rank():
         assert p.exitcode == 0
     assert (res[0][1] == res[1][1]).all()               # the differently initialised rank took rank 0's parameters
     assert res[0][2] == ["clean", "raised"] and res[1][2] == ["clean", "raised"], (res[0][2], res[1][2])
+
+
+# ---------------------------------------------------------------------------------------------------------------------------------------
+# The exchange step in slices (trainer._reduce_and_step, round 5): one asynchronous all-reduce per named optimizer, each optimizer stepping
+# behind ITS slice; which groups take part in the step is agreed on across the ranks (MAX of a per-group flag) -- a group one rank's
+# backward reached steps on EVERY rank, a group no rank reached keeps its moments and step count everywhere.
+# ---------------------------------------------------------------------------------------------------------------------------------------
+class _ToyScene3(torch.nn.Module):
+    def __init__(self):
+        super().__init__()
+        g = torch.Generator().manual_seed(0)
+        self.a = torch.nn.Parameter(torch.randn(6, 3, generator=g))
+        self.b = torch.nn.Parameter(torch.randn(5, generator=g))
+        self.c = torch.nn.Parameter(torch.randn(4, generator=g))       # no view ever depends on it
+        self.register_buffer("marker", torch.zeros(3))
+
+    def forward(self, data, smpl_observed_inputs=None, use_densifier=False, bg_mode=None):
+        az = data["azimuth"].float().reshape(())
+        base = torch.linspace(0, 1, 4 * 4 * 3).reshape(1, 4, 4, 3)
+        img = torch.sin(base * self.a.sum() + az * 0.01)
+        if bool(data.get("use_b", True)):
+            img = img + (self.b ** 2).sum() * torch.cos(base * (1.0 + az * 0.003))
+        return {"image": img, "alpha": torch.ones(1, 4, 4, 1), "depth": torch.ones(1, 4, 4, 1)}
+
+
+def _participation_worker(rank, world, port, q):
+    import sys
+    sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    import dwg_import  # noqa: F401
+    os.environ["MASTER_ADDR"] = "127.0.0.1"; os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from dreamwaltz_g_amd import configs, optim, sds_step, trainer
+    optim.FlatOptimizer._launch = _cpu_adam_launch
+    cfg = configs.TrainConfig(); cfg.device = "cpu"; cfg.prompt.text_augmentation = False
+    scene = _ToyScene3()
+    with torch.no_grad():
+        scene.marker.fill_(float(rank + 1))                # a buffer outside the flat parameter storage: rank 0's after construction
+    opts = optim.build_flat_optimizers({"avatar": optim.AdamSpec([dict(params=[scene.a], lr=1e-2)], eps=1e-15),
+                                        "nerf": optim.AdamSpec([dict(params=[scene.b], lr=1e-3)], betas=(0.9, 0.99), eps=1e-15),
+                                        "idle": optim.AdamSpec([dict(params=[scene.c], lr=1e-1)], eps=1e-15)}, torch.device("cpu"))
+    if rank == 1:                                          # a rank whose optimizer scalars differ (e.g. it alone resumed a checkpoint) ...
+        opts["nerf"].param_groups[0]["t"] = 5; opts["nerf"].t = 5; opts["nerf"].param_groups[0]["lr"] = 7e-3
+    w = torch.randn(1, 4, 4, 3, generator=torch.Generator().manual_seed(9))
+    tr = trainer.SDSTrainer(cfg, scene, sds_step._ImageLoss(w), opts, {}, use_controlnet=False, dist=dist, world=world, max_step=100)
+    synced = (float(scene.marker[0]), opts["nerf"].param_groups[0].get("t", 0), opts["nerf"].param_groups[0]["lr"])   # ... takes rank 0's
+    tr.set_views(2)
+    c0 = scene.c.detach().clone()
+    for step in range(3):
+        views = _toy_views([rank], step)
+        views[0]["use_b"] = (rank == 0)                    # only rank 0's view reaches `b`; nobody reaches `c`
+        tr.train_step(views)
+    buf = opts.buffers
+    q.put((rank, buf.flat.numpy().copy(), buf.m.numpy().copy(), [pg.get("t", 0) for o in opts.values() for pg in o.param_groups],
+           bool(torch.equal(scene.c.detach(), c0)), synced, tr.allreduce_steps >= 0))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_sliced_reduce_agrees_on_participation_across_ranks_and_syncs_optimizer_scalars():
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_participation_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = sorted([q.get(timeout=300) for _ in range(2)], key=lambda t: t[0])
+    for p in procs:
+        p.join(timeout=120)
+        assert p.exitcode == 0
+    (r0, f0, m0, t0, c_same0, s0, _), (r1, f1, m1, t1, c_same1, s1, _) = res
+    assert (f0 == f1).all() and (m0 == m1).all()          # replicas bit-identical: parameters AND first moments
+    assert t0 == t1 == [3, 3, 0]                          # `b` (reached by rank 0 only) stepped on both ranks, `c` (reached by nobody) on neither
+    assert c_same0 and c_same1
+    assert s0 == s1 == (1.0, 0, 1e-3)                     # construction: rank 0's buffer, step count and learning rate everywhere

@@ -68,7 +68,7 @@ def test_sds_call_matches_oracle():
     csd = sd15.random_state_dict(sd15.controlnet_param_shapes(ucfg), seed=2)
     vsd = sd15.random_state_dict(sd15.vae_encoder_param_shapes(vcfg), seed=3)
     dev = torch.device("cuda")
-    gd = guidance.ControlNetScoreDistillation(dev, ucfg, vcfg, usd, csd, vsd, image_hw=128)
+    gd = guidance.ControlNetScoreDistillation(dev, ucfg, vcfg, usd, csd, vsd, image_hw=128, dtype="bf16")
     g = torch.Generator().manual_seed(7)
     img = torch.rand(1, 3, 128, 128, generator=g)
     text = torch.randn(2, 77, ucfg.cross_dim, generator=g)
@@ -97,7 +97,7 @@ def test_graph_replay_matches_eager():
     from dreamwaltz_g_amd import guidance, sd15
     ucfg, vcfg = _small()
     dev = torch.device("cuda")
-    gd = guidance.ControlNetScoreDistillation(dev, ucfg, vcfg, image_hw=128, seed=4)
+    gd = guidance.ControlNetScoreDistillation(dev, ucfg, vcfg, image_hw=128, seed=4, dtype="bf16")
     g = torch.Generator().manual_seed(11)
     img = torch.rand(1, 3, 128, 128, generator=g).cuda()
     text = {"neg": torch.randn(1, 77, ucfg.cross_dim, generator=g).cuda(), "text": torch.randn(1, 77, ucfg.cross_dim, generator=g).cuda()}
