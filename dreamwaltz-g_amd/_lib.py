@@ -21,7 +21,7 @@ class RasterSettingsC(ctypes.Structure):
         ("sh_degree", ctypes.c_int32), ("sh_coeffs", ctypes.c_int32),
         ("prefiltered", ctypes.c_int32), ("debug", ctypes.c_int32),
         ("bg", ctypes.c_void_p), ("viewmatrix", ctypes.c_void_p), ("projmatrix", ctypes.c_void_p),
-        ("campos", ctypes.c_void_p), ("visit_order", ctypes.c_void_p),
+        ("campos", ctypes.c_void_p), ("visit_order", ctypes.c_void_p), ("tanfov", ctypes.c_void_p),
     ]
 
 
@@ -38,6 +38,7 @@ SIGNATURES = {
                                                   ctypes.POINTER(_sz)]),
     "dwg_raster_num_pairs_ptr": (_vp, [_vp]),
     "dwg_raster_camera_setup": (ctypes.c_int, [_vp, _vp, _vp, _vp, _vp]),
+    "dwg_raster_camera_block": (ctypes.c_int, [_vp, _vp, _vp, _vp, _vp, _vp, _vp]),
     "dwg_raster_forward_bin": (ctypes.c_int, [ctypes.POINTER(RasterSettingsC), _i32] + [_vp] * 9 + [_vp]),
     "dwg_raster_forward_render": (ctypes.c_int, [ctypes.POINTER(RasterSettingsC), _i32, _vp, _vp, _i64, _vp, _vp, _vp,
                                                  _vp, _vp]),

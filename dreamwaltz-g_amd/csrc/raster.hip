@@ -63,6 +63,7 @@ struct Params {
     const float* proj;
     const float* campos;
     const int32_t* visit_order;         // permutation in which the binning stages walk the Gaussians (NULL: index order)
+    const float* tanfov_dev;            // [tanfovx, tanfovy] in device memory (per frame at cam_stride) or NULL: the scalars above
     int stiles_x, stiles_y;             // supertiles (ST x ST blocks)
     // frames (blockIdx.y of the forward kernels): distance between consecutive frames'
     int64_t in_stride;                  // ... per-Gaussian input rows, in Gaussians (0: every frame reads the same rows)
@@ -183,6 +184,15 @@ __device__ __forceinline__ void cov3d_of(const float* scales, const float* rots,
     c6[3] = M[3] * M[3] + M[4] * M[4] + M[5] * M[5];
     c6[4] = M[3] * M[6] + M[4] * M[7] + M[5] * M[8];
     c6[5] = M[6] * M[6] + M[7] * M[7] + M[8] * M[8];
+}
+
+// The field of view of a camera that lives in device memory (dwg_raster_settings::tanfov): the launch's kernel arguments stay the same
+// from frame to frame -- what a captured step that samples a new camera every step needs -- and the focal lengths follow.
+__device__ __forceinline__ void camera_scalars(Params& p, size_t cam_offset) {
+    if (p.tanfov_dev) {
+        p.tanfovx = p.tanfov_dev[cam_offset]; p.tanfovy = p.tanfov_dev[cam_offset + 1];
+        p.focal_x = p.W / (2.f * p.tanfovx); p.focal_y = p.H / (2.f * p.tanfovy);
+    }
 }
 
 // EWA projection pieces shared by forward and backward
@@ -383,6 +393,7 @@ __global__ __launch_bounds__(PB) void k_preprocess(Params p, const float* __rest
     DWG_GEOM(rec0); DWG_GEOM(rec1); DWG_GEOM(rec2); DWG_GEOM(rect); DWG_GEOM(npairs); DWG_GEOM(idsum); DWG_GEOM(super_count); DWG_GEOM(kref_part);
     const size_t go = (size_t)blockIdx.y * (size_t)p.in_stride;            // this frame's first input row
     const size_t co = (size_t)blockIdx.y * (size_t)p.cam_stride;
+    camera_scalars(p, co);
     radii += (size_t)blockIdx.y * p.G;
     if (threadIdx.x < 16) cam[threadIdx.x] = p.view[co + threadIdx.x];
     else if (threadIdx.x < 32) cam[threadIdx.x] = p.proj[co + threadIdx.x - 16];
@@ -1307,6 +1318,7 @@ __global__ __launch_bounds__(256) void k_preprocess_bwd(Params p, const float* _
     __shared__ float cam[32];
     if (threadIdx.x < 16) cam[threadIdx.x] = p.view[threadIdx.x];
     else if (threadIdx.x < 32) cam[threadIdx.x] = p.proj[threadIdx.x - 16];
+    camera_scalars(p, 0);
     __syncthreads();
     int i = blockIdx.x * 256 + threadIdx.x;
     if (i >= p.G) return;
@@ -1477,6 +1489,25 @@ __global__ void k_camera_setup(const float* __restrict__ extrinsic, const float*
     }
 }
 
+// the same three products plus the field of view: out37 = [viewmatrix 16 | projmatrix 16 | campos 3 | tanfovx | tanfovy]
+__global__ void k_camera_block(const float* __restrict__ extrinsic, const float* __restrict__ projection, const float* __restrict__ c2w,
+                               const float* __restrict__ tanfovy, const float* __restrict__ tanfovx, float* __restrict__ out) {
+    const int t = threadIdx.x;
+    if (t < 16) {
+        const int r = t >> 2, c = t & 3;
+        out[t] = extrinsic[4 * c + r];
+        float v = 0.f;
+#pragma unroll
+        for (int k = 0; k < 4; k++) v += extrinsic[4 * k + r] * projection[4 * c + k];
+        out[16 + t] = v;
+    } else if (t < 19) {
+        out[32 + (t - 16)] = c2w[4 * (t - 16) + 3];
+    } else if (t == 19) {
+        out[35] = tanfovx ? tanfovx[0] : tanfovy[0];
+        out[36] = tanfovy[0];
+    }
+}
+
 static int make_params(const dwg_raster_settings* cfg, const dwg_raster_frames* fr, int G, Params* p) {
     if (!cfg || G < 0 || cfg->image_height <= 0 || cfg->image_width <= 0) return DWG_E_ARG;
     if (!cfg->bg || !cfg->viewmatrix || !cfg->projmatrix) return DWG_E_ARG;
@@ -1486,7 +1517,8 @@ static int make_params(const dwg_raster_settings* cfg, const dwg_raster_frames* 
     p->rtiles_x = dwg_cdiv(p->W, RT); p->rtiles_y = dwg_cdiv(p->H, RT);
     p->stiles_x = dwg_cdiv(p->tiles_x, ST); p->stiles_y = dwg_cdiv(p->tiles_y, ST);
     if (p->rtiles_x > 0x7fff || p->rtiles_y > 0x7fff) return DWG_E_ARG;
-    p->tanfovx = cfg->tanfovx; p->tanfovy = cfg->tanfovy;
+    if (!(cfg->tanfovx > 0.f) || !(cfg->tanfovy > 0.f)) return DWG_E_ARG;
+    p->tanfovx = cfg->tanfovx; p->tanfovy = cfg->tanfovy; p->tanfov_dev = cfg->tanfov;
     p->focal_x = p->W / (2.f * cfg->tanfovx); p->focal_y = p->H / (2.f * cfg->tanfovy);
     p->scale_mod = cfg->scale_modifier;
     p->sh_degree = cfg->sh_degree; p->sh_coeffs = cfg->sh_coeffs;
@@ -1532,6 +1564,14 @@ const int32_t* dwg_raster_num_pairs_ptr(const void* ws_geom) { return reinterpre
 int dwg_raster_camera_setup(const float* extrinsic, const float* projection, const float* c2w, float* out35, dwg_stream_t stream_) {
     if (!extrinsic || !projection || !c2w || !out35) return DWG_E_ARG;
     DWG_LAUNCH("raster_camera_setup", k_camera_setup, dim3(1), dim3(64), 0, (hipStream_t)stream_, extrinsic, projection, c2w, out35);
+    DWG_RETURN_IF_LAUNCH_FAILED();
+    return DWG_OK;
+}
+
+int dwg_raster_camera_block(const float* extrinsic, const float* projection, const float* c2w, const float* tanfovy, const float* tanfovx,
+                            float* out37, dwg_stream_t stream_) {
+    if (!extrinsic || !projection || !c2w || !tanfovy || !out37) return DWG_E_ARG;
+    DWG_LAUNCH("raster_camera_setup", k_camera_block, dim3(1), dim3(64), 0, (hipStream_t)stream_, extrinsic, projection, c2w, tanfovy, tanfovx, out37);
     DWG_RETURN_IF_LAUNCH_FAILED();
     return DWG_OK;
 }

@@ -29,6 +29,8 @@ class GaussianRasterizationSettings(NamedTuple):
     campos: torch.Tensor
     prefiltered: bool
     debug: bool
+    tanfov_dev: Optional[torch.Tensor] = None      # device float32 [2] = {tanfovx, tanfovy}: read by the kernels INSTEAD of the two scalars (a camera
+                                                   # that lives in device memory: include/dwg_raster.h dwg_raster_settings::tanfov)
 
 
 class PairCapacity:
@@ -97,6 +99,12 @@ def _settings_struct(rs: GaussianRasterizationSettings, device, sh_coeffs: int, 
     c.prefiltered = int(bool(rs.prefiltered)); c.debug = int(bool(rs.debug))
     c.bg = dev(rs.bg); c.viewmatrix = dev(rs.viewmatrix); c.projmatrix = dev(rs.projmatrix)
     c.campos = dev(rs.campos)
+    tfd = getattr(rs, "tanfov_dev", None)
+    if tfd is not None:
+        if not (tfd.is_cuda and tfd.dtype == torch.float32 and tfd.numel() >= 2 and tfd.is_contiguous()):
+            raise ValueError("tanfov_dev: a contiguous float32 CUDA tensor {tanfovx, tanfovy}")
+        keep.append(tfd)
+        c.tanfov = tfd.data_ptr()
     return c
 
 

@@ -108,7 +108,21 @@ class GaussianRenderer:
         tanfovy = data['tanfov'][0].item()
         tanfovx = data['tanfov_x'][0].item() if 'tanfov_x' in data else tanfovy
         device = world_view_matrix.device
-        if device.type == 'cuda':
+        tanfov_dev = None
+        if device.type == 'cuda' and data.get('tanfov_dev') is not None:
+            # A camera that lives in DEVICE memory (data['tanfov_dev'] = {tanfovx, tanfovy} next to the matrices): the field of view reaches
+            # the kernels through a pointer, not through kernel arguments -- a step captured into a graph follows whatever camera its static
+            # tensors hold at replay time (step_graph.GraphedTrainStep.step(pose, camera)); the two host scalars above are then only the
+            # settings object's record of the camera it was built with.
+            out = torch.empty(37, device=device, dtype=torch.float32)
+            tf = data['tanfov_dev']
+            p = _lib.ptr
+            _lib.check(_lib.lib().dwg_raster_camera_block(p(world_view_matrix.float().contiguous()), p(projection_matrix.float().contiguous()),
+                                                          p(data['c2w'][0].float().contiguous()), ctypes.c_void_p(tf.data_ptr() + 4), p(tf), p(out),
+                                                          ctypes.c_void_p(torch.cuda.current_stream(device).cuda_stream)),
+                       "dwg_raster_camera_block")
+            viewmatrix, projmatrix, campos, tanfov_dev = out[:16].view(4, 4), out[16:32].view(4, 4), out[32:35], out[35:37]
+        elif device.type == 'cuda':
             out = torch.empty(35, device=device, dtype=torch.float32)
             p = _lib.ptr
             _lib.check(_lib.lib().dwg_raster_camera_setup(p(world_view_matrix.float().contiguous()), p(projection_matrix.float().contiguous()),
@@ -125,7 +139,7 @@ class GaussianRenderer:
         raster_settings = {
             "image_height": image_height, "image_width": image_width, "tanfovx": tanfovx, "tanfovy": tanfovy,
             "bg": self._bg_dev[device], "viewmatrix": viewmatrix, "projmatrix": projmatrix, "sh_degree": self.sh_levels - 1,
-            "campos": campos,
+            "campos": campos, "tanfov_dev": tanfov_dev,
         }
         raster_settings.update(kwargs)
         for key, value in raster_settings.items():

@@ -104,6 +104,9 @@ class SDSStep:
                                      dist=dist, world=world, max_step=iters, densifiers=densifiers)
         self.trainer.set_views(self.views)
         self.step_idx = 0
+        # optional: step index -> the loader's camera dict of that step (camera.make_camera(..., device="cpu")) -- the reference samples a new
+        # camera every step (data/camera/__init__.py:124-165); None: the fixed camera of the benchmark configurations
+        self.camera_fn = None
 
     # kept names (bench.py / tools)
     @property
@@ -153,8 +156,32 @@ class SDSStep:
             joints = (A[:, :3, :3] * J[:, None, :]).sum(-1) + A[:, :3, 3]         # A carries the global translation (no library GEMM for 55 3x3 products)
             keypoints = torch.cat([joints, verts[c["pick"]]], dim=0)
             scene = cd_build(verts, c["triangles"])
-            return c["gen"].export_pose_chw(keypoints, scene, extrinsic=data["extrinsic"][0], intrinsics=c["intrinsics"],
-                                            width=c["hw"], height=c["hw"])
+            intr = data["cond_intrinsics"] if data.get("cond_intrinsics") is not None else c["intrinsics"]      # a moving camera brings its own
+            return c["gen"].export_pose_chw(keypoints, scene, extrinsic=data["extrinsic"][0], intrinsics=intr, width=c["hw"], height=c["hw"])
+
+    def camera_tensors(self, cam: dict) -> dict:
+        """What a step needs of the loader's camera dict `cam` (host tensors, camera.make_camera): the three matrices, the field of view as
+        {tanfovx, tanfovy} for the device-resident camera of a captured step, the condition image's pinhole intrinsics, and the two host
+        scalars of the learning-rate schedule's spatial scale."""
+        tfy = float(cam["tanfov"][0]); tfx = float(cam["tanfov_x"][0]) if "tanfov_x" in cam else tfy
+        out = {"extrinsic": cam["extrinsic"].float(), "projection": cam["projection"].float(), "c2w": cam["c2w"].float(),
+               "tanfov_dev": torch.tensor([tfx, tfy]), "radius": cam["radius"], "tanfov": cam["tanfov"]}
+        if getattr(self, "condition", None) is not None:
+            hw = self.condition["hw"]
+            f = hw / (2.0 * tfy)
+            out["cond_intrinsics"] = torch.tensor([[f, 0.0, hw / 2.0], [0.0, f, hw / 2.0], [0.0, 0.0, 1.0]])
+        return out
+
+    def _apply_camera(self, d: dict, cam: dict):
+        """The eager step's per-step camera: the loader's dict entries replaced in the view's data (host scalars stay on the host, as the
+        reference reads them with .item(): gaussian_renderer.py:28, trainer.py:713)."""
+        ct = self.camera_tensors(cam)
+        for k in ("extrinsic", "projection", "c2w"):
+            d[k] = ct[k].to(self.device)
+        for k in ("tanfov", "radius", "azimuth", "elevation"):
+            d[k] = cam[k]
+        if "cond_intrinsics" in ct:
+            d["cond_intrinsics"] = ct["cond_intrinsics"].to(self.device)
 
     def _upload_pose(self, cpu_inputs):
         """The per-step host input (the 165-float pose) goes up through pinned staging buffers with an asynchronous copy: a plain
@@ -179,6 +206,8 @@ class SDSStep:
         for v in self.my_views:
             d = self.view_data[v]
             d["smpl_inputs"] = self._upload_pose(synth.random_smpl_inputs(seed=1000 * v + self.step_idx, device="cpu"))
+            if self.camera_fn is not None:
+                self._apply_camera(d, self.camera_fn(self.step_idx))
             if self.guidance is not None:
                 d["rng_seed"] = (1234 + v) * 1000003 + self.step_idx      # the view's own device-RNG stream (Q12 draw order inside it)
             if getattr(self, "condition", None) is not None:
@@ -199,13 +228,19 @@ class SDSStep:
         poses = [{k: t.to(self.device) for k, t in synth.random_smpl_inputs(seed=1000 * v + self.step_idx + i, device="cpu").items()}
                  for i in range(warmup + 1)]
         data = {k: t for k, t in d.items() if k != "smpl_inputs"}
-        cond_fn = (lambda pose: self.condition_image(pose, d)) if getattr(self, "condition", None) is not None else None
+        cond_fn = (lambda pose, data=None: self.condition_image(pose, d if data is None else data)) if getattr(self, "condition", None) is not None else None
         # the view's device-RNG stream of step k (0-based) is seeded as run() seeds it: the trainer's index is k + 1 when the draws are made
         seed_fn = (lambda idx: (1234 + v) * 1000003 + (idx - 1)) if self.guidance is not None else None
         if self.guidance is not None and cond_fn is None:
             data["cond_images"] = d["cond_images"]
+        cam_kw, cams = {}, None
+        if self.camera_fn is not None:
+            # a camera per step, in device memory: the captured step follows it (step_graph.GraphedTrainStep.step(pose, camera))
+            cams = [self.camera_tensors(self.camera_fn(self.step_idx + i)) for i in range(warmup + 1)]
+            dev = lambda c: {k: (t.to(self.device) if k in step_graph.GraphedTrainStep.CAMERA_KEYS else t) for k, t in c.items()}   # noqa: E731
+            cam_kw = dict(example_camera=dev(cams[0]), warmup_cameras=[dev(c) for c in cams[:warmup]], capture_camera=dev(cams[warmup]))
         g = step_graph.GraphedTrainStep(self.trainer, data, poses[0], warmup_poses=poses[:warmup], capture_pose=poses[warmup],
-                                        condition_fn=cond_fn, seed_fn=seed_fn)
+                                        condition_fn=cond_fn, seed_fn=seed_fn, **cam_kw)
         self.step_idx += warmup + 1          # the warm-up steps and the capture's eager step were real optimizer steps
         step = self
 
@@ -213,7 +248,8 @@ class SDSStep:
             graph = g
 
             def step(self_inner):
-                out = g.step(synth.random_smpl_inputs(seed=1000 * v + step.step_idx, device="cpu"))
+                cam = step.camera_tensors(step.camera_fn(step.step_idx)) if step.camera_fn is not None else None
+                out = g.step(synth.random_smpl_inputs(seed=1000 * v + step.step_idx, device="cpu"), cam)
                 step.step_idx += 1
                 return out
         return _Runner()

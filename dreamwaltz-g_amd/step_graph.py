@@ -9,12 +9,15 @@ Why: the c2 step is ~0.9 ms of kernels and its ~250 launches + autograd bookkeep
 (DESIGN.md, round-3 verdict).  A replay costs one copy of the pose into static buffers, one 16-byte-per-group copy of the optimizer scalars
 and one graph launch.
 
-What is static in the graph: the camera, the Gaussian count, the rasterizer's pair capacity (frozen at `grow` x the largest count of the
+What is static in the graph: the Gaussian count, the rasterizer's pair capacity (frozen at `grow` x the largest count of the
 warm-up steps, as player.GraphedAnimation does; a step that needs more pairs is TRUNCATED by the kernels and flags it -- `check()` reports
 it, `recapture()` grows the capacity), the binning order of the rasterizer (results do not depend on it).  What moves per replay without
-being captured: the pose (static device buffers, refreshed by an asynchronous copy before the launch) and the optimizers' per-step scalars
+being captured: the pose (static device buffers, refreshed by an asynchronous copy before the launch), the optimizers' per-step scalars
 (learning-rate schedule, bias corrections: `FlatOptimizer.prepare_step` writes them to a pinned table, one copy puts them where
-`dwg_adam_step_dev` reads them).  The densifier and multi-view / multi-rank steps are not captured (they change shapes / need the host).
+`dwg_adam_step_dev` reads them) and -- round 5, `example_camera` -- the CAMERA: the reference samples a new one every step
+(/root/reference/data/camera/__init__.py:124-165, core/trainer.py:840-860), so extrinsic / projection / c2w and the field of view live in the
+same device block as the pose (the rasterizer reads the field of view through a pointer: dwg_raster_settings::tanfov) and `step(pose,
+camera)` refreshes them with the pose's copy.  Without `example_camera` the camera is the fixed one of the benchmark configurations.  The densifier and multi-view / multi-rank steps are not captured (they change shapes / need the host).
 """
 from typing import Dict
 
@@ -24,15 +27,20 @@ from .rasterizer import PairCapacity
 
 
 class GraphedTrainStep:
+    CAMERA_KEYS = ("extrinsic", "projection", "c2w", "tanfov_dev", "cond_intrinsics")
+
     def __init__(self, trainer, data: dict, example_pose: Dict[str, torch.Tensor], warmup_poses=None, grow: float = 4.0, capture_pose=None,
-                 condition_fn=None, seed_fn=None):
+                 condition_fn=None, seed_fn=None, example_camera: Dict[str, torch.Tensor] = None, warmup_cameras=None, capture_camera=None):
         """`trainer`: an SDSTrainer whose `diffusion` makes no host round trips inside a call -- the no-guidance image loss of c2, or a
         ControlNetScoreDistillation (recognised by `draw_view_randoms`: its random draws are made here, outside the graph); `data`: the
         loader's dict of the (fixed) camera WITHOUT 'smpl_inputs'; `example_pose`: device tensors (float32), copied into the graph's static
         pose buffers.  `condition_fn(pose) -> [1,3,H,W]`: the loader's condition image of the posed body, drawn inside the graph;
         `seed_fn(step index) -> int`: the seed of the step's device-RNG stream (guidance only; None: the generator just runs on).  Building
         it takes REAL optimizer steps: one per warm-up pose, and one more -- on `capture_pose` (default: the last warm-up pose again) -- at
-        the frozen pair capacity right before the capture."""
+        the frozen pair capacity right before the capture.  `example_camera`: float32 tensors for (a subset of) CAMERA_KEYS, shaped like the
+        loader's -- extrinsic / projection / c2w [1,4,4], tanfov_dev [2] = {tanfovx, tanfovy}, cond_intrinsics [3,3] -- plus optional host
+        scalars 'radius' / 'tanfov' (the learning-rate schedule's spatial scale, trainer.py:713): the captured step then renders whatever
+        camera `step(pose, camera)` was given (`warmup_cameras` / `capture_camera` pair with the warm-up / capture poses)."""
         self.trainer, self.grow = trainer, float(grow)
         self.device = next(iter(example_pose.values())).device
         if self.device.type != "cuda":
@@ -52,6 +60,13 @@ class GraphedTrainStep:
         for k, v in example_pose.items():
             offs[k] = o
             o += (v.numel() + 3) // 4 * 4
+        cam = {k: v for k, v in (example_camera or {}).items() if k in self.CAMERA_KEYS}
+        if any(v.dtype != torch.float32 for v in cam.values()):
+            raise TypeError("GraphedTrainStep: camera tensors must be float32")
+        coffs = {}
+        for k, v in cam.items():
+            coffs[k] = o
+            o += (v.numel() + 3) // 4 * 4
         self._block_floats = o
         self._block_dev = torch.zeros(o, device=self.device)
         self.hyper_dev = self._block_dev[:self._rows * 4].view(self._rows, 4)
@@ -59,6 +74,12 @@ class GraphedTrainStep:
         for k, v in example_pose.items():
             self.pose[k].copy_(v)
         self.data = dict(data); self.data["smpl_inputs"] = self.pose
+        # the camera's tensors, when it moves: views of the same block, put where the renderer / the condition image read them
+        self.camera = {k: self._block_dev[coffs[k]:coffs[k] + v.numel()].view(v.shape) for k, v in cam.items()}
+        for k, v in cam.items():
+            self.camera[k].copy_(v)
+            self.data[k] = self.camera[k]
+        self._cam_pinned = None
         self.condition_fn, self.seed_fn = condition_fn, seed_fn
         self.guided = hasattr(trainer.diffusion, "draw_view_randoms")
         self._rng, self._rand = None, None
@@ -71,6 +92,10 @@ class GraphedTrainStep:
         # finished (nothing else throttles the host here: the eager loop is paced by the rasterizer's pair-count event, a replay is not)
         self._slots = [torch.zeros(self._block_floats).pin_memory() for _ in range(4)]
         self._pinned = [{k: b[offs[k]:offs[k] + v.numel()].view(v.shape) for k, v in example_pose.items()} for b in self._slots]
+        self._cam_pinned = [{k: b[coffs[k]:coffs[k] + v.numel()].view(v.shape) for k, v in cam.items()} for b in self._slots]
+        for b in self._cam_pinned:
+            for k, v in cam.items():
+                b[k].copy_(v)
         self._hyper_slots = [b[:self._rows * 4].view(self._rows, 4) for b in self._slots]
         self._slot = 0
         self._slot_events = [None] * 4
@@ -85,8 +110,11 @@ class GraphedTrainStep:
         most = 0
         with torch.cuda.stream(self._side):
             shared = renderer.pair_state(self.device, H, W)
-            for pose in (list(warmup_poses) if warmup_poses is not None else [example_pose] * 3):
+            wposes = list(warmup_poses) if warmup_poses is not None else [example_pose] * 3
+            wcams = list(warmup_cameras) if warmup_cameras is not None else [None] * len(wposes)
+            for pose, wcam in zip(wposes, wcams):
                 self._set_pose_now(pose)
+                self._set_camera_now(wcam)
                 self._eager_step()
                 shared.resolve()
                 most = max(most, shared.last_num_pairs)
@@ -98,12 +126,27 @@ class GraphedTrainStep:
         if capture_pose is not None:
             with torch.cuda.stream(self._side):
                 self._set_pose_now(capture_pose)
+        if capture_camera is not None:
+            with torch.cuda.stream(self._side):
+                self._set_camera_now(capture_camera)
         self._capture()
 
     # -- pieces ------------------------------------------------------------------------------------------------------------
     def _set_pose_now(self, pose):
         for k, v in pose.items():
             self.pose[k].copy_(v, non_blocking=True)
+
+    def _camera_scale(self, camera):
+        """The learning-rate schedule's spatial scale of this step's camera (trainer.get_spatial_scale: radius x tanfov, host scalars)."""
+        if camera is not None and self.trainer.cfg.render.spatial_scale is None and "radius" in camera and "tanfov" in camera:
+            self._spatial_scale = float(camera["radius"].reshape(-1)[0]) * float(camera["tanfov"].reshape(-1)[0])
+
+    def _set_camera_now(self, camera):
+        if camera is None:
+            return
+        for k in self.camera:
+            self.camera[k].copy_(camera[k].to(self.device, non_blocking=True).reshape(self.camera[k].shape))
+        self._camera_scale(camera)
 
     def _host_prepare(self):
         """What the eager trainer does on the host around a step (trainer.py:861-870, 888-890): step index, learning-rate schedule, the
@@ -136,7 +179,8 @@ class GraphedTrainStep:
         if self.guided:
             forced = dict(posterior_noise=self._rand[0], timestep=self._rand[1], noise=self._rand[2])
             if self.condition_fn is not None:
-                self.data["cond_images"] = self.condition_fn(self.pose)
+                # (a moving camera: the condition image is drawn from the graph's own camera tensors)
+                self.data["cond_images"] = self.condition_fn(self.pose, self.data) if self.camera else self.condition_fn(self.pose)
         loss, render_outputs, _, _ = tr.train_forward(self.data, **forced)
         loss.backward()
         base = 0
@@ -183,12 +227,23 @@ class GraphedTrainStep:
                 m._last_forward = None
 
     # -- per step ------------------------------------------------------------------------------------------------------------
-    def step(self, pose_cpu: Dict[str, torch.Tensor]):
-        """One optimizer step for `pose_cpu` (host tensors): returns (loss, render outputs) -- static tensors, overwritten by the next step."""
+    def step(self, pose_cpu: Dict[str, torch.Tensor], camera_cpu: Dict[str, torch.Tensor] = None):
+        """One optimizer step for `pose_cpu` (host tensors) [seen by `camera_cpu`: host tensors for the keys of `example_camera`]: returns
+        (loss, render outputs) -- static tensors, overwritten by the next step."""
         i = self._slot; self._slot = (self._slot + 1) % len(self._pinned)
         if self._slot_events[i] is not None:
             self._slot_events[i].synchronize()                  # the replay that read this slot four steps ago is done
         self.hyper_host = self._hyper_slots[i]
+        if camera_cpu is not None:
+            if not self.camera:
+                raise ValueError("GraphedTrainStep.step: this step was captured with a fixed camera (no example_camera)")
+            self._camera_scale(camera_cpu)                      # before the optimizers' scalars are prepared: the schedule reads it
+            for k, dst in self._cam_pinned[i].items():
+                dst.copy_(camera_cpu[k].reshape(dst.shape))
+        elif self.camera:                                       # the camera of the previous step stays: carry it into this slot
+            prev = self._cam_pinned[(i - 1) % len(self._cam_pinned)]
+            for k, dst in self._cam_pinned[i].items():
+                dst.copy_(prev[k])
         self._host_prepare()
         self._draw()
         slot = self._pinned[i]

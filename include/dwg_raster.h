@@ -48,6 +48,11 @@ typedef struct dwg_raster_settings {
                                  * Since round 5 the binning granule is the 32x32-pixel supertile, whose workgroup-private
                                  * histograms merge their global atomics in index order as well: NULL (index order, coalesced
                                  * reads of the five input arrays) is the default; a spatially coherent order is still honoured. */
+    const float* tanfov;        /* [2] device or NULL: {tanfovx, tanfovy} read by the kernels INSTEAD of the two host scalars above (which
+                                 * must still be positive).  With it -- and viewmatrix / projmatrix / campos being device pointers anyway --
+                                 * nothing about the camera is a kernel argument: a step captured into a graph follows a camera that is
+                                 * re-sampled every step (/root/reference/data/camera/__init__.py:124-165) by refreshing the device block.
+                                 * Per frame at camera_stride like the matrices (dwg_raster_frames). */
 } dwg_raster_settings;
 
 /* Several frames per launch chain (round 5): frame f reads per-Gaussian input row g at [f * gaussian_stride + g] of every input array
@@ -84,6 +89,12 @@ const int32_t* dwg_raster_num_pairs_ptr(const void* ws_geom);
  * out35 = [viewmatrix 16 | projmatrix 16 | campos 3].  All pointers device, row-major 4x4. */
 int dwg_raster_camera_setup(const float* extrinsic, const float* projection, const float* c2w, float* out35,
                             dwg_stream_t stream);
+
+/* dwg_raster_camera_setup plus the field of view, all in device memory: out37 = [viewmatrix 16 | projmatrix 16 | campos 3 | tanfovx |
+ * tanfovy] from device extrinsic / projection / c2w [4,4] and device tanfovy [1] (+ tanfovx [1] or NULL: = tanfovy, the square image of
+ * gaussian_renderer.py:28-29).  out37 + 35 is what dwg_raster_settings::tanfov points at. */
+int dwg_raster_camera_block(const float* extrinsic, const float* projection, const float* c2w, const float* tanfovy,
+                            const float* tanfovx, float* out37, dwg_stream_t stream);
 
 /* Stage A: project, build splat records, count the exact-culled (Gaussian, 8x8 block) pairs per Gaussian and the Gaussians per 32x32
  * supertile, scan. */
