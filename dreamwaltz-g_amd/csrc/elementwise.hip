@@ -628,6 +628,39 @@ __global__ __launch_bounds__(256) void k_x_unpack(long long n8, const dwg_xs* __
         reinterpret_cast<float4*>(dst)[2 * i + 1] = make_float4(x.get(4), x.get(5), x.get(6), x.get(7));
     }
 }
+// Range telemetry of a stored f32x tensor (round 5): the format saturates at +-65504 instead of overflowing (dwg_x_split) and loses significand
+// bits once the hi half goes subnormal (|x| < 6.1e-5) -- silently, in the hot path.  This scan is the cold-path witness: it walks a tensor the
+// plan has written and counts  [0] hi halves AT +-65504 (a saturated value, or a legitimate one on the edge: equally worth a warning),
+// [1] non-zero values whose hi half is subnormal or zero, [2] non-finite hi halves, [3] max |x| (fp32 bits), [4] elements seen.
+__global__ __launch_bounds__(256) void k_x_range_scan(long long n8, const dwg_xs* __restrict__ src, unsigned long long* __restrict__ out) {
+    unsigned long long sat = 0, sub = 0, bad = 0;
+    float amax = 0.f;
+    for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < n8; i += (long long)gridDim.x * 256) {
+        const dwg_x8 x = dwg_x8::load(src + 8 * i);
+#pragma unroll
+        for (int e = 0; e < 8; e++) {
+            const unsigned short hb = __builtin_bit_cast(unsigned short, x.hi[e]), lb = __builtin_bit_cast(unsigned short, x.lo[e]);
+            const unsigned ex = (hb >> 10) & 0x1fu, man = hb & 0x3ffu;
+            if (ex == 0x1fu) { bad++; continue; }
+            if ((hb & 0x7fffu) == 0x7bffu) sat++;
+            if (ex == 0u && (man != 0u || (lb & 0x7fffu) != 0u)) sub++;
+            amax = fmaxf(amax, fabsf(x.get(e)));
+        }
+    }
+    // wave reduction, then one atomic per wave and counter (cold path)
+#pragma unroll
+    for (int off = 32; off >= 1; off >>= 1) {
+        sat += __shfl_xor((unsigned long long)sat, off); sub += __shfl_xor((unsigned long long)sub, off); bad += __shfl_xor((unsigned long long)bad, off);
+        amax = fmaxf(amax, __shfl_xor(amax, off));
+    }
+    if ((threadIdx.x & 63) == 0) {
+        if (sat) atomicAdd(&out[0], sat);
+        if (sub) atomicAdd(&out[1], sub);
+        if (bad) atomicAdd(&out[2], bad);
+        atomicMax(&out[3], (unsigned long long)__float_as_uint(amax));
+    }
+    if (blockIdx.x == 0 && threadIdx.x == 0) atomicAdd(&out[4], (unsigned long long)n8 * 8ull);
+}
 __global__ __launch_bounds__(256) void k_add_x(long long n8, const dwg_xs* __restrict__ a, const dwg_xs* __restrict__ b, dwg_xs* __restrict__ out) {
     for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < n8; i += (long long)gridDim.x * 256) {
         const dwg_x8 x = dwg_x8::load(a + 8 * i), y = dwg_x8::load(b + 8 * i);
@@ -957,6 +990,15 @@ int dwg_xfmt_unpack(int64_t n, const void* src, float* dst, dwg_stream_t stream)
     if (n < 0 || n % 8 || !src || !dst || ((uintptr_t)src | (uintptr_t)dst) % 16) return DWG_E_ARG;
     if (n == 0) return DWG_OK;
     DWG_LAUNCH("xfmt_unpack", k_x_unpack, dim3(grid_for(n / 8)), dim3(256), 0, (hipStream_t)stream, (long long)(n / 8), (const dwg_xs*)src, dst);
+    DWG_RETURN_IF_LAUNCH_FAILED();
+    return DWG_OK;
+}
+
+int dwg_xfmt_range_scan(int64_t n, const void* src, uint64_t* counters5, dwg_stream_t stream) {
+    if (n < 0 || n % 8 || !src || !counters5 || ((uintptr_t)src % 16) || ((uintptr_t)counters5 % 8)) return DWG_E_ARG;
+    if (n == 0) return DWG_OK;
+    DWG_LAUNCH("xfmt_range_scan", k_x_range_scan, dim3(grid_for(n / 8)), dim3(256), 0, (hipStream_t)stream, (long long)(n / 8), (const dwg_xs*)src,
+               (unsigned long long*)counters5);
     DWG_RETURN_IF_LAUNCH_FAILED();
     return DWG_OK;
 }

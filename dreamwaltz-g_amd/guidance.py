@@ -166,6 +166,25 @@ class ControlNetScoreDistillation:
     def plans(self):
         return (self.denoiser.plan, self.vae.fwd, self.vae.bwd)
 
+    def range_report(self, top=8):
+        """Where the f32x plans stand against the range of their storage format after the LAST call (round 5; sd15.Plan.range_report): per
+        plan -- denoiser, VAE forward, VAE backward -- the count of saturated (+-65504) / below-normal-range / non-finite stored values, the
+        largest magnitude and the layers with the most hits, plus the same counts for the packed weights.  `ok` is False when anything
+        saturated or went non-finite: the results then left what the reference's fp32 stage (/root/reference/core/guidance/basic.py:233,
+        configs/__init__.py:236,241) would have produced and DWG_BIND_DTYPE=f32 (exact-f32 plans) is the fallback.  One stream
+        synchronisation and ~10^3 small launches: call it every few hundred steps, not every step.  Plans of other precisions: None."""
+        if self.dtype_name != "f32x":
+            return None
+        names = ("denoiser", "vae_forward", "vae_backward")
+        rep = {n: p.range_report(top) for n, p in zip(names, self.plans())}
+        w = {}
+        for n, ws in (("unet", self.denoiser.weights[0]), ("controlnet", self.denoiser.weights[1]), ("vae", self.vae.weights)):
+            w[n] = dict(getattr(ws, "range", {"elements": 0, "saturated": 0, "subnormal": 0, "max_abs": 0.0}))
+        rep["weights"] = w
+        bad = sum(rep[n]["saturated"] + rep[n]["nonfinite"] for n in names) + sum(v["saturated"] for v in w.values())
+        rep["ok"] = bad == 0
+        return rep
+
     def capture_graphs(self):
         for p in self.plans():
             p.capture()

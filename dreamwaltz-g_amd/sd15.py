@@ -290,6 +290,8 @@ class Plan:
         self._lib = _lib.lib()
         self.branch = 0         # ops are tagged with the branch (stream) they run on; 0 = the caller's stream
         self._side = {}         # branch id -> library-owned side stream
+        self.scope = ""         # the layer being built (set by the Builder): names the buffers created inside it (range_report)
+        self.labels = []        # one per kept buffer
 
     # -- independent branches (run concurrently on side streams; parallel paths of the captured graph) -------------------
     def fork(self, b):
@@ -335,8 +337,36 @@ class Plan:
         zero = zero or os.environ.get("DWG_PLAN_ZERO") == "1"
         t = (torch.zeros if zero else torch.empty)(*shape, device=self.device, dtype=dtype)
         self.keep.append(t)
+        self.labels.append((len(self.keep) - 1, self.scope or "op%d" % len(self.ops)))
         self.tags.append((len(self.ops), tuple(shape)))
         return t
+
+    def range_report(self, top=8):
+        """Range telemetry of an f32x plan (round 5; verdict round 4, item 3): every activation buffer the plan owns is scanned AFTER a run
+        (cold path: one small launch per buffer, one read-back) for values the format cannot hold with fp32-grade precision -- hi halves at
+        +-65504 (the split saturates instead of overflowing, csrc/dwg_xfmt.h), non-zero values below fp16's normal range (|x| < 6.1e-5: fewer
+        than 22 significand bits), non-finite values.  Every layer output has its own buffer, so a hit names its layer.  The reference runs
+        this stage in fp32 (/root/reference/configs/__init__.py:236,241): `saturated` > 0 means the results left its range and
+        DWG_BIND_DTYPE=f32 (exact-f32 MFMA plans) is the fallback.  Other plan types: None."""
+        if not self.is_x:
+            return None
+        rows = [(i, lab) for (i, lab) in self.labels if self.keep[i].dtype == xfmt.DTYPE and self.keep[i].numel() % 8 == 0 and self.keep[i].numel() > 0
+                and self.keep[i].is_contiguous()]
+        if not rows:
+            return {"tensors": 0, "elements": 0, "saturated": 0, "subnormal": 0, "nonfinite": 0, "max_abs": 0.0, "worst": []}
+        cnt = torch.zeros(len(rows), 5, dtype=torch.int64, device=self.device)
+        st = ctypes.c_void_p(torch.cuda.current_stream(self.device).cuda_stream)
+        for r, (i, _) in enumerate(rows):
+            t = self.keep[i]
+            _lib.check(self._lib.dwg_xfmt_range_scan(t.numel(), ctypes.c_void_p(t.data_ptr()), ctypes.c_void_p(cnt[r].data_ptr()), st),
+                       "dwg_xfmt_range_scan")
+        c = cnt.cpu()
+        amax = c[:, 3].to(torch.int32).view(torch.float32)        # fp32 bits of max |x| (non-negative: fits int32)
+        per = [{"layer": lab, "shape": tuple(self.keep[i].shape), "saturated": int(c[r, 0]), "subnormal": int(c[r, 1]), "nonfinite": int(c[r, 2]),
+                "max_abs": float(amax[r])} for r, (i, lab) in enumerate(rows)]
+        worst = sorted(per, key=lambda d: (-(d["saturated"] + d["nonfinite"]), -d["max_abs"]))[:top]
+        return {"tensors": len(rows), "elements": int(c[:, 4].sum()), "saturated": int(c[:, 0].sum()), "subnormal": int(c[:, 1].sum()),
+                "nonfinite": int(c[:, 2].sum()), "max_abs": float(amax.max()), "worst": worst}
 
     # -- host <-> plan buffers: fp32 values in, the plan's storage type out (and back) ------------------------------------------
     def store(self, dst, src, stage=None):
@@ -453,6 +483,11 @@ class Weights:
     def _to_dev(self, w):
         """fp32 kernel-layout weight (contraction axis innermost) -> the plan's storage type on the device."""
         if self.is_x:
+            # range telemetry of the weights (xfmt.pack clamps at +-65504 without a trace): counted once, at plan build
+            a = w.abs()
+            r = self.__dict__.setdefault("range", {"elements": 0, "saturated": 0, "subnormal": 0, "max_abs": 0.0})
+            r["elements"] += a.numel(); r["saturated"] += int((a >= xfmt.X_MAX).sum()); r["subnormal"] += int(((a < 6.1035e-5) & (a > 0)).sum())
+            r["max_abs"] = max(r["max_abs"], float(a.max()) if a.numel() else 0.0)
             return xfmt.pack(w.to(self.device)).contiguous()
         return w.to(self.device, self.wdtype).contiguous()
 
@@ -542,6 +577,7 @@ class Builder:
              pad_tl=None, r_batch_bcast=False, weight=None, bias=True, in_dilation=1, tag=None):
         """x [B,H,W,C] NHWC bf16. bias_img: (tensor [B, ld] fp32, ld) per-image channel bias replacing the conv bias."""
         B, H, W, C = x.shape
+        self.p.scope = name
         wt = self.w.conv(name) if weight is None else weight
         Cout, KH, KW, Cin = wt.shape
         assert Cin == C, (name, Cin, C)
@@ -602,6 +638,7 @@ class Builder:
         return ws
 
     def groupnorm(self, x, name, eps, silu, keep_stats=False):
+        self.p.scope = name
         B, C = x.shape[0], x.shape[-1]
         HW = x.numel() // (B * C)
         y = self.p.buf(*x.shape)
@@ -623,6 +660,7 @@ class Builder:
         return dx
 
     def layernorm(self, x, name):
+        self.p.scope = name
         C = x.shape[-1]
         M = x.numel() // C
         y = self.p.buf(*x.shape)
@@ -718,6 +756,7 @@ class Builder:
 
     # -- blocks ----------------------------------------------------------------------------------------------------
     def resnet(self, x, pre, temb_bias, eps=1e-5):
+        self.p.scope = pre
         C = x.shape[-1]
         n1 = self.groupnorm(x, pre + ".norm1", eps, True)
         h1 = self.conv(n1, pre + ".conv1", bias_img=temb_bias)
@@ -754,6 +793,7 @@ class Builder:
         return ent[0][..., o:o + 2 * c]
 
     def transformer(self, x, pre, text, heads):
+        self.p.scope = pre
         B, H, W, C = x.shape
         n = self.groupnorm(x, pre + ".norm", 1e-6, False)
         h = self.conv(n, pre + ".proj_in", pad=0).view(B, H * W, C)
@@ -1086,8 +1126,24 @@ class VAEEncoderPlan:
         self.fwd.run()
         return self.moments.permute(0, 3, 1, 2)
 
+    # the backward pass is LINEAR in the incoming gradient: it is run on 2^k x the gradient, k chosen on the device so that max |g| lands in
+    # [GRAD_TARGET / 2, GRAD_TARGET], and the result is scaled back by 2^-k -- both exact.  Without it the 16-bit storage types see the
+    # gradient at whatever scale the loss has: an SDS gradient of 1e-4 sits at the bottom of fp16's normal range and its f32x lo halves go
+    # subnormal (measured round 4: VAE image gradient 2.0e-6 off the fp32 oracle at scale 1, 1.2e-4 at scale 1e-4; fp32 has no such floor:
+    # /root/reference/configs/__init__.py:236,241).  64 leaves three decades of head-room below 65504 for growth inside the network.
+    GRAD_TARGET = 64.0
+
     def backward(self, dmoments_nchw):
         """d loss / d moments [B,8,h,w] -> d loss / d image [B,3,H,W] fp32."""
-        self.bwd.store(self.dmoments, dmoments_nchw.permute(0, 2, 3, 1))
+        g = dmoments_nchw
+        inv = None
+        if self.bwd.dtype_name in ("f32x", "f16") and os.environ.get("DWG_VAE_GRAD_PRESCALE", "1") != "0":
+            amax = g.detach().abs().amax()
+            k = torch.floor(torch.log2(self.GRAD_TARGET / amax.clamp_min(1e-30))).clamp(-60.0, 100.0)
+            k = torch.where(amax > 0, k, torch.zeros_like(k))
+            g = g * torch.exp2(k)                          # exact: a power of two
+            inv = torch.exp2(1.0 - k)                      # 2 x 2^-k: the scale back and the d(2 x - 1)/dx of the input normalisation
+        self.bwd.store(self.dmoments, g.permute(0, 2, 3, 1))
         self.bwd.run()
-        return self.bwd.load(self.dx)[..., :3].permute(0, 3, 1, 2) * 2.0
+        dx = self.bwd.load(self.dx)[..., :3].permute(0, 3, 1, 2)
+        return dx * inv if inv is not None else dx * 2.0

@@ -134,9 +134,33 @@ def bind_guidance(ref, dtype=None, keep_modules=None):
         if stream_ok:
             hip.capture_graphs()
 
+    # f32x range safety (round 5): the split-precision plans saturate at +-65504 and thin out below 6.1e-5 where the reference's fp32
+    # pipeline (core/guidance/basic.py:233) does neither.  Every DWG_BIND_RANGE_CHECK_EVERY calls (default 200; 0: never) the stored
+    # activations of the last call are scanned; a hit is reported ONCE per layer set with the layers' names and the documented way out.
+    check_every = int(os.environ.get("DWG_BIND_RANGE_CHECK_EVERY", "200"))
+    state = {"calls": 0, "warned": set()}
+
+    def _range_check():
+        rep = hip.range_report()
+        ref.hip_range_report = rep
+        if rep is None or rep["ok"]:
+            return
+        layers = tuple(sorted({"%s:%s" % (n, d["layer"]) for n in ("denoiser", "vae_forward", "vae_backward") for d in rep[n]["worst"]
+                               if d["saturated"] or d["nonfinite"]}))
+        if layers not in state["warned"]:
+            state["warned"].add(layers)
+            import warnings
+            warnings.warn("dwg_bind: the f32x (split fp16) plans SATURATED at +-65504 or produced non-finite values in %s -- the reference's fp32 "
+                          "pipeline would not have; rerun with DWG_BIND_DTYPE=f32 (exact-f32 MFMA plans, ~2.5x slower)" % (", ".join(layers) or "the weights"),
+                          RuntimeWarning, stacklevel=3)
+
     def _predict(self, latents_model_input, text_embeddings, cond_inputs):
         hip.timestep = self.timestep                       # controlnet.py:83-114 reads self.timestep
-        return hip._predict(latents_model_input, text_embeddings, cond_inputs).to(latents_model_input.dtype)
+        out = hip._predict(latents_model_input, text_embeddings, cond_inputs).to(latents_model_input.dtype)
+        state["calls"] += 1
+        if check_every > 0 and hip.dtype_name == "f32x" and (state["calls"] == 1 or state["calls"] % check_every == 0):
+            _range_check()
+        return out
 
     def encode_images(self, images):
         if not isinstance(images, torch.Tensor):           # PIL inputs (visualisation only): the reference's own path

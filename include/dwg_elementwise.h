@@ -93,6 +93,11 @@ int dwg_transpose_2byte(int32_t batch, int32_t R, int32_t C, const void* in, int
  * plans (the reference hands fp32 latents, text embeddings and images across boundary B4: core/guidance/controlnet.py:83-114, vae.py:34-40). */
 int dwg_xfmt_pack(int64_t n, const float* src, void* dst, dwg_stream_t stream);
 int dwg_xfmt_unpack(int64_t n, const void* src, float* dst, dwg_stream_t stream);
+/* Range telemetry of a stored f32x tensor (cold path; the hot path saturates and goes subnormal silently): ADDS into counters5 (device,
+ * zeroed by the caller)  [0] hi halves at +-65504 (saturated, or on the edge),  [1] non-zero values whose hi half is subnormal or zero
+ * (|x| < 6.1e-5: fewer than 22 significand bits),  [2] non-finite values,  [3] max |x| as fp32 bits (atomic max),  [4] elements seen.
+ * The reference runs this stage in fp32 (/root/reference/configs/__init__.py:236,241): a non-zero [0] says the f32x plans left its range. */
+int dwg_xfmt_range_scan(int64_t n, const void* src, uint64_t* counters5, dwg_stream_t stream);
 /* dwg_transpose_2byte for any 2-byte plan type, and for f32x tensors (groups of 8 along c on the way in, along r on the way out). */
 int dwg_transpose_dt(int32_t dtype, int32_t batch, int32_t R, int32_t C, const void* in, int64_t ld_in, int64_t batch_stride_in, void* out,
                      int64_t ld_out, int64_t batch_stride_out, dwg_stream_t stream);
