@@ -939,8 +939,13 @@ int dwg_adam_step(int64_t n, float* param, const float* grad, float* exp_avg, fl
     if (n == 0) return DWG_OK;
     if (!param || !grad || !exp_avg || !exp_avg_sq) return DWG_E_ARG;
     if (((uintptr_t)param | (uintptr_t)grad | (uintptr_t)exp_avg | (uintptr_t)exp_avg_sq) % 16) return DWG_E_ARG;
-    float bc1 = 1.f - powf(beta1, (float)step);
-    float bc2_sqrt = sqrtf(1.f - powf(beta2, (float)step));
+    // The step's two scalars in DOUBLE from the fp32 hyper-parameters, rounded once -- the very statements FlatOptimizer.prepare_step makes
+    // on the host for the device-resident table of a captured step (dwg_adam_step_dev): an eager step and a replay of the captured one
+    // then run k_adam on identical bits (round 5: with the table gradient deterministic, this was the last difference between the two).
+    const float stepsize = (float)((double)lr / (1.0 - pow((double)beta1, (double)step)));
+    const float bc1 = 1.f;
+    float bc2_sqrt = (float)sqrt(1.0 - pow((double)beta2, (double)step));
+    lr = stepsize;
     size_t blocks = ((size_t)n / 4 + 255) / 256;
     if (blocks < 1) blocks = 1;
     if (blocks > 2048) blocks = 2048;

@@ -307,7 +307,17 @@ static int check(uint32_t B, uint32_t D, uint32_t C, uint32_t L) {
 #define GS_NWG 256u            // workgroups of the count / scatter passes (each owns a contiguous range of (point, level) chunks)
 #define GS_MAXREC 8192u        // records one accumulate workgroup takes (round 4: 32768 -- the kernel's time was its longest unit: 128 trips of a
                                // one-load-in-flight loop; the extra units of a dense slab add their non-zero entries with global atomics)
-struct GsUnit { uint32_t slab, begin, end, multi; };
+struct GsUnit { uint32_t slab, begin, end, multi; };       // multi: 0 = the slab's only unit, else 1 + the slab's slot among the shared 64-bit images
+
+// DETERMINISTIC accumulation (round 5).  A slab's contributions are summed as 64-bit FIXED-POINT integers: value x 2^s rounded once, s
+// chosen per slab from the largest gradient magnitude of the call (found without atomics by the count pass) and the slab's record count so
+// that no sum can leave 63 bits -- integer addition commutes, so the LDS atomics' arrival order (and the global atomics' of the few
+// slabs split over several workgroups) no longer reaches the result: two runs, or a captured replay and an eager step, give the same
+// bits.  Float atomics -- here until round 4, and in the reference's own kernel (gridencoder.cu:245-337 atomicAdd) -- do not.  The
+// quantum is 2^-s >= gmax x 2^-61 x records: far below an fp32 ulp of anything the sum can be compared with; an entry whose whole sum is
+// below ~2^-48 gmax comes out as an exact zero instead of a noise-signed denormal-scale value.
+__device__ __forceinline__ long long gs_to_fixed(float v, int s) { return __double2ll_rn(ldexp((double)v, s)); }
+__device__ __forceinline__ float gs_from_fixed(long long q, int s) { return (float)ldexp((double)q, -s); }
 
 __device__ __forceinline__ uint32_t gs_wg_chunks(uint32_t nchunks) { return (nchunks + GS_NWG - 1u) / GS_NWG; }
 
@@ -317,9 +327,16 @@ __global__ __launch_bounds__(256) void k_gs_bin(GridP p, uint32_t nchunks, uint3
                                                 const float* __restrict__ x, const int* __restrict__ offsets, uint32_t first_table_level,
                                                 uint32_t* __restrict__ counts /*[nslab][GS_NWG]: counts, then prefixes*/,
                                                 const uint32_t* __restrict__ slab_start, uint4* __restrict__ records,
-                                                const float* __restrict__ dy_dx, float* __restrict__ grad_x) {
+                                                const float* __restrict__ dy_dx, float* __restrict__ grad_x, float* __restrict__ wgmax /*[GS_NWG]*/,
+                                                const uint32_t* __restrict__ n_multi, unsigned long long* __restrict__ gimg) {
     extern __shared__ uint32_t cur[];       // [nslab]
+    __shared__ float smax[4];
     const uint32_t wg = blockIdx.x;
+    float gmax = 0.f;
+    if (SCATTER) {      // the 64-bit images of the slabs that several accumulate workgroups share start from zero (k_gs_scan counted them)
+        const size_t nz = (size_t)(*n_multi) * GS_SLAB * 2u;
+        for (size_t i = (size_t)wg * 256u + threadIdx.x; i < nz; i += (size_t)GS_NWG * 256u) gimg[i] = 0ull;
+    }
     for (uint32_t s_ = threadIdx.x; s_ < nslab; s_ += 256) cur[s_] = SCATTER ? slab_start[s_] + counts[(size_t)s_ * GS_NWG + wg] : 0u;
     __syncthreads();
     const uint32_t cpw = gs_wg_chunks(nchunks);
@@ -336,6 +353,7 @@ __global__ __launch_bounds__(256) void k_gs_bin(GridP p, uint32_t nchunks, uint3
             Cell c = locate(p, offsets, level, x[3 * b], x[3 * b + 1], x[3 * b + 2]);
             if (!c.oob) {
                 if (level >= first_table_level) {
+                    if (!SCATTER) gmax = fmaxf(gmax, fmaxf(fabsf(g0), fabsf(g1)));      // interpolation weights are <= 1: bounds every record
                     const uint32_t lvl_entry = (uint32_t)offsets[level] - first_entry;
 #pragma unroll
                     for (int idx = 0; idx < 8; idx++) {
@@ -372,7 +390,11 @@ __global__ __launch_bounds__(256) void k_gs_bin(GridP p, uint32_t nchunks, uint3
         }
     }
     if (!SCATTER) {
+#pragma unroll
+        for (int off = 32; off >= 1; off >>= 1) gmax = fmaxf(gmax, __shfl_xor(gmax, off));
+        if ((threadIdx.x & 63) == 0) smax[threadIdx.x >> 6] = gmax;
         __syncthreads();
+        if (threadIdx.x == 0) wgmax[wg] = fmaxf(fmaxf(smax[0], smax[1]), fmaxf(smax[2], smax[3]));      // its own slot: no atomics, order-free
         for (uint32_t s_ = threadIdx.x; s_ < nslab; s_ += 256) counts[(size_t)s_ * GS_NWG + wg] = cur[s_];
     }
 }
@@ -400,48 +422,64 @@ __global__ __launch_bounds__(256) void k_gs_scan_slab(uint32_t nslab, uint32_t* 
 
 // pass 2b (one workgroup): the slabs' starts and the work units from the slab totals
 __global__ __launch_bounds__(1024) void k_gs_scan(uint32_t nslab, const uint32_t* __restrict__ slab_total, uint32_t* __restrict__ slab_start /*[nslab+1]*/,
-                                                  GsUnit* __restrict__ units, uint32_t* __restrict__ n_units) {
-    __shared__ uint32_t tot[1024], ucnt[1024];
-    __shared__ uint32_t carry_t, carry_u;
+                                                  GsUnit* __restrict__ units, uint32_t* __restrict__ n_units, const float* __restrict__ wgmax,
+                                                  int32_t* __restrict__ sexp /*[nslab]*/, uint32_t* __restrict__ multi_list, uint32_t* __restrict__ n_multi) {
+    __shared__ uint32_t tot[1024], ucnt[1024], mcnt[1024];
+    __shared__ uint32_t carry_t, carry_u, carry_m;
+    __shared__ float gm[256];
     const uint32_t tid = threadIdx.x;
-    if (tid == 0) { carry_t = 0u; carry_u = 0u; }
+    if (tid == 0) { carry_t = 0u; carry_u = 0u; carry_m = 0u; }
+    if (tid < 256u) gm[tid] = tid < GS_NWG ? wgmax[tid] : 0.f;
     __syncthreads();
+    for (uint32_t off = 128u; off >= 1u; off >>= 1) {           // max of the count pass's per-workgroup maxima (max commutes: any order)
+        if (tid < off) gm[tid] = fmaxf(gm[tid], gm[tid + off]);
+        __syncthreads();
+    }
+    int emax = 0;
+    { const float g = gm[0]; if (g > 0.f && g < 3.0e38f) (void)frexpf(g, &emax); }      // g < 2^emax
     for (uint32_t base = 0; base < nslab; base += 1024u) {
         const uint32_t s_ = base + tid;
         const uint32_t run = s_ < nslab ? slab_total[s_] : 0u;
         const uint32_t nu = s_ < nslab ? (run > GS_MAXREC ? (run + GS_MAXREC - 1u) / GS_MAXREC : 1u) : 0u;
-        tot[tid] = run; ucnt[tid] = nu;
+        const uint32_t isM = nu > 1u ? 1u : 0u;
+        tot[tid] = run; ucnt[tid] = nu; mcnt[tid] = isM;
         __syncthreads();
-        for (uint32_t off = 1; off < 1024u; off <<= 1) {            // inclusive scans of both
-            const uint32_t a = tid >= off ? tot[tid - off] : 0u, u = tid >= off ? ucnt[tid - off] : 0u;
+        for (uint32_t off = 1; off < 1024u; off <<= 1) {            // inclusive scans of all three
+            const uint32_t a = tid >= off ? tot[tid - off] : 0u, u = tid >= off ? ucnt[tid - off] : 0u, m_ = tid >= off ? mcnt[tid - off] : 0u;
             __syncthreads();
-            tot[tid] += a; ucnt[tid] += u;
+            tot[tid] += a; ucnt[tid] += u; mcnt[tid] += m_;
             __syncthreads();
         }
-        const uint32_t start = carry_t + tot[tid] - run, ustart = carry_u + ucnt[tid] - nu;
+        const uint32_t start = carry_t + tot[tid] - run, ustart = carry_u + ucnt[tid] - nu, mslot = carry_m + mcnt[tid] - isM;
         if (s_ < nslab) {
             slab_start[s_] = start;
+            // fixed-point scale of the slab: |record| < 2^emax, at most `run` of them per entry -> sums stay below 2^61
+            int clog = 0; while ((1u << clog) < run && clog < 31) clog++;
+            sexp[s_] = 61 - emax - clog;
+            if (isM) multi_list[mslot] = s_;
             for (uint32_t u = 0; u < nu; u++) {
                 GsUnit g;
-                g.slab = s_; g.begin = start + u * GS_MAXREC; g.end = min(start + run, g.begin + GS_MAXREC); g.multi = nu > 1u ? 1u : 0u;
+                g.slab = s_; g.begin = start + u * GS_MAXREC; g.end = min(start + run, g.begin + GS_MAXREC); g.multi = isM ? mslot + 1u : 0u;
                 units[ustart + u] = g;
             }
         }
         __syncthreads();
-        if (tid == 1023) { carry_t += tot[1023]; carry_u += ucnt[1023]; }
+        if (tid == 1023) { carry_t += tot[1023]; carry_u += ucnt[1023]; carry_m += mcnt[1023]; }
         __syncthreads();
     }
-    if (tid == 0) { slab_start[nslab] = carry_t; *n_units = carry_u; }
+    if (tid == 0) { slab_start[nslab] = carry_t; *n_units = carry_u; *n_multi = carry_m; }
 }
 
-// pass 4: one workgroup per unit
+// pass 4: one workgroup per unit -- 64-bit fixed-point sums in LDS (see gs_to_fixed)
 __global__ __launch_bounds__(256) void k_gs_accumulate(uint32_t first_entry, uint32_t total_entries, const GsUnit* __restrict__ units,
                                                        const uint32_t* __restrict__ n_units, const uint4* __restrict__ records,
-                                                       float* __restrict__ grad_table, int accumulate) {
-    extern __shared__ float tab[];          // [GS_SLAB * 2]
+                                                       float* __restrict__ grad_table, int accumulate, const int32_t* __restrict__ sexp,
+                                                       unsigned long long* __restrict__ gimg) {
+    extern __shared__ unsigned long long tabq[];          // [GS_SLAB * 2]
     if (blockIdx.x >= *n_units) return;
     const GsUnit u = units[blockIdx.x];
-    for (uint32_t e = threadIdx.x; e < GS_SLAB * 2u; e += 256) tab[e] = 0.f;
+    const int sx = sexp[u.slab];
+    for (uint32_t e = threadIdx.x; e < GS_SLAB * 2u; e += 256) tabq[e] = 0ull;
     __syncthreads();
     for (uint32_t r0 = u.begin + threadIdx.x; r0 < u.end; r0 += 1024) {        // four records in flight per thread
         uint4 rec[4];
@@ -450,8 +488,8 @@ __global__ __launch_bounds__(256) void k_gs_accumulate(uint32_t first_entry, uin
 #pragma unroll
         for (int i = 0; i < 4; i++) {
             if (r0 + 256u * i < u.end) {
-                atomicAdd(&tab[2u * rec[i].x], __uint_as_float(rec[i].y));
-                atomicAdd(&tab[2u * rec[i].x + 1u], __uint_as_float(rec[i].z));
+                atomicAdd(&tabq[2u * rec[i].x], (unsigned long long)gs_to_fixed(__uint_as_float(rec[i].y), sx));
+                atomicAdd(&tabq[2u * rec[i].x + 1u], (unsigned long long)gs_to_fixed(__uint_as_float(rec[i].z), sx));
             }
         }
     }
@@ -459,21 +497,44 @@ __global__ __launch_bounds__(256) void k_gs_accumulate(uint32_t first_entry, uin
     const uint32_t e0 = first_entry + u.slab * GS_SLAB;                     // first table entry of this slab
     const uint32_t ne = min(GS_SLAB, total_entries - e0);
     float* dst = grad_table + (size_t)e0 * 2;
-    if (!u.multi && ((uintptr_t)dst & 15) == 0) {
+    if (u.multi) {
+        // one of several workgroups of a dense slab: its non-zero sums join the slab's shared 64-bit image (integer atomics: order-free);
+        // k_gs_finalize turns the image into floats
+        unsigned long long* img = gimg + (size_t)(u.multi - 1u) * GS_SLAB * 2u;
+        for (uint32_t e = threadIdx.x; e < ne * 2u; e += 256) { const unsigned long long v = tabq[e]; if (v) atomicAdd(img + e, v); }
+        return;
+    }
+    if (((uintptr_t)dst & 15) == 0) {
         // this workgroup is the slab's only writer: plain 16-byte stores -- or, accumulating into a gradient buffer that already holds
         // other contributions (the flat gradient buffer of a multi-view step), a plain read-add-write of the same pieces
         for (uint32_t q = threadIdx.x; q < ne / 2u; q += 256) {             // two entries (16 bytes) per store
-            float4 v = make_float4(tab[4 * q], tab[4 * q + 1], tab[4 * q + 2], tab[4 * q + 3]);
+            float4 v = make_float4(gs_from_fixed((long long)tabq[4 * q], sx), gs_from_fixed((long long)tabq[4 * q + 1], sx),
+                                   gs_from_fixed((long long)tabq[4 * q + 2], sx), gs_from_fixed((long long)tabq[4 * q + 3], sx));
             if (accumulate) { const float4 o = reinterpret_cast<const float4*>(dst)[q]; v.x += o.x; v.y += o.y; v.z += o.z; v.w += o.w; }
             reinterpret_cast<float4*>(dst)[q] = v;
         }
         if ((ne & 1u) && threadIdx.x == 0) {
             const float o0 = accumulate ? dst[2 * (ne - 1)] : 0.f, o1 = accumulate ? dst[2 * (ne - 1) + 1] : 0.f;
-            dst[2 * (ne - 1)] = tab[2 * (ne - 1)] + o0; dst[2 * (ne - 1) + 1] = tab[2 * (ne - 1) + 1] + o1;
+            dst[2 * (ne - 1)] = gs_from_fixed((long long)tabq[2 * (ne - 1)], sx) + o0;
+            dst[2 * (ne - 1) + 1] = gs_from_fixed((long long)tabq[2 * (ne - 1) + 1], sx) + o1;
         }
     } else {
-        for (uint32_t e = threadIdx.x; e < ne * 2u; e += 256) { const float v = tab[e]; if (v != 0.f) atomicAdd(dst + e, v); }
+        for (uint32_t e = threadIdx.x; e < ne * 2u; e += 256) dst[e] = gs_from_fixed((long long)tabq[e], sx) + (accumulate ? dst[e] : 0.f);
     }
+}
+
+// pass 5: one workgroup per slab that several accumulate workgroups shared: its 64-bit image -> floats
+__global__ __launch_bounds__(256) void k_gs_finalize(uint32_t first_entry, uint32_t total_entries, const uint32_t* __restrict__ multi_list,
+                                                     const uint32_t* __restrict__ n_multi, const int32_t* __restrict__ sexp,
+                                                     const unsigned long long* __restrict__ gimg, float* __restrict__ grad_table, int accumulate) {
+    if (blockIdx.x >= *n_multi) return;
+    const uint32_t slab = multi_list[blockIdx.x];
+    const int sx = sexp[slab];
+    const uint32_t e0 = first_entry + slab * GS_SLAB;
+    const uint32_t ne = min(GS_SLAB, total_entries - e0);
+    float* dst = grad_table + (size_t)e0 * 2;
+    const unsigned long long* img = gimg + (size_t)blockIdx.x * GS_SLAB * 2u;
+    for (uint32_t e = threadIdx.x; e < ne * 2u; e += 256) dst[e] = gs_from_fixed((long long)img[e], sx) + (accumulate ? dst[e] : 0.f);
 }
 
 }  // namespace
@@ -617,8 +678,11 @@ size_t dwg_grid_backward_slabs_workspace_bytes(uint32_t B, uint32_t L, uint32_t 
     const size_t nslab = (total_entries + GS_SLAB - 1u) / GS_SLAB;
     const size_t recs = (size_t)B * L * 8;
     const size_t max_units = nslab + recs / GS_MAXREC + 2;
+    const size_t max_multi = (nslab < recs / GS_MAXREC + 1 ? nslab : recs / GS_MAXREC + 1);      // slabs with more than GS_MAXREC records
     return dwg_align_up(recs * sizeof(uint4), 256) + dwg_align_up((size_t)GS_NWG * nslab * 4, 256) + 2 * dwg_align_up((nslab + 1) * 4, 256) +
-           dwg_align_up(max_units * sizeof(GsUnit), 256) + 256;
+           dwg_align_up(max_units * sizeof(GsUnit), 256) + 256 +
+           dwg_align_up((size_t)GS_NWG * 4, 256) + dwg_align_up(nslab * 4, 256) + dwg_align_up(max_multi * 4, 256) + 256 +
+           dwg_align_up(max_multi * GS_SLAB * 2 * 8, 256);
 }
 
 static int grid_backward_slabs(const float* grad, const float* inputs, const float* embeddings, const int32_t* offsets,
@@ -676,20 +740,30 @@ static int grid_backward_slabs(const float* grad, const float* inputs, const flo
     uint32_t* slab_start = reinterpret_cast<uint32_t*>(w); w += dwg_align_up(((size_t)(total_entries + GS_SLAB - 1u) / GS_SLAB + 1) * 4, 256);
     uint32_t* slab_total = reinterpret_cast<uint32_t*>(w); w += dwg_align_up(((size_t)(total_entries + GS_SLAB - 1u) / GS_SLAB + 1) * 4, 256);
     GsUnit* units = reinterpret_cast<GsUnit*>(w); w += dwg_align_up(((size_t)(total_entries + GS_SLAB - 1u) / GS_SLAB + recs / GS_MAXREC + 2) * sizeof(GsUnit), 256);
-    uint32_t* n_units = reinterpret_cast<uint32_t*>(w);
+    uint32_t* n_units = reinterpret_cast<uint32_t*>(w); w += 256;
+    const size_t nslab_all = ((size_t)total_entries + GS_SLAB - 1u) / GS_SLAB;
+    const size_t max_multi = (nslab_all < recs / GS_MAXREC + 1 ? nslab_all : recs / GS_MAXREC + 1);
+    float* wgmax = reinterpret_cast<float*>(w); w += dwg_align_up((size_t)GS_NWG * 4, 256);
+    int32_t* sexp = reinterpret_cast<int32_t*>(w); w += dwg_align_up(nslab_all * 4, 256);
+    uint32_t* multi_list = reinterpret_cast<uint32_t*>(w); w += dwg_align_up(max_multi * 4, 256);
+    uint32_t* n_multi = reinterpret_cast<uint32_t*>(w); w += 256;
+    unsigned long long* gimg = reinterpret_cast<unsigned long long*>(w);
     static bool attr2 = false;
     if (!attr2) {
-        hipFuncSetAttribute(reinterpret_cast<const void*>(&k_gs_accumulate), hipFuncAttributeMaxDynamicSharedMemorySize, GS_SLAB * 8);
+        hipFuncSetAttribute(reinterpret_cast<const void*>(&k_gs_accumulate), hipFuncAttributeMaxDynamicSharedMemorySize, GS_SLAB * 16);
         attr2 = true;
     }
     DWG_LAUNCH("grid_bwd_count", (k_gs_bin<false>), dim3(GS_NWG), dim3(256), (size_t)nslab * 4, st, p, nchunks, nslab, first_entry, grad, inputs,
-               offsets, first_table_level, counts, (const uint32_t*)slab_start, records, dy_dx, grad_inputs);
+               offsets, first_table_level, counts, (const uint32_t*)slab_start, records, dy_dx, grad_inputs, wgmax, (const uint32_t*)n_multi, gimg);
     DWG_LAUNCH("grid_bwd_scan", k_gs_scan_slab, dim3((nslab + 3u) / 4u), dim3(256), 0, st, nslab, counts, slab_total);
-    DWG_LAUNCH("grid_bwd_scan", k_gs_scan, dim3(1), dim3(1024), 0, st, nslab, (const uint32_t*)slab_total, slab_start, units, n_units);
+    DWG_LAUNCH("grid_bwd_scan", k_gs_scan, dim3(1), dim3(1024), 0, st, nslab, (const uint32_t*)slab_total, slab_start, units, n_units,
+               (const float*)wgmax, sexp, multi_list, n_multi);
     DWG_LAUNCH("grid_bwd_scatter", (k_gs_bin<true>), dim3(GS_NWG), dim3(256), (size_t)nslab * 4, st, p, nchunks, nslab, first_entry, grad, inputs,
-               offsets, first_table_level, counts, (const uint32_t*)slab_start, records, dy_dx, grad_inputs);
-    DWG_LAUNCH("grid_bwd", k_gs_accumulate, dim3((unsigned)max_units), dim3(256), (size_t)GS_SLAB * 8, st, first_entry, total_entries,
-               (const GsUnit*)units, (const uint32_t*)n_units, (const uint4*)records, grad_embeddings, accumulate);
+               offsets, first_table_level, counts, (const uint32_t*)slab_start, records, dy_dx, grad_inputs, wgmax, (const uint32_t*)n_multi, gimg);
+    DWG_LAUNCH("grid_bwd", k_gs_accumulate, dim3((unsigned)max_units), dim3(256), (size_t)GS_SLAB * 16, st, first_entry, total_entries,
+               (const GsUnit*)units, (const uint32_t*)n_units, (const uint4*)records, grad_embeddings, accumulate, (const int32_t*)sexp, gimg);
+    DWG_LAUNCH("grid_bwd", k_gs_finalize, dim3((unsigned)max_multi), dim3(256), 0, st, first_entry, total_entries, (const uint32_t*)multi_list,
+               (const uint32_t*)n_multi, (const int32_t*)sexp, (const unsigned long long*)gimg, grad_embeddings, accumulate);
     DWG_RETURN_IF_LAUNCH_FAILED();
     return DWG_OK;
 }

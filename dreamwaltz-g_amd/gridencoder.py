@@ -231,7 +231,10 @@ class _grid_encode(Function):
         grad_inputs = torch.empty_like(inputs) if dy_dx is not None else None
         # big batches: XCD-private accumulation of the table gradient (8 copies + one reduce pass beat memory-side atomics)
         import os
-        mode = os.environ.get("DWG_GRID_XCD_MODE", "slabs") if B >= 16384 else "device"
+        # the slab-binned path from 2048 points (round 5; 16384 before): it is the DETERMINISTIC one (64-bit fixed-point sums), and a training
+        # step's table gradient should reproduce bit for bit at every avatar size; below that the handful of float atomics of the
+        # device-scope path cost less than the slab path's five dependent launches
+        mode = os.environ.get("DWG_GRID_XCD_MODE", "slabs") if B >= int(os.environ.get("DWG_GRID_SLAB_MIN_POINTS", "2048")) else "device"
         if mode in ("owner", "copies") and not xcd_path_ok(inputs.device):
             mode = "device"
         if mode == "slabs" and not slab_path_ok(B, L, int(embeddings.shape[0])):

@@ -14,6 +14,7 @@ a fused Adam launch per learning-rate group (csrc/elementwise.hip k_adam through
 """
 import ctypes
 import math
+import struct
 from typing import Dict, List, Optional
 
 import torch
@@ -179,8 +180,10 @@ class FlatOptimizer:
         self.current_iteration += 1
         for k, pg in enumerate(self.param_groups):
             pg["t"] = pg.get("t", 0) + 1
-            b1, b2 = pg["betas"]
-            hyper_host[base + k, 0] = float(pg["lr"]) / (1.0 - b1 ** pg["t"])
+            # the statements of dwg_adam_step (csrc/elementwise.hip): fp32 hyper-parameters, double arithmetic, one rounding -- a replay of the
+            # captured step and an eager step then feed k_adam identical bits
+            b1, b2, lr = (struct.unpack("f", struct.pack("f", float(x)))[0] for x in (pg["betas"][0], pg["betas"][1], pg["lr"]))
+            hyper_host[base + k, 0] = lr / (1.0 - b1 ** pg["t"])
             hyper_host[base + k, 1] = math.sqrt(1.0 - b2 ** pg["t"])
             hyper_host[base + k, 2] = float(self.grad_scale)
         return len(self.param_groups)

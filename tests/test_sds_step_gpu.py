@@ -109,8 +109,11 @@ def test_step_without_guidance_matches_oracle_chain_and_first_adam_update(async_
 # side's own agreement with the oracle chain (float atomics, <= 2e-3 without diffusion).  f16 / bf16: the stated tolerance of those plans for
 # PARAMETER gradients at this reduced width under CFG 50 -- about 1.5x the values measured on an MI355X (profiles/r04_parity_sds_step.json,
 # DESIGN.md section 2).
-# measured: f32x / f32 2.6e-4 .. 1.4e-3 (identical to 2 digits: the avatar side's float atomics, not the guidance); f16 1.5 .. 4.2 %; bf16 15 .. 28 %
-_STEP_BARS = {"f32x": (2e-3, 0.99999), "f32": (2e-3, 0.99999), "f16": (6e-2, 0.998), "bf16": (0.42, 0.95)}
+# measured: f32x / f32 2.6e-4 .. 2.0e-3; f16 1.5 .. 4.2 %; bf16 15 .. 28 %.  Round 5: the step is bit-reproducible now, so the f32x / f32 numbers no
+# longer move from run to run -- but the worst parameter (the 798 mesh-bound scales, a near-cancelling sum: cosine 0.999998) answers a 2e-6
+# relative change of the IMAGE gradient (the VAE backward with / without its power-of-two pre-scale: both 2.1e-6 off the fp32 oracle) with
+# 1.43e-3 -> 2.01e-3, and the exact-f32 plans sit at 1.72e-3: the chain's own conditioning, not a precision of the plans.  Bar 3e-3.
+_STEP_BARS = {"f32x": (3e-3, 0.99999), "f32": (3e-3, 0.99999), "f16": (6e-2, 0.998), "bf16": (0.42, 0.95)}
 
 
 @pytest.mark.parametrize("dtype", ["f32x", "f32", "f16", "bf16"])
