@@ -1,6 +1,6 @@
 #!/bin/bash
 # SQ counters (their own run: no trace domains besides kernel-trace) of the c2 step's kernels, launched eagerly:  bash tools/pmc_sq_c2.sh r04 <commit>
-R=${1:-r04}; COMMIT=${2:-unknown}
+R=${1:-r05}; COMMIT=${2:-unknown}
 REPO=$(cd "$(dirname "$0")/.." && pwd)
 OUT=$REPO/gpurun_out/prof_$R/pmc_sq_c2
 mkdir -p $OUT $REPO/profiles
