@@ -275,19 +275,15 @@ def raster_report(prof, G, Kref, K, P, steps, pmc=False):
     tj, stale = _traffic() if pmc else (None, None)
     if tj is not None:       # HBM bytes per frame from the PMC passes (taken on the default c3 workload only)
         tk = tj["kernels"]
-        fwd = ("k_preprocess", "k_scan_super", "k_scatter_super", "k_sort_super", "k_scan_tiles", "k_render_fwd", "k_camera_setup")
+        fwd = ("k_preprocess", "k_scan_super", "k_scatter_super", "k_chunk_sort", "k_rank_merge", "k_split", "k_render_fwd", "k_camera_setup", "k_camera_block")
         bwd = ("k_render_bwd", "k_gather_partials", "k_preprocess_bwd")
         for key, names in (("raster_forward", fwd), ("raster_backward", bwd)):
             if key in out:
+                # ONE number: FETCH_SIZE x 2 for the kernels that stream, x 1 for the ones that gather (tools/pmc_traffic.py, calibrated on known
+                # byte counts: profiles/r05_fetch_calibration.json), + WRITE_SIZE
                 t = sum(v["hbm_bytes_per_launch"] * v.get("launches_per_step", 1) for k, v in tk.items() if k.split("<")[0] in names)
-                tu = sum(v.get("hbm_bytes_per_launch_uncorrected", v["hbm_bytes_per_launch"]) * v.get("launches_per_step", 1) for k, v in tk.items()
-                         if k.split("<")[0] in names)
                 out[key]["traffic"] = t
                 out[key]["traffic_over_algorithmic"] = t / out[key]["bytes"]
-                # the x2 FETCH_SIZE correction is calibrated for 16 B/lane streams, not for these kernels' 16-byte gathers: the truth lies
-                # between the uncorrected and the corrected sum
-                out[key]["traffic_uncorrected"] = tu
-                out[key]["traffic_over_algorithmic_uncorrected"] = tu / out[key]["bytes"]
                 out[key]["traffic_stale"] = bool(stale)
     return out
 

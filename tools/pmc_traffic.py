@@ -7,8 +7,15 @@ slots, FETCH_SIZE takes 3 and WRITE_SIZE 2 -- MI355X_MICROARCH.md, rocprofv3 PMC
     python tools/pmc_traffic.py gpurun_out/pmc_fetch/sds_counter_collection.csv gpurun_out/pmc_write/sds_counter_collection.csv profiles/r01_pmc_traffic.json
 
 Units / corrections (same guide, HBM section): counters are in KiB (x1024 -> bytes); on gfx950 FETCH_SIZE tallies the 128-byte
-requests of wide coalesced reads at 64 bytes, i.e. reports HALF the bytes of such streams -> the read side is doubled
-("fetch_corrected"); WRITE_SIZE is used as reported (uncalibrated).  Infinity-Cache hits are counted, not excluded."""
+requests of coalesced reads at 64 bytes, i.e. reports HALF the bytes of such streams -> the read side is doubled; WRITE_SIZE is used
+as reported (uncalibrated).  Infinity-Cache hits are counted, not excluded.
+
+Round 5 -- ONE number per kernel.  tools/calib_fetch.hip / profiles/r05_fetch_calibration.json measure FETCH_SIZE on known byte counts
+(1 GiB buffer, beyond the Infinity Cache): coalesced streams at 16 AND at 4 bytes per lane report 0.500 of their bytes; a random 16-byte
+gather reports 0.996 x (64 bytes per lane), i.e. its 64-byte requests at FACE VALUE; random 48-byte rows 1.66 x their useful bytes (1.5
+sectors per row, partly shared).  So the factor is 2 for kernels whose reads are coalesced streams and 1 for kernels whose reads are
+gathers; GATHER_KERNELS lists the latter (the rasterizer's record / row gathers and binary-search probes) and every kernel's entry says
+which factor it got."""
 import collections, csv, hashlib, json, os, re, sys
 
 
@@ -21,6 +28,10 @@ def sources_sha():
         if f.endswith((".hip", ".h")):
             h.update(f.encode()); h.update(open(os.path.join(d, f), "rb").read())
     return h.hexdigest()[:16]
+
+
+# kernels whose HBM reads are dominated by gathers (<= 16 bytes per lane at unrelated addresses): FETCH_SIZE at face value
+GATHER_KERNELS = ("k_render_fwd", "k_render_bwd", "k_gather_partials", "k_rank_merge", "k_grid_fwd", "k_grid_bwd")
 
 
 def short(name):
@@ -48,11 +59,12 @@ def main():
         if n == 0:
             continue
         fb, wb = f * 1024 / max(nf, 1), w * 1024 / max(nw, 1)
-        out[k] = {"launches": n, "fetch_bytes_per_launch_raw": fb, "fetch_bytes_per_launch_corrected": 2 * fb,
-                  "write_bytes_per_launch": wb, "hbm_bytes_per_launch": 2 * fb + wb, "hbm_bytes_per_launch_uncorrected": fb + wb}
+        factor = 1 if k.split("<")[0] in GATHER_KERNELS else 2
+        out[k] = {"launches": n, "fetch_bytes_per_launch_raw": fb, "fetch_factor": factor, "fetch_bytes_per_launch_corrected": factor * fb,
+                  "write_bytes_per_launch": wb, "hbm_bytes_per_launch": factor * fb + wb}
     json.dump({"sources_sha": sources_sha(), "commit": sys.argv[4] if len(sys.argv) > 4 else None, "plan_dtype": sys.argv[5] if len(sys.argv) > 5 else "f32x", "source": "rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate passes) over python bench.py --steps 2 --warmup 1 --eager",
-               "corrections": "KiB->bytes x1024; gfx950 FETCH_SIZE doubled for wide coalesced reads (MI355X_MICROARCH.md HBM section: calibrated for 16 B/lane streams = the GEMM / conv / norm "
-                              "kernels; for the gather-heavy rasterizer kernels the factor is uncalibrated: hbm_bytes_per_launch_uncorrected .. hbm_bytes_per_launch bracket the truth); WRITE_SIZE as reported",
+               "corrections": "KiB->bytes x1024; FETCH_SIZE x 2 for kernels that read coalesced streams, x 1 for gather kernels (fetch_factor per kernel; "
+                              "calibrated on known byte counts: profiles/r05_fetch_calibration.json, tools/calib_fetch.hip); WRITE_SIZE as reported",
                "kernels": out}, open(sys.argv[3], "w"), indent=1)
     for k, v in sorted(out.items(), key=lambda kv: -kv[1]["hbm_bytes_per_launch"] * kv[1]["launches"])[:14]:
         print("%-34s %5d launches  fetch(corr) %9.2f MB  write %9.2f MB" % (k, v["launches"], v["fetch_bytes_per_launch_corrected"] / 1e6, v["write_bytes_per_launch"] / 1e6))
