@@ -69,6 +69,9 @@ def parse():
     ap.add_argument("--step-graph", action="store_true", help="config c2 / single-GPU c3: the whole step (zero_grad, condition image, animate, raster, "
                                                               "VAE, ControlNet + UNet, backward, Adam) as ONE captured HIP graph replayed per pose "
                                                               "(step_graph.GraphedTrainStep)")
+    ap.add_argument("--moving-camera", action="store_true", help="config c2 / single-view c3: a NEW camera every step (radius, azimuth, elevation, field of "
+                    "view from a table of 64, as the reference's loader samples one per step) -- the captured step follows it through its "
+                    "device-resident camera block (step_graph.GraphedTrainStep.step(pose, camera))")
     ap.add_argument("--eager", action="store_true", help="launch every kernel eagerly (no hipGraph replay of the denoiser/VAE plans)")
     ap.add_argument("--no-gpu-condition", action="store_true", help="fixed condition image instead of the per-step GPU OpenPose image of the posed body")
     ap.add_argument("--sync-pairs", action="store_true", help="exact pair-buffer sizing through a 16-byte read-back per frame")
@@ -396,7 +399,8 @@ def _timed(ctx, fn, steps, warmup):
     return dt
 
 
-def run_sds(ctx, config, dtype=HEADLINE_DTYPE, views=None, steps=None, warmup=None, profile=True, batch_views=None, repeats=None, step_graph=None):
+def run_sds(ctx, config, dtype=HEADLINE_DTYPE, views=None, steps=None, warmup=None, profile=True, batch_views=None, repeats=None, step_graph=None,
+            moving_camera=False):
     """c2 / c3 / c4: SDSStep-based workloads.  Returns the JSON line as a dict (rank 0) or None."""
     args = ctx.args
     steps, warmup = defaults(config, steps, warmup)
@@ -414,6 +418,14 @@ def run_sds(ctx, config, dtype=HEADLINE_DTYPE, views=None, steps=None, warmup=No
     step = sds_step.SDSStep(n_gaussians=G, res=res, device=ctx.dev, rank=ctx.rank, world=ctx.world, guidance=guidance, dist=ctx.dist,
                             async_pair_count=not args.sync_pairs, gpu_condition=not args.no_gpu_condition, views=views, dtype=dtype,
                             guidance_obj=ctx.guidance_for(dtype, per_rank if batch_views else 1) if guidance else None)
+    moving = bool(getattr(args, "moving_camera", False) or moving_camera) and views == 1 and ctx.world == 1
+    if moving:
+        # the reference samples a camera per step (data/camera/__init__.py:124-165); its loader builds the matrices in dataloader workers,
+        # so the table is made ahead of the timed region here as well
+        from dreamwaltz_g_amd import camera as _cam
+        table = [_cam.make_camera(radius=1.8 + 0.05 * (i % 7), azimuth=(360.0 / 64) * i, elevation=70.0 + 2.5 * (i % 5), fovy=48.0 + 1.5 * (i % 6),
+                                  height=res, width=res, device="cpu") for i in range(64)]
+        step.camera_fn = lambda i: table[i % 64]
     if not args.eager:
         step.capture_graphs()       # denoiser / VAE plans replay as hipGraphs (identical kernels, one launch each)
     else:
@@ -501,6 +513,7 @@ def run_sds(ctx, config, dtype=HEADLINE_DTYPE, views=None, steps=None, warmup=No
         out["raster_mpix_per_s"] = rf["mpix_per_s"] if rf else None      # the rasterizer's own forward rate (pixels / forward-chain time)
         out["kernel_ms_per_step"] = {k: round(v[1] / prof_steps, 4) for k, v in sorted(prof.items(), key=lambda kv: -kv[1][1])[:40]}
     out["redone_frames"] = step.trainer.redone_frames
+    out["camera"] = "a new camera every step (64-entry table: radius, azimuth, elevation, field of view all move)" if moving else "fixed"
     if whole_graph:
         out["graph_recaptures"] = recaptures
     out["launch_mode"] = ("eager" if args.eager else "the WHOLE step (zero_grad, animate, raster fwd + bwd, Adam) replayed as one captured HIP graph per pose"
@@ -614,8 +627,8 @@ def run_c1(ctx, steps=None, warmup=None):
             "kernel_ms_per_step": {k: round(v[1] / ps, 4) for k, v in sorted(prof.items(), key=lambda kv: -kv[1][1])[:12]}}
 
 
-def _brief(line, keys=("value", "unit", "ms_per_step", "steps", "warmup", "repeats", "launch_mode", "dtype", "views_per_s", "views_per_step", "config", "roofline",
-                       "raster_mpix_per_s", "cpu_baseline", "metric", "redone_frames")):
+def _brief(line, keys=("value", "unit", "ms_per_step", "steps", "warmup", "repeats", "launch_mode", "camera", "dtype", "views_per_s", "views_per_step", "config",
+                       "roofline", "raster_mpix_per_s", "cpu_baseline", "metric", "redone_frames")):
     return {k: line[k] for k in keys if k in line}
 
 
@@ -649,6 +662,8 @@ def main():
             pre_cfgs["c2"] = _brief(c2)
             c2e = run_sds(ctx, "c2", steps=200, warmup=20, step_graph=False, profile=False)
             pre_cfgs["c2_eager_launches"] = _brief(c2e, ("value", "unit", "ms_per_step", "steps", "warmup", "launch_mode"))
+            c2m = run_sds(ctx, "c2", steps=200, warmup=20, step_graph=True, profile=False, moving_camera=True)     # ... with the reference's per-step camera
+            pre_cfgs["c2_moving_camera"] = _brief(c2m, ("value", "unit", "ms_per_step", "steps", "warmup", "launch_mode", "camera", "graph_recaptures"))
             c5 = run_c5(ctx, 200, 20)
             c1 = run_c1(ctx, 200, 20)
             if cpu_ok:
