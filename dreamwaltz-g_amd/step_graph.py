@@ -202,6 +202,12 @@ class GraphedTrainStep:
         state.overflow, state.pending, state.frozen = False, False, True
         for entry in renderer._visit_orders.values():      # the periodic refresh of the binning order must not fall into the captured step
             entry[1] = 0
+        # Capture has to run on a side stream, while the parameters' AccumulateGrad nodes were made by the warm-up steps on the current one:
+        # autograd warns once per process about that mismatch.  Inside a capture the accumulation is ordered by the capture itself (one
+        # stream), so the warning has nothing to report here.
+        warn_off = getattr(torch.autograd.graph, "set_warn_on_accumulate_grad_stream_mismatch", None)
+        if warn_off is not None:
+            warn_off(False)
         self._side.wait_stream(torch.cuda.current_stream(self.device))
         with torch.cuda.stream(self._side):
             key = renderer.pair_state_key(self.device, H, W)

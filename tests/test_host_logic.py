@@ -307,7 +307,14 @@ def test_mlp_gradients_go_in_place_only_into_genuine_flat_gradient_slices():
     assert mlp._flat_slice(w, w) is None                                           # zero_grad(set_to_none=True)-style callers
     w.grad = g.t().contiguous().t()                                                # same shape, not contiguous: not the flat slice
     assert mlp._flat_slice(w, w) is None
+    w.grad = torch.zeros_like(g)                                                   # same shape, contiguous, but REBOUND by the user: the optimizer never reads it
+    assert mlp._flat_slice(w, w) is None
     w.grad = g
+    assert mlp._flat_slice(w, w) is flat
+    assert mlp._flat_slice(w, w, needed=False) is None                             # autograd did not ask for this gradient (torch.autograd.grad of another input)
+    w.requires_grad_(False)
+    assert mlp._flat_slice(w, w) is None                                           # a frozen parameter keeps its slice untouched
+    w.requires_grad_(True)
     assert mlp._flat_slice(w, w) is flat
     flat.release([w, b])
     assert mlp._flat_slice(w, w) is None                                           # buffers replaced (densifier resize): no stale target
