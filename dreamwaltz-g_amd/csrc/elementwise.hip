@@ -178,16 +178,30 @@ __global__ __launch_bounds__(256) void k_mlp_wgrad_final(int blocks, int N, int 
 // Whole per-Gaussian MLP in ONE launch: y = L_n(... act(L_1(x)) ...), widths <= 64 (nerf_model.py:12-33: 32-64-64-4, ReLU;
 // deform_model.py:102-143: 32(+pose bias)-64-64-64-64-10, leaky ReLU).  Layer by layer these were 8 GEMM launches that each wrote a
 // [M, 64] fp32 activation to HBM and read it back (mlp_fwd: 0.35 ms of the 2 ms c5 frame).  Here a wave keeps ITS 32 rows of
-// activations in LDS across all layers (overwritten in place once a layer's MFMAs are done), the layer's weights are staged in LDS for
-// the four waves, and the contraction is exact-f32 MFMA (v_mfma_f32_32x32x2_f32, transposed: a lane owns one row and groups of four
+// activations in LDS across all layers (overwritten in place once a layer's MFMAs are done), every layer's weights sit in LDS for the
+// whole launch, and the contraction is exact-f32 MFMA (v_mfma_f32_32x32x2_f32, transposed: a lane owns one row and groups of four
 // consecutive output columns).  Hidden activations are written out only when the caller keeps them for the backward.
+//
+// Round 5.  At 300 k rows the static network took 93 us and the deformation network 190 us where their MFMAs need 31 and 62.  Timing
+// variants (MFMAs off / epilogue off) and the SQ counters put it on the code AROUND the MFMAs: the epilogue chose the activation and
+// tested the keep-hidden pointer per VALUE (six scalar branches and a dependent 4-byte LDS read of the bias for each of a lane's 32
+// values per layer), and the rows were staged with an integer division per element.  Now the hidden layers' activation and the
+// keep-hidden flag are compile-time (ACT_H, KEEP: the avatar's networks use one activation for all hidden layers), the accumulators
+// start at the bias (eight 16-byte LDS reads issued before the MFMAs instead of 32 dependent ones after), a layer's output goes to LDS
+// as 8-byte pairs, the rows come in as 16-byte pieces split by shifts with the NEXT group's pieces in flight while this group
+// computes, and the per-layer scalars are read from LDS instead of the argument struct: 70 and 144 us.  (Tried and dropped: keeping
+// the activations in registers -- the weights' columns permuted to the order the previous layer's accumulators hold them, no LDS
+// tile, twelve waves per CU -- was SLOWER, 88 / 155 us at its best wave count, whether the rows were loaded per lane in that layout
+// or coalesced and turned through LDS; the output of a 10-wide head turned through LDS into consecutive dwords: no change.)
 // ---------------------------------------------------------------------------------------------------------------------
 #define MLPC_MAXL 6
 #define MLPC_LD 68          // row stride in floats: multiple of 4 (16-byte fragment reads)
+#define MLPC_WAVES 8        // waves per workgroup sharing one LDS copy of the weights: two per SIMD hide each other's LDS / epilogue latencies
 struct MlpChainP {
     const float* x; int M, Kin, ldx, nlayers;
     const float* extra; int n_extra;        // vector folded into the first layer's bias through W_0's trailing columns (may be null / 0)
     int waves;                              // waves per workgroup of this launch (<= MLPC_WAVES)
+    int kshift;                             // log2(Kin) when Kin is a power of two and x rows are 16-byte aligned (vector staging), else -1
     const float* W[MLPC_MAXL]; const float* b[MLPC_MAXL]; float* hidden[MLPC_MAXL];
     int ldw[MLPC_MAXL], N[MLPC_MAXL], K[MLPC_MAXL], act[MLPC_MAXL];
     float* out; int ldo;
@@ -200,18 +214,88 @@ __device__ __forceinline__ float mlpc_act(float v, int act) {
 // as [half][ks] so that four consecutive steps are ONE 16-byte read (the interleaved order costs a 4-byte read per MFMA and operand)
 __device__ __forceinline__ int mlpc_pos(int k, int K) { return (k & 1) * (K >> 1) + (k >> 1); }
 
+// This lane's 16-byte pieces of the 32 rows starting at r0 (piece i = lane + 64 u: row i / (Kin / 4), columns 4 (i % (Kin / 4)) ..): coalesced,
+// all in flight at once.  Rows past M read as zero.
+__device__ __forceinline__ void mlpc_load_rows(const MlpChainP& p, int r0, int lane, int kq, float4 (&xr)[8]) {
+#pragma unroll
+    for (int u = 0; u < 8; u++) {
+        const int i = lane + 64 * u;
+        const int r = i >> (p.kshift - 2), c = i & (kq - 1);
+        xr[u] = (i < 32 * kq && r0 + r < p.M) ? *reinterpret_cast<const float4*>(p.x + (size_t)(r0 + r) * p.ldx + 4 * c)
+                                              : make_float4(0.f, 0.f, 0.f, 0.f);
+    }
+}
+
+// Activation of a HIDDEN layer's accumulators (which started at the bias; lane (m, half) holds row m, columns t*32 + 8q + 4 half + e), then
+// the next layer's input in place in LDS (k-permuted: two 8-byte stores per four columns) and, when the backward keeps it (KEEP), the
+// activation to HBM.  ACT is the layer's activation when the host found one activation for all hidden layers (1 ReLU, 2 leaky ReLU),
+// -1: chosen per value from `act` (any other chain).
+template <int ACT, bool KEEP>
+__device__ __forceinline__ void mlpc_epilogue_hidden(const __attribute__((ext_vector_type(16))) float& acc0, const __attribute__((ext_vector_type(16))) float& acc1,
+                                                     float* sX, int m, int half, int N, int Np, int act, float* hidden, int grow, int M) {
+#pragma unroll
+    for (int t = 0; t < 2; t++) {
+        if (t * 32 >= Np) break;
+#pragma unroll
+        for (int q = 0; q < 4; q++) {
+            const int n0 = t * 32 + 8 * q + 4 * half;
+            if (n0 >= N) continue;                          // padding columns of a width that is not a multiple of 32 (widths are multiples of 8: n0 < N covers n0 + 3)
+            float v[4];
+#pragma unroll
+            for (int e = 0; e < 4; e++) v[e] = mlpc_act(t == 0 ? acc0[4 * q + e] : acc1[4 * q + e], ACT < 0 ? act : ACT);
+            float* row = sX + m * MLPC_LD + (n0 >> 1);
+            *reinterpret_cast<float2*>(row) = make_float2(v[0], v[2]);
+            *reinterpret_cast<float2*>(row + (N >> 1)) = make_float2(v[1], v[3]);
+            if (KEEP) { if (grow < M) *reinterpret_cast<float4*>(hidden + (size_t)grow * N + n0) = make_float4(v[0], v[1], v[2], v[3]); }
+        }
+    }
+}
+
+// The LAST layer: activation (any of the four, per value: a 4- or 10-wide head is one or two blocks of four columns) -> `out`.
+__device__ __forceinline__ void mlpc_epilogue_last(const __attribute__((ext_vector_type(16))) float& acc0, const __attribute__((ext_vector_type(16))) float& acc1,
+                                                   int half, int N, int Np, int act, float* out, int ldo, bool out_vec, int grow, int M) {
+    if (grow >= M) return;
+#pragma unroll
+    for (int t = 0; t < 2; t++) {
+        if (t * 32 >= Np) break;
+#pragma unroll
+        for (int q = 0; q < 4; q++) {
+            const int n0 = t * 32 + 8 * q + 4 * half;
+            if (n0 >= N) continue;
+            float v[4];
+#pragma unroll
+            for (int e = 0; e < 4; e++) v[e] = mlpc_act(t == 0 ? acc0[4 * q + e] : acc1[4 * q + e], act);
+            if (out_vec && n0 + 3 < N) *reinterpret_cast<float4*>(out + (size_t)grow * ldo + n0) = make_float4(v[0], v[1], v[2], v[3]);
+            else {
+#pragma unroll
+                for (int e = 0; e < 4; e++) if (n0 + e < N) out[(size_t)grow * ldo + n0 + e] = v[e];
+            }
+        }
+    }
+}
+
 // PERSISTENT waves: a workgroup stages ALL layers' weights in LDS once and then every wave walks its own 32-row groups to the end of
 // the input with no workgroup barrier at all (its activations are wave-private, the weights read-only) -- restaging the weights per
 // 128-row tile with two barriers per layer left the MFMA pipe 30 % busy.
-#define MLPC_WAVES 8        // waves per workgroup sharing one LDS copy of the weights: two per SIMD hide each other's LDS / epilogue latencies
+template <int ACT_H, bool KEEP>
 __global__ __launch_bounds__(64 * MLPC_WAVES) void k_mlp_chain(MlpChainP p, int wfloats) {
     typedef __attribute__((ext_vector_type(16))) float f32x16_t;
     extern __shared__ __attribute__((aligned(16))) float smem[];
     float* sWall = smem;                                    // per layer [Np][MLPC_LD], k permuted
-    float* sBall = smem + wfloats;                          // [nlayers][64]
-    float* sXall = sBall + MLPC_MAXL * 64;                  // [MLPC_WAVES][32][MLPC_LD]
+    float* sBall = smem + wfloats;                          // [MLPC_MAXL][64]
+    float* sXall = sBall + MLPC_MAXL * 64;                  // [waves][32][MLPC_LD]
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int nthr = 64 * p.waves;
+    // Per-layer scalars, read from LDS inside the row-group loop: indexing the by-value argument struct with the (run-time) layer number
+    // compiles to scalar loads from the kernarg segment inside the loop; they are read ONCE here, with constant indices, by one thread.
+    __shared__ int sMeta[MLPC_MAXL][8];
+    if (tid == 0) {
+#pragma unroll
+        for (int l = 0; l < MLPC_MAXL; l++) {
+            const unsigned long long h = (unsigned long long)p.hidden[l];
+            sMeta[l][0] = p.N[l]; sMeta[l][1] = p.K[l]; sMeta[l][2] = p.act[l]; sMeta[l][3] = (int)(unsigned)h; sMeta[l][4] = (int)(unsigned)(h >> 32);
+        }
+    }
     {
         int off = 0;
         for (int l = 0; l < p.nlayers; l++) {
@@ -265,34 +349,64 @@ __global__ __launch_bounds__(64 * MLPC_WAVES) void k_mlp_chain(MlpChainP p, int 
     __syncthreads();
     float* sX = sXall + wave * 32 * MLPC_LD;
     const int m = lane & 31, half = lane >> 5;
-    const int ngroups = (p.M + 31) >> 5;
-    for (int g = blockIdx.x * p.waves + wave; g < ngroups; g += gridDim.x * p.waves) {
+    const int M = p.M, nlayers = p.nlayers, ldo = p.ldo;
+    float* const out = p.out;
+    const bool out_vec = !(ldo & 3) && !((uintptr_t)out & 15);
+    const int ngroups = (M + 31) >> 5;
+    const int kq = p.Kin >> 2;                              // 16-byte pieces per row
+    const bool vec = p.kshift >= 0;                         // Kin in {8, 16, 32, 64}, x rows 16-byte aligned (host)
+    float4 xr[8];                                           // 32 rows x Kin <= 64 floats = at most 8 pieces per lane
+    const int g0 = blockIdx.x * p.waves + wave, gstep = gridDim.x * p.waves;
+    if (vec && g0 < ngroups) mlpc_load_rows(p, g0 * 32, lane, kq, xr);
+    for (int g = g0; g < ngroups; g += gstep) {
         const int r0 = g * 32;
         __builtin_amdgcn_wave_barrier();
-        for (int i0 = lane; i0 < 32 * p.Kin; i0 += 8 * 64) {        // this wave's rows -> LDS, coalesced, eight loads in flight per lane
-            float v[8];
+        if (vec) {
 #pragma unroll
             for (int u = 0; u < 8; u++) {
-                const int i = i0 + 64 * u, r = i / p.Kin, k = i - r * p.Kin;
-                v[u] = (i < 32 * p.Kin && r0 + r < p.M) ? p.x[(size_t)(r0 + r) * p.ldx + k] : 0.f;
+                const int i = lane + 64 * u;
+                if (i < 32 * kq) {
+                    const int r = i >> (p.kshift - 2), k = (i & (kq - 1)) << 2;        // columns k .. k+3: even ones to [k/2, k/2+1], odd ones behind K/2
+                    float* row = sX + r * MLPC_LD + (k >> 1);
+                    *reinterpret_cast<float2*>(row) = make_float2(xr[u].x, xr[u].z);
+                    *reinterpret_cast<float2*>(row + (p.Kin >> 1)) = make_float2(xr[u].y, xr[u].w);
+                }
             }
+            if (g + gstep < ngroups) mlpc_load_rows(p, (g + gstep) * 32, lane, kq, xr);   // in flight while the layers below run
+        } else {
+            for (int i0 = lane; i0 < 32 * p.Kin; i0 += 8 * 64) {        // generic widths: eight 4-byte loads in flight per lane
+                float v[8];
 #pragma unroll
-            for (int u = 0; u < 8; u++) {
-                const int i = i0 + 64 * u, r = i / p.Kin, k = i - r * p.Kin;
-                if (i < 32 * p.Kin) sX[r * MLPC_LD + mlpc_pos(k, p.Kin)] = v[u];
+                for (int u = 0; u < 8; u++) {
+                    const int i = i0 + 64 * u, r = i / p.Kin, k = i - r * p.Kin;
+                    v[u] = (i < 32 * p.Kin && r0 + r < M) ? p.x[(size_t)(r0 + r) * p.ldx + k] : 0.f;
+                }
+#pragma unroll
+                for (int u = 0; u < 8; u++) {
+                    const int i = i0 + 64 * u, r = i / p.Kin, k = i - r * p.Kin;
+                    if (i < 32 * p.Kin) sX[r * MLPC_LD + mlpc_pos(k, p.Kin)] = v[u];
+                }
             }
         }
         __builtin_amdgcn_wave_barrier();
         const int grow = r0 + m;
         int off = 0;
-        for (int l = 0; l < p.nlayers; l++) {
-            const int N = p.N[l], K = p.K[l], Np = (N + 31) & ~31;
+        for (int l = 0; l < nlayers; l++) {
+            const int N = __builtin_amdgcn_readfirstlane(sMeta[l][0]), K = __builtin_amdgcn_readfirstlane(sMeta[l][1]), Np = (N + 31) & ~31;
             const float* sW = sWall + off;
             const float* sB = sBall + l * 64;
             off += Np * MLPC_LD;
+            // the accumulators START at the bias (lane (m, half) owns columns t*32 + 8q + 4 half + e): the epilogue then has no LDS read to wait for
             f32x16_t acc0, acc1;
+            {
+                const float4* pb = reinterpret_cast<const float4*>(sB + 4 * half);
 #pragma unroll
-            for (int r = 0; r < 16; r++) { acc0[r] = 0.f; acc1[r] = 0.f; }
+                for (int q = 0; q < 4; q++) {
+                    const float4 b0 = pb[2 * q], b1 = pb[8 + 2 * q];
+                    acc0[4 * q] = b0.x; acc0[4 * q + 1] = b0.y; acc0[4 * q + 2] = b0.z; acc0[4 * q + 3] = b0.w;
+                    acc1[4 * q] = b1.x; acc1[4 * q + 1] = b1.y; acc1[4 * q + 2] = b1.z; acc1[4 * q + 3] = b1.w;
+                }
+            }
             const float4* px = reinterpret_cast<const float4*>(sX + m * MLPC_LD + half * (K >> 1));
             const float4* pw0 = reinterpret_cast<const float4*>(sW + m * MLPC_LD + half * (K >> 1));
             const float4* pw1 = reinterpret_cast<const float4*>(sW + (32 + m) * MLPC_LD + half * (K >> 1));
@@ -321,29 +435,14 @@ __global__ __launch_bounds__(64 * MLPC_WAVES) void k_mlp_chain(MlpChainP p, int 
                 }
             }
             __builtin_amdgcn_wave_barrier();                // every lane's reads of this layer's input precede the in-place writes
-            const bool last = l + 1 == p.nlayers;
-#pragma unroll
-            for (int t = 0; t < 2; t++) {
-                if (t * 32 >= Np) break;
-                const f32x16_t& acc = t == 0 ? acc0 : acc1;
-#pragma unroll
-                for (int q = 0; q < 4; q++) {
-                    const int n0 = t * 32 + 8 * q + 4 * half;
-                    float v[4];
-#pragma unroll
-                    for (int e = 0; e < 4; e++) v[e] = mlpc_act(acc[4 * q + e] + sB[n0 + e], p.act[l]);
-                    if (!last) {
-                        if (n0 < N) {       // (the padding columns of a width that is not a multiple of 32 would land on valid positions)
-#pragma unroll
-                            for (int e = 0; e < 4; e++) sX[m * MLPC_LD + mlpc_pos(n0 + e, N)] = v[e];  // next layer's input (K = N), in place
-                        }
-                        if (p.hidden[l] && grow < p.M && n0 < N)
-                            *reinterpret_cast<float4*>(p.hidden[l] + (size_t)grow * N + n0) = make_float4(v[0], v[1], v[2], v[3]);
-                    } else if (grow < p.M) {
-#pragma unroll
-                        for (int e = 0; e < 4; e++) if (n0 + e < N) p.out[(size_t)grow * p.ldo + n0 + e] = v[e];
-                    }
-                }
+            const int act = __builtin_amdgcn_readfirstlane(sMeta[l][2]);
+            if (l + 1 < nlayers) {
+                float* hid = nullptr;
+                if (KEEP) hid = reinterpret_cast<float*>((unsigned long long)(unsigned)__builtin_amdgcn_readfirstlane(sMeta[l][3]) |
+                                                         ((unsigned long long)(unsigned)__builtin_amdgcn_readfirstlane(sMeta[l][4]) << 32));
+                mlpc_epilogue_hidden<ACT_H, KEEP>(acc0, acc1, sX, m, half, N, Np, act, hid, grow, M);
+            } else {
+                mlpc_epilogue_last(acc0, acc1, half, N, Np, act, out, ldo, out_vec, grow, M);
             }
             __builtin_amdgcn_wave_barrier();
         }
@@ -795,19 +894,33 @@ int dwg_mlp_chain_forward(int32_t M, int32_t Kin, const float* x, int32_t ldx, i
     }
     int wfloats = 0;
     for (int l = 0; l < nlayers; l++) wfloats += ((widths[l] + 31) & ~31) * MLPC_LD;
+    p.kshift = -1;
+    if (!(Kin & (Kin - 1)) && !(ldx & 3) && !((uintptr_t)x & 15)) { p.kshift = 0; while ((1 << p.kshift) < Kin) p.kshift++; }
     const size_t lds = ((size_t)wfloats + MLPC_MAXL * 64 + MLPC_WAVES * 32 * MLPC_LD) * sizeof(float);       // <= 150 KiB: one workgroup per CU
-    static bool attr_set = false;
-    if (!attr_set) {
-        hipFuncSetAttribute(reinterpret_cast<const void*>(&k_mlp_chain), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-        attr_set = true;
-    }
     // waves per workgroup: eight share one LDS copy of the weights when there are row groups for every SIMD of the chip (two waves per SIMD
     // hide each other's latencies); a small batch (the 10 k-Gaussian frames: 313 groups) runs four per workgroup -- twice the CUs, one wave per
     // SIMD, so that a group's serial chain of layers has the MFMA pipe to itself (c1: the deformation network's launch 54 us before)
     const int groups = dwg_cdiv(M, 32);
     p.waves = groups <= 1024 ? 4 : MLPC_WAVES;
     const int wgs = dwg_cdiv(groups, p.waves);
-    DWG_LAUNCH("mlp_chain_fwd", k_mlp_chain, dim3(wgs < 256 ? wgs : 256), dim3(64 * p.waves), lds, (hipStream_t)stream, p, wfloats);    // persistent
+    // one activation for all hidden layers (the avatar's two networks: ReLU, leaky ReLU) and whether hidden activations are kept are
+    // compile-time properties of the launch; anything else runs the generic instantiation
+    int act_h = nlayers > 1 ? acts[0] : 1;
+    for (int l = 1; l + 1 < nlayers; l++) if (acts[l] != act_h) act_h = -1;
+    if (act_h != 1 && act_h != 2) act_h = -1;
+    bool keep = false;
+    for (int l = 0; l + 1 < nlayers; l++) keep = keep || p.hidden[l];
+    for (int l = 0; l + 1 < nlayers; l++) if (keep && !p.hidden[l]) return DWG_E_ARG;        // all hidden activations or none
+    typedef void (*kern_t)(MlpChainP, int);
+    static const kern_t kerns[6] = {k_mlp_chain<1, false>, k_mlp_chain<1, true>, k_mlp_chain<2, false>, k_mlp_chain<2, true>,
+                                    k_mlp_chain<-1, false>, k_mlp_chain<-1, true>};
+    static bool attr_set = false;
+    if (!attr_set) {
+        for (int i = 0; i < 6; i++) (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kerns[i]), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        attr_set = true;
+    }
+    const kern_t kern = kerns[(act_h == 1 ? 0 : act_h == 2 ? 2 : 4) + (keep ? 1 : 0)];
+    DWG_LAUNCH("mlp_chain_fwd", kern, dim3(wgs < 256 ? wgs : 256), dim3(64 * p.waves), lds, (hipStream_t)stream, p, wfloats);    // persistent
     DWG_RETURN_IF_LAUNCH_FAILED();
     return DWG_OK;
 }

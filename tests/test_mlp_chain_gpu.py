@@ -40,6 +40,28 @@ def _reference(x, layers, acts, extra):
     return x, ps, h
 
 
+def _without_rows_on_a_kink(x, layers, acts, extra, eps=1e-5):
+    h = x.double()
+    e = None if extra is None else extra.detach().double().cpu().reshape(-1)
+    near = torch.zeros(x.shape[0], dtype=torch.bool)
+    for l, ((w, b), a) in enumerate(zip(layers, acts)):
+        w64 = w.detach().double().cpu()
+        K = h.shape[1]
+        z = h @ w64[:, :K].T
+        if l == 0 and e is not None:
+            z = z + (w64[:, K:] @ e)[None, :]
+        if b is not None:
+            z = z + b.detach().double().cpu()
+        if a in ("relu", "leaky_relu"):
+            near |= (z.abs() < eps).any(1)
+        h = _act64(z, a)
+    good = torch.nonzero(~near).flatten()
+    if near.any() and good.numel():
+        x = x.clone()
+        x[near] = x[good[0]].clone()
+    return x
+
+
 CASES = [
     # (M, Kin, widths, acts, n_extra, bias)
     (50001, 32, (64, 64, 4), ("relu", "relu", None), 0, True),                                                  # the static MLP (colour | opacity)
@@ -59,7 +81,7 @@ def test_chain_forward_and_fused_backward_match_float64_autograd(M, Kin, widths,
     assert not mlp.PER_LAYER_BACKWARD
     dev = torch.device("cuda")
     g = torch.Generator().manual_seed(M + Kin)
-    x = torch.randn(M, Kin, generator=g).to(dev).requires_grad_(True)
+    x = torch.randn(M, Kin, generator=g)
     layers, k = [], Kin
     for l, n in enumerate(widths):
         kin = k + (n_extra if l == 0 else 0)
@@ -68,6 +90,11 @@ def test_chain_forward_and_fused_backward_match_float64_autograd(M, Kin, widths,
         layers.append((w, b)); k = n
     extra = torch.randn(n_extra, generator=g).to(dev) if n_extra else None
     gy = torch.randn(M, widths[-1], generator=g).to(dev)
+    # ReLU / leaky ReLU have a kink at 0: a row with a pre-activation within rounding distance of it takes EITHER slope legitimately (the
+    # fp32 sum's order decides), and one such unit among 50 001 x 128 moves the rel-L2 of every gradient by ~1e-3.  Rows whose float64
+    # pre-activations come closer than 1e-5 to a kink are replaced by a row that does not (same M, same tails).
+    x = _without_rows_on_a_kink(x, layers, acts, extra)
+    x = x.to(dev).requires_grad_(True)
     y = mlp.mlp_chain(x, layers, list(acts), extra=extra)
     y.backward(gy)
     xr, pr, yr = _reference(x, layers, acts, extra)
