@@ -74,6 +74,34 @@ class Scene(nn.Module):
             gaussians.positions = gaussians.positions + t.unsqueeze(0)
         return gaussians
 
+    def forward_frames(self, data: dict, poses, bg_mode: Optional[str] = None) -> dict:
+        """Playback of F pose frames under one camera: `animate` per pose, then ONE rasterizer launch chain for all of them
+        (renderer.render_frames).  Frame f equals `forward(data, poses[f], use_densifier=False, bg_mode=bg_mode)` bit for bit -- the
+        reference's evaluation loop renders such sequences one pose at a time under inference mode (trainer.py:1019-1150).  Single avatar,
+        no gradients.  -> {'image' | 'image_fg' | 'depth' | 'alpha': [F, H, W, C]}."""
+        if self.avatars is not None:
+            raise NotImplementedError("forward_frames renders one avatar per frame")
+        frames = []
+        for pose in poses:
+            g = self.avatar_forward(smpl_observed_inputs=pose)
+            if self.use_zero_scales:
+                g.scales = g.scales * 0.1
+            if self.use_constant_colors:
+                g.colors = self.constant_colors.expand(g.colors.size(0), -1)
+            if self.use_constant_opacities:
+                g.opacities = self.constant_opacities.expand(g.opacities.size(0), -1)
+            if self.use_fixed_n_gaussians:
+                g = downsample_gaussians(g, self.fixed_n_gaussians)
+            frames.append(g)
+        outputs = self.renderer.render_frames(data=data, frames=frames)
+        if bg_mode in self.pure_colors:
+            outputs['image_bg'] = self.pure_colors.get_background_like(bg_mode, outputs['image'])
+            outputs['image_fg'] = outputs['image']
+            outputs['image'] = outputs['image'] + outputs['image_bg'] * (1 - outputs['alpha'])
+        else:
+            outputs['image_fg'] = outputs['image']
+        return outputs
+
     def forward(self, data: dict, smpl_observed_inputs: Optional[dict] = None, use_densifier: bool = True, bg_mode: Optional[str] = None,
                 **kwargs):
         if self.avatars is None:

@@ -70,3 +70,27 @@ def test_player_needs_the_async_pair_count():
     data = camera.make_camera(height=64, width=64, device=dev)
     with pytest.raises(ValueError):
         player.GraphedAnimation(scene, data, synth.random_smpl_inputs(seed=0, device=dev))
+
+
+@pytest.mark.parametrize("bg_mode", [None, "white"])
+def test_frames_per_launch_playback_equals_frame_by_frame(bg_mode):
+    """Scene.forward_frames: F pose frames animated one by one, rasterized by ONE launch chain (include/dwg_raster.h dwg_raster_frames) == the
+    reference's frame-by-frame evaluation loop (trainer.py:1019-1150: Scene.forward per pose under inference mode), every output bit."""
+    from dreamwaltz_g_amd import synth
+    dev = torch.device("cuda:0")
+    scene, data = _scene(20000, 256, dev)
+    poses = [synth.random_smpl_inputs(seed=10 + i, device=dev) for i in range(5)]
+    with torch.inference_mode():
+        single = [scene.forward(data, smpl_observed_inputs=p, use_densifier=False, bg_mode=bg_mode) for p in poses]
+        single = [{k: o[k].clone() for k in ("image", "image_fg", "alpha", "depth")} for o in single]
+        for F in (1, 3, 5):
+            batch = scene.forward_frames(data, poses[:F], bg_mode=bg_mode)
+            assert batch["image"].shape == (F, 256, 256, 3)
+            for f in range(F):
+                for k in ("image", "image_fg", "alpha", "depth"):
+                    assert torch.equal(batch[k][f:f + 1], single[f][k]), (F, f, k)
+            hdr = scene.renderer.last_frames_headers.cpu()
+            assert (hdr[:, 0] > 0).all() and (hdr[:, 1] == 0).all()           # pairs counted, nothing truncated
+    with pytest.raises(RuntimeError):
+        g = scene.avatar_forward(smpl_observed_inputs=poses[0])              # gradients enabled: not the playback path
+        scene.renderer.render_frames(data, [g])
