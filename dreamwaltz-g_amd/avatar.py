@@ -505,6 +505,7 @@ class DreamWaltzG(nn.Module):
         """Everything derived from parameters / buffers that a checkpoint load or an in-place edit may have changed."""
         self.cache_generation = getattr(self, "cache_generation", 0) + 1       # the trainer refills the caches on ONE stream (trainer._check_caches)
         self._canonical_cache = None
+        self._frozen_cache = None
         self._canonical_vertices = {}
         self.nerf_encoder._host_offsets_py = None
         self.lbs_model._subsets = []
@@ -587,6 +588,14 @@ class DreamWaltzG(nn.Module):
     def forward(self):
         return self.animate(None)
 
+    frozen_playback = False         # opt-in (Scene.forward_frames(frozen_avatar=True)): keep the pose-independent part of `animate` across frames
+    _frozen_cache = None
+
+    def _frozen_key(self):
+        ts = list(self.parameters()) + list(self.buffers())
+        return (optim.PARAM_EPOCH[0], getattr(self, "cache_generation", 0), self._nerf_bound_host,
+                tuple((t.data_ptr(), t._version, tuple(t.shape)) for t in ts))
+
     def animate(self, smpl_observed_inputs: Optional[dict] = None) -> GaussianOutput:
         """avatar.py:1500-1588."""
         if smpl_observed_inputs is None:
@@ -596,8 +605,14 @@ class DreamWaltzG(nn.Module):
         _, cV, ctr = self._canonical_cache
         _, oV, otr = self.lbs_model.forward(**smpl_observed_inputs)
         positions = self._positions
-        canonical_positions = self.lbs_transform(positions, ctr)
         N = positions.shape[0]
+        # Playback of a FROZEN avatar (opt-in: `frozen_playback`, gradients off): the canonical positions, their encoding and the static
+        # network's colours / opacities do not depend on the pose -- they are kept from the previous frame while no parameter has changed
+        # (key: the optimizers' step epoch, the cache generation, every parameter's / buffer's address and version counter).  The
+        # reference recomputes them per frame (avatar.py:1500-1588); the values are the same bits either way.
+        frozen_key = self._frozen_key() if (self.frozen_playback and not torch.is_grad_enabled() and not self.learn_betas) else None
+        hit = frozen_key is not None and self._frozen_cache is not None and self._frozen_cache[0] == frozen_key
+        canonical_positions = None if hit else self.lbs_transform(positions, ctr)
         if self.learn_betas:                         # avatar.py:1551-1553 (sub-stage 2.1: --render.learn_hand_betas True)
             _, cVb, _ = self.lbs_model.forward(**self.smpl_canonical_inputs, extra_betas=self._betas)
             _, oVb, _ = self.lbs_model.forward(**smpl_observed_inputs, extra_betas=self._betas)
@@ -617,9 +632,13 @@ class DreamWaltzG(nn.Module):
                     cvc = self._canonical_vertices[name] = cV.squeeze(0).transform_points(vc, indices=gm.predefined_vertex_indices)
                 ovc = oV.squeeze(0).transform_points(vc, indices=gm.predefined_vertex_indices)
             mesh_parts.append(gm(cvc, ovc))          # (cpos, pos_m, sc_m, q_m): one HIP launch each way (csrc/meshbind.hip)
-        all_cpos = torch.cat([canonical_positions] + [mp[0] for mp in mesh_parts], dim=0) if mesh_parts else canonical_positions
-        enc_all = self.nerf_encoder(all_cpos, bound=self._nerf_bound_host)
-        oc_all = self.nerf_opacity_and_color_net(enc_all)                      # static_mlp_forward (avatar.py:1283-1290), all rows
+        if hit:
+            enc_all, oc_all = self._frozen_cache[1], self._frozen_cache[2]
+        else:
+            all_cpos = torch.cat([canonical_positions] + [mp[0] for mp in mesh_parts], dim=0) if mesh_parts else canonical_positions
+            enc_all = self.nerf_encoder(all_cpos, bound=self._nerf_bound_host)
+            oc_all = self.nerf_opacity_and_color_net(enc_all)                  # static_mlp_forward (avatar.py:1283-1290), all rows
+            self._frozen_cache = (frozen_key, enc_all, oc_all) if frozen_key is not None else None
         enc = enc_all[:N]
         body_pose = smpl_observed_inputs.get('body_pose')
         if body_pose is None:

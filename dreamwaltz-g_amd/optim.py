@@ -101,6 +101,11 @@ class FlatBuffers:
                 p._dwg_flat = None
 
 
+# Bumped by everything that writes parameters behind autograd's back (the fused Adam launches write the flat buffer through a raw pointer:
+# no tensor version counter moves): caches of parameter-derived values key on it (avatar.DreamWaltzG._frozen_key).
+PARAM_EPOCH = [0]
+
+
 class FlatOptimizer:
     """One of the named optimizers, as a view [start, end) of the flat buffers: same surface the trainer uses on the reference's
     objects (param_groups, zero_grad, step, state_dict / load_state_dict, and update_learning_rate for 'avatar')."""
@@ -154,6 +159,7 @@ class FlatOptimizer:
         instead of this process's own record of which parameters its backward touched."""
         self.t += 1
         self.current_iteration += 1
+        PARAM_EPOCH[0] += 1
         for gi, pg in enumerate(self.param_groups):
             if pg.pop("skip_once", False):
                 # the densifier just replaced this group's parameter: torch.optim.Adam finds `grad is None` on the new Parameter and leaves
@@ -178,6 +184,7 @@ class FlatOptimizer:
         step replays the same launches every time.)"""
         self.t += 1
         self.current_iteration += 1
+        PARAM_EPOCH[0] += 1
         for k, pg in enumerate(self.param_groups):
             pg["t"] = pg.get("t", 0) + 1
             # the statements of dwg_adam_step (csrc/elementwise.hip): fp32 hyper-parameters, double arithmetic, one rounding -- a replay of the

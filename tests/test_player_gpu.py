@@ -94,3 +94,55 @@ def test_frames_per_launch_playback_equals_frame_by_frame(bg_mode):
     with pytest.raises(RuntimeError):
         g = scene.avatar_forward(smpl_observed_inputs=poses[0])              # gradients enabled: not the playback path
         scene.renderer.render_frames(data, [g])
+
+
+def test_frozen_avatar_playback_keeps_the_pose_independent_part_and_notices_every_parameter_change():
+    """Scene.forward_frames(frozen_avatar=True): the canonical encoding and the colour / opacity network run once, not per frame -- same
+    bits as frame-by-frame `forward`; an optimizer step (which writes the flat buffer through a raw pointer), an in-place edit of a
+    parameter, and `invalidate_caches()` each make the next frame recompute."""
+    from dreamwaltz_g_amd import _lib, optim, synth
+    dev = torch.device("cuda:0")
+    scene, data = _scene(20000, 256, dev)
+    av = scene.avatar
+    poses = [synth.random_smpl_inputs(seed=30 + i, device=dev) for i in range(4)]
+
+    def reference():
+        with torch.inference_mode():
+            return [scene.forward(data, smpl_observed_inputs=p, use_densifier=False, bg_mode=None)["image"].clone() for p in poses]
+
+    def played():
+        _lib.prof_enable(True)
+        with torch.inference_mode():
+            out = scene.forward_frames(data, poses, frozen_avatar=True)["image"].clone()
+        torch.cuda.synchronize()
+        t = _lib.prof_table(); _lib.prof_enable(False)
+        return out, t.get("grid_fwd", (0, 0.0))[0]
+
+    ref = reference()
+    out, enc_launches = played()
+    assert enc_launches == 1                                            # four frames, ONE encoder pass
+    assert all(torch.equal(out[f:f + 1], ref[f]) for f in range(4))
+    out, enc_launches = played()
+    assert enc_launches == 0 and all(torch.equal(out[f:f + 1], ref[f]) for f in range(4))      # kept across calls
+    # (a) an in-place edit of a parameter (version counter)
+    with torch.no_grad():
+        av.nerf_opacity_and_color_net.net[0].bias.add_(0.05)
+    ref = reference()
+    out, enc_launches = played()
+    assert enc_launches == 1 and all(torch.equal(out[f:f + 1], ref[f]) for f in range(4))
+    # (b) a write behind autograd's back, announced the way the fused optimizers announce theirs
+    pos = av._positions
+    alias = torch.empty(0, device=dev).set_(pos.untyped_storage(), pos.storage_offset(), pos.shape, pos.stride())   # own version counter
+    v0 = pos._version
+    alias.mul_(1.01)
+    assert pos._version == v0                                           # the parameter's own counter did not notice
+    optim.PARAM_EPOCH[0] += 1
+    ref = reference()
+    out, enc_launches = played()
+    assert enc_launches == 1 and all(torch.equal(out[f:f + 1], ref[f]) for f in range(4))
+    # (c) explicit invalidation (checkpoint load, densification)
+    av.invalidate_caches()
+    out, enc_launches = played()
+    assert enc_launches == 1 and all(torch.equal(out[f:f + 1], ref[f]) for f in range(4))
+    # not in use outside forward_frames(frozen_avatar=True)
+    assert av.frozen_playback is False
