@@ -25,7 +25,7 @@ def timed(fn, n=20, warm=3):
     return e0.elapsed_time(e1) / n * 1e3
 
 
-for G, H, W in [(10000, 256, 256), (50000, 512, 512), (300000, 1024, 1024)]:
+for G, H, W in [(10000, 256, 256), (50000, 512, 512), (100000, 512, 512), (300000, 1024, 1024)]:
     Fmax = 8
     scs = [rc.make_scene(G, H, W, seed=s) for s in range(Fmax)]
     dev = "cuda"
