@@ -48,7 +48,7 @@ fi
 # bench lines (the default command, then the two other BASELINE configs)
 if has bench; then
 # the default command carries c1 / c2 / c4 (8 views on one GPU) / c5 and the fp32 line as attachments
-timeout 900 python bench.py > $OUT/bench_default.log 2>&1; grep '^{"metric"' $OUT/bench_default.log | tail -1 > profiles/${R}_bench_line.json
+T0=$(date +%s); timeout 900 python bench.py > $OUT/bench_default.log 2>&1; echo "default bench.py run: $(( $(date +%s) - T0 )) s" | tee $OUT/bench_default.time; grep '^{"metric"' $OUT/bench_default.log | tail -1 > profiles/${R}_bench_line.json
 fi
 has calib && bash tools/calib_fetch.sh $R > $OUT/calib.log 2>&1
 has calib && tail -20 $OUT/calib.log
