@@ -610,7 +610,8 @@ class DreamWaltzG(nn.Module):
         # network's colours / opacities do not depend on the pose -- they are kept from the previous frame while no parameter has changed
         # (key: the optimizers' step epoch, the cache generation, every parameter's / buffer's address and version counter).  The
         # reference recomputes them per frame (avatar.py:1500-1588); the values are the same bits either way.
-        frozen_key = self._frozen_key() if (self.frozen_playback and not torch.is_grad_enabled() and not self.learn_betas) else None
+        frozen_key = self._frozen_key() if (self.frozen_playback and not torch.is_grad_enabled() and not self.learn_betas
+                                            and not (positions.is_cuda and torch.cuda.is_current_stream_capturing())) else None
         hit = frozen_key is not None and self._frozen_cache is not None and self._frozen_cache[0] == frozen_key
         canonical_positions = None if hit else self.lbs_transform(positions, ctr)
         if self.learn_betas:                         # avatar.py:1551-1553 (sub-stage 2.1: --render.learn_hand_betas True)

@@ -262,10 +262,22 @@ class DeformNetwork(nn.Module):
         self.gaussian_warp = nn.Linear(W, 3)
         self.gaussian_rotation = nn.Linear(W, 4)
         self.gaussian_scaling = nn.Linear(W, 3)
+        self._head_cache = None
 
     def forward(self, x, body_pose):
         # the three heads share one 64 -> 10 product (warp 3 | scaling 3 | rotation 4)
-        w = torch.cat([self.gaussian_warp.weight, self.gaussian_scaling.weight, self.gaussian_rotation.weight], 0)
-        b = torch.cat([self.gaussian_warp.bias, self.gaussian_scaling.bias, self.gaussian_rotation.bias], 0)
+        heads = (self.gaussian_warp, self.gaussian_scaling, self.gaussian_rotation)
+        if torch.is_grad_enabled() or (x.is_cuda and torch.cuda.is_current_stream_capturing()):
+            # (a captured frame re-runs the concatenation from the live parameters on every replay)
+            w = torch.cat([h.weight for h in heads], 0)
+            b = torch.cat([h.bias for h in heads], 0)
+        else:
+            # inference: the concatenated head is kept while the six tensors are the ones it was built from (address, version counter and the
+            # optimizers' write epoch -- the fused Adam writes parameters through a raw pointer): two launches fewer per frame
+            from . import optim
+            key = (optim.PARAM_EPOCH[0],) + tuple((t.data_ptr(), t._version) for h in heads for t in (h.weight, h.bias))
+            if self._head_cache is None or self._head_cache[0] != key:
+                self._head_cache = (key, torch.cat([h.weight for h in heads], 0).detach(), torch.cat([h.bias for h in heads], 0).detach())
+            w, b = self._head_cache[1], self._head_cache[2]
         o = mlp_chain(x, [(m.weight, m.bias) for m in self.layers] + [(w, b)], ["leaky_relu"] * self.D + [None], extra=body_pose)
         return o[:, 0:3], o[:, 3:6], o[:, 6:10]

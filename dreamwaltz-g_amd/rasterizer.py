@@ -146,7 +146,7 @@ class _RasterizeGaussians(torch.autograd.Function):
                    "dwg_raster_workspace_sizes")
         ws_geom = torch.empty(gb.value, dtype=torch.uint8, device=device)
         ws_image = torch.empty(ib.value, dtype=torch.uint8, device=device)
-        radii = torch.zeros(G, dtype=torch.int32, device=device)
+        radii = torch.empty(G, dtype=torch.int32, device=device)         # k_preprocess writes every entry (0 for what it culls)
         st = _stream(device)
         p = _lib.ptr
         if pair_state is not None:
@@ -286,7 +286,7 @@ def rasterize_frames(means3D, opacities, colors_precomp=None, shs=None, scales=N
     _lib.check(L.dwg_raster_workspace_sizes(G, H, W, 0, ctypes.byref(gb), ctypes.byref(pb), ctypes.byref(ib)), "dwg_raster_workspace_sizes")
     ws_geom = torch.empty(F * gb.value, dtype=torch.uint8, device=device)
     ws_image = torch.empty(F * ib.value, dtype=torch.uint8, device=device)
-    radii = torch.zeros(F, G, dtype=torch.int32, device=device)
+    radii = torch.empty(F, G, dtype=torch.int32, device=device)          # k_preprocess writes every entry (0 for what it culls)
     st, p = _stream(device), _lib.ptr
     _lib.check(L.dwg_raster_forward_bin_frames(ctypes.byref(cfg), ctypes.byref(fr), G, p(means3D), p(shs), p(colors_precomp), p(opac),
                                                p(scales), p(rotations), p(cov3D), p(radii), p(ws_geom), st), "dwg_raster_forward_bin_frames")
