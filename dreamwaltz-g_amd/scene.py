@@ -86,18 +86,20 @@ class Scene(nn.Module):
             raise NotImplementedError("forward_frames renders one avatar per frame")
         frames = []
         self.avatar.frozen_playback = bool(frozen_avatar)
-        for pose in poses:
-            g = self.avatar_forward(smpl_observed_inputs=pose)
-            if self.use_zero_scales:
-                g.scales = g.scales * 0.1
-            if self.use_constant_colors:
-                g.colors = self.constant_colors.expand(g.colors.size(0), -1)
-            if self.use_constant_opacities:
-                g.opacities = self.constant_opacities.expand(g.opacities.size(0), -1)
-            if self.use_fixed_n_gaussians:
-                g = downsample_gaussians(g, self.fixed_n_gaussians)
-            frames.append(g)
-        self.avatar.frozen_playback = False
+        try:
+            for pose in poses:
+                g = self.avatar_forward(smpl_observed_inputs=pose)
+                if self.use_zero_scales:
+                    g.scales = g.scales * 0.1
+                if self.use_constant_colors:
+                    g.colors = self.constant_colors.expand(g.colors.size(0), -1)
+                if self.use_constant_opacities:
+                    g.opacities = self.constant_opacities.expand(g.opacities.size(0), -1)
+                if self.use_fixed_n_gaussians:
+                    g = downsample_gaussians(g, self.fixed_n_gaussians)
+                frames.append(g)
+        finally:
+            self.avatar.frozen_playback = False
         outputs = self.renderer.render_frames(data=data, frames=frames)
         if bg_mode in self.pure_colors:
             outputs['image_bg'] = self.pure_colors.get_background_like(bg_mode, outputs['image'])
