@@ -20,7 +20,7 @@ def _st(t):
 
 class _LbsBlend(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, A, weights, points, quats, normalize):
+    def forward(ctx, A, weights, points, quats, normalize, grad_on=True):
         if not points.is_cuda:
             raise RuntimeError("dreamwaltz_g_amd LBS runs on the GPU only (HIP kernels)")
         A = A.detach().contiguous().float().reshape(-1, 16)
@@ -30,8 +30,9 @@ class _LbsBlend(torch.autograd.Function):
         N, J = weights.shape
         p_out = torch.empty_like(points)
         q_out = torch.empty_like(quats) if quats is not None else None
-        need_bwd = points.requires_grad or (quats is not None and quats.requires_grad)
-        T12 = torch.empty(N, 12, device=points.device) if need_bwd or True else None
+        # the blended transforms are kept for the backward -- not under no_grad / inference_mode (`grad_on`: the CALLER's grad mode; inside
+        # forward() it is always off): 48 bytes per Gaussian and launch that playback never reads
+        T12 = torch.empty(N, 12, device=points.device) if grad_on else None
         p = _lib.ptr
         _lib.check(_lib.lib().dwg_lbs_blend_forward(N, J, int(bool(normalize)), p(A), p(weights), p(points), p(quats),
                                                     p(p_out), p(q_out), p(T12), _st(points)), "dwg_lbs_blend_forward")
@@ -54,19 +55,19 @@ class _LbsBlend(torch.autograd.Function):
         p = _lib.ptr
         _lib.check(_lib.lib().dwg_lbs_blend_backward(N, p(T12), p(points), p(quats), p(g_p), p(g_q) if ctx.has_q else None,
                                                      p(gp), p(gq), _st(points)), "dwg_lbs_blend_backward")
-        return None, None, gp, gq, None
+        return None, None, gp, gq, None, None
 
 
 def lbs_blend(A, weights, points, quats=None, normalize_weights=False):
     """A [J,4,4] joint transforms (incl. translation), weights [N,J] -> points' (, quats')."""
-    return _LbsBlend.apply(A, weights, points, quats, normalize_weights)
+    return _LbsBlend.apply(A, weights, points, quats, normalize_weights, torch.is_grad_enabled())
 
 
 def lbs_blend_quaternions(A, weights, quats, normalize_weights=False):
     """RigidTransform.transform_quaternions(q, weights=, flip_rotation_axis=True) on its own (inverse_lbs.py:234-242): the same
     kernel with a zero point set (the weight rows dominate the traffic either way)."""
     pts = torch.zeros(quats.shape[0], 3, device=quats.device, dtype=torch.float32)
-    return _LbsBlend.apply(A, weights, pts, quats, normalize_weights)[1]
+    return _LbsBlend.apply(A, weights, pts, quats, normalize_weights, torch.is_grad_enabled())[1]
 
 
 def joint_chain(pose, joints, parents, transl=None, return_rot_mats=False, joint_shape_dirs=None, shape_coeffs=None):

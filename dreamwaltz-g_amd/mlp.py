@@ -112,7 +112,7 @@ class _MlpChain(torch.autograd.Function):
     names, one per layer), then w_0, b_0, w_1, b_1, ..."""
 
     @staticmethod
-    def forward(ctx, x, extra, acts, *wb):
+    def forward(ctx, x, extra, acts, grad_on, *wb):
         L = _lib.lib()
         nl = len(acts)
         ws = [wb[2 * l].contiguous().float() for l in range(nl)]
@@ -124,7 +124,10 @@ class _MlpChain(torch.autograd.Function):
         e = extra.reshape(-1).contiguous().float() if extra is not None else None
         biases = [None if b is None else b.contiguous().float() for b in bs]
         widths = [int(w.shape[0]) for w in ws]
-        keep = any(ctx.needs_input_grad)
+        # `grad_on`: the caller's grad mode (inside forward() it is always off, and needs_input_grad reflects requires_grad of the inputs even
+        # under no_grad / inference_mode): without it every inference frame wrote -- and the kernel kept -- the hidden activations of both
+        # networks (460 MB per 300 k-Gaussian frame) for a backward that never comes
+        keep = bool(grad_on) and any(ctx.needs_input_grad)
         hidden = [torch.empty(M, widths[l], device=dev) if keep else None for l in range(nl - 1)]
         out = torch.empty(M, widths[-1], device=dev)
         vp, i32 = ctypes.c_void_p * nl, ctypes.c_int32 * nl
@@ -166,7 +169,7 @@ class _MlpChain(torch.autograd.Function):
                 for l, w in enumerate(ws):
                     grads[2 * l] = torch.zeros_like(w)
                     grads[2 * l + 1] = torch.zeros(w.shape[0], device=dev) if ctx.has_b[l] else None
-                return (dx, None, None) + tuple(grads)
+                return (dx, None, None, None) + tuple(grads)
             # A weight / bias that is a leaf Parameter whose .grad is its slice of a flat gradient buffer (optim.FlatBuffers marks those:
             # `_dwg_flat`) gets its gradient ADDED into that slice by the reduce kernel and autograd is handed None -- no temporary, no
             # AccumulateGrad `add_` launch per parameter (sixteen per step for the two networks).  Anything else (the concatenated heads of
@@ -175,8 +178,8 @@ class _MlpChain(torch.autograd.Function):
             # flat-buffer parameter -- that caller would receive None while the slice is added to; it must wrap the FORWARD in
             # `gridencoder.table_grad_inplace(False)` (what the concurrent multi-view backwards do, trainer.py).
             nig = ctx.needs_input_grad
-            wflat = [_flat_slice(ctx.params[l][0], ws[l], nig[3 + 2 * l]) if ctx.inplace_ok else None for l in range(nl)]
-            bflat = [_flat_slice(ctx.params[l][1], None, nig[4 + 2 * l]) if (ctx.inplace_ok and ctx.has_b[l]) else None for l in range(nl)]
+            wflat = [_flat_slice(ctx.params[l][0], ws[l], nig[4 + 2 * l]) if ctx.inplace_ok else None for l in range(nl)]
+            bflat = [_flat_slice(ctx.params[l][1], None, nig[5 + 2 * l]) if (ctx.inplace_ok and ctx.has_b[l]) else None for l in range(nl)]
             dws = [ctx.params[l][0].grad if wflat[l] is not None else torch.empty_like(ws[l]) for l in range(nl)]
             dbs = torch.empty(nl, 64, device=dev)
             dbp = [ctx.params[l][1].grad.data_ptr() if bflat[l] is not None else dbs[l].data_ptr() for l in range(nl)]
@@ -199,7 +202,7 @@ class _MlpChain(torch.autograd.Function):
                     bflat[l].touch(ctx.params[l][1])
                 elif ctx.has_b[l]:
                     grads[2 * l + 1] = dbs[l, :w.shape[0]]
-            return (dx, None, None) + tuple(grads)
+            return (dx, None, None, None) + tuple(grads)
         g = dy
         # one zero fill for every layer's bias-gradient accumulator and weight-gradient tile (16 fills per step before)
         sizes = [(int(w.shape[0]), int(w.numel())) for w in ws]
@@ -216,7 +219,7 @@ class _MlpChain(torch.autograd.Function):
             grads[2 * l] = dw
             grads[2 * l + 1] = db if ctx.has_b[l] else None
             g = dx
-        return (g if ctx.needs_input_grad[0] else None, None, None) + tuple(grads)
+        return (g if ctx.needs_input_grad[0] else None, None, None, None) + tuple(grads)
 
 
 def mlp_chain(x, layers, acts, extra=None):
@@ -230,7 +233,7 @@ def mlp_chain(x, layers, acts, extra=None):
     flat = []
     for w, b in layers:
         flat += [w, b]
-    return _MlpChain.apply(x, extra, tuple(acts), *flat)
+    return _MlpChain.apply(x, extra, tuple(acts), torch.is_grad_enabled(), *flat)
 
 
 def linear(x, w, b=None, act=None, extra=None):
