@@ -36,8 +36,12 @@ FAILED = os.path.join(OUT, "gridencoder_ref.unbuildable.txt")
 
 def build(force=False, verbose=False):
     if not os.path.isdir(REF_SRC):
-        print("[oracle/_ref] %s not present (GPU box): using the prebuilt %s" % (REF_SRC, SO))
-        return SO if os.path.exists(SO) else None
+        if os.path.exists(SO):
+            print("[oracle/_ref] %s not present (GPU box): using the prebuilt %s" % (REF_SRC, SO))
+            return SO
+        print("[oracle/_ref] %s not present (GPU box) and no prebuilt %s (the build container could not produce one: see this file's header)"
+              % (REF_SRC, os.path.basename(SO)))
+        return None
     srcs = [os.path.join(REF_SRC, f) for f in ("gridencoder.cu", "bindings.cpp", "gridencoder.h")]
     newest = max(os.path.getmtime(x) for x in srcs + [os.path.abspath(__file__)])
     if not force and os.path.exists(SO) and os.path.getmtime(SO) >= newest:
