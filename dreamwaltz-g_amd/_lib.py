@@ -93,6 +93,9 @@ SIGNATURES = {
                                              _vp, _i64, _i64, _f32, _vp]),
     "dwg_attention_forward_dt": (ctypes.c_int, [_i32, _i32, _i32, _i32, _i32, _i32, _vp, _i64, _i64, _vp, _i64, _i64, _vp, _i64, _i64,
                                                 _vp, _i64, _i64, _f32, _vp]),
+    "dwg_attention_split_workspace_bytes": (_sz, [_i32, _i32, _i32, _i32, _i32, _i32]),
+    "dwg_attention_forward_ws": (ctypes.c_int, [_i32, _i32, _i32, _i32, _i32, _i32, _vp, _i64, _i64, _vp, _i64, _i64, _vp, _i64, _i64,
+                                                _vp, _i64, _i64, _f32, _vp, _sz, _vp]),
     "dwg_softmax_rows_forward": (ctypes.c_int, [_i32, _i32, _f32, _vp, _i64, _vp, _i64, _vp]),
     "dwg_softmax_rows_backward": (ctypes.c_int, [_i32, _i32, _f32, _vp, _i64, _vp, _i64, _vp, _i64, _vp]),
     "dwg_groupnorm_forward_dt": (ctypes.c_int, [_i32, _i32, _i32, _i32, _i32, _vp, _vp, _vp, _f32, _i32, _vp, _vp, _vp, _vp]),

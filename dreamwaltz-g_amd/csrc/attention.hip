@@ -249,6 +249,23 @@ int dwg_attention_forward_x(int32_t B, int32_t H, int32_t Nq, int32_t Nk, int32_
                             const void* K, int64_t ldk, int64_t bk, const void* V, int64_t ldv, int64_t bv, void* O, int64_t ldo,
                             int64_t bo, float scale, dwg_stream_t stream_);           // attention_x.hip (split-precision operands)
 
+size_t dwg_attention_split_workspace_bytes_x(int32_t B, int32_t H, int32_t Nq, int32_t Nk, int32_t d);          // attention_x.hip
+int dwg_attention_forward_x_ws(int32_t B, int32_t H, int32_t Nq, int32_t Nk, int32_t d, const void* Q, int64_t ldq, int64_t bq, const void* K,
+                               int64_t ldk, int64_t bk, const void* V, int64_t ldv, int64_t bv, void* O, int64_t ldo, int64_t bo, float scale,
+                               void* workspace, size_t workspace_bytes, dwg_stream_t stream_);
+
+size_t dwg_attention_split_workspace_bytes(int32_t dtype, int32_t B, int32_t H, int32_t Nq, int32_t Nk, int32_t d) {
+    return dtype == DWG_DTYPE_F32X ? dwg_attention_split_workspace_bytes_x(B, H, Nq, Nk, d) : 0;
+}
+
+int dwg_attention_forward_ws(int32_t dtype, int32_t B, int32_t H, int32_t Nq, int32_t Nk, int32_t d, const void* Q, int64_t ldq, int64_t bq,
+                             const void* K, int64_t ldk, int64_t bk, const void* V, int64_t ldv, int64_t bv, void* O, int64_t ldo,
+                             int64_t bo, float scale, void* workspace, size_t workspace_bytes, dwg_stream_t stream) {
+    if (dtype == DWG_DTYPE_F32X)
+        return dwg_attention_forward_x_ws(B, H, Nq, Nk, d, Q, ldq, bq, K, ldk, bk, V, ldv, bv, O, ldo, bo, scale, workspace, workspace_bytes, stream);
+    return dwg_attention_forward_dt(dtype, B, H, Nq, Nk, d, Q, ldq, bq, K, ldk, bk, V, ldv, bv, O, ldo, bo, scale, stream);
+}
+
 int dwg_attention_forward_dt(int32_t dtype, int32_t B, int32_t H, int32_t Nq, int32_t Nk, int32_t d, const void* Q, int64_t ldq, int64_t bq,
                              const void* K, int64_t ldk, int64_t bk, const void* V, int64_t ldv, int64_t bv, void* O, int64_t ldo,
                              int64_t bo, float scale, dwg_stream_t stream) {

@@ -30,6 +30,9 @@ struct AttnXP {
     long long ldq, ldk, ldv, ldo;          // row strides (logical elements)
     long long bq, bk, bv, bo;              // per-image strides; head h starts at column h*d
     float scale_log2;                      // softmax scale * log2(e)
+    int nsplit;                            // > 1: the keys are split into nsplit ranges (blockIdx.z); a workgroup writes its UNNORMALISED
+    float* ws;                             //      partial (O, running max, denominator) to ws[split][image*head][query][dvw] and
+    int dvw;                               //      k_flash_merge_x combines the ranges in split order
 };
 
 // DK = head dim padded to a multiple of 16, DV = padded to a multiple of 32.  LD > 0: the head dim is exactly LD < DV and row LD of the hi
@@ -80,7 +83,12 @@ __global__ __launch_bounds__(256, MINB) void k_flash_fwd_x(AttnXP p) {
         for (int r = 0; r < 16; r++) { acc[j][r] = 0.f; acx[j][r] = 0.f; }
     float m_run = -3.0e38f, acc_l = 0.f;
 
-    const int ntiles = (p.Nk + KT - 1) / KT;
+    // this workgroup's key tiles: all of them, or range blockIdx.z of nsplit (small query counts: a serial walk over all keys by the few
+    // workgroups there are left most of the chip idle -- 92 us for the 32x32 level's self-attention, 41 us for the 16x16 level's)
+    const int ntiles_all = (p.Nk + KT - 1) / KT;
+    const int tper = p.nsplit > 1 ? (ntiles_all + p.nsplit - 1) / p.nsplit : ntiles_all;
+    const int tbeg = p.nsplit > 1 ? (int)blockIdx.z * tper : 0;
+    const int ntiles = min(ntiles_all, tbeg + tper);
     constexpr int NKC = (KT * (DK / 8) + 255) / 256, NVC = (KT * (DV / 8) + 255) / 256;
     dwg_x8 kreg[NKC], vreg[NVC];
     int kkey[NKC], vkey[NVC];
@@ -120,8 +128,8 @@ __global__ __launch_bounds__(256, MINB) void k_flash_fwd_x(AttnXP p) {
     // K / V staging is software-pipelined through registers (tile t + 1 in flight while tile t is multiplied) -- except at d = 160, whose two
     // accumulator sets leave no registers for it: there the tile is fetched right before it is staged (8x8 / 16x16 latents: a few tiles)
     constexpr bool PF = DV <= 96;
-    if (PF && ntiles > 0) fetch(0);
-    for (int t = 0; t < ntiles; t++) {
+    if (PF && tbeg < ntiles) fetch(tbeg * KT);
+    for (int t = tbeg; t < ntiles; t++) {
         const int k0 = t * KT;
         if constexpr (!PF) fetch(k0);
         __syncthreads();
@@ -221,6 +229,21 @@ __global__ __launch_bounds__(256, MINB) void k_flash_fwd_x(AttnXP p) {
     } else {
         l_run = acc_l;
     }
+    if (p.nsplit > 1) {
+        // partial result of this key range: unnormalised O (both sets joined), the running maximum (log2 domain, scaled) and the denominator
+        const int q = q0 + ql;
+        if (q < p.Nq) {
+            float* row = p.ws + (((long long)blockIdx.z * gridDim.y + blockIdx.y) * p.Nq + q) * p.dvw;
+#pragma unroll
+            for (int j = 0; j < NVB; j++)
+#pragma unroll
+                for (int r4 = 0; r4 < 4; r4++)
+                    *reinterpret_cast<float4*>(row + 32 * j + 8 * r4 + 4 * half) =
+                        make_float4(acc[j][4 * r4], acc[j][4 * r4 + 1], acc[j][4 * r4 + 2], acc[j][4 * r4 + 3]);
+            if (half == 0) { row[DV] = m_run; row[DV + 1] = l_run; }
+        }
+        return;
+    }
     const float inv = l_run > 0.f ? 1.f / l_run : 0.f;
     if constexpr (!STAGE) {
         const int q = q0 + ql;
@@ -260,19 +283,83 @@ __global__ __launch_bounds__(256, MINB) void k_flash_fwd_x(AttnXP p) {
     }
 }
 
+// Combines the key ranges of a split attention launch, in range order: O = sum_s 2^(m_s - m) O_s / sum_s 2^(m_s - m) l_s  with  m = max_s m_s.
+// One thread per (query row, four channels); the output goes out in the f32x planes.
+__global__ __launch_bounds__(256) void k_flash_merge_x(AttnXP p, int BH, int DV) {
+    const int groups = p.d >> 2;
+    const long long idx = (long long)blockIdx.x * 256 + threadIdx.x;
+    const long long row = idx / groups;
+    const int g = (int)(idx - row * groups);
+    if (row >= (long long)BH * p.Nq) return;
+    const int bh = (int)(row / p.Nq), q = (int)(row - (long long)bh * p.Nq);
+    const long long sstride = (long long)BH * p.Nq * p.dvw;
+    const float* base = p.ws + row * p.dvw;
+    float m = -3.0e38f;
+    for (int s2 = 0; s2 < p.nsplit; s2++) m = fmaxf(m, base[s2 * sstride + DV]);
+    float L = 0.f, o[4] = {0.f, 0.f, 0.f, 0.f};
+    for (int s2 = 0; s2 < p.nsplit; s2++) {
+        const float* r = base + s2 * sstride;
+        const float w = __builtin_amdgcn_exp2f(r[DV] - m);
+        const float4 v = *reinterpret_cast<const float4*>(r + 4 * g);
+        L = fmaf(w, r[DV + 1], L);
+        o[0] = fmaf(w, v.x, o[0]); o[1] = fmaf(w, v.y, o[1]); o[2] = fmaf(w, v.z, o[2]); o[3] = fmaf(w, v.w, o[3]);
+    }
+    const float inv = L > 0.f ? 1.f / L : 0.f;
+    const float out[4] = {o[0] * inv, o[1] * inv, o[2] * inv, o[3] * inv};
+    const int img = bh / p.H, head = bh % p.H;
+    dwg_xs* O = p.O + img * p.bo + (long long)head * p.d;
+    dwg_x_put4(O + (long long)q * p.ldo, 4 * g, out);
+}
+
+// key ranges for a launch: none while the query blocks alone fill the chip or there are few key tiles; else enough ranges for ~512 workgroups,
+// at least two 32-key tiles per range, at most eight
+static int attn_splits(int B, int H, int Nq, int Nk) {
+    static const int off = getenv("DWG_ATTN_SPLIT") ? atoi(getenv("DWG_ATTN_SPLIT")) : -1;      // 0 / 1: never; n > 1: force n ranges
+    const int base = dwg_cdiv(Nq, 128) * B * H, ntiles = dwg_cdiv(Nk, 32);
+    if (off == 0 || off == 1) return 1;
+    int sp = off > 1 ? off : (base >= 256 ? 1 : dwg_cdiv(512, base));
+    if (sp > 8) sp = 8;
+    if (sp > ntiles / 2) sp = ntiles / 2;
+    return sp < 2 ? 1 : sp;
+}
+static int attn_dv(int d) { return d <= 32 ? 32 : (d <= 64 ? 64 : (d <= 96 ? 96 : 160)); }
+
 }  // namespace
 
 extern "C" {
 
+size_t dwg_attention_split_workspace_bytes_x(int32_t B, int32_t H, int32_t Nq, int32_t Nk, int32_t d) {
+    if (B <= 0 || H <= 0 || Nq <= 0 || Nk <= 0 || d <= 0 || d > 160) return 0;
+    const int sp = attn_splits(B, H, Nq, Nk);
+    return sp > 1 ? (size_t)sp * B * H * Nq * (attn_dv(d) + 4) * sizeof(float) : 0;
+}
+
+int dwg_attention_forward_x_ws(int32_t B, int32_t H, int32_t Nq, int32_t Nk, int32_t d, const void* Q, int64_t ldq, int64_t bq, const void* K,
+                               int64_t ldk, int64_t bk, const void* V, int64_t ldv, int64_t bv, void* O, int64_t ldo, int64_t bo, float scale,
+                               void* workspace, size_t workspace_bytes, dwg_stream_t stream_);
+
 int dwg_attention_forward_x(int32_t B, int32_t H, int32_t Nq, int32_t Nk, int32_t d, const void* Q, int64_t ldq, int64_t bq, const void* K,
                             int64_t ldk, int64_t bk, const void* V, int64_t ldv, int64_t bv, void* O, int64_t ldo, int64_t bo, float scale,
                             dwg_stream_t stream_) {
+    return dwg_attention_forward_x_ws(B, H, Nq, Nk, d, Q, ldq, bq, K, ldk, bk, V, ldv, bv, O, ldo, bo, scale, nullptr, 0, stream_);
+}
+
+// `workspace` (dwg_attention_split_workspace_bytes_x bytes, or NULL): with it, launches whose query blocks do not fill the chip split the
+// keys over workgroups and a second small launch merges the ranges (fixed order: run-to-run reproducible; the sums differ from the unsplit
+// launch's in rounding order only)
+int dwg_attention_forward_x_ws(int32_t B, int32_t H, int32_t Nq, int32_t Nk, int32_t d, const void* Q, int64_t ldq, int64_t bq, const void* K,
+                               int64_t ldk, int64_t bk, const void* V, int64_t ldv, int64_t bv, void* O, int64_t ldo, int64_t bo, float scale,
+                               void* workspace, size_t workspace_bytes, dwg_stream_t stream_) {
     if (B <= 0 || H <= 0 || Nq <= 0 || Nk <= 0 || d <= 0 || d % 8 || d > 160 || !Q || !K || !V || !O) return DWG_E_ARG;
     if ((ldq | ldk | ldv | ldo | bq | bk | bv | bo) % 8) return DWG_E_ARG;   // whole 8-channel groups
     if (((uintptr_t)Q | (uintptr_t)K | (uintptr_t)V | (uintptr_t)O) % 16) return DWG_E_ARG;
     AttnXP p{(const dwg_xs*)Q, (const dwg_xs*)K, (const dwg_xs*)V, (dwg_xs*)O, Nq, Nk, H, d, ldq, ldk, ldv, ldo, bq, bk, bv, bo,
-             scale * 1.4426950408889634f};
-    dim3 grid(dwg_cdiv(Nq, 128), B * H), block(256);
+             scale * 1.4426950408889634f, 1, nullptr, 0};
+    int sp = workspace ? attn_splits(B, H, Nq, Nk) : 1;
+    const int DVp = attn_dv(d);
+    if (sp > 1 && (((uintptr_t)workspace & 15) || (size_t)sp * B * H * Nq * (DVp + 4) * sizeof(float) > workspace_bytes)) sp = 1;
+    if (sp > 1) { p.nsplit = sp; p.ws = reinterpret_cast<float*>(workspace); p.dvw = DVp + 4; }
+    dim3 grid(dwg_cdiv(Nq, 128), B * H, sp), block(256);
     hipStream_t stream = (hipStream_t)stream_;
     const double flops = 4.0 * B * H * (double)Nq * Nk * d;     // QK^T and PV on the logical head size, one multiply-add per product
     if (d <= 32) DWG_LAUNCH_W("flash_attn_d32", "k_flash_fwd_x<32, 32, 0, 2>", flops, (k_flash_fwd_x<32, 32, 0, 2>), grid, block, 0, stream, p);
@@ -283,6 +370,11 @@ int dwg_attention_forward_x(int32_t B, int32_t H, int32_t Nq, int32_t Nk, int32_
     else if (d <= 96) DWG_LAUNCH_W("flash_attn_d96", "k_flash_fwd_x<96, 96, 0, 1>", flops, (k_flash_fwd_x<96, 96, 0, 1>), grid, block, 0, stream, p);
     else DWG_LAUNCH_W("flash_attn_d160", "k_flash_fwd_x<160, 160, 0, 1>", flops, (k_flash_fwd_x<160, 160, 0, 1>), grid, block, 0, stream, p);
     DWG_RETURN_IF_LAUNCH_FAILED();
+    if (sp > 1) {
+        const long long n = (long long)B * H * Nq * (d / 4);
+        DWG_LAUNCH("flash_attn_merge", k_flash_merge_x, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, stream, p, B * H, DVp);
+        DWG_RETURN_IF_LAUNCH_FAILED();
+    }
     return DWG_OK;
 }
 

@@ -703,6 +703,14 @@ class Builder:
                                           a_batch=(heads * Nq * Nk, Nq * Nk), b_batch=(v.stride(0), d), c_batch=(o.stride(0), d),
                                           name="attn_pv", run=False))
             return o
+        # small query counts (self-attention of the 32x32 / 16x16 levels): the keys are split over workgroups and merged by a second launch
+        # (include/dwg_nn.h dwg_attention_forward_ws) -- the workspace belongs to this call site
+        need = int(self.L.dwg_attention_split_workspace_bytes(self.p.dt, B, heads, Nq, Nk, d))
+        if need > 0:
+            ws = self.p.buf((need + 3) // 4, dtype=torch.float32)
+            self.p.add_call(self.L.dwg_attention_forward_ws, self.p.dt, B, heads, Nq, Nk, d, pp(q), q.stride(1), q.stride(0), pp(k), k.stride(1),
+                            k.stride(0), pp(v), v.stride(1), v.stride(0), pp(o), o.stride(1), o.stride(0), float(d) ** -0.5, pp(ws), need)
+            return o
         self.p.add_call(self.L.dwg_attention_forward_dt, self.p.dt, B, heads, Nq, Nk, d, pp(q), q.stride(1), q.stride(0), pp(k), k.stride(1),
                         k.stride(0), pp(v), v.stride(1), v.stride(0), pp(o), o.stride(1), o.stride(0), float(d) ** -0.5)
         return o

@@ -67,6 +67,15 @@ int dwg_geglu_forward_dt(int32_t dtype, int64_t M, int32_t F, const void* x, voi
 int dwg_attention_forward_dt(int32_t dtype, int32_t B, int32_t H, int32_t Nq, int32_t Nk, int32_t d, const void* Q, int64_t ldq,
                              int64_t bq, const void* K, int64_t ldk, int64_t bk, const void* V, int64_t ldv, int64_t bv, void* O,
                              int64_t ldo, int64_t bo, float scale, dwg_stream_t stream);
+/* The same with an optional workspace (dwg_attention_split_workspace_bytes: 0 when the launch would not use one).  With it, a launch whose
+ * query blocks do not fill the chip (self-attention of the 32x32 / 16x16 latent levels: 128 / 32 workgroups) splits the KEYS over workgroups and a
+ * second small launch merges the ranges in a fixed order -- run-to-run reproducible; the result differs from the unsplit launch's in rounding
+ * order only.  Split-precision (F32X) operands only; other types ignore the workspace.  Nothing in the reference to mirror: diffusers'
+ * scaled_dot_product_attention (core/guidance/controlnet.py:98-114 through the UNet's attention processors). */
+size_t dwg_attention_split_workspace_bytes(int32_t dtype, int32_t B, int32_t H, int32_t Nq, int32_t Nk, int32_t d);
+int dwg_attention_forward_ws(int32_t dtype, int32_t B, int32_t H, int32_t Nq, int32_t Nk, int32_t d, const void* Q, int64_t ldq,
+                             int64_t bq, const void* K, int64_t ldk, int64_t bk, const void* V, int64_t ldv, int64_t bv, void* O,
+                             int64_t ldo, int64_t bo, float scale, void* workspace, size_t workspace_bytes, dwg_stream_t stream);
 /* P / dS have element type `dtype`; S / dP stay fp32 */
 int dwg_softmax_rows_forward_dt(int32_t dtype, int32_t rows, int32_t n, float scale, const float* S, int64_t lds, void* P,
                                 int64_t ldp, dwg_stream_t stream);

@@ -137,6 +137,52 @@ def test_f32x_attention_kernel_alone_long_and_ragged():
     assert max(worst.values()) < 5e-6, worst
 
 
+def test_f32x_attention_with_the_keys_split_over_workgroups():
+    """dwg_attention_forward_ws: launches whose query blocks do not fill the chip (the 32x32 / 16x16 levels' self-attention, ragged query
+    counts) split the keys over workgroups and merge the ranges in a second launch -- fp32-grade against float64 like the unsplit launch,
+    bit-reproducible run to run, and a launch the heuristic leaves alone (many query blocks; 77 keys) asks for no workspace."""
+    import ctypes
+    from dreamwaltz_g_amd import _lib, xfmt
+    L = _lib.lib()
+    st = lambda: ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)   # noqa: E731
+    pp = lambda t: ctypes.c_void_p(t.data_ptr())  # noqa: E731
+    assert L.dwg_attention_split_workspace_bytes(3, 2, 8, 4096, 4096, 40) == 0         # 512 query blocks: no split
+    assert L.dwg_attention_split_workspace_bytes(3, 2, 8, 1024, 77, 80) == 0           # three key tiles: nothing to split
+    assert L.dwg_attention_split_workspace_bytes(1, 2, 8, 1024, 1024, 80) == 0         # bf16 unit: not built there
+    worst = {}
+    for (Bn, Hh, Nq, Nk, d) in [(2, 8, 1024, 1024, 80), (2, 8, 256, 256, 160), (1, 8, 300, 333, 40), (1, 2, 130, 1000, 64), (2, 8, 64, 250, 160)]:
+        g = torch.Generator().manual_seed(Nq + Nk + d)
+        q = torch.randn(Bn, Nq, Hh * d, generator=g); k = torch.randn(Bn, Nk, Hh * d, generator=g); v = torch.randn(Bn, Nk, Hh * d, generator=g)
+        qx, kx, vx = xfmt.pack(q).cuda(), xfmt.pack(k).cuda(), xfmt.pack(v).cuda()
+        need = int(L.dwg_attention_split_workspace_bytes(3, Bn, Hh, Nq, Nk, d))
+        assert need > 0, (Nq, Nk, d)
+        ws = torch.empty(need // 4, device="cuda")
+        outs = []
+        for rep in range(2):
+            o = torch.empty(Bn, Nq, Hh * d, device="cuda", dtype=xfmt.DTYPE)
+            ws.fill_(float("nan"))                                          # nothing may be read that this launch did not write
+            _lib.prof_enable(True)
+            rc = L.dwg_attention_forward_ws(3, Bn, Hh, Nq, Nk, d, pp(qx), Hh * d, Nq * Hh * d, pp(kx), Hh * d, Nk * Hh * d, pp(vx), Hh * d,
+                                            Nk * Hh * d, pp(o), Hh * d, Nq * Hh * d, float(d) ** -0.5, pp(ws), need, st())
+            assert rc == 0
+            torch.cuda.synchronize()
+            names = _lib.prof_table(); _lib.prof_enable(False)
+            assert "flash_attn_merge" in names, names.keys()                # the split path ran
+            outs.append(o)
+        assert torch.equal(outs[0], outs[1])
+        qh = q.double().view(Bn, Nq, Hh, d).permute(0, 2, 1, 3); kh = k.double().view(Bn, Nk, Hh, d).permute(0, 2, 1, 3)
+        vh = v.double().view(Bn, Nk, Hh, d).permute(0, 2, 1, 3)
+        ref = (torch.softmax(qh @ kh.transpose(-1, -2) * d ** -0.5, -1) @ vh).permute(0, 2, 1, 3).reshape(Bn, Nq, Hh * d)
+        worst["N%d_K%d_d%d" % (Nq, Nk, d)] = _rel(xfmt.unpack(outs[0].cpu()), ref)
+        # without the workspace the same entry point runs the unsplit launch
+        o1 = torch.empty(Bn, Nq, Hh * d, device="cuda", dtype=xfmt.DTYPE)
+        rc = L.dwg_attention_forward_ws(3, Bn, Hh, Nq, Nk, d, pp(qx), Hh * d, Nq * Hh * d, pp(kx), Hh * d, Nk * Hh * d, pp(vx), Hh * d,
+                                        Nk * Hh * d, pp(o1), Hh * d, Nq * Hh * d, float(d) ** -0.5, None, 0, st())
+        assert rc == 0 and _rel(xfmt.unpack(o1.cpu()), ref) < 5e-6
+    _note("f32x_attention_key_split", **worst)
+    assert max(worst.values()) < 5e-6, worst
+
+
 def test_f32x_vae_down_block():
     from dreamwaltz_g_amd import sd15
     from oracle import sd15 as osd
