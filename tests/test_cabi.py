@@ -39,6 +39,24 @@ def test_workspace_sizes_host_only():
     assert L.dwg_raster_workspace_sizes(-1, 512, 512, 0, None, None, None) != 0
 
 
+def test_attention_key_split_heuristic_host_only():
+    """dwg_attention_split_workspace_bytes (include/dwg_nn.h): which launches of the f32x attention split their keys over workgroups.  The SD-1.5
+    sites at CFG batch 2 (8 heads): the 64x64 level's 4096 queries fill the chip (no workspace); the 32x32 level (1024 queries, 128 query
+    blocks) and the 16x16 level (256 queries, 32 blocks) split; the 8x8 level has two key tiles and cross-attention three (77 keys): nothing
+    to split; eight views batched (B = 16) fill the chip at 32x32 too.  Bytes = ranges x B x H x Nq x (padded head + 4) floats."""
+    L = _lib.lib()
+    F32X, BF16 = 3, 1
+    f = L.dwg_attention_split_workspace_bytes
+    assert f(F32X, 2, 8, 4096, 4096, 40) == 0
+    assert f(F32X, 2, 8, 1024, 1024, 80) == 4 * 16 * 1024 * (96 + 4) * 4
+    assert f(F32X, 2, 8, 256, 256, 160) == 4 * 16 * 256 * (160 + 4) * 4
+    assert f(F32X, 2, 8, 64, 64, 160) == 0
+    assert f(F32X, 2, 8, 1024, 77, 80) == 0
+    assert f(F32X, 16, 8, 1024, 1024, 80) == 0
+    assert f(BF16, 2, 8, 1024, 1024, 80) == 0          # only the split-precision unit has the merge launch
+    assert f(F32X, 0, 8, 1024, 1024, 80) == 0 and f(F32X, 2, 8, 1024, 1024, 200) == 0
+
+
 def test_no_kernel_spills_beyond_the_known_ones():
     """The compiler's per-kernel resource report of the last build (csrc/_obj/*.resources.json, written by build.py): no kernel
     uses scratch memory except the three listed with their bounds.  (Round 2 lost 7 ms per step to an epilogue change that
