@@ -33,7 +33,8 @@ int dwg_mlp_wgrad(int32_t M, int32_t N, int32_t K, const float* dz, int32_t lddz
  * deform_model.py:113-115 expands and concatenates: its product with W_0[:, Kin : Kin + n_extra] is the same for all rows and is added to
  * b_0 inside the launch), widths <= 64, Kin and the
  * hidden widths multiples of 8, acts in {NONE, RELU, LEAKY_RELU, SIGMOID}.  out [M, widths[last]] with row stride ldo.  hidden (may be
- * NULL) holds per hidden layer a [M, widths[l]] buffer that receives h_{l+1} (kept for the backward), or NULL entries.
+ * NULL) holds per hidden layer a [M, widths[l]] buffer that receives h_{l+1} (kept for the backward) -- a buffer for EVERY hidden layer or for
+ * none (DWG_E_ARG otherwise: whether activations are kept is a compile-time property of the launch).  Inference passes NULL.
  * weights / ldw / biases / widths / acts / hidden are HOST arrays of length nlayers (<= 6). */
 int dwg_mlp_chain_forward(int32_t M, int32_t Kin, const float* x, int32_t ldx, int32_t nlayers, const float* const* weights,
                           const int32_t* ldw, const float* const* biases, const int32_t* widths, const int32_t* acts,
