@@ -21,7 +21,24 @@ for r in csv.DictReader(open(sys.argv[1])):
     if "k_mlp_chain<" not in k: continue
     k = k[k.index("k_mlp_chain<"):].split("(")[0]
     acc[k][r["Counter_Name"]] += float(r["Counter_Value"]); n[(k, r["Counter_Name"])] += 1
-for k, d in acc.items():
-    print(k, {c: round(v / n[(k, c)]) for c, v in d.items()})
+out = {k: {c: round(v / n[(k, c)]) for c, v in d.items()} for k, d in acc.items()}
+for k, d in out.items():
+    print(k, d)
+import json, os
+dst = os.path.join(os.path.dirname(sys.argv[1]), "..", "summary.jsonl")
+open(dst, "a").write(json.dumps(out) + "\n")
 PY
 done
+python - <<PY
+import json, os
+rows = [json.loads(l) for l in open("$OUT/summary.jsonl")]
+merged = {}
+for r in rows:
+    for k, d in r.items():
+        merged.setdefault(k, {}).update(d)
+os.makedirs("$REPO/gpurun_out/profiles_r05", exist_ok=True)
+json.dump({"source": "rocprofv3 --pmc (four passes) over python tools/bench_mlp.py 300000: per-launch averages of the per-Gaussian MLP chain "
+                     "(k_mlp_chain<1, false>: static network, <2, false>: deformation network, inference; <.., true>: hidden activations kept)",
+           "kernels": merged}, open("$REPO/gpurun_out/profiles_r05/r05_pmc_mlp.json", "w"), indent=1)
+print("wrote r05_pmc_mlp.json", list(merged))
+PY
