@@ -323,3 +323,28 @@ def test_mlp_gradients_go_in_place_only_into_genuine_flat_gradient_slices():
     with gridencoder.table_grad_inplace(False):
         assert not mlp._inplace_allowed()
     assert mlp._inplace_allowed()
+
+
+def test_parameter_epoch_moves_with_every_write_behind_autograds_back():
+    """optim.PARAM_EPOCH: the fused Adam writes parameters through a raw pointer, so no tensor version counter moves -- caches of
+    parameter-derived values (avatar.DreamWaltzG._frozen_key, mlp.DeformNetwork's concatenated heads) key on this epoch instead.  It must
+    move on every optimizer step, eager (`step`) or captured (`prepare_step`: the host half of a replayed step)."""
+    import torch
+    from dreamwaltz_g_amd import optim
+    from tests.test_distributed_cpu import _cpu_adam_launch
+    saved = optim.FlatOptimizer._launch
+    optim.FlatOptimizer._launch = _cpu_adam_launch
+    try:
+        a = torch.nn.Parameter(torch.randn(4, 3))
+        opts = optim.build_flat_optimizers({"avatar": optim.AdamSpec([dict(params=[a], lr=1e-2)], eps=1e-15)}, torch.device("cpu"))
+        o = opts["avatar"]
+        v0, e0 = a._version, optim.PARAM_EPOCH[0]
+        o.zero_grad()
+        (a * a).sum().backward()
+        o.step()
+        assert optim.PARAM_EPOCH[0] == e0 + 1
+        hyper = torch.zeros(64, 4)
+        o.prepare_step(hyper, 0)
+        assert optim.PARAM_EPOCH[0] == e0 + 2
+    finally:
+        optim.FlatOptimizer._launch = saved
