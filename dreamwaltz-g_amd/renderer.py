@@ -183,14 +183,26 @@ class GaussianRenderer:
         from .rasterizer import rasterize_frames
         if torch.is_grad_enabled() and any(g.positions.requires_grad for g in frames):
             raise RuntimeError("render_frames is the forward-only playback path: call it under torch.inference_mode() / no_grad()")
-        rasterizer = self.build_gaussian_rasterizer(data=data)
-        rs = rasterizer.raster_settings
-        cam = torch.cat([rs.viewmatrix.reshape(-1), rs.projmatrix.reshape(-1), rs.campos.reshape(-1)]).float()
+        # one camera for the batch (`data`: the loader's dict), or one per frame (`data`: a list of F such dicts -- the reference's evaluation
+        # loader hands a camera with every pose; image size and field of view must agree across the batch)
+        datas = list(data) if isinstance(data, (list, tuple)) else [data]
+        if len(datas) not in (1, len(frames)):
+            raise ValueError("render_frames: %d cameras for %d frames" % (len(datas), len(frames)))
+        rows, rs = [], None
+        for d in datas:
+            r = self.build_gaussian_rasterizer(data=d).raster_settings
+            if rs is not None and (r.image_height, r.image_width, r.tanfovx, r.tanfovy) != (rs.image_height, rs.image_width, rs.tanfovx, rs.tanfovy):
+                raise ValueError("render_frames: the frames of a batch share image size and field of view")
+            rs = rs or r
+            rows.append(torch.cat([r.viewmatrix.reshape(-1), r.projmatrix.reshape(-1), r.campos.reshape(-1)]).float())
+        cam = rows[0] if len(rows) == 1 else torch.stack(rows)
+        data = datas[0]
         g0 = frames[0]
         use_colors = g0.colors is not None
         if not use_colors and not self.compute_color_in_rasterizer:
-            for g in frames:
-                g.colors = self.compute_colors(sh_features=g.sh_features, positions=g.positions, camera_positions=data['c2w'][:, :3, 3])
+            for f, g in enumerate(frames):
+                g.colors = self.compute_colors(sh_features=g.sh_features, positions=g.positions,
+                                               camera_positions=datas[f if len(datas) > 1 else 0]['c2w'][:, :3, 3])
             use_colors = True
         use_cov = not self.compute_covariance_in_rasterizer
         if use_cov:

@@ -75,7 +75,8 @@ class Scene(nn.Module):
         return gaussians
 
     def forward_frames(self, data: dict, poses, bg_mode: Optional[str] = None, frozen_avatar: bool = False) -> dict:
-        """Playback of F pose frames under one camera: `animate` per pose, then ONE rasterizer launch chain for all of them
+        """Playback of F pose frames under one camera (`data`: the loader's dict) or each under its own (`data`: a list of F dicts, as the
+        reference's evaluation loader yields them): `animate` per pose, then ONE rasterizer launch chain for all of them
         (renderer.render_frames).  Frame f equals `forward(data, poses[f], use_densifier=False, bg_mode=bg_mode)` bit for bit -- the
         reference's evaluation loop renders such sequences one pose at a time under inference mode (trainer.py:1019-1150).  Single avatar,
         no gradients.  `frozen_avatar`: the avatar's parameters do not change between the frames (a trained avatar playing a motion): the

@@ -91,6 +91,17 @@ def test_frames_per_launch_playback_equals_frame_by_frame(bg_mode):
                     assert torch.equal(batch[k][f:f + 1], single[f][k]), (F, f, k)
             hdr = scene.renderer.last_frames_headers.cpu()
             assert (hdr[:, 0] > 0).all() and (hdr[:, 1] == 0).all()           # pairs counted, nothing truncated
+        # a camera per frame (the reference's evaluation loader yields one with every pose)
+        from dreamwaltz_g_amd import camera
+        cams = [camera.make_camera(radius=2.0 + 0.1 * f, azimuth=20.0 + 40.0 * f, elevation=80.0 - 5.0 * f, fovy=55.0, height=256, width=256, device=dev)
+                for f in range(3)]
+        own = [scene.forward(cams[f], smpl_observed_inputs=poses[f], use_densifier=False, bg_mode=bg_mode)["image"].clone() for f in range(3)]
+        batch = scene.forward_frames(cams, poses[:3], bg_mode=bg_mode)
+        for f in range(3):
+            assert torch.equal(batch["image"][f:f + 1], own[f]), f
+        assert not torch.equal(own[0], own[1])
+        with pytest.raises(ValueError):
+            scene.forward_frames(cams[:2], poses[:3])
     with pytest.raises(RuntimeError):
         g = scene.avatar_forward(smpl_observed_inputs=poses[0])              # gradients enabled: not the playback path
         scene.renderer.render_frames(data, [g])
