@@ -65,7 +65,7 @@ def parse():
     ap.add_argument("--headline-only", action="store_true", help="skip the attached configs / by_dtype / cpu_baseline legs")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-guidance", action="store_true", help="raster+LBS sub-path only (not the headline workload)")
-    ap.add_argument("--frames-per-launch", type=int, default=4, help="config c5: pose frames rasterized per launch chain (1: frame by frame)")
+    ap.add_argument("--frames-per-launch", type=int, default=4, help="config c5: pose frames per launch chain of the `batched_frames` side measurement (the value is always frame by frame)")
     ap.add_argument("--frame-graph", action="store_true", help="config c5: replay each frame as one captured hipGraph (player.GraphedAnimation)")
     ap.add_argument("--step-graph", action="store_true", help="config c2 / single-GPU c3: the whole step (zero_grad, condition image, animate, raster, "
                                                               "VAE, ControlNet + UNet, backward, Adam) as ONE captured HIP graph replayed per pose "
@@ -163,7 +163,7 @@ def _cpu_pass(w, backward):
         with torch.no_grad():
             oa.animate(w["params"], w["nets"], w["body"], w["obs"], w["cnl"], mesh=w["mesh"])
     t1 = time.perf_counter()
-    rc.oracle_forward(w["sc"], omp=True)
+    rc.oracle_forward(w["sc"], omp=True, near=None)
     if backward:
         rc.oracle_backward(w["sc"], w["wc"], None, None, dtype=np.float32, omp=True)
     t2 = time.perf_counter()
@@ -576,38 +576,42 @@ def run_c5(ctx, steps=None, warmup=None):
         i = idx[0]; idx[0] += F
         with torch.inference_mode():
             return scene.forward_frames(data, [poses[(i + f) % 240] for f in range(F)], bg_mode=None, frozen_avatar=frozen[0])
-    dt_frozen = None
+    # `value` is the reference's loop: ONE frame per call (/root/reference/core/trainer.py:1019-1150).  The batched form (F pose frames per
+    # rasterizer launch chain, bit-identical images) and the frozen-avatar form are measured right after it and reported in side fields.
+    dt = _timed(ctx, frame, steps, warmup)
+    dt_batched = dt_frozen = None
+    bsteps = (steps + F - 1) // F * F
     if F > 1:
-        steps, warmup = (steps + F - 1) // F * F, (warmup + F - 1) // F * F
-        dt = _timed(ctx, batch, steps // F, warmup // F)
-        # the same frames for a FROZEN avatar (opt-in of Scene.forward_frames): the pose-independent part of animate -- canonical positions, grid
-        # encoding, colour / opacity network -- is computed once and kept while no parameter changes.  Reported beside the c5 value, never as
-        # it: the reference recomputes that part per frame, and so does the `value` above.
+        bwarm = (warmup + F - 1) // F * F
+        dt_batched = _timed(ctx, batch, bsteps // F, bwarm // F)
         frozen[0] = True
-        dt_frozen = _timed(ctx, batch, steps // F, warmup // F)
+        dt_frozen = _timed(ctx, batch, bsteps // F, bwarm // F)
         frozen[0] = False
-    else:
-        dt = _timed(ctx, frame, steps, warmup)
     graphed = player is not None
     if graphed:                 # per-kernel timers need eager launches: same kernels, same inputs, after the timed region
         assert player.check(), "a replayed frame was truncated by the frozen pair capacity"
         player.close(); player = None
     _lib.prof_enable(True)
+    ps = min(steps, 5)
+    for _ in range(ps):
+        frame()
+    torch.cuda.synchronize()
+    prof = _lib.prof_table(); _lib.prof_enable(False)
+    K, Kref = scene.renderer.last_rasterizer.last_num_pairs
+    batched = None
     if F > 1:
-        ps = F * 2
+        _lib.prof_enable(True)
         for _ in range(2):
             batch()
         torch.cuda.synchronize()
-        prof = _lib.prof_table(); _lib.prof_enable(False)
+        profb = _lib.prof_table(); _lib.prof_enable(False)
         hdr = scene.renderer.last_frames_headers.cpu()
-        K, Kref = int(hdr[:, 0].float().mean()), int(hdr[:, 2].float().mean())
-    else:
-        ps = min(steps, 5)
-        for _ in range(ps):
-            frame()
-        torch.cuda.synchronize()
-        prof = _lib.prof_table(); _lib.prof_enable(False)
-        K, Kref = scene.renderer.last_rasterizer.last_num_pairs
+        Kb, Krefb = int(hdr[:, 0].float().mean()), int(hdr[:, 2].float().mean())
+        batched = {"frames_per_launch": F, "value": bsteps / dt_batched, "unit": "frames/s", "ms_per_frame": dt_batched / bsteps * 1e3,
+                   "what": "the same frames, F pose frames per rasterizer launch chain (Scene.forward_frames: animate per frame, one binning + "
+                           "compositing chain for the batch); every image bit-identical to the frame-by-frame one",
+                   "roofline": raster_report(profb, G, Krefb, Kb, res * res, 2 * F),
+                   "kernel_ms_per_frame": {k: round(v[1] / (2 * F), 4) for k, v in sorted(profb.items(), key=lambda kv: -kv[1][1])[:12]}}
     return {"metric": "AIST++-style animation inference (config c5): frames/s, %dk-Gaussian avatar, per-frame LBS+raster at %d^2" % (G // 1000, res),
             "value": steps / dt, "unit": "frames/s", "n_gpus": 1, "steps": steps, "warmup": warmup, "ms_per_step": dt / steps * 1e3,
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
@@ -615,12 +619,12 @@ def run_c5(ctx, steps=None, warmup=None):
                                    "inference_mode, 240 seeded random pose frames" % (N, M, res, res), "gaussians": G, "resolution": res},
             "roofline": raster_report(prof, G, Kref, K, res * res, ps),
             "launch_mode": "one hipGraph per frame (player.GraphedAnimation); kernel timers from eager frames after the timed region" if graphed
-                           else ("eager; %d pose frames per rasterizer launch chain (Scene.forward_frames: animate per frame, one binning + compositing "
-                                 "chain for the batch; --frames-per-launch 1: frame by frame)" % F if F > 1 else "eager, frame by frame"),
-            "frames_per_launch": F,
+                           else "eager, frame by frame (the reference's evaluation loop); `batched_frames`: F pose frames per launch chain",
+            "frames_per_launch": 1,
+            "batched_frames": batched,
             "frozen_avatar_playback": None if dt_frozen is None else {
-                "value": steps / dt_frozen, "unit": "frames/s", "ms_per_step": dt_frozen / steps * 1e3,
-                "what": "the same frames with Scene.forward_frames(frozen_avatar=True): canonical positions, grid encoding and the colour / opacity "
+                "value": bsteps / dt_frozen, "unit": "frames/s", "ms_per_step": dt_frozen / bsteps * 1e3,
+                "what": "the batched frames with Scene.forward_frames(frozen_avatar=True): canonical positions, grid encoding and the colour / opacity "
                         "network computed once and kept while no parameter changes (bit-identical images); NOT the c5 value -- there every frame "
                         "recomputes them, as the reference's evaluation loop does"},
             "kernel_ms_per_step": {k: round(v[1] / ps, 4) for k, v in sorted(prof.items(), key=lambda kv: -kv[1][1])[:20]}}
@@ -665,8 +669,45 @@ def run_c1(ctx, steps=None, warmup=None):
 
 
 def _brief(line, keys=("value", "unit", "ms_per_step", "steps", "warmup", "repeats", "launch_mode", "camera", "dtype", "views_per_s", "views_per_step", "config",
-                       "roofline", "raster_mpix_per_s", "cpu_baseline", "metric", "redone_frames", "frames_per_launch", "frozen_avatar_playback")):
+                       "roofline", "raster_mpix_per_s", "cpu_baseline", "metric", "redone_frames", "frames_per_launch", "batched_frames", "frozen_avatar_playback")):
     return {k: line[k] for k in keys if k in line}
+
+
+def flat_scalars(out, cfgs, by):
+    """The sub-metrics of BASELINE.json's metric ("...; raster Mpix/s vs HBM roofline") and the other configurations' rates as FLAT top-level
+    scalars: a record that keeps only scalar keys of the line still carries them (the nested blocks stay for readers)."""
+    def g(d, *path):
+        for k in path:
+            if not isinstance(d, dict) or d.get(k) is None:
+                return None
+            d = d[k]
+        return d
+    rl = out.get("roofline", {})
+    c5b = g(cfgs, "c5", "batched_frames")
+    flat = {
+        "mfma_all_frac": g(rl, "mfma_all", "frac"), "mfma_all_tflops": g(rl, "mfma_all", "tflops"),
+        "raster_fwd_ms": g(rl, "raster_forward", "ms"), "raster_fwd_frac": g(rl, "raster_forward", "frac_of_hbm_peak"),
+        "raster_fwd_GBps": g(rl, "raster_forward", "achieved_GBps"), "raster_fwd_traffic_ratio": g(rl, "raster_forward", "traffic_over_algorithmic"),
+        "raster_bwd_ms": g(rl, "raster_backward", "ms"), "raster_bwd_frac": g(rl, "raster_backward", "frac_of_hbm_peak"),
+        "raster_bwd_GBps": g(rl, "raster_backward", "achieved_GBps"), "raster_bwd_traffic_ratio": g(rl, "raster_backward", "traffic_over_algorithmic"),
+        "c1_frames_per_s": g(cfgs, "c1", "value"), "c1_raster_fwd_frac": g(cfgs, "c1", "roofline", "raster_forward", "frac_of_hbm_peak"),
+        "c2_steps_per_s": g(cfgs, "c2", "value"), "c2_steps_per_s_moving": g(cfgs, "c2_moving_camera", "value"),
+        "c2_steps_per_s_eager_launches": g(cfgs, "c2_eager_launches", "value"),
+        "c2_steps_per_s_bound_loop": g(cfgs, "c2_bound_loop", "value"),
+        "c2_raster_fwd_frac": g(cfgs, "c2", "roofline", "raster_forward", "frac_of_hbm_peak"),
+        "c2_raster_bwd_frac": g(cfgs, "c2", "roofline", "raster_backward", "frac_of_hbm_peak"),
+        "c3_steps_per_s_bound_loop": g(cfgs, "c3_bound_loop", "value"),
+        "c4_n1_views_per_s": g(cfgs, "c4_n1", "views_per_s"), "c4_n1_sequential_views_per_s": g(cfgs, "c4_n1_sequential_views", "views_per_s"),
+        "c4_n1_raster_fwd_frac_per_view": g(cfgs, "c4_n1", "roofline", "raster_forward", "frac_of_hbm_peak"),
+        "c4_n1_raster_bwd_frac_per_view": g(cfgs, "c4_n1", "roofline", "raster_backward", "frac_of_hbm_peak"),
+        "c5_frames_per_s_frame_by_frame": g(cfgs, "c5", "value"), "c5_raster_frac_frame_by_frame": g(cfgs, "c5", "roofline", "raster_forward", "frac_of_hbm_peak"),
+        "c5_frames_per_s": g(c5b, "value"), "c5_frames_per_launch": g(c5b, "frames_per_launch"),
+        "c5_raster_frac": g(c5b, "roofline", "raster_forward", "frac_of_hbm_peak"), "c5_raster_ms_per_frame": g(c5b, "roofline", "raster_forward", "ms"),
+        "c5_frames_per_s_frozen_avatar": g(cfgs, "c5", "frozen_avatar_playback", "value"),
+    }
+    for d in ("f32", "f16", "bf16"):
+        flat["steps_per_s_" + d] = g(by, d, "value")
+    return {k: v for k, v in flat.items() if v is not None}
 
 
 def main():
@@ -738,6 +779,7 @@ def main():
                           "tests/test_sd15_f32x_gpu.py, test_sd15_fp32_gpu.py, test_sd15_fp16_gpu.py, test_sd15_full_width_gpu.py")
             out["by_dtype"] = by
             out["configs"] = cfgs
+            out.update(flat_scalars(out, cfgs, by))
             # the per-precision rates right behind "dtype", so that they are inside the head of the line whatever its length
             head = {}
             for k, v in out.items():

@@ -316,6 +316,11 @@ struct GsUnit { uint32_t slab, begin, end, multi; };       // multi: 0 = the sla
 // bits.  Float atomics -- here until round 4, and in the reference's own kernel (gridencoder.cu:245-337 atomicAdd) -- do not.  The
 // quantum is 2^-s >= gmax x 2^-61 x records: far below an fp32 ulp of anything the sum can be compared with; an entry whose whole sum is
 // below ~2^-48 gmax comes out as an exact zero instead of a noise-signed denormal-scale value.
+// A NON-FINITE incoming gradient must stay visible (the float-atomic path and the reference's atomicAdd let NaN / Inf reach the table
+// gradient, where a GradScaler or the replica check sees it; a double -> integer conversion would turn it into 0 or a saturated value):
+// the count pass folds NaN / Inf into its maximum as +Inf, the scan then marks every slab GS_NONFINITE and the writers store NaN.
+#define GS_NONFINITE 0x7fffffff
+__device__ __forceinline__ float gs_abs_or_inf(float v) { const float a = fabsf(v); return a <= 3.0e38f ? a : __builtin_inff(); }   // NaN, Inf -> Inf
 __device__ __forceinline__ long long gs_to_fixed(float v, int s) { return __double2ll_rn(ldexp((double)v, s)); }
 __device__ __forceinline__ float gs_from_fixed(long long q, int s) { return (float)ldexp((double)q, -s); }
 
@@ -353,7 +358,7 @@ __global__ __launch_bounds__(256) void k_gs_bin(GridP p, uint32_t nchunks, uint3
             Cell c = locate(p, offsets, level, x[3 * b], x[3 * b + 1], x[3 * b + 2]);
             if (!c.oob) {
                 if (level >= first_table_level) {
-                    if (!SCATTER) gmax = fmaxf(gmax, fmaxf(fabsf(g0), fabsf(g1)));      // interpolation weights are <= 1: bounds every record
+                    if (!SCATTER) gmax = fmaxf(gmax, fmaxf(gs_abs_or_inf(g0), gs_abs_or_inf(g1)));      // interpolation weights are <= 1: bounds every record
                     const uint32_t lvl_entry = (uint32_t)offsets[level] - first_entry;
 #pragma unroll
                     for (int idx = 0; idx < 8; idx++) {
@@ -436,6 +441,7 @@ __global__ __launch_bounds__(1024) void k_gs_scan(uint32_t nslab, const uint32_t
         __syncthreads();
     }
     int emax = 0;
+    const bool nonfinite = !(gm[0] < 3.0e38f);          // a NaN / Inf gradient somewhere in the call (gs_abs_or_inf)
     { const float g = gm[0]; if (g > 0.f && g < 3.0e38f) (void)frexpf(g, &emax); }      // g < 2^emax
     for (uint32_t base = 0; base < nslab; base += 1024u) {
         const uint32_t s_ = base + tid;
@@ -455,7 +461,7 @@ __global__ __launch_bounds__(1024) void k_gs_scan(uint32_t nslab, const uint32_t
             slab_start[s_] = start;
             // fixed-point scale of the slab: |record| < 2^emax, at most `run` of them per entry -> sums stay below 2^61
             int clog = 0; while ((1u << clog) < run && clog < 31) clog++;
-            sexp[s_] = 61 - emax - clog;
+            sexp[s_] = nonfinite ? GS_NONFINITE : 61 - emax - clog;
             if (isM) multi_list[mslot] = s_;
             for (uint32_t u = 0; u < nu; u++) {
                 GsUnit g;
@@ -479,6 +485,13 @@ __global__ __launch_bounds__(256) void k_gs_accumulate(uint32_t first_entry, uin
     if (blockIdx.x >= *n_units) return;
     const GsUnit u = units[blockIdx.x];
     const int sx = sexp[u.slab];
+    if (sx == GS_NONFINITE) {                            // non-finite incoming gradient: the slab's gradient is NaN (multi-unit slabs: k_gs_finalize)
+        if (!u.multi) {
+            const uint32_t e0n = first_entry + u.slab * GS_SLAB, nen = min(GS_SLAB, total_entries - e0n);
+            for (uint32_t e = threadIdx.x; e < nen * 2u; e += 256) grad_table[(size_t)e0n * 2 + e] = __builtin_nanf("");
+        }
+        return;
+    }
     for (uint32_t e = threadIdx.x; e < GS_SLAB * 2u; e += 256) tabq[e] = 0ull;
     __syncthreads();
     for (uint32_t r0 = u.begin + threadIdx.x; r0 < u.end; r0 += 1024) {        // four records in flight per thread
@@ -534,6 +547,10 @@ __global__ __launch_bounds__(256) void k_gs_finalize(uint32_t first_entry, uint3
     const uint32_t ne = min(GS_SLAB, total_entries - e0);
     float* dst = grad_table + (size_t)e0 * 2;
     const unsigned long long* img = gimg + (size_t)blockIdx.x * GS_SLAB * 2u;
+    if (sx == GS_NONFINITE) {
+        for (uint32_t e = threadIdx.x; e < ne * 2u; e += 256) dst[e] = __builtin_nanf("");
+        return;
+    }
     for (uint32_t e = threadIdx.x; e < ne * 2u; e += 256) dst[e] = gs_from_fixed((long long)img[e], sx) + (accumulate ? dst[e] : 0.f);
 }
 

@@ -166,10 +166,13 @@ class SDSStep:
         tfy = float(cam["tanfov"][0]); tfx = float(cam["tanfov_x"][0]) if "tanfov_x" in cam else tfy
         out = {"extrinsic": cam["extrinsic"].float(), "projection": cam["projection"].float(), "c2w": cam["c2w"].float(),
                "tanfov_dev": torch.tensor([tfx, tfy]), "radius": cam["radius"], "tanfov": cam["tanfov"]}
+        for k in ("azimuth", "elevation"):          # host scalars of the view-dependent prompt selection (trainer._select_text)
+            if k in cam:
+                out[k] = cam[k]
         if getattr(self, "condition", None) is not None:
             hw = self.condition["hw"]
-            f = hw / (2.0 * tfy)
-            out["cond_intrinsics"] = torch.tensor([[f, 0.0, hw / 2.0], [0.0, f, hw / 2.0], [0.0, 0.0, 1.0]])
+            fx, fy = hw / (2.0 * tfx), hw / (2.0 * tfy)
+            out["cond_intrinsics"] = torch.tensor([[fx, 0.0, hw / 2.0], [0.0, fy, hw / 2.0], [0.0, 0.0, 1.0]])
         return out
 
     def _apply_camera(self, d: dict, cam: dict):
@@ -180,6 +183,10 @@ class SDSStep:
             d[k] = ct[k].to(self.device)
         for k in ("tanfov", "radius", "azimuth", "elevation"):
             d[k] = cam[k]
+        if "tanfov_x" in cam:                       # a non-square field of view: the renderer reads it next to tanfov (renderer.py)
+            d["tanfov_x"] = cam["tanfov_x"]
+        else:
+            d.pop("tanfov_x", None)
         if "cond_intrinsics" in ct:
             d["cond_intrinsics"] = ct["cond_intrinsics"].to(self.device)
 

@@ -83,6 +83,14 @@ class GraphedTrainStep:
         self.condition_fn, self.seed_fn = condition_fn, seed_fn
         self.guided = hasattr(trainer.diffusion, "draw_view_randoms")
         self._rng, self._rand = None, None
+        # The view-dependent prompt (trainer._select_text, /root/reference/core/trainer.py:941-955) is chosen ON THE HOST from the camera's
+        # azimuth / elevation: a captured step would keep the capture-time embedding for every later camera.  It lives in a static device
+        # buffer the captured call reads; `step()` copies the embedding of THIS camera's view into it before the replay.
+        self._text_static = None
+        if self.guided and trainer.view_prompt is not None and 'viewed' in trainer.text_embeds_dict:
+            emb0, _ = trainer._select_text(self.data)
+            self._text_static = emb0.detach().clone()
+            self._text_index = None
         if self.guided:
             trainer.diffusion.set_use_graphs(False)            # the plans' kernels go into THIS graph, not into graphs of their own
             self._rng = torch.Generator(device=self.device)
@@ -147,6 +155,22 @@ class GraphedTrainStep:
         for k in self.camera:
             self.camera[k].copy_(camera[k].to(self.device, non_blocking=True).reshape(self.camera[k].shape))
         self._camera_scale(camera)
+        self._select_view_text(camera)
+
+    def _select_view_text(self, camera):
+        """The prompt embedding of this camera's view -> the static buffer the captured call reads (one [1,77,d] device copy, only when the
+        view class changes).  A moving camera of a guided step with text augmentation MUST carry 'azimuth' / 'elevation'."""
+        if self._text_static is None:
+            return
+        if "azimuth" not in camera or "elevation" not in camera:
+            raise KeyError("GraphedTrainStep: a guided step with view-dependent prompts needs the camera's 'azimuth' and 'elevation' "
+                           "(the prompt is selected from them every step: trainer._select_text)")
+        tr = self.trainer
+        self.data["azimuth"], self.data["elevation"] = camera["azimuth"], camera["elevation"]
+        idx = int(tr.view_prompt(azim=camera["azimuth"], elev=camera["elevation"]).item())
+        if idx != self._text_index:
+            self._text_static.copy_(tr.text_embeds_dict['viewed'][idx], non_blocking=True)
+            self._text_index = idx
 
     def _host_prepare(self):
         """What the eager trainer does on the host around a step (trainer.py:861-870, 888-890): step index, learning-rate schedule, the
@@ -181,7 +205,11 @@ class GraphedTrainStep:
             if self.condition_fn is not None:
                 # (a moving camera: the condition image is drawn from the graph's own camera tensors)
                 self.data["cond_images"] = self.condition_fn(self.pose, self.data) if self.camera else self.condition_fn(self.pose)
-        loss, render_outputs, _, _ = tr.train_forward(self.data, **forced)
+        tr._text_override = self._text_static           # (None: the trainer selects as in the eager step)
+        try:
+            loss, render_outputs, _, _ = tr.train_forward(self.data, **forced)
+        finally:
+            tr._text_override = None
         loss.backward()
         base = 0
         for o in tr.optimizers.values():
@@ -244,6 +272,7 @@ class GraphedTrainStep:
             if not self.camera:
                 raise ValueError("GraphedTrainStep.step: this step was captured with a fixed camera (no example_camera)")
             self._camera_scale(camera_cpu)                      # before the optimizers' scalars are prepared: the schedule reads it
+            self._select_view_text(camera_cpu)
             for k, dst in self._cam_pinned[i].items():
                 dst.copy_(camera_cpu[k].reshape(dst.shape))
         elif self.camera:                                       # the camera of the previous step stays: carry it into this slot

@@ -99,6 +99,9 @@ class SDSTrainer:
 
     def _select_text(self, data):
         """View-dependent prompt selection (trainer.py:944-955): -> (embedding [1,77,d] or None, prompt string)."""
+        if getattr(self, "_text_override", None) is not None:
+            # a captured step (step_graph.GraphedTrainStep): the embedding of the step's view sits in a static buffer the replay reads
+            return self._text_override, self.cfg.guide.text
         if self.cfg.prompt.text_augmentation and 'viewed' in self.text_embeds_dict:
             view_index = self.view_prompt(azim=data['azimuth'], elev=data['elevation']).item()
             return self.text_embeds_dict['viewed'][view_index], self.view_prompt.texts[view_index]
@@ -368,8 +371,18 @@ class SDSTrainer:
                 pg["t"], pg["lr"] = int(vals[k]), vals[k + 1]; k += 2
         if isinstance(self.model, torch.nn.Module):
             for b in self.model.buffers():
-                if b.device == buf.flat.device and b.is_contiguous() and b.numel() > 0 and b.dtype != torch.bool:
-                    self.dist.broadcast(b, src=src)
+                if b.device != buf.flat.device or b.numel() == 0:
+                    continue
+                if not b.is_contiguous():
+                    raise RuntimeError("sync_replicas: a non-contiguous model buffer of shape %s cannot be broadcast in place" % (tuple(b.shape),))
+                self.dist.broadcast(b.view(torch.uint8) if b.dtype == torch.bool else b, src=src)
+        # the broadcasts wrote parameters through `.data` views: no tensor version moved, so everything keyed on the parameters' state must be
+        # told -- the optimizers' parameter epoch (inference caches of the MLP heads / the frozen avatar) and the avatar's canonical caches
+        from . import optim as _optim
+        _optim.PARAM_EPOCH[0] += 1
+        inv = getattr(self.model, "invalidate_caches", None) or getattr(getattr(self.model, "avatar", None), "invalidate_caches", None)
+        if inv is not None:
+            inv()
 
     def replica_checksum(self) -> torch.Tensor:
         """64-bit checksum of the flat parameter buffer: the sum of its fp32 words read as int32, in int64 (exact, order-independent)."""

@@ -135,16 +135,25 @@ def bind_guidance(ref, dtype=None, keep_modules=None):
             hip.capture_graphs()
 
     # f32x range safety (round 5): the split-precision plans saturate at +-65504 and thin out below 6.1e-5 where the reference's fp32
-    # pipeline (core/guidance/basic.py:233) does neither.  Every DWG_BIND_RANGE_CHECK_EVERY calls (default 200; 0: never) the stored
-    # activations of the last call are scanned; a hit is reported ONCE per layer set with the layers' names and the documented way out.
+    # pipeline (core/guidance/basic.py:233) does neither.  The stored activations of a call are scanned after EVERY one of the first
+    # DWG_BIND_RANGE_CHECK_FIRST calls (default 20: a run that saturates does so at its first high-noise timesteps, and must not train
+    # 200 steps on clipped values before anything is said) and every DWG_BIND_RANGE_CHECK_EVERY calls after that (default 200; 0: never);
+    # a hit is reported ONCE per layer set with the layers' names and the documented way out.  DWG_BIND_RANGE_STRICT=1 raises instead.
     check_every = int(os.environ.get("DWG_BIND_RANGE_CHECK_EVERY", "200"))
-    state = {"calls": 0, "warned": set()}
+    check_first = int(os.environ.get("DWG_BIND_RANGE_CHECK_FIRST", "20")) if check_every > 0 else 0
+    strict = os.environ.get("DWG_BIND_RANGE_STRICT") == "1"
+    state = {"calls": 0, "warned": set(), "checks": 0}
 
     def _range_check():
         rep = hip.range_report()
         ref.hip_range_report = rep
+        state["checks"] += 1
+        ref.hip_range_checks = state["checks"]
         if rep is None or rep["ok"]:
             return
+        if strict:
+            raise FloatingPointError("dwg_bind: the f32x plans saturated / produced non-finite values at call %d (DWG_BIND_RANGE_STRICT=1); "
+                                     "rerun with DWG_BIND_DTYPE=f32" % state["calls"])
         layers = tuple(sorted({"%s:%s" % (n, d["layer"]) for n in ("denoiser", "vae_forward", "vae_backward") for d in rep[n]["worst"]
                                if d["saturated"] or d["nonfinite"]}))
         if layers not in state["warned"]:
@@ -158,7 +167,7 @@ def bind_guidance(ref, dtype=None, keep_modules=None):
         hip.timestep = self.timestep                       # controlnet.py:83-114 reads self.timestep
         out = hip._predict(latents_model_input, text_embeddings, cond_inputs).to(latents_model_input.dtype)
         state["calls"] += 1
-        if check_every > 0 and hip.dtype_name == "f32x" and (state["calls"] == 1 or state["calls"] % check_every == 0):
+        if check_every > 0 and hip.dtype_name == "f32x" and (state["calls"] <= check_first or state["calls"] % check_every == 0):
             _range_check()
         return out
 

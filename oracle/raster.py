@@ -45,8 +45,9 @@ def _prep(dtype, *arrs):
 
 def forward(means3D, opacities, viewmatrix, projmatrix, tanfovx, tanfovy, bg, H, W, colors=None, shs=None,
             sh_degree=0, campos=None, scales=None, rotations=None, cov3D=None, scale_modifier=1.0,
-            dtype=np.float32, omp=False):
-    """Returns dict(color[3,H,W], depth[H,W], alpha[H,W], radii[G], final_T, n_contrib, num_pairs)."""
+            dtype=np.float32, omp=False, near=None):
+    """Returns dict(color[3,H,W], depth[H,W], alpha[H,W], radii[G], final_T, n_contrib, num_pairs).  `near=(rel_alpha, rel_T)`: also
+    `near` [H,W] uint8, the hard thresholds each pixel sits on within those relative margins (raster_oracle.c composite_forward)."""
     L = _lib(dtype, omp)
     real = ctypes.c_double if np.dtype(dtype) == np.float64 else ctypes.c_float
     means3D, opacities, viewmatrix, projmatrix, bg, colors, shs, campos, scales, rotations, cov3D = _prep(
@@ -56,13 +57,21 @@ def forward(means3D, opacities, viewmatrix, projmatrix, tanfovx, tanfovy, bg, H,
     color = np.zeros((3, H, W), dtype); depth = np.zeros((H, W), dtype); alpha = np.zeros((H, W), dtype)
     radii = np.zeros(G, np.int32); fT = np.zeros((H, W), dtype); nc = np.zeros((H, W), np.int32)
     K = ctypes.c_int64(0)
-    L.dwg_oracle_raster_forward.restype = ctypes.c_int
-    L.dwg_oracle_raster_forward(
-        ctypes.c_int(G), ctypes.c_int(H), ctypes.c_int(W), _p(means3D), _p(colors), _p(shs), ctypes.c_int(sh_degree),
-        ctypes.c_int(ncoef), _p(campos), _p(opacities.reshape(-1)), _p(scales), _p(rotations), _p(cov3D),
-        _p(viewmatrix.reshape(-1)), _p(projmatrix.reshape(-1)), real(tanfovx), real(tanfovy), _p(bg),
-        real(scale_modifier), _p(color), _p(depth), _p(alpha), _p(radii), _p(fT), _p(nc), ctypes.byref(K))
-    return dict(color=color, depth=depth, alpha=alpha, radii=radii, final_T=fT, n_contrib=nc, num_pairs=K.value)
+    args = [ctypes.c_int(G), ctypes.c_int(H), ctypes.c_int(W), _p(means3D), _p(colors), _p(shs), ctypes.c_int(sh_degree),
+            ctypes.c_int(ncoef), _p(campos), _p(opacities.reshape(-1)), _p(scales), _p(rotations), _p(cov3D),
+            _p(viewmatrix.reshape(-1)), _p(projmatrix.reshape(-1)), real(tanfovx), real(tanfovy), _p(bg),
+            real(scale_modifier), _p(color), _p(depth), _p(alpha), _p(radii), _p(fT), _p(nc), ctypes.byref(K)]
+    out = dict(color=color, depth=depth, alpha=alpha, radii=radii, final_T=fT, n_contrib=nc)
+    if near is not None:
+        nr = np.zeros((H, W), np.uint8)
+        L.dwg_oracle_raster_forward_near.restype = ctypes.c_int
+        L.dwg_oracle_raster_forward_near(*args, _p(nr), real(near[0]), real(near[1]))
+        out["near"] = nr
+    else:
+        L.dwg_oracle_raster_forward.restype = ctypes.c_int
+        L.dwg_oracle_raster_forward(*args)
+    out["num_pairs"] = K.value
+    return out
 
 
 def backward(means3D, opacities, viewmatrix, projmatrix, tanfovx, tanfovy, bg, H, W, g_color, g_depth=None,

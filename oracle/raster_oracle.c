@@ -261,8 +261,14 @@ static int build_state(state_t* st, int G, int H, int W, const REAL* means3D, co
     return 0;
 }
 
+/* near (optional, [H*W] bytes): which hard thresholds of the compositing loop this pixel sits ON, within a relative margin -- the
+ * pixels where two correct implementations whose exp() / products round differently may legitimately take different branches:
+ *   bit 0  a splat's alpha within `rel_a` of the 1/255 cut          bit 1  test_T within `rel_t` of the 1e-4 termination threshold
+ *   bit 2  a contributing splat and its successor in the tile list have depths equal to within 4 fp32 ulps (sort order)
+ *   bit 3  power within 1e-6 of 0 (the power > 0 skip)               bit 4  alpha within `rel_a` of the 0.99 clamp: harmless, recorded only
+ * The parity tests demand |err| <= 1e-4 on every pixel whose byte is 0 and count / bound the rest (tests/raster_cases.py). */
 static void composite_forward(const state_t* st, const REAL* bg, REAL* out_color, REAL* out_depth,
-                              REAL* out_alpha, REAL* final_T, int* n_contrib) {
+                              REAL* out_alpha, REAL* final_T, int* n_contrib, unsigned char* near, REAL rel_a, REAL rel_t) {
     int H = st->H, W = st->W;
 #pragma omp parallel for collapse(2) schedule(dynamic, 2)
     for (int ty = 0; ty < st->tiles_y; ty++) for (int tx = 0; tx < st->tiles_x; tx++) {
@@ -272,16 +278,36 @@ static void composite_forward(const state_t* st, const REAL* bg, REAL* out_color
         for (int px = tx * TILE; px < (tx + 1) * TILE && px < W; px++) {
             REAL T = 1, C[3] = {0, 0, 0}, D = 0, A = 0;
             int contributor = 0, last = 0;
+            unsigned char nr = 0;
             for (uint32_t k = a; k < b; k++) {
                 contributor++;
                 const splat_t* s = &st->s[st->sorted[k]];
                 REAL dx = s->x - (REAL)px, dy = s->y - (REAL)py;
                 REAL power = (REAL)-0.5 * (s->ca * dx * dx + s->cc * dy * dy) - s->cb * dx * dy;
+                if (near && power > (REAL)-1e-6 && power < (REAL)1e-6) nr |= 8;
                 if (power > 0) continue;
                 REAL alpha = s->opacity * (REAL)exp((double)power);
+                if (near) {
+                    const REAL cut = (REAL)(1.0 / 255.0);
+                    if (alpha > cut * (1 - rel_a) && alpha < cut * (1 + rel_a)) nr |= 1;
+                    if (alpha > (REAL)0.99 * (1 - rel_a) && alpha < (REAL)0.99 * (1 + rel_a)) nr |= 16;
+                }
                 if (alpha > (REAL)0.99) alpha = (REAL)0.99;
                 if (alpha < (REAL)(1.0 / 255.0)) continue;
                 REAL test_T = T * (1 - alpha);
+                if (near) {
+                    if (test_T > (REAL)0.0001 * (1 - rel_t) && test_T < (REAL)0.0001 * (1 + rel_t)) nr |= 2;
+                    if (k + 1 < b) {
+                        const REAL d0 = s->depth, d1 = st->s[st->sorted[k + 1]].depth;
+                        const REAL dd = d1 > d0 ? d1 - d0 : d0 - d1, mag = d0 > 0 ? d0 : -d0;
+                        if (dd <= (REAL)4.8e-7 * mag) {          /* ... and the successor is visible at this pixel too */
+                            const splat_t* s2 = &st->s[st->sorted[k + 1]];
+                            REAL ex = s2->x - (REAL)px, ey = s2->y - (REAL)py;
+                            REAL pw2 = (REAL)-0.5 * (s2->ca * ex * ex + s2->cc * ey * ey) - s2->cb * ex * ey;
+                            if (pw2 <= 0 && s2->opacity * (REAL)exp((double)pw2) >= (REAL)(0.5 / 255.0)) nr |= 4;
+                        }
+                    }
+                }
                 if (test_T < (REAL)0.0001) break;
                 REAL w = alpha * T;
                 C[0] += s->rgb[0] * w; C[1] += s->rgb[1] * w; C[2] += s->rgb[2] * w;
@@ -291,6 +317,7 @@ static void composite_forward(const state_t* st, const REAL* bg, REAL* out_color
             size_t pix = (size_t)py * W + px, P = (size_t)H * W;
             if (final_T) final_T[pix] = T;
             if (n_contrib) n_contrib[pix] = last;
+            if (near) near[pix] = nr;
             out_color[pix] = C[0] + T * bg[0];
             out_color[P + pix] = C[1] + T * bg[1];
             out_color[2 * P + pix] = C[2] + T * bg[2];
@@ -309,7 +336,25 @@ int dwg_oracle_raster_forward(int G, int H, int W, const REAL* means3D, const RE
     state_t st;
     build_state(&st, G, H, W, means3D, colors, shs, sh_degree, sh_ncoef, campos, opac, scales, quats,
                 cov3D_precomp, viewm, projm, tanfovx, tanfovy, scale_mod, radii);
-    composite_forward(&st, bg, out_color, out_depth, out_alpha, final_T, n_contrib);
+    composite_forward(&st, bg, out_color, out_depth, out_alpha, final_T, n_contrib, NULL, 0, 0);
+    if (num_pairs) *num_pairs = st.K;
+    free_state(&st);
+    return 0;
+}
+
+/* The same forward, plus the per-pixel threshold-proximity byte described at composite_forward (test bookkeeping, not a product of the
+ * algorithm restated here). */
+int dwg_oracle_raster_forward_near(int G, int H, int W, const REAL* means3D, const REAL* colors,
+                                   const REAL* shs, int sh_degree, int sh_ncoef, const REAL* campos,
+                                   const REAL* opac, const REAL* scales, const REAL* quats,
+                                   const REAL* cov3D_precomp, const REAL* viewm, const REAL* projm,
+                                   REAL tanfovx, REAL tanfovy, const REAL* bg, REAL scale_mod,
+                                   REAL* out_color, REAL* out_depth, REAL* out_alpha, int* radii,
+                                   REAL* final_T, int* n_contrib, int64_t* num_pairs, unsigned char* near, REAL rel_a, REAL rel_t) {
+    state_t st;
+    build_state(&st, G, H, W, means3D, colors, shs, sh_degree, sh_ncoef, campos, opac, scales, quats,
+                cov3D_precomp, viewm, projm, tanfovx, tanfovy, scale_mod, radii);
+    composite_forward(&st, bg, out_color, out_depth, out_alpha, final_T, n_contrib, near, rel_a, rel_t);
     if (num_pairs) *num_pairs = st.K;
     free_state(&st);
     return 0;
@@ -336,7 +381,7 @@ int dwg_oracle_raster_backward(int G, int H, int W, const REAL* means3D, const R
     REAL* oc = (REAL*)malloc(3 * P * sizeof(REAL)); REAL* od = (REAL*)malloc(P * sizeof(REAL));
     REAL* oa = (REAL*)malloc(P * sizeof(REAL)); REAL* fT = (REAL*)malloc(P * sizeof(REAL));
     int* nc = (int*)malloc(P * sizeof(int));
-    composite_forward(&st, bg, oc, od, oa, fT, nc);
+    composite_forward(&st, bg, oc, od, oa, fT, nc, NULL, 0, 0);
     REAL* g2d = (REAL*)calloc((size_t)(G > 0 ? G : 1) * 2, sizeof(REAL));   /* d/d(pixel xy) * (0.5W,0.5H) */
     REAL* gcon = (REAL*)calloc((size_t)(G > 0 ? G : 1) * 3, sizeof(REAL));
     REAL* gop = (REAL*)calloc((size_t)(G > 0 ? G : 1), sizeof(REAL));

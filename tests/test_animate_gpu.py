@@ -171,6 +171,27 @@ def test_grid_encoder_table_gradient_is_bit_reproducible(B):
         assert torch.equal(g, grads[0])
 
 
+@pytest.mark.parametrize("bad", [float("nan"), float("inf")])
+def test_grid_encoder_fixed_point_gradient_keeps_a_non_finite_gradient_visible(bad):
+    """Round 6 (advisor): the deterministic fixed-point accumulation converts floats to integers, which would turn a NaN / Inf incoming
+    gradient into 0 or a saturated value.  The count pass flags it and the table gradient comes out non-finite, as the float-atomic path's
+    (and the reference's atomicAdd, gridencoder.cu:245-337) does -- a GradScaler or the replica check can see it."""
+    from dreamwaltz_g_amd.gridencoder import grid_encode
+    B = 20000
+    x, table, offsets, pls, _ = _grid_case(B, B, 0)
+    xc = x.cuda().requires_grad_(True); tc = table.cuda().requires_grad_(True)
+    out = grid_encode(xc, tc, torch.from_numpy(offsets).cuda(), pls, 16, True, 0, False, 1)
+    go = torch.randn(out.shape, generator=torch.Generator().manual_seed(5)).cuda() * 1e-3
+    go[B // 2, 7] = bad
+    out.backward(go)
+    assert not bool(torch.isfinite(tc.grad).all())
+    # and a finite gradient right after it is finite again (no sticky state)
+    tc.grad = None; xc.grad = None
+    out = grid_encode(xc, tc, torch.from_numpy(offsets).cuda(), pls, 16, True, 0, False, 1)
+    out.backward(torch.nan_to_num(go, nan=0.0, posinf=0.0))
+    assert bool(torch.isfinite(tc.grad).all()) and float(tc.grad.abs().sum()) > 0
+
+
 def test_grid_encoder_backend_layout_and_module():
     """[L,B,C] layout of the `_gridencoder` backend + the GridEncoder module mirror (bound=2 mapping, grid.py:149-165)."""
     from dreamwaltz_g_amd import gridencoder as ge

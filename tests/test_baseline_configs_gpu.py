@@ -6,7 +6,8 @@
                                                                   (colour linearity, permutation invariance, alpha range)
 (c1 = 10 000 / 256x256 forward is the first case of tests/test_raster_gpu.py; c3's diffusion half is tests/test_guidance_gpu.py;
  c4 = c3 x 8 GPUs is bench.py --gpus 8, its reduce + Adam bookkeeping is tests/test_distributed_cpu.py.)
-Tolerances as in tests/test_raster_gpu.py: q99.9 |err| <= 1e-4 per pixel, gradients rel-L2 <= 2e-3.
+Tolerances as in tests/test_raster_gpu.py: max |err| <= 1e-4 per pixel off the algorithm's hard thresholds, threshold flips counted and
+bounded (raster_cases.check_images), gradients rel-L2 <= 2e-3.
 """
 import numpy as np
 import pytest
@@ -19,13 +20,7 @@ pytestmark = pytest.mark.gpu
 
 
 def _check_images(st, name):
-    # radii = ceil(3 sqrt(lambda_max)): an fp32 rounding difference in lambda flips the ceil at an integer boundary, so a radius may be
-    # off by one on a few Gaussians in 10^5; visibility (radius > 0, what the densifier filters on) must agree everywhere
-    rd = st["radii_diff"]
-    assert rd["visibility"] == 0 and rd["max"] <= 1 and rd["n"] <= 4, (name, rd)
-    for k in ("color", "depth", "alpha"):
-        assert st[k]["q999"] <= 1e-4, (name, k, st[k])
-        assert st[k]["frac_gt_1e4"] <= 5e-4, (name, k, st[k])
+    rc.check_images(st, name, note=name)
 
 
 def _skeleton(seed, J=55):

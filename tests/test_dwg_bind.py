@@ -180,3 +180,9 @@ def test_bound_guidance_seams_run_the_hip_plans():
     assert torch.equal(z1, z2)
     z1.sum().backward()
     assert img.grad is not None and float(img.grad.abs().sum()) > 0
+    # round 6: the f32x range scan runs after EVERY one of the first 20 bound calls (a run that saturates at call 3 must not train 197
+    # more calls on clipped values before a word is said), then every 200th
+    assert ref.hip_range_checks == 1 and ref.hip_range_report["ok"]
+    for _ in range(4):
+        ref._predict(lat, text, cond)
+    assert ref.hip_range_checks == 5

@@ -27,14 +27,17 @@ def _env():
     return env
 
 
-def _run_workers(prefix, world, views, steps):
+def _run_workers(prefix, world, views, steps, backend=None):
     worker = os.path.join(ROOT, "tests", "multiview_worker.py")
     if world == 1:
         cmd = [sys.executable, worker, prefix, str(views), str(steps)]
     else:
         cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(world), "--master-addr", "127.0.0.1",
                "--master-port", str(_free_port()), worker, prefix, str(views), str(steps)]
-    r = subprocess.run(cmd, env=_env(), capture_output=True, text=True, timeout=900)
+    env = _env()
+    if backend:
+        env["DWG_WORKER_BACKEND"] = backend
+    r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=900)
     assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-3000:]
     return [torch.load("%s_rank%d.pt" % (prefix, k)) for k in range(world)]
 
@@ -60,6 +63,26 @@ def test_two_ranks_on_one_gpu_equal_one_process_accumulating_the_same_views(tmp_
     # order lands 2 lr apart.  Such entries must be rare; everything else agrees to rounding.
     assert float((d > 1e-5).float().mean()) < 2e-3, float((d > 1e-5).float().mean())
     assert bool(moved.any())
+
+
+@pytest.mark.skipif(torch.cuda.device_count() < 2, reason="needs two GPUs: the real train_step on two ranks over RCCL (nccl backend)")
+def test_two_ranks_on_two_gpus_over_rccl(tmp_path):
+    """Round 6 (verdict round 5, next 7): whenever a lease has two GPUs, the REAL multi-rank step runs over RCCL / xGMI -- rank r on cuda:r,
+    `nccl` backend with device_id, the sliced asynchronous all-reduce of trainer._reduce_and_step -- even when the driver's SCALE run is
+    skipped.  Replicas bit-identical, equal to one process accumulating the same views, and the exchange step's duration is reported."""
+    V, steps = 4, 3
+    two = _run_workers(str(tmp_path / "rccl"), 2, V, steps, backend="nccl")
+    one = _run_workers(str(tmp_path / "one"), 1, V, steps)
+    assert [t["device"] for t in two] == ["cuda:0", "cuda:1"] and two[0]["backend"] == "nccl"
+    assert two[0]["views"] == [0, 2] and two[1]["views"] == [1, 3]
+    assert torch.equal(two[0]["grad"], two[1]["grad"]) and torch.equal(two[0]["flat"], two[1]["flat"])      # bit-identical replicas
+    assert _rel(two[0]["grad"], one[0]["grad"]) < 1e-4
+    assert two[0]["allreduce_ms"] is not None and two[0]["allreduce_ms"] > 0
+    print("[rccl] two ranks on two GPUs: allreduce %.3f ms per step (flat gradient %d floats)" % (two[0]["allreduce_ms"], two[0]["grad"].numel()))
+    path = os.path.join(ROOT, "gpurun_out", "rccl_two_ranks.json")
+    os.makedirs(os.path.dirname(path), exist_ok=True)
+    json.dump({"world": 2, "backend": "nccl", "allreduce_ms_per_step": two[0]["allreduce_ms"], "grad_floats": int(two[0]["grad"].numel()),
+               "replicas_bit_identical": True}, open(path, "w"))
 
 
 def test_bench_spawns_its_own_ranks(tmp_path):

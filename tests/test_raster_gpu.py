@@ -1,8 +1,9 @@
 """-m gpu parity tests: HIP rasterizer (through the C-ABI / drop-in module) vs the CPU oracle.
 
-Tolerances: the north_star asks for <= 1e-4 per pixel.  The forward has hard thresholds (alpha < 1/255,
-T < 1e-4, power > 0) at which a 1-ulp difference in exp() flips one splat for one pixel, so the test demands
-q99.9 of |err| <= 1e-4 and bounds the isolated flips (< 0.05 % of pixels above 1e-4, none above 2e-2).
+Tolerances: the north_star asks for <= 1e-4 per pixel, and that is asserted as a MAXIMUM (round 6; a quantile before): the forward has
+hard thresholds (alpha < 1/255, T < 1e-4, depth-order ties) at which a 1-ulp difference in exp() flips one splat for one pixel, the oracle
+marks the pixels that sit on one (within stated relative margins), and `raster_cases.check_images` demands max |err| <= 1e-4 over all OTHER
+pixels, counts the flips that actually happened among the marked ones (<= 0.05 % of the image, each <= 2e-2) and records both.
 Gradients (round 4: pair-ordered partials + per-Gaussian gather, no atomics, bit-reproducible): relative L2 error <= 2e-3 against the
 float64 oracle.
 """
@@ -16,14 +17,7 @@ pytestmark = pytest.mark.gpu
 
 
 def _check_images(st, name):
-    # radii = ceil(3 sqrt(lambda_max)): an fp32 rounding difference in lambda flips the ceil at an integer boundary, so a radius may be
-    # off by one on a few Gaussians in 10^5; visibility (radius > 0, what the densifier filters on) must agree everywhere
-    rd = st["radii_diff"]
-    assert rd["visibility"] == 0 and rd["max"] <= 1 and rd["n"] <= 4, (name, rd)
-    for k in ("color", "depth", "alpha"):
-        assert st[k]["q999"] <= 1e-4, (name, k, st[k])
-        assert st[k]["frac_gt_1e4"] <= 5e-4, (name, k, st[k])
-        assert st[k]["max"] <= 2e-2 * (10.0 if k == "depth" else 1.0), (name, k, st[k])
+    rc.check_images(st, name, note=name)
 
 
 @pytest.mark.parametrize("G,H,W,kw", [

@@ -163,3 +163,53 @@ def test_graphed_step_follows_a_camera_that_moves_every_step():
     for name in e0.optimizers:                               # the schedule's spatial scale followed the camera (radius x tanfov per step)
         for ge, gt in zip(e0.optimizers[name].param_groups, twin.optimizers[name].param_groups):
             assert ge["t"] == gt["t"] and abs(ge["lr"] - gt["lr"]) <= 1e-9 * max(1.0, abs(ge["lr"])), (name, ge["lr"], gt["lr"])
+
+
+def test_graphed_guided_step_follows_the_view_prompt_of_a_moving_camera():
+    """Round 6 (advisor, medium): the view-dependent prompt (trainer._select_text, /root/reference/core/trainer.py:941-955) is selected on the
+    host from the camera's azimuth / elevation.  A captured GUIDED step keeps the embedding in a static device buffer that `step(pose,
+    camera)` refreshes, so a camera that moves through several view classes gets each step's own prompt: graph == eager, bit for bit, and
+    the sequence really crosses view classes (a twin whose prompt is pinned to the capture-time view ends somewhere else)."""
+    import dwg_import  # noqa: F401
+    from dreamwaltz_g_amd import guidance, sd15, sds_step
+    dev = torch.device("cuda:0")
+    torch.cuda.set_stream(torch.cuda.Stream(device=dev))
+    res, n_steps, warm = 128, 5, 2
+    ucfg = sd15.UNetConfig(block_out_channels=(64, 128, 128, 128), cross_dim=64, cond_channels=(16, 32, 32, 64))
+    vcfg = sd15.VAEConfig(block_out_channels=(32, 64, 64, 64))
+    usd = sd15.random_state_dict(sd15.unet_param_shapes(ucfg), seed=1)
+    csd = sd15.random_state_dict(sd15.controlnet_param_shapes(ucfg), seed=2)
+    vsd = sd15.random_state_dict(sd15.vae_encoder_param_shapes(vcfg), seed=3)
+    gd = guidance.ControlNetScoreDistillation(dev, ucfg, vcfg, usd, csd, vsd, image_hw=res, dtype="f32x")
+    from dreamwaltz_g_amd import camera
+
+    def cam_fn(i):       # azimuth walks front -> left side -> back -> right side; field of view and radius move too
+        return camera.make_camera(radius=1.8 + 0.07 * (i % 5), azimuth=(55.0 * i) % 360.0, elevation=70.0 + 3.0 * (i % 4), fovy=45.0 + 2.5 * (i % 6),
+                                  height=res, width=res, device="cpu")
+
+    def make():
+        s = sds_step.SDSStep(n_gaussians=6000, res=res, device=dev, guidance=True, guidance_obj=gd, async_pair_count=True, iters=1000)
+        s.camera_fn = cam_fn
+        return s
+    e = make()
+    idxs = []
+    for _ in range(n_steps + warm + 1):
+        out = e.run()
+        d = e.view_data[e.my_views[0]]
+        idxs.append(int(e.trainer.view_prompt(azim=d["azimuth"], elev=d["elevation"])))
+    img_e = out[1]["image"].detach().clone()
+    assert len(set(idxs[warm + 1:])) >= 3, idxs                    # the replayed steps cross view classes
+    torch.cuda.synchronize()
+    twin = make()
+    runner = twin.graphed(warmup=warm)
+    assert runner.graph._text_static is not None
+    seen = []
+    for _ in range(n_steps):
+        loss, outs = runner.step()
+        seen.append(runner.graph._text_index)
+    assert not runner.graph.check()
+    assert seen == idxs[warm + 1:], (seen, idxs)
+    be, bt = e.optimizers.buffers, twin.optimizers.buffers
+    print("[parity] guided step_graph, moving camera + view prompts: params graph/eager %.3e, view classes %s" % (_rel(bt.flat, be.flat), seen))
+    assert torch.equal(bt.flat, be.flat) and torch.equal(bt.m, be.m) and torch.equal(outs["image"], img_e)
+    gd.set_use_graphs(True)
