@@ -361,18 +361,23 @@ __device__ __forceinline__ void epilogue_store4(const GemmP& p, float (&v)[4], i
 // loop: a ONE-k-step, ONE-workgroup launch took 6.7 us inside a captured graph against 1.5 us for an empty kernel, i.e. ~5 us of
 // instruction fetch per launch on ~470 launches per SDS step (tools/shape_sweep.py PROBE=1, DESIGN.md "what bounds the small GEMMs").
 // ---------------------------------------------------------------------------------------------------------------------
-// row stride 4 (mod 32) banks: conflict-free b128 rows.  One pass over all 128 rows when the kernel's operand stages are large enough, else two.
-template <int BN> struct EpiLds {
+// row stride 4 (mod 32) banks: conflict-free b128 rows.  One pass over all BM rows when the kernel's operand stages are large enough, else two / four.
+template <int BN, int BM = 128> struct EpiLds {
     static constexpr int LDC = BN + 4;
-    static constexpr int passes(size_t lds_bytes) { return lds_bytes >= (size_t)128 * LDC * 4 ? 1 : 2; }
-    static constexpr size_t bytes(int npass) { return (size_t)(128 / npass) * LDC * 4; }
+    static constexpr int passes(size_t lds_bytes) {
+        return lds_bytes >= (size_t)BM * LDC * 4 ? 1 : (lds_bytes >= (size_t)(BM / 2) * LDC * 4 ? 2 : 4);
+    }
+    static constexpr size_t bytes(int npass) { return (size_t)(BM / npass) * LDC * 4; }
 };
 
-// RowFn: tile-local row (0..127) -> global output row, or -1 (outside the problem)
-template <int BN, int NPASS, int TM, int TN, bool LIGHT, typename RowFn>
+// RowFn: tile-local row (0..BM-1) -> global output row, or -1 (outside the problem).  BM rows, NT threads (128 / 256 for the four-wave
+// kernels; 256 x 128 and 128 x 256 tiles on eight waves: round 6)
+template <int BN, int NPASS, int TM, int TN, bool LIGHT, int BM = 128, int NT = 256, typename RowFn>
 __device__ __forceinline__ void tile_epilogue_lds(const GemmP& p, f32x16 (&acc)[TM][TN], float* sC, int n0, int wm, int wn, int lane, int tid,
                                                   int ks_id, long long coff, long long roff, RowFn row_of) {
-    constexpr int LDC = EpiLds<BN>::LDC, C4 = BN / 4, PR = 128 / NPASS;      // PR rows per pass
+    constexpr int LDC = EpiLds<BN, BM>::LDC, C4 = BN / 4, PR = BM / NPASS;      // PR rows per pass
+    constexpr int BPP = BM / 32 / NPASS;                                         // 32-row blocks per pass
+    static_assert(NT % C4 == 0 && (C4 & (C4 - 1)) == 0, "a thread keeps one column group");
     const bool vec_ok = epilogue_vec_ok(p, coff, roff);
     const int lrow = lane & 31, lhalf = (lane >> 5) * 4;
     const bool geglu = p.act == 6;
@@ -387,8 +392,8 @@ __device__ __forceinline__ void tile_epilogue_lds(const GemmP& p, f32x16 (&acc)[
 #pragma unroll
         for (int i = 0; i < TM; i++) {
             const int rb = wm * TM + i;                 // 32-row block of this wave (wave-uniform)
-            if (NPASS == 2 && (rb >> 1) != q) continue;
-            float* dst = sC + ((NPASS == 2 ? (rb & 1) : rb) * 32 + lrow) * LDC + wn * 64 + lhalf;
+            if (NPASS > 1 && rb / BPP != q) continue;
+            float* dst = sC + ((NPASS > 1 ? rb % BPP : rb) * 32 + lrow) * LDC + wn * 64 + lhalf;
 #pragma unroll
             for (int j = 0; j < TN; j++)
 #pragma unroll
@@ -402,7 +407,7 @@ __device__ __forceinline__ void tile_epilogue_lds(const GemmP& p, f32x16 (&acc)[
             // blocks of 32, so columns [64 b, 64 b + 32) of the tile hold `hidden` and [64 b + 32, 64 b + 64) the matching `gate`: the product
             // is formed here and only the half-width result is stored (no [M, 8C] round trip).  N % 64 == 0.
             // a thread keeps ONE group of four output columns for the whole tile: the eight bias values and the column tests are loop invariants
-            constexpr int G = C4 / 2, RSTEP = 256 / G;
+            constexpr int G = C4 / 2, RSTEP = NT / G;
             const int o4 = tid & (G - 1), rl0 = tid / G;
             const int b = o4 >> 3, w = (o4 & 7) * 4;
             const int colp = n0 + b * 64 + w;
@@ -448,7 +453,7 @@ __device__ __forceinline__ void tile_epilogue_lds(const GemmP& p, f32x16 (&acc)[
             // tile (256 % C4 == 0), so the column bounds test, the per-column bias and every column offset are loop invariants and a piece
             // costs ~20-45 VALU instructions instead of the ~190 of the general loop below.  This matters: with one or two waves per SIMD the
             // prologue + epilogue instruction stream (4 cycles per wave64 VALU instruction) IS the launch time of the 5-20-k-step layers.
-            constexpr int RSTEP = 256 / C4;
+            constexpr int RSTEP = NT / C4;
             const int c4 = tid & (C4 - 1), rl0 = tid / C4;
             const int col = n0 + c4 * 4;
             if (col < p.N) {
@@ -501,7 +506,7 @@ __device__ __forceinline__ void tile_epilogue_lds(const GemmP& p, f32x16 (&acc)[
             continue;
         }
 #pragma unroll 1
-        for (int idx = tid; idx < PR * C4; idx += 256) {
+        for (int idx = tid; idx < PR * C4; idx += NT) {
             const int rl = idx / C4, c4 = idx - rl * C4;
             const int row = row_of(q * PR + rl), col = n0 + c4 * 4;
             if (row < 0 || col >= p.N) continue;
@@ -652,9 +657,9 @@ __global__ __launch_bounds__(256, (sizeof(T) == 4 || BN == 64) ? 2 : 1) void k_g
 // ---------------------------------------------------------------------------------------------------------------------
 __device__ __attribute__((aligned(16))) unsigned char g_zero16[16];
 
-template <int ROWS, bool CONV>
+template <int ROWS, bool CONV, int NW = 4>
 struct GldsLoader {
-    static constexpr int NJ = ROWS / 32;       // wave-instructions per wave per tile (each covers 8 rows); even
+    static constexpr int NJ = ROWS / (8 * NW);     // wave-instructions per wave per tile (each covers 8 rows); even
     const HT* rowptr[CONV ? 1 : NJ];
     int iy0[CONV ? NJ : 1], ix0[CONV ? NJ : 1];
     long long pix0[CONV ? NJ : 1];
@@ -749,10 +754,12 @@ struct GldsLoader {
 //   * per row: a base pointer at (iy0, ix0) [may lie outside the image, only dereferenced when valid] that already contains the
 //     lane's swizzled chunk offset, and a KH*KW-bit validity mask (row in range, tap inside the image).
 // Per k-step and row this leaves: test one mask bit, one 64-bit add, one select.
-template <int ROWS>
+template <int ROWS, int NW = 4, bool CAT = false>
 struct GldsConvFast {
-    static constexpr int NJ = ROWS / 32;
+    static constexpr int NJ = ROWS / (8 * NW);
     const unsigned char* pb[NJ];
+    const unsigned char* pb2[CAT ? NJ : 1];    // CAT (round 6): the skip-connection concat fused into the conv -- channels [0, cin1) from A, the rest
+                                               // from A2, both multiples of 64: a k-tile lies inside one tap AND one source (wave-uniform choice)
     unsigned int mask[NJ];
     int kcur, kend, tap, ci, ky, kx;       // wave-uniform
 
@@ -763,6 +770,7 @@ struct GldsConvFast {
         kcur = kbeg; kend = kend_;
         tap = kbeg / cv.Cin; ci = kbeg - tap * cv.Cin; ky = tap / cv.KW; kx = tap - ky * cv.KW;
         const int hw = cv.Hout * cv.Wout;
+        const int cs1 = CAT ? cv.cin1 : cv.Cin;
 #pragma unroll
         for (int j = 0; j < NJ; j++) {
             const int r = r0 + (wave * NJ + j) * 8 + sub;
@@ -779,21 +787,29 @@ struct GldsConvFast {
                 }
             mask[j] = m;
             const long long pix = ((long long)img * cv.Hin + iy0) * cv.Win + ix0;
-            pb[j] = reinterpret_cast<const unsigned char*>(base) + (pix * cv.Cin + (lg0 ^ ((j & 1) << 2)) * 8) * 2;
+            pb[j] = reinterpret_cast<const unsigned char*>(base) + (pix * cs1 + (lg0 ^ ((j & 1) << 2)) * 8) * 2;
+            if (CAT) pb2[j] = reinterpret_cast<const unsigned char*>(cv.A2) + (pix * (cv.Cin - cv.cin1) + (lg0 ^ ((j & 1) << 2)) * 8) * 2;
         }
     }
     __device__ __forceinline__ void advance(const ConvP& cv) {
+        // branch-free (scalar selects): a branch here would cut the k-step's basic block in two and keep the scheduler from placing the
+        // tile loads between the MFMAs
         kcur += 64; ci += 64;
-        if (ci >= cv.Cin) { ci = 0; ++tap; if (++kx == cv.KW) { kx = 0; ++ky; } }
+        const int w = ci >= cv.Cin ? 1 : 0;
+        ci = w ? 0 : ci; tap += w; kx += w;
+        const int w2 = kx == cv.KW ? 1 : 0;
+        kx = w2 ? 0 : kx; ky += w2;
     }
     __device__ __forceinline__ void issue(unsigned char* lds_tile, const ConvP& cv) {
         const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
         const unsigned char* zero = g_zero16;
-        const long long uoff = (((long long)ky * cv.Win + kx) * cv.Cin + ci) * 2;      // scalar
+        const bool second = CAT && ci >= cv.cin1;                                       // scalar
+        const int cs = CAT ? (second ? cv.Cin - cv.cin1 : cv.cin1) : cv.Cin;
+        const long long uoff = (((long long)ky * cv.Win + kx) * cs + (second ? ci - cv.cin1 : ci)) * 2;      // scalar
         const unsigned int bit = kcur < kend ? (1u << tap) : 0u;                        // scalar (tiles past kend: zero page)
 #pragma unroll
         for (int j = 0; j < NJ; j++) {
-            const unsigned char* src = (mask[j] & bit) ? pb[j] + uoff : zero;
+            const unsigned char* src = (mask[j] & bit) ? ((CAT && second) ? pb2[j] : pb[j]) + uoff : zero;
             unsigned char* dst = lds_tile + ((wave * NJ + j) * 8) * 128;
             __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
                                              (__attribute__((address_space(3))) void*)dst, 16, 0, 0);
@@ -810,16 +826,27 @@ __device__ __forceinline__ void wait_vmcnt() {
 // S-stage software pipeline: S-1 k-tiles are in flight (direct-to-LDS loads) while one is being multiplied; one barrier per
 // k-step.  Tiles past kend are still issued (from a 16-byte zero line) so that the outstanding-load count the s_waitcnt
 // relies on is a compile-time constant.
-template <int BM, int AKIND> struct ALoaderOf { typedef GldsLoader<BM, false> type; };
-template <int BM> struct ALoaderOf<BM, 1> { typedef GldsLoader<BM, true> type; };
-template <int BM> struct ALoaderOf<BM, 2> { typedef GldsConvFast<BM> type; };
+template <int BM, int AKIND, int NW = 4> struct ALoaderOf { typedef GldsLoader<BM, false, NW> type; };
+template <int BM, int NW> struct ALoaderOf<BM, 1, NW> { typedef GldsLoader<BM, true, NW> type; };
+template <int BM, int NW> struct ALoaderOf<BM, 2, NW> { typedef GldsConvFast<BM, NW, false> type; };
+template <int BM, int NW> struct ALoaderOf<BM, 3, NW> { typedef GldsConvFast<BM, NW, true> type; };
 
-// AKIND: 0 = plain rows (linear layers), 1 = generic implicit-GEMM convolution, 2 = convolution fast path (GldsConvFast)
-template <int BN, int AKIND, int S>
-__global__ __launch_bounds__(256, 2) void k_gemm_glds(GemmP p) {     // 2 waves / SIMD = the LDS-bound occupancy anyway; with <= 256 registers the
-                                                                      // accumulators stay in arch VGPRs (no v_accvgpr copies in prologue / epilogue)
-    constexpr int BM = 128;
-    constexpr int WN = BN / 64, WM = 4 / WN, TM = BM / WM / 32, TN = 2;
+// AKIND: 0 = plain rows (linear layers), 1 = generic implicit-GEMM convolution, 2 = convolution fast path (GldsConvFast), 3 = the fast path
+// over two concatenated sources (A | A2)
+// Tile geometry: 128 x 64 (four waves of 32 x 64), 128 x 128 (four waves of 64 x 64) and -- round 6 -- 256 x 128 / 128 x 256 on EIGHT waves of
+// 64 x 64 (512 threads, one workgroup per CU, three 48-KiB stages).  Why the big tiles: the mid / small-M layers of the denoiser are bound by
+// the operand bytes a CU can keep in flight global -> LDS (Little's law: LDS capacity / load latency), not by the MFMA pipe; a tile with twice
+// the area does twice the multiply-adds per byte in flight.
+template <int BM, int BN> struct GldsGeom {
+    static constexpr int WN = BN / 64, WM = (BM == 128 && BN == 64) ? 4 : BM / 64, NW = WM * WN, NT = NW * 64, TM = BM / WM / 32, TN = 2;
+};
+
+// DBG (timing experiments only, results are garbage; DWG_GEMM_DEBUG=n routes the conv-fast 128 x 64 and 256 x 128 launches here):
+//   1 = no fragment reads, no MFMAs (loads + barriers only)   2 = no tile loads (LDS reads + MFMAs + barriers)   3 = MFMAs only
+template <int BM, int BN, int AKIND, int S, int DBG = 0>
+__device__ __forceinline__ void gemm_glds_body(const GemmP& p) {
+    typedef GldsGeom<BM, BN> Geo;
+    constexpr int WN = Geo::WN, WM = Geo::WM, NW = Geo::NW, NT = Geo::NT, TM = Geo::TM, TN = Geo::TN;
     constexpr int ABYTES = BM * 128, BBYTES = BN * 128, STAGE = ABYTES + BBYTES;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];     // [2][A tile | B tile], rows of 128 B
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -860,12 +887,12 @@ __global__ __launch_bounds__(256, 2) void k_gemm_glds(GemmP p) {     // 2 waves 
 #pragma unroll
             for (int r = 0; r < 16; r++) acx[i][j][r] = 0.f;
 #endif
-    typename ALoaderOf<BM, AKIND>::type la;
-    GldsLoader<BN, false> lb;
+    typename ALoaderOf<BM, AKIND, NW>::type la;
+    GldsLoader<BN, false, NW> lb;
     la.init(A, p.sam, p.M, m0, kbeg, kend, p.conv);
     lb.init(B, p.sbn, p.N, n0, kbeg, kend, p.conv);
     const int nk = kend > kbeg ? (kend - kbeg + 63) / 64 : 0;
-    constexpr int LPT = (BM + BN) * 128 / (256 * 16);   // direct-to-LDS loads per thread per stage
+    constexpr int LPT = (BM + BN) * 128 / (NT * 16);    // direct-to-LDS loads per thread per stage
 #pragma unroll
     for (int s = 0; s < S - 1; s++) {
         la.issue(smem_raw + s * STAGE, p.conv); lb.issue(smem_raw + s * STAGE + ABYTES, p.conv);
@@ -873,61 +900,117 @@ __global__ __launch_bounds__(256, 2) void k_gemm_glds(GemmP p) {     // 2 waves 
     }
     // fragment addressing: row r, logical chunk cl -> byte r*128 + ((cl ^ swz(r)) << 4); here swz(r) == (lane >> 1) & 7
     const int frow = lane & 31, fx = (lane >> 1) & 7, fh = lane >> 5;
-    int cur = 0, nxt = S - 1;
-    for (int kt = 0; kt < nk; kt++) {
-        wait_vmcnt<(S - 2) * LPT>();        // this thread's loads of tile kt have landed ...
-        __builtin_amdgcn_s_barrier();       // ... and everybody's; everybody is also done reading the buffer refilled next
-        if (p.dbg != 2) { la.issue(smem_raw + nxt * STAGE, p.conv); lb.issue(smem_raw + nxt * STAGE + ABYTES, p.conv); }
-        la.advance(p.conv); lb.advance(p.conv);
-        if (p.dbg == 1) { cur = cur + 1 == S ? 0 : cur + 1; nxt = nxt + 1 == S ? 0 : nxt + 1; continue; }
-        const unsigned char* ta = smem_raw + cur * STAGE + (wm * TM * 32 + frow) * 128;
-        const unsigned char* tb = smem_raw + cur * STAGE + ABYTES + (wn * 64 + frow) * 128;
+    // ---- main loop (round 6: software-pipelined inside the wave).  Rounds 2-5 ran, per k-step and wave: barrier -> ~55 address instructions
+    // + the tile's direct-to-LDS loads -> [ds_read fragments -> s_waitcnt lgkmcnt(0) -> MFMAs] per 16-k slab -- the LDS latency exposed four
+    // times per k-step and the load issue in front of the MFMAs instead of between them: the MFMA pipe idled ~3/4 of the time (24-27 % of
+    // its rate on every mid / small-M layer, whatever the tile).  Now the fragments of slab s + 1 (the first slab of tile kt + 1 included:
+    // the barrier sits in the MIDDLE of the k-step, before that read) are in flight while slab s is multiplied, and the next tile's loads are
+    // issued in the shadow of the first slab's MFMAs.  Two fragment sets: 64 more registers in the 64 x 64 f32x wave tile (still < 256).
 #ifdef DWG_GEMM_X_TU
-        // a 128-byte row holds 32 logical k: chunks [h0 l0 h1 l1 h2 l2 h3 l3], eight k each.  MFMA slab ks (16 k): lanes 0-31 take group 2 ks,
-        // lanes 32-63 group 2 ks + 1 -- hi chunk 4 ks + 2 fh, lo chunk right behind it.
+    constexpr int KS = 2;               // 16-k MFMA slabs per 64-half k-step: a 128-byte row holds 32 logical k as [h0 l0 h1 l1 h2 l2 h3 l3]
+    struct Frag { bf16x8 ah[TM], al[TM], bh[TN], bl[TN]; };
+#else
+    constexpr int KS = 4;
+    struct Frag { bf16x8 af[TM], bf[TN]; };
+#endif
+    auto load_frags = [&](int stage, int ks, Frag& f) {
+        const unsigned char* ta = smem_raw + stage * STAGE + (wm * TM * 32 + frow) * 128;
+        const unsigned char* tb = smem_raw + stage * STAGE + ABYTES + (wn * 64 + frow) * 128;
+#ifdef DWG_GEMM_X_TU
+        // MFMA slab ks (16 k): lanes 0-31 take group 2 ks, lanes 32-63 group 2 ks + 1 -- hi chunk 4 ks + 2 fh, lo chunk right behind it
+        const int offh = (((ks * 4 + fh * 2) ^ fx) << 4), offl = (((ks * 4 + fh * 2 + 1) ^ fx) << 4);
 #pragma unroll
-        for (int ks = 0; ks < 2; ks++) {
-            const int offh = (((ks * 4 + fh * 2) ^ fx) << 4), offl = (((ks * 4 + fh * 2 + 1) ^ fx) << 4);
-            bf16x8 ah[TM], al[TM], bh[TN], bl[TN];
+        for (int i = 0; i < TM; i++) {
+            f.ah[i] = *reinterpret_cast<const bf16x8*>(ta + i * 32 * 128 + offh);
+            f.al[i] = *reinterpret_cast<const bf16x8*>(ta + i * 32 * 128 + offl);
+        }
 #pragma unroll
-            for (int i = 0; i < TM; i++) {
-                ah[i] = *reinterpret_cast<const bf16x8*>(ta + i * 32 * 128 + offh);
-                al[i] = *reinterpret_cast<const bf16x8*>(ta + i * 32 * 128 + offl);
-            }
-#pragma unroll
-            for (int j = 0; j < TN; j++) {
-                bh[j] = *reinterpret_cast<const bf16x8*>(tb + j * 32 * 128 + offh);
-                bl[j] = *reinterpret_cast<const bf16x8*>(tb + j * 32 * 128 + offl);
-            }
-#pragma unroll
-            for (int i = 0; i < TM; i++)
-#pragma unroll
-                for (int j = 0; j < TN; j++) acc[i][j] = DWG_MFMA16(bh[j], ah[i], acc[i][j]);   // transposed: see tile_epilogue_t
-#pragma unroll
-            for (int i = 0; i < TM; i++)
-#pragma unroll
-                for (int j = 0; j < TN; j++) acx[i][j] = DWG_MFMA16(bl[j], ah[i], acx[i][j]);
-#pragma unroll
-            for (int i = 0; i < TM; i++)
-#pragma unroll
-                for (int j = 0; j < TN; j++) acx[i][j] = DWG_MFMA16(bh[j], al[i], acx[i][j]);
+        for (int j = 0; j < TN; j++) {
+            f.bh[j] = *reinterpret_cast<const bf16x8*>(tb + j * 32 * 128 + offh);
+            f.bl[j] = *reinterpret_cast<const bf16x8*>(tb + j * 32 * 128 + offl);
         }
 #else
+        const int off = (((ks * 2 + fh) ^ fx) << 4);
 #pragma unroll
-        for (int ks = 0; ks < 4; ks++) {
-            const int off = (((ks * 2 + fh) ^ fx) << 4);
-            bf16x8 af[TM], bf[TN];
+        for (int i = 0; i < TM; i++) f.af[i] = *reinterpret_cast<const bf16x8*>(ta + i * 32 * 128 + off);
 #pragma unroll
-            for (int i = 0; i < TM; i++) af[i] = *reinterpret_cast<const bf16x8*>(ta + i * 32 * 128 + off);
-#pragma unroll
-            for (int j = 0; j < TN; j++) bf[j] = *reinterpret_cast<const bf16x8*>(tb + j * 32 * 128 + off);
-#pragma unroll
-            for (int i = 0; i < TM; i++)
-#pragma unroll
-                for (int j = 0; j < TN; j++) acc[i][j] = DWG_MFMA16(bf[j], af[i], acc[i][j]);   // transposed: see tile_epilogue_t
-        }
+        for (int j = 0; j < TN; j++) f.bf[j] = *reinterpret_cast<const bf16x8*>(tb + j * 32 * 128 + off);
 #endif
-        cur = cur + 1 == S ? 0 : cur + 1; nxt = nxt + 1 == S ? 0 : nxt + 1;
+    };
+    auto mma = [&](const Frag& f) {
+#ifdef DWG_GEMM_X_TU
+#pragma unroll
+        for (int i = 0; i < TM; i++)
+#pragma unroll
+            for (int j = 0; j < TN; j++) acc[i][j] = DWG_MFMA16(f.bh[j], f.ah[i], acc[i][j]);   // transposed: see tile_epilogue_t
+#pragma unroll
+        for (int i = 0; i < TM; i++)
+#pragma unroll
+            for (int j = 0; j < TN; j++) acx[i][j] = DWG_MFMA16(f.bl[j], f.ah[i], acx[i][j]);
+#pragma unroll
+        for (int i = 0; i < TM; i++)
+#pragma unroll
+            for (int j = 0; j < TN; j++) acx[i][j] = DWG_MFMA16(f.bh[j], f.al[i], acx[i][j]);
+#else
+#pragma unroll
+        for (int i = 0; i < TM; i++)
+#pragma unroll
+            for (int j = 0; j < TN; j++) acc[i][j] = DWG_MFMA16(f.bf[j], f.af[i], acc[i][j]);   // transposed: see tile_epilogue_t
+#endif
+    };
+    // vmcnt <= N and lgkmcnt == 0 in one s_waitcnt: the loads of the tile read next have landed, and this wave's own fragment reads of the
+    // stage that is refilled after the barrier have completed (they are consumed only AFTER the barrier now)
+    auto wait_tile_and_lds = [&]() {
+        constexpr int N = (S - 2) * LPT;
+        __builtin_amdgcn_s_waitcnt((N & 15) | ((N >> 4) << 14) | (7 << 4) | (0 << 8));
+    };
+    Frag F[2];
+    int cur = 0, nxt = S - 1;
+    if (nk > 0) {
+        wait_vmcnt<(S - 2) * LPT>();        // this thread's loads of tile 0 have landed ...
+        __builtin_amdgcn_s_barrier();       // ... and everybody's
+        load_frags(0, 0, F[0]);
+        __builtin_amdgcn_s_waitcnt(0xC07F);         // lgkmcnt(0): the loop is entered with nothing pending (see the wait at its end)
+    }
+    // MFMAs per slab and wave: the issue of the next tile's loads is spread over the first slab's (igrouplp hints: one MFMA, then a load and
+    // its address arithmetic in the MFMA's shadow)
+#ifdef DWG_GEMM_X_TU
+    constexpr int MPS = 3 * TM * TN;
+#else
+    constexpr int MPS = TM * TN;
+#endif
+    for (int kt = 0; kt < nk; kt++) {
+        const int cnext = cur + 1 == S ? 0 : cur + 1;
+#pragma unroll
+        for (int ks = 0; ks < KS; ks++) {
+            if (ks + 1 < KS) {
+                if (DBG != 1 && DBG != 3) load_frags(cur, ks + 1, F[(ks + 1) & 1]);
+            } else {
+                wait_tile_and_lds();
+                __builtin_amdgcn_s_barrier();       // tile kt + 1 is in LDS for everybody; everybody is done reading tile kt
+                if (DBG != 1 && DBG != 3) load_frags(cnext, 0, F[0]);         // (past the last tile: a stage of zero-page / stale rows, never multiplied)
+            }
+            __builtin_amdgcn_sched_barrier(0);      // the fragment reads stay AHEAD of the MFMAs that hide their latency
+            if (ks == 0) {
+                // tile kt + S - 1 goes into the stage every wave finished reading before the barrier inside the PREVIOUS k-step
+                if (DBG != 2 && DBG != 3) { la.issue(smem_raw + nxt * STAGE, p.conv); lb.issue(smem_raw + nxt * STAGE + ABYTES, p.conv); }
+                la.advance(p.conv); lb.advance(p.conv);
+            }
+            if (DBG != 1) mma(F[ks & 1]);
+            if (ks == 0) {
+#pragma unroll
+                for (int m = 0; m < MPS; m++) {
+                    __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);                          // one MFMA
+                    __builtin_amdgcn_sched_group_barrier(0x006, (LPT * 10 + MPS - 1) / MPS, 0); // VALU / SALU of a load's address
+                    __builtin_amdgcn_sched_group_barrier(0x020, (LPT + MPS - 1) / MPS, 0);      // the load(s)
+                }
+            }
+            __builtin_amdgcn_sched_barrier(0);
+        }
+        // nothing of this wave's is pending in LDS when the next k-step starts (the reads above went out a slab's MFMAs ago: free), so the
+        // compiler's counter bookkeeping does not have to wait for the NEXT slab's reads before the first MFMA of the loop
+        __builtin_amdgcn_s_waitcnt(0xC07F);         // lgkmcnt(0) only
+        cur = cnext; nxt = nxt + 1 == S ? 0 : nxt + 1;
     }
     wait_vmcnt<0>();                        // drain the zero-line tail loads before LDS is handed back
 #ifdef DWG_GEMM_X_TU
@@ -938,11 +1021,41 @@ __global__ __launch_bounds__(256, 2) void k_gemm_glds(GemmP p) {     // 2 waves 
 #pragma unroll
             for (int r = 0; r < 16; r++) acc[i][j][r] = fmaf(acx[i][j][r], DWG_X_LO_INV, acc[i][j][r]);
 #endif
-    constexpr int NPASS = EpiLds<BN>::passes((size_t)S * STAGE);
-    static_assert((size_t)S * STAGE >= EpiLds<BN>::bytes(NPASS), "epilogue staging fits in the operand stages");
-    tile_epilogue_lds<BN, NPASS, TM, TN, false>(p, acc, reinterpret_cast<float*>(smem_raw), n0, wm, wn, lane, tid, ks_id, z1 * p.bC1 + z2 * p.bC2,
+    constexpr int NPASS = EpiLds<BN, BM>::passes((size_t)S * STAGE);
+    static_assert((size_t)S * STAGE >= EpiLds<BN, BM>::bytes(NPASS), "epilogue staging fits in the operand stages");
+    tile_epilogue_lds<BN, NPASS, TM, TN, false, BM, NT>(p, acc, reinterpret_cast<float*>(smem_raw), n0, wm, wn, lane, tid, ks_id, z1 * p.bC1 + z2 * p.bC2,
                                          z1 * p.bR1 + z2 * p.bR2, [&](int rl) { const int r = m0 + rl; return r < p.M ? r : -1; });
 }
+
+template <int BN, int AKIND, int S>
+__global__ __launch_bounds__(256, 2) void k_gemm_glds(GemmP p) {     // 2 waves / SIMD = the LDS-bound occupancy anyway; with <= 256 registers the
+                                                                      // accumulators stay in arch VGPRs (no v_accvgpr copies in prologue / epilogue)
+    gemm_glds_body<128, BN, AKIND, S>(p);
+}
+
+// the eight-wave tiles (256 x 128 | 128 x 256): one workgroup per CU = 2 waves / SIMD
+template <int BM, int BN, int AKIND, int S>
+__global__ __launch_bounds__(512, 2) void k_gemm_glds8(GemmP p) {
+    static_assert(GldsGeom<BM, BN>::NT == 512, "eight waves");
+    gemm_glds_body<BM, BN, AKIND, S>(p);
+}
+#ifdef DWG_GEMM_X_TU
+template <int DBG> __global__ __launch_bounds__(256, 2) void k_gemm_dbg4(GemmP p) { gemm_glds_body<128, 64, 2, 3, DBG>(p); }
+template <int DBG> __global__ __launch_bounds__(512, 2) void k_gemm_dbg8(GemmP p) { gemm_glds_body<256, 128, 2, 3, DBG>(p); }
+template <int DBG> static void launch_dbg(const GemmP& p, bool big, hipStream_t stream) {
+    if (big) {
+        const size_t lds = (size_t)3 * 384 * 128;
+        hipFuncSetAttribute(reinterpret_cast<const void*>(&k_gemm_dbg8<DBG>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        dim3 grid(((p.M + 255) / 256) * ((p.N + 127) / 128) * (p.splitk > 1 ? p.splitk : 1));
+        hipLaunchKernelGGL((k_gemm_dbg8<DBG>), grid, dim3(512), lds, stream, p);
+    } else {
+        const size_t lds = (size_t)3 * 192 * 128;
+        hipFuncSetAttribute(reinterpret_cast<const void*>(&k_gemm_dbg4<DBG>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        dim3 grid(((p.M + 127) / 128) * ((p.N + 63) / 64) * (p.splitk > 1 ? p.splitk : 1));
+        hipLaunchKernelGGL((k_gemm_dbg4<DBG>), grid, dim3(256), lds, stream, p);
+    }
+}
+#endif
 
 // Algorithmic flops of one launch for the profiler table: 2*M*N*K, with the zero taps of an input-dilated (strided-conv
 // dgrad) convolution not counted.
@@ -965,10 +1078,10 @@ static void launch_glds_s(const GemmP& p, int batch, hipStream_t stream, const c
     }
     dim3 grid(((p.M + 127) / 128) * ((p.N + BN - 1) / BN) * (p.splitk > 1 ? p.splitk : 1), 1, batch);
     // profiler symbols spelled as rocprofv3 prints the instantiation: k_gemm_glds<BN, AKIND, S>
-    static const char* const sym[2][2][3] = {{{"k_gemm_glds<64, 0, 2>", "k_gemm_glds<64, 1, 2>", "k_gemm_glds<64, 2, 2>"},
-                                              {"k_gemm_glds<64, 0, 3>", "k_gemm_glds<64, 1, 3>", "k_gemm_glds<64, 2, 3>"}},
-                                             {{"k_gemm_glds<128, 0, 2>", "k_gemm_glds<128, 1, 2>", "k_gemm_glds<128, 2, 2>"},
-                                              {"k_gemm_glds<128, 0, 3>", "k_gemm_glds<128, 1, 3>", "k_gemm_glds<128, 2, 3>"}}};
+    static const char* const sym[2][2][4] = {{{"k_gemm_glds<64, 0, 2>", "k_gemm_glds<64, 1, 2>", "k_gemm_glds<64, 2, 2>", "k_gemm_glds<64, 3, 2>"},
+                                              {"k_gemm_glds<64, 0, 3>", "k_gemm_glds<64, 1, 3>", "k_gemm_glds<64, 2, 3>", "k_gemm_glds<64, 3, 3>"}},
+                                             {{"k_gemm_glds<128, 0, 2>", "k_gemm_glds<128, 1, 2>", "k_gemm_glds<128, 2, 2>", "k_gemm_glds<128, 3, 2>"},
+                                              {"k_gemm_glds<128, 0, 3>", "k_gemm_glds<128, 1, 3>", "k_gemm_glds<128, 2, 3>", "k_gemm_glds<128, 3, 3>"}}};
     DWG_LAUNCH_W(name, sym[BN == 128][S == 3][AKIND], gemm_flops(p, batch), (k_gemm_glds<BN, AKIND, S>), grid, dim3(256), lds, stream, p);
     if (p.splitk > 1 && p.ws) {
         long long n = (long long)p.M * p.N;
@@ -976,6 +1089,33 @@ static void launch_glds_s(const GemmP& p, int batch, hipStream_t stream, const c
         int blocks = (int)((n + 255) / 256); if (blocks > 2048) blocks = 2048;
         DWG_LAUNCH("splitk_epilogue", k_splitk_epilogue, dim3(blocks), dim3(256), 0, stream, p);
     }
+}
+
+// The eight-wave tiles: BM x BN = 256 x 128 | 128 x 256, 512 threads, S stages of 48 KiB (S = 3: 144 of the CU's 160 KiB)
+template <int BM, int BN, int AKIND, int S>
+static void launch_glds8(const GemmP& p, int batch, hipStream_t stream, const char* name) {
+    const size_t lds = (size_t)S * (BM + BN) * 128;
+    static bool attr_set = false;
+    if (!attr_set) {
+        hipFuncSetAttribute(reinterpret_cast<const void*>(&k_gemm_glds8<BM, BN, AKIND, S>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        attr_set = true;
+    }
+    dim3 grid(((p.M + BM - 1) / BM) * ((p.N + BN - 1) / BN) * (p.splitk > 1 ? p.splitk : 1), 1, batch);
+    static const char* const sym[2][4] = {{"k_gemm_glds8<256, 128, 0>", "k_gemm_glds8<256, 128, 1>", "k_gemm_glds8<256, 128, 2>", "k_gemm_glds8<256, 128, 3>"},
+                                          {"k_gemm_glds8<128, 256, 0>", "k_gemm_glds8<128, 256, 1>", "k_gemm_glds8<128, 256, 2>", "k_gemm_glds8<128, 256, 3>"}};
+    DWG_LAUNCH_W(name, sym[BN == 256][AKIND], gemm_flops(p, batch), (k_gemm_glds8<BM, BN, AKIND, S>), grid, dim3(512), lds, stream, p);
+    if (p.splitk > 1 && p.ws) {
+        long long n = (long long)p.M * p.N;
+        if ((p.N & 3) == 0) n >>= 2;                 // four columns per thread
+        int blocks = (int)((n + 255) / 256); if (blocks > 2048) blocks = 2048;
+        DWG_LAUNCH("splitk_epilogue", k_splitk_epilogue, dim3(blocks), dim3(256), 0, stream, p);
+    }
+}
+template <int AKIND>
+static void launch_big(const GemmP& p, int bm, int batch, hipStream_t stream, const char* name) {
+    static const int stages = getenv("DWG_GEMM_BIG_STAGES") ? atoi(getenv("DWG_GEMM_BIG_STAGES")) : 3;
+    if (bm == 256) { if (stages >= 3) launch_glds8<256, 128, AKIND, 3>(p, batch, stream, name); else launch_glds8<256, 128, AKIND, 2>(p, batch, stream, name); }
+    else { if (stages >= 3) launch_glds8<128, 256, AKIND, 3>(p, batch, stream, name); else launch_glds8<128, 256, AKIND, 2>(p, batch, stream, name); }
 }
 
 // Pipeline depth.  Measured on MI355X at HEAD of round 2 (bench.py, DWG_GEMM_STAGES=2|3, average launch): the 128x64 tile gains from a
@@ -1272,6 +1412,44 @@ static int auto_splitk(int M, int N, int K, int bn, int bk) {
     return sk >= 2 ? (int)sk : 1;
 }
 
+// Round 6: the eight-wave tiles.  Returns BM (256: the 256 x 128 tile, 128: the 128 x 256 tile) or 0 (keep the four-wave tiles), and the
+// split-K factor that fills the chip with ONE workgroup per CU.  Shape-only, so that the workspace query and the launch agree.
+//   * only where the k-loop is long enough to pay for the larger prologue / epilogue (K >= DWG_GEMM_BIG_MINK physical halves);
+//   * M >= 192: 256 x 128 when N fills whole 128-wide tiles (or is large); M <= 128: 128 x 256 for N >= 256;
+//   * layers with >= DWG_GEMM_BIG_MAXTILES big tiles already fill the chip with small tiles at full rate (the VAE): left alone.
+static int big_tile(int M, int N, int K, int* splitk_out) {
+    static const int mode = getenv("DWG_GEMM_BIG") ? atoi(getenv("DWG_GEMM_BIG")) : 1;
+    static const int mink = getenv("DWG_GEMM_BIG_MINK") ? atoi(getenv("DWG_GEMM_BIG_MINK")) : 1280;
+    static const int skmax = getenv("DWG_GEMM_BIG_SKMAX") ? atoi(getenv("DWG_GEMM_BIG_SKMAX")) : 24;
+    static const int maxtiles = getenv("DWG_GEMM_BIG_MAXTILES") ? atoi(getenv("DWG_GEMM_BIG_MAXTILES")) : 2048;
+    static const int minsteps = getenv("DWG_GEMM_BIG_MINSTEPS") ? atoi(getenv("DWG_GEMM_BIG_MINSTEPS")) : 8;
+    static const int tall_only = getenv("DWG_GEMM_BIG_TALL_ONLY") ? atoi(getenv("DWG_GEMM_BIG_TALL_ONLY")) : 0;
+    if (splitk_out) *splitk_out = 1;
+    if (mode == 0 || K < mink) return 0;
+    int bm = 0;
+    if (M >= 192) { if (N >= 128 && (N % 128 == 0 || N >= 640)) bm = 256; }
+    else if (N >= 256 && !tall_only) bm = 128;
+    if (!bm) return 0;
+    const int bn = bm == 256 ? 128 : 256;
+    const long long tiles = (long long)((M + bm - 1) / bm) * ((N + bn - 1) / bn);
+    if (tiles > maxtiles) return 0;
+    static const int target = getenv("DWG_GEMM_BIG_TARGET") ? atoi(getenv("DWG_GEMM_BIG_TARGET")) : 256;     // one workgroup per CU
+    static const int minwg = getenv("DWG_GEMM_BIG_MINWG") ? atoi(getenv("DWG_GEMM_BIG_MINWG")) : 200;
+    long long sk = 1;
+    if (tiles < target) {
+        sk = target / tiles;            // FLOOR: tiles x sk must not exceed the CU count -- a 257th workgroup is a second round of the whole launch
+        const long long kmax = K / (minsteps * 64);
+        if (sk > kmax) sk = kmax;
+        if (sk > skmax) sk = skmax;
+        if (sk < 1) sk = 1;
+    }
+    // a grid that leaves a fifth of the CUs idle, or spills a few workgroups into a second round: the small tiles' finer grain wins
+    const long long wgs = tiles * sk, rounds = (wgs + target - 1) / target;
+    if (mode < 2 && (wgs < minwg || wgs * 100 < rounds * target * 80)) return 0;
+    if (splitk_out) *splitk_out = (int)sk;
+    return bm;
+}
+
 template <typename T>
 static int pick_mode(const void* base, long long srow, long long sk, int nrows, int K, const long long* boffs, int nboffs) {
     constexpr int VEC = TT<T>::VEC;
@@ -1339,6 +1517,10 @@ size_t DWG_GEMM_WS_FN(const dwg_gemm_desc* d) {
     if ((long long)d->M * d->N >= (1LL << 33)) return 0;       // k_splitk_epilogue indexes the float4 pieces of C with 32 bits
     const int bn = tile_bn(d), bk = d->dtype == DWG_DTYPE_HALF ? TT<HT>::BK : TT<float>::BK;
     int sk = d->splitk > 1 ? d->splitk : (d->splitk == 0 && d->act != DWG_ACT_GEGLU_PAIR ? auto_splitk(d->M, d->N, d->K, bn, bk) : 1);
+    if (d->dtype == DWG_DTYPE_HALF && d->splitk == 0 && d->act != DWG_ACT_GEGLU_PAIR) {      // the eight-wave tiles split deeper (one workgroup per CU)
+        int bsk = 1;
+        if (big_tile(d->M, d->N, d->K, &bsk) && bsk > sk) sk = bsk;
+    }
     return sk > 1 ? (size_t)sk * d->M * d->N * sizeof(float) : 0;
 }
 
@@ -1432,19 +1614,49 @@ int DWG_GEMM_FN(const dwg_gemm_desc* d, dwg_stream_t stream_) {
             if (sk < 2) { sk = 1; p.ws = nullptr; }
             p.splitk = sk;
         }
+        // the eight-wave tiles (round 6): long-K layers that do not take the LDS-patch kernel
+        int big_sk = 1;
+        int big_bm = (glds_ok && !patch_ok && d->splitk <= 1) ? big_tile(d->M, d->N, d->K, &big_sk) : 0;
+        if (big_bm) {
+            if (d->act == DWG_ACT_GEGLU_PAIR || !d->workspace || batch != 1 || d->splitk == 1 || (long long)d->M * d->N >= (1LL << 33)) big_sk = 1;
+            while (big_sk > 1 && (size_t)big_sk * d->M * d->N * sizeof(float) > d->workspace_bytes) big_sk--;
+            const int bbn = big_bm == 256 ? 128 : 256;
+            const long long tiles = (long long)((d->M + big_bm - 1) / big_bm) * ((d->N + bbn - 1) / bbn) * batch;
+            static const int force = getenv("DWG_GEMM_BIG") ? atoi(getenv("DWG_GEMM_BIG")) : 1;
+            const long long wgs = tiles * big_sk, rounds = (wgs + 255) / 256;
+            if (force < 2 && (wgs < 200 || wgs * 100 < rounds * 256 * 80)) big_bm = 0;      // (an unsplittable launch that would leave CUs idle)
+        }
         if (patch_ok) {
             if (narrow) launch_conv3x3_patch<64>(p, stream, name); else launch_conv3x3_patch<128>(p, stream, name);
         } else if (glds_ok) {
             static const bool no_fast = getenv("DWG_CONV_NO_FAST") != nullptr;
+            static const bool no_cat_fast = getenv("DWG_CONV_NO_CAT_FAST") != nullptr;
+            const bool fast_geom = amode == MODE_CONV && d->conv_cin % 64 == 0 && p.conv.dil == 1 && p.conv.up == 1 && d->conv_kh * d->conv_kw <= 32 && !no_fast;
             const int akind = amode != MODE_CONV ? 0
-                              : (d->conv_cin % 64 == 0 && p.conv.dil == 1 && p.conv.up == 1 && !d->A2 && d->conv_kh * d->conv_kw <= 32 &&
-                                 !no_fast ? 2 : 1);
-            if (narrow) {
-                if (akind == 2) launch_glds<64, 2>(p, batch, stream, name);
+                              : (fast_geom && !d->A2 ? 2
+                                 : (fast_geom && d->A2 && d->conv_cin1 % 64 == 0 && (d->conv_cin - d->conv_cin1) % 64 == 0 && !no_cat_fast ? 3 : 1));
+#ifdef DWG_GEMM_X_TU
+            if (dbg && akind == 2 && ((big_bm == 256) || (!big_bm && narrow))) {         // timing experiments (no epilogue launch: garbage anyway)
+                if (big_bm) { p.splitk = big_sk; p.ws = big_sk > 1 ? reinterpret_cast<float*>(d->workspace) : nullptr; }
+                if (dbg == 1) launch_dbg<1>(p, big_bm != 0, stream); else if (dbg == 2) launch_dbg<2>(p, big_bm != 0, stream);
+                else if (dbg == 3) launch_dbg<3>(p, big_bm != 0, stream); else launch_dbg<0>(p, big_bm != 0, stream);
+                return DWG_OK;
+            }
+#endif
+            if (big_bm) {
+                p.splitk = big_sk; p.ws = big_sk > 1 ? reinterpret_cast<float*>(d->workspace) : nullptr;
+                if (akind == 3) launch_big<3>(p, big_bm, batch, stream, name);
+                else if (akind == 2) launch_big<2>(p, big_bm, batch, stream, name);
+                else if (akind == 1) launch_big<1>(p, big_bm, batch, stream, name);
+                else launch_big<0>(p, big_bm, batch, stream, name);
+            } else if (narrow) {
+                if (akind == 3) launch_glds<64, 3>(p, batch, stream, name);
+                else if (akind == 2) launch_glds<64, 2>(p, batch, stream, name);
                 else if (akind == 1) launch_glds<64, 1>(p, batch, stream, name);
                 else launch_glds<64, 0>(p, batch, stream, name);
             } else {
-                if (akind == 2) launch_glds<128, 2>(p, batch, stream, name);
+                if (akind == 3) launch_glds<128, 3>(p, batch, stream, name);
+                else if (akind == 2) launch_glds<128, 2>(p, batch, stream, name);
                 else if (akind == 1) launch_glds<128, 1>(p, batch, stream, name);
                 else launch_glds<128, 0>(p, batch, stream, name);
             }

@@ -46,8 +46,9 @@ def _prep(dtype, *arrs):
 def forward(means3D, opacities, viewmatrix, projmatrix, tanfovx, tanfovy, bg, H, W, colors=None, shs=None,
             sh_degree=0, campos=None, scales=None, rotations=None, cov3D=None, scale_modifier=1.0,
             dtype=np.float32, omp=False, near=None):
-    """Returns dict(color[3,H,W], depth[H,W], alpha[H,W], radii[G], final_T, n_contrib, num_pairs).  `near=(rel_alpha, rel_T)`: also
-    `near` [H,W] uint8, the hard thresholds each pixel sits on within those relative margins (raster_oracle.c composite_forward)."""
+    """Returns dict(color[3,H,W], depth[H,W], alpha[H,W], radii[G], final_T, n_contrib, num_pairs).  `near=(rel_alpha, rel_T, pos_ulps)`:
+    also `near` [H,W] uint8, the hard thresholds each pixel sits on within those margins (raster_oracle.c composite_forward; pos_ulps: how
+    many fp32 ulps of the pixel coordinate two projections of one centre may differ by)."""
     L = _lib(dtype, omp)
     real = ctypes.c_double if np.dtype(dtype) == np.float64 else ctypes.c_float
     means3D, opacities, viewmatrix, projmatrix, bg, colors, shs, campos, scales, rotations, cov3D = _prep(
@@ -65,7 +66,8 @@ def forward(means3D, opacities, viewmatrix, projmatrix, tanfovx, tanfovy, bg, H,
     if near is not None:
         nr = np.zeros((H, W), np.uint8)
         L.dwg_oracle_raster_forward_near.restype = ctypes.c_int
-        L.dwg_oracle_raster_forward_near(*args, _p(nr), real(near[0]), real(near[1]))
+        pos_eps = float(near[2]) * 1.1920929e-07 * max(H, W) if len(near) > 2 else 0.0
+        L.dwg_oracle_raster_forward_near(*args, _p(nr), real(near[0]), real(near[1]), real(pos_eps))
         out["near"] = nr
     else:
         L.dwg_oracle_raster_forward.restype = ctypes.c_int

@@ -263,12 +263,13 @@ static int build_state(state_t* st, int G, int H, int W, const REAL* means3D, co
 
 /* near (optional, [H*W] bytes): which hard thresholds of the compositing loop this pixel sits ON, within a relative margin -- the
  * pixels where two correct implementations whose exp() / products round differently may legitimately take different branches:
- *   bit 0  a splat's alpha within `rel_a` of the 1/255 cut          bit 1  test_T within `rel_t` of the 1e-4 termination threshold
+ *   bit 0  a splat's alpha within `rel_a` + |grad power| x `pos_eps` of the 1/255 cut (pos_eps: how far two fp32 projections of the same
+ *          centre may lie apart, ~2 ulps of the pixel coordinate)    bit 1  test_T within `rel_t` of the 1e-4 termination threshold
  *   bit 2  a contributing splat and its successor in the tile list have depths equal to within 4 fp32 ulps (sort order)
  *   bit 3  power within 1e-6 of 0 (the power > 0 skip)               bit 4  alpha within `rel_a` of the 0.99 clamp: harmless, recorded only
  * The parity tests demand |err| <= 1e-4 on every pixel whose byte is 0 and count / bound the rest (tests/raster_cases.py). */
 static void composite_forward(const state_t* st, const REAL* bg, REAL* out_color, REAL* out_depth,
-                              REAL* out_alpha, REAL* final_T, int* n_contrib, unsigned char* near, REAL rel_a, REAL rel_t) {
+                              REAL* out_alpha, REAL* final_T, int* n_contrib, unsigned char* near, REAL rel_a, REAL rel_t, REAL pos_eps) {
     int H = st->H, W = st->W;
 #pragma omp parallel for collapse(2) schedule(dynamic, 2)
     for (int ty = 0; ty < st->tiles_y; ty++) for (int tx = 0; tx < st->tiles_x; tx++) {
@@ -289,7 +290,11 @@ static void composite_forward(const state_t* st, const REAL* bg, REAL* out_color
                 REAL alpha = s->opacity * (REAL)exp((double)power);
                 if (near) {
                     const REAL cut = (REAL)(1.0 / 255.0);
-                    if (alpha > cut * (1 - rel_a) && alpha < cut * (1 + rel_a)) nr |= 1;
+                    REAL gx = s->ca * dx + s->cb * dy, gy = s->cb * dx + s->cc * dy;
+                    if (gx < 0) gx = -gx;
+                    if (gy < 0) gy = -gy;
+                    const REAL ra = rel_a + (gx + gy) * pos_eps;
+                    if (alpha > cut * (1 - ra) && alpha < cut * (1 + ra)) nr |= 1;
                     if (alpha > (REAL)0.99 * (1 - rel_a) && alpha < (REAL)0.99 * (1 + rel_a)) nr |= 16;
                 }
                 if (alpha > (REAL)0.99) alpha = (REAL)0.99;
@@ -336,7 +341,7 @@ int dwg_oracle_raster_forward(int G, int H, int W, const REAL* means3D, const RE
     state_t st;
     build_state(&st, G, H, W, means3D, colors, shs, sh_degree, sh_ncoef, campos, opac, scales, quats,
                 cov3D_precomp, viewm, projm, tanfovx, tanfovy, scale_mod, radii);
-    composite_forward(&st, bg, out_color, out_depth, out_alpha, final_T, n_contrib, NULL, 0, 0);
+    composite_forward(&st, bg, out_color, out_depth, out_alpha, final_T, n_contrib, NULL, 0, 0, 0);
     if (num_pairs) *num_pairs = st.K;
     free_state(&st);
     return 0;
@@ -350,11 +355,12 @@ int dwg_oracle_raster_forward_near(int G, int H, int W, const REAL* means3D, con
                                    const REAL* cov3D_precomp, const REAL* viewm, const REAL* projm,
                                    REAL tanfovx, REAL tanfovy, const REAL* bg, REAL scale_mod,
                                    REAL* out_color, REAL* out_depth, REAL* out_alpha, int* radii,
-                                   REAL* final_T, int* n_contrib, int64_t* num_pairs, unsigned char* near, REAL rel_a, REAL rel_t) {
+                                   REAL* final_T, int* n_contrib, int64_t* num_pairs, unsigned char* near, REAL rel_a, REAL rel_t,
+                                   REAL pos_eps) {
     state_t st;
     build_state(&st, G, H, W, means3D, colors, shs, sh_degree, sh_ncoef, campos, opac, scales, quats,
                 cov3D_precomp, viewm, projm, tanfovx, tanfovy, scale_mod, radii);
-    composite_forward(&st, bg, out_color, out_depth, out_alpha, final_T, n_contrib, near, rel_a, rel_t);
+    composite_forward(&st, bg, out_color, out_depth, out_alpha, final_T, n_contrib, near, rel_a, rel_t, pos_eps);
     if (num_pairs) *num_pairs = st.K;
     free_state(&st);
     return 0;
@@ -381,7 +387,7 @@ int dwg_oracle_raster_backward(int G, int H, int W, const REAL* means3D, const R
     REAL* oc = (REAL*)malloc(3 * P * sizeof(REAL)); REAL* od = (REAL*)malloc(P * sizeof(REAL));
     REAL* oa = (REAL*)malloc(P * sizeof(REAL)); REAL* fT = (REAL*)malloc(P * sizeof(REAL));
     int* nc = (int*)malloc(P * sizeof(int));
-    composite_forward(&st, bg, oc, od, oa, fT, nc, NULL, 0, 0);
+    composite_forward(&st, bg, oc, od, oa, fT, nc, NULL, 0, 0, 0);
     REAL* g2d = (REAL*)calloc((size_t)(G > 0 ? G : 1) * 2, sizeof(REAL));   /* d/d(pixel xy) * (0.5W,0.5H) */
     REAL* gcon = (REAL*)calloc((size_t)(G > 0 ? G : 1) * 3, sizeof(REAL));
     REAL* gop = (REAL*)calloc((size_t)(G > 0 ? G : 1), sizeof(REAL));
