@@ -1324,6 +1324,295 @@ __global__ __launch_bounds__(256, 2) void k_conv3x3_patch(GemmP p) {   // 2 wave
     });
 }
 
+// ---------------------------------------------------------------------------------------------------------------------
+// Round 6: the LDS-patch convolution with a PIPELINED step.  k_conv3x3_patch above runs, per (64-channel slab, tap): __syncthreads() [= wait
+// for EVERY outstanding load: the next tap's weight tile was issued one step earlier, so its latency is exposed each step] -> issue -> read
+// fragments -> wait -> MFMAs.  Here (same data layout, same arithmetic, same results):
+//   * NBS weight stages: the tile of step g + NBS - 1 is issued in step g and awaited by COUNT (s_waitcnt vmcnt(N), N a compile-time
+//     constant per unrolled tap: every wave issues the same number of loads per step -- the last patch instruction is duplicated where the
+//     patch does not divide evenly -- and steps past the end load from the zero page);
+//   * the fragments of the next 16-k slab -- of the next tap, of the next slab's first tap -- are read while the current one is
+//     multiplied; the barrier sits in the middle of a step, after the last slab's fragment reads have completed;
+//   * the step's loads are issued between its first slab's MFMAs;
+//   * NW = 8: a 16 x 16-pixel tile (256 rows) x BN = 128 on eight waves -- half the weight-tile traffic per multiply-add of the 8 x 16 tile,
+//     one workgroup per CU -- for the layers whose grid still fills the chip (the VAE's, the 32^2 / 16^2 levels with split-K).
+// ---------------------------------------------------------------------------------------------------------------------
+template <bool V> struct BoolC { static constexpr bool value = V; };
+template <int BN, int NW> struct Patch2Geom {
+    static constexpr int PH = NW == 8 ? 16 : 8, PW = 16, HP = PH + 2, WP = PW + 2, NPIX = HP * WP, BM = PH * PW;
+    static constexpr int NPI = (NPIX + 7) / 8;                  // wave-instructions per patch (8 pixels of 128 B each)
+    static constexpr int PPW = (NPI + NW - 1) / NW;             // patch loads per thread and slab (the tail duplicates the wave's last one)
+    static constexpr int WN = BN / 64, WM = NW / WN, TM = BM / WM / 32, TN = 2, NT = NW * 64;
+    static constexpr int NJW = BN / (8 * NW);                   // weight-tile loads per thread and step
+    static constexpr int PBYTES = NPI * 8 * 128, BBYTES = BN * 128;
+};
+
+template <int BN, bool SPLIT, int NW, int NBS>
+__global__ __launch_bounds__(NW * 64, 2) void k_conv3x3_patch2(GemmP p) {
+    typedef Patch2Geom<BN, NW> G;
+    constexpr int PH = G::PH, PW = G::PW, WP = G::WP, NPIX = G::NPIX, NPI = G::NPI, PPW = G::PPW;
+    constexpr int WN = G::WN, WM = G::WM, TM = G::TM, TN = G::TN, NT = G::NT, NJW = G::NJW, BM = G::BM;
+    constexpr int PBYTES = G::PBYTES, BBYTES = G::BBYTES;
+    static_assert(NJW >= 1 && (NJW % 2 == 0 || NJW == 1), "row-block parity");
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];     // [2 patches][NBS weight tiles]
+    unsigned char* sP = smem_raw;
+    unsigned char* sB = smem_raw + 2 * PBYTES;
+    const ConvP& cv = p.conv;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wv = __builtin_amdgcn_readfirstlane(wave);
+    const int wm = wave / WN, wn = wave % WN;
+    const int tiles_x = (cv.Wout + PW - 1) / PW, tiles_y = (cv.Hout + PH - 1) / PH;
+    const int nimg = p.M / (cv.Hout * cv.Wout);
+    const int gm = nimg * tiles_y * tiles_x, ntn = (p.N + BN - 1) / BN;
+    int id = blockIdx.x;
+    {
+        const int nwg = gridDim.x, q = nwg / 8, r = nwg % 8, xcd = id % 8, loc = id / 8;
+        id = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + loc;
+    }
+    int ks_id = 0;
+    if constexpr (SPLIT) { ks_id = id / (gm * ntn); id -= ks_id * gm * ntn; }
+    const int mt = id / ntn, n0 = (id % ntn) * BN;
+    const int img = mt / (tiles_y * tiles_x), trem = mt % (tiles_y * tiles_x);
+    const int y0 = (trem / tiles_x) * PH, x0 = (trem % tiles_x) * PW;
+    const HT* X = reinterpret_cast<const HT*>(p.A) + (long long)img * cv.Hin * cv.Win * cv.Cin;
+    const HT* Wt = reinterpret_cast<const HT*>(p.B);
+    const HT* zero = reinterpret_cast<const HT*>(g_zero16);
+    const int sub = lane >> 3, lg0 = (lane & 7) ^ (sub >> 1);      // logical chunk of an even 8-row block; odd: ^ 4
+
+    // patch loader: this wave issues patch instructions wv, wv + NW, ... (PPW of them: the tail repeats the wave's last valid one -- same
+    // source, same destination -- so that every wave's outstanding-load count is the same); lane -> patch pixel inst * 8 + sub.
+    // Per-pixel source offsets (in elements, without the slab's channel offset) are loop invariants.
+    // (the per-pixel source offsets are recomputed at every slab's tap 0 -- once per nine steps, in the MFMAs' shadow -- instead of living
+    // in 2 x PPW registers the 64 x 64 wave tile does not have)
+    auto issue_patch = [&](int cc, bool valid, unsigned char* dst) {
+#pragma unroll
+        for (int q = 0; q < PPW; q++) {
+            int inst = wv + q * NW;
+            if (inst >= NPI) inst -= NW;                       // duplicate of the previous one
+            const int pi = inst * 8 + sub;
+            const int py = pi / WP, px = pi - py * WP;
+            const int iy = y0 - 1 + py, ix = x0 - 1 + px;
+            const bool ok = valid && pi < NPIX && iy >= 0 && iy < cv.Hin && ix >= 0 && ix < cv.Win;
+            const HT* src = ok ? X + ((long long)iy * cv.Win + ix) * cv.Cin + (lg0 ^ ((inst & 1) << 2)) * 8 + cc * 64 : zero;
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
+                                             (__attribute__((address_space(3))) void*)(dst + inst * 8 * 128), 16, 0, 0);
+        }
+    };
+    const HT* wrow[NJW];
+#pragma unroll
+    for (int j = 0; j < NJW; j++) {
+        const int r = n0 + (wv * NJW + j) * 8 + sub;
+        wrow[j] = r < p.N ? Wt + (long long)r * p.sbn + (lg0 ^ (((wv * NJW + j) & 1) << 2)) * 8 : nullptr;
+    }
+    auto issue_w = [&](int cc, int tap, bool valid, unsigned char* dst) {
+        const long long kofs = (long long)tap * cv.Cin + cc * 64;          // wave-uniform
+#pragma unroll
+        for (int j = 0; j < NJW; j++) {
+            const HT* src = (valid && wrow[j]) ? wrow[j] + kofs : zero;
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
+                                             (__attribute__((address_space(3))) void*)(dst + (wv * NJW + j) * 8 * 128), 16, 0, 0);
+        }
+    };
+    f32x16 acc[TM][TN];
+#pragma unroll
+    for (int i = 0; i < TM; i++)
+#pragma unroll
+        for (int j = 0; j < TN; j++)
+#pragma unroll
+            for (int r = 0; r < 16; r++) acc[i][j][r] = 0.f;
+#ifdef DWG_GEMM_X_TU
+    f32x16 acx[TM][TN];
+#pragma unroll
+    for (int i = 0; i < TM; i++)
+#pragma unroll
+        for (int j = 0; j < TN; j++)
+#pragma unroll
+            for (int r = 0; r < 16; r++) acx[i][j][r] = 0.f;
+    constexpr int KS = 2, MPS = 3 * TM * TN;
+    struct Frag { bf16x8 ah[TM], al[TM], bh[TN], bl[TN]; };
+#else
+    constexpr int KS = 4, MPS = TM * TN;
+    struct Frag { bf16x8 af[TM], bf[TN]; };
+#endif
+    // this lane's output pixels (rows of the A operand): r = (wm*TM + i)*32 + (lane & 31) -> (oy, ox) = (r / PW, r % PW)
+    int pbase[TM];
+#pragma unroll
+    for (int i = 0; i < TM; i++) {
+        const int r = (wm * TM + i) * 32 + (lane & 31);
+        pbase[i] = (r / PW) * WP + (r % PW);
+    }
+    int cc0 = 0, ncc = cv.Cin / 64;
+    if constexpr (SPLIT) {
+        const int per = (ncc + p.splitk - 1) / p.splitk;
+        cc0 = ks_id * per; ncc = min(ncc, cc0 + per);
+    }
+    const int frow = lane & 31, fx = (lane >> 1) & 7, fh = lane >> 5;
+    const int nsteps = max(0, ncc - cc0) * 9;
+    // step g (0-based over this workgroup's slabs): slab cc0 + g / 9, tap g % 9, weight stage g % NBS, patch buffer (g / 9) & 1
+    auto load_frags = [&](const unsigned char* pa, int toff, const unsigned char* tbs, int ks, Frag& f) {
+        const unsigned char* tb = tbs + (wn * 64 + frow) * 128;
+#ifdef DWG_GEMM_X_TU
+        const int cl = ks * 4 + fh * 2;                  // hi chunk; the lo chunk is cl + 1 (see gemm_glds_body)
+#pragma unroll
+        for (int i = 0; i < TM; i++) {
+            const int pi = pbase[i] + toff, sw = (pi >> 1) & 7;
+            f.ah[i] = *reinterpret_cast<const bf16x8*>(pa + pi * 128 + ((cl ^ sw) << 4));
+            f.al[i] = *reinterpret_cast<const bf16x8*>(pa + pi * 128 + (((cl + 1) ^ sw) << 4));
+        }
+#pragma unroll
+        for (int j = 0; j < TN; j++) {
+            f.bh[j] = *reinterpret_cast<const bf16x8*>(tb + j * 32 * 128 + ((cl ^ fx) << 4));
+            f.bl[j] = *reinterpret_cast<const bf16x8*>(tb + j * 32 * 128 + (((cl + 1) ^ fx) << 4));
+        }
+#else
+        const int cl = ks * 2 + fh;
+#pragma unroll
+        for (int i = 0; i < TM; i++) {
+            const int pi = pbase[i] + toff;
+            f.af[i] = *reinterpret_cast<const bf16x8*>(pa + pi * 128 + ((cl ^ ((pi >> 1) & 7)) << 4));
+        }
+#pragma unroll
+        for (int j = 0; j < TN; j++) f.bf[j] = *reinterpret_cast<const bf16x8*>(tb + j * 32 * 128 + ((cl ^ fx) << 4));
+#endif
+    };
+    auto mma = [&](const Frag& f) {
+#ifdef DWG_GEMM_X_TU
+#pragma unroll
+        for (int i = 0; i < TM; i++)
+#pragma unroll
+            for (int j = 0; j < TN; j++) acc[i][j] = DWG_MFMA16(f.bh[j], f.ah[i], acc[i][j]);   // transposed
+#pragma unroll
+        for (int i = 0; i < TM; i++)
+#pragma unroll
+            for (int j = 0; j < TN; j++) acx[i][j] = DWG_MFMA16(f.bl[j], f.ah[i], acx[i][j]);
+#pragma unroll
+        for (int i = 0; i < TM; i++)
+#pragma unroll
+            for (int j = 0; j < TN; j++) acx[i][j] = DWG_MFMA16(f.bh[j], f.al[i], acx[i][j]);
+#else
+#pragma unroll
+        for (int i = 0; i < TM; i++)
+#pragma unroll
+            for (int j = 0; j < TN; j++) acc[i][j] = DWG_MFMA16(f.bf[j], f.af[i], acc[i][j]);   // transposed
+#endif
+    };
+    // prologue: the first slab's patch, then the weight tiles of steps 0 .. NBS - 2
+    issue_patch(cc0, nsteps > 0, sP + (cc0 & 1) * PBYTES);
+#pragma unroll
+    for (int g = 0; g < NBS - 1; g++) issue_w(cc0 + g / 9, g % 9, g < nsteps, sB + g * BBYTES);
+    Frag F[2];
+    if (nsteps > 0) {
+        wait_vmcnt<(NBS - 2) * NJW>();          // the patch and the weight tile of step 0 have landed (loads return in order)
+        __builtin_amdgcn_s_barrier();
+        load_frags(sP + (cc0 & 1) * PBYTES, 0, sB, 0, F[0]);
+        __builtin_amdgcn_s_waitcnt(0xC07F);     // lgkmcnt(0): the loop is entered with nothing pending in LDS
+    }
+    int bst = 0;                                 // weight stage of the current step
+    // One step = one tap of one slab.  Tap 0 (which also issues the next slab's patch) is its own copy of the body; taps 1 .. 8 run as a ROLLED
+    // loop -- with all nine unrolled the compiler keeps the taps' 72 fragment addresses live across the slab and the 64 x 64 f32x wave tile
+    // (128 accumulator + 64 fragment registers) spills.
+    auto step = [&](auto is_tap0, int tap, int cc, const unsigned char* pa, const unsigned char* pan) {
+        constexpr bool TAP0 = decltype(is_tap0)::value;
+        const int ty = tap >= 6 ? 2 : (tap >= 3 ? 1 : 0);
+        const int toff = ty * WP + (tap - 3 * ty);
+        const int bnext = bst + 1 == NBS ? 0 : bst + 1;
+        const int bfill = bst == 0 ? NBS - 1 : bst - 1;                    // the stage of step g - 1 == the stage of step g + NBS - 1
+        const unsigned char* tb = sB + bst * BBYTES;
+#pragma unroll
+        for (int ks = 0; ks < KS; ks++) {
+            if (ks + 1 < KS) {
+                load_frags(pa, toff, tb, ks + 1, F[(ks + 1) & 1]);
+            } else {
+                // the weight tile of step g + 1 (and, at tap 8, the next slab's patch: issued nine steps ago) has landed; loads issued
+                // after it: the tiles of steps g + 2 .. g + NBS - 1, and a patch iff one was issued in steps g - NBS + 2 .. g
+                if (TAP0 || tap <= NBS - 2) {
+                    constexpr int N = (NBS - 2) * NJW + PPW;
+                    __builtin_amdgcn_s_waitcnt((N & 15) | ((N >> 4) << 14) | (7 << 4) | (0 << 8));
+                } else {
+                    constexpr int N = (NBS - 2) * NJW;
+                    __builtin_amdgcn_s_waitcnt((N & 15) | ((N >> 4) << 14) | (7 << 4) | (0 << 8));
+                }
+                __builtin_amdgcn_s_barrier();
+                const int ntap = tap == 8 ? 0 : tap + 1;
+                const int nty = ntap >= 6 ? 2 : (ntap >= 3 ? 1 : 0);
+                load_frags(tap == 8 ? pan : pa, nty * WP + (ntap - 3 * nty), sB + bnext * BBYTES, 0, F[0]);   // (past the last step: stale rows, never multiplied)
+            }
+            __builtin_amdgcn_sched_barrier(0);
+            if (ks == 0) {
+                // step g + NBS - 1's weight tile (tap + NBS - 1 wraps into the next slab), then -- at tap 0 -- the next slab's patch
+                const int ft = tap + NBS - 1, fcc = cc + (ft >= 9 ? 1 : 0), ftap = ft >= 9 ? ft - 9 : ft;
+                issue_w(fcc, ftap, fcc < ncc, sB + bfill * BBYTES);
+                if (TAP0) issue_patch(cc + 1, cc + 1 < ncc, const_cast<unsigned char*>(pan));
+            }
+            mma(F[ks & 1]);
+            if (ks == 0) {
+                constexpr int NL = NJW + (TAP0 ? PPW : 0);
+#pragma unroll
+                for (int m = 0; m < MPS; m++) {
+                    __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+                    __builtin_amdgcn_sched_group_barrier(0x006, (NL * 8 + MPS - 1) / MPS, 0);
+                    __builtin_amdgcn_sched_group_barrier(0x020, (NL + MPS - 1) / MPS, 0);
+                }
+            }
+            __builtin_amdgcn_sched_barrier(0);
+        }
+        __builtin_amdgcn_s_waitcnt(0xC07F);     // lgkmcnt(0): see gemm_glds_body
+        bst = bnext;
+    };
+    for (int cc = cc0; cc < ncc; cc++) {
+        const unsigned char* pa = sP + (cc & 1) * PBYTES;
+        const unsigned char* pan = sP + ((cc + 1) & 1) * PBYTES;
+        step(BoolC<true>{}, 0, cc, pa, pan);
+#pragma unroll 1
+        for (int tap = 1; tap < 9; tap++) step(BoolC<false>{}, tap, cc, pa, pan);
+    }
+    wait_vmcnt<0>();
+    __builtin_amdgcn_s_barrier();
+#ifdef DWG_GEMM_X_TU
+#pragma unroll
+    for (int i = 0; i < TM; i++)
+#pragma unroll
+        for (int j = 0; j < TN; j++)
+#pragma unroll
+            for (int r = 0; r < 16; r++) acc[i][j][r] = fmaf(acx[i][j][r], DWG_X_LO_INV, acc[i][j][r]);
+#endif
+    constexpr int NPASS = EpiLds<BN, BM>::passes((size_t)2 * PBYTES + NBS * BBYTES);
+    static_assert((size_t)2 * PBYTES + NBS * BBYTES >= EpiLds<BN, BM>::bytes(NPASS), "epilogue staging fits in the patch / weight buffers");
+    tile_epilogue_lds<BN, NPASS, TM, TN, !SPLIT, BM, NT>(p, acc, reinterpret_cast<float*>(smem_raw), n0, wm, wn, lane, tid, ks_id, 0, 0, [&](int rr) {
+        const int y = y0 + rr / PW, x = x0 + rr % PW;
+        return (y < cv.Hout && x < cv.Wout) ? (img * cv.Hout + y) * cv.Wout + x : -1;
+    });
+}
+
+template <int BN, int NW, int NBS>
+static void launch_conv3x3_patch2(const GemmP& p, hipStream_t stream, const char* name) {
+    typedef Patch2Geom<BN, NW> G;
+    const size_t lds = (size_t)2 * G::PBYTES + (size_t)NBS * G::BBYTES;
+    const ConvP& cv = p.conv;
+    const int nimg = p.M / (cv.Hout * cv.Wout);
+    const int gm = nimg * ((cv.Hout + G::PH - 1) / G::PH) * ((cv.Wout + G::PW - 1) / G::PW);
+    dim3 grid(gm * ((p.N + BN - 1) / BN) * (p.splitk > 1 ? p.splitk : 1));
+    static bool attr_set = false;
+    if (!attr_set) {
+        hipFuncSetAttribute(reinterpret_cast<const void*>(&k_conv3x3_patch2<BN, false, NW, NBS>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        hipFuncSetAttribute(reinterpret_cast<const void*>(&k_conv3x3_patch2<BN, true, NW, NBS>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        attr_set = true;
+    }
+    const char* sym = NW == 8 ? (p.splitk > 1 && p.ws ? "k_conv3x3_patch2<128, split, 8>" : "k_conv3x3_patch2<128, 8>")
+                              : (BN == 64 ? (p.splitk > 1 && p.ws ? "k_conv3x3_patch2<64, split, 4>" : "k_conv3x3_patch2<64, 4>")
+                                          : (p.splitk > 1 && p.ws ? "k_conv3x3_patch2<128, split, 4>" : "k_conv3x3_patch2<128, 4>"));
+    if (p.splitk > 1 && p.ws)
+        DWG_LAUNCH_W(name, sym, gemm_flops(p, 1), (k_conv3x3_patch2<BN, true, NW, NBS>), grid, dim3(NW * 64), lds, stream, p);
+    else
+        DWG_LAUNCH_W(name, sym, gemm_flops(p, 1), (k_conv3x3_patch2<BN, false, NW, NBS>), grid, dim3(NW * 64), lds, stream, p);
+    if (p.splitk > 1 && p.ws) {
+        long long n = (long long)p.M * p.N;
+        if ((p.N & 3) == 0) n >>= 2;
+        int blocks = (int)((n + 255) / 256); if (blocks > 2048) blocks = 2048;
+        DWG_LAUNCH("splitk_epilogue", k_splitk_epilogue, dim3(blocks), dim3(256), 0, stream, p);
+    }
+}
+
 template <int BN>
 static void launch_conv3x3_patch(const GemmP& p, hipStream_t stream, const char* name) {
     constexpr int NPI = (10 * 18 + 7) / 8;
@@ -1598,12 +1887,41 @@ int DWG_GEMM_FN(const dwg_gemm_desc* d, dwg_stream_t stream_) {
         // per flop than the im2col loader, which is what bounds these layers).  Below 64x64 latents it needs split-K over the
         // channel slabs to fill the chip; DWG_CONV_PATCH_MINM = smallest M it is used for (experiment switch).
         const int patch_min_m = getenv("DWG_CONV_PATCH_MINM") ? atoi(getenv("DWG_CONV_PATCH_MINM")) : 8192;
-        bool patch_ok = glds_ok && amode == MODE_CONV && batch == 1 && d->conv_kh == 3 && d->conv_kw == 3 &&
-                        d->conv_stride == 1 && p.conv.dil == 1 && p.conv.up == 1 && d->conv_pad_t == 1 && d->conv_pad_l == 1 &&
-                        !d->A2 && d->conv_cin % 64 == 0 && d->conv_hout == d->conv_hin && d->conv_wout == d->conv_win &&
-                        d->conv_wout >= 16 && d->conv_hout >= 8 && d->M >= patch_min_m && (d->act == 0 || d->act == 3 || p.splitk > 1) &&
-                        getenv("DWG_CONV_NO_PATCH") == nullptr;
-        if (patch_ok && p.splitk > 1) {
+        static const int patch2 = getenv("DWG_CONV_PATCH2") ? atoi(getenv("DWG_CONV_PATCH2")) : 1;            // 0: the round-2 kernel
+        static const int patch2_low = getenv("DWG_CONV_PATCH2_LOWRES") ? atoi(getenv("DWG_CONV_PATCH2_LOWRES")) : 1;
+        const bool patch_geom = glds_ok && amode == MODE_CONV && batch == 1 && d->conv_kh == 3 && d->conv_kw == 3 &&
+                                d->conv_stride == 1 && p.conv.dil == 1 && p.conv.up == 1 && d->conv_pad_t == 1 && d->conv_pad_l == 1 &&
+                                !d->A2 && d->conv_cin % 64 == 0 && d->conv_hout == d->conv_hin && d->conv_wout == d->conv_win &&
+                                d->conv_wout >= 16 && d->conv_hout >= 8 && getenv("DWG_CONV_NO_PATCH") == nullptr;
+        bool patch_ok = patch_geom && d->M >= patch_min_m && (d->act == 0 || d->act == 3 || p.splitk > 1);
+        // Round 6: the pipelined patch kernel on EIGHT waves (16 x 16-pixel tile x 128 columns) where whole 16 x 16 tiles cover the image and the
+        // grid -- with split-K over the 64-channel slabs when it has to -- still gives >= 200 workgroups; this also brings the 32^2 / 16^2
+        // levels of the denoiser (M < 8192, split-K) onto the patch kernel
+        int p2_nw = 0, p2_sk = 1;
+        if (patch2 && patch_geom && d->splitk <= 1 && d->conv_hout % 16 == 0 && d->conv_wout % 16 == 0 && (d->N % 128 == 0 || d->N >= 512) &&
+            (d->M >= patch_min_m || patch2_low)) {
+            const long long tiles8 = (long long)(d->M / 256) * ((d->N + 127) / 128);
+            const int ncc = d->conv_cin / 64;
+            long long sk = 1;
+            if (tiles8 < 200 && d->workspace && d->splitk == 0 && (long long)d->M * d->N < (1LL << 33)) {
+                sk = 256 / tiles8;
+                if (sk > ncc / 2) sk = ncc / 2;
+                while (sk > 1 && (size_t)sk * d->M * d->N * sizeof(float) > d->workspace_bytes) sk--;
+                if (sk < 1) sk = 1;
+                const long long per = (ncc + sk - 1) / sk;
+                sk = (ncc + per - 1) / per;                          // no empty slices
+            }
+            const long long wgs = tiles8 * sk, rounds = (wgs + 255) / 256;
+            static const int nw8 = getenv("DWG_CONV_PATCH2_NW8") ? atoi(getenv("DWG_CONV_PATCH2_NW8")) : 1;   // 0: never, 1: auto, 2: whenever legal
+            // one workgroup per CU exposes every tile's prologue (first patch from HBM) and epilogue (128 KB of stores): with few steps per
+            // tile (the VAE's 512^2 / 256^2 layers: 36 - 72) the four-wave kernel's two workgroups per CU overlap them; DWG_CONV_PATCH2_NW8_MINSTEPS
+            static const int minsteps8 = getenv("DWG_CONV_PATCH2_NW8_MINSTEPS") ? atoi(getenv("DWG_CONV_PATCH2_NW8_MINSTEPS")) : 100;
+            const long long steps = (long long)((ncc + sk - 1) / sk) * 9;
+            const bool worth = nw8 == 2 || (nw8 == 1 && (sk > 1 || steps >= minsteps8 || d->M < patch_min_m));
+            if (worth && wgs >= 200 && wgs * 100 >= rounds * 256 * 80 && (d->act == 0 || d->act == 3 || sk > 1)) { p2_nw = 8; p2_sk = (int)sk; patch_ok = true; }
+        }
+        if (patch_ok && !p2_nw && patch2) p2_nw = 4;
+        if (patch_ok && p2_nw != 8 && p.splitk > 1) {
             // re-derive the slice count for this kernel's tiling: (8x16 pixel tiles) x (N / BN) workgroups, >= 2 slabs per slice
             const int gm = (d->M / (d->conv_hout * d->conv_wout)) * ((d->conv_hout + 7) / 8) * ((d->conv_wout + 15) / 16);
             const int blocks = gm * ((d->N + (narrow ? 64 : 128) - 1) / (narrow ? 64 : 128));
@@ -1614,6 +1932,7 @@ int DWG_GEMM_FN(const dwg_gemm_desc* d, dwg_stream_t stream_) {
             if (sk < 2) { sk = 1; p.ws = nullptr; }
             p.splitk = sk;
         }
+        if (p2_nw == 8) { p.splitk = p2_sk; p.ws = p2_sk > 1 ? reinterpret_cast<float*>(d->workspace) : nullptr; }
         // the eight-wave tiles (round 6): long-K layers that do not take the LDS-patch kernel
         int big_sk = 1;
         int big_bm = (glds_ok && !patch_ok && d->splitk <= 1) ? big_tile(d->M, d->N, d->K, &big_sk) : 0;
@@ -1626,7 +1945,11 @@ int DWG_GEMM_FN(const dwg_gemm_desc* d, dwg_stream_t stream_) {
             const long long wgs = tiles * big_sk, rounds = (wgs + 255) / 256;
             if (force < 2 && (wgs < 200 || wgs * 100 < rounds * 256 * 80)) big_bm = 0;      // (an unsplittable launch that would leave CUs idle)
         }
-        if (patch_ok) {
+        if (patch_ok && p2_nw == 8) {
+            launch_conv3x3_patch2<128, 8, 4>(p, stream, name);
+        } else if (patch_ok && p2_nw == 4) {
+            if (narrow) launch_conv3x3_patch2<64, 4, 4>(p, stream, name); else launch_conv3x3_patch2<128, 4, 2>(p, stream, name);
+        } else if (patch_ok) {
             if (narrow) launch_conv3x3_patch<64>(p, stream, name); else launch_conv3x3_patch<128>(p, stream, name);
         } else if (glds_ok) {
             static const bool no_fast = getenv("DWG_CONV_NO_FAST") != nullptr;

@@ -14,7 +14,12 @@ L = _lib.lib()
 keep = []
 
 
+ZERO = os.environ.get("PROBE_ZERO") == "1"       # all-zero operands: the same instruction stream without the data-dependent power draw
+
+
 def cv(t):
+    if ZERO:
+        t = torch.zeros_like(t)
     return xfmt.pack(t) if DT == "f32x" else t.to(torch.bfloat16)
 
 
@@ -47,13 +52,15 @@ def make(kind, B, H, Cin, Cout, k, M=None, copies=6):
 
 CASES = [("conv r16 1280", "conv", 2, 16, 1280, 1280, 3, None), ("conv r32 640", "conv", 2, 32, 640, 640, 3, None),
          ("conv r8 1280", "conv", 2, 8, 1280, 1280, 3, None), ("conv r64 320 (patch)", "conv", 2, 64, 320, 320, 3, None),
+         ("vae r512 128", "conv", 1, 512, 128, 128, 3, None), ("vae r256 256", "conv", 1, 256, 256, 256, 3, None),
+         ("vae r128 512", "conv", 1, 128, 512, 512, 3, None), ("vae r64 512", "conv", 1, 64, 512, 512, 3, None),
          ("ff_out 2048x640x2560", "lin", 0, 0, 2560, 640, 0, 2048), ("qkv 512x3840x1280", "lin", 0, 0, 1280, 3840, 0, 512),
          ("attn_out 8192x320x320", "lin", 0, 0, 320, 320, 0, 8192), ("big 4096^3", "lin", 0, 0, 4096, 4096, 0, 4096)]
 only = os.environ.get("PROBE_ONLY")
 for name, kind, B, H, Cin, Cout, k, M in CASES:
     if only and only not in name:
         continue
-    descs, Mm, N, K = make(kind, B, H, Cin, Cout, k, M, copies=2 if "4096" in name else 6)
+    descs, Mm, N, K = make(kind, B, H, Cin, Cout, k, M, copies=2 if ("4096" in name or "vae" in name) else 6)
     for d in descs:
         gemm.run_desc(d, st)
     torch.cuda.synchronize()
