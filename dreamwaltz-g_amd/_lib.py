@@ -47,6 +47,8 @@ SIGNATURES = {
                                                         _vp, _vp, _vp, _vp]),
     "dwg_raster_backward": (ctypes.c_int, [ctypes.POINTER(RasterSettingsC), _i32] + [_vp] * 7 + [_vp, _vp, _i64, _vp, _vp]
                             + [_vp] * 3 + [_vp] * 8 + [_vp]),
+    "dwg_raster_backward_frames": (ctypes.c_int, [ctypes.POINTER(RasterSettingsC), ctypes.POINTER(RasterFramesC), _i32] + [_vp] * 7
+                                   + [_vp, _vp, _i64, _vp, _vp] + [_vp] * 3 + [_vp] * 8 + [_vp]),
     # include/dwg_lbs.h
     "dwg_lbs_joint_chain": (ctypes.c_int, [_i32, _vp, _vp, _vp, _vp, _vp, _vp, _i32, _vp, _vp, _vp]),
     "dwg_lbs_blend_forward": (ctypes.c_int, [_i32, _i32, _i32] + [_vp] * 7 + [_vp]),

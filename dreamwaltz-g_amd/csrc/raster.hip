@@ -1110,6 +1110,16 @@ __global__ __launch_bounds__(64) void k_render_bwd(Params p, const int32_t* __re
     __shared__ uint32_t sgo[64];
     __shared__ float qt[SUB * SUBLD], wt[SUB * SUBLD];
     __shared__ float gpx[4][64];
+    // frames (blockIdx.y): this frame's workspaces and its slice of the image gradients
+    DWG_GEOM(header); DWG_PAIRS(seg_tile); DWG_GEOM(seg_start); DWG_GEOM(tile_start); DWG_GEOM(tile_count); DWG_GEOM(tile_neff);
+    DWG_PAIRS(sorted); DWG_GEOM(rect); DWG_GEOM(goff); DWG_GEOM(rec0); DWG_GEOM(rec1); DWG_GEOM(rec2); DWG_PAIRS(ckpt);
+    DWG_IMAGE(final_T); DWG_IMAGE(n_contrib); DWG_IMAGE(craw); DWG_PAIRS(part);
+    {
+        const size_t fo = (size_t)blockIdx.y * (size_t)p.H * p.W;
+        g_color += 3 * fo;
+        if (g_depth) g_depth += fo;
+        if (g_alpha) g_alpha += fo;
+    }
     const int64_t seg = blockIdx.x;
     if (seg >= (int64_t)header[H_NSEG] || seg >= cap_segs || header[H_OVERFLOW]) return;    // a truncated frame is redone by the caller
     tag = (uint32_t)header[H_TAG];                             // the frame's tag (the argument is unused: see g_frame_tag)
@@ -1247,7 +1257,10 @@ __global__ __launch_bounds__(64) void k_render_bwd(Params p, const int32_t* __re
 // counts are heavy-tailed -- at 192 the launch was its tail, waves parked 0.82 of the time) are summed by their whole wave, lane-strided over
 // the rows, and joined by a fixed tree.
 __global__ __launch_bounds__(256) void k_gather_partials(int G, const uint32_t* __restrict__ goff, const float* __restrict__ part, int64_t cap,
-                                                         const int32_t* __restrict__ header, uint32_t tag, float* __restrict__ gacc, int GBIG) {
+                                                         const int32_t* __restrict__ header, uint32_t tag, float* __restrict__ gacc, int GBIG,
+                                                         size_t geom_stride, size_t pairs_stride) {
+    goff = frame_ptr(goff, geom_stride); header = frame_ptr(header, geom_stride); part = frame_ptr(part, pairs_stride);     // frame blockIdx.y
+    gacc += (size_t)blockIdx.y * (size_t)G * GSTRIDE;
     const int i = blockIdx.x * 64 + (threadIdx.x >> 2), h = threadIdx.x & 3, lane = threadIdx.x & 63;
     const bool ok = !header[H_OVERFLOW];                       // a truncated frame is redone by the caller: zeros
     tag = (uint32_t)header[H_TAG];
@@ -1316,9 +1329,28 @@ __global__ __launch_bounds__(256) void k_preprocess_bwd(Params p, const float* _
                                                         float* __restrict__ dopac, float* __restrict__ dscales,
                                                         float* __restrict__ drots, float* __restrict__ dcov3D) {
     __shared__ float cam[32];
-    if (threadIdx.x < 16) cam[threadIdx.x] = p.view[threadIdx.x];
-    else if (threadIdx.x < 32) cam[threadIdx.x] = p.proj[threadIdx.x - 16];
-    camera_scalars(p, 0);
+    // frames (blockIdx.y): this frame's camera, input rows, workspaces and gradient rows ([F, G, ...] outputs)
+    const size_t co = (size_t)blockIdx.y * (size_t)p.cam_stride, go = (size_t)blockIdx.y * (size_t)p.in_stride, fg = (size_t)blockIdx.y * (size_t)p.G;
+    if (threadIdx.x < 16) cam[threadIdx.x] = p.view[co + threadIdx.x];
+    else if (threadIdx.x < 32) cam[threadIdx.x] = p.proj[co + threadIdx.x - 16];
+    camera_scalars(p, co);
+    const float* campos = p.campos ? p.campos + co : nullptr;
+    DWG_GEOM(rect); DWG_GEOM(rec2);
+    means3D += 3 * go;
+    if (shs) shs += go * (size_t)p.sh_coeffs * 3;
+    if (colors) colors += 3 * go;
+    if (scales) scales += 3 * go;
+    if (rots) rots += 4 * go;
+    if (cov3Dp) cov3Dp += 6 * go;
+    gacc += fg * GSTRIDE;
+    dmeans3D += 3 * fg;
+    if (dmeans2D) dmeans2D += 3 * fg;
+    if (dshs) dshs += fg * (size_t)p.sh_coeffs * 3;
+    if (dcolors) dcolors += 3 * fg;
+    if (dopac) dopac += fg;
+    if (dscales) dscales += 3 * fg;
+    if (drots) drots += 4 * fg;
+    if (dcov3D) dcov3D += 6 * fg;
     __syncthreads();
     int i = blockIdx.x * 256 + threadIdx.x;
     if (i >= p.G) return;
@@ -1388,7 +1420,7 @@ __global__ __launch_bounds__(256) void k_preprocess_bwd(Params p, const float* _
         if (live) {
             const float* sh = shs + (size_t)i * M * 3;
             unsigned cb = __float_as_uint(rec2[i].w);
-            float3 d = make_float3(pos.x - p.campos[0], pos.y - p.campos[1], pos.z - p.campos[2]);
+            float3 d = make_float3(pos.x - campos[0], pos.y - campos[1], pos.z - campos[2]);
             float nrm = sqrtf(d.x * d.x + d.y * d.y + d.z * d.z);
             float inv = 1.f / nrm;
             float x = d.x * inv, y = d.y * inv, z = d.z * inv;
@@ -1696,14 +1728,15 @@ int dwg_raster_forward_render(const dwg_raster_settings* cfg, int32_t G, void* w
     return dwg_raster_forward_render_frames(cfg, nullptr, G, ws_geom, ws_pairs, pair_capacity, ws_image, out_color, out_depth, out_alpha, stream_);
 }
 
-int dwg_raster_backward(const dwg_raster_settings* cfg, int32_t G, const float* means3D, const float* shs,
-                        const float* colors_precomp, const float* opacities, const float* scales,
-                        const float* rotations, const float* cov3D_precomp, const void* ws_geom, const void* ws_pairs,
-                        int64_t pair_capacity, const void* ws_image, void* ws_grad, const float* dL_dout_color,
-                        const float* dL_dout_depth, const float* dL_dout_alpha, float* dL_dmeans3D, float* dL_dmeans2D, float* dL_dshs, float* dL_dcolors, float* dL_dopacities,
-                        float* dL_dscales, float* dL_drotations, float* dL_dcov3D, dwg_stream_t stream_) {
+int dwg_raster_backward_frames(const dwg_raster_settings* cfg, const dwg_raster_frames* frames, int32_t G, const float* means3D, const float* shs,
+                               const float* colors_precomp, const float* opacities, const float* scales,
+                               const float* rotations, const float* cov3D_precomp, const void* ws_geom, const void* ws_pairs,
+                               int64_t pair_capacity, const void* ws_image, void* ws_grad, const float* dL_dout_color,
+                               const float* dL_dout_depth, const float* dL_dout_alpha, float* dL_dmeans3D, float* dL_dmeans2D, float* dL_dshs,
+                               float* dL_dcolors, float* dL_dopacities, float* dL_dscales, float* dL_drotations, float* dL_dcov3D,
+                               dwg_stream_t stream_) {
     Params p;
-    int rc = make_params(cfg, nullptr, G, &p);
+    int rc = make_params(cfg, frames, G, &p);
     if (rc) return rc;
     if (!ws_geom || !ws_pairs || !ws_image || !ws_grad || !dL_dout_color || !dL_dmeans3D || pair_capacity < 0)
         return DWG_E_ARG;
@@ -1711,13 +1744,15 @@ int dwg_raster_backward(const dwg_raster_settings* cfg, int32_t G, const float* 
     if (G == 0) return DWG_OK;
     if ((shs == nullptr) == (colors_precomp == nullptr)) return DWG_E_ARG;
     if (((scales == nullptr) || (rotations == nullptr)) == (cov3D_precomp == nullptr)) return DWG_E_ARG;
+    const int F = frames ? frames->num_frames : 1;
     hipStream_t stream = (hipStream_t)stream_;
     GeomLayout L = geom_layout(G, p.H, p.W);
     PairLayout PL = pair_layout(pair_capacity, p.H, p.W);
     ImageLayout IL = image_layout(p.H, p.W);
+    p.geom_stride = L.total; p.pairs_stride = PL.total; p.image_stride = IL.total;
     const int64_t cap_segs = seg_capacity(pair_capacity > 0 ? pair_capacity : 1, p.H, p.W);
     const char* ws = (const char*)ws_geom; const char* wp = (const char*)ws_pairs; const char* wi = (const char*)ws_image;
-    // per-pair partials in pair-row order (no atomics), then each Gaussian's contiguous rows summed into ws_grad [G][GSTRIDE]
+    // per-pair partials in pair-row order (no atomics), then each Gaussian's contiguous rows summed into ws_grad [F][G][GSTRIDE]
     // a fresh tag per backward: rows of the pair-ordered partials count only if this frame wrote them (no clearing of the buffer)
     // (the tag itself is header[H_TAG], drawn on the device by the forward's scan kernel: see g_frame_tag)
     const uint32_t tag = 0u;
@@ -1728,17 +1763,28 @@ int dwg_raster_backward(const dwg_raster_settings* cfg, int32_t G, const float* 
         (const float4*)(ws + L.rec2), pair_capacity, (const float*)(wp + PL.ckpt), (const float*)(wi + IL.final_T),                              \
         (const int*)(wi + IL.n_contrib), (const float*)(wi + IL.craw), dL_dout_color, dL_dout_depth, dL_dout_alpha,                              \
         (float*)(const_cast<char*>(wp) + PL.part)
-    if (dL_dout_depth) DWG_LAUNCH("raster_render_bwd", k_render_bwd<true>, dim3((unsigned)cap_segs), dim3(64), 0, stream, DWG_BWD_ARGS);
-    else DWG_LAUNCH("raster_render_bwd", k_render_bwd<false>, dim3((unsigned)cap_segs), dim3(64), 0, stream, DWG_BWD_ARGS);
+    if (dL_dout_depth) DWG_LAUNCH("raster_render_bwd", k_render_bwd<true>, dim3((unsigned)cap_segs, F), dim3(64), 0, stream, DWG_BWD_ARGS);
+    else DWG_LAUNCH("raster_render_bwd", k_render_bwd<false>, dim3((unsigned)cap_segs, F), dim3(64), 0, stream, DWG_BWD_ARGS);
 #undef DWG_BWD_ARGS
-    DWG_LAUNCH("raster_gather_bwd", k_gather_partials, dim3(dwg_cdiv(G, 64)), dim3(256), 0, stream, G, (const uint32_t*)(ws + L.goff),
-               (const float*)(wp + PL.part), pair_capacity, (const int32_t*)(ws + L.header), tag, (float*)ws_grad, gbig);
-    DWG_LAUNCH("raster_preprocess_bwd", k_preprocess_bwd, dim3(dwg_cdiv(G, 256)), dim3(256), 0, stream, p, means3D, shs, colors_precomp,
+    DWG_LAUNCH("raster_gather_bwd", k_gather_partials, dim3(dwg_cdiv(G, 64), F), dim3(256), 0, stream, G, (const uint32_t*)(ws + L.goff),
+               (const float*)(wp + PL.part), pair_capacity, (const int32_t*)(ws + L.header), tag, (float*)ws_grad, gbig, p.geom_stride, p.pairs_stride);
+    DWG_LAUNCH("raster_preprocess_bwd", k_preprocess_bwd, dim3(dwg_cdiv(G, 256), F), dim3(256), 0, stream, p, means3D, shs, colors_precomp,
                scales, rotations, cov3D_precomp, (const uint2*)(ws + L.rect), (const float4*)(ws + L.rec2),
                (const float*)ws_grad, dL_dmeans3D, dL_dmeans2D, dL_dshs, dL_dcolors, dL_dopacities, dL_dscales,
                dL_drotations, dL_dcov3D);
     DWG_RETURN_IF_LAUNCH_FAILED();
     return DWG_OK;
+}
+
+int dwg_raster_backward(const dwg_raster_settings* cfg, int32_t G, const float* means3D, const float* shs,
+                        const float* colors_precomp, const float* opacities, const float* scales,
+                        const float* rotations, const float* cov3D_precomp, const void* ws_geom, const void* ws_pairs,
+                        int64_t pair_capacity, const void* ws_image, void* ws_grad, const float* dL_dout_color,
+                        const float* dL_dout_depth, const float* dL_dout_alpha, float* dL_dmeans3D, float* dL_dmeans2D, float* dL_dshs, float* dL_dcolors, float* dL_dopacities,
+                        float* dL_dscales, float* dL_drotations, float* dL_dcov3D, dwg_stream_t stream_) {
+    return dwg_raster_backward_frames(cfg, nullptr, G, means3D, shs, colors_precomp, opacities, scales, rotations, cov3D_precomp, ws_geom, ws_pairs,
+                                      pair_capacity, ws_image, ws_grad, dL_dout_color, dL_dout_depth, dL_dout_alpha, dL_dmeans3D, dL_dmeans2D,
+                                      dL_dshs, dL_dcolors, dL_dopacities, dL_dscales, dL_drotations, dL_dcov3D, stream_);
 }
 
 }  // extern "C"

@@ -241,26 +241,141 @@ class _RasterizeGaussians(torch.autograd.Function):
         return d_means3D, d_means2D, d_sh, d_colors, d_opac, d_scales, d_rots, d_cov, None, None, None, None
 
 
+class _RasterizeFrames(torch.autograd.Function):
+    """F frames per launch chain, forward AND backward (include/dwg_raster.h dwg_raster_*_frames): the (work, F) grids of the seven forward
+    and three backward launches.  Inputs [F, G, ...] (a posed set of Gaussians per frame) or [G, ...] (shared: their gradients are the sum
+    over the frames, added in frame order); frame f's images and gradient rows are bit for bit those of the single-frame call."""
+
+    @staticmethod
+    def forward(ctx, means3D, opac, colors_precomp, shs, scales, rotations, cov3D, cameras, H, W, tanfovx, tanfovy, bg, sh_degree,
+                scale_modifier, pair_capacity, info, pair_state=None):
+        L = _lib.lib()
+        device = means3D.device
+        per_frame = means3D.dim() == 3
+        F = int(means3D.shape[0]) if per_frame else (int(cameras.shape[0]) if cameras.dim() == 2 else 1)
+        G = int(means3D.shape[-2])
+        M = int(shs.shape[-2]) if shs is not None else 0
+        keep = []
+        rs = GaussianRasterizationSettings(H, W, float(tanfovx), float(tanfovy), bg, float(scale_modifier), cameras.reshape(-1)[0:16],
+                                           cameras.reshape(-1)[16:32], int(sh_degree), cameras.reshape(-1)[32:35], False, False)
+        cfg = _settings_struct(rs, device, M, keep)
+        fr = _lib.RasterFramesC(F, G if per_frame else 0, 35 if (cameras.dim() == 2 and cameras.shape[0] == F and F > 1) else 0)
+        gb, pb, ib = ctypes.c_size_t(), ctypes.c_size_t(), ctypes.c_size_t()
+        _lib.check(L.dwg_raster_workspace_sizes(G, H, W, 0, ctypes.byref(gb), ctypes.byref(pb), ctypes.byref(ib)), "dwg_raster_workspace_sizes")
+        ws_geom = torch.empty(F * gb.value, dtype=torch.uint8, device=device)
+        ws_image = torch.empty(F * ib.value, dtype=torch.uint8, device=device)
+        radii = torch.empty(F, G, dtype=torch.int32, device=device)          # k_preprocess writes every entry (0 for what it culls)
+        st, p = _stream(device), _lib.ptr
+        _lib.check(L.dwg_raster_forward_bin_frames(ctypes.byref(cfg), ctypes.byref(fr), G, p(means3D), p(shs), p(colors_precomp), p(opac),
+                                                   p(scales), p(rotations), p(cov3D), p(radii), p(ws_geom), st), "dwg_raster_forward_bin_frames")
+        if pair_state is not None:
+            pair_state.resolve()               # the previous chain's counts (long complete): keeps `cap` current, latches an overflow
+        if pair_capacity is not None:
+            cap = int(pair_capacity)
+        elif pair_state is not None and pair_state.cap > 0:
+            cap = pair_state.cap               # no host synchronisation (PairCapacity): every frame of the chain gets the state's capacity
+        else:                                  # one read-back of the F pair counts sizes the shared capacity exactly
+            hdrs = ws_geom.view(F, gb.value)[:, :16].contiguous().view(torch.int32)
+            cap = max(int(hdrs[:, 0].max().item()), 1)
+            if pair_state is not None:
+                pair_state.seed(cap)
+                cap = pair_state.cap
+        _lib.check(L.dwg_raster_workspace_sizes(G, H, W, cap, ctypes.byref(gb), ctypes.byref(pb), ctypes.byref(ib)), "dwg_raster_workspace_sizes")
+        ws_pairs = torch.empty(F * pb.value, dtype=torch.uint8, device=device)
+        color = torch.empty(F, 3, H, W, dtype=torch.float32, device=device)
+        depth = torch.empty(F, 1, H, W, dtype=torch.float32, device=device)
+        alpha = torch.empty(F, 1, H, W, dtype=torch.float32, device=device)
+        _lib.check(L.dwg_raster_forward_render_frames(ctypes.byref(cfg), ctypes.byref(fr), G, p(ws_geom), p(ws_pairs), cap, p(ws_image),
+                                                      p(color), p(depth), p(alpha), st), "dwg_raster_forward_render_frames")
+        info["headers"] = ws_geom.view(F, -1)[:, :16].contiguous().view(torch.int32)     # device tensor: [F, 4] = K, overflow, K_ref, segments
+        info["capacity"] = cap
+        if pair_state is not None and not pair_state.frozen:
+            # the chain's largest pair count and whether ANY frame was truncated travel to the host behind the launches (pinned 16 bytes)
+            if pair_state.host is None:
+                pair_state.host = torch.zeros(4, dtype=torch.int32).pin_memory()
+            hd = info["headers"]
+            pair_state.host.copy_(torch.stack((hd[:, 0].max(), hd[:, 1].max(), hd[:, 2].sum() // F, hd[:, 3].max())), non_blocking=True)     # [2]: the views' mean K_ref (what the byte formula of a view uses)
+            pair_state.seq += 1
+            ev = torch.cuda.Event(); ev.record(torch.cuda.current_stream(device))
+            pair_state.event, pair_state.pending, pair_state.pending_seq = ev, True, pair_state.seq
+        ctx.pair_state = pair_state
+        ctx.frame_seq = pair_state.seq if pair_state is not None else 0
+        ctx.geo = (F, G, H, W, M, per_frame, cap, float(tanfovx), float(tanfovy), int(sh_degree), float(scale_modifier))
+        ctx.set_materialize_grads(False)
+        ctx.save_for_backward(means3D, opac, colors_precomp, shs, scales, rotations, cov3D, cameras, bg if torch.is_tensor(bg) else None,
+                              ws_geom, ws_pairs, ws_image)
+        ctx.bg = bg
+        ctx.mark_non_differentiable(radii)
+        return color, radii, depth, alpha
+
+    @staticmethod
+    def backward(ctx, g_color, g_radii, g_depth, g_alpha):
+        L = _lib.lib()
+        means3D, opac, colors_precomp, shs, scales, rotations, cov3D, cameras, bg_t, ws_geom, ws_pairs, ws_image = ctx.saved_tensors
+        F, G, H, W, M, per_frame, cap, tanfovx, tanfovy, sh_degree, scale_modifier = ctx.geo
+        device = means3D.device
+        if ctx.pair_state is not None:
+            ctx.pair_state.resolve()
+            if ctx.frame_seq in ctx.pair_state.overflow_seqs:
+                # a frame of this chain was truncated by the pair capacity: its owner renders the step's views again (SDSTrainer.train_step);
+                # the chain contributes ZEROS, as a truncated single frame does
+                z = lambda t: None if t is None else torch.zeros_like(t)     # noqa: E731
+                return (z(means3D), z(opac), z(colors_precomp), z(shs), z(scales), z(rotations), z(cov3D)) + (None,) * 11
+        keep = []
+        rs = GaussianRasterizationSettings(H, W, tanfovx, tanfovy, bg_t if bg_t is not None else ctx.bg, scale_modifier, cameras.reshape(-1)[0:16],
+                                           cameras.reshape(-1)[16:32], sh_degree, cameras.reshape(-1)[32:35], False, False)
+        cfg = _settings_struct(rs, device, M, keep)
+        fr = _lib.RasterFramesC(F, G if per_frame else 0, 35 if (cameras.dim() == 2 and cameras.shape[0] == F and F > 1) else 0)
+        g_color = torch.zeros(F, 3, H, W, device=device) if g_color is None else _f32c(g_color)
+        g_depth = None if g_depth is None else _f32c(g_depth)
+        g_alpha = None if g_alpha is None else _f32c(g_alpha)
+        new = lambda *tail: torch.empty((F, G) + tail, device=device)      # noqa: E731
+        d_means3D, d_means2D, d_opac = new(3), new(3), new()
+        d_sh = new(M, 3) if shs is not None else None
+        d_colors = new(3) if colors_precomp is not None else None
+        d_scales = new(3) if scales is not None else None
+        d_rots = new(4) if rotations is not None else None
+        d_cov = new(6) if cov3D is not None else None
+        ws_grad = torch.empty(F * max(G, 1) * 12, dtype=torch.float32, device=device)
+        p = _lib.ptr
+        _lib.check(L.dwg_raster_backward_frames(ctypes.byref(cfg), ctypes.byref(fr), G, p(means3D), p(shs), p(colors_precomp), p(opac), p(scales),
+                                                p(rotations), p(cov3D), p(ws_geom), p(ws_pairs), cap, p(ws_image), p(ws_grad), p(g_color),
+                                                p(g_depth), p(g_alpha), p(d_means3D), p(d_means2D), p(d_sh), p(d_colors), p(d_opac), p(d_scales),
+                                                p(d_rots), p(d_cov), _stream(device)), "dwg_raster_backward_frames")
+
+        def fold(t, like):
+            """[F, G, ...] gradient rows -> the input's shape: per-frame inputs take their rows, shared inputs the sum over the frames."""
+            if t is None or like is None:
+                return None
+            if not per_frame:
+                acc = t[0]
+                for f in range(1, F):           # frame order, one add per frame: the same bits as F single-frame backwards accumulated in turn
+                    acc = acc + t[f]
+                t = acc
+            return t.reshape(like.shape)
+        return (fold(d_means3D, means3D), fold(d_opac, opac), fold(d_colors, colors_precomp), fold(d_sh, shs), fold(d_scales, scales),
+                fold(d_rots, rotations), fold(d_cov, cov3D)) + (None,) * 11
+
+
 def rasterize_frames(means3D, opacities, colors_precomp=None, shs=None, scales=None, rotations=None, cov3D_precomp=None, *,
-                     cameras, image_height, image_width, tanfovx, tanfovy, bg, sh_degree=0, scale_modifier=1.0, pair_capacity=None):
-    """Forward of F frames in ONE launch chain (include/dwg_raster.h `dwg_raster_frames`; no autograd: the playback path).
+                     cameras, image_height, image_width, tanfovx, tanfovy, bg, sh_degree=0, scale_modifier=1.0, pair_capacity=None,
+                     pair_state: Optional[PairCapacity] = None):
+    """F frames in ONE launch chain (include/dwg_raster.h `dwg_raster_frames`), differentiable: the playback path calls it under no_grad,
+    the batched multi-view step with the V views of the step as its frames.
 
     Per-Gaussian inputs are either [F, G, ...] (one posed set of Gaussians per frame) or [G, ...] (shared by all frames);
     `cameras` is [F, 35] or [35] float32 = [viewmatrix 16 | projmatrix 16 | campos 3] rows as `dwg_raster_camera_setup` writes them.
-    Frame f's outputs are bit-identical to a single-frame call with its inputs (the reference's call at
-    /root/reference/core/gaussian/gaussian_renderer.py:186-195, once per frame).
-    -> color [F,3,H,W], radii [F,G] int32, depth [F,1,H,W], alpha [F,1,H,W], info dict(num_pairs [F], overflow [F], capacity)."""
+    Frame f's outputs -- and, in the backward, its gradient rows -- are bit-identical to a single-frame call with its inputs (the
+    reference's call at /root/reference/core/gaussian/gaussian_renderer.py:186-195, once per frame).
+    -> color [F,3,H,W], radii [F,G] int32, depth [F,1,H,W], alpha [F,1,H,W], info dict(headers [F,4] device int32, capacity)."""
     if not means3D.is_cuda:
         raise RuntimeError("dreamwaltz_g_amd rasterizer runs on the GPU only (HIP kernels); got a CPU tensor")
-    L = _lib.lib()
-    device = means3D.device
     per_frame = means3D.dim() == 3
     cameras = _f32c(cameras)
     F = int(means3D.shape[0]) if per_frame else (int(cameras.shape[0]) if cameras.dim() == 2 else 1)
     if cameras.dim() == 2 and int(cameras.shape[0]) not in (1, F):
         raise ValueError("rasterize_frames: %d cameras for %d frames" % (cameras.shape[0], F))
     G = int(means3D.shape[-2])
-    H, W = int(image_height), int(image_width)
 
     def arr(t, tail):
         if t is None:
@@ -272,38 +387,14 @@ def rasterize_frames(means3D, opacities, colors_precomp=None, shs=None, scales=N
         return t
     means3D = arr(means3D, (3,)); opac = arr(opacities, ())
     colors_precomp = arr(colors_precomp, (3,)); scales = arr(scales, (3,)); rotations = arr(rotations, (4,)); cov3D = arr(cov3D_precomp, (6,))
-    M = 0
     if shs is not None:
-        shs = _f32c(shs); M = int(shs.shape[-2])
+        shs = _f32c(shs)
     if (shs is None) == (colors_precomp is None):
         raise Exception("Please provide excatly one of either SHs or precomputed colors!")
-    keep = []
-    rs = GaussianRasterizationSettings(H, W, float(tanfovx), float(tanfovy), bg, float(scale_modifier), cameras.reshape(-1)[0:16],
-                                       cameras.reshape(-1)[16:32], int(sh_degree), cameras.reshape(-1)[32:35], False, False)
-    cfg = _settings_struct(rs, device, M, keep)
-    fr = _lib.RasterFramesC(F, G if per_frame else 0, 35 if (cameras.dim() == 2 and cameras.shape[0] == F and F > 1) else 0)
-    gb, pb, ib = ctypes.c_size_t(), ctypes.c_size_t(), ctypes.c_size_t()
-    _lib.check(L.dwg_raster_workspace_sizes(G, H, W, 0, ctypes.byref(gb), ctypes.byref(pb), ctypes.byref(ib)), "dwg_raster_workspace_sizes")
-    ws_geom = torch.empty(F * gb.value, dtype=torch.uint8, device=device)
-    ws_image = torch.empty(F * ib.value, dtype=torch.uint8, device=device)
-    radii = torch.empty(F, G, dtype=torch.int32, device=device)          # k_preprocess writes every entry (0 for what it culls)
-    st, p = _stream(device), _lib.ptr
-    _lib.check(L.dwg_raster_forward_bin_frames(ctypes.byref(cfg), ctypes.byref(fr), G, p(means3D), p(shs), p(colors_precomp), p(opac),
-                                               p(scales), p(rotations), p(cov3D), p(radii), p(ws_geom), st), "dwg_raster_forward_bin_frames")
-    hdrs = ws_geom.view(F, gb.value)[:, :16].contiguous().view(torch.int32)
-    if pair_capacity is None:              # one read-back of the F pair counts sizes the shared capacity exactly
-        cap = max(int(hdrs[:, 0].max().item()), 1)
-    else:
-        cap = int(pair_capacity)
-    _lib.check(L.dwg_raster_workspace_sizes(G, H, W, cap, ctypes.byref(gb), ctypes.byref(pb), ctypes.byref(ib)), "dwg_raster_workspace_sizes")
-    ws_pairs = torch.empty(F * pb.value, dtype=torch.uint8, device=device)
-    color = torch.empty(F, 3, H, W, dtype=torch.float32, device=device)
-    depth = torch.empty(F, 1, H, W, dtype=torch.float32, device=device)
-    alpha = torch.empty(F, 1, H, W, dtype=torch.float32, device=device)
-    _lib.check(L.dwg_raster_forward_render_frames(ctypes.byref(cfg), ctypes.byref(fr), G, p(ws_geom), p(ws_pairs), cap, p(ws_image),
-                                                  p(color), p(depth), p(alpha), st), "dwg_raster_forward_render_frames")
-    hdrs = ws_geom.view(F, -1)[:, :16].contiguous().view(torch.int32)         # device tensor: [F, 4] = K, overflow, K_ref, segments
-    return color, radii, depth, alpha, dict(headers=hdrs, capacity=cap)
+    info = {}
+    color, radii, depth, alpha = _RasterizeFrames.apply(means3D, opac, colors_precomp, shs, scales, rotations, cov3D, cameras, int(image_height),
+                                                        int(image_width), tanfovx, tanfovy, bg, sh_degree, scale_modifier, pair_capacity, info, pair_state)
+    return color, radii, depth, alpha, info
 
 
 def morton_order(positions: torch.Tensor, bits: int = 10) -> torch.Tensor:

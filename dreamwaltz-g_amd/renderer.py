@@ -52,6 +52,18 @@ def stream_keyed(renderer) -> bool:
     return bool(getattr(renderer, "per_stream_pair_states", False))
 
 
+class _ChainCounts:
+    """`last_num_pairs` of a frames chain: (largest pair count after exact culling, the views' mean reference tile-pair count)."""
+
+    def __init__(self, pair_state):
+        self.pair_state, self.visit_order = pair_state, None
+
+    @property
+    def last_num_pairs(self):
+        self.pair_state.resolve()
+        return self.pair_state.last_num_pairs, self.pair_state.last_num_pairs_ref
+
+
 class GaussianRenderer:
     def __init__(self, sh_levels=4, bg_color=(0.0, 0.0, 0.0), compute_color_in_rasterizer=True,
                  compute_covariance_in_rasterizer=True, async_pair_count=False, reorder_every: Optional[int] = None) -> None:
@@ -175,14 +187,13 @@ class GaussianRenderer:
         return get_colors(sh_features=sh_features, directions=directions, sh_levels=sh_levels)
 
     def render_frames(self, data: dict, frames) -> dict:
-        """F posed sets of Gaussians seen by ONE camera, rasterized by ONE launch chain (rasterizer.rasterize_frames; forward only -- the
-        playback path: trainer.py:1019-1150 renders a pose sequence frame by frame under inference mode).  Frame f of the result is
+        """F posed sets of Gaussians seen by ONE camera (or each by its own), rasterized by ONE launch chain (rasterizer.rasterize_frames):
+        the playback path under inference mode (trainer.py:1019-1150 renders a pose sequence frame by frame), and -- differentiable since
+        round 6, the backward on (work, F) grids too -- the V views of a batched multi-view training step.  Frame f of the result is
         bit-identical to `render(data, frames[f])`; what changes is the cost: the rasterizer's seven dependent launches are paid once per
         batch and each runs over F times the work (per frame, 300 k Gaussians at 1024^2: 0.44 ms alone, 0.25 ms at F = 4).
         -> {'image': [F, H, W, 3], 'depth': [F, H, W, 1], 'alpha': [F, H, W, 1]}."""
         from .rasterizer import rasterize_frames
-        if torch.is_grad_enabled() and any(g.positions.requires_grad for g in frames):
-            raise RuntimeError("render_frames is the forward-only playback path: call it under torch.inference_mode() / no_grad()")
         # one camera for the batch (`data`: the loader's dict), or one per frame (`data`: a list of F such dicts -- the reference's evaluation
         # loader hands a camera with every pose; image size and field of view must agree across the batch)
         datas = list(data) if isinstance(data, (list, tuple)) else [data]
@@ -215,7 +226,13 @@ class GaussianRenderer:
             shs=None if use_colors else st("sh_features"), scales=None if use_cov else st("scales"),
             rotations=None if use_cov else st("quaternions"), cov3D_precomp=st("cov3D") if use_cov else None,
             cameras=cam, image_height=rs.image_height, image_width=rs.image_width, tanfovx=rs.tanfovx, tanfovy=rs.tanfovy,
-            bg=rs.bg, sh_degree=rs.sh_degree)
+            bg=rs.bg, sh_degree=rs.sh_degree,
+            # a training chain (gradients wanted) sizes its pair buffers like the single-frame training path: from the renderer's running state,
+            # without a host wait; playback keeps the exact per-chain read-back
+            pair_state=self.pair_state(g0.positions.device, rs.image_height, rs.image_width) if torch.is_grad_enabled() and g0.positions.requires_grad else None)
+        ps = self.pair_state(g0.positions.device, rs.image_height, rs.image_width) if torch.is_grad_enabled() and g0.positions.requires_grad else None
+        if ps is not None:
+            self.last_rasterizer = _ChainCounts(ps)             # what `last_rasterizer.last_num_pairs` reports after a training chain
         self.last_frames_headers = info["headers"]                  # device [F, 4]: block pairs, overflow, reference tile pairs, segments
         return {"image": color.permute(0, 2, 3, 1), "depth": depth.permute(0, 2, 3, 1), "alpha": alpha.permute(0, 2, 3, 1)}
 

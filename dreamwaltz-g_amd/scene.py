@@ -4,6 +4,8 @@ compositing `image + bg (1 - alpha)` for bg_mode in {black, white, gray}.  Learn
 hot path (scene.py:123-132,158-165) and are rejected."""
 from typing import Iterable, Optional
 
+import contextlib
+
 import torch
 import torch.nn as nn
 
@@ -109,6 +111,50 @@ class Scene(nn.Module):
         else:
             outputs['image_fg'] = outputs['image']
         return outputs
+
+    def forward_views(self, datas, poses, bg_mode: Optional[str] = None, streams=None) -> list:
+        """The V views of a batched multi-view training step (trainer.train_forward_views): `animate` per view (`poses[v]`: that view's
+        smpl inputs, or None for the canonical pose) -- each on its own stream when `streams` is given, they are independent chains of
+        small launches -- then ONE differentiable rasterizer launch chain for all of them (renderer.render_frames: forward AND backward on
+        (work, V) grids).  View v of the result equals `forward(datas[v], poses[v], use_densifier=False, bg_mode=bg_mode)` bit for bit,
+        and so do the gradients it sends back.  Single avatar.  -> a list of V output dicts ([1, H, W, C] tensors)."""
+        if self.avatars is not None:
+            raise NotImplementedError("forward_views renders one avatar per view")
+        main = torch.cuda.current_stream(self.avatar.device) if streams else None
+        frames = []
+        for v, pose in enumerate(poses):
+            if streams:
+                streams[v].wait_stream(main)
+            with (torch.cuda.stream(streams[v]) if streams else contextlib.nullcontext()):
+                g = self.avatar_forward(smpl_observed_inputs=pose)
+                if self.use_zero_scales:
+                    g.scales = g.scales * 0.1
+                if self.use_constant_colors:
+                    g.colors = self.constant_colors.expand(g.colors.size(0), -1)
+                if self.use_constant_opacities:
+                    g.opacities = self.constant_opacities.expand(g.opacities.size(0), -1)
+                if self.use_fixed_n_gaussians:
+                    g = downsample_gaussians(g, self.fixed_n_gaussians)
+            if streams:
+                for t in (g.positions, g.opacities, g.colors, g.sh_features, g.scales, g.quaternions):
+                    if t is not None:
+                        t.record_stream(main)
+            frames.append(g)
+        if streams:
+            for side in streams[:len(frames)]:
+                main.wait_stream(side)
+        out = self.renderer.render_frames(data=list(datas), frames=frames)
+        views = []
+        for v in range(len(frames)):
+            o = {k: t[v:v + 1] for k, t in out.items()}
+            if bg_mode in self.pure_colors:
+                o['image_bg'] = self.pure_colors.get_background_like(bg_mode, o['image'])
+                o['image_fg'] = o['image']
+                o['image'] = o['image'] + o['image_bg'] * (1 - o['alpha'])
+            else:
+                o['image_fg'] = o['image']
+            views.append(o)
+        return views
 
     def forward(self, data: dict, smpl_observed_inputs: Optional[dict] = None, use_densifier: bool = True, bg_mode: Optional[str] = None,
                 **kwargs):

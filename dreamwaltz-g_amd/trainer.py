@@ -148,9 +148,28 @@ class SDSTrainer:
         self._views_warm = True
         return self._guide_views(images, texts, names, conds, draws, outs, forced)
 
+    def _views_on_one_chain(self, views):
+        """The batched step rasterizes its V views on ONE launch chain, forward and backward (Scene.forward_views; round 6) when the views
+        agree on image size and field of view and nothing needs the per-view rasterizer objects (densification statistics).
+        DWG_VIEW_FRAMES=0: every view runs its own seven + three launches (the round-5 path)."""
+        if os.environ.get("DWG_VIEW_FRAMES", "1") == "0" or not hasattr(self.model, "forward_views") or getattr(self.model, "avatars", None) is not None:
+            return False
+        if self.densifiers is not None or not all(torch.is_tensor(v.get('extrinsic')) and v['extrinsic'].is_cuda for v in views):
+            return False
+        cams = {(int(v['image_height']), int(v['image_width']), float(v['tanfov'][0]), float(v['tanfov_x'][0]) if 'tanfov_x' in v else None) for v in views}
+        return len(cams) == 1
+
     def _render_views(self, views, multi, main, images, texts, names, conds, draws, outs, forced):
+        chain = self._views_on_one_chain(views)
+        if chain:
+            animated = self.cfg.prompt.scene != 'canonical' or self.cfg.render.always_animate
+            ros = self.model.forward_views(views, [v['smpl_inputs'] if animated else None for v in views],
+                                           streams=self._view_streams[:len(views)] if multi else None)
         for i, data in enumerate(views):
-            if multi:
+            if chain:
+                ro = ros[i]
+                img = ro['image'].permute(0, 3, 1, 2)
+            elif multi:
                 side = self._view_streams[i]
                 side.wait_stream(main)
                 with torch.cuda.stream(side):

@@ -138,6 +138,21 @@ int dwg_raster_backward(const dwg_raster_settings* cfg, int32_t num_gaussians,
                         float* dL_dshs, float* dL_dcolors, float* dL_dopacities, float* dL_dscales,
                         float* dL_drotations, float* dL_dcov3D, dwg_stream_t stream);
 
+/* The backward of `frames->num_frames` frames per launch (frames == NULL: one frame): the three launches run on (work, F) grids.
+ * Workspaces are the frame-major ones the forward_*_frames calls filled (same pair_capacity); inputs and cameras lie at the strides of
+ * `frames` exactly as in the forward; ws_grad >= F * 12 * G floats; image gradients are [F, 3, H, W] / [F, 1, H, W]; every gradient
+ * output is frame-major [F, G, ...] (the caller sums over frames where the frames share their Gaussians).  Frame f's rows are bit for
+ * bit those of a single-frame dwg_raster_backward on that frame (the call of gaussian_renderer.py:186-195 differentiated once per view). */
+int dwg_raster_backward_frames(const dwg_raster_settings* cfg, const dwg_raster_frames* frames, int32_t num_gaussians,
+                               const float* means3D, const float* shs, const float* colors_precomp,
+                               const float* opacities, const float* scales, const float* rotations,
+                               const float* cov3D_precomp, const void* ws_geom, const void* ws_pairs,
+                               int64_t pair_capacity, const void* ws_image, void* ws_grad,
+                               const float* dL_dout_color, const float* dL_dout_depth,
+                               const float* dL_dout_alpha, float* dL_dmeans3D, float* dL_dmeans2D,
+                               float* dL_dshs, float* dL_dcolors, float* dL_dopacities, float* dL_dscales,
+                               float* dL_drotations, float* dL_dcov3D, dwg_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

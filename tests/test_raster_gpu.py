@@ -265,3 +265,46 @@ def test_frames_per_launch_equal_single_frames_bit_for_bit(shared_gaussians):
         assert torch.equal(one["color"], color[f]) and torch.equal(one["depth"], depth[f]) and torch.equal(one["alpha"], alpha[f]), f
         assert torch.equal(one["radii"], radii[f]), f
     _check_images(rc.image_err_stats(dict(color=color[1], depth=depth[1], alpha=alpha[1], radii=radii[1]), rc.oracle_forward(scenes[1])), "frame 1")
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("shared", [False, True])
+def test_frames_backward_equals_single_frame_backwards_bit_for_bit(shared):
+    """dwg_raster_backward_frames (round 6): F views on ONE launch chain, forward and backward, against F single-frame calls
+    (gaussian_renderer.py:186-195 once per view): images, radii and every gradient row identical in every bit.  `shared`: the views look at
+    the SAME Gaussians with different cameras (the batched multi-view step) -- the shared inputs' gradients are the frame-ordered sum."""
+    from dreamwaltz_g_amd.rasterizer import rasterize_frames
+    F, G, H, W = 3, 6000, 192, 160
+    scs = [rc.make_scene(G, H, W, seed=3 if shared else 3 + f, azimuth=20.0 + 50.0 * f, elevation=70.0 + 8.0 * f) for f in range(F)]
+    dev = "cuda"
+    cams = torch.stack([torch.cat([s["viewmatrix"].reshape(-1), s["projmatrix"].reshape(-1), s["campos"].reshape(-1)]) for s in scs]).to(dev)
+    g_img = [torch.randn(3, H, W, generator=torch.Generator().manual_seed(10 + f)).to(dev) for f in range(F)]
+    g_dep = [torch.randn(1, H, W, generator=torch.Generator().manual_seed(20 + f)).to(dev) for f in range(F)]
+    g_alp = [torch.randn(1, H, W, generator=torch.Generator().manual_seed(30 + f)).to(dev) for f in range(F)]
+    singles = []
+    for f, sc in enumerate(scs):
+        out = rc.hip_render(sc, device=dev, requires_grad=True)
+        (out["color"] * g_img[f]).sum().add((out["depth"] * g_dep[f]).sum()).add((out["alpha"] * g_alp[f]).sum()).backward()
+        singles.append(out)
+    keys = ("means3D", "opacities", "colors", "scales", "rotations")
+    if shared:
+        leaves = {k: scs[0][k].to(dev).clone().requires_grad_(True) for k in keys}
+    else:
+        leaves = {k: torch.stack([s[k] for s in scs]).to(dev).clone().requires_grad_(True) for k in keys}
+    color, radii, depth, alpha, info = rasterize_frames(leaves["means3D"], leaves["opacities"], colors_precomp=leaves["colors"], scales=leaves["scales"],
+                                                        rotations=leaves["rotations"], cameras=cams, image_height=H, image_width=W,
+                                                        tanfovx=scs[0]["tanfovx"], tanfovy=scs[0]["tanfovy"], bg=scs[0]["bg"].to(dev))
+    assert not bool(info["headers"][:, 1].any())
+    ((color * torch.stack(g_img)).sum() + (depth * torch.stack(g_dep)).sum() + (alpha * torch.stack(g_alp)).sum()).backward()
+    for f in range(F):
+        assert torch.equal(color[f], singles[f]["color"]) and torch.equal(depth[f], singles[f]["depth"]) and torch.equal(alpha[f], singles[f]["alpha"])
+        assert torch.equal(radii[f], singles[f]["radii"])
+    for k in keys:
+        if shared:
+            want = singles[0]["leaves"][k].grad.clone()
+            for f in range(1, F):
+                want = want + singles[f]["leaves"][k].grad
+            assert torch.equal(leaves[k].grad, want), k
+        else:
+            for f in range(F):
+                assert torch.equal(leaves[k].grad[f], singles[f]["leaves"][k].grad), (k, f)
