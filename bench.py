@@ -75,6 +75,8 @@ def parse():
                     "device-resident camera block (step_graph.GraphedTrainStep.step(pose, camera))")
     ap.add_argument("--eager", action="store_true", help="launch every kernel eagerly (no hipGraph replay of the denoiser/VAE plans)")
     ap.add_argument("--no-gpu-condition", action="store_true", help="fixed condition image instead of the per-step GPU OpenPose image of the posed body")
+    ap.add_argument("--bound-loop", action="store_true", help="config c2 / c3: the step as the reference's own loop drives it through dropin/dwg_bind.py "
+                    "(launch by launch, new camera per step, exact pair sizing per frame, loader-side condition image)")
     ap.add_argument("--sync-pairs", action="store_true", help="exact pair-buffer sizing through a 16-byte read-back per frame")
     ap.add_argument("--sequential-views", action="store_true", help="config c4: one guidance call per view (gradients accumulated) instead of one "
                                                                     "batched VAE / denoiser pass for all the views of a rank")
@@ -401,9 +403,18 @@ def _timed(ctx, fn, steps, warmup):
 
 
 def run_sds(ctx, config, dtype=HEADLINE_DTYPE, views=None, steps=None, warmup=None, profile=True, batch_views=None, repeats=None, step_graph=None,
-            moving_camera=False):
-    """c2 / c3 / c4: SDSStep-based workloads.  Returns the JSON line as a dict (rank 0) or None."""
+            moving_camera=False, bound_loop=None):
+    """c2 / c3 / c4: SDSStep-based workloads.  Returns the JSON line as a dict (rank 0) or None.
+    `bound_loop`: the step as the reference's OWN loop drives it through the binding (dropin/dwg_bind.py; /root/reference/core/trainer.py:840-896):
+    zero_grad -> update_learning_rate -> render -> guidance -> backward -> every optimizer's step, launch by launch from Python (no captured
+    step), a NEW camera every step, the pair workspace sized by the 16-byte read-back per frame (the binding builds its Scene with
+    async_pair_count=False: the reference's loop body knows nothing about re-rendering a truncated frame) and the condition image handed
+    over by the loader (the reference draws it on the CPU in its dataloader workers, outside the seams) -- the denoiser / VAE plans replay
+    as the hipGraphs bind_guidance captures.  This is the rate a `main.py` user gets."""
     args = ctx.args
+    bound = bool(getattr(args, "bound_loop", False)) if bound_loop is None else bool(bound_loop)
+    if bound:
+        moving_camera, step_graph = True, False
     steps, warmup = defaults(config, steps, warmup)
     guidance = config in ("c3", "c4") and not args.no_guidance
     G = args.gaussians or (50000 if config == "c2" else 100000)
@@ -417,7 +428,7 @@ def run_sds(ctx, config, dtype=HEADLINE_DTYPE, views=None, steps=None, warmup=No
         batch_views = config == "c4" and not args.sequential_views
     batch_views = bool(batch_views and guidance and per_rank > 1 and views % ctx.world == 0)
     step = sds_step.SDSStep(n_gaussians=G, res=res, device=ctx.dev, rank=ctx.rank, world=ctx.world, guidance=guidance, dist=ctx.dist,
-                            async_pair_count=not args.sync_pairs, gpu_condition=not args.no_gpu_condition, views=views, dtype=dtype,
+                            async_pair_count=not (args.sync_pairs or bound), gpu_condition=not (args.no_gpu_condition or bound), views=views, dtype=dtype,
                             guidance_obj=ctx.guidance_for(dtype, per_rank if batch_views else 1) if guidance else None)
     moving = bool(getattr(args, "moving_camera", False) or moving_camera) and views == 1 and ctx.world == 1
     if moving:
@@ -517,6 +528,9 @@ def run_sds(ctx, config, dtype=HEADLINE_DTYPE, views=None, steps=None, warmup=No
     out["camera"] = "a new camera every step (64-entry table: radius, azimuth, elevation, field of view all move)" if moving else "fixed"
     if whole_graph:
         out["graph_recaptures"] = recaptures
+    if bound:
+        out["bound_loop"] = ("driven as /root/reference/core/trainer.py:840-896 drives it through dropin/dwg_bind.py: launch by launch, new camera per step, "
+                             "16-byte pair-count read-back per frame, loader-side condition image")
     out["launch_mode"] = ("eager" if args.eager else "the WHOLE step (zero_grad, animate, raster fwd + bwd, Adam) replayed as one captured HIP graph per pose"
                           if whole_graph else "hipGraph replay of denoiser/VAE plans; kernel timers from an eager replay after the timed region")
     return out
@@ -697,6 +711,7 @@ def flat_scalars(out, cfgs, by):
         "c2_raster_fwd_frac": g(cfgs, "c2", "roofline", "raster_forward", "frac_of_hbm_peak"),
         "c2_raster_bwd_frac": g(cfgs, "c2", "roofline", "raster_backward", "frac_of_hbm_peak"),
         "c3_steps_per_s_bound_loop": g(cfgs, "c3_bound_loop", "value"),
+        "c3_bound_loop_steps_per_s": g(cfgs, "c3_bound_loop", "value"), "c2_bound_loop_steps_per_s": g(cfgs, "c2_bound_loop", "value"),
         "c4_n1_views_per_s": g(cfgs, "c4_n1", "views_per_s"), "c4_n1_sequential_views_per_s": g(cfgs, "c4_n1_sequential_views", "views_per_s"),
         "c4_n1_raster_fwd_frac_per_view": g(cfgs, "c4_n1", "roofline", "raster_forward", "frac_of_hbm_peak"),
         "c4_n1_raster_bwd_frac_per_view": g(cfgs, "c4_n1", "roofline", "raster_backward", "frac_of_hbm_peak"),
@@ -742,6 +757,8 @@ def main():
             pre_cfgs["c2_eager_launches"] = _brief(c2e, ("value", "unit", "ms_per_step", "steps", "warmup", "launch_mode"))
             c2m = run_sds(ctx, "c2", steps=200, warmup=20, step_graph=True, profile=False, moving_camera=True)     # ... with the reference's per-step camera
             pre_cfgs["c2_moving_camera"] = _brief(c2m, ("value", "unit", "ms_per_step", "steps", "warmup", "launch_mode", "camera", "graph_recaptures"))
+            c2b = run_sds(ctx, "c2", steps=200, warmup=20, profile=False, bound_loop=True)      # ... driven as the reference's loop drives it through the binding
+            pre_cfgs["c2_bound_loop"] = _brief(c2b, ("value", "unit", "ms_per_step", "steps", "warmup", "launch_mode", "camera"))
             c5 = run_c5(ctx, 200, 20)
             c1 = run_c1(ctx, 200, 20)
             if cpu_ok:
@@ -755,6 +772,8 @@ def main():
             rk = ("kernel", "achieved", "peak", "frac", "mfma_all")
             by = {HEADLINE_DTYPE: _brief(out, ("value", "unit", "ms_per_step", "dtype")) | {"roofline": {k: out["roofline"].get(k) for k in rk}}}
             cfgs = dict(pre_cfgs)
+            c3b = run_sds(ctx, "c3", steps=20, warmup=5, profile=False, bound_loop=True)     # the headline workload as a `main.py` user's loop runs it
+            cfgs["c3_bound_loop"] = _brief(c3b, ("value", "unit", "ms_per_step", "steps", "warmup", "launch_mode", "camera"))
             c4 = run_sds(ctx, "c4", profile=False)                       # 8 views through ONE VAE / denoiser pass per step; median of 3 x 10 steps
             cfgs["c4_n1"] = _brief(c4)
             ctx.guidance.pop((HEADLINE_DTYPE, 8), None); torch.cuda.empty_cache()

@@ -25,6 +25,11 @@ class RasterSettingsC(ctypes.Structure):
     ]
 
 
+class SegmentC(ctypes.Structure):
+    """include/dwg_gaussian.h dwg_segment."""
+    _fields_ = [("dst", ctypes.c_void_p), ("src", ctypes.c_void_p), ("count", ctypes.c_int64)]
+
+
 class RasterFramesC(ctypes.Structure):
     """struct dwg_raster_frames (include/dwg_raster.h)."""
     _fields_ = [("num_frames", ctypes.c_int32), ("gaussian_stride", ctypes.c_int64), ("camera_stride", ctypes.c_int64)]
@@ -121,6 +126,11 @@ SIGNATURES = {
     "dwg_sds_gradient": (ctypes.c_int, [_i32, ctypes.c_int64, _vp, _vp, _vp, _i32, _vp, ctypes.c_float, _i32, _i32, _vp, _vp, _vp]),
     # include/dwg_gaussian.h
     "dwg_gaussian_assemble_forward": (ctypes.c_int, [_i32, _i32, _vp, _vp, _f32, _vp, _vp, _f32, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
+    "dwg_gaussian_assemble_forward_ld": (ctypes.c_int, [_i32, _i32, _vp, _vp, _f32, _vp, _vp, _i32, _f32, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
+    "dwg_gaussian_assemble_backward_ld": (ctypes.c_int, [_i32, _i32, _f32, _vp, _f32, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i32, _i32,
+                                                         _vp, _vp, _vp]),
+    "dwg_copy_segments": (ctypes.c_int, [_i32, _vp, _f32, _f32, _vp]),
+    "dwg_add_segments": (ctypes.c_int, [_i32, _vp, _vp]),
     "dwg_gaussian_assemble_backward": (ctypes.c_int, [_i32, _i32, _f32, _vp, _f32, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp,
                                                        _vp, _vp, _vp, _vp]),
     # include/dwg_meshbind.h

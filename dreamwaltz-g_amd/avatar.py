@@ -636,25 +636,27 @@ class DreamWaltzG(nn.Module):
         if hit:
             enc_all, oc_all = self._frozen_cache[1], self._frozen_cache[2]
         else:
-            all_cpos = torch.cat([canonical_positions] + [mp[0] for mp in mesh_parts], dim=0) if mesh_parts else canonical_positions
-            enc_all = self.nerf_encoder(all_cpos, bound=self._nerf_bound_host)
+            # the encoder's input rows, gathered AND normalised ((x + bound) / (2 bound): GridEncoder.forward) by one launch
+            (unit_cpos,) = asm_ops.concat_rows([[canonical_positions] + [mp[0] for mp in mesh_parts]], bound=self._nerf_bound_host)
+            enc_all = self.nerf_encoder(unit_cpos, normalized=True)
             oc_all = self.nerf_opacity_and_color_net(enc_all)                  # static_mlp_forward (avatar.py:1283-1290), all rows
             self._frozen_cache = (frozen_key, enc_all, oc_all) if frozen_key is not None else None
         enc = enc_all[:N]
         body_pose = smpl_observed_inputs.get('body_pose')
         if body_pose is None:
             body_pose = torch.zeros(1, 63, device=positions.device)
-        offsets, mlp_scales, _mlp_quats = self.dynamic_mlp_forward(enc, body_pose)
+        mlp_out = self.nerf_scale_and_quaternion_net(enc, body_pose, packed=True)      # dynamic_mlp_forward: [warp 3 | scaling 3 | rotation 4] per row
         # non_rigid_transform (avatar.py:1464-1498, default flags) + the sigmoid / exp / normalize activations: one HIP launch
-        pos, scales, quats, col_all, op_all = asm_ops.assemble(positions, offsets, self._scales, mlp_scales, self._quaternions, oc_all,
-                                                               self.init_offset, self.init_scale)
+        pos, scales, quats, col_all, op_all = asm_ops.assemble_packed(positions, mlp_out, self._scales, self._quaternions, oc_all,
+                                                                      self.init_offset, self.init_scale)
         pos, quats = self.lbs_transform(pos, otr, quaternions=quats)
         if not mesh_parts:
             return GaussianOutput(positions=pos, opacities=op_all, colors=col_all, quaternions=quats, scales=scales)
         # merge_gaussians (gaussian_utils.py:56-68): colours / opacities already come out in the merged row order
-        return GaussianOutput(positions=torch.cat([pos] + [mp[1] for mp in mesh_parts], dim=0), opacities=op_all, colors=col_all,
-                              quaternions=torch.cat([quats] + [mp[3] for mp in mesh_parts], dim=0),
-                              scales=torch.cat([scales] + [mp[2] for mp in mesh_parts], dim=0))
+        # (positions, quaternions and scales of the free and the mesh-bound rows: one launch for the three merged tensors)
+        m_pos, m_quats, m_scales = asm_ops.concat_rows([[pos] + [mp[1] for mp in mesh_parts], [quats] + [mp[3] for mp in mesh_parts],
+                                                        [scales] + [mp[2] for mp in mesh_parts]])
+        return GaussianOutput(positions=m_pos, opacities=op_all, colors=col_all, quaternions=m_quats, scales=m_scales)
 
     # -- optimizers (avatar.py:1590-1635) --------------------------------------------------------------------------------
     # per-Gaussian opacity PARAMETERS do not exist on this avatar (avatar.py:1233-1244; its opacities come out of the MLP): the reference's

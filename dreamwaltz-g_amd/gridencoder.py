@@ -309,8 +309,10 @@ class GridEncoder(nn.Module):
         super()._load_from_state_dict(*args, **kwargs)
         self._host_offsets_py = None       # `offsets` may have been replaced: re-read it once on the next forward
 
-    def forward(self, inputs, bound=1):
-        inputs = (inputs + bound) / (2 * bound)
+    def forward(self, inputs, bound=1, normalized=False):
+        """`normalized`: the inputs already are (x + bound) / (2 bound) (avatar.animate normalises while it gathers the rows)."""
+        if not normalized:
+            inputs = (inputs + bound) / (2 * bound)
         prefix_shape = list(inputs.shape[:-1])
         inputs = inputs.view(-1, self.input_dim)
         if self._host_offsets_py is None:

@@ -253,6 +253,59 @@ class MLP(nn.Module):
         return mlp_chain(x, [(m.weight, m.bias) for m in self.net], ["relu"] * (self.num_layers - 1) + [None])
 
 
+class _PackRows(torch.autograd.Function):
+    """Several tensors stacked along dim 0 into ONE (weights) and their 1-D companions into another (biases), one launch (dwg_copy_segments)
+    -- the three output heads of the deformation network as the single 64 -> 10 layer mlp_chain multiplies.  Backward: a piece that is a
+    flat-buffer Parameter gets its rows of the packed gradient ADDED into its gradient slice by one launch for all such pieces
+    (dwg_add_segments; autograd sees None and the participation is recorded), any other piece gets its rows back as a view."""
+
+    @staticmethod
+    def forward(ctx, n, *pieces):
+        ws, bs = pieces[:n], pieces[n:]
+        dev = ws[0].device
+        W = torch.empty((sum(int(w.shape[0]) for w in ws),) + tuple(ws[0].shape[1:]), device=dev)
+        B = torch.empty(sum(int(b.shape[0]) for b in bs), device=dev)
+        segs, ow, ob = [], 0, 0
+        keep = []
+        for w in ws:
+            wc = w.contiguous().float(); keep.append(wc)
+            segs.append(_lib.SegmentC(W.data_ptr() + 4 * ow, wc.data_ptr(), wc.numel())); ow += wc.numel()
+        for b in bs:
+            bc = b.contiguous().float(); keep.append(bc)
+            segs.append(_lib.SegmentC(B.data_ptr() + 4 * ob, bc.data_ptr(), bc.numel())); ob += bc.numel()
+        arr = (_lib.SegmentC * len(segs))(*segs)
+        _lib.check(_lib.lib().dwg_copy_segments(len(segs), ctypes.cast(arr, ctypes.c_void_p), 0.0, 0.0, _st(W)), "dwg_copy_segments")
+        ctx.pieces, ctx.n, ctx.inplace_ok = pieces, n, _inplace_allowed()
+        return W, B
+
+    @staticmethod
+    def backward(ctx, gW, gB):
+        n, pieces = ctx.n, ctx.pieces
+        out, segs, touched = [None] * len(pieces), [], []
+        gW = None if gW is None else gW.contiguous().float()
+        gB = None if gB is None else gB.contiguous().float()
+        ow = ob = 0
+        for i, p in enumerate(pieces):
+            g, off = (gW, ow) if i < n else (gB, ob)
+            cnt = p.numel()
+            if g is not None and ctx.needs_input_grad[1 + i]:
+                flat = _flat_slice(p, None, True) if ctx.inplace_ok else None
+                if flat is not None:
+                    segs.append(_lib.SegmentC(p.grad.data_ptr(), g.data_ptr() + 4 * off, cnt)); touched.append((flat, p))
+                else:
+                    out[i] = g.reshape(-1)[off:off + cnt].view(p.shape)
+            if i < n:
+                ow += cnt
+            else:
+                ob += cnt
+        if segs:
+            arr = (_lib.SegmentC * len(segs))(*segs)
+            _lib.check(_lib.lib().dwg_add_segments(len(segs), ctypes.cast(arr, ctypes.c_void_p), _st(gW if gW is not None else gB)), "dwg_add_segments")
+            for flat, p in touched:
+                flat.touch(p)
+        return (None,) + tuple(out)
+
+
 class DeformNetwork(nn.Module):
     def __init__(self, xyz_input_ch=32, pose_input_ch=63, D=4, W=64, multires=10, residual=False, is_6dof=False):
         super().__init__()
@@ -267,13 +320,18 @@ class DeformNetwork(nn.Module):
         self.gaussian_scaling = nn.Linear(W, 3)
         self._head_cache = None
 
-    def forward(self, x, body_pose):
+    def forward(self, x, body_pose, packed=False):
+        """-> (warp, scaling, rotation) as the reference's DeformNetwork returns them, or -- `packed` -- the one [N, 10] tensor they are
+        column blocks of (assemble.assemble_packed reads the blocks in place)."""
         # the three heads share one 64 -> 10 product (warp 3 | scaling 3 | rotation 4)
         heads = (self.gaussian_warp, self.gaussian_scaling, self.gaussian_rotation)
         if torch.is_grad_enabled() or (x.is_cuda and torch.cuda.is_current_stream_capturing()):
             # (a captured frame re-runs the concatenation from the live parameters on every replay)
-            w = torch.cat([h.weight for h in heads], 0)
-            b = torch.cat([h.bias for h in heads], 0)
+            if x.is_cuda:
+                w, b = _PackRows.apply(3, *([h.weight for h in heads] + [h.bias for h in heads]))     # one launch; gradients straight into the flat slices
+            else:
+                w = torch.cat([h.weight for h in heads], 0)
+                b = torch.cat([h.bias for h in heads], 0)
         else:
             # inference: the concatenated head is kept while the six tensors are the ones it was built from (address, version counter and the
             # optimizers' write epoch -- the fused Adam writes parameters through a raw pointer): two launches fewer per frame
@@ -283,4 +341,4 @@ class DeformNetwork(nn.Module):
                 self._head_cache = (key, torch.cat([h.weight for h in heads], 0).detach(), torch.cat([h.bias for h in heads], 0).detach())
             w, b = self._head_cache[1], self._head_cache[2]
         o = mlp_chain(x, [(m.weight, m.bias) for m in self.layers] + [(w, b)], ["leaky_relu"] * self.D + [None], extra=body_pose)
-        return o[:, 0:3], o[:, 3:6], o[:, 6:10]
+        return o if packed else (o[:, 0:3], o[:, 3:6], o[:, 6:10])

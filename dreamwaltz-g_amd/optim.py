@@ -244,6 +244,13 @@ class FlatOptimizerDict(dict):
         for o in self.values():
             o.grad_scale = s
 
+    def zero_grad(self):
+        """`zero_grad()` of every named optimizer with ONE fill: their gradient ranges are disjoint pieces of the one flat buffer."""
+        self.buffers.grad.zero_()
+        self.buffers.tracking = False
+        for p in self.params:
+            p._dwg_touched = False
+
 
 def _group_ranges(specs: Dict[str, AdamSpec], buf: FlatBuffers) -> Dict[str, list]:
     """[start, end) of every param group inside the flat buffers (16-byte aligned ends), in the order the parameters were laid out."""

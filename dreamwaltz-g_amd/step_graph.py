@@ -197,8 +197,11 @@ class GraphedTrainStep:
     def _device_body(self):
         """The captured region."""
         tr = self.trainer
-        for o in tr.optimizers.values():
-            o.zero_grad()
+        if hasattr(tr.optimizers, "buffers") and hasattr(tr.optimizers, "zero_grad"):
+            tr.optimizers.zero_grad()                   # one fill of the flat gradient buffer for every named optimizer
+        else:
+            for o in tr.optimizers.values():
+                o.zero_grad()
         forced = {}
         if self.guided:
             forced = dict(posterior_noise=self._rand[0], timestep=self._rand[1], noise=self._rand[2])
@@ -210,7 +213,7 @@ class GraphedTrainStep:
             loss, render_outputs, _, _ = tr.train_forward(self.data, **forced)
         finally:
             tr._text_override = None
-        loss.backward()
+        tr._backward(loss)
         base = 0
         for o in tr.optimizers.values():
             base += o.launch_step(self.hyper_dev, base)

@@ -33,6 +33,7 @@ class SDSTrainer:
         self.redone_frames = 0
         self._view_rng = None
         self._view_streams, self._views_warm = [], False
+        self._unit = None
         self._cache_generation = getattr(getattr(model, "avatar", None), "cache_generation", None)
         self.past_checkpoints = []
         self.set_views(world)                       # one view per rank unless the caller says otherwise: mean of the summed gradients,
@@ -224,25 +225,40 @@ class SDSTrainer:
             sd_kwargs['cond_inputs'] = data['cond_images']
         sd_kwargs.update(forced)
         sd_outputs = self.diffusion(**sd_kwargs)
-        diffusion_loss = sd_outputs['diffusion_loss'] * self.cfg.guide.lambda_guidance
+        # (lambda_guidance == 1 and no regularizer on this path: the two element-wise launches `loss * 1 + 0` are not made; the value is the same)
+        lam = self.cfg.guide.lambda_guidance
+        diffusion_loss = sd_outputs['diffusion_loss'] if lam == 1 else sd_outputs['diffusion_loss'] * lam
         render_outputs['regularizations'] = {}
-        total_loss = 0.0
-        total_loss += diffusion_loss
+        total_loss = diffusion_loss
         return total_loss, render_outputs, sd_outputs, text
 
     def _begin_step(self, spatial_scale):
         """zero_grad + update_learning_rate on every optimizer (trainer.py:861-870).  The reference does this between the forward and the
         backward of its one view; nothing in a forward reads a gradient, so doing it first is the same step -- and it is what lets a
         multi-view step accumulate several backwards into the one flat gradient buffer."""
+        flat = hasattr(self.optimizers, "buffers") and hasattr(self.optimizers, "zero_grad")      # the package's own dict: one fill for all of them
+        if flat:
+            self.optimizers.zero_grad()
         for optimizer in self.optimizers.values():
-            optimizer.zero_grad()
+            if not flat:
+                optimizer.zero_grad()
             if hasattr(optimizer, 'update_learning_rate'):
                 optimizer.update_learning_rate(iteration=self.train_step_index, spatial_scale=spatial_scale)
 
     def _forward_backward(self, data, **forced):
         loss, render_outputs, sd_outputs, text = self.train_forward(data, **forced)
-        loss.backward()
+        self._backward(loss)
         return loss, render_outputs, sd_outputs, text
+
+    def _backward(self, loss):
+        """loss.backward() -- the seed gradient of a one-element loss is the constant 1: kept per (device, shape), not refilled by a launch
+        every step."""
+        if loss.numel() != 1 or loss.dtype != torch.float32:
+            return loss.backward()
+        key = (loss.device, tuple(loss.shape))
+        if self._unit is None or self._unit[0] != key:
+            self._unit = (key, torch.ones(loss.shape, device=loss.device))
+        loss.backward(gradient=self._unit[1])
 
     def _view(self, data, **forced):
         """Forward + backward of ONE view, accumulated into the flat gradient buffer.  Sync-free pair sizing: the rasterizer's backward
@@ -282,7 +298,7 @@ class SDSTrainer:
             renderer = getattr(self.model, "renderer", None)
             while True:
                 loss, outs, sd_outputs, names = self.train_forward_views(views, **forced)
-                loss.backward()
+                self._backward(loss)
                 if renderer is None or not renderer.consume_overflow():
                     break
                 self.redone_frames += 1         # a truncated frame contributed zeros, the others did not: start the step's gradient over
