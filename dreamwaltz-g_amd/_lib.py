@@ -25,6 +25,12 @@ class RasterSettingsC(ctypes.Structure):
     ]
 
 
+class AdamGroupC(ctypes.Structure):
+    """include/dwg_elementwise.h dwg_adam_group."""
+    _fields_ = [("param", ctypes.c_void_p), ("grad", ctypes.c_void_p), ("exp_avg", ctypes.c_void_p), ("exp_avg_sq", ctypes.c_void_p),
+                ("n", ctypes.c_int64), ("beta1", ctypes.c_float), ("beta2", ctypes.c_float), ("eps", ctypes.c_float), ("hyper_row", ctypes.c_int32)]
+
+
 class SegmentC(ctypes.Structure):
     """include/dwg_gaussian.h dwg_segment."""
     _fields_ = [("dst", ctypes.c_void_p), ("src", ctypes.c_void_p), ("count", ctypes.c_int64)]
@@ -90,6 +96,7 @@ SIGNATURES = {
                                               _vp, _vp, _i32, _vp, _vp]),
     "dwg_adam_step": (ctypes.c_int, [_i64, _vp, _vp, _vp, _vp, _f32, _f32, _f32, _f32, _i32, _f32, _vp]),
     "dwg_adam_step_dev": (ctypes.c_int, [_i64, _vp, _vp, _vp, _vp, _vp, _f32, _f32, _f32, _vp]),
+    "dwg_adam_step_groups_dev": (ctypes.c_int, [_i32, _vp, _vp, _vp]),
     # include/dwg_nn.h
     "dwg_groupnorm_forward": (ctypes.c_int, [_i32, _i32, _i32, _i32, _vp, _vp, _vp, _f32, _i32, _vp, _vp, _vp, _vp]),
     "dwg_groupnorm_backward": (ctypes.c_int, [_i32, _i32, _i32, _i32, _vp, _vp, _vp, _vp, _vp, _f32, _i32, _vp, _vp, _vp, _vp, _vp]),

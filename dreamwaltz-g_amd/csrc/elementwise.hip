@@ -104,6 +104,36 @@ __global__ __launch_bounds__(256) void k_adam(size_t n, float* __restrict__ p, c
     }
 }
 
+struct AdamGroups { dwg_adam_group g[DWG_ADAM_MAX_GROUPS]; };
+
+// k_adam for several parameter groups: blockIdx.y = group (groups shorter than the grid's x extent leave their surplus workgroups idle)
+__global__ __launch_bounds__(256) void k_adam_groups(AdamGroups G, const float* __restrict__ hyper) {
+    const dwg_adam_group a = G.g[blockIdx.y];
+    const size_t n = (size_t)a.n, n4 = n / 4;
+    size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= n4 && n4 * 4 + i >= n) return;
+    const size_t stride = (size_t)gridDim.x * 256;
+    float* __restrict__ p = a.param; const float* __restrict__ g = a.grad; float* __restrict__ m = a.exp_avg; float* __restrict__ v = a.exp_avg_sq;
+    float4* p4 = reinterpret_cast<float4*>(p); const float4* g4 = reinterpret_cast<const float4*>(g);
+    float4* m4 = reinterpret_cast<float4*>(m); float4* v4 = reinterpret_cast<float4*>(v);
+    const float* h = hyper + 4 * (size_t)a.hyper_row;
+    const float step = h[0], bc2_sqrt = h[1], grad_scale = h[2], b1 = a.beta1, b2 = a.beta2, eps = a.eps;
+    for (size_t k = i; k < n4; k += stride) {
+        float4 pp = p4[k], gg = g4[k], mm = m4[k], vv = v4[k];
+#define UPD(c) { float gr = gg.c * grad_scale; mm.c = b1 * mm.c + (1.f - b1) * gr; vv.c = b2 * vv.c + (1.f - b2) * gr * gr; \
+                 pp.c -= step * mm.c / (sqrtf(vv.c) / bc2_sqrt + eps); }
+        UPD(x) UPD(y) UPD(z) UPD(w)
+#undef UPD
+        p4[k] = pp; m4[k] = mm; v4[k] = vv;
+    }
+    for (size_t k = n4 * 4 + i; k < n; k += stride) {
+        float gr = g[k] * grad_scale;
+        float mm = b1 * m[k] + (1.f - b1) * gr, vv = b2 * v[k] + (1.f - b2) * gr * gr;
+        m[k] = mm; v[k] = vv;
+        p[k] -= step * mm / (sqrtf(vv) / bc2_sqrt + eps);
+    }
+}
+
 // dW[n][k] = sum_m dz[m][n] * x[m][k]  for the per-Gaussian MLPs (N, K <= 64, M ~ 1e5): every workgroup reduces a slab of
 // rows into a 64x64 tile (exact-f32 MFMA, one 32x32 quadrant per wave) from LDS-staged 64-row chunks and writes ONE partial tile; a second
 // pass sums the partial tiles in a fixed order (deterministic, no atomics).
@@ -1079,6 +1109,29 @@ int dwg_adam_step_dev(int64_t n, float* param, const float* grad, float* exp_avg
     if (blocks > 2048) blocks = 2048;
     DWG_LAUNCH("adam_step", k_adam, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, (size_t)n, param, grad, exp_avg,
                exp_avg_sq, 0.f, beta1, beta2, eps, 1.f, 1.f, 1.f, hyper);
+    DWG_RETURN_IF_LAUNCH_FAILED();
+    return DWG_OK;
+}
+
+int dwg_adam_step_groups_dev(int32_t count, const dwg_adam_group* groups, const float* hyper, dwg_stream_t stream) {
+    if (count < 0 || count > DWG_ADAM_MAX_GROUPS || !hyper || (count > 0 && !groups)) return DWG_E_ARG;
+    AdamGroups G;
+    size_t blocks = 0;
+    int used = 0;
+    for (int i = 0; i < count; i++) {
+        const dwg_adam_group& a = groups[i];
+        if (a.n < 0 || a.hyper_row < 0) return DWG_E_ARG;
+        if (a.n == 0) continue;
+        if (!a.param || !a.grad || !a.exp_avg || !a.exp_avg_sq) return DWG_E_ARG;
+        if (((uintptr_t)a.param | (uintptr_t)a.grad | (uintptr_t)a.exp_avg | (uintptr_t)a.exp_avg_sq) % 16) return DWG_E_ARG;
+        G.g[used++] = a;
+        size_t b = ((size_t)a.n / 4 + 255) / 256;
+        if (b < 1) b = 1;
+        blocks = b > blocks ? b : blocks;
+    }
+    if (used == 0) return DWG_OK;
+    if (blocks > 2048) blocks = 2048;
+    DWG_LAUNCH("adam_step", k_adam_groups, dim3((unsigned)blocks, used), dim3(256), 0, (hipStream_t)stream, G, hyper);
     DWG_RETURN_IF_LAUNCH_FAILED();
     return DWG_OK;
 }

@@ -244,6 +244,30 @@ class FlatOptimizerDict(dict):
         for o in self.values():
             o.grad_scale = s
 
+    def launch_steps(self, hyper_dev: torch.Tensor):
+        """DEVICE half of every named optimizer's step in ONE launch (dwg_adam_step_groups_dev): group k of the dict's k-th optimizer reads
+        the row `FlatOptimizer.prepare_step` filled for it (rows are handed out in dict order, as step_graph does).  Falls back to one launch
+        per group beyond DWG_ADAM_MAX_GROUPS groups."""
+        b = self.buffers
+        groups, base = [], 0
+        for o in self.values():
+            for k, pg in enumerate(o.param_groups):
+                n, off = pg["end"] - pg["start"], pg["start"] * 4
+                if n > 0:
+                    groups.append(_lib.AdamGroupC(b.flat.data_ptr() + off, b.grad.data_ptr() + off, b.m.data_ptr() + off, b.v.data_ptr() + off, n,
+                                                  float(pg["betas"][0]), float(pg["betas"][1]), float(pg["eps"]), base + k))
+            base += len(o.param_groups)
+        if len(groups) > 16:
+            base = 0
+            for o in self.values():
+                base += o.launch_step(hyper_dev, base)
+            return base
+        arr = (_lib.AdamGroupC * max(len(groups), 1))(*groups)
+        st = ctypes.c_void_p(torch.cuda.current_stream(b.flat.device).cuda_stream)
+        _lib.check(_lib.lib().dwg_adam_step_groups_dev(len(groups), ctypes.cast(arr, ctypes.c_void_p), ctypes.c_void_p(hyper_dev.data_ptr()), st),
+                   "dwg_adam_step_groups_dev")
+        return base
+
     def zero_grad(self):
         """`zero_grad()` of every named optimizer with ONE fill: their gradient ranges are disjoint pieces of the one flat buffer."""
         self.buffers.grad.zero_()

@@ -214,9 +214,12 @@ class GraphedTrainStep:
         finally:
             tr._text_override = None
         tr._backward(loss)
-        base = 0
-        for o in tr.optimizers.values():
-            base += o.launch_step(self.hyper_dev, base)
+        if hasattr(tr.optimizers, "launch_steps"):
+            tr.optimizers.launch_steps(self.hyper_dev)          # every group of every named optimizer: one fused Adam launch
+        else:
+            base = 0
+            for o in tr.optimizers.values():
+                base += o.launch_step(self.hyper_dev, base)
         return loss, render_outputs
 
     def _eager_step(self):

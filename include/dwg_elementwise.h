@@ -67,6 +67,18 @@ int dwg_adam_step(int64_t n, float* param, const float* grad, float* exp_avg, fl
 int dwg_adam_step_dev(int64_t n, float* param, const float* grad, float* exp_avg, float* exp_avg_sq, const float* hyper, float beta1,
                       float beta2, float eps, dwg_stream_t stream);
 
+/* dwg_adam_step_dev for up to DWG_ADAM_MAX_GROUPS parameter groups in ONE launch (the captured step steps every group of every named
+ * optimizer at its end: eight launches of a few microseconds each before): group g updates its n floats with its own betas / eps and the
+ * scalars of row `hyper_row` of the device table hyper[rows][4].  Same arithmetic per element as dwg_adam_step_dev. */
+#define DWG_ADAM_MAX_GROUPS 16
+typedef struct dwg_adam_group {
+    float* param; const float* grad; float* exp_avg; float* exp_avg_sq;
+    int64_t n;
+    float beta1, beta2, eps;
+    int32_t hyper_row;
+} dwg_adam_group;
+int dwg_adam_step_groups_dev(int32_t count, const dwg_adam_group* groups, const float* hyper, dwg_stream_t stream);
+
 /* NHWC channel concat (torch.cat([h, skip], 1) of the UNet up blocks): out[r] = [a[r] | b[r]], bf16, Ca % 8 == Cb % 8 == 0. */
 int dwg_concat_channels(int64_t rows, int32_t Ca, int32_t Cb, const void* a, const void* b, void* out, dwg_stream_t stream);
 /* out = a + b on bf16 buffers (n % 8 == 0): gradient joins of the VAE-encoder backward. */

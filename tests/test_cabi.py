@@ -97,7 +97,8 @@ def test_ctypes_structures_have_the_layout_of_the_c_headers(tmp_path):
     """The structs that cross the C-ABI by pointer: the ctypes mirrors must agree with include/*.h field for field."""
     from dreamwaltz_g_amd import gemm
     for header, struct, mirror in (("dwg_raster.h", "dwg_raster_settings", _lib.RasterSettingsC), ("dwg_raster.h", "dwg_raster_frames", _lib.RasterFramesC),
-                                   ("dwg_gemm.h", "dwg_gemm_desc", gemm.GemmDesc), ("dwg_gaussian.h", "dwg_segment", _lib.SegmentC)):
+                                   ("dwg_gemm.h", "dwg_gemm_desc", gemm.GemmDesc), ("dwg_gaussian.h", "dwg_segment", _lib.SegmentC),
+                                   ("dwg_elementwise.h", "dwg_adam_group", _lib.AdamGroupC)):
         names = [f[0] for f in mirror._fields_]
         size, offsets = _c_struct_layout(header, struct, names, tmp_path)        # a field the header lacks fails to compile
         assert size == ctypes.sizeof(mirror), (struct, size, ctypes.sizeof(mirror))
