@@ -1853,7 +1853,14 @@ int DWG_GEMM_FN(const dwg_gemm_desc* d, dwg_stream_t stream_) {
             if (sk > 1) p.ws = reinterpret_cast<float*>(d->workspace);
         }
     }
-    p.conv.enabled = d->conv_enabled;
+    // A 1 x 1 / stride 1 / unpadded convolution over NHWC rows IS the plain product of the [M, Cin] row matrix: it takes the plain-row loader
+    // (no per-stage pixel arithmetic), DWG_CONV1X1_PLAIN=0: the convolution loader as before
+    static const bool conv1x1_plain = !(getenv("DWG_CONV1X1_PLAIN") && atoi(getenv("DWG_CONV1X1_PLAIN")) == 0);
+    const bool plain1x1 = conv1x1_plain && d->conv_enabled && d->conv_kh == 1 && d->conv_kw == 1 && d->conv_stride == 1 && d->conv_pad_t == 0 &&
+                          d->conv_pad_l == 0 && d->conv_in_dilation <= 1 && d->conv_in_upsample <= 1 && !d->A2 && d->conv_hout == d->conv_hin &&
+                          d->conv_wout == d->conv_win && d->K == d->conv_cin && d->batch1 * d->batch2 == 1;
+    if (plain1x1) { p.sam = d->conv_cin; p.sak = 1; }
+    p.conv.enabled = d->conv_enabled && !plain1x1;
     p.conv.Cin = d->conv_cin; p.conv.Hin = d->conv_hin; p.conv.Win = d->conv_win; p.conv.Hout = d->conv_hout;
     p.conv.Wout = d->conv_wout; p.conv.KH = d->conv_kh; p.conv.KW = d->conv_kw; p.conv.stride = d->conv_stride;
     p.conv.pad_t = d->conv_pad_t; p.conv.pad_l = d->conv_pad_l; p.conv.dil = d->conv_in_dilation > 1 ? d->conv_in_dilation : 1;
@@ -1874,7 +1881,7 @@ int DWG_GEMM_FN(const dwg_gemm_desc* d, dwg_stream_t stream_) {
         typedef HT T;
         int amode, bmode;
         long long ao[2] = {p.bA1, p.bA2}, bo[2] = {p.bB1, p.bB2};
-        if (d->conv_enabled) {
+        if (d->conv_enabled && !plain1x1) {
             if (d->conv_cin % 8 != 0 || ((uintptr_t)d->A % 16) != 0) return DWG_E_ARG;
             if (d->A2 && (d->conv_cin1 % 8 != 0 || d->conv_cin1 <= 0 || d->conv_cin1 >= d->conv_cin || ((uintptr_t)d->A2 % 16) != 0))
                 return DWG_E_ARG;
@@ -1999,7 +2006,7 @@ int DWG_GEMM_FN(const dwg_gemm_desc* d, dwg_stream_t stream_) {
         typedef float T;
         long long ao[2] = {p.bA1, p.bA2}, bo[2] = {p.bB1, p.bB2};
         int amode;
-        if (d->conv_enabled) {
+        if (d->conv_enabled && !plain1x1) {
             if (d->conv_cin % 4 != 0 || ((uintptr_t)d->A % 16) != 0) return DWG_E_ARG;
             if (d->A2 && (d->conv_cin1 % 4 != 0 || d->conv_cin1 <= 0 || d->conv_cin1 >= d->conv_cin || ((uintptr_t)d->A2 % 16) != 0))
                 return DWG_E_ARG;
