@@ -6,7 +6,7 @@ set -u
 R=${1:-r05}
 COMMIT=${2:-unknown}
 # DWG_PROFILE_PARTS: which passes to run (default all): eager graph pmc bench
-PARTS=${DWG_PROFILE_PARTS:-"eager graph pmc sq bench small calib"}
+PARTS=${DWG_PROFILE_PARTS:-"eager graph pmc sq bench small calib parity"}
 has() { case " $PARTS " in *" $1 "*) return 0;; *) return 1;; esac; }
 REPO=$(cd "$(dirname "$0")/.." && pwd)
 OUT=$REPO/gpurun_out/prof_$R
@@ -52,6 +52,14 @@ T0=$(date +%s); timeout 900 python bench.py > $OUT/bench_default.log 2>&1; echo 
 fi
 has calib && bash tools/calib_fetch.sh $R > $OUT/calib.log 2>&1
 has calib && tail -20 $OUT/calib.log
+# parity records at HEAD (round-5 verdict, weak #3): the parity tests write per-case max / q99.9 / threshold-flip counts / gradient rel-L2 to
+# gpurun_out/parity_*.json; the round's copies are what profiles/ keeps
+if has parity; then
+rm -f gpurun_out/parity_*.json
+timeout 1500 python -m pytest tests/test_raster_gpu.py tests/test_baseline_configs_gpu.py tests/test_sd15_f32x_gpu.py tests/test_sd15_fp32_gpu.py tests/test_sd15_fp16_gpu.py tests/test_sd15_full_width_gpu.py tests/test_golden_r2_gpu.py tests/test_sds_step_gpu.py tests/test_guidance_gpu.py -q -m gpu > $OUT/parity_tests.log 2>&1
+tail -3 $OUT/parity_tests.log
+for f in gpurun_out/parity_*.json; do [ -f "$f" ] && cp "$f" profiles/${R}_$(basename $f); done
+fi
 # large raw traces stay on the box
 find $OUT -name "*kernel_trace.csv" -size +8M -delete; find $OUT -name "*counter_collection.csv" -size +8M -delete; find $OUT -name "*.db" -delete
 mkdir -p gpurun_out/profiles_$R && cp profiles/${R}_* gpurun_out/profiles_$R/
