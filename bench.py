@@ -711,7 +711,6 @@ def flat_scalars(out, cfgs, by):
         "c2_raster_fwd_frac": g(cfgs, "c2", "roofline", "raster_forward", "frac_of_hbm_peak"),
         "c2_raster_bwd_frac": g(cfgs, "c2", "roofline", "raster_backward", "frac_of_hbm_peak"),
         "c3_steps_per_s_bound_loop": g(cfgs, "c3_bound_loop", "value"),
-        "c3_bound_loop_steps_per_s": g(cfgs, "c3_bound_loop", "value"), "c2_bound_loop_steps_per_s": g(cfgs, "c2_bound_loop", "value"),
         "c4_n1_views_per_s": g(cfgs, "c4_n1", "views_per_s"), "c4_n1_sequential_views_per_s": g(cfgs, "c4_n1_sequential_views", "views_per_s"),
         "c4_n1_raster_fwd_frac_per_view": g(cfgs, "c4_n1", "roofline", "raster_forward", "frac_of_hbm_peak"),
         "c4_n1_raster_bwd_frac_per_view": g(cfgs, "c4_n1", "roofline", "raster_backward", "frac_of_hbm_peak"),

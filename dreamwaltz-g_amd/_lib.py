@@ -66,6 +66,8 @@ SIGNATURES = {
     "dwg_lbs_blend_backward": (ctypes.c_int, [_i32] + [_vp] * 7 + [_vp]),
     "dwg_lbs_vertex_transform": (ctypes.c_int, [_i32] * 4 + [_vp] * 8 + [_vp]),
     "dwg_lbs_vertex_transform_backward_shape": (ctypes.c_int, [_i32] * 3 + [_vp] * 9 + [_vp]),
+    "dwg_lbs_vertex_transform_backward_shape_ws": (ctypes.c_int, [_i32] * 3 + [_vp] * 10 + [_vp]),
+    "dwg_lbs_vertex_transform_backward_shape_workspace_floats": (ctypes.c_size_t, [_i32]),
     # include/dwg_gridenc.h
     "dwg_grid_encode_forward": (ctypes.c_int, [_vp, _vp, _vp, _vp, _u32, _u32, _u32, _u32, _f32, _u32, _vp, _u32, _u32, _u32,
                                                _u32, _vp]),
@@ -145,6 +147,7 @@ SIGNATURES = {
     "dwg_meshbind_forward": (ctypes.c_int, [_i32, _i32, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
     "dwg_meshbind_backward": (ctypes.c_int, [_i32, _i32, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
     "dwg_meshbind_backward_verts": (ctypes.c_int, [_i32, _i32] + [_vp] * 15 + [_vp]),
+    "dwg_meshbind_backward_verts_gather": (ctypes.c_int, [_i32, _i32, _i32] + [_vp] * 18 + [_vp]),
     "dwg_mesh_vertex_normals_backward": (ctypes.c_int, [_i32, _i32] + [_vp] * 8 + [_vp]),
     # include/dwg_condition.h
     "dwg_condition_keypoints": (ctypes.c_int, [_i32, _vp, _vp, _vp, _i32, _vp, _i32, _vp, _vp, ctypes.c_float, ctypes.c_float,

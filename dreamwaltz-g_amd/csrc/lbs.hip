@@ -207,25 +207,25 @@ __global__ __launch_bounds__(256) void k_vertex_transform(int Vp, int J, int S, 
 
 // Backward of k_vertex_transform w.r.t. the shape coefficients (and the translation column of A): for a fixed pose the
 // transformed vertex is LINEAR in the coefficients,  v' = sum_j w_vj [Rg_j (x + S_v beta + P_v) + t_j(beta)],  so
-//   g_shape[l] += sum_v  S_v[:, l] . (T_v[:3,:3]^T g_v)            (this kernel, first term)
-//   g_At[j]    += sum_v  w_vj g_v                                  (this kernel; chained to beta by k_joint_chain_bwd)
-// Grid-stride over vertices, one wave per vertex; each lane keeps its coefficients' partial sums in registers, the block
-// combines its waves in LDS and issues one global atomic per coefficient.
+//   g_shape[l] = sum_v  S_v[:, l] . (T_v[:3,:3]^T g_v)            (this kernel, first term)
+//   g_At[j]    = sum_v  w_vj g_v                                  (this kernel; chained to beta by k_joint_chain_bwd)
+// No float atomics (round 6; `learn_hand_betas` is ON in sub-stage 2.1 of the shipped recipe, scripts/train_w_expr.sh:66): a wave walks its
+// vertices in a fixed order and every lane keeps ITS coefficients' and ITS joints' sums in registers (lane l owns coefficients l + 64 u and
+// joints l + 64 q); the workgroup adds its four waves' sums in wave order and writes ONE row of partials; k_vertex_transform_bwd_reduce adds
+// the workgroups' rows in workgroup order.  The same bits on every run.
 #define MAXS_PER_LANE 8          // S <= 512 shape coefficients
+#define VTB_ROW (64 * MAXS_PER_LANE + MAXJ * 3)
 __global__ __launch_bounds__(256) void k_vertex_transform_bwd(int Vp, int J, int S, const float* __restrict__ A,
                                                               const float* __restrict__ w_sub, const float* __restrict__ sdirs,
                                                               const float* __restrict__ g_out /*[Vp,3]*/,
-                                                              float* __restrict__ g_shape /*[S] accumulate*/,
-                                                              float* __restrict__ g_At /*[J,3] accumulate*/) {
+                                                              float* __restrict__ part /*[gridDim.x][VTB_ROW]*/) {
     __shared__ float sA[MAXJ * 12];
-    __shared__ float sS[512];
-    __shared__ float sT[MAXJ * 3];
+    __shared__ float sW[4][VTB_ROW];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     for (int k = tid; k < J * 12; k += 256) { int j = k / 12, e = k - j * 12; sA[k] = A[16 * j + e]; }
-    for (int k = tid; k < 512; k += 256) sS[k] = 0.f;
-    for (int k = tid; k < MAXJ * 3; k += 256) sT[k] = 0.f;
     __syncthreads();
-    float acc[MAXS_PER_LANE];
+    float acc[MAXS_PER_LANE], accT[3] = {0.f, 0.f, 0.f};       // (MAXJ == 64: one joint per lane)
+    static_assert(MAXJ <= 64, "a lane owns one joint");
 #pragma unroll
     for (int u = 0; u < MAXS_PER_LANE; u++) acc[u] = 0.f;
     for (int t = blockIdx.x * 4 + wave; t < Vp; t += gridDim.x * 4) {
@@ -234,13 +234,13 @@ __global__ __launch_bounds__(256) void k_vertex_transform_bwd(int Vp, int J, int
         for (int e = 0; e < 9; e++) R[e] = 0.f;
         const float* wr = w_sub + (size_t)t * J;
         const float g0 = g_out[3 * t], g1 = g_out[3 * t + 1], g2 = g_out[3 * t + 2];
-        for (int j = lane; j < J; j += 64) {
-            const float wj = wr[j];
+        if (lane < J) {
+            const float wj = wr[lane];
 #pragma unroll
             for (int r = 0; r < 3; r++)
 #pragma unroll
-                for (int c = 0; c < 3; c++) R[3 * r + c] += wj * sA[j * 12 + 4 * r + c];
-            atomicAdd(&sT[3 * j], wj * g0); atomicAdd(&sT[3 * j + 1], wj * g1); atomicAdd(&sT[3 * j + 2], wj * g2);
+                for (int c = 0; c < 3; c++) R[3 * r + c] = wj * sA[lane * 12 + 4 * r + c];
+            accT[0] += wj * g0; accT[1] += wj * g1; accT[2] += wj * g2;
         }
 #pragma unroll
         for (int e = 0; e < 9; e++) R[e] = dwg_wave_sum_all(R[e]);
@@ -255,13 +255,22 @@ __global__ __launch_bounds__(256) void k_vertex_transform_bwd(int Vp, int J, int
         }
     }
 #pragma unroll
-    for (int u = 0; u < MAXS_PER_LANE; u++) {
-        const int l = lane + 64 * u;
-        if (l < S) atomicAdd(&sS[l], acc[u]);
-    }
+    for (int u = 0; u < MAXS_PER_LANE; u++) sW[wave][lane + 64 * u] = acc[u];
+#pragma unroll
+    for (int c = 0; c < 3; c++) sW[wave][64 * MAXS_PER_LANE + 3 * lane + c] = accT[c];
     __syncthreads();
-    for (int l = tid; l < S; l += 256) if (sS[l] != 0.f) atomicAdd(&g_shape[l], sS[l]);
-    for (int k = tid; k < J * 3; k += 256) if (sT[k] != 0.f) atomicAdd(&g_At[k], sT[k]);
+    for (int k = tid; k < VTB_ROW; k += 256) part[(size_t)blockIdx.x * VTB_ROW + k] = ((sW[0][k] + sW[1][k]) + sW[2][k]) + sW[3][k];
+}
+
+// g_shape[l] = sum over the workgroups' partial rows, in workgroup order; likewise g_At.  (both OVERWRITTEN)
+__global__ __launch_bounds__(256) void k_vertex_transform_bwd_reduce(int nblocks, int J, int S, const float* __restrict__ part,
+                                                                     float* __restrict__ g_shape, float* __restrict__ g_At) {
+    const int k = blockIdx.x * 256 + threadIdx.x;
+    if (k >= S + 3 * J) return;
+    const int col = k < S ? k : 64 * MAXS_PER_LANE + (k - S);
+    float v = 0.f;
+    for (int b = 0; b < nblocks; b++) v += part[(size_t)b * VTB_ROW + col];
+    if (k < S) g_shape[k] = v; else g_At[k - S] = v;
 }
 
 // d loss / d A[:, :3, 3] -> d loss / d shape through the rest joints (one workgroup; the 55-joint chain is serial by nature and
@@ -352,25 +361,54 @@ int dwg_lbs_vertex_transform(int32_t Vp, int32_t J, int32_t n_shape, int32_t n_p
     return DWG_OK;
 }
 
-int dwg_lbs_vertex_transform_backward_shape(int32_t Vp, int32_t J, int32_t n_shape, const float* A, const float* lbs_weights_sub,
-                                            const float* shapedirs_sub, const float* g_out, const float* pose, const int32_t* parents,
-                                            const float* joint_shape_dirs, float* g_A_transl_scratch, float* g_shape,
-                                            dwg_stream_t stream_) {
+size_t dwg_lbs_vertex_transform_backward_shape_workspace_floats(int32_t Vp) {
+    int blocks = dwg_cdiv(Vp > 0 ? Vp : 1, 4); if (blocks > 64) blocks = 64;
+    return (size_t)blocks * VTB_ROW;
+}
+
+int dwg_lbs_vertex_transform_backward_shape_ws(int32_t Vp, int32_t J, int32_t n_shape, const float* A, const float* lbs_weights_sub,
+                                               const float* shapedirs_sub, const float* g_out, const float* pose, const int32_t* parents,
+                                               const float* joint_shape_dirs, float* g_A_transl_scratch, float* g_shape, float* workspace,
+                                               dwg_stream_t stream_) {
     if (Vp < 0 || J <= 0 || J > MAXJ || n_shape <= 0 || n_shape > 64 * MAXS_PER_LANE) return DWG_E_ARG;
     if (!A || !lbs_weights_sub || !shapedirs_sub || !g_out || !pose || !parents || !joint_shape_dirs || !g_A_transl_scratch || !g_shape)
         return DWG_E_ARG;
     hipStream_t stream = (hipStream_t)stream_;
-    if (hipMemsetAsync(g_shape, 0, sizeof(float) * (size_t)n_shape, stream) != hipSuccess) return DWG_E_LAUNCH;
-    if (hipMemsetAsync(g_A_transl_scratch, 0, sizeof(float) * 3 * (size_t)J, stream) != hipSuccess) return DWG_E_LAUNCH;
-    if (Vp > 0) {
-        int blocks = dwg_cdiv(Vp, 4); if (blocks > 64) blocks = 64;
-        DWG_LAUNCH("lbs_vertex_transform_bwd", k_vertex_transform_bwd, dim3(blocks), dim3(256), 0, stream, Vp, J, n_shape, A, lbs_weights_sub,
-                   shapedirs_sub, g_out, g_shape, g_A_transl_scratch);
-        DWG_LAUNCH("lbs_joint_chain_bwd", k_joint_chain_bwd, dim3(1), dim3(256), 0, stream, J, pose, parents, joint_shape_dirs, n_shape,
-                   (const float*)g_A_transl_scratch, g_shape);
+    if (Vp == 0) {
+        if (hipMemsetAsync(g_shape, 0, sizeof(float) * (size_t)n_shape, stream) != hipSuccess) return DWG_E_LAUNCH;
+        return DWG_OK;
     }
+    if (!workspace) return DWG_E_ARG;          // up to 64 workgroups, one row of partial sums each
+    int blocks = dwg_cdiv(Vp, 4); if (blocks > 64) blocks = 64;
+    DWG_LAUNCH("lbs_vertex_transform_bwd", k_vertex_transform_bwd, dim3(blocks), dim3(256), 0, stream, Vp, J, n_shape, A, lbs_weights_sub,
+               shapedirs_sub, g_out, workspace);
+    DWG_LAUNCH("lbs_vertex_transform_bwd_reduce", k_vertex_transform_bwd_reduce, dim3(dwg_cdiv(n_shape + 3 * J, 256)), dim3(256), 0, stream, blocks, J,
+               n_shape, (const float*)workspace, g_shape, g_A_transl_scratch);
+    DWG_LAUNCH("lbs_joint_chain_bwd", k_joint_chain_bwd, dim3(1), dim3(256), 0, stream, J, pose, parents, joint_shape_dirs, n_shape,
+               (const float*)g_A_transl_scratch, g_shape);
     DWG_RETURN_IF_LAUNCH_FAILED();
     return DWG_OK;
+}
+
+int dwg_lbs_vertex_transform_backward_shape(int32_t Vp, int32_t J, int32_t n_shape, const float* A, const float* lbs_weights_sub,
+                                            const float* shapedirs_sub, const float* g_out, const float* pose, const int32_t* parents,
+                                            const float* joint_shape_dirs, float* g_A_transl_scratch, float* g_shape,
+                                            dwg_stream_t stream_) {
+    // The entry point without a workspace argument keeps ONE library-owned row block per device (64 rows, 180 KB): calls on different
+    // streams of one device would share it, so they are serialised against each other by an event (this form exists for C callers of
+    // the round-2 signature; the Python path passes its own workspace to the _ws form).
+    static float* ws = nullptr;
+    static hipEvent_t done = nullptr;
+    if (!ws) {
+        if (hipMalloc(&ws, sizeof(float) * 64 * VTB_ROW) != hipSuccess) return DWG_E_LAUNCH;
+        if (hipEventCreateWithFlags(&done, hipEventDisableTiming) != hipSuccess) return DWG_E_LAUNCH;
+        hipEventRecord(done, (hipStream_t)stream_);
+    }
+    if (hipStreamWaitEvent((hipStream_t)stream_, done, 0) != hipSuccess) return DWG_E_LAUNCH;
+    const int rc = dwg_lbs_vertex_transform_backward_shape_ws(Vp, J, n_shape, A, lbs_weights_sub, shapedirs_sub, g_out, pose, parents,
+                                                               joint_shape_dirs, g_A_transl_scratch, g_shape, ws, stream_);
+    hipEventRecord(done, (hipStream_t)stream_);
+    return rc;
 }
 
 }  // extern "C"

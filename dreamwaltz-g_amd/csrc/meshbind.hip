@@ -76,7 +76,8 @@ __global__ __launch_bounds__(256) void k_meshbind_bwd(int M, int n_per, const fl
                                                       const float* __restrict__ g_scl, const float* __restrict__ g_quat,
                                                       float* __restrict__ g_bary, float* __restrict__ g_sc,
                                                       float* __restrict__ g_vc /*[Vp,3] accumulate | null*/,
-                                                      float* __restrict__ g_vo, float* __restrict__ g_vn) {
+                                                      float* __restrict__ g_vo, float* __restrict__ g_vn,
+                                                      float* __restrict__ corner /*[M][3][9] | null: per-(Gaussian, corner) rows {gP, gN, gPc} instead of the atomics*/) {
     const int i = blockIdx.x * 256 + threadIdx.x;
     if (i >= M) return;
     const int* t = tri + 3 * (size_t)(i / n_per);
@@ -90,9 +91,18 @@ __global__ __launch_bounds__(256) void k_meshbind_bwd(int M, int n_per, const fl
     if (g_quat) { gq[0] = g_quat[4 * (size_t)i]; gq[1] = g_quat[4 * (size_t)i + 1]; gq[2] = g_quat[4 * (size_t)i + 2]; gq[3] = g_quat[4 * (size_t)i + 3]; }
     float gb[3] = {0.f, 0.f, 0.f}, gsc[3];
     float gP[3][3] = {{0.f, 0.f, 0.f}, {0.f, 0.f, 0.f}, {0.f, 0.f, 0.f}}, gN[3][3] = {{0.f, 0.f, 0.f}, {0.f, 0.f, 0.f}, {0.f, 0.f, 0.f}};
-    const bool want_v = g_vo != nullptr;
+    const bool want_v = g_vo != nullptr || corner != nullptr;
     dwg_meshbind_point_bwd(b, s, P, N, (float)n_per, gp, gs, gq, gb, gsc, want_v ? gP : nullptr, want_v ? gN : nullptr);
-    if (want_v) {
+    if (corner) {
+#pragma unroll
+        for (int v = 0; v < 3; v++)
+#pragma unroll
+            for (int c = 0; c < 3; c++) {
+                corner[((size_t)i * 3 + v) * 9 + c] = gP[v][c];
+                corner[((size_t)i * 3 + v) * 9 + 3 + c] = gN[v][c];
+                corner[((size_t)i * 3 + v) * 9 + 6 + c] = 0.f;
+            }
+    } else if (want_v) {
 #pragma unroll
         for (int v = 0; v < 3; v++)
 #pragma unroll
@@ -105,8 +115,13 @@ __global__ __launch_bounds__(256) void k_meshbind_bwd(int M, int n_per, const fl
         gather3(vc, t, P);
         const float gc[3] = {g_pos_c[3 * (size_t)i], g_pos_c[3 * (size_t)i + 1], g_pos_c[3 * (size_t)i + 2]};
         float gPc[3][3] = {{0.f, 0.f, 0.f}, {0.f, 0.f, 0.f}, {0.f, 0.f, 0.f}};
-        dwg_meshbind_position_bwd(b, P, gc, gb, g_vc ? gPc : nullptr);
-        if (g_vc) {
+        dwg_meshbind_position_bwd(b, P, gc, gb, (g_vc || corner) ? gPc : nullptr);
+        if (corner) {
+#pragma unroll
+            for (int v = 0; v < 3; v++)
+#pragma unroll
+                for (int c = 0; c < 3; c++) corner[((size_t)i * 3 + v) * 9 + 6 + c] = gPc[v][c];
+        } else if (g_vc) {
 #pragma unroll
             for (int v = 0; v < 3; v++)
 #pragma unroll
@@ -157,6 +172,70 @@ __global__ __launch_bounds__(256) void k_face_normals_bwd(int Fp, const float* _
     }
 }
 
+// True iff entry e of vertex v's incident-face list names a face that an EARLIER entry of the list already named (a face listing a vertex
+// twice): its corners were added then.
+__device__ __forceinline__ bool mb_seen_before(const int* __restrict__ vf_faces, int e0, int e) {
+    for (int q = e0; q < e; q++) if (vf_faces[q] == vf_faces[e]) return true;
+    return false;
+}
+
+// g_vo / g_vn / g_vc of vertex v = the rows of the Gaussians on its incident faces at the corner that IS v, added in list order (faces as the
+// incident-face table lists them, Gaussians of a face in index order): one thread per vertex, no atomics, the same bits on every run.
+__global__ __launch_bounds__(256) void k_meshbind_gather_verts(int Vp, int n_per, const int* __restrict__ tri, const int* __restrict__ vf_off,
+                                                               const int* __restrict__ vf_faces, const float* __restrict__ corner,
+                                                               float* __restrict__ g_vc, float* __restrict__ g_vo, float* __restrict__ g_vn) {
+    const int v = blockIdx.x * 256 + threadIdx.x;
+    if (v >= Vp) return;
+    float a[9] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+    const int e0 = vf_off[v], e1 = vf_off[v + 1];
+    for (int e = e0; e < e1; e++) {
+        if (mb_seen_before(vf_faces, e0, e)) continue;
+        const int f = vf_faces[e];
+        for (int c = 0; c < 3; c++) {
+            if (tri[3 * (size_t)f + c] != v) continue;
+            for (int k = 0; k < n_per; k++) {
+                const float* r = corner + (((size_t)f * n_per + k) * 3 + c) * 9;
+#pragma unroll
+                for (int q = 0; q < 9; q++) a[q] += r[q];
+            }
+        }
+    }
+#pragma unroll
+    for (int q = 0; q < 3; q++) {
+        g_vo[3 * (size_t)v + q] = a[q]; g_vn[3 * (size_t)v + q] = a[3 + q];
+        if (g_vc) g_vc[3 * (size_t)v + q] = a[6 + q];
+    }
+}
+
+// k_face_normals_bwd as a gather: vertex v adds, in list order, the corner gradients of its incident faces (a face's three corner gradients
+// are recomputed by each of its corners' threads: a few thousand faces).  g_verts is ACCUMULATED into (one thread per vertex: no race).
+__global__ __launch_bounds__(256) void k_face_normals_bwd_gather(int Vp, const float* __restrict__ verts, const int* __restrict__ tri,
+                                                                 const int* __restrict__ vf_off, const int* __restrict__ vf_faces,
+                                                                 const float* __restrict__ g_s, float* __restrict__ g_verts) {
+    const int v = blockIdx.x * 256 + threadIdx.x;
+    if (v >= Vp) return;
+    float acc[3] = {0.f, 0.f, 0.f};
+    const int e0 = vf_off[v], e1 = vf_off[v + 1];
+    for (int e = e0; e < e1; e++) {
+        if (mb_seen_before(vf_faces, e0, e)) continue;
+        const int f = vf_faces[e];
+        const int idx[3] = {tri[3 * (size_t)f], tri[3 * (size_t)f + 1], tri[3 * (size_t)f + 2]};
+        float gfn[3], p3[3][3], gcorner[3][3];
+#pragma unroll
+        for (int k = 0; k < 3; k++) gfn[k] = g_s[3 * (size_t)idx[0] + k] + g_s[3 * (size_t)idx[1] + k] + g_s[3 * (size_t)idx[2] + k];
+#pragma unroll
+        for (int c = 0; c < 3; c++)
+#pragma unroll
+            for (int k = 0; k < 3; k++) p3[c][k] = verts[3 * (size_t)idx[c] + k];
+        dwg_mb_face_normal_bwd(p3[0], p3[1], p3[2], gfn, gcorner[0], gcorner[1], gcorner[2]);
+#pragma unroll
+        for (int c = 0; c < 3; c++)
+            if (idx[c] == v) { acc[0] += gcorner[c][0]; acc[1] += gcorner[c][1]; acc[2] += gcorner[c][2]; }
+    }
+#pragma unroll
+    for (int k = 0; k < 3; k++) g_verts[3 * (size_t)v + k] += acc[k];
+}
+
 }  // namespace
 
 extern "C" {
@@ -200,7 +279,7 @@ int dwg_meshbind_backward(int32_t Fp, int32_t n_per_tri, const float* bary, cons
     const int M = Fp * n_per_tri;
     DWG_LAUNCH("meshbind_bwd", k_meshbind_bwd, dim3(dwg_cdiv(M, 256)), dim3(256), 0, (hipStream_t)stream_, M, n_per_tri, bary, scale_params,
                verts_cnl, verts_obs, vnormals_obs, triangles, g_pos_cnl, g_pos, g_scales, g_quats, g_bary, g_scale_params,
-               (float*)nullptr, (float*)nullptr, (float*)nullptr);
+               (float*)nullptr, (float*)nullptr, (float*)nullptr, (float*)nullptr);
     DWG_RETURN_IF_LAUNCH_FAILED();
     return DWG_OK;
 }
@@ -217,7 +296,29 @@ int dwg_meshbind_backward_verts(int32_t Fp, int32_t n_per_tri, const float* bary
     const int M = Fp * n_per_tri;
     DWG_LAUNCH("meshbind_bwd", k_meshbind_bwd, dim3(dwg_cdiv(M, 256)), dim3(256), 0, (hipStream_t)stream_, M, n_per_tri, bary, scale_params,
                verts_cnl, verts_obs, vnormals_obs, triangles, g_pos_cnl, g_pos, g_scales, g_quats, g_bary, g_scale_params, g_verts_cnl,
-               g_verts_obs, g_vnormals_obs);
+               g_verts_obs, g_vnormals_obs, (float*)nullptr);
+    DWG_RETURN_IF_LAUNCH_FAILED();
+    return DWG_OK;
+}
+
+int dwg_meshbind_backward_verts_gather(int32_t Vp, int32_t Fp, int32_t n_per_tri, const float* bary, const float* scale_params,
+                                       const float* verts_cnl, const float* verts_obs, const float* vnormals_obs, const int32_t* triangles,
+                                       const int32_t* vf_offsets, const int32_t* vf_faces, const float* g_pos_cnl, const float* g_pos,
+                                       const float* g_scales, const float* g_quats, float* g_bary, float* g_scale_params, float* corner_rows,
+                                       float* g_verts_cnl, float* g_verts_obs, float* g_vnormals_obs, dwg_stream_t stream_) {
+    if (Vp < 0 || Fp < 0 || n_per_tri <= 0) return DWG_E_ARG;
+    if (Fp == 0 || Vp == 0) return DWG_OK;
+    if (!bary || !scale_params || !verts_obs || !vnormals_obs || !triangles || !g_bary || !g_scale_params) return DWG_E_ARG;
+    if (!vf_offsets || !vf_faces || !corner_rows || !g_verts_obs || !g_vnormals_obs) return DWG_E_ARG;
+    if (g_pos_cnl && !verts_cnl) return DWG_E_ARG;
+    if (g_verts_cnl && !(verts_cnl && g_pos_cnl)) return DWG_E_ARG;
+    const int M = Fp * n_per_tri;
+    hipStream_t stream = (hipStream_t)stream_;
+    DWG_LAUNCH("meshbind_bwd", k_meshbind_bwd, dim3(dwg_cdiv(M, 256)), dim3(256), 0, stream, M, n_per_tri, bary, scale_params,
+               verts_cnl, verts_obs, vnormals_obs, triangles, g_pos_cnl, g_pos, g_scales, g_quats, g_bary, g_scale_params, (float*)nullptr,
+               (float*)nullptr, (float*)nullptr, corner_rows);
+    DWG_LAUNCH("meshbind_gather_verts", k_meshbind_gather_verts, dim3(dwg_cdiv(Vp, 256)), dim3(256), 0, stream, Vp, n_per_tri, triangles,
+               vf_offsets, vf_faces, (const float*)corner_rows, g_verts_cnl, g_verts_obs, g_vnormals_obs);
     DWG_RETURN_IF_LAUNCH_FAILED();
     return DWG_OK;
 }
@@ -233,8 +334,9 @@ int dwg_mesh_vertex_normals_backward(int32_t Vp, int32_t Fp, const float* verts,
     DWG_LAUNCH("mesh_face_normals", k_face_normals, dim3(dwg_cdiv(Fp, 256)), dim3(256), 0, stream, Fp, verts, triangles, face_normals_scratch);
     DWG_LAUNCH("mesh_vertex_normals_bwd", k_vertex_normals_bwd_sum, dim3(dwg_cdiv(Vp, 256)), dim3(256), 0, stream, Vp,
                (const float*)face_normals_scratch, vf_offsets, vf_faces, g_vertex_normals, g_sum_scratch);
-    DWG_LAUNCH("mesh_face_normals_bwd", k_face_normals_bwd, dim3(dwg_cdiv(Fp, 256)), dim3(256), 0, stream, Fp, verts, triangles,
-               (const float*)g_sum_scratch, g_verts);
+    // (round 6: a per-vertex gather over the incident-face table instead of per-face float atomics: the same bits on every run)
+    DWG_LAUNCH("mesh_face_normals_bwd", k_face_normals_bwd_gather, dim3(dwg_cdiv(Vp, 256)), dim3(256), 0, stream, Vp, verts, triangles, vf_offsets,
+               vf_faces, (const float*)g_sum_scratch, g_verts);
     DWG_RETURN_IF_LAUNCH_FAILED();
     return DWG_OK;
 }

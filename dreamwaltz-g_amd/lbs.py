@@ -133,9 +133,10 @@ class _VertexTransformFn(torch.autograd.Function):
         g_shape = torch.empty(S, device=A.device)
         scratch = torch.empty(J, 3, device=A.device)
         p = _lib.ptr
-        _lib.check(_lib.lib().dwg_lbs_vertex_transform_backward_shape(
-            Vp, J, S, p(A), p(w_sub), p(sd), p(g_out.contiguous().float()), p(pose), p(parents), p(jdirs), p(scratch), p(g_shape),
-            _st(A)), "dwg_lbs_vertex_transform_backward_shape")
+        ws = torch.empty(int(_lib.lib().dwg_lbs_vertex_transform_backward_shape_workspace_floats(Vp)), device=A.device)     # one row of partial sums per workgroup
+        _lib.check(_lib.lib().dwg_lbs_vertex_transform_backward_shape_ws(
+            Vp, J, S, p(A), p(w_sub), p(sd), p(g_out.contiguous().float()), p(pose), p(parents), p(jdirs), p(scratch), p(g_shape), p(ws),
+            _st(A)), "dwg_lbs_vertex_transform_backward_shape_ws")
         return None, g_shape.reshape(ctx.shape_shape), None, None, None, None, None, None, None, None
 
 

@@ -132,11 +132,16 @@ class _MeshBindFull(torch.autograd.Function):
                                                p(cg(g_pos)), p(cg(g_scl)), p(cg(g_quat)), p(g_bary), p(g_sc), _st(bary_c)),
                        "dwg_meshbind_backward")
             return g_bary.reshape(ctx.bary_shape), g_sc, None, None, None, None, None, None
-        g_vc = torch.zeros_like(vc) if vc is not None else None
-        g_vo, g_vn = torch.zeros_like(vo), torch.zeros_like(vo)
-        _lib.check(L.dwg_meshbind_backward_verts(Fp, ctx.n_per_tri, p(bary_c), p(scales_c), p(vc), p(vo), p(vn), p(tri), p(g_pos_c),
-                                                 p(cg(g_pos)), p(cg(g_scl)), p(cg(g_quat)), p(g_bary), p(g_sc), p(g_vc), p(g_vo), p(g_vn),
-                                                 _st(bary_c)), "dwg_meshbind_backward_verts")
+        # vertex gradients without float atomics: per-(Gaussian, corner) rows, then a per-vertex gather in incident-face order (the same bits
+        # on every run; the three outputs are overwritten, no zero fills)
+        g_vc = torch.empty_like(vc) if (vc is not None and g_pos_c is not None) else None
+        g_vo, g_vn = torch.empty_like(vo), torch.empty_like(vo)
+        rows = torch.empty(Fp * ctx.n_per_tri * 27, device=vo.device)
+        _lib.check(L.dwg_meshbind_backward_verts_gather(Vp, Fp, ctx.n_per_tri, p(bary_c), p(scales_c), p(vc), p(vo), p(vn), p(tri), p(vf_off),
+                                                        p(vf_faces), p(g_pos_c), p(cg(g_pos)), p(cg(g_scl)), p(cg(g_quat)), p(g_bary), p(g_sc),
+                                                        p(rows), p(g_vc), p(g_vo), p(g_vn), _st(bary_c)), "dwg_meshbind_backward_verts_gather")
+        if g_vc is None and vc is not None:
+            g_vc = torch.zeros_like(vc)
         fn = torch.empty(max(Fp, 1), 3, device=vo.device)
         gs = torch.empty(Vp, 3, device=vo.device)
         _lib.check(L.dwg_mesh_vertex_normals_backward(Vp, Fp, p(vo), p(tri), p(vf_off), p(vf_faces), p(g_vn), p(fn), p(gs), p(g_vo),

@@ -62,6 +62,15 @@ int dwg_lbs_vertex_transform_backward_shape(int32_t Vp, int32_t J, int32_t n_sha
                                             const int32_t* parents, const float* joint_shape_dirs, float* g_A_transl_scratch,
                                             float* g_shape, dwg_stream_t stream);
 
+/* The same gradient with a caller-owned workspace of dwg_lbs_vertex_transform_backward_shape_workspace_floats(Vp) floats (one row of
+ * partial sums per workgroup): what the Python path calls.  No float atomics in either form (round 6): the sums are formed in a fixed order,
+ * the same bits on every run; the form above keeps one library-owned workspace per process and serialises its callers on it. */
+size_t dwg_lbs_vertex_transform_backward_shape_workspace_floats(int32_t Vp);
+int dwg_lbs_vertex_transform_backward_shape_ws(int32_t Vp, int32_t J, int32_t n_shape, const float* A, const float* lbs_weights_sub,
+                                               const float* shapedirs_sub, const float* g_out, const float* pose, const int32_t* parents,
+                                               const float* joint_shape_dirs, float* g_A_transl_scratch, float* g_shape, float* workspace,
+                                               dwg_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -48,6 +48,17 @@ int dwg_meshbind_backward_verts(int32_t Fp, int32_t n_per_tri, const float* bary
                                 float* g_verts_cnl /*[Vp,3]*/, float* g_verts_obs /*[Vp,3]*/, float* g_vnormals_obs /*[Vp,3]*/,
                                 dwg_stream_t stream);
 
+/* dwg_meshbind_backward_verts WITHOUT float atomics (round 6; `learn_hand_betas` is on in sub-stage 2.1 of the shipped recipe,
+ * scripts/train_w_expr.sh:66): the per-Gaussian kernel writes one row {g position, g normal, g canonical position} per (Gaussian, corner)
+ * into `corner_rows` (Fp * n_per_tri * 27 floats) and a per-vertex pass adds the rows of the vertex's incident faces (vf_offsets /
+ * vf_faces: the table dwg_mesh_vertex_normals takes) in table order.  g_verts_* [Vp,3] are OVERWRITTEN (g_verts_cnl may be NULL);
+ * dwg_mesh_vertex_normals_backward then accumulates into g_verts_obs, also by a per-vertex gather.  The same bits on every run. */
+int dwg_meshbind_backward_verts_gather(int32_t Vp, int32_t Fp, int32_t n_per_tri, const float* bary, const float* scale_params,
+                                       const float* verts_cnl, const float* verts_obs, const float* vnormals_obs, const int32_t* triangles,
+                                       const int32_t* vf_offsets, const int32_t* vf_faces, const float* g_pos_cnl, const float* g_pos,
+                                       const float* g_scales, const float* g_quats, float* g_bary, float* g_scale_params, float* corner_rows,
+                                       float* g_verts_cnl, float* g_verts_obs, float* g_vnormals_obs, dwg_stream_t stream);
+
 /* Backward of dwg_mesh_vertex_normals (autograd through compute_normal, utils/mesh.py:34-94): adds d loss / d verts into g_verts
  * [Vp,3] given d loss / d vertex_normals.  face_normals_scratch [Fp,3] and g_sum_scratch [Vp,3] are overwritten. */
 int dwg_mesh_vertex_normals_backward(int32_t Vp, int32_t Fp, const float* verts, const int32_t* triangles, const int32_t* vf_offsets,

@@ -72,6 +72,23 @@ def test_animate_matches_the_reference_animate(tag, lhb):
         assert e < 3e-3, (name, e)
 
 
+def test_learned_hand_betas_gradients_are_bit_reproducible():
+    """Round 6: no float atomics are left on the `learn_hand_betas` path (sub-stage 2.1 of the shipped recipe turns it on,
+    /root/reference/scripts/train_w_expr.sh:66): the shape-coefficient sums of the LBS backward are formed per lane, per wave, per workgroup
+    in a fixed order, and the mesh-vertex gradients are gathered per vertex over the incident-face table.  Two runs: identical bits."""
+    grads = []
+    for _ in range(2):
+        a, obs = _golden_avatar(True)
+        out = a.animate(obs)
+        loss = sum((out[f] * T("sd.animate_betas.lossw." + f).cuda()).sum() for f in ("positions", "opacities", "colors", "quaternions", "scales"))
+        loss.backward()
+        gm = a.mesh_binding_gaussians["hands"]
+        grads.append([a._betas.grad.clone(), gm._bary_coords.grad.clone(), gm._scales.grad.clone(), a._positions.grad.clone()])
+    for x, y in zip(*grads):
+        assert torch.equal(x, y)
+    assert float(grads[0][0].abs().max()) > 0.0
+
+
 def test_reference_shaped_lbs_seam_on_the_kernels():
     """lbs_model.forward(**smpl_inputs) -> (transform_J, transform_V, transforms) used the way the REFERENCE's DreamWaltzG.lbs_transform
     and animate use it (avatar.py:1426-1462,1570-1577): compose / squeeze / transform_points(weights=|indices=) /
