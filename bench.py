@@ -45,8 +45,8 @@ from dreamwaltz_g_amd import sds_step  # noqa: E402
 HBM_PEAK_GBS = 8000.0                                  # MI355X_MICROARCH.md: 8 TB/s HBM3E
 MFMA_PEAK_TFLOPS = {"bf16": 2500.0, "f16": 2500.0, "f32": 157.3, "f32x": 2500.0}      # dense MFMA peaks per operand type (same guide); f32x runs on the
                                                                                        # f16 MFMA pipe, its ALGORITHMIC flops (one multiply-add per product, not the three MFMAs) are priced against that peak
-N1_LINE_JSON = os.path.join(ROOT, "profiles", "r05_bench_line.json")           # the round's single-GPU line: N = 1 references of an N > 1 line
-TRAFFIC_JSON = os.path.join(ROOT, "profiles", "r05_pmc_traffic.json")      # PMC passes over the f32x (headline) step: tools/profile_round.sh
+N1_LINE_JSON = os.path.join(ROOT, "profiles", "r06_bench_line.json")           # the round's single-GPU line: N = 1 references of an N > 1 line
+TRAFFIC_JSON = os.path.join(ROOT, "profiles", "r06_pmc_traffic.json")      # PMC passes over the f32x (headline) step: tools/profile_round.sh
 HEADLINE_DTYPE = "f32x"       # the reference runs the guidance stage in fp32 (configs/__init__.py:236,241): the headline is a same-precision number
 HEADLINE_METRIC = "SDS steps/sec @512^2, 100k Gaussians, SD1.5+ControlNet; raster Mpix/s vs HBM roofline"
 
@@ -286,7 +286,7 @@ def raster_report(prof, G, Kref, K, P, steps, pmc=False):
         for key, names in (("raster_forward", fwd), ("raster_backward", bwd)):
             if key in out:
                 # ONE number: FETCH_SIZE x 2 for the kernels that stream, x 1 for the ones that gather (tools/pmc_traffic.py, calibrated on known
-                # byte counts: profiles/r05_fetch_calibration.json), + WRITE_SIZE
+                # byte counts: profiles/r06_fetch_calibration.json), + WRITE_SIZE
                 t = sum(v["hbm_bytes_per_launch"] * v.get("launches_per_step", 1) for k, v in tk.items() if k.split("<")[0] in names)
                 out[key]["traffic"] = t
                 out[key]["traffic_over_algorithmic"] = t / out[key]["bytes"]
