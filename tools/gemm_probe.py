@@ -17,10 +17,23 @@ keep = []
 ZERO = os.environ.get("PROBE_ZERO") == "1"       # all-zero operands: the same instruction stream without the data-dependent power draw
 
 
+LO_BITS = int(os.environ.get("PROBE_LO_BITS", "11"))   # f32x only: significand bits kept in the lo halves (11 = the format's own; fewer: low bits zeroed -> less toggling)
+HI_ONLY = os.environ.get("PROBE_HI_ONLY") == "1"         # f32x only: lo halves all zero (the data of an fp16 tensor through the three-MFMA stream)
+
+
 def cv(t):
     if ZERO:
         t = torch.zeros_like(t)
-    return xfmt.pack(t) if DT == "f32x" else t.to(torch.bfloat16)
+    if DT != "f32x":
+        return t.to(torch.bfloat16)
+    x = xfmt.pack(t)
+    if LO_BITS < 11 or HI_ONLY:
+        h = x.view(torch.int16).view(x.shape[:-1] + (x.shape[-1] // 8, 2, 8)).clone()      # [..., group, {hi, lo}, 8]
+        mask = 0 if HI_ONLY else (~((1 << (11 - LO_BITS)) - 1)) & 0xFFFF
+        mask = mask - 65536 if mask >= 32768 else mask
+        h[..., 1, :] &= mask
+        x = h.reshape(x.shape[:-1] + (x.shape[-1] * 2,)).view(torch.int32)
+    return x
 
 
 ODT = torch.int32 if DT == "f32x" else torch.bfloat16
