@@ -75,15 +75,17 @@ __global__ __launch_bounds__(256) void k_assemble_bwd(int n_free, int n_total, f
 
 struct SegJobs { dwg_segment j[DWG_MAX_SEGMENTS]; };
 
-// job blockIdx.y: count floats from src to dst; div != 0: out = (in + add) / div (the grid encoder's input normalisation, gridencoder grid.py:
-// `(inputs + bound) / (2 * bound)`, applied while the canonical positions are gathered -- the same two operations, the same bits)
+// job blockIdx.y: count floats from src to dst; div != 0: out = (in + add) * (1 / div) -- the grid encoder's input normalisation (gridencoder
+// grid.py `(inputs + bound) / (2 * bound)`) applied while the canonical positions are gathered, in the form torch's elementwise kernels give a
+// division by a scalar (one reciprocal in fp32, then a multiply per element): the same bits as the reference's two launches
 __global__ __launch_bounds__(256) void k_copy_segments(SegJobs J, float add, float div) {
+    const float inv = div != 0.f ? 1.f / div : 0.f;
     const dwg_segment s = J.j[blockIdx.y];
     const float* __restrict__ src = reinterpret_cast<const float*>(s.src);
     float* __restrict__ dst = reinterpret_cast<float*>(s.dst);
     for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < s.count; i += (long long)gridDim.x * 256) {
         const float v = src[i];
-        dst[i] = div != 0.f ? (v + add) / div : v;
+        dst[i] = div != 0.f ? (v + add) * inv : v;
     }
 }
 

