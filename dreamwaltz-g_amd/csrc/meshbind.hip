@@ -133,7 +133,7 @@ __global__ __launch_bounds__(256) void k_meshbind_bwd(int M, int n_per, const fl
 }
 
 // Backward of k_vertex_normals / k_face_normals: g_vn [Vp,3] -> gradient of the summed face normals per vertex (g_s), then per
-// face the sum over its corners, the face-normal chain and a scatter to the three corner positions.
+// face the sum over its corners and the face-normal chain, gathered per vertex over the incident-face table (k_face_normals_bwd_gather below).
 __global__ __launch_bounds__(256) void k_vertex_normals_bwd_sum(int Vp, const float* __restrict__ fn, const int* __restrict__ vf_off,
                                                                 const int* __restrict__ vf_faces, const float* __restrict__ g_vn,
                                                                 float* __restrict__ g_s) {
@@ -150,26 +150,6 @@ __global__ __launch_bounds__(256) void k_vertex_normals_bwd_sum(int Vp, const fl
         dwg_mb_safe_normalize_bwd(n, gy, g);
     }
     g_s[3 * v] = g[0]; g_s[3 * v + 1] = g[1]; g_s[3 * v + 2] = g[2];
-}
-
-__global__ __launch_bounds__(256) void k_face_normals_bwd(int Fp, const float* __restrict__ verts, const int* __restrict__ tri,
-                                                          const float* __restrict__ g_s, float* __restrict__ g_verts) {
-    const int f = blockIdx.x * 256 + threadIdx.x;
-    if (f >= Fp) return;
-    const int ia = tri[3 * f], ib = tri[3 * f + 1], ic = tri[3 * f + 2];
-    const float* a = verts + 3 * (size_t)ia; const float* b = verts + 3 * (size_t)ib; const float* c = verts + 3 * (size_t)ic;
-    float gfn[3];
-#pragma unroll
-    for (int k = 0; k < 3; k++) gfn[k] = g_s[3 * (size_t)ia + k] + g_s[3 * (size_t)ib + k] + g_s[3 * (size_t)ic + k];
-    float ga[3], gb[3], gc[3];
-    const float av[3] = {a[0], a[1], a[2]}, bv[3] = {b[0], b[1], b[2]}, cv[3] = {c[0], c[1], c[2]};
-    dwg_mb_face_normal_bwd(av, bv, cv, gfn, ga, gb, gc);
-#pragma unroll
-    for (int k = 0; k < 3; k++) {
-        atomicAdd(g_verts + 3 * (size_t)ia + k, ga[k]);
-        atomicAdd(g_verts + 3 * (size_t)ib + k, gb[k]);
-        atomicAdd(g_verts + 3 * (size_t)ic + k, gc[k]);
-    }
 }
 
 // True iff entry e of vertex v's incident-face list names a face that an EARLIER entry of the list already named (a face listing a vertex

@@ -41,7 +41,8 @@ int dwg_meshbind_backward(int32_t Fp, int32_t n_per_tri, const float* bary, cons
 
 /* Same as dwg_meshbind_backward and additionally ACCUMULATES (buffers zeroed by the caller) the gradients w.r.t. the posed
  * vertices, their vertex normals and the canonical vertices -- needed when the vertices depend on a learnable parameter
- * (`learn_hand_betas` / `learn_face_betas`: avatar.py:1551-1577, scripts/train_w_expr.sh:66).  g_verts_cnl may be NULL. */
+ * (`learn_hand_betas` / `learn_face_betas`: avatar.py:1551-1577, scripts/train_w_expr.sh:66).  g_verts_cnl may be NULL.  (This form scatters with float atomics -- sums in arrival order --
+ * and is kept for C callers of the round-2 signature; the Python path calls dwg_meshbind_backward_verts_gather below.) */
 int dwg_meshbind_backward_verts(int32_t Fp, int32_t n_per_tri, const float* bary, const float* scale_params, const float* verts_cnl,
                                 const float* verts_obs, const float* vnormals_obs, const int32_t* triangles, const float* g_pos_cnl,
                                 const float* g_pos, const float* g_scales, const float* g_quats, float* g_bary, float* g_scale_params,
