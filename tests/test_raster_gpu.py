@@ -308,3 +308,38 @@ def test_frames_backward_equals_single_frame_backwards_bit_for_bit(shared):
         else:
             for f in range(F):
                 assert torch.equal(leaves[k].grad[f], singles[f]["leaves"][k].grad), (k, f)
+
+
+@pytest.mark.gpu
+def test_frames_chain_with_too_small_a_pair_capacity_reports_it_and_returns_zero_gradients():
+    """The sync-free sizing of a training chain (PairCapacity): a chain whose capacity turns out too small is truncated by the kernels, the
+    state latches the overflow (the owner of the step renders its views again: SDSTrainer.train_step), the chain's backward contributes
+    ZEROS, and the next chain -- capacity grown from the counts that came back -- is complete and equals exactly-sized single frames."""
+    from dreamwaltz_g_amd.rasterizer import rasterize_frames, PairCapacity
+    F, G, H, W = 2, 4000, 128, 128
+    scs = [rc.make_scene(G, H, W, seed=5, azimuth=10.0 + 70.0 * f) for f in range(F)]
+    dev = "cuda"
+    cams = torch.stack([torch.cat([s["viewmatrix"].reshape(-1), s["projmatrix"].reshape(-1), s["campos"].reshape(-1)]) for s in scs]).to(dev)
+    keys = ("means3D", "opacities", "colors", "scales", "rotations")
+    state = PairCapacity(min_pairs=16)
+    state.cap = 64                                        # far below the frames' pair counts
+    outs = []
+    for attempt in range(2):
+        leaves = {k: scs[0][k].to(dev).clone().requires_grad_(True) for k in keys}
+        color, radii, depth, alpha, info = rasterize_frames(leaves["means3D"], leaves["opacities"], colors_precomp=leaves["colors"],
+                                                            scales=leaves["scales"], rotations=leaves["rotations"], cameras=cams, image_height=H,
+                                                            image_width=W, tanfovx=scs[0]["tanfovx"], tanfovy=scs[0]["tanfovy"],
+                                                            bg=scs[0]["bg"].to(dev), pair_state=state)
+        color.sum().backward()
+        outs.append((color.detach().clone(), leaves["means3D"].grad.clone(), bool(info["headers"][:, 1].any())))
+        truncated = state.consume_overflow()
+        if attempt == 0:
+            assert outs[0][2] and truncated                                   # the kernels flagged it, the state latched it
+            assert float(outs[0][1].abs().max()) == 0.0                       # zero gradient, not a partial one
+            assert state.cap >= int(info["headers"][:, 0].max())              # grown from the counts that came back
+        else:
+            assert not outs[1][2] and not truncated
+    for f, sc in enumerate(scs):
+        single = rc.hip_render(dict(sc, **{k: scs[0][k] for k in keys}), device=dev)
+        assert torch.equal(outs[1][0][f], single["color"])
+    assert float(outs[1][1].abs().max()) > 0.0
