@@ -161,6 +161,7 @@ class ControlNetScoreDistillation:
         self.min_step_cfg = self.cfg.min_timestep if min_timestep is None else min_timestep
         self.max_step_cfg = self.cfg.max_timestep if max_timestep is None else max_timestep
         self.timestep, self.guidance_scale = None, self.initial_guidance_scale
+        self._side = None                 # side stream of the denoiser's prelude (preprocess)
 
     # -- plans ---------------------------------------------------------------------------------------------------------
     def plans(self):
@@ -186,11 +187,11 @@ class ControlNetScoreDistillation:
         return rep
 
     def capture_graphs(self):
-        for p in self.plans():
+        for p in self.plans() + (self.denoiser.pre,):
             p.capture()
 
     def set_use_graphs(self, on: bool):
-        for p in self.plans():
+        for p in self.plans() + (self.denoiser.pre,):
             p.use_graph = bool(on)
 
     # -- time_prior.py:292-352 ------------------------------------------------------------------------------------------
@@ -264,12 +265,38 @@ class ControlNetScoreDistillation:
 
     def preprocess(self, inputs, train_step, max_iteration, posterior_noise=None, generator=None, **kwargs):
         """basic.py:420-438.  `generator`: the device generator every random draw of the call comes from (None: the default one, as in
-        the reference) -- a multi-view step gives each view its own stream."""
+        the reference) -- a multi-view step gives each view its own stream.
+        Round 6: the two random draws of this stage keep their order (#1 the VAE posterior noise, #2 the timestep), but both are made BEFORE
+        the encoder runs -- neither depends on its result -- so that the part of the denoiser that needs only the timestep, the text and the
+        condition image (sd15.DenoiserPlan.prefetch: time embeddings, ControlNet hint embedding, text k / v projections) can run on a side
+        stream UNDER the VAE encoder (`prefetch`: (text_embeds_dict, cond_inputs) of the call, or None)."""
         batch_size = inputs.size(0)
+        prefetch = kwargs.pop('_prefetch', None)
+        # (a step being captured into ONE graph keeps the prelude on the capturing stream, in front of the main plan: sd15.DenoiserPlan.run)
+        early = (prefetch is not None and inputs.is_cuda and inputs.size(1) == 3 and os.environ.get("DWG_DENOISER_PREFETCH", "1") != "0"
+                 and not torch.cuda.is_current_stream_capturing())
+        if early and posterior_noise is None:
+            shape = (batch_size, self.vae_cfg.latent_channels, self.latent_hw, self.latent_hw)
+            posterior_noise = torch.randn(shape, device=inputs.device, dtype=inputs.dtype, generator=generator)        # RNG draw #1
+        if early:
+            self.guidance_scale = kwargs.pop('guidance_scale') if 'guidance_scale' in kwargs else self.get_guidance_scale(train_step, max_iteration)
+            self.timestep = (kwargs.pop('timestep') if 'timestep' in kwargs
+                             else self.get_timestep(batch_size, train_step, max_iteration, generator=generator))
+            text_embeds_dict, cond_inputs = prefetch
+            if self.do_classifier_free_guidance and torch.is_tensor(cond_inputs):
+                with torch.no_grad():
+                    text_keys = ('neg', 'text') if self.use_negative_text else ('null', 'text')
+                    text = self.prepare_text_embeddings(text_embeds_dict, text_keys)
+                    cond = self.prepare_condition(cond_inputs, cond_height=self.latent_hw * self.vae_scale_factor,
+                                                  cond_width=self.latent_hw * self.vae_scale_factor, batch_size=2 * batch_size, dtype=torch.float32)
+                    if self._side is None:
+                        self._side = torch.cuda.Stream(device=self.device)
+                    self.denoiser.prefetch(self.timestep, text, cond[:self.views], stream=self._side)
         latents, inputs = self.prepare_latents(inputs, posterior_noise, generator=generator)
-        self.guidance_scale = kwargs.pop('guidance_scale') if 'guidance_scale' in kwargs else self.get_guidance_scale(train_step, max_iteration)
-        self.timestep = (kwargs.pop('timestep') if 'timestep' in kwargs
-                         else self.get_timestep(batch_size, train_step, max_iteration, generator=generator))
+        if not early:
+            self.guidance_scale = kwargs.pop('guidance_scale') if 'guidance_scale' in kwargs else self.get_guidance_scale(train_step, max_iteration)
+            self.timestep = (kwargs.pop('timestep') if 'timestep' in kwargs
+                             else self.get_timestep(batch_size, train_step, max_iteration, generator=generator))
         return latents, inputs, kwargs
 
     # -- controlnet.py:33-72 ---------------------------------------------------------------------------------------------
@@ -385,7 +412,7 @@ class ControlNetScoreDistillation:
                                                           scaler=kwargs.get('scaler'), mask=mask))
         kwargs.pop('scaler', None)
         latents, inputs, kwargs = self.preprocess(inputs, train_step, max_iteration, posterior_noise=posterior_noise, generator=generator,
-                                                  **kwargs)
+                                                  _prefetch=(text_embeds_dict, kwargs.get('cond_inputs')), **kwargs)
         with torch.no_grad():
             if noise is None:
                 noise = torch.randn(latents.shape, device=latents.device, dtype=latents.dtype, generator=generator)   # RNG draw #3

@@ -779,6 +779,14 @@ class Builder:
         launches of ~12 us each in the UNet, 7 in the ControlNet -> 1 + 1); a block's k and v are column slices of its output."""
         batches = self.__dict__.setdefault("_text_kv", {})
         key = text.data_ptr()
+        base = getattr(text, "_base", None)
+        if key not in batches and base is not None and base.data_ptr() in batches and batches[base.data_ptr()] is not None \
+                and base.dim() == text.dim() and base.shape[1:] == text.shape[1:] and text.is_contiguous():
+            # a batch-row slice of a text whose projections exist already (the halves of a split decoder; a prelude that ran on the whole
+            # batch): the same rows of that output
+            r0 = (text.data_ptr() - base.data_ptr()) // (base.stride(0) * base.element_size())
+            out, offs, _ = batches[base.data_ptr()]
+            batches[key] = (out[r0:r0 + text.shape[0]], offs, text)
         if key not in batches:
             if os.environ.get("DWG_TEXT_KV_PER_BLOCK") == "1":           # experiment switch: the round-1 schedule
                 batches[key] = None
@@ -898,9 +906,17 @@ class DenoiserPlan:
         assert batch % self.views == 0, (batch, views)
         self.plan = Plan(device, dtype)
         p = self.plan
+        # The PRELUDE (round 6): everything of the call that does not depend on the latents -- both time embeddings and their per-resnet
+        # projections, the ControlNet's hint embedding of the condition image (eight convolutions down from 8h x 8w), the text k / v projections of
+        # every cross-attention of both networks -- is a plan of its own.  `run()` replays it in front of the main plan; a caller that knows the
+        # timestep, the text and the condition image before the latents exist (guidance.__call__: they exist before the VAE encoder runs) starts
+        # it on a side stream with `prefetch()` and it runs UNDER the VAE encoder, whose launches are matrix-bound.
+        self.pre = Plan(device, dtype)
+        self._pre_event, self._pre_ready, self._pre_stream = None, False, None
         wu, wc = weights if weights is not None else (Weights(unet_sd, device, dtype), Weights(cn_sd, device, dtype))
         self.weights = (wu, wc)     # kernel-layout weight tensors must outlive the plan that points at them
         bu, bc = Builder(p, wu, cfg.groups, "unet"), Builder(p, wc, cfg.groups, "cnet")
+        pu, pc = Builder(self.pre, wu, cfg.groups, "unet"), Builder(self.pre, wc, cfg.groups, "cnet")
         B, hw = batch, latent_hw
         self.latents = p.buf(B, hw, hw, _pad8(cfg.in_channels), zero=True)
         self.text = p.buf(B, text_len, cfg.cross_dim)
@@ -917,42 +933,113 @@ class DenoiserPlan:
         # encoder, and below 64x64 neither fills the chip alone, so the two run as parallel paths (side stream / graph branch).
         import os
         par = os.environ.get("DWG_SERIAL_DENOISER") != "1"
-        if par:
-            p.fork(1)
-        with p.on_branch(1 if par else 0):
-            self.temb_c = _TimeEmbed(bc, wc, cfg, B, _encoder_resnet_names(cfg))
-            e = "controlnet_cond_embedding"
-            hnt = bc.conv(self.cond, e + ".conv_in", act="silu")
-            nblk = 2 * (len(cfg.cond_channels) - 1)
-            for k in range(nblk):
-                hnt = bc.conv(hnt, "%s.blocks.%d" % (e, k), stride=2 if k % 2 == 1 else 1, act="silu")
-            hnt = bc.conv(hnt, e + ".conv_out")
-            cskips, cmid = _build_encoder(bc, cfg, self.latents, self.temb_c, self.text, hint=hnt)
-        self.temb_u = _TimeEmbed(bu, wu, cfg, B, _encoder_resnet_names(cfg) + up_names)
-        skips, mid = _build_encoder(bu, cfg, self.latents, self.temb_u, self.text)
-        if par:
-            p.join(1)
-        # ---- zero convs whose epilogue adds the UNet skip they feed
-        skips = [bc.conv(cs, "controlnet_down_blocks.%d" % k, pad=0, residual=skips[k]) for k, cs in enumerate(cskips)]
-        h = bc.conv(cmid, "controlnet_mid_block", pad=0, residual=mid)
-        # ---- UNet decoder
+        # DWG_DENOISER_SPLIT: 0 = every chain on the whole CFG batch; 1 (default) = the DECODER split by batch half -- it is ONE chain, and its
+        # memory-bound layers (GroupNorm, LayerNorm, split-K reduces) otherwise have nothing to run under: the halves are two independent
+        # chains (side stream / graph branch) with half the rows per launch; 2 = the encoders split by half as well (four chains)
+        split = int(os.environ.get("DWG_DENOISER_SPLIT", "1")) if (par and B % 2 == 0) else 0
+        if split >= 2 and self.views != 1:
+            split = 1                                   # (the four-chain form shares ONE view's hint embedding between the halves)
         nb = len(cfg.block_out_channels)
-        for i in range(nb):
-            for j in range(cfg.layers_per_block + 1):
-                pre = "up_blocks.%d.resnets.%d" % (i, j)
-                h = bu.resnet(bu.cat(h, skips.pop()), pre, self.temb_u.bias_for(pre))
-                if rev_attn[i]:
-                    h = bu.transformer(h, "up_blocks.%d.attentions.%d" % (i, j), self.text, cfg.heads)
-            if i != nb - 1:
-                h = bu.conv(h, "up_blocks.%d.upsamplers.0.conv" % i, upsample=2)
-        n = bu.groupnorm(h, "conv_norm_out", 1e-5, True)
-        self.eps = bu.conv(n, "conv_out", out_dtype=torch.float32)
 
-    def set_inputs(self, latents_nchw, t, text, cond_nchw=None):
-        """latents [B,4,h,w] fp32, t scalar / [V] (one per view, repeated over the CFG entries) / [B], text [B,77,768],
-        cond [V,3,8h,8w] in [0,1] (optional)."""
+        class _Rows:
+            """A _TimeEmbed seen through a slice of the batch rows."""
+            def __init__(self, temb, rows):
+                self.temb, self.rows = temb, rows
+
+            def bias_for(self, name):
+                tb, ld = self.temb.bias_for(name)
+                return (tb[self.rows], ld)
+
+        def decoder(h, skips, rows, first=0, last=None):
+            """up blocks first .. last - 1 on the batch rows `rows` (+ the output convolution when the last block is included)"""
+            last = nb if last is None else last
+            skips = list(skips)
+            tu = _Rows(self.temb_u, rows)
+            for i in range(first, last):
+                for j in range(cfg.layers_per_block + 1):
+                    pre = "up_blocks.%d.resnets.%d" % (i, j)
+                    h = bu.resnet(bu.cat(h, skips.pop()), pre, tu.bias_for(pre))
+                    if rev_attn[i]:
+                        h = bu.transformer(h, "up_blocks.%d.attentions.%d" % (i, j), self.text[rows], cfg.heads)
+                if i != nb - 1:
+                    h = bu.conv(h, "up_blocks.%d.upsamplers.0.conv" % i, upsample=2)
+            if last < nb:
+                return h, skips
+            n = bu.groupnorm(h, "conv_norm_out", 1e-5, True)
+            return bu.conv(n, "conv_out", out_dtype=torch.float32)
+
+        def zero_convs(cskips, cmid, skips, mid):
+            """the ControlNet's zero convolutions, whose epilogue adds the UNet skip they feed"""
+            return ([bc.conv(cs, "controlnet_down_blocks.%d" % k, pad=0, residual=skips[k]) for k, cs in enumerate(cskips)],
+                    bc.conv(cmid, "controlnet_mid_block", pad=0, residual=mid))
+
+        def hint_embedding(b_):
+            e = "controlnet_cond_embedding"
+            hnt = b_.conv(self.cond, e + ".conv_in", act="silu")
+            for k in range(2 * (len(cfg.cond_channels) - 1)):
+                hnt = b_.conv(hnt, "%s.blocks.%d" % (e, k), stride=2 if k % 2 == 1 else 1, act="silu")
+            return b_.conv(hnt, e + ".conv_out")
+        self.eps_halves = None
+        whole = slice(0, B)
+        # ---- the prelude plan: two independent chains (ControlNet side / UNet side)
+        suffix = ".attn2.to_k"
+        first_block = lambda w_: sorted(n[:-len(suffix + ".weight")] for n in w_.sd if n.endswith(suffix + ".weight"))[0]     # noqa: E731
+        self.pre.fork(1)
+        with self.pre.on_branch(1):
+            self.temb_c = _TimeEmbed(pc, wc, cfg, B, _encoder_resnet_names(cfg))
+            hnt = hint_embedding(pc)
+            pc.text_kv(self.text, first_block(wc))
+        self.temb_u = _TimeEmbed(pu, wu, cfg, B, _encoder_resnet_names(cfg) + up_names)
+        pu.text_kv(self.text, first_block(wu))
+        self.pre.join(1)
+        bu.__dict__["_text_kv"] = pu.__dict__["_text_kv"]       # the main plan's cross-attentions read the prelude's projections
+        bc.__dict__["_text_kv"] = pc.__dict__["_text_kv"]
+        if split < 2:
+            if par:
+                p.fork(1)
+            with p.on_branch(1 if par else 0):
+                cskips, cmid = _build_encoder(bc, cfg, self.latents, self.temb_c, self.text, hint=hnt)
+            skips, mid = _build_encoder(bu, cfg, self.latents, self.temb_u, self.text)
+            if par:
+                p.join(1)
+            skips, h = zero_convs(cskips, cmid, skips, mid)
+            if split == 1:
+                # the low-resolution up blocks stay on the whole batch: their launches are bound by the WEIGHTS they stream (59 - 118 MB per
+                # 3 x 3 convolution of the 1280-channel levels), which two half-batch chains would read twice
+                first = min(nb - 1, max(0, int(os.environ.get("DWG_DECODER_SPLIT_FROM", "2"))))
+                if first > 0:
+                    h, skips = decoder(h, skips, whole, 0, first)
+                lo, hi = slice(0, B // 2), slice(B // 2, B)
+                p.fork(1)
+                with p.on_branch(1):
+                    e1 = decoder(h[hi], [t[hi] for t in skips], hi, first)
+                e0 = decoder(h[lo], [t[lo] for t in skips], lo, first)
+                p.join(1)
+                self.eps_halves, self.eps = (e0, e1), None
+            else:
+                self.eps = decoder(h, skips, whole)
+        else:
+            # four encoder chains (UNet / ControlNet x batch half), then one zero-convolution + decoder chain per half
+            lo, hi = slice(0, B // 2), slice(B // 2, B)
+            for br in (1, 2, 3):
+                p.fork(br)
+            enc = {}
+            for br, (bld, w_, temb, rows, hint) in {0: (bu, wu, self.temb_u, lo, None), 1: (bc, wc, self.temb_c, lo, hnt),
+                                                    2: (bu, wu, self.temb_u, hi, None), 3: (bc, wc, self.temb_c, hi, hnt)}.items():
+                with p.on_branch(br):
+                    enc[br] = _build_encoder(bld, cfg, self.latents[rows], _Rows(temb, rows), self.text[rows], hint=hint)
+            p.join(1)                                   # the lower half's chain (branch 0) needs its ControlNet encoder
+            p.ops.append(("fork", 3, 2))                # ... and the upper half's (branch 2) its own
+            outs = {}
+            for br, cn, rows in ((2, 3, hi), (0, 1, lo)):
+                with p.on_branch(br):
+                    sk, hh = zero_convs(enc[cn][0], enc[cn][1], enc[br][0], enc[br][1])
+                    outs[br] = decoder(hh, sk, rows)
+            p.join(2)
+            self.eps_halves, self.eps = (outs[0], outs[2]), None
+
+    def _store_prelude_inputs(self, t, text, cond_nchw):
         p = self.plan
-        p.store(self.latents, latents_nchw.permute(0, 2, 3, 1), self._lat_stage)
         t = t.reshape(-1)
         if t.numel() not in (1, self.B):
             assert self.B % t.numel() == 0, (self.B, t.numel())
@@ -971,8 +1058,45 @@ class DenoiserPlan:
         if cond_nchw is not None:
             p.store(self.cond, cond_nchw.permute(0, 2, 3, 1), self._cond_stage)
 
+    def prefetch(self, t, text, cond_nchw=None, stream=None):
+        """Starts the prelude (time embeddings, hint embedding, text k / v) for the NEXT `run()` now -- on `stream` (a side stream: it then
+        runs beside whatever the caller's stream does until `run()`, which waits for it) or on the current stream.  The following
+        `set_inputs` only needs the latents; passing t / text / cond there again is allowed and ignored."""
+        dev = self.device
+        if stream is None or torch.device(dev).type != "cuda":
+            self._store_prelude_inputs(t, text, cond_nchw)
+            self.pre.run()
+            self._pre_ready, self._pre_event = True, None
+            return
+        main = torch.cuda.current_stream(dev)
+        stream.wait_stream(main)                               # the inputs' producers
+        with torch.cuda.stream(stream):
+            self._store_prelude_inputs(t, text, cond_nchw)
+            self.pre.run()
+            ev = torch.cuda.Event()
+            ev.record(stream)
+        for x in (t, text, cond_nchw):
+            if torch.is_tensor(x) and x.is_cuda:
+                x.record_stream(stream)
+        self._pre_ready, self._pre_event = True, ev
+
+    def set_inputs(self, latents_nchw, t=None, text=None, cond_nchw=None):
+        """latents [B,4,h,w] fp32, t scalar / [V] (one per view, repeated over the CFG entries) / [B], text [B,77,768],
+        cond [V,3,8h,8w] in [0,1] (optional).  After a `prefetch()` only the latents are taken."""
+        self.plan.store(self.latents, latents_nchw.permute(0, 2, 3, 1), self._lat_stage)
+        if not self._pre_ready:
+            self._store_prelude_inputs(t, text, cond_nchw)
+
     def run(self):
+        if self._pre_ready:
+            if self._pre_event is not None:
+                torch.cuda.current_stream(self.device).wait_event(self._pre_event)
+        else:
+            self.pre.run()
+        self._pre_ready, self._pre_event = False, None
         self.plan.run()
+        if self.eps_halves is not None:
+            return torch.cat(self.eps_halves, dim=0).permute(0, 3, 1, 2)
         return self.eps.permute(0, 3, 1, 2)   # [B,4,h,w] view (fp32)
 
 
