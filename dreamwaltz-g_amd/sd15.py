@@ -933,10 +933,12 @@ class DenoiserPlan:
         # encoder, and below 64x64 neither fills the chip alone, so the two run as parallel paths (side stream / graph branch).
         import os
         par = os.environ.get("DWG_SERIAL_DENOISER") != "1"
-        # DWG_DENOISER_SPLIT: 0 = every chain on the whole CFG batch; 1 (default) = the DECODER split by batch half -- it is ONE chain, and its
+        # DWG_DENOISER_SPLIT: 0 (default) = every chain on the whole CFG batch; 1 = the DECODER split by batch half -- it is ONE chain, and its
         # memory-bound layers (GroupNorm, LayerNorm, split-K reduces) otherwise have nothing to run under: the halves are two independent
-        # chains (side stream / graph branch) with half the rows per launch; 2 = the encoders split by half as well (four chains)
-        split = int(os.environ.get("DWG_DENOISER_SPLIT", "1")) if (par and B % 2 == 0) else 0
+        # chains (side stream / graph branch) with half the rows per launch; 2 = the encoders split by half as well (four chains).
+        # Measured (DESIGN.md "Measured (round 6)"): 1 is 0.9 % faster per step (25.58 -> 25.35 ms) at 18 % more launches, each of them a less
+        # efficient half-batch launch (kernel time summed over the step 26.8 -> 28.9 ms) -- wall time is bought with chip time, so it stays opt-in
+        split = int(os.environ.get("DWG_DENOISER_SPLIT", "0")) if (par and B % 2 == 0) else 0
         if split >= 2 and self.views != 1:
             split = 1                                   # (the four-chain form shares ONE view's hint embedding between the halves)
         nb = len(cfg.block_out_channels)
