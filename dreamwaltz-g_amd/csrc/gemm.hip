@@ -62,6 +62,8 @@ struct GemmP {
     int act; float alpha;
     int out_bf16, res_bf16, bias_per_row, splitk, accumulate;
     float* ws;          // split-K slab workspace [splitk][M][N] (nullptr: atomicAdd into C)
+    int* cnt;           // per-tile arrival counters (workspace header, zero between launches): the LAST slice of a tile sums the slabs and
+                        // stores C inside the GEMM kernel -- no k_splitk_epilogue launch (nullptr: the separate reduce launch)
     int dbg;            // DWG_GEMM_DEBUG (timing experiments, results are garbage): 1 = k_gemm_glds skips LDS reads + MFMAs, 2 = skips the tile loads
     int bias_row_div;   // > 0: bias index = (row / bias_row_div) * bias_ld + col  (per-image channel bias: conv bias + time embedding)
     long long bias_ld;
@@ -372,9 +374,91 @@ template <int BN, int BM = 128> struct EpiLds {
 
 // RowFn: tile-local row (0..BM-1) -> global output row, or -1 (outside the problem).  BM rows, NT threads (128 / 256 for the four-wave
 // kernels; 256 x 128 and 128 x 256 tiles on eight waves: round 6)
+// 16-byte accesses at DEVICE scope (relaxed agent-scope atomics on the two 8-byte halves: sc1 -- written through / fetched past the
+// XCD-private L2): what lets slabs cross XCDs inside one kernel WITHOUT release / acquire fences -- a fence writes back and invalidates
+// the whole L2 (measured: the step went from 24 to 42 ms with __threadfence() here).
+__device__ __forceinline__ void st_agent4(float* ptr, const float4& v) {
+    unsigned long long* u = reinterpret_cast<unsigned long long*>(ptr);
+    const unsigned long long lo = (unsigned long long)__float_as_uint(v.x) | ((unsigned long long)__float_as_uint(v.y) << 32);
+    const unsigned long long hi = (unsigned long long)__float_as_uint(v.z) | ((unsigned long long)__float_as_uint(v.w) << 32);
+    __hip_atomic_store(u, lo, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    __hip_atomic_store(u + 1, hi, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+__device__ __forceinline__ float4 ld_agent4(const float4* ptr) {
+    const unsigned long long* u = reinterpret_cast<const unsigned long long*>(ptr);
+    const unsigned long long lo = __hip_atomic_load(u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    const unsigned long long hi = __hip_atomic_load(u + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    return make_float4(__uint_as_float((unsigned)lo), __uint_as_float((unsigned)(lo >> 32)), __uint_as_float((unsigned)hi),
+                       __uint_as_float((unsigned)(hi >> 32)));
+}
+
+// Split-K without a reduce launch: every slice of a tile has written its slab (above); the workgroup that arrives LAST at the tile's counter
+// sums the slabs in slice order and stores C through the same epilogue_store4 as k_splitk_epilogue -- the same additions in the same order,
+// so the result does not depend on which slice arrives last (bit-identical to the two-launch path).  The slabs of the other slices were
+// written on other XCDs: they are stored and loaded at device scope (st_agent4 / ld_agent4) and every store has completed (vmcnt(0)) before
+// the workgroup's arrival is counted.  The counter goes back to zero for the next launch that uses this workspace.
+template <int BN, int BM, int NT, typename RowFn>
+__device__ __forceinline__ void splitk_reduce_in_kernel(const GemmP& p, float* sC, int n0, int tid, long long coff, long long roff, bool vec_ok,
+                                                     RowFn row_of, int tile_id) {
+    constexpr int C4 = BN / 4;
+    __builtin_amdgcn_s_waitcnt(0x0F70);             // vmcnt(0): this thread's slab stores have completed at device scope
+    __syncthreads();
+    int* flag = reinterpret_cast<int*>(sC);
+    if (tid == 0) {
+        const int arrived = atomicAdd(p.cnt + tile_id, 1);
+        const int last = arrived == p.splitk - 1;
+        if (last) atomicExch(p.cnt + tile_id, 0);
+        *flag = last;
+    }
+    __syncthreads();
+    if (!*flag) return;
+    // PB pieces x four slices in flight per round: one workgroup sums the whole tile, so the round count (memory latencies in a row) is its time
+    const long long n4 = ((long long)p.M * p.N) >> 2;
+    constexpr int PIECES = BM * C4 / NT, PB = PIECES % 4 == 0 ? 4 : 1;   // (8 x 4 float4 in flight spills the 256-register kernels)
+    static_assert(BM * C4 % NT == 0, "whole pieces per thread");
+#pragma unroll 1
+    for (int k0 = 0; k0 < PIECES; k0 += PB) {
+        const float4* src[PB];
+        int row[PB], col[PB];
+        float4 a[PB];
+#pragma unroll
+        for (int j = 0; j < PB; j++) {
+            const int idx = tid + (k0 + j) * NT, rl = idx / C4, c4 = idx - rl * C4;
+            row[j] = row_of(rl); col[j] = n0 + c4 * 4;
+            if (col[j] >= p.N) row[j] = -1;
+            src[j] = reinterpret_cast<const float4*>(p.ws + (row[j] < 0 ? 0LL : (long long)row[j] * p.N + col[j]));     // (not stored: any valid piece)
+        }
+#pragma unroll 1
+        for (int s0 = 0; s0 < p.splitk; s0 += 4) {
+            float4 u[PB][4];
+#pragma unroll
+            for (int t = 0; t < 4; t++)
+                if (s0 + t < p.splitk) {
+#pragma unroll
+                    for (int j = 0; j < PB; j++) u[j][t] = ld_agent4(src[j] + (long long)(s0 + t) * n4);
+                }
+#pragma unroll
+            for (int t = 0; t < 4; t++)
+                if (s0 + t < p.splitk) {
+#pragma unroll
+                    for (int j = 0; j < PB; j++) {
+                        if (s0 + t == 0) a[j] = u[j][0];
+                        else { a[j].x += u[j][t].x; a[j].y += u[j][t].y; a[j].z += u[j][t].z; a[j].w += u[j][t].w; }
+                    }
+                }
+        }
+#pragma unroll
+        for (int j = 0; j < PB; j++) {
+            if (row[j] < 0) continue;
+            float v[4] = {a[j].x, a[j].y, a[j].z, a[j].w};
+            epilogue_store4(p, v, row[j], col[j], coff, roff, vec_ok);
+        }
+    }
+}
+
 template <int BN, int NPASS, int TM, int TN, bool LIGHT, int BM = 128, int NT = 256, typename RowFn>
 __device__ __forceinline__ void tile_epilogue_lds(const GemmP& p, f32x16 (&acc)[TM][TN], float* sC, int n0, int wm, int wn, int lane, int tid,
-                                                  int ks_id, long long coff, long long roff, RowFn row_of) {
+                                                  int ks_id, long long coff, long long roff, RowFn row_of, int tile_id = 0) {
     constexpr int LDC = EpiLds<BN, BM>::LDC, C4 = BN / 4, PR = BM / NPASS;      // PR rows per pass
     constexpr int BPP = BM / 32 / NPASS;                                         // 32-row blocks per pass
     static_assert(NT % C4 == 0 && (C4 & (C4 - 1)) == 0, "a thread keeps one column group");
@@ -468,7 +552,9 @@ __device__ __forceinline__ void tile_epilogue_lds(const GemmP& p, f32x16 (&acc)[
                     const float4 a = *reinterpret_cast<const float4*>(sC + rl * LDC + c4 * 4);
                     float v[4] = {a.x * p.alpha, a.y * p.alpha, a.z * p.alpha, a.w * p.alpha};
                     if (slab) {
-                        *reinterpret_cast<float4*>(p.ws + ((long long)ks_id * p.M + row) * p.N + col) = make_float4(v[0], v[1], v[2], v[3]);
+                        float* dst = p.ws + ((long long)ks_id * p.M + row) * p.N + col;
+                        if (p.cnt) st_agent4(dst, make_float4(v[0], v[1], v[2], v[3]));
+                        else *reinterpret_cast<float4*>(dst) = make_float4(v[0], v[1], v[2], v[3]);
                         continue;
                     }
                     if (col_bias) { v[0] += bc.x; v[1] += bc.y; v[2] += bc.z; v[3] += bc.w; }
@@ -515,7 +601,8 @@ __device__ __forceinline__ void tile_epilogue_lds(const GemmP& p, f32x16 (&acc)[
             if (p.splitk > 1) {
                 if (p.ws) {                              // slab, reduced by k_splitk_epilogue
                     float* dst = p.ws + ((long long)ks_id * p.M + row) * p.N + col;
-                    if ((p.N & 3) == 0) *reinterpret_cast<float4*>(dst) = make_float4(v[0], v[1], v[2], v[3]);
+                    if (p.cnt) st_agent4(dst, make_float4(v[0], v[1], v[2], v[3]));       // (counters: N % 4 == 0, host-checked)
+                    else if ((p.N & 3) == 0) *reinterpret_cast<float4*>(dst) = make_float4(v[0], v[1], v[2], v[3]);
                     else {
 #pragma unroll
                         for (int e = 0; e < 4; e++) if (col + e < p.N) dst[e] = v[e];
@@ -529,6 +616,9 @@ __device__ __forceinline__ void tile_epilogue_lds(const GemmP& p, f32x16 (&acc)[
             }
             epilogue_store4<LIGHT>(p, v, row, col, coff, roff, vec_ok);
         }
+    }
+    if constexpr (!LIGHT) {
+        if (p.splitk > 1 && p.cnt) splitk_reduce_in_kernel<BN, BM, NT>(p, sC, n0, tid, coff, roff, vec_ok, row_of, tile_id);
     }
 }
 
@@ -579,6 +669,21 @@ __global__ __launch_bounds__(256) void k_splitk_epilogue(GemmP p) {
         int row = (int)(i / p.N), col = (int)(i - (long long)row * p.N);
         epilogue_store(p, v, row, col, 0, 0);
     }
+}
+
+// the reduce launch of a split-K product whose kernel did not reduce in place (no counters: GemmP::cnt)
+static void launch_splitk_epilogue(const GemmP& p, hipStream_t stream) {
+    if (!(p.splitk > 1 && p.ws) || p.cnt) return;
+    long long n = (long long)p.M * p.N;
+    if ((p.N & 3) == 0) n >>= 2;                 // four columns per thread
+    int blocks = (int)((n + 255) / 256); if (blocks > 2048) blocks = 2048;
+    DWG_LAUNCH("splitk_epilogue", k_splitk_epilogue, dim3(blocks), dim3(256), 0, stream, p);
+}
+// the in-kernel reduce needs one counter per output tile (the workspace header holds DWG_GEMM_WS_COUNTERS) and four-column pieces
+static GemmP with_counters(const GemmP& p, long long tiles) {
+    GemmP q = p;
+    if (!(q.cnt && q.splitk > 1 && q.ws && (q.N & 3) == 0 && tiles <= DWG_GEMM_WS_COUNTERS)) q.cnt = nullptr;
+    return q;
 }
 
 template <typename T, int BN, int AMODE, int BMODE>
@@ -643,7 +748,8 @@ __global__ __launch_bounds__(256, (sizeof(T) == 4 || BN == 64) ? 2 : 1) void k_g
     constexpr int NPASS = EpiLds<BN>::passes((size_t)2 * (BM + BN) * LDT * sizeof(T));
     static_assert((size_t)2 * (BM + BN) * LDT * sizeof(T) >= EpiLds<BN>::bytes(NPASS), "epilogue staging fits in the operand stages");
     tile_epilogue_lds<BN, NPASS, TM, TN, false>(p, acc, reinterpret_cast<float*>(smem_raw), n0, wm, wn, lane, tid, ks_id, z1 * p.bC1 + z2 * p.bC2,
-                                         z1 * p.bR1 + z2 * p.bR2, [&](int rl) { const int r = m0 + rl; return r < p.M ? r : -1; });
+                                         z1 * p.bR1 + z2 * p.bR2, [&](int rl) { const int r = m0 + rl; return r < p.M ? r : -1; },
+                                         (int)blockIdx.x * ntn + (int)(blockIdx.y % ntn));
 }
 
 // ---------------------------------------------------------------------------------------------------------------------
@@ -1024,7 +1130,7 @@ __device__ __forceinline__ void gemm_glds_body(const GemmP& p) {
     constexpr int NPASS = EpiLds<BN, BM>::passes((size_t)S * STAGE);
     static_assert((size_t)S * STAGE >= EpiLds<BN, BM>::bytes(NPASS), "epilogue staging fits in the operand stages");
     tile_epilogue_lds<BN, NPASS, TM, TN, false, BM, NT>(p, acc, reinterpret_cast<float*>(smem_raw), n0, wm, wn, lane, tid, ks_id, z1 * p.bC1 + z2 * p.bC2,
-                                         z1 * p.bR1 + z2 * p.bR2, [&](int rl) { const int r = m0 + rl; return r < p.M ? r : -1; });
+                                         z1 * p.bR1 + z2 * p.bR2, [&](int rl) { const int r = m0 + rl; return r < p.M ? r : -1; }, tile);
 }
 
 template <int BN, int AKIND, int S>
@@ -1069,7 +1175,8 @@ static double gemm_flops(const GemmP& p, int batch) {
 }
 
 template <int BN, int AKIND, int S>
-static void launch_glds_s(const GemmP& p, int batch, hipStream_t stream, const char* name) {
+static void launch_glds_s(const GemmP& p_, int batch, hipStream_t stream, const char* name) {
+    const GemmP p = with_counters(p_, (long long)((p_.M + 127) / 128) * ((p_.N + BN - 1) / BN));
     size_t lds = (size_t)S * (128 + BN) * 128;
     static bool attr_set = false;
     if (!attr_set) {
@@ -1083,17 +1190,13 @@ static void launch_glds_s(const GemmP& p, int batch, hipStream_t stream, const c
                                              {{"k_gemm_glds<128, 0, 2>", "k_gemm_glds<128, 1, 2>", "k_gemm_glds<128, 2, 2>", "k_gemm_glds<128, 3, 2>"},
                                               {"k_gemm_glds<128, 0, 3>", "k_gemm_glds<128, 1, 3>", "k_gemm_glds<128, 2, 3>", "k_gemm_glds<128, 3, 3>"}}};
     DWG_LAUNCH_W(name, sym[BN == 128][S == 3][AKIND], gemm_flops(p, batch), (k_gemm_glds<BN, AKIND, S>), grid, dim3(256), lds, stream, p);
-    if (p.splitk > 1 && p.ws) {
-        long long n = (long long)p.M * p.N;
-        if ((p.N & 3) == 0) n >>= 2;                 // four columns per thread
-        int blocks = (int)((n + 255) / 256); if (blocks > 2048) blocks = 2048;
-        DWG_LAUNCH("splitk_epilogue", k_splitk_epilogue, dim3(blocks), dim3(256), 0, stream, p);
-    }
+    launch_splitk_epilogue(p, stream);
 }
 
 // The eight-wave tiles: BM x BN = 256 x 128 | 128 x 256, 512 threads, S stages of 48 KiB (S = 3: 144 of the CU's 160 KiB)
 template <int BM, int BN, int AKIND, int S>
-static void launch_glds8(const GemmP& p, int batch, hipStream_t stream, const char* name) {
+static void launch_glds8(const GemmP& p_, int batch, hipStream_t stream, const char* name) {
+    const GemmP p = with_counters(p_, (long long)((p_.M + BM - 1) / BM) * ((p_.N + BN - 1) / BN));
     const size_t lds = (size_t)S * (BM + BN) * 128;
     static bool attr_set = false;
     if (!attr_set) {
@@ -1104,12 +1207,7 @@ static void launch_glds8(const GemmP& p, int batch, hipStream_t stream, const ch
     static const char* const sym[2][4] = {{"k_gemm_glds8<256, 128, 0>", "k_gemm_glds8<256, 128, 1>", "k_gemm_glds8<256, 128, 2>", "k_gemm_glds8<256, 128, 3>"},
                                           {"k_gemm_glds8<128, 256, 0>", "k_gemm_glds8<128, 256, 1>", "k_gemm_glds8<128, 256, 2>", "k_gemm_glds8<128, 256, 3>"}};
     DWG_LAUNCH_W(name, sym[BN == 256][AKIND], gemm_flops(p, batch), (k_gemm_glds8<BM, BN, AKIND, S>), grid, dim3(512), lds, stream, p);
-    if (p.splitk > 1 && p.ws) {
-        long long n = (long long)p.M * p.N;
-        if ((p.N & 3) == 0) n >>= 2;                 // four columns per thread
-        int blocks = (int)((n + 255) / 256); if (blocks > 2048) blocks = 2048;
-        DWG_LAUNCH("splitk_epilogue", k_splitk_epilogue, dim3(blocks), dim3(256), 0, stream, p);
-    }
+    launch_splitk_epilogue(p, stream);
 }
 template <int AKIND>
 static void launch_big(const GemmP& p, int bm, int batch, hipStream_t stream, const char* name) {
@@ -1321,7 +1419,7 @@ __global__ __launch_bounds__(256, 2) void k_conv3x3_patch(GemmP p) {   // 2 wave
     tile_epilogue_lds<BN, NPASS, TM, TN, !SPLIT>(p, acc, reinterpret_cast<float*>(smem_raw), n0, wm, wn, lane, tid, ks_id, 0, 0, [&](int rr) {
         const int y = y0 + (rr >> 4), x = x0 + (rr & 15);
         return (y < cv.Hout && x < cv.Wout) ? (img * cv.Hout + y) * cv.Wout + x : -1;
-    });
+    }, id);
 }
 
 // ---------------------------------------------------------------------------------------------------------------------
@@ -1581,16 +1679,17 @@ __global__ __launch_bounds__(NW * 64, 2) void k_conv3x3_patch2(GemmP p) {
     tile_epilogue_lds<BN, NPASS, TM, TN, !SPLIT, BM, NT>(p, acc, reinterpret_cast<float*>(smem_raw), n0, wm, wn, lane, tid, ks_id, 0, 0, [&](int rr) {
         const int y = y0 + rr / PW, x = x0 + rr % PW;
         return (y < cv.Hout && x < cv.Wout) ? (img * cv.Hout + y) * cv.Wout + x : -1;
-    });
+    }, id);
 }
 
 template <int BN, int NW, int NBS>
-static void launch_conv3x3_patch2(const GemmP& p, hipStream_t stream, const char* name) {
+static void launch_conv3x3_patch2(const GemmP& p_, hipStream_t stream, const char* name) {
     typedef Patch2Geom<BN, NW> G;
     const size_t lds = (size_t)2 * G::PBYTES + (size_t)NBS * G::BBYTES;
-    const ConvP& cv = p.conv;
-    const int nimg = p.M / (cv.Hout * cv.Wout);
+    const ConvP& cv = p_.conv;
+    const int nimg = p_.M / (cv.Hout * cv.Wout);
     const int gm = nimg * ((cv.Hout + G::PH - 1) / G::PH) * ((cv.Wout + G::PW - 1) / G::PW);
+    const GemmP p = with_counters(p_, (long long)gm * ((p_.N + BN - 1) / BN));
     dim3 grid(gm * ((p.N + BN - 1) / BN) * (p.splitk > 1 ? p.splitk : 1));
     static bool attr_set = false;
     if (!attr_set) {
@@ -1605,21 +1704,17 @@ static void launch_conv3x3_patch2(const GemmP& p, hipStream_t stream, const char
         DWG_LAUNCH_W(name, sym, gemm_flops(p, 1), (k_conv3x3_patch2<BN, true, NW, NBS>), grid, dim3(NW * 64), lds, stream, p);
     else
         DWG_LAUNCH_W(name, sym, gemm_flops(p, 1), (k_conv3x3_patch2<BN, false, NW, NBS>), grid, dim3(NW * 64), lds, stream, p);
-    if (p.splitk > 1 && p.ws) {
-        long long n = (long long)p.M * p.N;
-        if ((p.N & 3) == 0) n >>= 2;
-        int blocks = (int)((n + 255) / 256); if (blocks > 2048) blocks = 2048;
-        DWG_LAUNCH("splitk_epilogue", k_splitk_epilogue, dim3(blocks), dim3(256), 0, stream, p);
-    }
+    launch_splitk_epilogue(p, stream);
 }
 
 template <int BN>
-static void launch_conv3x3_patch(const GemmP& p, hipStream_t stream, const char* name) {
+static void launch_conv3x3_patch(const GemmP& p_, hipStream_t stream, const char* name) {
     constexpr int NPI = (10 * 18 + 7) / 8;
     const size_t lds = (size_t)2 * NPI * 8 * 128 + (size_t)2 * BN * 128;
-    const ConvP& cv = p.conv;
-    const int nimg = p.M / (cv.Hout * cv.Wout);
+    const ConvP& cv = p_.conv;
+    const int nimg = p_.M / (cv.Hout * cv.Wout);
     const int gm = nimg * ((cv.Hout + 7) / 8) * ((cv.Wout + 15) / 16);
+    const GemmP p = with_counters(p_, (long long)gm * ((p_.N + BN - 1) / BN));
     dim3 grid(gm * ((p.N + BN - 1) / BN) * (p.splitk > 1 ? p.splitk : 1));
     static bool attr_set = false;
     if (!attr_set) {
@@ -1633,16 +1728,12 @@ static void launch_conv3x3_patch(const GemmP& p, hipStream_t stream, const char*
     else
         DWG_LAUNCH_W(name, (BN == 64 ? "k_conv3x3_patch<64>" : "k_conv3x3_patch<128>"), gemm_flops(p, 1), (k_conv3x3_patch<BN, false>), grid,
                      dim3(256), lds, stream, p);
-    if (p.splitk > 1 && p.ws) {
-        long long n = (long long)p.M * p.N;
-        if ((p.N & 3) == 0) n >>= 2;
-        int blocks = (int)((n + 255) / 256); if (blocks > 2048) blocks = 2048;
-        DWG_LAUNCH("splitk_epilogue", k_splitk_epilogue, dim3(blocks), dim3(256), 0, stream, p);
-    }
+    launch_splitk_epilogue(p, stream);
 }
 
 template <typename T, int BN, int AMODE, int BMODE>
-static void launch(const GemmP& p, int batch, hipStream_t stream, const char* name) {
+static void launch(const GemmP& p_, int batch, hipStream_t stream, const char* name) {
+    const GemmP p = with_counters(p_, (long long)((p_.M + 127) / 128) * ((p_.N + BN - 1) / BN));
     constexpr int LDT = TT<T>::BK + TT<T>::PAD;
     size_t lds = (size_t)2 * (128 + BN) * LDT * sizeof(T);
     dim3 grid((p.M + 127) / 128, ((p.N + BN - 1) / BN) * (p.splitk > 1 ? p.splitk : 1), batch);
@@ -1654,12 +1745,7 @@ static void launch(const GemmP& p, int batch, hipStream_t stream, const char* na
     }
     DWG_LAUNCH_W(name, (sizeof(T) == 2 ? "k_gemm<" DWG_HALF_NAME ">" : "k_gemm<f32>"), gemm_flops(p, batch), (k_gemm<T, BN, AMODE, BMODE>), grid,
                  dim3(256), lds, stream, p);
-    if (p.splitk > 1 && p.ws) {
-        long long n = (long long)p.M * p.N;
-        if ((p.N & 3) == 0) n >>= 2;                 // four columns per thread
-        int blocks = (int)((n + 255) / 256); if (blocks > 2048) blocks = 2048;
-        DWG_LAUNCH("splitk_epilogue", k_splitk_epilogue, dim3(blocks), dim3(256), 0, stream, p);
-    }
+    launch_splitk_epilogue(p, stream);
 }
 
 template <typename T, int BN, int AMODE>
@@ -1810,7 +1896,7 @@ size_t DWG_GEMM_WS_FN(const dwg_gemm_desc* d) {
         int bsk = 1;
         if (big_tile(d->M, d->N, d->K, &bsk) && bsk > sk) sk = bsk;
     }
-    return sk > 1 ? (size_t)sk * d->M * d->N * sizeof(float) : 0;
+    return sk > 1 ? (size_t)sk * d->M * d->N * sizeof(float) + DWG_GEMM_WS_HEADER_BYTES : 0;     // slabs + the tile-counter header
 }
 
 int DWG_GEMM_FN(const dwg_gemm_desc* d, dwg_stream_t stream_) {
@@ -1830,6 +1916,16 @@ int DWG_GEMM_FN(const dwg_gemm_desc* d, dwg_stream_t stream_) {
     if (d->splitk > 1 && !d->workspace && (d->out_dtype != DWG_DTYPE_F32 || d->bias || d->residual || d->act)) return DWG_E_ARG;
     if (d->accumulate && d->out_dtype != DWG_DTYPE_F32) return DWG_E_ARG;
     if (d->act == DWG_ACT_GEGLU_PAIR && (d->N % 64 != 0 || d->residual || d->splitk > 1 || d->bias_per_row || d->bias_row_div)) return DWG_E_ARG;
+    // workspace_counters: the first DWG_GEMM_WS_HEADER_BYTES of the workspace are tile counters (zero between launches), the slabs follow
+    dwg_gemm_desc wd = *d;
+    int* ws_counters = nullptr;
+    if (wd.workspace && wd.workspace_counters) {
+        if (wd.workspace_bytes <= DWG_GEMM_WS_HEADER_BYTES || ((uintptr_t)wd.workspace & 15)) return DWG_E_ARG;
+        ws_counters = reinterpret_cast<int*>(wd.workspace);
+        wd.workspace = reinterpret_cast<char*>(wd.workspace) + DWG_GEMM_WS_HEADER_BYTES;
+        wd.workspace_bytes -= DWG_GEMM_WS_HEADER_BYTES;
+    }
+    d = &wd;
     GemmP p;
     p.A = d->A; p.B = d->B; p.C = d->C; p.bias = d->bias; p.residual = d->residual;
     p.M = d->M; p.N = d->N; p.K = d->K;
@@ -1841,7 +1937,7 @@ int DWG_GEMM_FN(const dwg_gemm_desc* d, dwg_stream_t stream_) {
     p.act = d->act; p.alpha = d->alpha;
     p.out_bf16 = d->out_dtype == DWG_DTYPE_HALF; p.res_bf16 = d->residual_dtype == DWG_DTYPE_HALF;
     p.bias_per_row = d->bias_per_row; p.splitk = d->splitk > 1 ? d->splitk : 1; p.accumulate = d->accumulate;
-    p.ws = nullptr;
+    p.ws = nullptr; p.cnt = ws_counters;
     static const int dbg = getenv("DWG_GEMM_DEBUG") ? atoi(getenv("DWG_GEMM_DEBUG")) : 0;
     p.dbg = dbg;
     {

@@ -30,7 +30,7 @@ class GemmDesc(ctypes.Structure):
         ("conv_in_upsample", ctypes.c_int32), ("A2", ctypes.c_void_p), ("conv_cin1", ctypes.c_int32),
         ("bias_row_div", ctypes.c_int32), ("bias_ld", ctypes.c_int64),
         ("workspace", ctypes.c_void_p), ("workspace_bytes", ctypes.c_size_t),
-        ("force_register_staging", ctypes.c_int32),
+        ("force_register_staging", ctypes.c_int32), ("workspace_counters", ctypes.c_int32),
         ("name", ctypes.c_char_p),
     ]
 

@@ -403,8 +403,12 @@ class Plan:
             desc.splitk = 0     # library picks a split-K factor for shapes that cannot fill the chip
             need = self._lib.dwg_gemm_workspace_bytes(ctypes.byref(desc))
             if need > 0:
-                ws = self.buf(int(need) // 4, dtype=torch.float32)
-                desc.workspace, desc.workspace_bytes = ws.data_ptr(), int(need)
+                # this call site's own workspace.  DWG_SPLITK_FUSED=1: with a zeroed counter header -- the last slice of a tile reduces inside the
+                # GEMM kernel (bit-identical; measured SLOWER on MI355X, 29.1 vs 25.0 ms per step: DESIGN.md "Measured (round 6)")
+                import os
+                fused = os.environ.get("DWG_SPLITK_FUSED") == "1"
+                ws = self.buf(int(need) // 4, dtype=torch.float32, zero=fused)
+                desc.workspace, desc.workspace_bytes, desc.workspace_counters = ws.data_ptr(), int(need), int(fused)
             else:
                 desc.splitk = 1
         self.keep.append(desc)

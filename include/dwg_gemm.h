@@ -27,6 +27,8 @@ extern "C" {
 
 /* DWG_DTYPE_F32 / _BF16 / _F16 / _F32X: dwg_types.h */
 
+#define DWG_GEMM_WS_COUNTERS 4096                              /* tile counters in a workspace header (dwg_gemm_desc::workspace_counters) */
+#define DWG_GEMM_WS_HEADER_BYTES (DWG_GEMM_WS_COUNTERS * 4)
 #define DWG_ACT_NONE 0
 #define DWG_ACT_RELU 1
 #define DWG_ACT_LEAKY_RELU 2 /* slope 0.01 (F.leaky_relu default, deform_model.py:121) */
@@ -68,12 +70,18 @@ typedef struct dwg_gemm_desc {
     void* workspace;          /* optional split-K slab workspace (device), see dwg_gemm_workspace_bytes */
     size_t workspace_bytes;
     int32_t force_register_staging; /* != 0: use the register-staged kernel even where the direct-to-LDS path applies (A/B testing) */
+    int32_t workspace_counters; /* != 0: the first DWG_GEMM_WS_HEADER_BYTES of `workspace` are tile-arrival counters that belong to the
+                                 library: ZERO when the workspace is handed over, zero again after every dwg_gemm that used it (calls
+                                 that share a workspace must not overlap in time).  The slabs follow the header, and the slice that
+                                 arrives last at a tile sums the slabs (in slice order: the same bits as the reduce pass) inside the
+                                 GEMM kernel -- no reduce launch.  0: the whole workspace is slabs, reduce pass as before. */
     const char* name;         /* optional label for dwg_prof */
 } dwg_gemm_desc;
 
 int dwg_gemm(const dwg_gemm_desc* desc, dwg_stream_t stream);
 
-/* Bytes of split-K workspace the library would like for this descriptor (0: no split would be used). */
+/* Bytes of split-K workspace the library would like for this descriptor (0: no split would be used): the slabs plus
+   DWG_GEMM_WS_HEADER_BYTES for the counter header of `workspace_counters`. */
 size_t dwg_gemm_workspace_bytes(const dwg_gemm_desc* desc);
 
 #ifdef __cplusplus

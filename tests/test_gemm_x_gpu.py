@@ -209,6 +209,62 @@ def test_x_conv3x3_small_latents_splitk_paths(C, H, patch_min_m):
     assert _rel(_u(y), ref) < TOL
 
 
+@pytest.mark.parametrize("case", ["gemm_small_m", "gemm_qkv", "gemm_ff_out", "conv_1280_16", "conv_640_32", "conv_320_64", "conv_im2col"])
+def test_x_splitk_reduce_inside_the_kernel_matches_the_reduce_pass_bit_for_bit(case):
+    """dwg_gemm_desc::workspace_counters (round 6): the slice that arrives last at a tile sums the slabs inside the GEMM kernel.  Same
+    additions in the same order as k_splitk_epilogue: identical bits, whichever slice is last; the counters are zero again afterwards (the
+    second and third run on the same workspace agree); no reduce launch."""
+    import os
+    from dreamwaltz_g_amd import gemm, _lib
+    g = torch.Generator().manual_seed(len(case))
+    os.environ.pop("DWG_CONV_PATCH_MINM", None)
+    if case.startswith("gemm"):
+        M, N, K = {"gemm_small_m": (128, 1280, 11520), "gemm_qkv": (512, 3840, 1280), "gemm_ff_out": (2048, 640, 2560)}[case]
+        x = torch.randn(M, K, generator=g); w = torch.randn(N, K, generator=g) / K ** 0.5
+        b = torch.randn(N, generator=g); r = torch.randn(M, N, generator=g)
+        xc, wc, bc, rx = _x(x), _x(w), b.cuda(), _x(r)
+        shape = (M, N)
+        make = lambda y: gemm.gemm_raw(xc, wc, y, M, N, K, (K, 1), (K, 1), N, bias=bc, residual=rx, ldr=N, act="silu", run=False)  # noqa: E731
+    else:
+        C, H = {"conv_1280_16": (1280, 16), "conv_640_32": (640, 32), "conv_320_64": (320, 64), "conv_im2col": (640, 32)}[case]
+        if case == "conv_im2col":
+            os.environ["DWG_CONV_PATCH_MINM"] = "1000000"
+        Bn = 2
+        x = torch.randn(Bn, C, H, H, generator=g); w = torch.randn(C, C, 3, 3, generator=g) / (C * 9) ** 0.5
+        bimg = torch.randn(Bn, C, generator=g); r = torch.randn(Bn, H, H, C, generator=g)
+        xc, wc, bc, rcu = _x(x.permute(0, 2, 3, 1)), _x(w.permute(0, 2, 3, 1)), bimg.cuda(), _x(r)
+        M, K = Bn * H * H, 9 * C
+        shape = (Bn, H, H, C)
+        make = lambda y: gemm.gemm_raw(xc, wc, y, M, C, K, (0, 1), (K, 1), C, bias=bc, bias_row_div=H * H, bias_ld=C, residual=rcu, ldr=C,  # noqa: E731
+                                       conv=(C, H, H, H, H, 3, 3, 1, 1, 1, 1), run=False)
+    st = ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+    try:
+        outs, launches = [], []
+        for counters in (0, 1, 1, 1):
+            y = torch.empty(shape, device="cuda", dtype=torch.int32)
+            d = make(y)
+            d.splitk = 0
+            need = _lib.lib().dwg_gemm_workspace_bytes(ctypes.byref(d))
+            if need == 0:
+                pytest.skip("the library does not split this shape")
+            if counters == 0 or len(outs) == 1:
+                ws = torch.zeros(need // 4, device="cuda")          # the fused runs share ONE workspace: counters must come back to zero
+            d.workspace, d.workspace_bytes, d.workspace_counters = ws.data_ptr(), need, counters
+            _lib.prof_enable(True)
+            gemm.run_desc(d, st)
+            torch.cuda.synchronize()
+            launches.append(_lib.prof_symbols()); _lib.prof_enable(False)
+            outs.append(y.clone())
+            if counters:
+                assert int(ws[:4096].view(torch.int32).abs().sum()) == 0, "tile counters not back at zero"
+    finally:
+        os.environ.pop("DWG_CONV_PATCH_MINM", None)
+    assert any("splitk_epilogue" in k for k in launches[0]), launches[0].keys()
+    for k in (1, 2, 3):
+        assert not any("splitk_epilogue" in s_ for s_ in launches[k]), launches[k].keys()
+        assert torch.equal(outs[0], outs[k]), (case, k)
+
+
 def test_x_rejects_what_the_format_cannot_express():
     """K-strided operands and channel counts that are not whole 8-groups are argument errors, not silent fallbacks."""
     from dreamwaltz_g_amd import gemm
