@@ -86,3 +86,11 @@ for name, kind, B, H, Cin, Cout, k, M in CASES:
     e1.record(); torch.cuda.synchronize()
     us = e0.elapsed_time(e1) / (REP * len(descs)) * 1e3
     print("%-26s M=%-5d N=%-5d K=%-6d %8.1f us  %6.0f TF/s" % (name, Mm, N, K, us, 2.0 * Mm * N * K / us / 1e6), flush=True)
+    if os.environ.get("PROBE_PROF") == "1":         # per-kernel split of the same call (dwg_prof: events around every launch)
+        _lib.prof_enable(True)
+        for d in descs:
+            gemm.run_desc(d, st)
+        torch.cuda.synchronize()
+        for sym, (n, ms, _) in sorted(_lib.prof_symbols().items()):
+            print("    %-44s x%-3d %8.1f us each" % (sym, n, ms / n * 1e3), flush=True)
+        _lib.prof_enable(False)
