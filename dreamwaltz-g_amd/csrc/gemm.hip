@@ -1776,14 +1776,16 @@ static int tile_bn(const dwg_gemm_desc* d) {
 
 // split-K factor for shapes that cannot fill 256 CUs with 128 x BN output tiles (small-M layers: 8x8 / 16x16 latents)
 static int auto_splitk(int M, int N, int K, int bn, int bk) {
-    static const int target = getenv("DWG_SPLITK_TARGET") ? atoi(getenv("DWG_SPLITK_TARGET")) : 512;
+    // round 6: 256 workgroups of >= 12 k-steps (was 512 of >= 8): a weight-streaming slice is bound by 128-byte row pieces out of HBM, and
+    // longer slices stream better than more of them (8 x 8-latent convolution 33.4 -> 28.2 us; the step 25.33 -> 25.07 ms)
+    static const int target = getenv("DWG_SPLITK_TARGET") ? atoi(getenv("DWG_SPLITK_TARGET")) : 256;
     static const int nosplit = getenv("DWG_SPLITK_NOSPLIT") ? atoi(getenv("DWG_SPLITK_NOSPLIT")) : 384;
-    static const int minsteps = getenv("DWG_SPLITK_MINSTEPS") ? atoi(getenv("DWG_SPLITK_MINSTEPS")) : 8;
+    static const int minsteps = getenv("DWG_SPLITK_MINSTEPS") ? atoi(getenv("DWG_SPLITK_MINSTEPS")) : 12;
     long long blocks = (long long)((M + 127) / 128) * ((N + bn - 1) / bn);
     if (blocks >= nosplit || K < 2 * minsteps * bk) return 1;
     if (2.0 * M * N * K < 4.0e8) return 1;      // tiny products are launch-bound: a second (reduce) launch costs more than it buys
-    long long sk = target / blocks;             // aim at ~2 workgroups per CU
-    long long kmax = K / (minsteps * bk);       // keep >= 8 k-steps per slice
+    long long sk = target / blocks;             // aim at ~1 workgroup per CU
+    long long kmax = K / (minsteps * bk);       // keep >= 12 k-steps per slice
     if (sk > kmax) sk = kmax;
     if (sk > 16) sk = 16;
     return sk >= 2 ? (int)sk : 1;
