@@ -89,6 +89,9 @@ SIGNATURES = {
     "dwg_transpose_dt": (ctypes.c_int, [_i32, _i32, _i32, _i32, _vp, _i64, _i64, _vp, _i64, _i64, _vp]),
     "dwg_xfmt_pack": (ctypes.c_int, [_i64, _vp, _vp, _vp]),
     "dwg_xfmt_unpack": (ctypes.c_int, [_i64, _vp, _vp, _vp]),
+    "dwg_vae_image_pack": (ctypes.c_int, [_i32, _i32, _i32, _vp, _vp, _vp]),
+    "dwg_vae_grad_prescale_pack": (ctypes.c_int, [_i32, _i32, _vp, ctypes.c_float, _vp, _vp, _vp]),
+    "dwg_vae_dx_unpack": (ctypes.c_int, [_i32, _i32, _i32, _vp, _vp, _vp, _vp]),
     "dwg_xfmt_range_scan": (ctypes.c_int, [_i64, _vp, _vp, _vp]),
     # include/dwg_elementwise.h
     "dwg_act_backward_colsum": (ctypes.c_int, [_i32, _i32, _i32, _vp, _vp, _vp, _vp, _vp]),

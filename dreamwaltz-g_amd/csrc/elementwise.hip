@@ -757,6 +757,66 @@ __global__ __launch_bounds__(256) void k_x_unpack(long long n8, const dwg_xs* __
         reinterpret_cast<float4*>(dst)[2 * i + 1] = make_float4(x.get(4), x.get(5), x.get(6), x.get(7));
     }
 }
+// ---- the f32x VAE encoder's input / output converters in one launch each (round 6; before: 4 / ~14 / 3 element-wise torch launches on the
+// step's serial chain) ------------------------------------------------------------------------------------------------------------------
+// image [B,3,H,W] fp32 in [0,1] -> x [B,H,W,8] f32x: channels 0..2 = 2 v - 1 (VaeImageProcessor.normalize; 2 v is exact, one rounding as in
+// `image * 2.0 - 1.0`), channels 3..7 = 0 (the first convolution's padded input group)
+__global__ __launch_bounds__(256) void k_vae_image_pack(long long npix, long long hw, const float* __restrict__ img, dwg_xs* __restrict__ x) {
+    for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < npix; i += (long long)gridDim.x * 256) {
+        const long long b = i / hw, r = i - b * hw;
+        const float* src = img + b * 3 * hw + r;
+        dwg_x8 o;
+#pragma unroll
+        for (int e = 0; e < 8; e++) o.set(e, e < 3 ? src[e * hw] * 2.0f - 1.0f : 0.f);
+        o.store(x + 8 * i);
+    }
+}
+// d moments [B,8,h,w] fp32 -> dmoments [B,h,w,8] f32x, pre-scaled by the power of two that brings max |g| into [target / 2, target]
+// (sd15.VAEEncoderPlan.GRAD_TARGET: the backward is linear, the scale is exact and is taken out again by k_vae_dx_unpack); inv_out =
+// 2 * 2^-k (the scale back times d(2 v - 1) / dv).  target <= 0: no pre-scale (k = 0).  ONE workgroup: 32 768 values at B = 1.
+__global__ __launch_bounds__(1024) void k_vae_grad_prescale_pack(int B, int hw, const float* __restrict__ g, float target, dwg_xs* __restrict__ dst,
+                                                                 float* __restrict__ inv_out) {
+    __shared__ float s_max[16];
+    __shared__ float s_scale;
+    const long long n = (long long)B * 8 * hw;
+    float m = 0.f;
+    for (long long i = threadIdx.x; i < n; i += 1024) m = fmaxf(m, fabsf(g[i]));
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) m = fmaxf(m, __shfl_xor(m, o));
+    if ((threadIdx.x & 63) == 0) s_max[threadIdx.x >> 6] = m;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        float amax = 0.f;
+        for (int w = 0; w < 16; w++) amax = fmaxf(amax, s_max[w]);
+        float k = 0.f;
+        if (target > 0.f && amax > 0.f) k = fminf(fmaxf(floorf(log2f(target / fmaxf(amax, 1e-30f))), -60.f), 100.f);
+        s_scale = ldexpf(1.0f, (int)k);
+        inv_out[0] = ldexpf(1.0f, 1 - (int)k);
+    }
+    __syncthreads();
+    const float sc = s_scale;
+    const long long npix = (long long)B * hw;
+    for (long long i = threadIdx.x; i < npix; i += 1024) {
+        const long long b = i / hw, r = i - b * hw;
+        const float* src = g + b * 8 * hw + r;
+        dwg_x8 o;
+#pragma unroll
+        for (int e = 0; e < 8; e++) o.set(e, src[(long long)e * hw] * sc);
+        o.store(dst + 8 * i);
+    }
+}
+// dx [B,H,W,8] f32x (channels 0..2) -> d image [B,3,H,W] fp32, times inv[0]
+__global__ __launch_bounds__(256) void k_vae_dx_unpack(long long npix, long long hw, const dwg_xs* __restrict__ dx, const float* __restrict__ inv,
+                                                       float* __restrict__ out) {
+    const float sc = inv[0];
+    for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < npix; i += (long long)gridDim.x * 256) {
+        const long long b = i / hw, r = i - b * hw;
+        const dwg_x8 x = dwg_x8::load(dx + 8 * i);
+        float* dst = out + b * 3 * hw + r;
+#pragma unroll
+        for (int e = 0; e < 3; e++) dst[e * hw] = x.get(e) * sc;
+    }
+}
 // Range telemetry of a stored f32x tensor (round 5): the format saturates at +-65504 instead of overflowing (dwg_x_split) and loses significand
 // bits once the hi half goes subnormal (|x| < 6.1e-5) -- silently, in the hot path.  This scan is the cold-path witness: it walks a tensor the
 // plan has written and counts  [0] hi halves AT +-65504 (a saturated value, or a legitimate one on the edge: equally worth a warning),
@@ -1161,6 +1221,32 @@ int dwg_xfmt_unpack(int64_t n, const void* src, float* dst, dwg_stream_t stream)
     if (n < 0 || n % 8 || !src || !dst || ((uintptr_t)src | (uintptr_t)dst) % 16) return DWG_E_ARG;
     if (n == 0) return DWG_OK;
     DWG_LAUNCH("xfmt_unpack", k_x_unpack, dim3(grid_for(n / 8)), dim3(256), 0, (hipStream_t)stream, (long long)(n / 8), (const dwg_xs*)src, dst);
+    DWG_RETURN_IF_LAUNCH_FAILED();
+    return DWG_OK;
+}
+
+int dwg_vae_image_pack(int32_t B, int32_t H, int32_t W, const float* image_nchw, void* x_xs, dwg_stream_t stream) {
+    if (B < 0 || H < 0 || W < 0 || !image_nchw || !x_xs || ((uintptr_t)x_xs % 16)) return DWG_E_ARG;
+    const long long hw = (long long)H * W, npix = (long long)B * hw;
+    if (npix == 0) return DWG_OK;
+    DWG_LAUNCH("vae_image_pack", k_vae_image_pack, dim3(grid_for(npix)), dim3(256), 0, (hipStream_t)stream, npix, hw, image_nchw, (dwg_xs*)x_xs);
+    DWG_RETURN_IF_LAUNCH_FAILED();
+    return DWG_OK;
+}
+
+int dwg_vae_grad_prescale_pack(int32_t B, int32_t hw, const float* g_nchw, float target, void* dst_xs, float* inv_out, dwg_stream_t stream) {
+    if (B <= 0 || hw <= 0 || !g_nchw || !dst_xs || !inv_out || ((uintptr_t)dst_xs % 16)) return DWG_E_ARG;
+    DWG_LAUNCH("vae_grad_prescale_pack", k_vae_grad_prescale_pack, dim3(1), dim3(1024), 0, (hipStream_t)stream, B, hw, g_nchw, target,
+               (dwg_xs*)dst_xs, inv_out);
+    DWG_RETURN_IF_LAUNCH_FAILED();
+    return DWG_OK;
+}
+
+int dwg_vae_dx_unpack(int32_t B, int32_t H, int32_t W, const void* dx_xs, const float* inv, float* out_nchw, dwg_stream_t stream) {
+    if (B < 0 || H < 0 || W < 0 || !dx_xs || !inv || !out_nchw || ((uintptr_t)dx_xs % 16)) return DWG_E_ARG;
+    const long long hw = (long long)H * W, npix = (long long)B * hw;
+    if (npix == 0) return DWG_OK;
+    DWG_LAUNCH("vae_dx_unpack", k_vae_dx_unpack, dim3(grid_for(npix)), dim3(256), 0, (hipStream_t)stream, npix, hw, (const dwg_xs*)dx_xs, inv, out_nchw);
     DWG_RETURN_IF_LAUNCH_FAILED();
     return DWG_OK;
 }

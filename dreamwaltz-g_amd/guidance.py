@@ -84,7 +84,7 @@ class _VAEEncode(torch.autograd.Function):
     @staticmethod
     def forward(ctx, images, plan):
         ctx.plan = plan
-        return plan.encode(images).clone()
+        return plan.encode(images).contiguous()      # (a permuted view of the plan's own buffer: always a copy; NCHW-dense for the posterior kernel)
 
     @staticmethod
     def backward(ctx, g):

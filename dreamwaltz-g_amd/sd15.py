@@ -1260,9 +1260,24 @@ class VAEEncoderPlan:
 
     def encode(self, image_nchw):
         """image [B,3,H,W] fp32 in [0,1] -> moments [B,8,h,w] fp32 (NCHW view)."""
-        self.fwd.store(self.x, (image_nchw * 2.0 - 1.0).permute(0, 2, 3, 1), self._x_stage)
+        if self._fused_io(image_nchw):
+            img = image_nchw.contiguous()
+            _lib.check(self.fwd._lib.dwg_vae_image_pack(self.B, self.hw, self.hw, _lib.ptr(img), _lib.ptr(self.x), self._st()), "dwg_vae_image_pack")
+        else:
+            self.fwd.store(self.x, (image_nchw * 2.0 - 1.0).permute(0, 2, 3, 1), self._x_stage)
         self.fwd.run()
         return self.moments.permute(0, 3, 1, 2)
+
+    def _st(self):
+        return ctypes.c_void_p(torch.cuda.current_stream(self.device).cuda_stream)
+
+    def _fused_io(self, t):
+        """f32x plans: the boundary conversions (2 v - 1 + NHWC + pack; max |g| + power-of-two pre-scale + NHWC + pack; unpack + NCHW + scale
+        back) are one HIP launch each instead of 4 / ~14 / 3 element-wise torch launches (DWG_VAE_FUSED_IO=0: the torch statements)."""
+        image = t.dim() == 4 and t.shape[1] == 3 and tuple(t.shape[-2:]) == (self.hw, self.hw)
+        grad = t.dim() == 4 and t.shape[1] == 8 and tuple(t.shape[-2:]) == tuple(self.moments.shape[1:3])
+        return (self.fwd.is_x and t.is_cuda and t.dtype == torch.float32 and (image or grad) and t.shape[0] == self.B
+                and os.environ.get("DWG_VAE_FUSED_IO", "1") != "0")
 
     # the backward pass is LINEAR in the incoming gradient: it is run on 2^k x the gradient, k chosen on the device so that max |g| lands in
     # [GRAD_TARGET / 2, GRAD_TARGET], and the result is scaled back by 2^-k -- both exact.  Without it the 16-bit storage types see the
@@ -1274,6 +1289,18 @@ class VAEEncoderPlan:
     def backward(self, dmoments_nchw):
         """d loss / d moments [B,8,h,w] -> d loss / d image [B,3,H,W] fp32."""
         g = dmoments_nchw
+        if self._fused_io(g):
+            g = g.detach().contiguous()
+            prescale = os.environ.get("DWG_VAE_GRAD_PRESCALE", "1") != "0"
+            inv = torch.empty(1, device=self.device, dtype=torch.float32)
+            h, w_ = int(self.moments.shape[1]), int(self.moments.shape[2])
+            _lib.check(self.bwd._lib.dwg_vae_grad_prescale_pack(self.B, h * w_, _lib.ptr(g), float(self.GRAD_TARGET if prescale else 0.0),
+                                                                _lib.ptr(self.dmoments), _lib.ptr(inv), self._st()), "dwg_vae_grad_prescale_pack")
+            self.bwd.run()
+            out = torch.empty(self.B, 3, self.hw, self.hw, device=self.device, dtype=torch.float32)
+            _lib.check(self.bwd._lib.dwg_vae_dx_unpack(self.B, self.hw, self.hw, _lib.ptr(self.dx), _lib.ptr(inv), _lib.ptr(out), self._st()),
+                       "dwg_vae_dx_unpack")
+            return out
         inv = None
         if self.bwd.dtype_name in ("f32x", "f16") and os.environ.get("DWG_VAE_GRAD_PRESCALE", "1") != "0":
             amax = g.detach().abs().amax()

@@ -106,6 +106,16 @@ int dwg_transpose_2byte(int32_t batch, int32_t R, int32_t C, const void* in, int
  * plans (the reference hands fp32 latents, text embeddings and images across boundary B4: core/guidance/controlnet.py:83-114, vae.py:34-40). */
 int dwg_xfmt_pack(int64_t n, const float* src, void* dst, dwg_stream_t stream);
 int dwg_xfmt_unpack(int64_t n, const void* src, float* dst, dwg_stream_t stream);
+/* The f32x VAE encoder's boundary converters, one launch each (AutoencoderKL.encode inside the SDS autograd graph:
+ * /root/reference/core/guidance/vae.py:34-40, basic.py:368-372).
+ *   dwg_vae_image_pack:          image [B,3,H,W] fp32 in [0,1] -> x [B,H,W,8] f32x, channels 0..2 = 2 v - 1 (VaeImageProcessor.normalize), 3..7 = 0.
+ *   dwg_vae_grad_prescale_pack:  d moments [B,8,hw] fp32 -> [B,hw,8] f32x times 2^k, k = floor(log2(target / max|g|)) clamped to [-60, 100]
+ *                                (0 when max|g| = 0 or target <= 0): the backward is linear and 16-bit halves need the gradient in their range;
+ *                                inv_out[0] = 2 * 2^-k (device scalar; the factor 2 is d(2 v - 1) / dv).
+ *   dwg_vae_dx_unpack:           dx [B,H,W,8] f32x, channels 0..2 -> d image [B,3,H,W] fp32, times inv[0]. */
+int dwg_vae_image_pack(int32_t B, int32_t H, int32_t W, const float* image_nchw, void* x_xs, dwg_stream_t stream);
+int dwg_vae_grad_prescale_pack(int32_t B, int32_t hw, const float* g_nchw, float target, void* dst_xs, float* inv_out, dwg_stream_t stream);
+int dwg_vae_dx_unpack(int32_t B, int32_t H, int32_t W, const void* dx_xs, const float* inv, float* out_nchw, dwg_stream_t stream);
 /* Range telemetry of a stored f32x tensor (cold path; the hot path saturates and goes subnormal silently): ADDS into counters5 (device,
  * zeroed by the caller)  [0] hi halves at +-65504 (saturated, or on the edge),  [1] non-zero values whose hi half is subnormal or zero
  * (|x| < 6.1e-5: fewer than 22 significand bits),  [2] non-finite values,  [3] max |x| as fp32 bits (atomic max),  [4] elements seen.

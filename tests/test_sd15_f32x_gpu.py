@@ -287,6 +287,39 @@ def test_full_width_vae_encoder_f32x_vs_oracle():
     assert rep["saturated"] == 0 and rep["nonfinite"] == 0 and rep["max_abs"] < 65504.0 / 8, rep
 
 
+@pytest.mark.parametrize("scale", [1.0, 3e-5, 0.0, 7e3])
+def test_f32x_vae_boundary_converters_equal_the_torch_statements(scale):
+    """dwg_vae_image_pack / dwg_vae_grad_prescale_pack / dwg_vae_dx_unpack (one launch each; sd15.VAEEncoderPlan.encode / backward) against the
+    element-wise statements they replace: same values bit for bit -- 2 v - 1, the power-of-two pre-scale chosen from max |g|, the scale back."""
+    import ctypes
+    from dreamwaltz_g_amd import _lib, xfmt
+    L = _lib.lib()
+    st = ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+    g = torch.Generator().manual_seed(3)
+    B, H, h = 2, 48, 6
+    img = torch.rand(B, 3, H, H, generator=g).cuda()
+    x = torch.full((B, H, H, 8), 12345, dtype=torch.int32, device="cuda")
+    _lib.check(L.dwg_vae_image_pack(B, H, H, _lib.ptr(img), _lib.ptr(x), st), "dwg_vae_image_pack")
+    want = torch.zeros(B, H, H, 8, device="cuda"); want[..., :3] = (img * 2.0 - 1.0).permute(0, 2, 3, 1)
+    assert torch.equal(x, xfmt.pack(want))
+    gm = (torch.randn(B, 8, h, h, generator=g) * scale).cuda()
+    dst = torch.empty(B, h, h, 8, dtype=torch.int32, device="cuda"); inv = torch.empty(1, device="cuda")
+    _lib.check(L.dwg_vae_grad_prescale_pack(B, h * h, _lib.ptr(gm), 64.0, _lib.ptr(dst), _lib.ptr(inv), st), "dwg_vae_grad_prescale_pack")
+    amax = gm.abs().amax()
+    k = torch.floor(torch.log2(64.0 / amax.clamp_min(1e-30))).clamp(-60.0, 100.0)
+    k = torch.where(amax > 0, k, torch.zeros_like(k))
+    assert torch.equal(dst, xfmt.pack((gm * torch.exp2(k)).permute(0, 2, 3, 1).contiguous())), (float(k), float(inv))
+    assert float(inv) == float(torch.exp2(1.0 - k))
+    if scale > 0:
+        assert 32.0 <= float(xfmt.unpack(dst).abs().max()) <= 64.0
+    _lib.check(L.dwg_vae_grad_prescale_pack(B, h * h, _lib.ptr(gm), 0.0, _lib.ptr(dst), _lib.ptr(inv), st), "dwg_vae_grad_prescale_pack")   # no pre-scale
+    assert torch.equal(dst, xfmt.pack(gm.permute(0, 2, 3, 1).contiguous())) and float(inv) == 2.0
+    dx = xfmt.pack(torch.randn(B, H, H, 8, generator=g).cuda())
+    out = torch.empty(B, 3, H, H, device="cuda"); inv.fill_(0.375)
+    _lib.check(L.dwg_vae_dx_unpack(B, H, H, _lib.ptr(dx), _lib.ptr(inv), _lib.ptr(out), st), "dwg_vae_dx_unpack")
+    assert torch.equal(out, (xfmt.unpack(dx)[..., :3].permute(0, 3, 1, 2) * inv).contiguous())
+
+
 def test_f32x_range_report_names_the_layer_that_saturates():
     """Round 5: range telemetry of the f32x plans (sd15.Plan.range_report, csrc/elementwise.hip k_x_range_scan).  A ResNet block fed (a)
     ordinary activations, (b) heavy-tailed ones -- a few channels 1e3 times the rest, as SD-1.5's known outlier channels are -- and (c)
