@@ -288,7 +288,7 @@ class ControlNetScoreDistillation:
                     text_keys = ('neg', 'text') if self.use_negative_text else ('null', 'text')
                     text = self.prepare_text_embeddings(text_embeds_dict, text_keys)
                     cond = self.prepare_condition(cond_inputs, cond_height=self.latent_hw * self.vae_scale_factor,
-                                                  cond_width=self.latent_hw * self.vae_scale_factor, batch_size=2 * batch_size, dtype=torch.float32)
+                                                  cond_width=self.latent_hw * self.vae_scale_factor, batch_size=self.views, dtype=torch.float32)
                     if self._side is None:
                         self._side = torch.cuda.Stream(device=self.device)
                     self.denoiser.prefetch(self.timestep, text, cond[:self.views], stream=self._side)
@@ -313,7 +313,8 @@ class ControlNetScoreDistillation:
             elif isinstance(image[0], torch.Tensor):
                 image = torch.cat(image, dim=0)
         repeat_by = batch_size if image.shape[0] == 1 else num_images_per_prompt
-        image = image.repeat_interleave(repeat_by, dim=0)
+        if repeat_by != 1:                       # (repeat_interleave(1) would still copy the image: one launch per call for nothing)
+            image = image.repeat_interleave(repeat_by, dim=0)
         return image.to(device=device, dtype=dtype)
 
     def prepare_condition(self, cond_inputs, cond_width, cond_height, batch_size, dtype) -> torch.Tensor:
@@ -326,17 +327,33 @@ class ControlNetScoreDistillation:
         """latents [2,4,h,w], text [2,77,768], cond_inputs: list[PIL] | PIL | tensor [1 or 2,3,8h,8w] in [0,1].  The timestep is
         self.timestep, as in the reference."""
         _, _, lh, lw = latents_model_input.shape
+        # the reference repeats the condition to the CFG batch (controlnet.py:50-54: batch_size = latents.size(0)); the repeated rows are identical
+        # and only the first `views` are read below (the hint embedding is computed once per view and broadcast), so they are not made
         cond = self.prepare_condition(cond_inputs, cond_height=lh * self.vae_scale_factor, cond_width=lw * self.vae_scale_factor,
-                                      batch_size=latents_model_input.size(0), dtype=torch.float32)
-        # the repeated condition rows are identical (controlnet.py:50-54): the hint embedding is computed once per view and broadcast
+                                      batch_size=self.views, dtype=torch.float32)
         self.denoiser.set_inputs(latents_model_input, self.timestep, text_embeddings, cond[:self.views])
         return self.denoiser.run()
 
     def prepare_text_embeddings(self, text_embeds_dict: dict, text_keys: tuple):
         embeds = [text_embeds_dict[k] for k in text_keys]
+        # the prompts' embeddings are computed once per run (core/trainer.py:232-263) and handed over unchanged every step: the concatenation
+        # of the SAME tensors (identity + version counter + storage) is kept instead of being rebuilt twice per call (prefetch + prediction)
+        # (never while a stream capture is recording: a captured step must CONTAIN the concatenation of its static text buffers)
+        capturing = embeds[0].is_cuda and torch.cuda.is_current_stream_capturing()
+        key = tuple((id(e), e._version, e.data_ptr(), tuple(e.shape)) for e in embeds) + (self.views,)
+        cache = self.__dict__.setdefault("_text_cat", {})
+        hit = None if capturing else cache.get(key)
+        if hit is not None and all(a is b for a, b in zip(hit[0], embeds)):
+            return hit[1]
+        src = embeds
         if self.views > 1:          # one embedding per view; a single one is shared by all views
             embeds = [e.expand(self.views, -1, -1) if e.size(0) == 1 else e for e in embeds]
-        return torch.concat(embeds, dim=0)
+        out = torch.concat(embeds, dim=0)
+        if not capturing:
+            if len(cache) >= 16:
+                cache.clear()
+            cache[key] = (list(src), out)
+        return out
 
     def draw_view_randoms(self, generator=None, train_step=None, max_iteration=None):
         """The three device draws of ONE view's call in the reference's order (checklist Q12): VAE posterior noise [1,4,h,w], timestep [1],

@@ -11,8 +11,9 @@ from dreamwaltz_g_amd import sds_step
 
 G = int(sys.argv[1]) if len(sys.argv) > 1 else 50000
 res = int(sys.argv[2]) if len(sys.argv) > 2 else 512
+GUIDE = len(sys.argv) > 3 and sys.argv[3] == "1"
 torch.cuda.set_stream(torch.cuda.Stream())
-st = sds_step.SDSStep(n_gaussians=G, res=res, device="cuda", guidance=False)
+st = sds_step.SDSStep(n_gaussians=G, res=res, device="cuda", guidance=GUIDE)
 for _ in range(3):
     st.run()
 torch.cuda.synchronize()
