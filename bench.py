@@ -300,7 +300,11 @@ def roofline(prof, prof_sym, prof_steps, G, Kref, K, P, dtype="bf16"):
     out = {}
     peak = MFMA_PEAK_TFLOPS[dtype]
     if prof_sym:
-        name, (count, total_ms, work) = max(prof_sym.items(), key=lambda kv: kv[1][1])
+        # largest total time; symbols within 8 % of the largest are ranked by their algorithmic work instead: an event bracket over-reads a
+        # ~18 us launch by ~3 us (dispatch + release, which rocprofv3's kernel trace does not count: csrc/prof.hip), enough to reorder a
+        # near-tie between 170 launches of 20 us and 17 of 215 us per step against the order the committed rocprofv3 summary shows
+        top_ms = max(v[1] for v in prof_sym.values())
+        name, (count, total_ms, work) = max(((k, v) for k, v in prof_sym.items() if v[1] >= 0.92 * top_ms), key=lambda kv: (kv[1][2], kv[1][1]))
         avg_ms = total_ms / max(1, count)
         if work > 0:
             ach = work / count / (avg_ms * 1e-3) / 1e12
