@@ -57,6 +57,35 @@ def test_attention_key_split_heuristic_host_only():
     assert f(F32X, 0, 8, 1024, 1024, 80) == 0 and f(F32X, 2, 8, 1024, 1024, 200) == 0
 
 
+def test_round6_entry_points_validate_their_arguments_host_only():
+    """Argument errors are reported before any device call (DWG_E_ARG), empty calls succeed: the VAE boundary converters and the split-K
+    workspace header of dwg_gemm_desc::workspace_counters."""
+    from dreamwaltz_g_amd import gemm
+    L = _lib.lib()
+    fake = ctypes.c_void_p(4096)                    # 16-byte aligned, never dereferenced on the host
+    odd = ctypes.c_void_p(4100)
+    assert L.dwg_vae_image_pack(0, 512, 512, fake, fake, None) == 0 and L.dwg_vae_image_pack(1, 0, 512, fake, fake, None) == 0
+    assert L.dwg_vae_image_pack(1, 8, 8, None, fake, None) != 0 and L.dwg_vae_image_pack(1, 8, 8, fake, odd, None) != 0
+    assert L.dwg_vae_image_pack(-1, 8, 8, fake, fake, None) != 0
+    assert L.dwg_vae_grad_prescale_pack(0, 64, fake, 64.0, fake, fake, None) != 0          # one workgroup scans the whole gradient: B >= 1
+    assert L.dwg_vae_grad_prescale_pack(1, 64, fake, 64.0, fake, None, None) != 0 and L.dwg_vae_grad_prescale_pack(1, 64, fake, 64.0, odd, fake, None) != 0
+    assert L.dwg_vae_dx_unpack(0, 8, 8, fake, fake, fake, None) == 0
+    assert L.dwg_vae_dx_unpack(1, 8, 8, fake, None, fake, None) != 0 and L.dwg_vae_dx_unpack(1, 8, 8, odd, fake, fake, None) != 0
+    # the workspace query counts the 16 KB counter header on top of the slabs; a workspace that cannot hold the header is an argument error
+    d = gemm.GemmDesc()
+    d.A, d.B, d.C = 4096, 8192, 12288
+    d.M, d.N, d.K = 128, 1280, 11520
+    d.a_row_stride, d.a_k_stride, d.b_row_stride, d.b_k_stride, d.ldc = 11520, 1, 11520, 1, 1280
+    d.batch1 = d.batch2 = 1
+    d.dtype, d.out_dtype, d.alpha, d.splitk = gemm.F32X, gemm.F32X, 1.0, 0
+    need = L.dwg_gemm_workspace_bytes(ctypes.byref(d))
+    assert need > 16384 and (need - 16384) % (128 * 1280 * 4) == 0, need
+    d.workspace, d.workspace_bytes, d.workspace_counters = 4096, 16384, 1
+    assert L.dwg_gemm(ctypes.byref(d), None) != 0
+    d.workspace, d.workspace_bytes = 4100, need
+    assert L.dwg_gemm(ctypes.byref(d), None) != 0
+
+
 def test_no_kernel_spills_beyond_the_known_ones():
     """The compiler's per-kernel resource report of the last build (csrc/_obj/*.resources.json, written by build.py): no kernel
     uses scratch memory except the three listed with their bounds.  (Round 2 lost 7 ms per step to an epilogue change that
